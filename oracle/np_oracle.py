@@ -1,0 +1,478 @@
+"""TEST INFRASTRUCTURE ONLY -- numpy restatement of the reference's online-optimisation hot path.
+
+Every function cites the reference file:line it restates (paths relative to /root/reference).  The
+restatement is pinned against the reference itself: oracle/make_golden.py imports the unmodified
+reference in the build container, runs it on seeded inputs and commits inputs+outputs under
+tests/golden/; tests/test_oracle_golden.py checks this module against those vectors.  The one piece
+with no reference source (PrRoIPool, empty submodule) is "parity unpinned" and self-pinned instead
+(tests/test_oracle_prroi.py).
+
+All routines are dtype-generic: pass float64 arrays for a high-precision oracle, float32 arrays to
+mimic the reference's arithmetic type.  Pure numpy (no torch) so it runs anywhere.
+"""
+import math
+
+import numpy as np
+
+
+# --------------------------------------------------------------------------------------------
+# filter layer: ltr/models/layers/filter.py
+# --------------------------------------------------------------------------------------------
+
+def apply_filter(feat, filt, out_hw=None):
+    """Cross-correlation of one filter (or F filters) with n feature maps.
+
+    Restates `apply_filter` (ltr/models/layers/filter.py:5-57) for one sequence: zero padding
+    K//2 (:16), stride 1, so an even K yields H+1 outputs and an odd K yields H.
+      feat (n,C,H,W); filt (C,KH,KW) -> (n,OH,OW)   or   filt (F,C,KH,KW) -> (n,F,OH,OW)
+    `out_hw` crops the result to its top-left corner (operation.conv2d mode='same',
+    pytracking/libs/operation.py:17-32, drops the last row/col for even K).
+    """
+    multi = filt.ndim == 4
+    f = filt if multi else filt[None]
+    n, C, H, W = feat.shape
+    F, C2, KH, KW = f.shape
+    assert C == C2
+    ph, pw = KH // 2, KW // 2
+    OH, OW = H + 2 * ph - KH + 1, W + 2 * pw - KW + 1
+    fp = np.zeros((n, C, H + 2 * ph, W + 2 * pw), dtype=feat.dtype)
+    fp[:, :, ph:ph + H, pw:pw + W] = feat
+    out = np.zeros((n, F, OH, OW), dtype=feat.dtype)
+    for u in range(KH):
+        for v in range(KW):
+            out += np.einsum("nchw,fc->nfhw", fp[:, :, u:u + OH, v:v + OW], f[:, :, u, v], optimize=True)
+    if out_hw is not None:
+        out = out[:, :, :out_hw[0], :out_hw[1]]
+    return out if multi else out[:, 0]
+
+
+def apply_feat_transpose(feat, inp, ksz):
+    """Adjoint of `apply_filter` w.r.t. the filter.
+
+    Restates `apply_feat_transpose` -> `_apply_feat_transpose_v2/_v3` (filter.py:91-182):
+      grad[c,u,v] = sum_{i,y,x} feat[i,c,y+u-p,x+v-p] * inp[i,y,x]   (p = K//2, zero padded)
+      feat (n,C,H,W); inp (n,OH,OW) -> (C,KH,KW);  inp (n,F,OH,OW) -> (F,C,KH,KW).
+    `inp` may be smaller than the full correlation output (ATOM's 'same' crop): missing rows/cols
+    are treated as zero.
+    """
+    KH, KW = (ksz, ksz) if isinstance(ksz, int) else ksz
+    multi = inp.ndim == 4
+    r = inp if multi else inp[:, None]
+    n, C, H, W = feat.shape
+    F = r.shape[1]
+    ph, pw = KH // 2, KW // 2
+    OH, OW = r.shape[-2:]
+    fp = np.zeros((n, C, H + 2 * ph, W + 2 * pw), dtype=feat.dtype)
+    fp[:, :, ph:ph + H, pw:pw + W] = feat
+    g = np.zeros((F, C, KH, KW), dtype=feat.dtype)
+    for u in range(KH):
+        for v in range(KW):
+            g[:, :, u, v] = np.einsum("nchw,nfhw->fc", fp[:, :, u:u + OH, v:v + OW], r, optimize=True)
+    return g if multi else g[0]
+
+
+# --------------------------------------------------------------------------------------------
+# activations + distance map: ltr/models/layers/activation.py, distance.py
+# --------------------------------------------------------------------------------------------
+
+def leaky_relu_par(x, a):
+    """activation.py:32-37  LeakyReluPar."""
+    return (1.0 - a) / 2.0 * np.abs(x) + (1.0 + a) / 2.0 * x
+
+
+def leaky_relu_par_deriv(x, a):
+    """activation.py:39-44  LeakyReluParDeriv (sign(0) = 0)."""
+    return (1.0 - a) / 2.0 * np.sign(x) + (1.0 + a) / 2.0
+
+
+def bent_ident_par(x, a, b=1.0):
+    """activation.py:47-55."""
+    return (1.0 - a) / 2.0 * (np.sqrt(x * x + 4.0 * b * b) - 2.0 * b) + (1.0 + a) / 2.0 * x
+
+
+def bent_ident_par_deriv(x, a, b=1.0):
+    """activation.py:58-66."""
+    return (1.0 - a) / 2.0 * (x / np.sqrt(x * x + 4.0 * b * b)) + (1.0 + a) / 2.0
+
+
+def softmax_reg(x, reg=None):
+    """activation.py:7-16: softmax over the last axis with an optional extra constant logit."""
+    m = x.max(axis=-1, keepdims=True)
+    if reg is not None:
+        m = np.maximum(m, reg)
+    e = np.exp(x - m)
+    den = e.sum(axis=-1, keepdims=True)
+    if reg is not None:
+        den = den + np.exp(reg - m)
+    return e / den
+
+
+def distance_map(center, output_sz, num_bins, bin_displacement):
+    """distance.py:17-39  DistanceMap.forward.  center (n,2) = (row, col) -> (n,bins,OH,OW)."""
+    dt = center.dtype
+    k = np.arange(num_bins, dtype=dt).reshape(1, -1, 1, 1)
+    k0 = np.arange(output_sz[0], dtype=dt).reshape(1, 1, -1, 1)
+    k1 = np.arange(output_sz[1], dtype=dt).reshape(1, 1, 1, -1)
+    d0 = k0 - center[:, 0].reshape(-1, 1, 1, 1)
+    d1 = k1 - center[:, 1].reshape(-1, 1, 1, 1)
+    dist = np.sqrt(d0 * d0 + d1 * d1)
+    bin_diff = dist / dt.type(bin_displacement) - k
+    head = np.maximum(1.0 - np.abs(bin_diff[:, :-1]), 0.0)
+    tail = np.clip(1.0 + bin_diff[:, -1:], 0.0, 1.0)
+    return np.concatenate((head, tail), axis=1).astype(dt)
+
+
+# --------------------------------------------------------------------------------------------
+# DiMP / DiMP-L2 / PrDiMP steepest descent: ltr/models/target_classifier/optimizer.py
+# --------------------------------------------------------------------------------------------
+
+def _centers(bb, K, feat_stride):
+    """optimizer.py:112-113: (row, col) target centre in score-map cells."""
+    off = (K % 2) / 2.0
+    c = (bb[:, :2] + bb[:, 2:] / 2.0) / bb.dtype.type(feat_stride)
+    return c[:, ::-1] - bb.dtype.type(off)
+
+
+def dimp_sd(w0, feat, bb, sample_weight, *, num_iter, step_length, filter_reg, min_filter_reg,
+            feat_stride, label_w, mask_w, spatial_w, bin_displacement, alpha_eps=0.0,
+            mask_act="sigmoid", score_act="relu", act_param=None, compute_losses=True):
+    """`DiMPSteepestDescentGN.forward` (optimizer.py:85-170), one sequence.
+
+    w0 (C,K,K); feat (n,C,H,W); bb (n,4) xywh; sample_weight (n,) or None.
+    label_w/mask_w/spatial_w: the (bins,) weights of the three 1x1 predictors (:57-72).
+    Returns (iterates (T+1,C,K,K), losses list).
+    """
+    dt = feat.dtype
+    n, C, H, W = feat.shape
+    K = w0.shape[-1]
+    O = (H + (K + 1) % 2, W + (K + 1) % 2)
+    step = dt.type(step_length)
+    reg = dt.type(max(filter_reg * filter_reg, min_filter_reg ** 2))      # :109
+    dmap = distance_map(_centers(bb.astype(dt), K, feat_stride), O, len(label_w), bin_displacement)
+    label = np.einsum("nbhw,b->nhw", dmap, label_w.astype(dt))           # :117
+    mask = np.einsum("nbhw,b->nhw", dmap, mask_w.astype(dt))             # :118
+    if mask_act == "sigmoid":
+        mask = 1.0 / (1.0 + np.exp(-mask))
+    spatial = np.einsum("nbhw,b->nhw", dmap, spatial_w.astype(dt))       # :119
+    if sample_weight is None:                                            # :122-125
+        sws = dt.type(math.sqrt(1.0 / n)) * spatial
+    else:
+        sws = np.sqrt(sample_weight.astype(dt)).reshape(n, 1, 1) * spatial
+    if score_act == "relu":
+        act, dact = leaky_relu_par, leaky_relu_par_deriv
+    else:
+        act = lambda x, a: bent_ident_par(x, a, act_param)
+        dact = lambda x, a: bent_ident_par_deriv(x, a, act_param)
+    w = w0.astype(dt)
+    iterates, losses = [w], []
+    for _ in range(num_iter):
+        s = apply_filter(feat, w)                                        # :137
+        sa = act(s, mask)
+        m = dact(s, mask)
+        r = sws * (sa - label)                                           # :140
+        if compute_losses:
+            losses.append((r ** 2).sum() + reg * (w ** 2).sum())         # :143
+        g = apply_feat_transpose(feat, m * (sws * r), K) + reg * w       # :146-148
+        q = sws * (m * apply_filter(feat, g))                            # :151-152
+        a_num = (g * g).sum()                                            # :155
+        a_den = max((q * q).sum() + (reg + dt.type(alpha_eps)) * a_num, dt.type(1e-8))
+        w = w - (step * (a_num / a_den)) * g                             # :160
+        iterates.append(w)
+    if compute_losses:
+        sa = act(apply_filter(feat, w), mask)                            # :165-168
+        losses.append(((sws * (sa - label)) ** 2).sum() + reg * (w ** 2).sum())
+    return np.stack(iterates), losses
+
+
+def dimp_l2_sd(w0, feat, bb, sample_weight, *, num_iter, step_length, filter_reg, min_filter_reg,
+               feat_stride, gauss_sigma, hinge_threshold, alpha_eps=0.0, compute_losses=True):
+    """`DiMPL2SteepestDescentGN.forward` (optimizer.py:211-291), one sequence."""
+    dt = feat.dtype
+    n, C, H, W = feat.shape
+    K = w0.shape[-1]
+    O = (H + (K + 1) % 2, W + (K + 1) % 2)
+    step = dt.type(step_length)
+    reg = dt.type(max(filter_reg * filter_reg, min_filter_reg ** 2))
+    ctr = _centers(bb.astype(dt), K, feat_stride)
+    k0 = np.arange(O[0], dtype=dt).reshape(1, -1, 1)
+    k1 = np.arange(O[1], dtype=dt).reshape(1, 1, -1)
+    coef = dt.type(-1.0 / (2 * gauss_sigma ** 2))
+    g0 = np.exp(coef * (k0 - ctr[:, 0].reshape(-1, 1, 1)) ** 2)         # :201-208
+    g1 = np.exp(coef * (k1 - ctr[:, 1].reshape(-1, 1, 1)) ** 2)
+    label = g0 * g1
+    mask = (label > hinge_threshold).astype(dt)                          # :245
+    label = label * mask
+    if sample_weight is None:
+        sws = np.full((n, 1, 1), math.sqrt(1.0 / n), dtype=dt)
+    else:
+        sws = np.sqrt(sample_weight.astype(dt)).reshape(n, 1, 1)
+    w = w0.astype(dt)
+    iterates, losses = [w], []
+    for _ in range(num_iter):
+        s = apply_filter(feat, w)
+        sa = mask * s + (1.0 - mask) * np.maximum(s, 0)                  # :262
+        m = mask + (1.0 - mask) * (s > 0).astype(dt)                     # :263
+        r = sws * (sa - label)
+        if compute_losses:
+            losses.append((r ** 2).sum() + reg * (w ** 2).sum())
+        g = apply_feat_transpose(feat, m * (sws * r), K) + reg * w
+        q = sws * (m * apply_filter(feat, g))
+        a_num = (g * g).sum()
+        a_den = max((q * q).sum() + (reg + dt.type(alpha_eps)) * a_num, dt.type(1e-8))
+        w = w - (step * (a_num / a_den)) * g
+        iterates.append(w)
+    if compute_losses:
+        s = apply_filter(feat, w)
+        sa = mask * s + (1.0 - mask) * np.maximum(s, 0)
+        losses.append(((sws * (sa - label)) ** 2).sum() + reg * (w ** 2).sum())
+    return np.stack(iterates), losses
+
+
+def prdimp_label_density(ctr, O, *, gauss_sigma, label_threshold=0.0, normalize_label=False,
+                         label_shrink=0.0, uni_weight=0.0):
+    """`PrDiMPSteepestDescentNewton.get_label_density` (optimizer.py:331-353)."""
+    dt = ctr.dtype
+    k0 = np.arange(O[0], dtype=dt).reshape(1, -1, 1)
+    k1 = np.arange(O[1], dtype=dt).reshape(1, 1, -1)
+    d0 = (k0 - ctr[:, 0].reshape(-1, 1, 1)) ** 2
+    d1 = (k1 - ctr[:, 1].reshape(-1, 1, 1)) ** 2
+    if gauss_sigma == 0:                                                 # :337-344 one-hot argmin
+        oh0 = np.zeros_like(d0)
+        oh1 = np.zeros_like(d1)
+        oh0[np.arange(d0.shape[0]), d0[:, :, 0].argmin(-1), 0] = 1.0
+        oh1[np.arange(d1.shape[0]), 0, d1[:, 0, :].argmin(-1)] = 1.0
+        gauss = oh0 * oh1
+    else:
+        coef = dt.type(-1.0 / (2 * gauss_sigma ** 2))
+        g0 = np.exp(coef * d0)
+        g1 = np.exp(coef * d1)
+        gauss = (g0 / dt.type(2 * math.pi * gauss_sigma ** 2)) * g1      # :348
+    gauss = gauss * (gauss > label_threshold).astype(dt)                 # :349
+    if normalize_label:
+        gauss = gauss / (gauss.sum(axis=(-2, -1), keepdims=True) + dt.type(1e-8))
+    return (dt.type(1.0 - label_shrink) *
+            (dt.type(1.0 - uni_weight) * gauss + dt.type(uni_weight / (O[0] * O[1]))))
+
+
+def prdimp_sd(w0, feat, bb, sample_weight, *, num_iter, step_length, filter_reg, min_filter_reg,
+              feat_stride, gauss_sigma, alpha_eps=0.0, uni_weight=0.0, normalize_label=False,
+              label_shrink=0.0, softmax_reg_val=None, label_threshold=0.0, compute_losses=True):
+    """`PrDiMPSteepestDescentNewton.forward` (optimizer.py:355-439), one sequence."""
+    dt = feat.dtype
+    n, C, H, W = feat.shape
+    K = w0.shape[-1]
+    O = (H + (K + 1) % 2, W + (K + 1) % 2)
+    step = dt.type(step_length)
+    reg = dt.type(max(filter_reg * filter_reg, min_filter_reg ** 2))
+    ctr = _centers(bb.astype(dt), K, feat_stride)
+    label = prdimp_label_density(ctr, O, gauss_sigma=gauss_sigma, label_threshold=label_threshold,
+                                 normalize_label=normalize_label, label_shrink=label_shrink,
+                                 uni_weight=uni_weight)
+    if sample_weight is None:                                            # :387-390 (NOT sqrt'ed)
+        swp = np.full((n,), 1.0 / n, dtype=dt)
+    else:
+        swp = sample_weight.astype(dt).reshape(n)
+    exp_reg = dt.type(0 if softmax_reg_val is None else math.exp(softmax_reg_val))
+
+    def loss_fn(s, w):                                                   # :393-396
+        lse = np.log(np.exp(s).sum(axis=(-2, -1)) + exp_reg)
+        return (swp * (lse - (label * s).sum(axis=(-2, -1)))).sum() + reg * (w ** 2).sum()
+
+    w = w0.astype(dt)
+    iterates, losses = [w], []
+    for _ in range(num_iter):
+        s = apply_filter(feat, w)                                        # :406
+        P = softmax_reg(s.reshape(n, -1), softmax_reg_val).reshape(s.shape)
+        res = swp.reshape(n, 1, 1) * (P - label)                         # :408
+        if compute_losses:
+            losses.append(loss_fn(s, w))
+        g = apply_feat_transpose(feat, res, K) + reg * w                 # :414-415
+        sg = apply_filter(feat, g)                                       # :418
+        psg = P * sg
+        h = psg - P * psg.sum(axis=(-2, -1), keepdims=True)              # :420
+        ghg = np.maximum((sg * h).reshape(n, -1).sum(axis=1), 0)         # :421
+        ghg = (swp * ghg).sum()                                          # :422
+        a_num = (g * g).sum()
+        a_den = max(ghg + (reg + dt.type(alpha_eps)) * a_num, dt.type(1e-8))
+        w = w - (step * (a_num / a_den)) * g                             # :430
+        iterates.append(w)
+    if compute_losses:
+        losses.append(loss_fn(apply_filter(feat, w), w))
+    return np.stack(iterates), losses
+
+
+# --------------------------------------------------------------------------------------------
+# ATOM: pytracking/libs/optimization.py (CG), pytracking/tracker/atom/optim.py (ConvProblem)
+# --------------------------------------------------------------------------------------------
+
+def mlu(x, min_val):
+    """activation.py:20-29  MLU(x) = elu(leaky_relu(x, 1/min_val), min_val)."""
+    y = np.where(x >= 0, x, x / min_val)
+    return np.where(y > 0, y, min_val * (np.exp(np.minimum(y, 0)) - 1.0)).astype(x.dtype)
+
+
+def mlu_deriv(x, min_val):
+    """d MLU/dx: 1 for x>=0, exp(x/min_val) for x<0."""
+    return np.where(x >= 0, 1.0, np.exp(np.minimum(x, 0) / min_val)).astype(x.dtype)
+
+
+def atom_conv_residuals(x, samples, y, sample_weights, filter_reg, act_min_val):
+    """`ConvProblem.__call__` (atom/optim.py:79-94): returns (data residuals (n,H,W), reg residual)."""
+    H, W = samples.shape[-2:]
+    s = apply_filter(samples, x, out_hw=(H, W))                          # conv2d mode='same'
+    r = np.sqrt(sample_weights).reshape(-1, 1, 1) * (mlu(s, act_min_val) - y)
+    return s, r, math.sqrt(filter_reg) * x
+
+
+def atom_cg(x0, samples, y, sample_weights, *, filter_reg, act_min_val, num_iter,
+            fletcher_reeves=False, state=None, direction_forget_factor=0.0):
+    """`ConjugateGradient.run` + `ConjugateGradientBase.run_CG` for `ConvProblem`
+    (optimization.py:72-163, 227-289; atom/optim.py:71-99), explicit J / J^T instead of autograd.
+
+    x0 (C,K,K); samples (n,C,H,W); y (n,H,W); sample_weights (n,).
+    state: dict(p, rho, r_prev) carried across calls (only used when direction_forget_factor != 0).
+    Returns (x_new, state).
+    """
+    dt = samples.dtype
+    if num_iter == 0:
+        return x0, state
+    H, W = samples.shape[-2:]
+    K = x0.shape[-1]
+    lam = dt.type(filter_reg)
+    s0, r0, _ = atom_conv_residuals(x0, samples, y, sample_weights, filter_reg, act_min_val)
+    d = np.sqrt(sample_weights).reshape(-1, 1, 1).astype(dt) * mlu_deriv(s0, act_min_val)
+
+    def JT(rd, rr):
+        return apply_feat_transpose(samples, d * rd, K) + dt.type(math.sqrt(filter_reg)) * rr
+
+    def A(p):
+        Jp = d * apply_filter(samples, p, out_hw=(H, W))
+        return apply_feat_transpose(samples, d * Jp, K) + lam * p
+
+    b = -JT(r0, dt.type(math.sqrt(filter_reg)) * x0)                     # optimization.py:262-265
+    if direction_forget_factor == 0 or state is None:                    # :82-85
+        p, rho, r_prev = None, dt.type(1.0), None
+    else:
+        p, rho, r_prev = state["p"], state["rho"], state["r_prev"]
+        if p is not None:
+            rho = rho / dt.type(direction_forget_factor)
+    r = b.copy()
+    delta = None
+    for ii in range(num_iter):
+        z = r                                                            # M1 = M2 = identity
+        rho1 = rho
+        rho = (r * z).sum()
+        if rho == 0:                                                     # :108-113
+            break
+        if p is None:
+            p = z.copy()
+        else:
+            if fletcher_reeves:
+                beta = rho / rho1
+            else:
+                beta = (rho - (r_prev * z).sum()) / rho1                 # :121-122
+            beta = max(beta, dt.type(0))                                 # :124
+            p = z + p * beta
+        q = A(p)
+        pq = (p * q).sum()
+        alpha = rho / pq                                                 # :131
+        if not fletcher_reeves:
+            r_prev = r.copy()
+        delta = p * alpha if delta is None else delta + p * alpha
+        if ii < num_iter - 1:                                            # :145-146
+            r = r - q * alpha
+    x = x0 if delta is None else x0 + delta
+    return x, dict(p=p, rho=rho, r_prev=r_prev)
+
+
+# --------------------------------------------------------------------------------------------
+# Precise RoI Pooling (PARITY UNPINNED: submodule empty; see oracle/prroi_torch.py header)
+# --------------------------------------------------------------------------------------------
+
+def _G(u):
+    t = np.clip(u, -1.0, 1.0)
+    return np.where(t <= 0, 0.5 * (t + 1.0) ** 2, 1.0 - 0.5 * (1.0 - t) ** 2)
+
+
+def _hat(u):
+    return np.maximum(0.0, 1.0 - np.abs(u))
+
+
+def _prroi_geometry(rois, PH, PW, scale, H, W):
+    dt = rois.dtype
+    x0, y0, x1, y1 = (rois[:, k] * dt.type(scale) for k in (1, 2, 3, 4))
+    bw = np.maximum(x1 - x0, 0) / PW
+    bh = np.maximum(y1 - y0, 0) / PH
+    q = np.arange(PW, dtype=dt)
+    p = np.arange(PH, dtype=dt)
+    xs = x0[:, None] + q[None] * bw[:, None]
+    xe = xs + bw[:, None]
+    ys = y0[:, None] + p[None] * bh[:, None]
+    ye = ys + bh[:, None]
+    ii = np.arange(W, dtype=dt)
+    jj = np.arange(H, dtype=dt)
+    wx = _G(xe[:, :, None] - ii) - _G(xs[:, :, None] - ii)
+    wy = _G(ye[:, :, None] - jj) - _G(ys[:, :, None] - jj)
+    return xs, xe, ys, ye, bw, bh, wx.astype(dt), wy.astype(dt)
+
+
+def prroi_forward(features, rois, PH, PW, scale):
+    """out[r,c,p,q] = (1/A) * integral over bin (p,q) of the bilinear interpolant."""
+    N, C, H, W = features.shape
+    xs, xe, ys, ye, bw, bh, wx, wy = _prroi_geometry(rois, PH, PW, scale, H, W)
+    area = bw * bh
+    fr = features[rois[:, 0].astype(np.int64)]
+    integ = np.einsum("rcji,rpj,rqi->rcpq", fr, wy, wx, optimize=True)
+    safe = np.where(area > 0, area, 1.0)
+    out = integ / safe[:, None, None, None]
+    return np.where((area > 0)[:, None, None, None], out, 0.0).astype(features.dtype)
+
+
+def prroi_backward_feat(grad_out, features_shape, rois, PH, PW, scale):
+    """d out / d features: scatter of wy*wx/A (Appendix A)."""
+    N, C, H, W = features_shape
+    xs, xe, ys, ye, bw, bh, wx, wy = _prroi_geometry(rois, PH, PW, scale, H, W)
+    area = bw * bh
+    inv = np.where(area > 0, 1.0 / np.where(area > 0, area, 1.0), 0.0)
+    contrib = np.einsum("rcpq,rpj,rqi,r->rcji", grad_out, wy, wx, inv, optimize=True)
+    g = np.zeros(features_shape, dtype=grad_out.dtype)
+    np.add.at(g, rois[:, 0].astype(np.int64), contrib)
+    return g
+
+
+def prroi_backward_coor(grad_out, features, rois, PH, PW, scale):
+    """d out / d rois[:,1:5] via the boundary integrals of Appendix A.  Returns (R,5), column 0 = 0."""
+    N, C, H, W = features.shape
+    dt = features.dtype
+    xs, xe, ys, ye, bw, bh, wx, wy = _prroi_geometry(rois, PH, PW, scale, H, W)
+    area = bw * bh
+    ok = area > 0
+    inv = np.where(ok, 1.0 / np.where(ok, area, 1.0), 0.0)
+    fr = features[rois[:, 0].astype(np.int64)]
+    out = np.einsum("rcji,rpj,rqi->rcpq", fr, wy, wx, optimize=True) * inv[:, None, None, None]
+    ii = np.arange(W, dtype=dt)
+    jj = np.arange(H, dtype=dt)
+    hx_s = _hat(xs[:, :, None] - ii)
+    hx_e = _hat(xe[:, :, None] - ii)
+    hy_s = _hat(ys[:, :, None] - jj)
+    hy_e = _hat(ye[:, :, None] - jj)
+    Lx_s = np.einsum("rcji,rpj,rqi->rcpq", fr, wy, hx_s, optimize=True)
+    Lx_e = np.einsum("rcji,rpj,rqi->rcpq", fr, wy, hx_e, optimize=True)
+    Ly_s = np.einsum("rcji,rpj,rqi->rcpq", fr, hy_s, wx, optimize=True)
+    Ly_e = np.einsum("rcji,rpj,rqi->rcpq", fr, hy_e, wx, optimize=True)
+    bh4 = bh[:, None, None, None]
+    bw4 = bw[:, None, None, None]
+    inv4 = inv[:, None, None, None]
+    d_xs = (-Lx_s + bh4 * out) * inv4
+    d_xe = (Lx_e - bh4 * out) * inv4
+    d_ys = (-Ly_s + bw4 * out) * inv4
+    d_ye = (Ly_e - bw4 * out) * inv4
+    q = np.arange(PW, dtype=dt).reshape(1, 1, 1, PW)
+    p = np.arange(PH, dtype=dt).reshape(1, 1, PH, 1)
+    g = grad_out
+    gr = np.zeros((rois.shape[0], 5), dtype=dt)
+    gr[:, 1] = (g * (d_xs * (1 - q / PW) + d_xe * (1 - (q + 1) / PW))).sum(axis=(1, 2, 3))
+    gr[:, 3] = (g * (d_xs * (q / PW) + d_xe * ((q + 1) / PW))).sum(axis=(1, 2, 3))
+    gr[:, 2] = (g * (d_ys * (1 - p / PH) + d_ye * (1 - (p + 1) / PH))).sum(axis=(1, 2, 3))
+    gr[:, 4] = (g * (d_ys * (p / PH) + d_ye * ((p + 1) / PH))).sum(axis=(1, 2, 3))
+    return gr * dt.type(scale)

@@ -1,0 +1,115 @@
+"""Seeded synthetic workloads for the hot path.
+
+There are no checkpoints and no datasets (no network), so every test, golden vector and benchmark
+draws its inputs from the generators below.  They use numpy's PCG64 `default_rng(seed)` so the same
+seed reproduces the same arrays in the build container (where the goldens are generated from the
+reference) and on the GPU box (where the HIP path is checked against them) without shipping the
+33 MB feature tensors.
+
+Hyper-parameters are the deployed values the reference trains/tracks with (no learned values
+exist here):
+  DiMP-50   ltr/train_settings/dimp/dimp50.py:91-95, pytracking/parameter/dimp/dimp50.py
+  PrDiMP-50 ltr/train_settings/dimp/prdimp50.py:95-98, pytracking/parameter/dimp/prdimp50.py
+  ATOM      pytracking/parameter/atom/default.py
+"""
+import math
+
+import numpy as np
+
+
+def clf_features(rng, n, C, H, W, K):
+    """N(0,1) features, instance-L2-normalised like `InstanceL2Norm(scale=sqrt(1/(C*K*K)))`
+    (ltr/models/layers/normalization.py:15-20, dimpnet.py:159): x * sqrt(C*H*W / sum x^2) * scale."""
+    x = rng.standard_normal((n, C, H, W), dtype=np.float32)
+    ss = (x.astype(np.float64) ** 2).sum(axis=(1, 2, 3), keepdims=True)
+    scale = math.sqrt(1.0 / (C * K * K))
+    return (x * np.sqrt(C * H * W / ss) * scale).astype(np.float32)
+
+
+def target_boxes(rng, n, crop=288.0):
+    """xywh boxes around the crop centre: w,h ~ U(40,80), centre jitter U(-8,8) px (section 8d)."""
+    wh = rng.uniform(40.0, 80.0, size=(n, 2))
+    ctr = crop / 2.0 + rng.uniform(-8.0, 8.0, size=(n, 2))
+    return np.concatenate((ctr - wh / 2.0, wh), axis=1).astype(np.float32)
+
+
+def decay_weights(n, lr=0.01):
+    """Steady-state DiMP memory weights (pytracking/tracker/dimp/dimp.py:445-484): the sample
+    inserted j updates ago carries lr*(1-lr)^j, normalised to sum 1."""
+    w = lr * (1.0 - lr) ** np.arange(n - 1, -1, -1, dtype=np.float64)
+    return (w / w.sum()).astype(np.float32)
+
+
+def gauss_lut(num_bins, bin_displacement, sigma):
+    """`label_map_predictor` initial weights (optimizer.py:45-54)."""
+    d = np.arange(num_bins, dtype=np.float32) * np.float32(bin_displacement)
+    if sigma == 0:
+        g = np.zeros_like(d)
+        g[0] = 1
+    else:
+        g = np.exp(-0.5 * (d / np.float32(sigma)) ** 2)
+    return (g - g.min()).astype(np.float32)
+
+
+def mask_lut(num_bins, bin_displacement, mask_init_factor, mask_act="sigmoid"):
+    """`target_mask_predictor[0]` initial weights (optimizer.py:57-66)."""
+    d = np.arange(num_bins, dtype=np.float32) * np.float32(bin_displacement)
+    bias = 0.0 if mask_act == "sigmoid" else 0.5
+    return (mask_init_factor * np.tanh(2.0 - d) + bias).astype(np.float32)
+
+
+DIMP50 = dict(  # dimpnet50(...) as instantiated by train_settings/dimp/dimp50.py:91-95
+    C=512, H=18, W=18, K=4, feat_stride=16, num_iter=5, memory=50,
+    init_step_length=0.9, init_filter_reg=0.1, min_filter_reg=1e-3, init_gauss_sigma=0.9,
+    num_dist_bins=100, bin_displacement=0.1, mask_init_factor=3.0, mask_act="sigmoid",
+    score_act="relu", alpha_eps=0.0,
+)
+
+PRDIMP50 = dict(  # klcedimpnet50(...) per train_settings/dimp/prdimp50.py:95-98; 22x22 per parameter/dimp/prdimp50.py:12
+    C=512, H=22, W=22, K=4, feat_stride=16, num_iter=5, memory=50,
+    init_step_length=1.0, init_filter_reg=0.05, min_filter_reg=0.05, gauss_sigma=0.9,
+    alpha_eps=0.05, normalize_label=True, init_uni_weight=None, label_shrink=0.0,
+    softmax_reg=None, label_threshold=0.0,
+)
+
+ATOM18 = dict(  # pytracking/parameter/atom/default.py:20-21,26-28,40,44-45,58-62,74
+    C=64, H=18, W=18, K=4, memory=250, cg_iter=5, filter_reg=0.1, act_min_val=0.05,
+    output_sigma_factor=0.25, search_area_scale=5.0,
+)
+
+
+def dimp_problem(seed, n, cfg=DIMP50, with_weights=True, small=None):
+    """Inputs of one `filter_optimizer` call: (w0, feat, bb, sw).  `small` overrides C/H/W for the
+    oracle-sized parity cases."""
+    c = dict(cfg)
+    if small:
+        c.update(small)
+    rng = np.random.default_rng(seed)
+    feat = clf_features(rng, n, c["C"], c["H"], c["W"], c["K"])
+    crop = c["feat_stride"] * c["H"]
+    bb = target_boxes(rng, n, crop=float(crop))
+    if crop < 200:      # tiny maps: shrink the boxes with the crop
+        bb = (bb * (crop / 288.0)).astype(np.float32)
+    sw = decay_weights(n) if with_weights else None
+    w0 = (rng.standard_normal((c["C"], c["K"], c["K"]), dtype=np.float32) *
+          np.float32(0.5 * math.sqrt(1.0 / (c["C"] * c["K"] ** 2))))
+    return w0, feat, bb, sw
+
+
+def atom_problem(seed, n, cfg=ATOM18, small=None):
+    """Inputs of one ATOM `ConjugateGradient.run` call (section 8d cfg1)."""
+    c = dict(cfg)
+    if small:
+        c.update(small)
+    rng = np.random.default_rng(seed)
+    C, H, W, K = c["C"], c["H"], c["W"], c["K"]
+    samples = (rng.standard_normal((n, C, H, W), dtype=np.float32) * np.float32(0.1))
+    # label_function_spatial Gaussians (pytracking/libs/dcf.py:56-72 semantics): centred labels with jitter
+    sigma = c["output_sigma_factor"] * H / c["search_area_scale"] * 2.0
+    ctr = np.stack((H / 2.0 + rng.uniform(-2, 2, n), W / 2.0 + rng.uniform(-2, 2, n)), axis=1)
+    yy = np.arange(H, dtype=np.float64).reshape(1, -1, 1)
+    xx = np.arange(W, dtype=np.float64).reshape(1, 1, -1)
+    y = np.exp(-0.5 * ((yy - ctr[:, 0].reshape(-1, 1, 1)) ** 2 + (xx - ctr[:, 1].reshape(-1, 1, 1)) ** 2) / sigma ** 2)
+    sw = decay_weights(n)
+    x0 = rng.standard_normal((C, K, K), dtype=np.float32) * np.float32(0.05)
+    return x0, samples, y.astype(np.float32), sw

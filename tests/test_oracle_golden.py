@@ -1,0 +1,118 @@
+"""The numpy oracle (oracle/np_oracle.py) against the golden vectors produced by the unmodified
+reference (oracle/make_golden.py).  CPU only.  Tolerances: the oracle is run in float64 on the
+float32 inputs, the reference computed in float32, so agreement is limited by the reference's own
+rounding (measured 1e-7..1e-6 abs on these magnitudes); 2e-5 abs/rel is asserted."""
+import numpy as np
+import pytest
+
+from oracle import np_oracle as O
+from pytracking_amd import synth
+from conftest import load_golden
+
+ATOL = 2e-5
+
+
+def close(a, b, atol=ATOL, rtol=2e-5):
+    np.testing.assert_allclose(np.asarray(a, dtype=np.float64), np.asarray(b, dtype=np.float64), atol=atol, rtol=rtol)
+
+
+@pytest.mark.parametrize("tag", ["k4", "k3", "k1", "k5"])
+def test_filter_ops_single(tag):
+    g = load_golden("filter_ops")
+    feat, filt = g[f"{tag}_feat"].astype(np.float64), g[f"{tag}_filt"].astype(np.float64)
+    close(O.apply_filter(feat, filt), g[f"{tag}_scores"])
+    adj = O.apply_feat_transpose(feat, g[f"{tag}_inp"].astype(np.float64), filt.shape[-1])
+    close(adj, g[f"{tag}_adj_v2"], atol=1e-4)
+    close(adj, g[f"{tag}_adj_v3"], atol=1e-4)
+
+
+def test_filter_ops_multifilter_and_sequences():
+    g = load_golden("filter_ops")
+    f64 = lambda k: g[k].astype(np.float64)
+    close(O.apply_filter(f64("mf_feat"), f64("mf_filt")), g["mf_scores"])
+    close(O.apply_feat_transpose(f64("mf_feat"), f64("mf_inp"), 3), g["mf_adj"], atol=1e-4)
+    for s in range(2):
+        close(O.apply_filter(f64("s2_feat")[:, s], f64("s2_filt")[s]), g["s2_scores"][:, s])
+        close(O.apply_feat_transpose(f64("s2_feat")[:, s], f64("s2_inp")[:, s], 4), g["s2_adj"][s], atol=1e-4)
+
+
+def _dimp_kwargs(cfg, **over):
+    kw = dict(step_length=cfg["init_step_length"], filter_reg=cfg["init_filter_reg"],
+              min_filter_reg=cfg["min_filter_reg"], feat_stride=cfg["feat_stride"],
+              label_w=synth.gauss_lut(cfg["num_dist_bins"], cfg["bin_displacement"], cfg["init_gauss_sigma"]),
+              mask_w=synth.mask_lut(cfg["num_dist_bins"], cfg["bin_displacement"], cfg["mask_init_factor"]),
+              spatial_w=np.ones(cfg["num_dist_bins"], np.float32), bin_displacement=cfg["bin_displacement"],
+              alpha_eps=cfg["alpha_eps"])
+    kw.update(over)
+    return kw
+
+
+@pytest.mark.parametrize("name", ["dimp_sd_small_w", "dimp_sd_small_now", "dimp_sd_mid"])
+def test_dimp_sd_small(name):
+    g = load_golden(name)
+    over = {k: float(g[k]) for k in ("filter_reg", "min_filter_reg", "alpha_eps") if k in g}
+    sw = g["sw"].astype(np.float64) if "sw" in g else None
+    its, losses = O.dimp_sd(g["w0"].astype(np.float64), g["feat"].astype(np.float64), g["bb"].astype(np.float64), sw,
+                            num_iter=int(g["num_iter"]), **_dimp_kwargs(synth.DIMP50, **over))
+    close(its, g["iterates"])
+    close(losses, g["losses"], atol=1e-5, rtol=1e-4)
+    close(O.apply_filter(g["feat"].astype(np.float64), its[-1]), g["scores"])
+
+
+def test_dimp_sd_cfg2_n15_full_size():
+    g = load_golden("dimp_sd_cfg2_n15")
+    w0, feat, bb, sw = synth.dimp_problem(int(g["seed"]), int(g["n"]))
+    # float64 oracle on the float32 inputs: a float32 numpy run can flip sign(s) of a near-zero score
+    # (LeakyReluParDeriv is discontinuous, activation.py:43-44) and jump by ~3e-5 at a later iteration.
+    f64 = lambda a: a.astype(np.float64)
+    its, losses = O.dimp_sd(f64(w0), f64(feat), f64(bb), f64(sw), num_iter=5, **_dimp_kwargs(synth.DIMP50))
+    close(its, g["iterates"], atol=2e-6)
+    close(losses, g["losses"], atol=1e-5, rtol=1e-4)
+
+
+def test_dimp_l2_small():
+    g = load_golden("dimp_l2_small")
+    f64 = lambda k: g[k].astype(np.float64)
+    its, losses = O.dimp_l2_sd(f64("w0"), f64("feat"), f64("bb"), f64("sw"), num_iter=int(g["num_iter"]),
+                               step_length=float(g["step_length"]), filter_reg=float(g["filter_reg"]),
+                               min_filter_reg=float(g["min_filter_reg"]), feat_stride=16,
+                               gauss_sigma=float(g["gauss_sigma"]), hinge_threshold=float(g["hinge_threshold"]))
+    close(its, g["iterates"])
+    close(losses, g["losses"], atol=1e-5, rtol=1e-4)
+
+
+def _prdimp_kwargs(cfg, **over):
+    kw = dict(step_length=cfg["init_step_length"], filter_reg=cfg["init_filter_reg"],
+              min_filter_reg=cfg["min_filter_reg"], feat_stride=cfg["feat_stride"], gauss_sigma=cfg["gauss_sigma"],
+              alpha_eps=cfg["alpha_eps"], normalize_label=cfg["normalize_label"])
+    kw.update(over)
+    return kw
+
+
+def test_prdimp_small_and_options():
+    g = load_golden("prdimp_sd_small")
+    f64 = lambda k: g[k].astype(np.float64)
+    its, losses = O.prdimp_sd(f64("w0"), f64("feat"), f64("bb"), f64("sw"), num_iter=int(g["num_iter"]),
+                              **_prdimp_kwargs(synth.PRDIMP50))
+    close(its, g["iterates"])
+    close(losses, g["losses"], atol=1e-5, rtol=1e-4)
+    g = load_golden("prdimp_sd_opts")
+    its, losses = O.prdimp_sd(f64("w0"), f64("feat"), f64("bb"), None, num_iter=int(g["num_iter"]),
+                              **_prdimp_kwargs(synth.PRDIMP50, softmax_reg_val=float(g["softmax_reg"]),
+                                               uni_weight=float(g["uni_weight"]), label_shrink=float(g["label_shrink"]),
+                                               label_threshold=float(g["label_threshold"])))
+    close(its, g["iterates"])
+    close(losses, g["losses"], atol=1e-5, rtol=1e-4)
+
+
+@pytest.mark.parametrize("name", ["atom_cg_small_pr", "atom_cg_small_fr"])
+def test_atom_cg_small(name):
+    g = load_golden(name)
+    f64 = lambda k: g[k].astype(np.float64)
+    x = f64("x0")
+    state = None
+    for call in range(g["x_out"].shape[0]):
+        x, state = O.atom_cg(x, f64("samples"), f64("y"), f64("sw"), filter_reg=synth.ATOM18["filter_reg"],
+                             act_min_val=synth.ATOM18["act_min_val"], num_iter=int(g["num_iter"]),
+                             fletcher_reeves=bool(g["fletcher_reeves"]), state=state)
+        close(x, g["x_out"][call], atol=1e-5, rtol=1e-4)
