@@ -1,0 +1,176 @@
+/*
+ * pt_hot.h -- C ABI of libpt_hot.so: the MI355X (gfx950) implementation of PyTracking's per-frame
+ * online model-optimisation hot path.
+ *
+ * The reference (visionml/pytracking) has no FFI of its own on this path -- its operator API is a set of
+ * Python callables.  Each entry point below names the reference callable it replaces
+ * (paths relative to the reference root); the host-side mirror that binds them lives in
+ * pytracking_amd/ (ctypes), and INTEGRATION.md shows the stub a maintainer would add to the reference.
+ *
+ * Conventions (all entry points):
+ *   - plain pointers + sizes only; every pointer is a DEVICE pointer to contiguous fp32 unless stated;
+ *   - the caller owns every buffer; the library never allocates or frees device memory and keeps no
+ *     global state; scratch space is passed in (`ws`, sized by the matching *_ws_bytes());
+ *   - asynchronous on `stream` (a hipStream_t passed as void*; NULL = default stream), no device
+ *     synchronisation, no host callbacks -> every call is hipGraph-capturable;
+ *   - returns PT_OK (0) or a negative pt_status; nothing is launched when an argument check fails;
+ *   - layouts are the reference's: feature maps NCHW (n, C, H, W), filters (C, KH, KW), boxes xywh.
+ */
+#ifndef PT_HOT_H
+#define PT_HOT_H
+
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+typedef enum pt_status {
+    PT_OK = 0,
+    PT_ERR_NULL = -1,        /* required pointer is NULL */
+    PT_ERR_SHAPE = -2,       /* non-positive or inconsistent dimension */
+    PT_ERR_UNSUPPORTED = -3, /* valid request the kernels do not cover (e.g. KH*KW > 16 in the fused solver) */
+    PT_ERR_WORKSPACE = -4,   /* workspace too small / misaligned */
+    PT_ERR_LAUNCH = -5       /* hipGetLastError() != hipSuccess after a launch */
+} pt_status;
+
+const char* pt_strerror(int status);
+/* ABI version; bumped when a signature changes. */
+int pt_abi_version(void);
+
+/* ------------------------------------------------------------------------------------------------
+ * Filter layer -- ltr/models/layers/filter.py
+ * ---------------------------------------------------------------------------------------------- */
+
+/* apply_filter (filter.py:5-57), one sequence, one filter:
+ *   scores[i,y,x] = sum_{c,u,v} feat[i,c,y+u-KH/2,x+v-KW/2] * filt[c,u,v]      (zero padded)
+ * feat (n,C,H,W) with sample stride `feat_stride_n` floats (= C*H*W when dense; S*C*H*W for a 5-D
+ * (n,S,C,H,W) tensor, the caller then loops over sequences); filt (C,KH,KW); scores (n,OH,OW) dense.
+ * OH/OW may be the full correlation size H+2*(KH/2)-KH+1 (reference apply_filter) or anything smaller:
+ * the top-left OHxOW corner is produced (pytracking/libs/operation.py:17-32 conv2d(mode='same')).
+ * Requires KH*KW <= 16. */
+size_t pt_apply_filter_ws_bytes(int n, int C, int H, int W, int KH, int KW, int OH, int OW);
+int pt_apply_filter_f32(const float* feat, long feat_stride_n, const float* filt, float* scores,
+                        int n, int C, int H, int W, int KH, int KW, int OH, int OW,
+                        void* ws, size_t ws_bytes, void* stream);
+
+/* apply_feat_transpose (filter.py:91-182; _v2 and _v3 compute the same quantity):
+ *   grad[c,u,v] = sum_{i,y,x} feat[i,c,y+u-KH/2,x+v-KW/2] * inp[i,y,x]
+ * inp (n,OH,OW) dense; grad (C,KH,KW).  Requires KH*KW <= 16 (16-byte loads when (H*W) % 4 == 0). */
+size_t pt_feat_transpose_ws_bytes(int n, int C, int H, int W, int KH, int KW, int OH, int OW);
+int pt_feat_transpose_f32(const float* feat, long feat_stride_n, const float* inp, float* grad,
+                          int n, int C, int H, int W, int KH, int KW, int OH, int OW,
+                          void* ws, size_t ws_bytes, void* stream);
+
+/* ------------------------------------------------------------------------------------------------
+ * Steepest-descent filter optimisers -- ltr/models/target_classifier/optimizer.py
+ * ---------------------------------------------------------------------------------------------- */
+
+enum { PT_SD_DIMP = 0, PT_SD_DIMP_L2 = 1, PT_SD_PRDIMP = 2 };
+enum { PT_ACT_RELU = 0, PT_ACT_BENTPAR = 1 };       /* score_act (optimizer.py:74-82) */
+enum { PT_MASK_SIGMOID = 0, PT_MASK_LINEAR = 1 };   /* mask_act  (optimizer.py:58-66) */
+
+/* Host-side parameter block, read at call time (the trackers mutate the module attributes at run
+ * time, pytracking/tracker/dimp/dimp.py:589-602, so nothing is baked in). */
+typedef struct pt_sd_params {
+    int   kind;            /* PT_SD_* */
+    float step_length;     /* exp(log_step_length)                               optimizer.py:108 */
+    float reg;             /* max(filter_reg^2, min_filter_reg^2)                optimizer.py:109 */
+    float alpha_eps;       /*                                                    optimizer.py:156 */
+    float feat_stride;     /*                                                    optimizer.py:113 */
+    /* PT_SD_DIMP: learned radial look-up tables = the three 1x1 conv weights (optimizer.py:57-72).
+     * DEVICE pointers to `num_bins` floats each. */
+    int   num_bins;
+    float bin_displacement;
+    const float* label_lut;
+    const float* mask_lut;
+    const float* spatial_lut;
+    int   mask_act;        /* PT_MASK_* */
+    int   score_act;       /* PT_ACT_*  */
+    float act_param;       /* BentIdentPar b */
+    /* PT_SD_DIMP_L2 (optimizer.py:174-291) */
+    float gauss_sigma;     /* also PT_SD_PRDIMP */
+    float hinge_threshold;
+    /* PT_SD_PRDIMP (optimizer.py:294-439) */
+    float uni_weight;
+    int   normalize_label;
+    float label_shrink;
+    int   has_softmax_reg;
+    float softmax_reg;
+    float label_threshold;
+} pt_sd_params;
+
+/* {DiMPSteepestDescentGN, DiMPL2SteepestDescentGN, PrDiMPSteepestDescentNewton}.forward for one
+ * sequence (optimizer.py:85-170, 211-291, 355-439):
+ *   w_in (C,K,K) is not modified; w_iters receives all num_iter+1 iterates ((num_iter+1),C,K,K),
+ *   w_iters[0] = w_in; losses (num_iter+1 floats) may be NULL (= compute_losses False);
+ *   bb (n,4) xywh in crop pixels; sample_weight (n) or NULL.
+ * Requires K*K <= 16 and (H*W) % 4 == 0. */
+size_t pt_sd_ws_bytes(int n, int C, int H, int W, int K);
+int pt_sd_solve_f32(const pt_sd_params* p, const float* w_in, const float* feat, long feat_stride_n,
+                    const float* bb, const float* sample_weight,
+                    int n, int C, int H, int W, int K, int num_iter,
+                    float* w_iters, float* losses, void* ws, size_t ws_bytes, void* stream);
+
+/* ------------------------------------------------------------------------------------------------
+ * ATOM conjugate gradient -- pytracking/libs/optimization.py:72-163,227-289 (ConjugateGradient.run +
+ * run_CG) specialised to pytracking/tracker/atom/optim.py:71-99 (ConvProblem) with the MLU response
+ * activation (ltr/models/layers/activation.py:20-29).
+ *   x (C,K,K) is updated IN PLACE (optimization.py:259-260); samples (n,C,H,W); y (n,H,W);
+ *   sample_weights (n).  cg_state: 2*C*K*K+4 floats the caller keeps between calls
+ *   (p, r_prev, rho, has_p) -- only consulted when direction_forget_factor != 0.
+ * ---------------------------------------------------------------------------------------------- */
+size_t pt_atom_cg_ws_bytes(int n, int C, int H, int W, int K);
+int pt_atom_cg_f32(float* x, const float* samples, long samples_stride_n, const float* y,
+                   const float* sample_weights, float filter_reg, float act_min_val,
+                   int n, int C, int H, int W, int K, int num_iter, int fletcher_reeves,
+                   float direction_forget_factor, float* cg_state,
+                   void* ws, size_t ws_bytes, void* stream);
+
+/* ------------------------------------------------------------------------------------------------
+ * Precise RoI Pooling -- replaces ltr/external/PreciseRoIPooling (empty git submodule;
+ * import sites ltr/models/target_classifier/initializer.py:4,18,45 and
+ * ltr/models/bbreg/atom_iou_net.py:4,31-32,41-42,126-127,157,160).
+ *   features (N,C,H,W); rois (R,5) = [batch_idx, x0, y0, x1, y1]; out / grad_out (R,C,PH,PW).
+ *   bwd_feat ACCUMULATES into grad_features (caller zeroes it); bwd_coor writes grad_rois (R,5),
+ *   column 0 = 0.
+ * ---------------------------------------------------------------------------------------------- */
+int pt_prroi_fwd_f32(const float* features, const float* rois, float* out,
+                     int N, int C, int H, int W, int R, int PH, int PW, float spatial_scale, void* stream);
+int pt_prroi_bwd_feat_f32(const float* grad_out, const float* rois, float* grad_features,
+                          int N, int C, int H, int W, int R, int PH, int PW, float spatial_scale, void* stream);
+int pt_prroi_bwd_coor_f32(const float* grad_out, const float* features, const float* rois, float* grad_rois,
+                          int N, int C, int H, int W, int R, int PH, int PW, float spatial_scale, void* stream);
+
+/* ------------------------------------------------------------------------------------------------
+ * One synthetic tracking frame of the benchmark workload (BASELINE.json metric):
+ *   classify(test_feat) -> on-device arg-max -> overwrite memory slot `slot` (features + box centred on
+ *   the peak) -> steepest-descent solve over the n memory samples, all on `stream`, no host sync.
+ * mem_feat (n,C,H,W), mem_bb (n,4), sample_weight (n), filter (C,K,K) in/out, scores_out (OH*OW),
+ * peak_out (2 floats: row, col).
+ * ---------------------------------------------------------------------------------------------- */
+size_t pt_track_frame_ws_bytes(int n, int C, int H, int W, int K);
+int pt_track_frame_f32(const pt_sd_params* p, float* filter, float* mem_feat, float* mem_bb,
+                       const float* sample_weight, const float* test_feat, int slot,
+                       int n, int C, int H, int W, int K, int num_iter,
+                       float* scores_out, float* peak_out, void* ws, size_t ws_bytes, void* stream);
+
+/* ------------------------------------------------------------------------------------------------
+ * Measurement hook (bench.py roofline leg; not part of the reference's API).  While a profile is attached,
+ * every launch of the two feature-pass kernels is bracketed by HIP events on the stream it is launched on.
+ * The attachment is the only process-global state of the library; it must not be used during graph capture.
+ *   kernel ids: 0 = correlation pass (k_corr), 1 = adjoint pass (k_adj).
+ * ---------------------------------------------------------------------------------------------- */
+typedef struct pt_profile pt_profile;
+int pt_profile_create(pt_profile** out, int max_launches_per_kernel);
+int pt_profile_attach(pt_profile* prof);            /* NULL detaches */
+/* Synchronises on the recorded events; returns summed milliseconds and launch count of one kernel id. */
+int pt_profile_collect(pt_profile* prof, int kernel_id, double* total_ms, long* launches);
+int pt_profile_reset(pt_profile* prof);
+int pt_profile_destroy(pt_profile* prof);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* PT_HOT_H */

@@ -1,0 +1,127 @@
+"""Loader + ctypes prototypes for libpt_hot.so (C ABI declared in include/pt_hot.h).
+
+The product path has no fallback: if the shared library is missing or a call fails, a RuntimeError is
+raised.  `build_library()` compiles it in-tree with hipcc for gfx950 (cross-compiles without a GPU).
+"""
+import ctypes
+import os
+import subprocess
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(_HERE, "libpt_hot.so")
+SOURCES = ["filter_kernels.hip", "sd_solver.hip", "atom_cg.hip", "prroi.hip", "api.hip", "profile.hip"]
+HEADERS = ["common.h", "pt_internal.h", "rbuild.h", os.path.join("..", "..", "include", "pt_hot.h")]
+
+PT_SD_DIMP, PT_SD_DIMP_L2, PT_SD_PRDIMP = 0, 1, 2
+PT_ACT_RELU, PT_ACT_BENTPAR = 0, 1
+PT_MASK_SIGMOID, PT_MASK_LINEAR = 0, 1
+
+EXPORTS = [
+    "pt_strerror", "pt_abi_version",
+    "pt_apply_filter_ws_bytes", "pt_apply_filter_f32",
+    "pt_feat_transpose_ws_bytes", "pt_feat_transpose_f32",
+    "pt_sd_ws_bytes", "pt_sd_solve_f32",
+    "pt_atom_cg_ws_bytes", "pt_atom_cg_f32",
+    "pt_prroi_fwd_f32", "pt_prroi_bwd_feat_f32", "pt_prroi_bwd_coor_f32",
+    "pt_track_frame_ws_bytes", "pt_track_frame_f32",
+    "pt_profile_create", "pt_profile_attach", "pt_profile_collect", "pt_profile_reset", "pt_profile_destroy",
+]
+
+
+class SdParams(ctypes.Structure):
+    """Mirror of `pt_sd_params` (include/pt_hot.h)."""
+    _fields_ = [
+        ("kind", ctypes.c_int), ("step_length", ctypes.c_float), ("reg", ctypes.c_float),
+        ("alpha_eps", ctypes.c_float), ("feat_stride", ctypes.c_float),
+        ("num_bins", ctypes.c_int), ("bin_displacement", ctypes.c_float),
+        ("label_lut", ctypes.c_void_p), ("mask_lut", ctypes.c_void_p), ("spatial_lut", ctypes.c_void_p),
+        ("mask_act", ctypes.c_int), ("score_act", ctypes.c_int), ("act_param", ctypes.c_float),
+        ("gauss_sigma", ctypes.c_float), ("hinge_threshold", ctypes.c_float),
+        ("uni_weight", ctypes.c_float), ("normalize_label", ctypes.c_int), ("label_shrink", ctypes.c_float),
+        ("has_softmax_reg", ctypes.c_int), ("softmax_reg", ctypes.c_float), ("label_threshold", ctypes.c_float),
+    ]
+
+
+def needs_build() -> bool:
+    if not os.path.exists(LIB_PATH):
+        return True
+    t = os.path.getmtime(LIB_PATH)
+    deps = [os.path.join(_HERE, "csrc", s) for s in SOURCES + HEADERS]
+    return any(os.path.getmtime(d) > t for d in deps if os.path.exists(d))
+
+
+def build_library(force=False, verbose=False) -> str:
+    """hipcc --offload-arch=gfx950 -> pytracking_amd/libpt_hot.so (in-tree, travels with the repo snapshot)."""
+    if not force and not needs_build():
+        return LIB_PATH
+    hipcc = os.environ.get("HIPCC", "/opt/rocm/bin/hipcc")
+    cmd = [hipcc, "--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-shared", "-Wno-pass-failed",
+           "-o", LIB_PATH] + [os.path.join(_HERE, "csrc", s) for s in SOURCES]
+    res = subprocess.run(cmd, capture_output=True, text=True)
+    if verbose or res.returncode != 0:
+        print(" ".join(cmd))
+        print(res.stdout, res.stderr)
+    if res.returncode != 0:
+        raise RuntimeError("hipcc failed building libpt_hot.so:\n" + res.stderr)
+    return LIB_PATH
+
+
+_lib = None
+
+
+def lib():
+    """The loaded library (ctypes.CDLL) with argtypes set.  Raises if it has not been built."""
+    global _lib
+    if _lib is not None:
+        return _lib
+    if not os.path.exists(LIB_PATH):
+        raise RuntimeError(f"{LIB_PATH} is missing: run `python -c 'import __graft_entry__ as g; g.build()'` "
+                           "(there is no CPU fallback on the product path)")
+    L = ctypes.CDLL(LIB_PATH)
+    vp, f, i, l, sz = ctypes.c_void_p, ctypes.c_float, ctypes.c_int, ctypes.c_long, ctypes.c_size_t
+    L.pt_strerror.restype = ctypes.c_char_p
+    L.pt_strerror.argtypes = [i]
+    L.pt_abi_version.restype = i
+    L.pt_apply_filter_ws_bytes.restype = sz
+    L.pt_apply_filter_ws_bytes.argtypes = [i] * 8
+    L.pt_apply_filter_f32.restype = i
+    L.pt_apply_filter_f32.argtypes = [vp, l, vp, vp] + [i] * 8 + [vp, sz, vp]
+    L.pt_feat_transpose_ws_bytes.restype = sz
+    L.pt_feat_transpose_ws_bytes.argtypes = [i] * 8
+    L.pt_feat_transpose_f32.restype = i
+    L.pt_feat_transpose_f32.argtypes = [vp, l, vp, vp] + [i] * 8 + [vp, sz, vp]
+    L.pt_sd_ws_bytes.restype = sz
+    L.pt_sd_ws_bytes.argtypes = [i] * 5
+    L.pt_sd_solve_f32.restype = i
+    L.pt_sd_solve_f32.argtypes = [ctypes.POINTER(SdParams), vp, vp, l, vp, vp] + [i] * 6 + [vp, vp, vp, sz, vp]
+    L.pt_atom_cg_ws_bytes.restype = sz
+    L.pt_atom_cg_ws_bytes.argtypes = [i] * 5
+    L.pt_atom_cg_f32.restype = i
+    L.pt_atom_cg_f32.argtypes = [vp, vp, l, vp, vp, f, f] + [i] * 7 + [f, vp, vp, sz, vp]
+    for name in ("pt_prroi_fwd_f32", "pt_prroi_bwd_feat_f32"):
+        fn = getattr(L, name)
+        fn.restype = i
+        fn.argtypes = [vp, vp, vp] + [i] * 7 + [f, vp]
+    L.pt_prroi_bwd_coor_f32.restype = i
+    L.pt_prroi_bwd_coor_f32.argtypes = [vp, vp, vp, vp] + [i] * 7 + [f, vp]
+    L.pt_track_frame_ws_bytes.restype = sz
+    L.pt_track_frame_ws_bytes.argtypes = [i] * 5
+    L.pt_track_frame_f32.restype = i
+    L.pt_track_frame_f32.argtypes = [ctypes.POINTER(SdParams), vp, vp, vp, vp, vp] + [i] * 7 + [vp, vp, vp, sz, vp]
+    L.pt_profile_create.restype = i
+    L.pt_profile_create.argtypes = [ctypes.POINTER(vp), i]
+    L.pt_profile_attach.restype = i
+    L.pt_profile_attach.argtypes = [vp]
+    L.pt_profile_collect.restype = i
+    L.pt_profile_collect.argtypes = [vp, i, ctypes.POINTER(ctypes.c_double), ctypes.POINTER(ctypes.c_long)]
+    L.pt_profile_reset.restype = i
+    L.pt_profile_reset.argtypes = [vp]
+    L.pt_profile_destroy.restype = i
+    L.pt_profile_destroy.argtypes = [vp]
+    _lib = L
+    return L
+
+
+def check(status: int, what: str):
+    if status != 0:
+        raise RuntimeError(f"{what} failed: {lib().pt_strerror(status).decode()} ({status})")

@@ -1,0 +1,83 @@
+"""Device-resident state of one synthetic tracking sequence and the per-frame hot-path step
+(SURVEY.md section 8d): classify -> arg-max -> memory insert -> steepest-descent solve, executed by
+`pt_track_frame_f32` on the current stream with no host synchronisation (graph-capturable).
+
+Used by bench.py, __graft_entry__.smoke() and the GPU tests.  One `TrackState` = one video sequence = one
+GPU (sequences are independent).
+"""
+import ctypes
+import math
+
+import numpy as np
+import torch
+
+from . import _lib, synth
+from .filter import _ptr, _stream
+
+
+class TrackState:
+    def __init__(self, cfg, n, seed, device="cuda", kind="dimp"):
+        self.cfg, self.n, self.kind = dict(cfg), int(n), kind
+        c = self.cfg
+        dev = torch.device(device)
+        w0, feat, bb, sw = synth.dimp_problem(seed, n, c)
+        self.mem_feat = torch.from_numpy(feat).to(dev)
+        self.mem_bb = torch.from_numpy(bb).to(dev)
+        self.sample_weight = torch.from_numpy(sw).to(dev)
+        self.filter = torch.from_numpy(w0 if kind == "dimp" else w0 * 0).to(dev)
+        OH = c["H"] + (c["K"] + 1) % 2
+        OW = c["W"] + (c["K"] + 1) % 2
+        self.scores = torch.zeros(OH, OW, dtype=torch.float32, device=dev)
+        self.peak = torch.zeros(2, dtype=torch.float32, device=dev)
+        p = _lib.SdParams()
+        p.feat_stride = float(c["feat_stride"])
+        p.step_length = float(c["init_step_length"])
+        p.reg = max(c["init_filter_reg"] ** 2, c["min_filter_reg"] ** 2)
+        p.alpha_eps = float(c["alpha_eps"])
+        if kind == "dimp":
+            p.kind = _lib.PT_SD_DIMP
+            self._luts = [torch.from_numpy(a).to(dev) for a in (
+                synth.gauss_lut(c["num_dist_bins"], c["bin_displacement"], c["init_gauss_sigma"]),
+                synth.mask_lut(c["num_dist_bins"], c["bin_displacement"], c["mask_init_factor"], c["mask_act"]),
+                np.ones(c["num_dist_bins"], np.float32))]
+            p.num_bins = c["num_dist_bins"]
+            p.bin_displacement = float(c["bin_displacement"])
+            p.label_lut, p.mask_lut, p.spatial_lut = (t.data_ptr() for t in self._luts)
+            p.mask_act = _lib.PT_MASK_SIGMOID if c["mask_act"] == "sigmoid" else _lib.PT_MASK_LINEAR
+            p.score_act = _lib.PT_ACT_RELU
+            p.act_param = 1.0
+        else:
+            p.kind = _lib.PT_SD_PRDIMP
+            p.gauss_sigma = float(c["gauss_sigma"])
+            p.normalize_label = int(bool(c["normalize_label"]))
+            p.uni_weight = float(c["init_uni_weight"] or 0.0)
+            p.label_shrink = float(c["label_shrink"])
+            p.has_softmax_reg = int(c["softmax_reg"] is not None)
+            p.softmax_reg = float(c["softmax_reg"] or 0.0)
+            p.label_threshold = float(c["label_threshold"])
+        self.params = p
+        L = _lib.lib()
+        nb = L.pt_track_frame_ws_bytes(n, c["C"], c["H"], c["W"], c["K"])
+        if nb == 0:
+            raise RuntimeError("pt_track_frame_ws_bytes rejected the configuration")
+        self.ws = torch.empty(nb, dtype=torch.uint8, device=dev)
+
+    def step(self, test_feat, slot, num_iter):
+        """test_feat (C,H,W) device tensor.  Asynchronous."""
+        c = self.cfg
+        assert test_feat.is_contiguous() and test_feat.dtype == torch.float32
+        rc = _lib.lib().pt_track_frame_f32(
+            ctypes.byref(self.params), _ptr(self.filter), _ptr(self.mem_feat), _ptr(self.mem_bb),
+            _ptr(self.sample_weight), _ptr(test_feat), int(slot), self.n, c["C"], c["H"], c["W"], c["K"], int(num_iter),
+            _ptr(self.scores), _ptr(self.peak), _ptr(self.ws), self.ws.numel(), _stream())
+        _lib.check(rc, "pt_track_frame_f32")
+
+    # algorithmic work of one frame, SURVEY.md section 8(d)
+    def bytes_per_solve(self, num_iter):
+        c = self.cfg
+        return 2 * num_iter * 4 * self.n * c["C"] * c["H"] * c["W"]
+
+    def flops_per_solve(self, num_iter):
+        c = self.cfg
+        O = c["H"] + (c["K"] + 1) % 2
+        return 3 * num_iter * 2 * self.n * c["C"] * c["K"] ** 2 * O * O

@@ -1,0 +1,87 @@
+// Measurement hook: HIP-event brackets around the feature-pass kernels (see include/pt_hot.h).
+#include <vector>
+#include "common.h"
+#include "pt_internal.h"
+
+struct pt_profile {
+    int cap;
+    std::vector<hipEvent_t> start[2], stop[2];
+    int used[2];
+    bool open[2];
+};
+
+static pt_profile* g_prof = nullptr;
+
+extern "C" int pt_profile_create(pt_profile** out, int max_launches_per_kernel) {
+    if (!out) return PT_ERR_NULL;
+    if (max_launches_per_kernel <= 0) return PT_ERR_SHAPE;
+    pt_profile* p = new pt_profile();
+    p->cap = max_launches_per_kernel;
+    for (int k = 0; k < 2; ++k) {
+        p->start[k].resize(p->cap);
+        p->stop[k].resize(p->cap);
+        p->used[k] = 0;
+        p->open[k] = false;
+        for (int e = 0; e < p->cap; ++e) {
+            if (hipEventCreate(&p->start[k][e]) != hipSuccess || hipEventCreate(&p->stop[k][e]) != hipSuccess)
+                return PT_ERR_LAUNCH;
+        }
+    }
+    *out = p;
+    return PT_OK;
+}
+
+extern "C" int pt_profile_attach(pt_profile* prof) {
+    g_prof = prof;
+    return PT_OK;
+}
+
+extern "C" int pt_profile_reset(pt_profile* prof) {
+    if (!prof) return PT_ERR_NULL;
+    prof->used[0] = prof->used[1] = 0;
+    prof->open[0] = prof->open[1] = false;
+    return PT_OK;
+}
+
+extern "C" int pt_profile_collect(pt_profile* prof, int kernel_id, double* total_ms, long* launches) {
+    if (!prof || !total_ms || !launches) return PT_ERR_NULL;
+    if (kernel_id < 0 || kernel_id > 1) return PT_ERR_SHAPE;
+    double tot = 0.0;
+    for (int e = 0; e < prof->used[kernel_id]; ++e) {
+        if (hipEventSynchronize(prof->stop[kernel_id][e]) != hipSuccess) return PT_ERR_LAUNCH;
+        float ms = 0.f;
+        if (hipEventElapsedTime(&ms, prof->start[kernel_id][e], prof->stop[kernel_id][e]) != hipSuccess)
+            return PT_ERR_LAUNCH;
+        tot += ms;
+    }
+    *total_ms = tot;
+    *launches = prof->used[kernel_id];
+    return PT_OK;
+}
+
+extern "C" int pt_profile_destroy(pt_profile* prof) {
+    if (!prof) return PT_ERR_NULL;
+    if (g_prof == prof) g_prof = nullptr;
+    for (int k = 0; k < 2; ++k)
+        for (int e = 0; e < prof->cap; ++e) {
+            hipEventDestroy(prof->start[k][e]);
+            hipEventDestroy(prof->stop[k][e]);
+        }
+    delete prof;
+    return PT_OK;
+}
+
+void pt_prof_begin(int k, hipStream_t st) {
+    pt_profile* p = g_prof;
+    if (!p || p->used[k] >= p->cap) return;
+    hipEventRecord(p->start[k][p->used[k]], st);
+    p->open[k] = true;
+}
+
+void pt_prof_end(int k, hipStream_t st) {
+    pt_profile* p = g_prof;
+    if (!p || !p->open[k]) return;
+    hipEventRecord(p->stop[k][p->used[k]], st);
+    p->used[k]++;
+    p->open[k] = false;
+}

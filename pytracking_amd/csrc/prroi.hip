@@ -1,0 +1,193 @@
+// Precise RoI Pooling for gfx950.  Replaces the CUDA-only extension the reference imports from the (empty)
+// git submodule ltr/external/PreciseRoIPooling (import sites: ltr/models/target_classifier/initializer.py:4,18,45,
+// ltr/models/bbreg/atom_iou_net.py:4,31-32,41-42,126-127,157,160).
+//
+// Definition (Jiang et al., ECCV 2018): with f the bilinear interpolant of the feature map
+// (hat basis, zero outside the map) the output of bin (p,q) of RoI r is the exact integral of f over the bin divided
+// by the bin area.  The integral separates:  sum_{j,i} F[j,i] * wy_j * wx_i  with
+//   wx_i = G(xe - i) - G(xs - i),  G = CDF of the hat function,
+// non-zero only for i in [floor(xs), ceil(xe)].  The gradient w.r.t. the bin edges is the boundary line integral
+// (Lx, Ly below) minus the mean-value term; RoI coordinates get it through xs = X0 + q*bw etc.
+//
+// The op is tiny (10 RoIs x 256 ch x 25 bins per IoUNet refine step): it is launch-latency bound, so each kernel
+// is a single flat launch; no LDS staging is needed because a bin touches <= ~4x4 pixels that stay in L1/L2.
+#include "common.h"
+#include "pt_internal.h"
+
+__device__ __forceinline__ float hat_cdf(float u) {
+    if (u <= -1.f) return 0.f;
+    if (u <= 0.f) return 0.5f * (u + 1.f) * (u + 1.f);
+    if (u <= 1.f) return 1.f - 0.5f * (1.f - u) * (1.f - u);
+    return 1.f;
+}
+__device__ __forceinline__ float hat(float u) { return fmaxf(0.f, 1.f - fabsf(u)); }
+
+struct Bin {
+    float xs, xe, ys, ye, bw, bh, area;
+    int b, i0, i1, j0, j1;
+};
+
+__device__ __forceinline__ Bin make_bin(const float* __restrict__ roi, int p, int q, int PH, int PW, float scale, int H,
+                                        int W) {
+    Bin k;
+    k.b = (int)roi[0];
+    const float X0 = roi[1] * scale, Y0 = roi[2] * scale, X1 = roi[3] * scale, Y1 = roi[4] * scale;
+    k.bw = fmaxf(X1 - X0, 0.f) / (float)PW;
+    k.bh = fmaxf(Y1 - Y0, 0.f) / (float)PH;
+    k.xs = X0 + (float)q * k.bw;
+    k.xe = k.xs + k.bw;
+    k.ys = Y0 + (float)p * k.bh;
+    k.ye = k.ys + k.bh;
+    k.area = k.bw * k.bh;
+    k.i0 = max(0, (int)floorf(k.xs));
+    k.i1 = min(W - 1, (int)ceilf(k.xe));
+    k.j0 = max(0, (int)floorf(k.ys));
+    k.j1 = min(H - 1, (int)ceilf(k.ye));
+    return k;
+}
+
+__global__ void k_prroi_fwd(const float* __restrict__ feat, const float* __restrict__ rois, float* __restrict__ out,
+                            int N, int C, int H, int W, int R, int PH, int PW, float scale) {
+    const long idx = (long)blockIdx.x * blockDim.x + threadIdx.x;
+    const long total = (long)R * C * PH * PW;
+    if (idx >= total) return;
+    const int q = (int)(idx % PW);
+    const int p = (int)((idx / PW) % PH);
+    const int c = (int)((idx / ((long)PW * PH)) % C);
+    const int r = (int)(idx / ((long)PW * PH * C));
+    const Bin k = make_bin(rois + 5 * r, p, q, PH, PW, scale, H, W);
+    float acc = 0.f;
+    if (k.area > 0.f && k.b >= 0 && k.b < N) {
+        const float* __restrict__ f = feat + ((long)k.b * C + c) * H * W;
+        for (int j = k.j0; j <= k.j1; ++j) {
+            const float wy = hat_cdf(k.ye - (float)j) - hat_cdf(k.ys - (float)j);
+            float row = 0.f;
+            for (int i = k.i0; i <= k.i1; ++i)
+                row += f[j * W + i] * (hat_cdf(k.xe - (float)i) - hat_cdf(k.xs - (float)i));
+            acc += wy * row;
+        }
+        acc /= k.area;
+    }
+    out[idx] = acc;
+}
+
+__global__ void k_prroi_bwd_feat(const float* __restrict__ gout, const float* __restrict__ rois,
+                                 float* __restrict__ gfeat, int N, int C, int H, int W, int R, int PH, int PW,
+                                 float scale) {
+    const long idx = (long)blockIdx.x * blockDim.x + threadIdx.x;
+    const long total = (long)R * C * PH * PW;
+    if (idx >= total) return;
+    const int q = (int)(idx % PW);
+    const int p = (int)((idx / PW) % PH);
+    const int c = (int)((idx / ((long)PW * PH)) % C);
+    const int r = (int)(idx / ((long)PW * PH * C));
+    const Bin k = make_bin(rois + 5 * r, p, q, PH, PW, scale, H, W);
+    if (!(k.area > 0.f) || k.b < 0 || k.b >= N) return;
+    const float g = gout[idx] / k.area;
+    float* __restrict__ f = gfeat + ((long)k.b * C + c) * H * W;
+    for (int j = k.j0; j <= k.j1; ++j) {
+        const float wy = hat_cdf(k.ye - (float)j) - hat_cdf(k.ys - (float)j);
+        for (int i = k.i0; i <= k.i1; ++i) {
+            const float w = wy * (hat_cdf(k.xe - (float)i) - hat_cdf(k.xs - (float)i));
+            if (w != 0.f) atomicAdd(f + j * W + i, g * w);
+        }
+    }
+}
+
+// one workgroup per RoI; threads stride over (c,p,q); fixed-order block reduction of the four coordinate sums
+__global__ __launch_bounds__(256) void k_prroi_bwd_coor(const float* __restrict__ gout, const float* __restrict__ feat,
+                                                        const float* __restrict__ rois, float* __restrict__ grois,
+                                                        int N, int C, int H, int W, int R, int PH, int PW,
+                                                        float scale) {
+    __shared__ float scratch[16];
+    const int r = blockIdx.x;
+    const int per = C * PH * PW;
+    float gx0 = 0.f, gy0 = 0.f, gx1 = 0.f, gy1 = 0.f;
+    for (int e = threadIdx.x; e < per; e += blockDim.x) {
+        const int q = e % PW, p = (e / PW) % PH, c = e / (PW * PH);
+        const Bin k = make_bin(rois + 5 * r, p, q, PH, PW, scale, H, W);
+        if (!(k.area > 0.f) || k.b < 0 || k.b >= N) continue;
+        const float* __restrict__ f = feat + ((long)k.b * C + c) * H * W;
+        float integ = 0.f, lxs = 0.f, lxe = 0.f, lys = 0.f, lye = 0.f;
+        for (int j = k.j0; j <= k.j1; ++j) {
+            const float wy = hat_cdf(k.ye - (float)j) - hat_cdf(k.ys - (float)j);
+            const float hys = hat(k.ys - (float)j), hye = hat(k.ye - (float)j);
+            float row = 0.f, rxs = 0.f, rxe = 0.f;
+            for (int i = k.i0; i <= k.i1; ++i) {
+                const float v = f[j * W + i];
+                row += v * (hat_cdf(k.xe - (float)i) - hat_cdf(k.xs - (float)i));
+                rxs += v * hat(k.xs - (float)i);
+                rxe += v * hat(k.xe - (float)i);
+            }
+            integ += wy * row;
+            lxs += wy * rxs;
+            lxe += wy * rxe;
+            lys += hys * row;
+            lye += hye * row;
+        }
+        const float inv = 1.f / k.area;
+        const float o = integ * inv;
+        const float d_xs = (-lxs + k.bh * o) * inv, d_xe = (lxe - k.bh * o) * inv;
+        const float d_ys = (-lys + k.bw * o) * inv, d_ye = (lye - k.bw * o) * inv;
+        const float g = gout[(long)r * per + e];
+        const float fq = (float)q / (float)PW, fq1 = (float)(q + 1) / (float)PW;
+        const float fp = (float)p / (float)PH, fp1 = (float)(p + 1) / (float)PH;
+        gx0 += g * (d_xs * (1.f - fq) + d_xe * (1.f - fq1));
+        gx1 += g * (d_xs * fq + d_xe * fq1);
+        gy0 += g * (d_ys * (1.f - fp) + d_ye * (1.f - fp1));
+        gy1 += g * (d_ys * fp + d_ye * fp1);
+    }
+    gx0 = block_sum(gx0, scratch);
+    gy0 = block_sum(gy0, scratch);
+    gx1 = block_sum(gx1, scratch);
+    gy1 = block_sum(gy1, scratch);
+    if (threadIdx.x == 0) {
+        float* o = grois + 5 * r;
+        o[0] = 0.f;
+        o[1] = gx0 * scale;
+        o[2] = gy0 * scale;
+        o[3] = gx1 * scale;
+        o[4] = gy1 * scale;
+    }
+}
+
+static int prroi_check(const void* a, const void* b, const void* c, int N, int C, int H, int W, int R, int PH, int PW) {
+    if (!a || !b || !c) return PT_ERR_NULL;
+    if (N <= 0 || C <= 0 || H <= 0 || W <= 0 || R < 0 || PH <= 0 || PW <= 0) return PT_ERR_SHAPE;
+    return PT_OK;
+}
+
+extern "C" int pt_prroi_fwd_f32(const float* features, const float* rois, float* out, int N, int C, int H, int W, int R,
+                                int PH, int PW, float spatial_scale, void* stream) {
+    int rc = prroi_check(features, rois, out, N, C, H, W, R, PH, PW);
+    if (rc || R == 0) return rc;
+    const long total = (long)R * C * PH * PW;
+    hipLaunchKernelGGL(k_prroi_fwd, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, (hipStream_t)stream, features,
+                       rois, out, N, C, H, W, R, PH, PW, spatial_scale);
+    PT_CHECK_LAUNCH();
+    return PT_OK;
+}
+
+extern "C" int pt_prroi_bwd_feat_f32(const float* grad_out, const float* rois, float* grad_features, int N, int C, int H,
+                                     int W, int R, int PH, int PW, float spatial_scale, void* stream) {
+    int rc = prroi_check(grad_out, rois, grad_features, N, C, H, W, R, PH, PW);
+    if (rc || R == 0) return rc;
+    const long total = (long)R * C * PH * PW;
+    hipLaunchKernelGGL(k_prroi_bwd_feat, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, (hipStream_t)stream,
+                       grad_out, rois, grad_features, N, C, H, W, R, PH, PW, spatial_scale);
+    PT_CHECK_LAUNCH();
+    return PT_OK;
+}
+
+extern "C" int pt_prroi_bwd_coor_f32(const float* grad_out, const float* features, const float* rois, float* grad_rois,
+                                     int N, int C, int H, int W, int R, int PH, int PW, float spatial_scale,
+                                     void* stream) {
+    int rc = prroi_check(grad_out, features, rois, N, C, H, W, R, PH, PW);
+    if (rc) return rc;
+    if (!grad_rois) return PT_ERR_NULL;
+    if (R == 0) return PT_OK;
+    hipLaunchKernelGGL(k_prroi_bwd_coor, dim3(R), dim3(256), 0, (hipStream_t)stream, grad_out, features, rois, grad_rois,
+                       N, C, H, W, R, PH, PW, spatial_scale);
+    PT_CHECK_LAUNCH();
+    return PT_OK;
+}

@@ -1,0 +1,45 @@
+// Internal launch plans + launcher prototypes shared by the translation units of libpt_hot.
+#pragma once
+#include <hip/hip_runtime.h>
+#include <stddef.h>
+#include "../../include/pt_hot.h"
+
+// Geometry of the two feature passes for one (n, C, H, W, KH, KW) problem.
+//   corr pass:  grid (n, KS): one workgroup per (sample, channel slice) -> partial score maps
+//               spart[KS][n][OH*OW]; the consumer sums the KS slices in a fixed order.
+//   adj  pass:  grid (ceil(C/16), KSPL): one workgroup per (16-channel block, slice of the flattened
+//               n*H*W position axis in groups of 16) -> gpart[KSPL][C*KK]; consumer sums KSPL slices.
+struct PtPlan {
+    int n, C, H, W, KH, KW, OH, OW;
+    int HW, KK, OO;
+    int KS, cper;        // corr: channel slices, channels per slice (multiple of 4)
+    int corr_threads;    // corr block size (one wave per 64-position tile, max 16 waves)
+    size_t corr_lds;     // dynamic LDS bytes of the corr kernel
+    int NG;              // adj: number of 16-position groups = ceil(n*HW/16)
+    int KSPL, gper;      // adj: position slices, groups per slice
+    bool vec4;           // HW % 4 == 0 -> 16-byte feature loads
+};
+
+PtPlan pt_make_plan(int n, int C, int H, int W, int KH, int KW, int OH, int OW);
+
+// sizes in floats
+static inline size_t pt_spart_floats(const PtPlan& p) { return (size_t)p.KS * p.n * p.OO; }
+static inline size_t pt_R_floats(const PtPlan& p) { return (size_t)p.NG * 256; }
+static inline size_t pt_gpart_floats(const PtPlan& p) { return (size_t)p.KSPL * p.C * p.KK; }
+static inline size_t pt_align_floats(size_t x) { return (x + 63) & ~(size_t)63; }   // 256-byte carve granule
+
+int pt_launch_corr(const PtPlan& p, const float* feat, long stride_n, const float* filt, float* spart, hipStream_t st);
+int pt_launch_adj(const PtPlan& p, const float* feat, long stride_n, const float* R, float* gpart, hipStream_t st);
+// scores[i][o] = sum_ks spart[ks][i][o]
+int pt_launch_sum_slices(const float* part, float* out, int slices, size_t count, hipStream_t st);
+// R (im2col of the residual map, MFMA-B layout) from inp (n, OH, OW)
+int pt_launch_build_R(const PtPlan& p, const float* inp, float* R, hipStream_t st);
+
+#define PT_CHECK_LAUNCH()                                    \
+    do {                                                     \
+        if (hipGetLastError() != hipSuccess) return PT_ERR_LAUNCH; \
+    } while (0)
+
+// measurement hook (profile.hip): no-ops unless a pt_profile is attached
+void pt_prof_begin(int kernel_id, hipStream_t st);
+void pt_prof_end(int kernel_id, hipStream_t st);

@@ -1,0 +1,159 @@
+"""Host-side mirror of `ltr/models/layers/filter.py` on top of libpt_hot.so.
+
+Same names, argument meaning and shape conventions as the reference:
+    apply_filter(feat, filter, dilation_factors=None)            filter.py:5-57
+    apply_feat_transpose(feat, input, filter_ksz, training, groups)   filter.py:91-107
+    filter_gradient(feat, filter, label=None, training=True)     filter.py:203-216
+feat is (images, [sequences], C, H, W); filter (sequences, C, KH, KW); scores (images, sequences, OH, OW).
+
+Device tensors only -- there is no CPU fallback on the product path (tests compare against oracle/).
+`apply_filter` and `apply_feat_transpose` are each other's backward w.r.t. filter / input, so the pair
+stays usable under autograd for filter-space optimisers; gradients w.r.t. the features are a training-only
+path that is out of scope and raise NotImplementedError.
+"""
+import ctypes
+
+import torch
+
+from . import _lib
+
+_WS = {}
+
+
+def workspace(nbytes: int, device) -> torch.Tensor:
+    """Caller-owned scratch for the C ABI (the library never allocates).  One growing buffer per device;
+    reuse across calls is safe because every call is ordered on the current stream."""
+    key = (device.type, device.index)
+    buf = _WS.get(key)
+    if buf is None or buf.numel() < nbytes:
+        buf = torch.empty(max(int(nbytes), 1 << 20), dtype=torch.uint8, device=device)
+        _WS[key] = buf
+    return buf
+
+
+def _stream():
+    return ctypes.c_void_p(torch.cuda.current_stream().cuda_stream)
+
+
+def _ptr(t):
+    return ctypes.c_void_p(t.data_ptr())
+
+
+def _require_device(*tensors):
+    for t in tensors:
+        if not t.is_cuda:
+            raise RuntimeError("pytracking_amd ops run on the MI355X only (got a CPU tensor); "
+                               "the CPU restatement lives in oracle/ and is test infrastructure")
+        if t.dtype != torch.float32:
+            raise RuntimeError(f"pytracking_amd ops are fp32 (got {t.dtype})")
+
+
+def _out_size(H, W, KH, KW):
+    return H + 2 * (KH // 2) - KH + 1, W + 2 * (KW // 2) - KW + 1
+
+
+def corr_raw(feat4, filt3, out_hw=None):
+    """feat4 (n,C,H,W) [sample-strided view allowed], filt3 (C,KH,KW) -> (n,OH,OW)."""
+    n, C, H, W = feat4.shape
+    KH, KW = filt3.shape[-2:]
+    OH, OW = out_hw if out_hw is not None else _out_size(H, W, KH, KW)
+    if feat4.stride()[1:] != (H * W, W, 1):
+        feat4 = feat4.contiguous()
+    filt3 = filt3.contiguous()
+    L = _lib.lib()
+    out = torch.empty((n, OH, OW), dtype=torch.float32, device=feat4.device)
+    nb = L.pt_apply_filter_ws_bytes(n, C, H, W, KH, KW, OH, OW)
+    ws = workspace(nb, feat4.device)
+    rc = L.pt_apply_filter_f32(_ptr(feat4), feat4.stride(0), _ptr(filt3), _ptr(out), n, C, H, W, KH, KW, OH, OW,
+                               _ptr(ws), ws.numel(), _stream())
+    _lib.check(rc, "pt_apply_filter_f32")
+    return out
+
+
+def adj_raw(feat4, inp3, ksz):
+    """feat4 (n,C,H,W), inp3 (n,OH,OW) -> (C,KH,KW)."""
+    n, C, H, W = feat4.shape
+    KH, KW = ksz
+    OH, OW = inp3.shape[-2:]
+    if feat4.stride()[1:] != (H * W, W, 1):
+        feat4 = feat4.contiguous()
+    inp3 = inp3.contiguous()
+    L = _lib.lib()
+    out = torch.empty((C, KH, KW), dtype=torch.float32, device=feat4.device)
+    nb = L.pt_feat_transpose_ws_bytes(n, C, H, W, KH, KW, OH, OW)
+    ws = workspace(nb, feat4.device)
+    rc = L.pt_feat_transpose_f32(_ptr(feat4), feat4.stride(0), _ptr(inp3), _ptr(out), n, C, H, W, KH, KW, OH, OW,
+                                 _ptr(ws), ws.numel(), _stream())
+    _lib.check(rc, "pt_feat_transpose_f32")
+    return out
+
+
+def _as5d(feat):
+    return feat if feat.dim() == 5 else feat.unsqueeze(1)
+
+
+class _ApplyFilter(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, feat, filt):
+        f5 = _as5d(feat)
+        S = f5.shape[1]
+        scores = torch.stack([corr_raw(f5[:, s], filt[s]) for s in range(S)], dim=1)
+        ctx.save_for_backward(feat, filt)
+        return scores
+
+    @staticmethod
+    def backward(ctx, grad):
+        feat, filt = ctx.saved_tensors
+        if ctx.needs_input_grad[0]:
+            raise NotImplementedError("gradient of apply_filter w.r.t. the features (training path) is out of scope")
+        return None, _ApplyFeatTranspose.apply(feat, grad, tuple(filt.shape[-2:]))
+
+
+class _ApplyFeatTranspose(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, feat, inp, ksz):
+        f5 = _as5d(feat)
+        S = f5.shape[1]
+        out = torch.stack([adj_raw(f5[:, s], inp[:, s], ksz) for s in range(S)], dim=0)
+        ctx.save_for_backward(feat)
+        ctx.ksz = ksz
+        ctx.inp_hw = tuple(inp.shape[-2:])
+        return out
+
+    @staticmethod
+    def backward(ctx, grad):
+        (feat,) = ctx.saved_tensors
+        if ctx.needs_input_grad[0]:
+            raise NotImplementedError("gradient of apply_feat_transpose w.r.t. the features is out of scope")
+        return None, _ApplyFilter.apply(feat, grad), None
+
+
+def apply_filter(feat, filter, dilation_factors=None):
+    """Cross-correlate each sequence's filter with its features (reference: filter.py:5-57)."""
+    _require_device(feat, filter)
+    if filter.dim() == 5 or dilation_factors is not None:
+        raise NotImplementedError("multi-filter / dilated apply_filter (LWL, filter.py:29-52) is a later SURVEY 8 row")
+    num_sequences = feat.shape[1] if feat.dim() == 5 else 1
+    assert filter.shape[0] == num_sequences and feat.shape[-3] == filter.shape[-3]
+    return _ApplyFilter.apply(feat, filter)
+
+
+def apply_feat_transpose(feat, input, filter_ksz, training=True, groups=1):
+    """Adjoint of apply_filter w.r.t. the filter (reference: filter.py:91-107; `training` only selected
+    between two equivalent conv formulations there)."""
+    if groups != 1:
+        raise NotImplementedError('Not implemented other values of group.')
+    _require_device(feat, input)
+    if input.dim() == 5:
+        raise NotImplementedError("multi-filter apply_feat_transpose (filter.py:158-182) is a later SURVEY 8 row")
+    if isinstance(filter_ksz, int):
+        filter_ksz = (filter_ksz, filter_ksz)
+    return _ApplyFeatTranspose.apply(feat, input, tuple(filter_ksz))
+
+
+def filter_gradient(feat, filter, label=None, training=True):
+    """reference: filter.py:203-216."""
+    residuals = apply_filter(feat, filter)
+    if label is not None:
+        residuals = residuals - label
+    return apply_feat_transpose(feat, residuals, (filter.shape[-2], filter.shape[-1]), training=training)

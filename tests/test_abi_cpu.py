@@ -1,0 +1,76 @@
+"""CPU-side checks of the drop-in boundary: the C-ABI library builds/loads and exports every symbol the
+header declares (no compute calls -- there is no GPU here), argument checking returns the documented
+status codes, and the host-side mirrors keep the reference's names and state_dict keys."""
+import ctypes
+import os
+import re
+
+import pytest
+import torch
+
+from pytracking_amd import _lib
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+@pytest.fixture(scope="module")
+def L():
+    _lib.build_library()
+    return _lib.lib()
+
+
+def test_header_symbols_exported(L):
+    hdr = open(os.path.join(ROOT, "include", "pt_hot.h")).read()
+    declared = set(re.findall(r"\b(pt_[a-z0-9_]+)\s*\(", hdr))
+    declared -= {"pt_status", "pt_sd_params", "pt_profile"}
+    assert declared == set(_lib.EXPORTS), declared ^ set(_lib.EXPORTS)
+    for name in declared:
+        assert hasattr(L, name), name
+    assert L.pt_abi_version() == 1
+
+
+def test_argument_checks_do_not_launch(L):
+    p = _lib.SdParams()
+    n = None
+    one = ctypes.c_void_p(256)
+    assert L.pt_apply_filter_f32(n, 0, n, n, 1, 1, 1, 1, 1, 1, 1, 1, n, 0, n) == -1          # PT_ERR_NULL
+    assert L.pt_apply_filter_f32(one, 324, one, one, 0, 8, 18, 18, 4, 4, 19, 19, one, 0, n) == -2   # shape
+    assert L.pt_apply_filter_f32(one, 324, one, one, 1, 8, 18, 18, 5, 5, 18, 18, one, 0, n) == -3   # 25 taps
+    assert L.pt_apply_filter_f32(one, 8 * 324, one, one, 1, 8, 18, 18, 4, 4, 19, 19, one, 0, n) == -4  # workspace
+    assert L.pt_sd_solve_f32(ctypes.byref(p), n, n, 0, n, n, 1, 1, 1, 1, 1, 1, n, n, n, 0, n) == -1
+    assert L.pt_prroi_fwd_f32(one, one, one, 1, 1, 0, 4, 1, 2, 2, 1.0, n) == -2
+    assert b"workspace" in L.pt_strerror(-4)
+    assert L.pt_sd_ws_bytes(50, 512, 18, 18, 4) > 0
+    assert L.pt_sd_ws_bytes(0, 512, 18, 18, 4) == 0
+    assert L.pt_track_frame_ws_bytes(50, 512, 18, 18, 4) > L.pt_sd_ws_bytes(50, 512, 18, 18, 4)
+
+
+def test_module_mirror_state_dict_keys():
+    from pytracking_amd import optimizer
+    m = optimizer.DiMPSteepestDescentGN(num_iter=5, init_step_length=0.9, init_filter_reg=0.1, init_gauss_sigma=0.9,
+                                        num_dist_bins=100, bin_displacement=0.1, mask_init_factor=3.0)
+    # keys a reference checkpoint carries for this module (optimizer.py:39-72)
+    assert set(m.state_dict().keys()) == {"log_step_length", "filter_reg", "label_map_predictor.weight",
+                                          "target_mask_predictor.0.weight", "spatial_weight_predictor.weight"}
+    assert m.label_map_predictor.weight.shape == (1, 100, 1, 1)
+    from pytracking_amd import synth
+    torch.testing.assert_close(m.label_map_predictor.weight.reshape(-1),
+                               torch.from_numpy(synth.gauss_lut(100, 0.1, 0.9)), atol=1e-6, rtol=0)
+    torch.testing.assert_close(m.target_mask_predictor[0].weight.reshape(-1),
+                               torch.from_numpy(synth.mask_lut(100, 0.1, 3.0)), atol=1e-6, rtol=0)
+    p = optimizer.PrDiMPSteepestDescentNewton()
+    assert set(p.state_dict().keys()) == {"log_step_length", "filter_reg"}
+
+
+def test_product_path_refuses_cpu_tensors():
+    from pytracking_amd import filter as F
+    with pytest.raises(RuntimeError, match="MI355X"):
+        F.apply_filter(torch.zeros(1, 4, 6, 6), torch.zeros(1, 4, 4, 4))
+
+
+def test_product_never_imports_oracle():
+    pkg = os.path.join(ROOT, "pytracking_amd")
+    for fn in os.listdir(pkg):
+        if fn.endswith(".py"):
+            src = open(os.path.join(pkg, fn)).read()
+            assert "import oracle" not in src and "from oracle" not in src, fn

@@ -1,0 +1,311 @@
+"""GPU parity: the HIP path (through the C ABI) against the numpy oracle and the reference-generated golden
+vectors on identical seeded inputs.  Tolerance: BASELINE.json north_star asks for 1e-4 abs on score maps /
+filters; 2e-5 is asserted where the arithmetic is smooth, 1e-4 where a sign(s) flip of a near-zero score can
+move an iterate discontinuously (LeakyReluParDeriv, activation.py:43-44)."""
+import numpy as np
+import pytest
+import torch
+
+from conftest import load_golden
+from oracle import np_oracle as O
+from pytracking_amd import synth
+
+pytestmark = pytest.mark.gpu
+
+DEV = "cuda"
+
+
+def T(a):
+    return torch.from_numpy(np.ascontiguousarray(a)).to(DEV)
+
+
+def close(a, b, atol, rtol=0.0):
+    a = a.detach().cpu().numpy() if isinstance(a, torch.Tensor) else np.asarray(a)
+    np.testing.assert_allclose(a.astype(np.float64), np.asarray(b, dtype=np.float64), atol=atol, rtol=rtol)
+
+
+# ------------------------------------------------------------------------------------------------------
+# filter layer
+# ------------------------------------------------------------------------------------------------------
+@pytest.mark.parametrize("tag", ["k4", "k3", "k1"])
+def test_apply_filter_and_transpose_golden(tag):
+    from pytracking_amd import filter as F
+    g = load_golden("filter_ops")
+    feat, filt = T(g[f"{tag}_feat"]), T(g[f"{tag}_filt"][None])
+    s = F.apply_filter(feat, filt)
+    assert s.shape == (feat.shape[0], 1) + g[f"{tag}_scores"].shape[1:]
+    close(s[:, 0], g[f"{tag}_scores"], atol=2e-5)
+    K = filt.shape[-1]
+    adj = F.apply_feat_transpose(feat, T(g[f"{tag}_inp"])[:, None], (K, K), training=False)
+    close(adj[0], g[f"{tag}_adj_v2"], atol=1e-4)
+
+
+def test_apply_filter_two_sequences_and_errors():
+    from pytracking_amd import filter as F
+    g = load_golden("filter_ops")
+    s = F.apply_filter(T(g["s2_feat"]), T(g["s2_filt"]))
+    close(s, g["s2_scores"], atol=2e-5)
+    adj = F.apply_feat_transpose(T(g["s2_feat"]), T(g["s2_inp"]), 4, training=False)
+    close(adj, g["s2_adj"], atol=1e-4)
+    with pytest.raises(RuntimeError, match="not covered"):
+        F.apply_filter(T(g["k5_feat"]), T(g["k5_filt"][None]))          # 25 taps > 16
+    with pytest.raises(NotImplementedError):
+        F.apply_filter(T(g["mf_feat"])[:, None], T(g["mf_filt"])[None])  # multi-filter: later row
+
+
+@pytest.mark.parametrize("n,C,H,W,K", [(1, 512, 18, 18, 4), (50, 512, 18, 18, 4), (7, 64, 22, 22, 4),
+                                       (3, 20, 9, 7, 3), (2, 33, 5, 6, 2), (5, 256, 18, 18, 1)])
+def test_filter_ops_vs_oracle(n, C, H, W, K):
+    from pytracking_amd import filter as F
+    rng = np.random.default_rng(n * 1000 + C)
+    feat = synth.clf_features(rng, n, C, H, W, max(K, 1))
+    filt = rng.standard_normal((C, K, K), dtype=np.float32) * 0.05
+    s = F.apply_filter(T(feat), T(filt[None]))[:, 0]
+    ref = O.apply_filter(feat.astype(np.float64), filt.astype(np.float64))
+    close(s, ref, atol=2e-5)
+    inp = rng.standard_normal(ref.shape).astype(np.float32)
+    adj = F.apply_feat_transpose(T(feat), T(inp)[:, None], (K, K))[0]
+    refa = O.apply_feat_transpose(feat.astype(np.float64), inp.astype(np.float64), K)
+    close(adj, refa, atol=2e-5 * max(1.0, np.abs(refa).max()))
+    # adjointness <F w, r> == <w, F^T r>  (size-independent property)
+    lhs = float((s.double().cpu() * torch.from_numpy(inp).double()).sum())
+    rhs = float((adj.double().cpu() * torch.from_numpy(filt).double()).sum())
+    assert abs(lhs - rhs) <= 1e-4 * max(1.0, abs(lhs))
+
+
+def test_apply_filter_same_crop_and_autograd_pair():
+    from pytracking_amd import filter as F
+    rng = np.random.default_rng(5)
+    feat = rng.standard_normal((4, 16, 18, 18), dtype=np.float32)
+    filt = rng.standard_normal((16, 4, 4), dtype=np.float32)
+    s = F.corr_raw(T(feat), T(filt), out_hw=(18, 18))                     # operation.conv2d(mode='same')
+    close(s, O.apply_filter(feat.astype(np.float64), filt.astype(np.float64), out_hw=(18, 18)), atol=1e-4)
+    # autograd: d/dfilter <apply_filter(feat, filter), r> = apply_feat_transpose(feat, r)
+    w = T(filt[None]).requires_grad_(True)
+    r = T(rng.standard_normal((4, 1, 19, 19), dtype=np.float32))
+    (F.apply_filter(T(feat), w) * r).sum().backward()
+    close(w.grad[0], O.apply_feat_transpose(feat.astype(np.float64), r[:, 0].cpu().numpy().astype(np.float64), 4),
+          atol=1e-3)
+
+
+# ------------------------------------------------------------------------------------------------------
+# steepest-descent solvers
+# ------------------------------------------------------------------------------------------------------
+def _dimp_module(cfg=synth.DIMP50, **over):
+    from pytracking_amd import optimizer
+    c = dict(cfg, **over)
+    return optimizer.DiMPSteepestDescentGN(
+        num_iter=c["num_iter"], feat_stride=c["feat_stride"], init_step_length=c["init_step_length"],
+        init_filter_reg=c["init_filter_reg"], init_gauss_sigma=c["init_gauss_sigma"], num_dist_bins=c["num_dist_bins"],
+        bin_displacement=c["bin_displacement"], mask_init_factor=c["mask_init_factor"], score_act=c["score_act"],
+        mask_act=c["mask_act"], min_filter_reg=c["min_filter_reg"], alpha_eps=c["alpha_eps"]).to(DEV).eval()
+
+
+def _run(mod, w0, feat, bb, sw, num_iter, compute_losses=True):
+    with torch.no_grad():
+        w, its, losses = mod(T(w0)[None], T(feat), T(bb), sample_weight=None if sw is None else T(sw),
+                             num_iter=num_iter, compute_losses=compute_losses)
+    assert len(its) == num_iter + 1 and w is its[-1]
+    return torch.stack([i[0] for i in its]), (torch.stack(losses) if losses else None)
+
+
+@pytest.mark.parametrize("name", ["dimp_sd_small_w", "dimp_sd_small_now", "dimp_sd_mid"])
+def test_dimp_sd_golden_small(name):
+    g = load_golden(name)
+    mod = _dimp_module()
+    if "filter_reg" in g:     # run-time mutated attributes (dimp.py:589-602)
+        mod.filter_reg.data[0] = float(g["filter_reg"])
+        mod.min_filter_reg = float(g["min_filter_reg"])
+        mod.alpha_eps = float(g["alpha_eps"])
+    its, losses = _run(mod, g["w0"], g["feat"], g["bb"], g.get("sw"), int(g["num_iter"]))
+    close(its, g["iterates"], atol=2e-5)
+    close(losses, g["losses"], atol=2e-5, rtol=1e-4)
+    its2, l2 = _run(mod, g["w0"], g["feat"], g["bb"], g.get("sw"), int(g["num_iter"]), compute_losses=False)
+    assert l2 is None and torch.equal(its, its2)                          # deterministic, loss flag is side-effect free
+
+
+@pytest.mark.parametrize("name", ["dimp_sd_cfg2_n50", "dimp_sd_cfg2_n15"])
+def test_dimp_sd_golden_baseline_size(name):
+    """BASELINE.json configs[1]: DiMP-50, 512x18x18, K=4, 5 iterations, n=50 / n=15 memory samples."""
+    from pytracking_amd import filter as F
+    g = load_golden(name)
+    w0, feat, bb, sw = synth.dimp_problem(int(g["seed"]), int(g["n"]))
+    its, losses = _run(_dimp_module(), w0, feat, bb, sw, 5)
+    close(its, g["iterates"], atol=1e-4)
+    close(losses, g["losses"], atol=1e-4, rtol=1e-4)
+    scores = F.apply_filter(T(feat), its[-1][None])[:, 0]
+    close(scores, g["scores"], atol=1e-4)
+    assert np.all(np.diff(losses.cpu().numpy()) < 0)                      # monotone decrease
+
+
+def test_dimp_l2_golden():
+    from pytracking_amd import optimizer
+    g = load_golden("dimp_l2_small")
+    mod = optimizer.DiMPL2SteepestDescentGN(num_iter=3, feat_stride=16, init_step_length=float(g["step_length"]),
+                                            gauss_sigma=float(g["gauss_sigma"]),
+                                            hinge_threshold=float(g["hinge_threshold"]),
+                                            init_filter_reg=float(g["filter_reg"]),
+                                            min_filter_reg=float(g["min_filter_reg"])).to(DEV).eval()
+    its, losses = _run(mod, g["w0"], g["feat"], g["bb"], g["sw"], int(g["num_iter"]))
+    close(its, g["iterates"], atol=2e-5)
+    close(losses, g["losses"], atol=2e-5, rtol=1e-4)
+
+
+def _prdimp_module(cfg=synth.PRDIMP50, **over):
+    from pytracking_amd import optimizer
+    c = dict(cfg, **over)
+    return optimizer.PrDiMPSteepestDescentNewton(
+        num_iter=c["num_iter"], feat_stride=c["feat_stride"], init_step_length=c["init_step_length"],
+        init_filter_reg=c["init_filter_reg"], gauss_sigma=c["gauss_sigma"], min_filter_reg=c["min_filter_reg"],
+        alpha_eps=c["alpha_eps"], init_uni_weight=c["init_uni_weight"], normalize_label=c["normalize_label"],
+        label_shrink=c["label_shrink"], softmax_reg=c["softmax_reg"], label_threshold=c["label_threshold"]).to(DEV).eval()
+
+
+def test_prdimp_golden_small_and_options():
+    g = load_golden("prdimp_sd_small")
+    its, losses = _run(_prdimp_module(), g["w0"], g["feat"], g["bb"], g["sw"], int(g["num_iter"]))
+    close(its, g["iterates"], atol=2e-5)
+    close(losses, g["losses"], atol=2e-5, rtol=1e-4)
+    g = load_golden("prdimp_sd_opts")
+    mod = _prdimp_module(softmax_reg=float(g["softmax_reg"]), init_uni_weight=float(g["uni_weight"]),
+                         label_shrink=float(g["label_shrink"]), label_threshold=float(g["label_threshold"]))
+    its, losses = _run(mod, g["w0"], g["feat"], g["bb"], None, int(g["num_iter"]))
+    close(its, g["iterates"], atol=2e-5)
+    close(losses, g["losses"], atol=2e-5, rtol=1e-4)
+
+
+def test_prdimp_golden_baseline_size():
+    """BASELINE.json configs[2] shape: PrDiMP-50, 512x22x22, n=50, 5 iterations."""
+    g = load_golden("prdimp_sd_cfg3_n50")
+    w0, feat, bb, sw = synth.dimp_problem(int(g["seed"]), int(g["n"]), synth.PRDIMP50)
+    its, losses = _run(_prdimp_module(), w0 * 0, feat, bb, sw, 5)
+    close(its, g["iterates"], atol=1e-4)
+    close(losses, g["losses"], atol=1e-4, rtol=1e-4)
+
+
+def test_sd_zero_iterations_and_single_sample():
+    mod = _dimp_module()
+    w0, feat, bb, sw = synth.dimp_problem(3, 1, small=dict(C=16, H=10, W=10))
+    its, losses = _run(mod, w0, feat, bb, sw, 0)
+    assert its.shape[0] == 1 and losses.shape[0] == 1
+    ref_its, ref_l = O.dimp_sd(w0.astype(np.float64), feat.astype(np.float64), bb.astype(np.float64),
+                               sw.astype(np.float64), num_iter=2, step_length=0.9, filter_reg=0.1, min_filter_reg=1e-3,
+                               feat_stride=16, label_w=synth.gauss_lut(100, 0.1, 0.9), mask_w=synth.mask_lut(100, 0.1, 3.0),
+                               spatial_w=np.ones(100, np.float32), bin_displacement=0.1)
+    close(losses[0], ref_l[0], atol=1e-5, rtol=1e-4)
+    its, losses = _run(mod, w0, feat, bb, sw, 2)
+    close(its, ref_its, atol=2e-5)
+
+
+# ------------------------------------------------------------------------------------------------------
+# ATOM conjugate gradient
+# ------------------------------------------------------------------------------------------------------
+def _atom_run(x0, samples, y, sw, iters, fr, calls):
+    from pytracking_amd.optimization import ConjugateGradient, ConvProblem, MLU
+    x = [T(x0.copy())[None].clone()]
+    prob = ConvProblem([T(samples)], [T(y)[:, None]], [synth.ATOM18["filter_reg"]], [T(sw)],
+                       MLU(synth.ATOM18["act_min_val"]))
+    opt = ConjugateGradient(prob, x, fletcher_reeves=fr, direction_forget_factor=0)
+    outs = []
+    for _ in range(calls):
+        opt.run(iters)
+        outs.append(x[0][0].clone())
+    return torch.stack(outs)
+
+
+@pytest.mark.parametrize("name", ["atom_cg_small_pr", "atom_cg_small_fr"])
+def test_atom_cg_golden_small(name):
+    g = load_golden(name)
+    out = _atom_run(g["x0"], g["samples"], g["y"], g["sw"], int(g["num_iter"]), bool(g["fletcher_reeves"]),
+                    g["x_out"].shape[0])
+    close(out, g["x_out"], atol=2e-5, rtol=1e-4)
+
+
+def test_atom_cg_golden_config1_size():
+    """BASELINE.json configs[0] solver shape: ATOM, 250 x 64 x 18 x 18 memory, PR-CG 5 iterations."""
+    g = load_golden("atom_cg_cfg1_n250")
+    x0, samples, y, sw = synth.atom_problem(int(g["seed"]), int(g["n"]))
+    out = _atom_run(x0, samples, y, sw, 5, False, 1)
+    close(out, g["x_out"], atol=1e-4, rtol=1e-3)
+
+
+# ------------------------------------------------------------------------------------------------------
+# Precise RoI pooling (oracle self-pinned; see oracle/prroi_torch.py)
+# ------------------------------------------------------------------------------------------------------
+@pytest.mark.parametrize("PH,PW,scale,H,W", [(4, 4, 1 / 16, 18, 18), (5, 5, 1 / 8, 36, 36), (3, 3, 1 / 16, 18, 18),
+                                             (1, 1, 1 / 16, 18, 18), (2, 3, 0.5, 7, 9)])
+def test_prroi_forward_backward_vs_oracle(PH, PW, scale, H, W):
+    from pytracking_amd.prroi_pool import PrRoIPool2D
+    rng = np.random.default_rng(PH * 10 + PW)
+    N, C, R = 2, 24, 11
+    feat = rng.standard_normal((N, C, H, W), dtype=np.float32)
+    ext = np.array([W, H], dtype=np.float64) / scale
+    xy0 = rng.uniform(-0.1, 0.6, (R, 2)) * ext
+    wh = rng.uniform(0.05, 0.6, (R, 2)) * ext
+    rois = np.concatenate((rng.integers(0, N, (R, 1)).astype(np.float64), xy0, xy0 + wh), 1).astype(np.float32)
+    rois[-1, 3] = rois[-1, 1]                                   # zero-area RoI -> zeros, zero gradients
+    rois[-2, 1:] = [4 * ext[0], 4 * ext[1], 5 * ext[0], 5 * ext[1]]   # fully outside the map
+    f = T(feat).requires_grad_(True)
+    r = T(rois).requires_grad_(True)
+    out = PrRoIPool2D(PH, PW, scale)(f, r)
+    ref = O.prroi_forward(feat.astype(np.float64), rois.astype(np.float64), PH, PW, scale)
+    close(out, ref, atol=2e-5)
+    gout = rng.standard_normal(ref.shape).astype(np.float32)
+    out.backward(T(gout))
+    close(f.grad, O.prroi_backward_feat(gout.astype(np.float64), feat.shape, rois.astype(np.float64), PH, PW, scale),
+          atol=1e-4)
+    refc = O.prroi_backward_coor(gout.astype(np.float64), feat.astype(np.float64), rois.astype(np.float64), PH, PW, scale)
+    close(r.grad, refc, atol=2e-4 * max(1.0, np.abs(refc).max()))
+    assert float(r.grad[:, 0].abs().max()) == 0.0
+
+
+def test_prroi_consumers_golden():
+    """Reference FilterInitializerLinear pooling and the IoU-predictor proposal gradient (golden produced by the
+    reference modules with the PrRoIPool restatement plugged in)."""
+    from pytracking_amd.prroi_pool import PrRoIPool2D
+    g = load_golden("filter_init_linear")
+    bb = g["bb"]
+    n = bb.shape[0]
+    rois = np.concatenate((np.arange(n, dtype=np.float32)[:, None], bb[:, :2], bb[:, :2] + bb[:, 2:]), 1)
+    pooled = PrRoIPool2D(4, 4, 1 / 16)(T(g["conv_out"]), T(rois))
+    close(pooled.mean(0), g["weights"][0], atol=2e-5)
+    g = load_golden("iou_predict")
+    sd = {k[3:].replace("__", "."): T(v) for k, v in g.items() if k.startswith("sd_")}
+    c3 = T(g["c3"]) * T(g["mod3"]).reshape(1, -1, 1, 1)
+    c4 = T(g["c4"]) * T(g["mod4"]).reshape(1, -1, 1, 1)
+    props = T(g["proposals"]).requires_grad_(True)
+    xyxy = torch.cat((props[0, :, :2], props[0, :, :2] + props[0, :, 2:]), 1)
+    roi = torch.cat((torch.zeros(xyxy.shape[0], 1, device=DEV), xyxy), 1)
+    r3 = PrRoIPool2D(5, 5, 1 / 8)(c3, roi)
+    r4 = PrRoIPool2D(3, 3, 1 / 16)(c4, roi)
+
+    def block(x, pre):
+        z = torch.nn.functional.linear(x.reshape(x.shape[0], -1), sd[pre + ".linear.weight"], sd[pre + ".linear.bias"])
+        z = (z - sd[pre + ".bn.running_mean"]) / torch.sqrt(sd[pre + ".bn.running_var"] + 1e-5)
+        return torch.relu(z * sd[pre + ".bn.weight"] + sd[pre + ".bn.bias"])
+    iou = torch.nn.functional.linear(torch.cat((block(r3, "fc3_rt"), block(r4, "fc4_rt")), 1),
+                                     sd["iou_predictor.weight"], sd["iou_predictor.bias"]).reshape(1, -1)
+    close(iou, g["iou"], atol=5e-5)
+    iou.backward(gradient=torch.ones_like(iou))                            # dimp.py:737-745
+    close(props.grad, g["grad"], atol=5e-5, rtol=1e-3)
+
+
+# ------------------------------------------------------------------------------------------------------
+# benchmark frame (C ABI pt_track_frame_f32) against a composition of the oracle pieces
+# ------------------------------------------------------------------------------------------------------
+def test_track_frame_matches_oracle_composition():
+    from pytracking_amd import bench_frame
+    from oracle import frame_port
+    cfg = dict(synth.DIMP50, C=32, H=18, W=18)
+    n = 6
+    st = bench_frame.TrackState(cfg, n, seed=77, device=DEV)
+    rng = np.random.default_rng(78)
+    x = synth.clf_features(rng, 1, cfg["C"], cfg["H"], cfg["W"], cfg["K"])
+    mem0, bb0, w0 = st.mem_feat.cpu().numpy().copy(), st.mem_bb.cpu().numpy().copy(), st.filter.cpu().numpy().copy()
+    st.step(T(x)[0], slot=2, num_iter=3)
+    torch.cuda.synchronize()
+    ref = frame_port.oracle_step(cfg, mem0, bb0, st.sample_weight.cpu().numpy(), w0, x[0], slot=2, num_iter=3)
+    close(st.scores, ref["scores"], atol=2e-5)
+    assert tuple(st.peak.cpu().numpy().astype(int)) == tuple(ref["peak"])
+    close(st.mem_bb, ref["bb"], atol=1e-4)
+    close(st.filter, ref["filter"], atol=2e-5)

@@ -116,3 +116,14 @@ def test_atom_cg_small(name):
                              act_min_val=synth.ATOM18["act_min_val"], num_iter=int(g["num_iter"]),
                              fletcher_reeves=bool(g["fletcher_reeves"]), state=state)
         close(x, g["x_out"][call], atol=1e-5, rtol=1e-4)
+
+
+def test_torch_port_matches_reference():
+    """The torch-CPU port that bench.py times as `cpu_baseline` reproduces the reference's iterates."""
+    import torch
+    from oracle.frame_port import TorchCpuTracker
+    g = load_golden("dimp_sd_cfg2_n15")
+    tr = TorchCpuTracker(synth.DIMP50, int(g["n"]), int(g["seed"]))
+    with torch.no_grad():
+        w = tr.solve(tr.filter, tr.mem_feat, tr.mem_bb, tr.sw, 5)
+    close(w[0].numpy(), g["iterates"][-1], atol=2e-6)
