@@ -106,7 +106,7 @@ typedef struct pt_sd_params {
  *   w_in (C,K,K) is not modified; w_iters receives all num_iter+1 iterates ((num_iter+1),C,K,K),
  *   w_iters[0] = w_in; losses (num_iter+1 floats) may be NULL (= compute_losses False);
  *   bb (n,4) xywh in crop pixels; sample_weight (n) or NULL.
- * Requires K*K <= 16 and (H*W) % 4 == 0. */
+ * Requires K*K <= 16 (feature loads are 16-byte wide when (H*W) % 4 == 0, scalar otherwise). */
 size_t pt_sd_ws_bytes(int n, int C, int H, int W, int K);
 int pt_sd_solve_f32(const pt_sd_params* p, const float* w_in, const float* feat, long feat_stride_n,
                     const float* bb, const float* sample_weight,

@@ -87,44 +87,6 @@ extern "C" int pt_feat_transpose_f32(const float* feat, long feat_stride_n, cons
 // ---------------------------------------------------------------------------------------------------
 // benchmark frame: classify -> arg-max -> memory insert -> solve   
 // ---------------------------------------------------------------------------------------------------
-// sums the classification partials, finds the first maximum (torch.max semantics, pytracking/libs/dcf.py:156-164)
-// and re-centres the box of memory slot `slot` on it (inverse of the centre formula of optimizer.py:112-113).
-__global__ __launch_bounds__(512) void k_classify_fin(const float* __restrict__ spart, int KS, int OH, int OW,
-                                                      float* __restrict__ scores, float* __restrict__ peak,
-                                                      float* __restrict__ mem_bb, int slot, float feat_stride, int K) {
-    __shared__ float bv[8];
-    __shared__ int bi[8];
-    const int OO = OH * OW;
-    float best = -INFINITY;
-    int besti = 0x7fffffff;
-    for (int o = threadIdx.x; o < OO; o += blockDim.x) {
-        float s = 0.f;
-        for (int k = 0; k < KS; ++k) s += spart[(long)k * OO + o];
-        scores[o] = s;
-        if (s > best) { best = s; besti = o; }
-    }
-#pragma unroll
-    for (int off = 32; off > 0; off >>= 1) {
-        const float ov = __shfl_xor(best, off, 64);
-        const int oi = __shfl_xor(besti, off, 64);
-        if (ov > best || (ov == best && oi < besti)) { best = ov; besti = oi; }
-    }
-    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
-    if (lane == 0) { bv[wave] = best; bi[wave] = besti; }
-    __syncthreads();
-    if (threadIdx.x == 0) {
-        for (int w = 1; w < 8; ++w)
-            if (bv[w] > best || (bv[w] == best && bi[w] < besti)) { best = bv[w]; besti = bi[w]; }
-        const int row = besti / OW, col = besti - row * OW;
-        peak[0] = (float)row;
-        peak[1] = (float)col;
-        const float off = (float)(K % 2) * 0.5f;
-        float* b = mem_bb + 4 * slot;
-        b[0] = ((float)col + off) * feat_stride - b[2] * 0.5f;
-        b[1] = ((float)row + off) * feat_stride - b[3] * 0.5f;
-    }
-}
-
 struct TfCarve { size_t spart1, w_iters, sd, total; };
 static TfCarve tf_carve(int n, int C, int H, int W, int K) {
     const int OH = H + (K + 1) % 2, OW = W + (K + 1) % 2;
@@ -149,32 +111,23 @@ extern "C" int pt_track_frame_f32(const pt_sd_params* prm, float* filter, float*
                                   size_t ws_bytes, void* stream) {
     if (!prm || !filter || !mem_feat || !mem_bb || !test_feat || !scores_out || !peak_out || !ws) return PT_ERR_NULL;
     if (n <= 0 || C <= 0 || H <= 0 || W <= 0 || K <= 0 || num_iter < 0 || slot < 0 || slot >= n) return PT_ERR_SHAPE;
-    if (K * K > 16 || (H * W) % 4 != 0 || num_iter > 64) return PT_ERR_UNSUPPORTED;
+    if (K * K > 16 || num_iter > 64) return PT_ERR_UNSUPPORTED;
     TfCarve cv = tf_carve(n, C, H, W, K);
     if (ws_bytes < cv.total * sizeof(float) || ((uintptr_t)ws % 256) != 0) return PT_ERR_WORKSPACE;
     hipStream_t st = (hipStream_t)stream;
     const int OH = H + (K + 1) % 2, OW = W + (K + 1) % 2;
     const long CHW = (long)C * H * W;
     float* base = (float*)ws;
-    // 1. classify the test frame with the current filter (dimp.py:190-194 -> linear_filter.py:75-80)
+    // 1. classify the test frame with the current filter (dimp.py:190-194 -> linear_filter.py:75-80); the pass also
+    //    stores the features it streams into memory slot `slot` (dimp.py:429-441 update_memory)
     PtPlan p1 = pt_make_plan(1, C, H, W, K, K, OH, OW);
-    int rc = pt_launch_corr(p1, test_feat, CHW, filter, base + cv.spart1, st);
+    PtCorrFuse fz = {nullptr, 0, nullptr, 0.f, nullptr, nullptr, mem_feat + (long)slot * CHW};
+    int rc = pt_launch_corr(p1, test_feat, CHW, filter, base + cv.spart1, st, &fz);
     if (rc) return rc;
-    // 2. localise on device and re-centre the box of the slot about to be overwritten
-    hipLaunchKernelGGL(k_classify_fin, dim3(1), dim3(512), 0, st, base + cv.spart1, p1.KS, OH, OW, scores_out, peak_out,
-                       mem_bb, slot, prm->feat_stride, K);
-    PT_CHECK_LAUNCH();
-    // 3. memory insert (dimp.py:429-441 update_memory)
-    if (hipMemcpyAsync(mem_feat + (long)slot * CHW, test_feat, CHW * sizeof(float), hipMemcpyDeviceToDevice, st) !=
-        hipSuccess)
-        return PT_ERR_LAUNCH;
-    // 4. re-optimise the filter over the whole memory (dimp.py:633-639)
-    float* w_iters = base + cv.w_iters;
-    rc = pt_sd_solve_f32(prm, filter, mem_feat, CHW, mem_bb, sample_weight, n, C, H, W, K, num_iter, w_iters, nullptr,
-                         base + cv.sd, (cv.total - cv.sd) * sizeof(float), st);
-    if (rc) return rc;
-    if (hipMemcpyAsync(filter, w_iters + (long)num_iter * C * K * K, (size_t)C * K * K * sizeof(float),
-                       hipMemcpyDeviceToDevice, st) != hipSuccess)
-        return PT_ERR_LAUNCH;
-    return PT_OK;
+    // 2. localisation (arg-max, box re-centring) runs as the prologue of the solver's map kernel;
+    // 3. re-optimise the filter over the whole memory (dimp.py:633-639); the last iterate lands in `filter`
+    PtClsFin cls = {base + cv.spart1, p1.KS, slot, scores_out, peak_out, mem_bb};
+    return pt_sd_solve_impl(prm, filter, mem_feat, CHW, mem_bb, sample_weight, n, C, H, W, K, num_iter,
+                            base + cv.w_iters, nullptr, base + cv.sd, (cv.total - cv.sd) * sizeof(float), st,
+                            /*copy_w0=*/false, /*w_final=*/filter, &cls);
 }

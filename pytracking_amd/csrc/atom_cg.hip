@@ -157,9 +157,8 @@ extern "C" int pt_atom_cg_f32(float* x, const float* samples, long samples_strid
                               float* cg_state, void* ws, size_t ws_bytes, void* stream) {
     if (!x || !samples || !y || !sample_weights || !cg_state || !ws) return PT_ERR_NULL;
     if (n <= 0 || C <= 0 || H <= 0 || W <= 0 || K <= 0 || num_iter < 0) return PT_ERR_SHAPE;
-    if (K * K > 16 || (H * W) % 4 != 0) return PT_ERR_UNSUPPORTED;
-    if (samples_stride_n < (long)C * H * W || samples_stride_n % 4 != 0 || ((uintptr_t)samples % 16) != 0)
-        return PT_ERR_UNSUPPORTED;
+    if (K * K > 16) return PT_ERR_UNSUPPORTED;
+    if (samples_stride_n < (long)C * H * W) return PT_ERR_SHAPE;
     if (num_iter == 0) return PT_OK;                                    // optimization.py:230-231
     hipStream_t st = (hipStream_t)stream;
     PtPlan p = pt_make_plan(n, C, H, W, K, K, H, W);                    // conv2d(mode='same'): OH=H, OW=W

@@ -28,7 +28,19 @@ static inline size_t pt_R_floats(const PtPlan& p) { return (size_t)p.NG * 256; }
 static inline size_t pt_gpart_floats(const PtPlan& p) { return (size_t)p.KSPL * p.C * p.KK; }
 static inline size_t pt_align_floats(size_t x) { return (x + 63) & ~(size_t)63; }   // 256-byte carve granule
 
-int pt_launch_corr(const PtPlan& p, const float* feat, long stride_n, const float* filt, float* spart, hipStream_t st);
+// Optional stages fused into the correlation pass (all pointers may be null).
+struct PtCorrFuse {
+    const float* gpart;   // filter operand = sum_k gpart[k] + reg*w instead of `filt` (KSPL slices of C*KK floats)
+    int KSPL;
+    const float* w;
+    float reg;
+    float* g_out;         // (C*KK) reduced gradient, written by the workgroups of sample 0
+    float* anum_part;     // (KS)   per-channel-slice sum of g^2, written by the workgroups of sample 0
+    float* copy_dst;      // (C,H,W) destination of a copy of sample 0's features (requires n == 1)
+};
+
+int pt_launch_corr(const PtPlan& p, const float* feat, long stride_n, const float* filt, float* spart, hipStream_t st,
+                   const PtCorrFuse* fuse = nullptr);
 int pt_launch_adj(const PtPlan& p, const float* feat, long stride_n, const float* R, float* gpart, hipStream_t st);
 // scores[i][o] = sum_ks spart[ks][i][o]
 int pt_launch_sum_slices(const float* part, float* out, int slices, size_t count, hipStream_t st);
@@ -39,6 +51,18 @@ int pt_launch_build_R(const PtPlan& p, const float* inp, float* R, hipStream_t s
     do {                                                     \
         if (hipGetLastError() != hipSuccess) return PT_ERR_LAUNCH; \
     } while (0)
+
+// classification epilogue of the benchmark frame (runs inside the solver's maps launch)
+struct PtClsFin {
+    const float* spart;   // (KS, OH*OW) classification partials
+    int KS, slot;
+    float *scores, *peak, *mem_bb;
+};
+
+int pt_sd_solve_impl(const pt_sd_params* prm, const float* w_in, const float* feat, long feat_stride_n, const float* bb,
+                     const float* sample_weight, int n, int C, int H, int W, int K, int num_iter, float* w_iters,
+                     float* losses, void* ws, size_t ws_bytes, hipStream_t st, bool copy_w0, float* w_final,
+                     const PtClsFin* cls);
 
 // measurement hook (profile.hip): no-ops unless a pt_profile is attached
 void pt_prof_begin(int kernel_id, hipStream_t st);

@@ -13,8 +13,8 @@
 //   pw INIT         s_0, residual map r, its im2col R, per-sample loss                        [n WGs]
 //   repeat T times:
 //     adj(R)        partial gradients                                                         [C/16 x KSPL WGs]
-//     gfin          g = sum partials + reg*w_t ; a_num = |g|^2                                [1 WG]
-//     corr(g)       partial (F g) maps                                                        [n x KS WGs]
+//     corr(g)       g = sum partials + reg*w_t reduced in the prologue, |g|^2 slices,
+//                   partial (F g) maps                                                        [n x KS WGs]
 //     pw SGQ        sg = F g ; per-sample curvature term q_i                                  [n WGs]
 //     pw UPDATE     alpha ; w_{t+1} ; s_{t+1} ; next residual map + R ; loss                  [n WGs]
 #include "common.h"
@@ -36,11 +36,22 @@ struct SdArgs {
     float *spart;                // (KS,n,OO)
     float *R;                    // (NG,256)
     float *gpart, *g;            // (KSPL,CKK), (CKK)
-    float *scal;                 // [0] = a_num
+    float *anum;                 // (KS) per-channel-slice |g|^2 (written by the corr(g) pass)
     float *qs;                   // (n)
     float *lossp;                // (T+1, n)
-    float *w_iters;              // (T+1, CKK)  caller's buffer
+    float *w_iters;              // (T+1, CKK)  caller's buffer; iterate 0 lives at w0
+    const float *w0;             // initial filter
+    float *w_final;              // optional: the last iterate is written here instead of w_iters[T]
+    // optional classification epilogue run by the workgroup of sample `cls_slot` before its maps
+    // (benchmark frame: sum the classify partials, arg-max, re-centre that sample's box)
+    const float *cls_spart;
+    int cls_KS, cls_slot;
+    float *cls_scores, *cls_peak, *cls_bb;
 };
+
+__device__ __forceinline__ const float* sd_w(const SdArgs& a, int t) {
+    return t == 0 ? a.w0 : a.w_iters + (long)t * a.CKK;
+}
 
 // ----------------------------------------------------------------------------------------------------
 // maps: one workgroup per sample
@@ -54,10 +65,55 @@ __device__ __forceinline__ float pl_lut(const float* __restrict__ w, int bins, f
     return w[k0] * (1.0f - fr) + w[k0 + 1] * fr;
 }
 
+// sums the classification partials, finds the first maximum (torch.max semantics, pytracking/libs/dcf.py:156-164)
+// and re-centres the box of memory slot `cls_slot` on it (inverse of the centre formula of optimizer.py:112-113).
+__device__ void sd_classify_fin(const SdArgs& a) {
+    __shared__ float bv[16];
+    __shared__ int bi[16];
+    float best = -INFINITY;
+    int besti = 0x7fffffff;
+    for (int o = threadIdx.x; o < a.OO; o += blockDim.x) {
+        float s = 0.f;
+        int k = 0;
+        for (; k + 8 <= a.cls_KS; k += 8) {                 // independent loads in flight, fixed summation order
+            float v[8];
+#pragma unroll
+            for (int q = 0; q < 8; ++q) v[q] = a.cls_spart[(long)(k + q) * a.OO + o];
+#pragma unroll
+            for (int q = 0; q < 8; ++q) s += v[q];
+        }
+        for (; k < a.cls_KS; ++k) s += a.cls_spart[(long)k * a.OO + o];
+        a.cls_scores[o] = s;
+        if (s > best) { best = s; besti = o; }
+    }
+#pragma unroll
+    for (int off = 32; off > 0; off >>= 1) {
+        const float ov = __shfl_xor(best, off, 64);
+        const int oi = __shfl_xor(besti, off, 64);
+        if (ov > best || (ov == best && oi < besti)) { best = ov; besti = oi; }
+    }
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6, nw = (blockDim.x + 63) >> 6;
+    if (lane == 0) { bv[wave] = best; bi[wave] = besti; }
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        for (int w = 1; w < nw; ++w)
+            if (bv[w] > best || (bv[w] == best && bi[w] < besti)) { best = bv[w]; besti = bi[w]; }
+        const int row = besti / a.OW, col = besti - row * a.OW;
+        a.cls_peak[0] = (float)row;
+        a.cls_peak[1] = (float)col;
+        const float off = (float)(a.K % 2) * 0.5f;
+        float* b = a.cls_bb + 4 * a.cls_slot;
+        b[0] = ((float)col + off) * a.feat_stride - b[2] * 0.5f;
+        b[1] = ((float)row + off) * a.feat_stride - b[3] * 0.5f;
+    }
+    __syncthreads();
+}
+
 __global__ void k_sd_maps(SdArgs a) {
     __shared__ float scratch[16];
     __shared__ int amin[2];
     const int i = blockIdx.x;
+    if (a.cls_spart && i == a.cls_slot) sd_classify_fin(a);     // uniform per workgroup
     const float off = (float)(a.K % 2) * 0.5f;
     const float* b = a.bb + 4 * i;
     const float ctr_r = (b[1] + b[3] * 0.5f) / a.feat_stride - off;     // optimizer.py:112-113 (flip -> row first)
@@ -125,24 +181,6 @@ __global__ void k_sd_maps(SdArgs a) {
 }
 
 // ----------------------------------------------------------------------------------------------------
-// gfin: g = sum_k gpart[k] + reg * w_t ; a_num = sum g^2   (single workgroup, fixed summation order)
-// ----------------------------------------------------------------------------------------------------
-__global__ __launch_bounds__(1024) void k_sd_gfin(SdArgs a, int t) {
-    __shared__ float scratch[16];
-    const float* w = a.w_iters + (long)t * a.CKK;
-    float acc = 0.f;
-    for (int e = threadIdx.x; e < a.CKK; e += blockDim.x) {
-        float v = 0.f;
-        for (int k = 0; k < a.KSPL; ++k) v += a.gpart[(long)k * a.CKK + e];
-        v += a.reg * w[e];
-        a.g[e] = v;
-        acc += v * v;
-    }
-    const float tot = block_sum(acc, scratch);
-    if (threadIdx.x == 0) a.scal[0] = tot;
-}
-
-// ----------------------------------------------------------------------------------------------------
 // pointwise stages: one workgroup per sample
 // ----------------------------------------------------------------------------------------------------
 __device__ __forceinline__ void act_pair(int score_act, float bpar, float x, float am, float& act, float& der) {
@@ -161,11 +199,29 @@ __device__ __forceinline__ void act_pair(int score_act, float bpar, float x, flo
     }
 }
 
+// sum of the KS channel-slice partials of one score element (loads issued together, fixed summation order)
+__device__ __forceinline__ float sd_sum_slices(const SdArgs& a, int i, int o) {
+    const float* p = a.spart + (long)i * a.OO + o;
+    const long st = (long)a.n * a.OO;
+    float s = 0.f;
+    int k = 0;
+    for (; k + 8 <= a.KS; k += 8) {
+        float v[8];
+#pragma unroll
+        for (int q = 0; q < 8; ++q) v[q] = p[(k + q) * st];
+#pragma unroll
+        for (int q = 0; q < 8; ++q) s += v[q];
+    }
+    for (; k < a.KS; ++k) s += p[k * st];
+    return s;
+}
+
 __device__ __forceinline__ float sd_alpha_step(const SdArgs& a) {
     // optimizer.py:155-160 / :425-430: alpha = |g|^2 / max(sum_i q_i + (reg+eps)|g|^2, 1e-8), times the step length
     float den = 0.f;
     for (int k = 0; k < a.n; ++k) den += a.qs[k];
-    const float a_num = a.scal[0];
+    float a_num = 0.f;
+    for (int k = 0; k < a.KS; ++k) a_num += a.anum[k];
     den = fmaxf(den + (a.reg + a.alpha_eps) * a_num, 1e-8f);
     return a.step * (a_num / den);
 }
@@ -185,8 +241,7 @@ __global__ __launch_bounds__(512) void k_sd_pw(SdArgs a, int stage, int t, int l
         float acc = 0.f;
         if (!prdimp) {
             for (int o = threadIdx.x; o < a.OO; o += blockDim.x) {
-                float sgv = 0.f;
-                for (int k = 0; k < a.KS; ++k) sgv += a.spart[((long)k * a.n + i) * a.OO + o];
+                const float sgv = sd_sum_slices(a, i, o);
                 a.sg[base + o] = sgv;
                 float act, der;
                 act_pair(sact, a.act_param, a.s[base + o], a.mask[base + o], act, der);
@@ -198,8 +253,7 @@ __global__ __launch_bounds__(512) void k_sd_pw(SdArgs a, int stage, int t, int l
         } else {
             float psum = 0.f;
             for (int o = threadIdx.x; o < a.OO; o += blockDim.x) {
-                float sgv = 0.f;
-                for (int k = 0; k < a.KS; ++k) sgv += a.spart[((long)k * a.n + i) * a.OO + o];
+                const float sgv = sd_sum_slices(a, i, o);
                 a.sg[base + o] = sgv;
                 lds[o] = sgv;
                 psum += a.mask[base + o] * sgv;                                     // :419
@@ -221,8 +275,8 @@ __global__ __launch_bounds__(512) void k_sd_pw(SdArgs a, int stage, int t, int l
         astep = sd_alpha_step(a);
         // this workgroup's slice of the filter update  w_t = w_{t-1} - step*alpha*g   (:160)
         const int chunk = (a.CKK + a.n - 1) / a.n;
-        const float* wp = a.w_iters + (long)(t - 1) * a.CKK;
-        float* wn = a.w_iters + (long)t * a.CKK;
+        const float* wp = sd_w(a, t - 1);
+        float* wn = (last && a.w_final) ? a.w_final : a.w_iters + (long)t * a.CKK;
         const int e0 = i * chunk, e1 = min(a.CKK, e0 + chunk);
         for (int e = e0 + threadIdx.x; e < e1; e += blockDim.x) wn[e] = wp[e] - astep * a.g[e];
         if (last && !want_loss) return;
@@ -232,12 +286,8 @@ __global__ __launch_bounds__(512) void k_sd_pw(SdArgs a, int stage, int t, int l
     if (!prdimp) {
         for (int o = threadIdx.x; o < a.OO; o += blockDim.x) {
             float sv;
-            if (stage == PW_INIT) {
-                sv = 0.f;
-                for (int k = 0; k < a.KS; ++k) sv += a.spart[((long)k * a.n + i) * a.OO + o];
-            } else {
-                sv = a.s[base + o] - astep * a.sg[base + o];
-            }
+            if (stage == PW_INIT) sv = sd_sum_slices(a, i, o);
+            else sv = a.s[base + o] - astep * a.sg[base + o];
             a.s[base + o] = sv;
             float act, der;
             act_pair(sact, a.act_param, sv, a.mask[base + o], act, der);
@@ -251,12 +301,8 @@ __global__ __launch_bounds__(512) void k_sd_pw(SdArgs a, int stage, int t, int l
         float mx = a.has_softmax_reg ? a.softmax_reg : -INFINITY;
         for (int o = threadIdx.x; o < a.OO; o += blockDim.x) {
             float sv;
-            if (stage == PW_INIT) {
-                sv = 0.f;
-                for (int k = 0; k < a.KS; ++k) sv += a.spart[((long)k * a.n + i) * a.OO + o];
-            } else {
-                sv = a.s[base + o] - astep * a.sg[base + o];
-            }
+            if (stage == PW_INIT) sv = sd_sum_slices(a, i, o);
+            else sv = a.s[base + o] - astep * a.sg[base + o];
             a.s[base + o] = sv;
             sv_l[o] = sv;
             mx = fmaxf(mx, sv);
@@ -294,7 +340,7 @@ __global__ __launch_bounds__(512) void k_sd_pw(SdArgs a, int stage, int t, int l
 __global__ void k_sd_loss(SdArgs a, float* __restrict__ losses) {
     __shared__ float scratch[16];
     const int t = blockIdx.x;
-    const float* w = a.w_iters + (long)t * a.CKK;
+    const float* w = sd_w(a, t);
     float acc = 0.f;
     for (int e = threadIdx.x; e < a.CKK; e += blockDim.x) acc += w[e] * w[e];
     const float wn = block_sum(acc, scratch);
@@ -309,7 +355,7 @@ __global__ void k_sd_loss(SdArgs a, float* __restrict__ losses) {
 // host side
 // ----------------------------------------------------------------------------------------------------
 struct SdCarve {
-    size_t label, mask, sws, s, sg, spart, R, gpart, g, scal, qs, lossp, total;
+    size_t label, mask, sws, s, sg, spart, R, gpart, g, anum, qs, lossp, total;
 };
 
 static SdCarve sd_carve(const PtPlan& p, int max_iter) {
@@ -322,7 +368,7 @@ static SdCarve sd_carve(const PtPlan& p, int max_iter) {
     c.R = take(pt_R_floats(p));
     c.gpart = take(pt_gpart_floats(p));
     c.g = take((size_t)p.C * p.KK);
-    c.scal = take(64);
+    c.anum = take(64);
     c.qs = take(p.n);
     c.lossp = take((size_t)(max_iter + 1) * p.n);
     c.total = off;
@@ -338,19 +384,24 @@ extern "C" size_t pt_sd_ws_bytes(int n, int C, int H, int W, int K) {
     return sd_carve(p, PT_SD_MAX_ITER).total * sizeof(float);
 }
 
-extern "C" int pt_sd_solve_f32(const pt_sd_params* prm, const float* w_in, const float* feat, long feat_stride_n,
-                               const float* bb, const float* sample_weight, int n, int C, int H, int W, int K,
-                               int num_iter, float* w_iters, float* losses, void* ws, size_t ws_bytes, void* stream) {
+// Internal entry shared by pt_sd_solve_f32 and pt_track_frame_f32.
+//   copy_w0  : also materialise iterate 0 in w_iters[0] (public API contract)
+//   w_final  : if non-null the last iterate is written there (may alias w_in) instead of w_iters[T]
+//   cls      : optional classification epilogue (see SdArgs), run inside the maps launch
+int pt_sd_solve_impl(const pt_sd_params* prm, const float* w_in, const float* feat, long feat_stride_n, const float* bb,
+                     const float* sample_weight, int n, int C, int H, int W, int K, int num_iter, float* w_iters,
+                     float* losses, void* ws, size_t ws_bytes, hipStream_t st, bool copy_w0, float* w_final,
+                     const PtClsFin* cls) {
     if (!prm || !w_in || !feat || !bb || !w_iters || !ws) return PT_ERR_NULL;
     if (n <= 0 || C <= 0 || H <= 0 || W <= 0 || K <= 0 || num_iter < 0) return PT_ERR_SHAPE;
-    if (K * K > 16 || (H * W) % 4 != 0 || num_iter > PT_SD_MAX_ITER) return PT_ERR_UNSUPPORTED;
-    if (feat_stride_n < (long)C * H * W || feat_stride_n % 4 != 0 || ((uintptr_t)feat % 16) != 0) return PT_ERR_UNSUPPORTED;
+    if (K * K > 16 || num_iter > PT_SD_MAX_ITER) return PT_ERR_UNSUPPORTED;
+    if (feat_stride_n < (long)C * H * W) return PT_ERR_SHAPE;
     if (prm->kind == PT_SD_DIMP && (!prm->label_lut || !prm->mask_lut || !prm->spatial_lut || prm->num_bins < 1))
         return PT_ERR_NULL;
     if (prm->kind < PT_SD_DIMP || prm->kind > PT_SD_PRDIMP) return PT_ERR_UNSUPPORTED;
-    hipStream_t st = (hipStream_t)stream;
     const int OH = H + (K + 1) % 2, OW = W + (K + 1) % 2;               // optimizer.py:105
     PtPlan p = pt_make_plan(n, C, H, W, K, K, OH, OW);
+    if (p.KS > 64) return PT_ERR_UNSUPPORTED;
     SdCarve cv = sd_carve(p, PT_SD_MAX_ITER);
     if (ws_bytes < cv.total * sizeof(float) || ((uintptr_t)ws % 256) != 0) return PT_ERR_WORKSPACE;
     float* base = (float*)ws;
@@ -368,29 +419,36 @@ extern "C" int pt_sd_solve_f32(const pt_sd_params* prm, const float* w_in, const
     a.spatial_lut = prm->spatial_lut;
     a.label = base + cv.label; a.mask = base + cv.mask; a.sws = base + cv.sws; a.s = base + cv.s; a.sg = base + cv.sg;
     a.spart = base + cv.spart; a.R = base + cv.R; a.gpart = base + cv.gpart; a.g = base + cv.g;
-    a.scal = base + cv.scal; a.qs = base + cv.qs; a.lossp = base + cv.lossp; a.w_iters = w_iters;
+    a.anum = base + cv.anum; a.qs = base + cv.qs; a.lossp = base + cv.lossp; a.w_iters = w_iters;
+    a.w0 = w_in; a.w_final = w_final;
+    a.cls_spart = nullptr; a.cls_KS = 0; a.cls_slot = -1; a.cls_scores = nullptr; a.cls_peak = nullptr; a.cls_bb = nullptr;
+    if (cls) {
+        a.cls_spart = cls->spart; a.cls_KS = cls->KS; a.cls_slot = cls->slot; a.cls_scores = cls->scores;
+        a.cls_peak = cls->peak; a.cls_bb = cls->mem_bb;
+    }
 
     const int want_loss = losses != nullptr;
     const size_t pw_lds = (size_t)a.OO * sizeof(float) * (a.kind == PT_SD_PRDIMP ? 2 : 1);
 
-    if (w_iters != w_in) {
+    if (copy_w0 && w_iters != w_in) {
         if (hipMemcpyAsync(w_iters, w_in, (size_t)a.CKK * sizeof(float), hipMemcpyDeviceToDevice, st) != hipSuccess)
             return PT_ERR_LAUNCH;
     }
-    if (num_iter == 0 && !want_loss) return PT_OK;
+    if (num_iter == 0 && !want_loss && !cls) return PT_OK;
 
     hipLaunchKernelGGL(k_sd_maps, dim3(n), dim3(256), 0, st, a);
     PT_CHECK_LAUNCH();
-    int rc = pt_launch_corr(p, feat, feat_stride_n, w_iters, a.spart, st);
+    if (num_iter == 0 && !want_loss) return PT_OK;
+    int rc = pt_launch_corr(p, feat, feat_stride_n, w_in, a.spart, st);
     if (rc) return rc;
     hipLaunchKernelGGL(k_sd_pw, dim3(n), dim3(512), pw_lds, st, a, (int)PW_INIT, 0, (int)(num_iter == 0), want_loss);
     PT_CHECK_LAUNCH();
     for (int t = 0; t < num_iter; ++t) {
         rc = pt_launch_adj(p, feat, feat_stride_n, a.R, a.gpart, st);
         if (rc) return rc;
-        hipLaunchKernelGGL(k_sd_gfin, dim3(1), dim3(1024), 0, st, a, t);
-        PT_CHECK_LAUNCH();
-        rc = pt_launch_corr(p, feat, feat_stride_n, a.g, a.spart, st);
+        // g_t = sum_k gpart[k] + reg*w_t is reduced in the prologue of the correlation pass (optimizer.py:146-151)
+        PtCorrFuse fz = {a.gpart, p.KSPL, t == 0 ? w_in : w_iters + (long)t * a.CKK, a.reg, a.g, a.anum, nullptr};
+        rc = pt_launch_corr(p, feat, feat_stride_n, nullptr, a.spart, st, &fz);
         if (rc) return rc;
         hipLaunchKernelGGL(k_sd_pw, dim3(n), dim3(512), pw_lds, st, a, (int)PW_SGQ, t, 0, 0);
         PT_CHECK_LAUNCH();
@@ -403,4 +461,11 @@ extern "C" int pt_sd_solve_f32(const pt_sd_params* prm, const float* w_in, const
         PT_CHECK_LAUNCH();
     }
     return PT_OK;
+}
+
+extern "C" int pt_sd_solve_f32(const pt_sd_params* prm, const float* w_in, const float* feat, long feat_stride_n,
+                               const float* bb, const float* sample_weight, int n, int C, int H, int W, int K,
+                               int num_iter, float* w_iters, float* losses, void* ws, size_t ws_bytes, void* stream) {
+    return pt_sd_solve_impl(prm, w_in, feat, feat_stride_n, bb, sample_weight, n, C, H, W, K, num_iter, w_iters, losses,
+                            ws, ws_bytes, (hipStream_t)stream, /*copy_w0=*/true, /*w_final=*/nullptr, /*cls=*/nullptr);
 }
