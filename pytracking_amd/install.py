@@ -1,0 +1,152 @@
+"""Install the MI355X hot path behind the reference's own Python call boundary.
+
+    import pytracking_amd.install as amd
+    amd.install()                     # before the tracker / network is constructed
+    # ... `pytracking.tracker.dimp.DiMP`, `atom.ATOM` etc. now run unchanged on top of libpt_hot.so
+
+What gets rebound (import path = contract; nothing in the reference tree is edited):
+
+  ltr.models.layers.filter.apply_filter / apply_feat_transpose / filter_gradient      -> pytracking_amd.filter
+  ltr.models.target_classifier.optimizer.{DiMPSteepestDescentGN, DiMPL2SteepestDescentGN,
+                                           PrDiMPSteepestDescentNewton}               -> pytracking_amd.optimizer
+  ltr.external.PreciseRoIPooling.pytorch.prroi_pool.PrRoIPool2D  (module is CREATED: the submodule is empty)
+                                                                                      -> pytracking_amd.prroi_pool
+  pytracking.libs.optimization.ConjugateGradient  (ConvProblem + MLU fast path)       -> pytracking_amd.optimization
+
+Dispatch rule of the rebound *functions*: device fp32 tensors of a shape the gfx950 kernels cover go to the C ABI;
+everything else (CPU tensors, multi-filter LWL filters, dilations, K*K > 16) is outside SURVEY section 8's scope and
+is handed to the reference's ORIGINAL function object -- its own stock-PyTorch code, not a re-implementation --
+unless `strict=True`, in which case it raises.  The rebound *classes* have no such escape: they run the fused
+solver or raise.
+"""
+import importlib
+import sys
+import types
+
+import torch
+
+from . import filter as _filter
+from . import optimization as _optimization
+from . import optimizer as _optimizer
+from . import prroi_pool as _prroi
+
+_state = {"installed": False, "originals": {}}
+
+
+def _covered(feat, filt, dilation_factors=None):
+    return (isinstance(feat, torch.Tensor) and feat.is_cuda and feat.dtype == torch.float32 and filt.is_cuda
+            and filt.dim() == 4 and dilation_factors is None and filt.shape[-1] * filt.shape[-2] <= 16)
+
+
+def _make_dispatchers(orig_mod, strict):
+    o_apply, o_adj, o_grad = orig_mod.apply_filter, orig_mod.apply_feat_transpose, orig_mod.filter_gradient
+
+    def apply_filter(feat, filter, dilation_factors=None):
+        if _covered(feat, filter, dilation_factors):
+            return _filter.apply_filter(feat, filter)
+        if strict:
+            raise NotImplementedError("apply_filter: configuration outside the gfx950 hot path")
+        return o_apply(feat, filter, dilation_factors)
+
+    def apply_feat_transpose(feat, input, filter_ksz, training=True, groups=1):
+        ksz = (filter_ksz, filter_ksz) if isinstance(filter_ksz, int) else tuple(filter_ksz)
+        if feat.is_cuda and feat.dtype == torch.float32 and input.dim() == 4 and groups == 1 and ksz[0] * ksz[1] <= 16:
+            return _filter.apply_feat_transpose(feat, input, ksz, training=training, groups=groups)
+        if strict:
+            raise NotImplementedError("apply_feat_transpose: configuration outside the gfx950 hot path")
+        return o_adj(feat, input, filter_ksz, training=training, groups=groups)
+
+    def filter_gradient(feat, filter, label=None, training=True):
+        if _covered(feat, filter):
+            return _filter.filter_gradient(feat, filter, label=label, training=training)
+        if strict:
+            raise NotImplementedError("filter_gradient: configuration outside the gfx950 hot path")
+        return o_grad(feat, filter, label=label, training=training)
+
+    for fn, o in ((apply_filter, o_apply), (apply_feat_transpose, o_adj), (filter_gradient, o_grad)):
+        fn.__doc__ = o.__doc__
+        fn.__wrapped__ = o
+    return apply_filter, apply_feat_transpose, filter_gradient
+
+
+def provide_prroi_module():
+    """Create `ltr.external.PreciseRoIPooling.pytorch.prroi_pool` (an empty git submodule in the reference) in
+    sys.modules so that `from ltr.external.PreciseRoIPooling.pytorch.prroi_pool import PrRoIPool2D`
+    (initializer.py:4, atom_iou_net.py:4) resolves to the HIP implementation."""
+    for pkg in ("ltr.external", "ltr.external.PreciseRoIPooling", "ltr.external.PreciseRoIPooling.pytorch"):
+        if pkg not in sys.modules:
+            m = types.ModuleType(pkg)
+            m.__path__ = []
+            sys.modules[pkg] = m
+    name = "ltr.external.PreciseRoIPooling.pytorch.prroi_pool"
+    pm = types.ModuleType(name)
+    pm.PrRoIPool2D = _prroi.PrRoIPool2D
+    pm.prroi_pool2d = _prroi.prroi_pool2d
+    sys.modules[name] = pm
+    parent = sys.modules["ltr.external.PreciseRoIPooling.pytorch"]
+    parent.prroi_pool = pm
+    return pm
+
+
+def install(strict=False, atom_cg=True):
+    """Rebind the boundary symbols.  Call after the reference is importable (`sys.path`) and before networks or
+    trackers are constructed.  Idempotent."""
+    if _state["installed"]:
+        return
+    provide_prroi_module()                                        # must precede `import ltr.models...`
+    fmod = importlib.import_module("ltr.models.layers.filter")
+    omod = importlib.import_module("ltr.models.target_classifier.optimizer")
+    orig = _state["originals"]
+    orig["filter"] = (fmod.apply_filter, fmod.apply_feat_transpose, fmod.filter_gradient)
+    a, t, g = _make_dispatchers(fmod, strict)
+    fmod.apply_filter, fmod.apply_feat_transpose, fmod.filter_gradient = a, t, g
+    # modules that did `import ltr.models.layers.filter as filter_layer` see the rebinding through the module
+    # object; nothing in the hot path does `from ... import apply_filter`.
+    names = ("DiMPSteepestDescentGN", "DiMPL2SteepestDescentGN", "PrDiMPSteepestDescentNewton")
+    orig["optimizer"] = tuple(getattr(omod, n) for n in names)
+    for n in names:
+        setattr(omod, n, getattr(_optimizer, n))
+    if atom_cg:
+        try:
+            pmod = importlib.import_module("pytracking.libs.optimization")
+            amod = importlib.import_module("pytracking.tracker.atom.optim")
+        except Exception:          # pytracking side not importable (missing cv2 ...): the ltr side is still installed
+            pmod = amod = None
+        if pmod is not None:
+            orig["cg"] = pmod.ConjugateGradient
+            ref_cg, ref_problem = pmod.ConjugateGradient, amod.ConvProblem
+
+            class ConjugateGradient(ref_cg):
+                """ConvProblem + MLU on device -> fused gfx950 CG; any other problem -> the reference class."""
+
+                def __new__(cls, problem, variable, *args, **kw):
+                    act = getattr(problem, "response_activation", None)
+                    fast = (isinstance(problem, ref_problem) and hasattr(act, "min_val") and len(variable) == 1
+                            and variable[0].is_cuda and not kw.get("debug", False)
+                            and kw.get("standard_alpha", True) and kw.get("cg_eps", 0.0) == 0.0)
+                    if fast:
+                        return _optimization.ConjugateGradient(problem, variable, *args, **kw)
+                    if strict:
+                        raise NotImplementedError("ConjugateGradient: problem outside the gfx950 hot path")
+                    return ref_cg.__new__(cls)
+
+            pmod.ConjugateGradient = ConjugateGradient
+            tmod = sys.modules.get("pytracking.tracker.atom.atom")
+            if tmod is not None and hasattr(tmod, "ConjugateGradient"):
+                tmod.ConjugateGradient = ConjugateGradient
+    _state["installed"] = True
+
+
+def uninstall():
+    if not _state["installed"]:
+        return
+    orig = _state["originals"]
+    fmod = importlib.import_module("ltr.models.layers.filter")
+    omod = importlib.import_module("ltr.models.target_classifier.optimizer")
+    fmod.apply_filter, fmod.apply_feat_transpose, fmod.filter_gradient = orig["filter"]
+    for n, c in zip(("DiMPSteepestDescentGN", "DiMPL2SteepestDescentGN", "PrDiMPSteepestDescentNewton"), orig["optimizer"]):
+        setattr(omod, n, c)
+    if "cg" in orig:
+        importlib.import_module("pytracking.libs.optimization").ConjugateGradient = orig["cg"]
+    _state["installed"] = False
+    orig.clear()

@@ -1,0 +1,43 @@
+"""The reference-side binding (pytracking_amd/install.py) against the real reference tree.  Runs only where
+/root/reference exists (the build container); the GPU box has no reference and skips."""
+import pytest
+import torch
+
+from oracle import ref_harness
+
+pytestmark = pytest.mark.skipif(not ref_harness.available(), reason="reference tree not mounted")
+
+
+def test_install_rebinds_boundary_symbols_and_restores():
+    ref_harness.install()
+    import sys
+    saved_prroi = sys.modules.get("ltr.external.PreciseRoIPooling.pytorch.prroi_pool")
+    import ltr.models.layers.filter as fl
+    import ltr.models.target_classifier.optimizer as opt
+    orig_apply, orig_cls = fl.apply_filter, opt.DiMPSteepestDescentGN
+    from pytracking_amd import install as amd, optimizer as ours, prroi_pool
+    amd.install()
+    try:
+        assert opt.DiMPSteepestDescentGN is ours.DiMPSteepestDescentGN
+        assert opt.PrDiMPSteepestDescentNewton is ours.PrDiMPSteepestDescentNewton
+        assert fl.apply_filter is not orig_apply and fl.apply_filter.__wrapped__ is orig_apply
+        from ltr.external.PreciseRoIPooling.pytorch.prroi_pool import PrRoIPool2D
+        assert PrRoIPool2D is prroi_pool.PrRoIPool2D
+        # CPU tensors are outside the hot path: the dispatcher hands them to the reference's own function
+        feat, filt = torch.randn(2, 1, 8, 6, 6), torch.randn(1, 8, 4, 4)
+        torch.testing.assert_close(fl.apply_filter(feat, filt), orig_apply(feat, filt))
+        # a network built now instantiates the mirrored optimiser and loads a reference state_dict
+        ref_mod = orig_cls(num_iter=5, feat_stride=16, init_step_length=0.9, init_filter_reg=0.1, init_gauss_sigma=0.9,
+                           num_dist_bins=100, bin_displacement=0.1, mask_init_factor=3.0)
+        mine = opt.DiMPSteepestDescentGN(num_iter=5, feat_stride=16, init_step_length=1.0, init_filter_reg=0.3,
+                                         init_gauss_sigma=0.5, num_dist_bins=100, bin_displacement=0.1,
+                                         mask_init_factor=4.0)
+        mine.load_state_dict(ref_mod.state_dict(), strict=True)
+        torch.testing.assert_close(mine.label_map_predictor.weight, ref_mod.label_map_predictor.weight)
+        import pytracking.libs.optimization as po
+        assert po.ConjugateGradient is not amd._state["originals"]["cg"]
+    finally:
+        amd.uninstall()
+        if saved_prroi is not None:
+            sys.modules["ltr.external.PreciseRoIPooling.pytorch.prroi_pool"] = saved_prroi
+    assert fl.apply_filter is orig_apply and opt.DiMPSteepestDescentGN is orig_cls
