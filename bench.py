@@ -26,7 +26,7 @@ ROOT = os.path.dirname(os.path.abspath(__file__))
 if ROOT not in sys.path:
     sys.path.insert(0, ROOT)
 
-from pytracking_amd import _lib, bench_frame, synth  # noqa: E402
+from pytracking_amd import _lib, bench_frame, sequences, synth  # noqa: E402
 
 HBM_PEAK_GBS = 8000.0      # MI355X_MICROARCH.md: HBM3E 8.0 TB/s spec
 NUM_ITER = 5
@@ -165,9 +165,10 @@ def main():
                 _lib.check(L.pt_profile_collect(prof, kid, ctypes.byref(ms), ctypes.byref(cnt)), "pt_profile_collect")
                 kern[name] = (ms.value, cnt.value)
             L.pt_profile_destroy(prof)
-            # k_corr launches include the n=1 classify pass (0.66 MB); count its bytes exactly
-            corr_bytes = kprof * (NUM_ITER + 1) * feat_bytes + kprof * 4 * cfg["C"] * cfg["H"] * cfg["W"]
-            adj_bytes = kprof * NUM_ITER * feat_bytes
+            # per frame: 1 + NUM_ITER correlation passes (the first one also classifies the test frame) and NUM_ITER
+            # adjoint passes, each streaming the n-sample memory once
+            corr_bytes = kern["k_corr"][1] * feat_bytes
+            adj_bytes = kern["k_adj"][1] * feat_bytes
             stats = {"k_corr": (corr_bytes, *kern["k_corr"]), "k_adj": (adj_bytes, *kern["k_adj"])}
             dom = max(stats, key=lambda k: stats[k][1])
             b, ms, cnt = stats[dom]
@@ -181,12 +182,9 @@ def main():
                     "solve_level": {"algorithmic_bytes_per_frame": st.bytes_per_solve(NUM_ITER),
                                     "achieved_GBs": None}}
 
-    tmax = elapsed
-    if dist is not None:
-        t = torch.tensor([elapsed], dtype=torch.float64, device=dev)
-        dist.all_reduce(t, op=dist.ReduceOp.MAX)           # the only collective: slowest rank's time
-        tmax = float(t.item())
-    value = world * K / tmax
+    # the only collective: the end-of-batch (frames, seconds) gather; whole-job rate = all frames / slowest rank
+    total_frames, tmax, _ = sequences.gather_throughput(K, elapsed, device=dev)
+    value = total_frames / tmax
 
     if rank == 0:
         if roof is not None:

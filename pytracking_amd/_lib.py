@@ -9,8 +9,8 @@ import subprocess
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.path.join(_HERE, "libpt_hot.so")
-SOURCES = ["filter_kernels.hip", "sd_solver.hip", "atom_cg.hip", "prroi.hip", "api.hip", "profile.hip"]
-HEADERS = ["common.h", "pt_internal.h", "rbuild.h", os.path.join("..", "..", "include", "pt_hot.h")]
+SOURCES = ["filter_kernels.hip", "fast_passes.hip", "sd_solver.hip", "atom_cg.hip", "prroi.hip", "api.hip", "profile.hip"]
+HEADERS = ["common.h", "pt_internal.h", "rbuild.h", "sd_common.h", os.path.join("..", "..", "include", "pt_hot.h")]
 
 PT_SD_DIMP, PT_SD_DIMP_L2, PT_SD_PRDIMP = 0, 1, 2
 PT_ACT_RELU, PT_ACT_BENTPAR = 0, 1

@@ -1,4 +1,5 @@
 // C-ABI entry points that are thin compositions of the kernels: filter-layer ops and the benchmark frame.
+#include <algorithm>
 #include "common.h"
 #include "pt_internal.h"
 
@@ -29,7 +30,10 @@ static int filt_check(int n, int C, int H, int W, int KH, int KW, int OH, int OW
 extern "C" size_t pt_apply_filter_ws_bytes(int n, int C, int H, int W, int KH, int KW, int OH, int OW) {
     if (filt_check(n, C, H, W, KH, KW, OH, OW)) return 0;
     PtPlan p = pt_make_plan(n, C, H, W, KH, KW, OH, OW);
-    return pt_align_floats(pt_spart_floats(p)) * sizeof(float);
+    size_t fl = pt_align_floats(pt_spart_floats(p));
+    PtFast f = pt_fast_plan(n, C, H, W, KH, KW, OH, OW);
+    if (f.ok) fl = std::max(fl, pt_align_floats(pt_fast_spart_floats(f)));
+    return fl * sizeof(float);
 }
 
 extern "C" int pt_apply_filter_f32(const float* feat, long feat_stride_n, const float* filt, float* scores, int n, int C,
@@ -39,11 +43,17 @@ extern "C" int pt_apply_filter_f32(const float* feat, long feat_stride_n, const 
     int rc = filt_check(n, C, H, W, KH, KW, OH, OW);
     if (rc) return rc;
     if (feat_stride_n < (long)C * H * W) return PT_ERR_SHAPE;
-    PtPlan p = pt_make_plan(n, C, H, W, KH, KW, OH, OW);
-    if (ws_bytes < pt_align_floats(pt_spart_floats(p)) * sizeof(float) || ((uintptr_t)ws % 256) != 0)
+    if (ws_bytes < pt_apply_filter_ws_bytes(n, C, H, W, KH, KW, OH, OW) || ((uintptr_t)ws % 256) != 0)
         return PT_ERR_WORKSPACE;
     hipStream_t st = (hipStream_t)stream;
     float* spart = (float*)ws;
+    PtFast f = pt_fast_plan(n, C, H, W, KH, KW, OH, OW);
+    if (f.ok && ((uintptr_t)feat % 16) == 0 && (feat_stride_n % 4) == 0) {
+        rc = pt_launch_corr2(f, feat, feat_stride_n, filt, spart, st);
+        if (rc) return rc;
+        return pt_launch_sum_slices(spart, scores, 8, (size_t)n * f.OO, st);
+    }
+    PtPlan p = pt_make_plan(n, C, H, W, KH, KW, OH, OW);
     rc = pt_launch_corr(p, feat, feat_stride_n, filt, spart, st);
     if (rc) return rc;
     return pt_launch_sum_slices(spart, scores, p.KS, (size_t)n * p.OO, st);
@@ -61,7 +71,10 @@ static FtCarve ft_carve(const PtPlan& p) {
 extern "C" size_t pt_feat_transpose_ws_bytes(int n, int C, int H, int W, int KH, int KW, int OH, int OW) {
     if (filt_check(n, C, H, W, KH, KW, OH, OW)) return 0;
     PtPlan p = pt_make_plan(n, C, H, W, KH, KW, OH, OW);
-    return ft_carve(p).total * sizeof(float);
+    size_t fl = ft_carve(p).total;
+    PtFast f = pt_fast_plan(n, C, H, W, KH, KW, OH, OW);
+    if (f.ok) fl = std::max(fl, pt_align_floats(pt_fast_gpart_floats(f)));
+    return fl * sizeof(float);
 }
 
 extern "C" int pt_feat_transpose_f32(const float* feat, long feat_stride_n, const float* inp, float* grad, int n, int C,
@@ -71,10 +84,18 @@ extern "C" int pt_feat_transpose_f32(const float* feat, long feat_stride_n, cons
     int rc = filt_check(n, C, H, W, KH, KW, OH, OW);
     if (rc) return rc;
     if (feat_stride_n < (long)C * H * W) return PT_ERR_SHAPE;
+    if (ws_bytes < pt_feat_transpose_ws_bytes(n, C, H, W, KH, KW, OH, OW) || ((uintptr_t)ws % 256) != 0)
+        return PT_ERR_WORKSPACE;
+    hipStream_t st = (hipStream_t)stream;
+    PtFast f = pt_fast_plan(n, C, H, W, KH, KW, OH, OW);
+    if (f.ok && ((uintptr_t)feat % 16) == 0 && (feat_stride_n % 4) == 0) {
+        float* gp = (float*)ws;
+        rc = pt_launch_adj2_plain(f, feat, feat_stride_n, inp, gp, st);
+        if (rc) return rc;
+        return pt_launch_sum_slices(gp, grad, f.KSPL, (size_t)C * f.KK, st);
+    }
     PtPlan p = pt_make_plan(n, C, H, W, KH, KW, OH, OW);
     FtCarve cv = ft_carve(p);
-    if (ws_bytes < cv.total * sizeof(float) || ((uintptr_t)ws % 256) != 0) return PT_ERR_WORKSPACE;
-    hipStream_t st = (hipStream_t)stream;
     float* R = (float*)ws + cv.R;
     float* gpart = (float*)ws + cv.gpart;
     rc = pt_launch_build_R(p, inp, R, st);
@@ -118,6 +139,16 @@ extern "C" int pt_track_frame_f32(const pt_sd_params* prm, float* filter, float*
     const int OH = H + (K + 1) % 2, OW = W + (K + 1) % 2;
     const long CHW = (long)C * H * W;
     float* base = (float*)ws;
+    PtFast f = pt_fast_plan(n, C, H, W, K, K, OH, OW);
+    if (f.ok && ((uintptr_t)mem_feat % 16) == 0 && ((uintptr_t)test_feat % 16) == 0) {
+        // Fast path: the first correlation of the solve reads sample `slot` from test_feat (and stores it into the
+        // memory slot, dimp.py:429-441); its score row under the current filter IS the classification of the test
+        // frame (dimp.py:190-194 -> linear_filter.py:75-80).  Localisation runs in the init stage.
+        PtClsFin cls = {nullptr, 0, slot, scores_out, peak_out, mem_bb};
+        return pt_sd_solve_impl(prm, filter, mem_feat, CHW, mem_bb, sample_weight, n, C, H, W, K, num_iter,
+                                base + cv.w_iters, nullptr, base + cv.sd, (cv.total - cv.sd) * sizeof(float), st,
+                                /*copy_w0=*/false, /*w_final=*/filter, &cls, /*src=*/test_feat);
+    }
     // 1. classify the test frame with the current filter (dimp.py:190-194 -> linear_filter.py:75-80); the pass also
     //    stores the features it streams into memory slot `slot` (dimp.py:429-441 update_memory)
     PtPlan p1 = pt_make_plan(1, C, H, W, K, K, OH, OW);
@@ -129,5 +160,5 @@ extern "C" int pt_track_frame_f32(const pt_sd_params* prm, float* filter, float*
     PtClsFin cls = {base + cv.spart1, p1.KS, slot, scores_out, peak_out, mem_bb};
     return pt_sd_solve_impl(prm, filter, mem_feat, CHW, mem_bb, sample_weight, n, C, H, W, K, num_iter,
                             base + cv.w_iters, nullptr, base + cv.sd, (cv.total - cv.sd) * sizeof(float), st,
-                            /*copy_w0=*/false, /*w_final=*/filter, &cls);
+                            /*copy_w0=*/false, /*w_final=*/filter, &cls, /*src=*/nullptr);
 }

@@ -1,0 +1,670 @@
+// XCD-aligned feature passes for the common tracker shapes (C in {128,256,512,1024}, H*W % 4 == 0).
+//
+// Both passes stream the whole sample memory once.  MI355X has 8 XCDs with a private 4 MiB L2 each and dispatches
+// workgroup b to XCD b % 8 (observed placement, used for speed only -- nothing below depends on it for correctness).
+// Channel range [x*C/8, (x+1)*C/8) of EVERY sample is always processed by workgroups with b % 8 == x, in the
+// correlation pass and in the adjoint pass alike, so consecutive passes of a solve re-read the eighth of the memory
+// their XCD already holds in L2 (DiMP-50: 4.15 MB per XCD; profiles/r01_l2_probe.txt: 3.7 us per aligned pass vs
+// 5.9 us when the ownership rotates).
+//
+//   k_corr2 : apply_filter (ltr/models/layers/filter.py:5-57).  Workgroup = (sample i, XCD x); its waves are
+//             (64-position tile t, half h of the XCD's k-steps).  T[h][tap][pos] = sum_c filt[c][tap]*feat[i][c][pos]
+//             on v_mfma_f32_16x16x4_f32, then the 16-tap shift-and-add from LDS -> spart[x][i][OH*OW].
+//             A trailing <= 4 quads (18x18: positions 320..323) use ONE MFMA per k-step with the positions as the
+//             16 columns instead of a mostly empty 64-position tile.
+//   k_adj2  : apply_feat_transpose (filter.py:91-182).  Workgroup = (16-channel block cb of XCD x, position slice ks);
+//             wave w owns U contiguous 16-position groups.  G[c][tap] = sum_P feat[c][P] * r[P shifted by tap]; the B
+//             operand is gathered from zero-padded residual maps the workgroup builds in LDS -- there is no im2col
+//             buffer in HBM.  In the solver the maps come from the fused update prologue (alpha, s_{t}, residual).
+#include "common.h"
+#include "pt_internal.h"
+#include "sd_common.h"
+
+#ifndef PT_ABL
+#define PT_ABL 0      // experiments/fast_floor.hip only
+#endif
+#ifdef PT_TRACE       // experiments/fast_floor.hip only: per-workgroup phase time stamps (100 MHz wall clock)
+__device__ unsigned long long* pt_trace_buf;
+#define PT_STAMP(k) do { if (threadIdx.x == 0 && pt_trace_buf) pt_trace_buf[blockIdx.x * 8 + (k)] = wall_clock64(); } while (0)
+#else
+#define PT_STAMP(k) do { } while (0)
+#endif
+
+// ---------------------------------------------------------------------------------------------------
+// geometry
+// ---------------------------------------------------------------------------------------------------
+PtFast pt_fast_plan(int n, int C, int H, int W, int KH, int KW, int OH, int OW) {
+    PtFast p;
+    p.ok = 0;
+    p.n = n; p.C = C; p.H = H; p.W = W; p.KH = KH; p.KW = KW; p.OH = OH; p.OW = OW;
+    p.HW = H * W; p.KK = KH * KW; p.OO = OH * OW;
+    if ((p.HW % 4) != 0 || W < 4 || p.KK > 16) return p;
+    if (C != 128 && C != 256 && C != 512 && C != 1024) return p;
+    if ((long)n * p.HW >= (1L << 20)) return p;
+    p.Q = p.HW / 4;
+    p.TF = p.Q / 16;
+    p.rem = p.Q % 16;
+    p.left = (p.rem > 0 && p.rem <= 4) ? 1 : 0;
+    p.tiles = p.TF + ((p.rem > 0 && !p.left) ? 1 : 0);
+    if (p.TF < 1 || 2 * p.tiles > 16) return p;
+    p.CX = C / 8;
+    p.NK = p.CX / 8;
+    p.HWp = 64 * (p.TF + (p.rem > 0 ? 1 : 0)) + 4;
+    p.corr_threads = 2 * p.tiles * 64;
+    p.corr_lds = ((size_t)p.CX * 16 + (size_t)2 * p.KK * p.HWp) * sizeof(float);
+    if (p.corr_lds > 150 * 1024) return p;
+    p.CB = C / 16;
+    p.bpx = p.CB / 8;
+    p.NG = (int)(((long)n * p.HW + 15) / 16);
+    p.KSPL = 0;
+    for (int ks = 8; ks <= 16; ks *= 2) {
+        const int gper = pt_ceil_div(p.NG, ks), U = pt_ceil_div(gper, 8);
+        if (U <= 16) { p.gper = gper; p.U = U; p.KSPL = pt_ceil_div(p.NG, gper); break; }
+    }
+    if (p.KSPL == 0) return p;
+    p.PH = H + KH - 1;
+    // padded row stride of the residual maps in LDS: >= W + KW - 1 and == 8 (mod 16), so that the 16 taps x 2 quads a
+    // ds_read_b32 half-wave gathers (offsets v + u*PW + 4*kq) fall into 32 distinct banks for the usual 4x4 filter
+    p.PW = W + KW - 1;
+    while ((p.PW % 16) != 8) ++p.PW;
+    p.ns_max = (p.gper * 16 + p.HW - 1) / p.HW + 1;
+    p.adj_lds = ((size_t)p.ns_max * p.PH * p.PW + 16) * sizeof(float);
+    if (p.adj_lds > 96 * 1024 || p.OO > 1024) return p;
+    p.E = p.OO <= 384 ? 6 : (p.OO <= 576 ? 9 : 16);
+    p.ok = 1;
+    return p;
+}
+
+// exact floor(v / d) for the small non-negative integers of this file (v * (1/d) is >= 0.5/d away from an integer)
+__device__ __forceinline__ int fdiv(int v, float inv_d) { return (int)(((float)v + 0.5f) * inv_d); }
+
+// ---------------------------------------------------------------------------------------------------
+// k_corr2
+// ---------------------------------------------------------------------------------------------------
+struct Corr2Args {
+    const float* feat; long stride_n; const float* filt; float* spart;
+    int n, C, H, W, KH, KW, OH, OW, CX, TF, rem, tiles, HWp;
+    // fused gradient reduction (optimizer.py:146-148): filter operand = sum_k gpart[k] + reg*w
+    const float* gpart; int KSPL; const float* w; float reg; float* g_out; float* anum_part;
+    // source override: sample `slot` is read from `src` (C,H,W) and stored to copy_dst (the memory slot)
+    int slot; const float* src; float* copy_dst;
+};
+
+// generic (slow) form of one filter-operand element; only used for slices larger than 4 elements per thread
+__device__ __forceinline__ float corr2_filter_elem(const Corr2Args& a, int KK, int cx0, int e, bool publish, float& gsq) {
+    const int cl = e >> 4, tp = e & 15;
+    const bool ok = tp < KK;
+    const long ge = (long)(cx0 + cl) * KK + (ok ? tp : 0);
+    float v;
+    if (a.gpart) {
+        const long CKK = (long)a.C * KK;
+        v = 0.f;
+        for (int k = 0; k < a.KSPL; ++k) v += a.gpart[(long)k * CKK + ge];
+        v += a.reg * a.w[ge];
+        if (ok) {
+            gsq += v * v;
+            if (publish) a.g_out[ge] = v;
+        }
+    } else {
+        v = a.filt[ge];
+    }
+    return ok ? v : 0.f;
+}
+
+// FUSE = 0: filter operand read from `filt`.  FUSE = 8 / 16 / 32: operand = sum of <= FUSE gradient partials + reg*w
+// (optimizer.py:146-148), every load of the reduction issued before the first wait.
+// Two workgroups (<= 20 waves) per CU need <= 96 VGPRs: 5 waves per SIMD for the common channel counts.
+template <int NK, bool LEFT, int FUSE>
+__global__ __launch_bounds__(1024, (NK <= 8 ? 5 : 4)) void k_corr2(Corr2Args a) {
+    extern __shared__ __attribute__((aligned(16))) float lds[];     // afilt[CX][16] | T[2][KK][HWp]
+    __shared__ float scratch[16];
+    constexpr int EPT = 2;
+    constexpr int FP = FUSE > 0 ? FUSE : 1;
+    const int b = blockIdx.x, x = b & 7, i = b >> 3;
+    const int HW = a.H * a.W, KK = a.KH * a.KW;
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const int kq = lane >> 4, j = lane & 15;
+    const int h = wave >= a.tiles ? 1 : 0, t = wave - h * a.tiles;
+    const int cx0 = a.CX * x;
+    const int nsl = a.CX * 16;
+    float* __restrict__ afilt = lds;
+    float* __restrict__ Tl = lds + nsl + (long)h * KK * a.HWp;
+    const bool over = a.src != nullptr && i == a.slot;
+    const float* __restrict__ fi = over ? a.src : a.feat + (long)i * a.stride_n;
+    const bool publish = FUSE > 0 && i == 0;
+    PT_STAMP(0);
+
+    // ---- filter operand: straight-line, clamped addresses, all loads in flight together.  With 16 taps the slice
+    //      is one contiguous run of CX*16 floats: 16-byte loads, one per thread; otherwise up to EPT scalars.
+    const bool k16 = KK == 16;
+    const int n4 = nsl >> 1;                                        // 8-byte pieces (keeps the register count low
+    const int e4 = min((int)threadIdx.x, n4 - 1);                   //  enough for two workgroups per CU)
+    f32x2 part4[FP], wv4 = {0, 0};
+    float part[EPT][FP], wv[EPT];
+    long gev[EPT];
+    bool okv[EPT];
+    if (k16) {
+        const long g4 = ((long)cx0 * 16 >> 1) + e4;
+        if (FUSE > 0) {
+            const long CKK4 = (long)a.C * 8;
+#pragma unroll
+            for (int k = 0; k < FP; ++k) part4[k] = ((const f32x2*)a.gpart)[(long)min(k, a.KSPL - 1) * CKK4 + g4];
+            wv4 = ((const f32x2*)a.w)[g4];
+        } else {
+            part4[0] = ((const f32x2*)a.filt)[g4];
+        }
+    } else {
+#pragma unroll
+        for (int q = 0; q < EPT; ++q) {
+            const int e = threadIdx.x + q * blockDim.x;
+            const int ec = min(e, nsl - 1);
+            const int cl = ec >> 4, tp = ec & 15;
+            okv[q] = e < nsl && tp < KK;
+            gev[q] = (long)(cx0 + cl) * KK + (tp < KK ? tp : 0);
+            if (FUSE > 0) {
+                const long CKK = (long)a.C * KK;
+#pragma unroll
+                for (int k = 0; k < FP; ++k) part[q][k] = a.gpart[(long)min(k, a.KSPL - 1) * CKK + gev[q]];
+                wv[q] = a.w[gev[q]];
+            } else {
+                part[q][0] = a.filt[gev[q]];
+            }
+        }
+    }
+
+    // ---- this wave's whole feature slice in flight: NK float4 (+ NK scalars for the trailing quads)
+    const int cbase = cx0 + 4 * (h * NK) + kq;
+    const int pos = 64 * t + 4 * j;
+    const bool pv = pos < HW;
+    const float* __restrict__ fp = fi + (pv ? pos : 0) + (long)cbase * HW;
+    f32x4 bq[NK];
+#pragma unroll
+    for (int k = 0; k < NK; ++k) bq[k] = *(const f32x4*)(fp + (long)(4 * k) * HW);
+    float bl[NK];
+    const int lpos = 64 * a.TF + j;
+    const bool lv = LEFT && t == 0 && j < 4 * a.rem;
+    if (LEFT && t == 0) {
+        const float* __restrict__ lp = fi + (lv ? lpos : 0) + (long)cbase * HW;
+#pragma unroll
+        for (int k = 0; k < NK; ++k) bl[k] = lp[(long)(4 * k) * HW];
+    }
+
+    PT_STAMP(1);
+    // ---- reduce + publish the filter slice
+    float gsq = 0.f;
+    if (k16) {
+        f32x2 v4;
+        if (FUSE > 0) {
+            v4 = (f32x2){0, 0};
+#pragma unroll
+            for (int k = 0; k < FP; ++k)
+                if (k < a.KSPL) v4 += part4[k];                                     // fixed order
+            v4 += a.reg * wv4;
+            if ((int)threadIdx.x < n4) {
+                gsq = v4[0] * v4[0] + v4[1] * v4[1];
+                if (publish) ((f32x2*)a.g_out)[((long)cx0 * 16 >> 1) + e4] = v4;
+            }
+        } else {
+            v4 = part4[0];
+        }
+        if ((int)threadIdx.x < n4) ((f32x2*)afilt)[e4] = v4;
+        for (int q4 = threadIdx.x + blockDim.x; q4 < n4; q4 += blockDim.x)          // slices larger than the block
+            for (int m = 0; m < 2; ++m) afilt[2 * q4 + m] = corr2_filter_elem(a, KK, cx0, 2 * q4 + m, publish, gsq);
+    } else {
+#pragma unroll
+        for (int q = 0; q < EPT; ++q) {
+            const int e = threadIdx.x + q * blockDim.x;
+            float v;
+            if (FUSE > 0) {
+                v = 0.f;
+#pragma unroll
+                for (int k = 0; k < FP; ++k) v += k < a.KSPL ? part[q][k] : 0.f;   // fixed order
+                v += a.reg * wv[q];
+                if (okv[q]) {
+                    gsq += v * v;
+                    if (publish) a.g_out[gev[q]] = v;
+                }
+            } else {
+                v = part[q][0];
+            }
+            if (e < nsl) afilt[e] = okv[q] ? v : 0.f;
+        }
+        for (int e = threadIdx.x + EPT * blockDim.x; e < nsl; e += blockDim.x)
+            afilt[e] = corr2_filter_elem(a, KK, cx0, e, publish, gsq);
+    }
+    if (publish) {                                                  // uniform per workgroup
+        const float tot = block_sum(gsq, scratch);
+        if (threadIdx.x == 0) a.anum_part[x] = tot;
+    }
+    __syncthreads();
+    PT_STAMP(2);
+
+    // ---- memory insert rides on the pass (pytracking/tracker/dimp/dimp.py:429-441)
+    if (over && a.copy_dst) {
+        float* __restrict__ dp = a.copy_dst + pos + (long)cbase * HW;
+        if (pv) {
+#pragma unroll
+            for (int k = 0; k < NK; ++k) *(f32x4*)(dp + (long)(4 * k) * HW) = bq[k];
+        }
+        if (lv) {
+            float* __restrict__ dl = a.copy_dst + lpos + (long)cbase * HW;
+#pragma unroll
+            for (int k = 0; k < NK; ++k) dl[(long)(4 * k) * HW] = bl[k];
+        }
+    }
+
+    f32x4 acc0 = {0, 0, 0, 0}, acc1 = {0, 0, 0, 0}, acc2 = {0, 0, 0, 0}, acc3 = {0, 0, 0, 0}, accL = {0, 0, 0, 0};
+#pragma unroll
+    for (int k = 0; k < NK; ++k) {
+        const float av = afilt[(4 * (h * NK + k) + kq) * 16 + j];
+        if (PT_ABL & 1) { acc0 += av * bq[k]; continue; }
+        acc0 = mfma16(av, bq[k][0], acc0);
+        acc1 = mfma16(av, bq[k][1], acc1);
+        acc2 = mfma16(av, bq[k][2], acc2);
+        acc3 = mfma16(av, bq[k][3], acc3);
+        if (LEFT && t == 0) accL = mfma16(av, lv ? bl[k] : 0.f, accL);
+    }
+    PT_STAMP(3);
+#pragma unroll
+    for (int r = 0; r < 4; ++r) {
+        const int row = 4 * kq + r;
+        if (row < KK) {
+            f32x4 v = {acc0[r], acc1[r], acc2[r], acc3[r]};
+            *(f32x4*)(Tl + row * a.HWp + pos) = v;                 // columns >= HW land in the padding
+            if (LEFT && t == 0) Tl[row * a.HWp + lpos] = accL[r];  // j >= 4*rem: padding as well (lpos < HWp)
+        }
+    }
+    __syncthreads();
+    PT_STAMP(4);
+
+    // ---- shift-and-add of the tap planes (both halves), fixed order
+    const int ph = a.KH / 2, pw = a.KW / 2, OO = a.OH * a.OW;
+    const float inv_ow = 1.0f / (float)a.OW;
+    const float* __restrict__ T0 = lds + nsl;
+    const float* __restrict__ T1 = T0 + (long)KK * a.HWp;
+    float* __restrict__ out = a.spart + ((long)x * a.n + i) * OO;
+    if (PT_ABL & 2) { if (threadIdx.x < 64) out[threadIdx.x] = T0[threadIdx.x * 7] + T1[threadIdx.x]; return; }
+    if (a.KH == 4 && a.KW == 4) {                                   // the trackers' filter size: fully unrolled
+        for (int o = threadIdx.x; o < OO; o += blockDim.x) {
+            const int y = fdiv(o, inv_ow), xx0 = o - y * a.OW;
+            float tv[16];
+#pragma unroll
+            for (int u = 0; u < 4; ++u) {
+                const int yy = y + u - 2;
+#pragma unroll
+                for (int v = 0; v < 4; ++v) {
+                    const int xx = xx0 + v - 2;
+                    const bool ok = (unsigned)yy < (unsigned)a.H && (unsigned)xx < (unsigned)a.W;
+                    const int idx = (u * 4 + v) * a.HWp + (ok ? yy * a.W + xx : 0);
+                    const float tsum = T0[idx] + T1[idx];
+                    tv[u * 4 + v] = ok ? tsum : 0.f;
+                }
+            }
+            float s = 0.f;
+#pragma unroll
+            for (int q = 0; q < 16; ++q) s += tv[q];
+            out[o] = s;
+        }
+        PT_STAMP(5);
+        return;
+    }
+    for (int o = threadIdx.x; o < OO; o += blockDim.x) {
+        const int y = fdiv(o, inv_ow), xx0 = o - y * a.OW;
+        float s = 0.f;
+        for (int u = 0; u < a.KH; ++u) {
+            const int yy = y + u - ph;
+            if ((unsigned)yy >= (unsigned)a.H) continue;
+            for (int v = 0; v < a.KW; ++v) {
+                const int xx = xx0 + v - pw;
+                if ((unsigned)xx < (unsigned)a.W) {
+                    const int idx = (u * a.KW + v) * a.HWp + yy * a.W + xx;
+                    s += T0[idx] + T1[idx];
+                }
+            }
+        }
+        out[o] = s;
+    }
+}
+
+int pt_launch_corr2(const PtFast& p, const float* feat, long stride_n, const float* filt, float* spart, hipStream_t st,
+                    const PtCorrFuse* fuse, int slot, const float* src, float* copy_dst) {
+    Corr2Args a;
+    a.feat = feat; a.stride_n = stride_n; a.filt = filt; a.spart = spart;
+    a.n = p.n; a.C = p.C; a.H = p.H; a.W = p.W; a.KH = p.KH; a.KW = p.KW; a.OH = p.OH; a.OW = p.OW;
+    a.CX = p.CX; a.TF = p.TF; a.rem = p.rem; a.tiles = p.tiles; a.HWp = p.HWp;
+    a.gpart = nullptr; a.KSPL = 0; a.w = nullptr; a.reg = 0.f; a.g_out = nullptr; a.anum_part = nullptr;
+    if (fuse) { a.gpart = fuse->gpart; a.KSPL = fuse->KSPL; a.w = fuse->w; a.reg = fuse->reg; a.g_out = fuse->g_out; a.anum_part = fuse->anum_part; }
+    a.slot = slot; a.src = src; a.copy_dst = copy_dst;
+    if (((uintptr_t)feat % 16) || (stride_n % 4) || ((uintptr_t)src % 16) || ((uintptr_t)copy_dst % 16)) return PT_ERR_UNSUPPORTED;
+    if (p.KK == 16 && (((uintptr_t)filt % 16) || ((uintptr_t)a.gpart % 16) || ((uintptr_t)a.w % 16) || ((uintptr_t)a.g_out % 16)))
+        return PT_ERR_UNSUPPORTED;
+    dim3 grid(8 * p.n), block(p.corr_threads);
+    pt_prof_begin(0, st);
+#define PT_C2F(NKV, LF)                                                                                          \
+    do {                                                                                                         \
+        if (!a.gpart) hipLaunchKernelGGL((k_corr2<NKV, LF, 0>), grid, block, p.corr_lds, st, a);                 \
+        else if (a.KSPL <= 8) hipLaunchKernelGGL((k_corr2<NKV, LF, 8>), grid, block, p.corr_lds, st, a);         \
+        else hipLaunchKernelGGL((k_corr2<NKV, LF, 16>), grid, block, p.corr_lds, st, a);                         \
+    } while (0)
+#define PT_C2(NKV)                  \
+    do {                            \
+        if (p.left) PT_C2F(NKV, true); \
+        else PT_C2F(NKV, false);    \
+    } while (0)
+    if (p.NK == 2) PT_C2(2);
+    else if (p.NK == 4) PT_C2(4);
+    else if (p.NK == 8) PT_C2(8);
+    else PT_C2(16);
+#undef PT_C2F
+#undef PT_C2
+    pt_prof_end(0, st);
+    PT_CHECK_LAUNCH();
+    return PT_OK;
+}
+
+// ---------------------------------------------------------------------------------------------------
+// k_adj2
+// ---------------------------------------------------------------------------------------------------
+struct Adj2Args {
+    const float* feat; long stride_n; float* gpart;
+    int n, C, H, W, KH, KW, OH, OW, NG, gper, U, bpx, PH, PW, ns_max;
+    const float* inp;        // V_PLAIN: residual maps (n, OH, OW)
+    SdArgs sd;               // solver variants: solver state
+    int t, want_loss;        //                  iterate index of the maps this launch builds
+};
+
+// residual-map providers of k_adj2
+enum { V_PLAIN = 0, V_DIMP_RELU = 1, V_DIMP_BENT = 2, V_L2 = 3, V_PRDIMP = 4 };
+
+// per-lane inputs of the update stage for one sample: E strided elements per lane
+template <int E>
+struct PReg { float s[E], sg[E], lab[E], msk[E], sw[E]; };
+
+template <int V, int E>
+__device__ __forceinline__ void sdp_load(const Adj2Args& a, int i, int lane, PReg<E>& r) {
+    const int OO = a.OH * a.OW;
+    const long base = (long)i * OO;
+    // t == 0: there is no F g yet; astep is 0 and any finite operand does
+    const float* __restrict__ sgp = a.t > 0 ? a.sd.sg : a.sd.s_in;
+#pragma unroll
+    for (int e = 0; e < E; ++e) {
+        const long q = base + min(lane + 64 * e, OO - 1);
+        if (V == V_PLAIN) {
+            r.s[e] = a.inp[q];
+        } else {
+            r.s[e] = a.sd.s_in[q];
+            r.sg[e] = sgp[q];
+            if (V != V_PRDIMP) {
+                const f32x4 lm = ((const f32x4*)a.sd.lms)[q];        // {label, mask, sws, -} packed by k_fast_init
+                r.lab[e] = lm[0];
+                r.msk[e] = lm[1];
+                r.sw[e] = lm[2];
+            } else {
+                r.lab[e] = a.sd.label[q];
+            }
+        }
+    }
+}
+
+// Update stage of the steepest-descent iteration for sample i, executed by one wave
+// (optimizer.py:137-146,160 / :403-408,430): s_t = s_{t-1} - step*alpha*(F g); residual map -> zero-padded LDS map;
+// the owning workgroup (`home`) also stores s_t (and the PrDiMP softmax) and the sample's loss term.
+template <int V, int E>
+__device__ __forceinline__ void sdp_compute(const Adj2Args& a, int i, int lane, const PReg<E>& r, float astep,
+                                            float* __restrict__ map, int oy, int ox, bool home) {
+    const SdArgs& sd = a.sd;
+    const int OO = a.OH * a.OW;
+    const long base = (long)i * OO;
+    const float inv_ow = 1.0f / (float)a.OW;
+    float sv[E], val[E], aux[E];
+    float lacc = 0.f;
+    if (V == V_PLAIN) {
+#pragma unroll
+        for (int e = 0; e < E; ++e) val[e] = r.s[e];
+    } else if (V != V_PRDIMP) {
+#pragma unroll
+        for (int e = 0; e < E; ++e) {
+            sv[e] = r.s[e] - astep * r.sg[e];
+            float act, der;
+            const float x = sv[e], am = r.msk[e];
+            if (V == V_DIMP_RELU) {                                                 // activation.py:32-46
+                const float sgn = (x > 0.f) ? 1.f : ((x < 0.f) ? -1.f : 0.f);
+                act = (1.0f - am) * 0.5f * fabsf(x) + (1.0f + am) * 0.5f * x;
+                der = (1.0f - am) * 0.5f * sgn + (1.0f + am) * 0.5f;
+            } else if (V == V_DIMP_BENT) {                                          // activation.py:49-66
+                const float bp = sd.act_param, rt = sqrtf(x * x + 4.0f * bp * bp);
+                act = (1.0f - am) * 0.5f * (rt - 2.0f * bp) + (1.0f + am) * 0.5f * x;
+                der = (1.0f - am) * 0.5f * (x / rt) + (1.0f + am) * 0.5f;
+            } else {                                                                // optimizer.py:262-263
+                act = am * x + (1.0f - am) * fmaxf(x, 0.f);
+                der = am + (1.0f - am) * (x > 0.f ? 1.f : 0.f);
+            }
+            const float rr = r.sw[e] * (act - r.lab[e]);                            // :140
+            lacc += (lane + 64 * e < OO) ? rr * rr : 0.f;
+            val[e] = der * (r.sw[e] * rr);                                          // :146
+        }
+    } else {
+        const float swp = sd.has_sw ? sd.sw[i] : 1.0f / (float)sd.n;                // :387-390
+        float mx = sd.has_softmax_reg ? sd.softmax_reg : -INFINITY;
+#pragma unroll
+        for (int e = 0; e < E; ++e) {
+            sv[e] = r.s[e] - astep * r.sg[e];
+            if (lane + 64 * e < OO) mx = fmaxf(mx, sv[e]);
+        }
+        mx = wave_max(mx);
+        float es = 0.f, ls = 0.f;
+#pragma unroll
+        for (int e = 0; e < E; ++e) {
+            const bool ok = lane + 64 * e < OO;
+            aux[e] = ok ? expf(sv[e] - mx) : 0.f;
+            es += aux[e];
+            ls += ok ? r.lab[e] * sv[e] : 0.f;
+        }
+        es = wave_sum(es);
+        ls = wave_sum(ls);
+        if (sd.has_softmax_reg) es += expf(sd.softmax_reg - mx);                    // activation.py:7-16
+        const float inv = 1.0f / es;
+#pragma unroll
+        for (int e = 0; e < E; ++e) {
+            aux[e] *= inv;                                                          // softmax P
+            val[e] = swp * (aux[e] - r.lab[e]);                                     // :408
+        }
+        lacc = swp * (logf(es) + mx - ls);                                          // :393-396 (same in every lane)
+    }
+#pragma unroll
+    for (int e = 0; e < E; ++e) {
+        const int o = lane + 64 * e;
+        if (o < OO) {
+            const int y = fdiv(o, inv_ow), x = o - y * a.OW;
+            map[(y + oy) * a.PW + x + ox] = val[e];
+        }
+    }
+    if (V != V_PLAIN && home) {
+#pragma unroll
+        for (int e = 0; e < E; ++e) {
+            const int o = lane + 64 * e;
+            if (o < OO) {
+                if (a.t > 0) sd.s[base + o] = sv[e];
+                if (V == V_PRDIMP) sd.mask[base + o] = aux[e];
+            }
+        }
+        if (a.want_loss) {
+            const float tot = V == V_PRDIMP ? lacc : wave_sum(lacc);
+            if (lane == 0) sd.lossp[(long)a.t * sd.n + i] = tot;
+        }
+    }
+}
+
+template <int V, int E>
+__global__ __launch_bounds__(512) void k_adj2(Adj2Args a) {
+    extern __shared__ __attribute__((aligned(16))) float maps[];    // [ns_max][PH][PW] zero-padded residual maps + 16 zeros
+    __shared__ float red[8][256];
+    const int b = blockIdx.x, x = b & 7, rr = b >> 3;
+    const int cb = a.bpx * x + rr % a.bpx, ks = rr / a.bpx;
+    const int HW = a.H * a.W, KK = a.KH * a.KW, PHPW = a.PH * a.PW;
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const int kq = lane >> 4, j = lane & 15;
+    const int gbeg = ks * a.gper, gend = min(a.NG, gbeg + a.gper);
+    const int total = a.n * HW;
+    const float inv_hw = 1.0f / (float)HW, inv_w = 1.0f / (float)a.W;
+    const int i_lo = fdiv(gbeg * 16, inv_hw);
+    const int i_hi = min(a.n - 1, fdiv(gend * 16 - 1, inv_hw));
+    const int ns = i_hi - i_lo + 1;
+    const int ZB = a.ns_max * PHPW;                                 // 16 zeros: what masked lanes gather
+    // residual coordinate of (position (y,x), tap (u,v)) is (y-u+KH/2, x-v+KW/2); in the padded map the residual
+    // pixel (yy,xx) sits at (yy + oy, xx + ox)
+    const int oy = a.KH - 1 - a.KH / 2, ox = a.KW - 1 - a.KW / 2;
+
+    PT_STAMP(0);
+    for (int e = threadIdx.x; e < ns * PHPW; e += blockDim.x) maps[e] = 0.f;
+    if (threadIdx.x < 16) maps[ZB + threadIdx.x] = 0.f;
+
+    // ---- update-stage inputs first (they return first) ...
+    PReg<E> pr;
+    const bool have = wave < ns;
+    sdp_load<V, E>(a, i_lo + min(wave, ns - 1), lane, pr);
+    float q_in = 0.f, an_in = 0.f;                                  // alpha_{t-1} inputs; reduced after the A loads are issued
+    float w_prev = 0.f, g_prev = 0.f;                               // this thread's element of the filter update
+    const bool wupd = V != V_PLAIN && a.t > 0 && ks == 0;
+    const long wge = (long)cb * 16 * KK + min((int)threadIdx.x, 16 * KK - 1);
+    if (V != V_PLAIN && a.t > 0) {
+        for (int k = lane; k < a.sd.n; k += 64) q_in += a.sd.qs[k];
+        an_in = lane < a.sd.KS ? a.sd.anum[lane] : 0.f;
+        if (wupd) {                                                 // uniform per workgroup
+            w_prev = sd_w(a.sd, a.t - 1)[wge];
+            g_prev = a.sd.g[wge];
+        }
+    }
+    // ---- ... then the A operand: the U contiguous 16-position groups of this wave, all in flight
+    const int c = cb * 16 + j;
+    const float* __restrict__ fc = a.feat + (long)c * HW;
+    const int g0 = gbeg + wave * a.U;
+    f32x4 av[16];
+    int il[16], p0[16];
+#pragma unroll
+    for (int u = 0; u < 16; ++u) {
+        const int g = g0 + u;
+        const int P0 = 16 * g + 4 * kq;
+        const bool okk = u < a.U && g < gend && P0 < total;
+        const int Pc = okk ? P0 : 16 * g0 + 4 * kq < total ? 16 * g0 + 4 * kq : 0;   // masked groups re-read a line already fetched
+        const int i = fdiv(Pc, inv_hw);
+        il[u] = okk ? i - i_lo : -1;
+        p0[u] = Pc - i * HW;
+        av[u] = *(const f32x4*)(fc + (long)i * a.stride_n + p0[u]);
+    }
+
+    PT_STAMP(1);
+    float astep = 0.f;
+    if (V != V_PLAIN && a.t > 0) {                                  // optimizer.py:155-160 / :425-430
+        const float a_num = wave_sum(an_in);
+        const float den = fmaxf(wave_sum(q_in) + (a.sd.reg + a.sd.alpha_eps) * a_num, 1e-8f);
+        astep = a.sd.step * (a_num / den);
+    }
+    __syncthreads();                                                // maps zeroed
+    PT_STAMP(2);
+    {
+        const int i = i_lo + wave;
+        const int hg = (i * HW) >> 4;                               // the slice holding the sample's first group owns it
+        const bool home = cb == 0 && hg >= gbeg && hg < gend;
+        if (have && !(PT_ABL & 16)) sdp_compute<V, E>(a, i, lane, pr, astep, maps + wave * PHPW, oy, ox, home);
+    }
+    for (int sl = wave + 8; sl < ns; sl += 8) {                     // more samples than waves (tiny maps)
+        const int i = i_lo + sl;
+        const int hg = (i * HW) >> 4;
+        const bool home = cb == 0 && hg >= gbeg && hg < gend;
+        sdp_load<V, E>(a, i, lane, pr);
+        sdp_compute<V, E>(a, i, lane, pr, astep, maps + sl * PHPW, oy, ox, home);
+    }
+    if (wupd && (int)threadIdx.x < 16 * KK)                         // w_t = w_{t-1} - step*alpha*g   (:160)
+        a.sd.w_iters[(long)a.t * a.sd.CKK + wge] = w_prev - astep * g_prev;
+    PT_STAMP(3);
+    __syncthreads();
+    PT_STAMP(4);
+
+    // ---- G[c][tap] += feat[c][P] * r[P shifted by tap]
+    const int uj = j / a.KW, vj = j - uj * a.KW;
+    const int tapoff = (a.KH - 1 - uj) * a.PW + (a.KW - 1 - vj);
+    const bool tapv = j < KK;
+    f32x4 accA = {0, 0, 0, 0}, accB = {0, 0, 0, 0};
+    float bv[16][4];
+#pragma unroll
+    for (int u = 0; u < 16; ++u) {                                  // all gathers in flight before the first MFMA
+        const bool okb = il[u] >= 0 && tapv;
+        const int y0 = fdiv(p0[u], inv_w), x0 = p0[u] - y0 * a.W;
+        // a quad may wrap to the next feature row: one row further in the padded map is PW - W cells more
+        const int idx0 = okb ? il[u] * PHPW + tapoff + y0 * a.PW + x0 : ZB;
+        const int wr = okb ? a.PW - a.W : 0;
+        bv[u][0] = maps[idx0];
+        bv[u][1] = maps[idx0 + 1 + (x0 + 1 >= a.W ? wr : 0)];
+        bv[u][2] = maps[idx0 + 2 + (x0 + 2 >= a.W ? wr : 0)];
+        bv[u][3] = maps[idx0 + 3 + (x0 + 3 >= a.W ? wr : 0)];
+    }
+#pragma unroll
+    for (int u = 0; u < 16; ++u) {
+        if (PT_ABL & 8) { accA += av[u]; continue; }
+        // masked lanes multiply a finite, re-read feature value by a gathered zero
+        accA = mfma16(av[u][0], bv[u][0], accA);
+        accB = mfma16(av[u][1], bv[u][1], accB);
+        accA = mfma16(av[u][2], bv[u][2], accA);
+        accB = mfma16(av[u][3], bv[u][3], accB);
+    }
+    PT_STAMP(5);
+#pragma unroll
+    for (int r = 0; r < 4; ++r) red[wave][(4 * kq + r) * 16 + j] = accA[r] + accB[r];
+    __syncthreads();
+    if (threadIdx.x < 256) {
+        const int e = threadIdx.x, row = e >> 4, tap = e & 15;
+        float s = 0.f;
+#pragma unroll
+        for (int w = 0; w < 8; ++w) s += red[w][e];
+        if (tap < KK) a.gpart[(long)ks * a.C * KK + (long)(cb * 16 + row) * KK + tap] = s;
+    }
+    PT_STAMP(6);
+}
+
+static void adj2_fill(const PtFast& p, Adj2Args& a, const float* feat, long stride_n, float* gpart) {
+    a.feat = feat; a.stride_n = stride_n; a.gpart = gpart;
+    a.n = p.n; a.C = p.C; a.H = p.H; a.W = p.W; a.KH = p.KH; a.KW = p.KW; a.OH = p.OH; a.OW = p.OW;
+    a.NG = p.NG; a.gper = p.gper; a.U = p.U; a.bpx = p.bpx; a.PH = p.PH; a.PW = p.PW; a.ns_max = p.ns_max;
+    a.inp = nullptr; a.t = 0; a.want_loss = 0;
+}
+
+template <int V>
+static void adj2_dispatch(const PtFast& p, const Adj2Args& a, hipStream_t st) {
+    dim3 grid(p.CB * p.KSPL), block(512);
+    if (p.E == 6) hipLaunchKernelGGL((k_adj2<V, 6>), grid, block, p.adj_lds, st, a);
+    else if (p.E == 9) hipLaunchKernelGGL((k_adj2<V, 9>), grid, block, p.adj_lds, st, a);
+    else hipLaunchKernelGGL((k_adj2<V, 16>), grid, block, p.adj_lds, st, a);
+}
+
+int pt_launch_adj2_plain(const PtFast& p, const float* feat, long stride_n, const float* inp, float* gpart,
+                         hipStream_t st) {
+    if (((uintptr_t)feat % 16) || (stride_n % 4)) return PT_ERR_UNSUPPORTED;
+    Adj2Args a;
+    adj2_fill(p, a, feat, stride_n, gpart);
+    a.inp = inp;
+    a.sd = SdArgs();
+    pt_prof_begin(1, st);
+    adj2_dispatch<V_PLAIN>(p, a, st);
+    pt_prof_end(1, st);
+    PT_CHECK_LAUNCH();
+    return PT_OK;
+}
+
+int pt_launch_adj2_sd(const PtFast& p, const float* feat, long stride_n, const SdArgs& sd, int t, int want_loss,
+                      hipStream_t st) {
+    if (((uintptr_t)feat % 16) || (stride_n % 4)) return PT_ERR_UNSUPPORTED;
+    Adj2Args a;
+    adj2_fill(p, a, feat, stride_n, sd.gpart);
+    a.sd = sd;
+    a.t = t;
+    a.want_loss = want_loss;
+    pt_prof_begin(1, st);
+    if (sd.kind == PT_SD_PRDIMP) adj2_dispatch<V_PRDIMP>(p, a, st);
+    else if (sd.kind == PT_SD_DIMP_L2) adj2_dispatch<V_L2>(p, a, st);
+    else if (sd.score_act == PT_ACT_BENTPAR) adj2_dispatch<V_DIMP_BENT>(p, a, st);
+    else adj2_dispatch<V_DIMP_RELU>(p, a, st);
+    pt_prof_end(1, st);
+    PT_CHECK_LAUNCH();
+    return PT_OK;
+}

@@ -47,6 +47,29 @@ int pt_launch_sum_slices(const float* part, float* out, int slices, size_t count
 // R (im2col of the residual map, MFMA-B layout) from inp (n, OH, OW)
 int pt_launch_build_R(const PtPlan& p, const float* inp, float* R, hipStream_t st);
 
+// ---- XCD-aligned fast path (fast_passes.hip): C in {128,256,512,1024}, H*W % 4 == 0 -------------------------
+struct PtFast {
+    int ok;
+    int n, C, H, W, KH, KW, OH, OW, HW, KK, OO, Q;
+    int CX, NK, TF, rem, tiles, left, HWp, corr_threads;   // corr2: grid 8*n, waves = 2 halves x tiles
+    size_t corr_lds;
+    int CB, bpx, NG, KSPL, gper, U, PH, PW, ns_max, E;     // adj2: grid CB*KSPL, 8 waves x U contiguous groups
+    size_t adj_lds;
+};
+PtFast pt_fast_plan(int n, int C, int H, int W, int KH, int KW, int OH, int OW);
+static inline size_t pt_fast_spart_floats(const PtFast& p) { return (size_t)8 * p.n * p.OO; }
+static inline size_t pt_fast_gpart_floats(const PtFast& p) { return (size_t)p.KSPL * p.C * p.KK; }
+// spart[x][i][OH*OW], x = XCD channel range (8 slices).  `slot`/`src`/`copy_dst`: sample `slot` is read from `src`
+// and stored to `copy_dst` while it streams (src == nullptr: no override).
+int pt_launch_corr2(const PtFast& p, const float* feat, long stride_n, const float* filt, float* spart, hipStream_t st,
+                    const PtCorrFuse* fuse = nullptr, int slot = -1, const float* src = nullptr,
+                    float* copy_dst = nullptr);
+int pt_launch_adj2_plain(const PtFast& p, const float* feat, long stride_n, const float* inp, float* gpart,
+                         hipStream_t st);
+struct SdArgs;
+int pt_launch_adj2_sd(const PtFast& p, const float* feat, long stride_n, const SdArgs& sd, int t, int want_loss,
+                      hipStream_t st);
+
 #define PT_CHECK_LAUNCH()                                    \
     do {                                                     \
         if (hipGetLastError() != hipSuccess) return PT_ERR_LAUNCH; \
@@ -62,7 +85,7 @@ struct PtClsFin {
 int pt_sd_solve_impl(const pt_sd_params* prm, const float* w_in, const float* feat, long feat_stride_n, const float* bb,
                      const float* sample_weight, int n, int C, int H, int W, int K, int num_iter, float* w_iters,
                      float* losses, void* ws, size_t ws_bytes, hipStream_t st, bool copy_w0, float* w_final,
-                     const PtClsFin* cls);
+                     const PtClsFin* cls, const float* src);
 
 // measurement hook (profile.hip): no-ops unless a pt_profile is attached
 void pt_prof_begin(int kernel_id, hipStream_t st);

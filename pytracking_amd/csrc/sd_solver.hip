@@ -17,188 +17,25 @@
 //                   partial (F g) maps                                                        [n x KS WGs]
 //     pw SGQ        sg = F g ; per-sample curvature term q_i                                  [n WGs]
 //     pw UPDATE     alpha ; w_{t+1} ; s_{t+1} ; next residual map + R ; loss                  [n WGs]
+#include <algorithm>
 #include "common.h"
 #include "pt_internal.h"
 #include "rbuild.h"
+#include "sd_common.h"
 
 enum { PW_INIT = 0, PW_SGQ = 1, PW_UPDATE = 2 };
-
-struct SdArgs {
-    // problem
-    int n, C, H, W, K, OH, OW, OO, CKK, KS, KSPL;
-    int kind, score_act, mask_act, has_sw, has_softmax_reg, normalize_label, num_bins;
-    float step, reg, alpha_eps, feat_stride, bin_disp, act_param, gauss_sigma, hinge_thr;
-    float uni_weight, label_shrink, softmax_reg, label_thr;
-    const float *bb, *sw, *label_lut, *mask_lut, *spatial_lut;
-    // workspace
-    float *label, *mask, *sws;   // (n,OO) maps.  PrDiMP: mask holds the softmax P, sws unused
-    float *s, *sg;               // (n,OO) scores of the current iterate, F g
-    float *spart;                // (KS,n,OO)
-    float *R;                    // (NG,256)
-    float *gpart, *g;            // (KSPL,CKK), (CKK)
-    float *anum;                 // (KS) per-channel-slice |g|^2 (written by the corr(g) pass)
-    float *qs;                   // (n)
-    float *lossp;                // (T+1, n)
-    float *w_iters;              // (T+1, CKK)  caller's buffer; iterate 0 lives at w0
-    const float *w0;             // initial filter
-    float *w_final;              // optional: the last iterate is written here instead of w_iters[T]
-    // optional classification epilogue run by the workgroup of sample `cls_slot` before its maps
-    // (benchmark frame: sum the classify partials, arg-max, re-centre that sample's box)
-    const float *cls_spart;
-    int cls_KS, cls_slot;
-    float *cls_scores, *cls_peak, *cls_bb;
-};
-
-__device__ __forceinline__ const float* sd_w(const SdArgs& a, int t) {
-    return t == 0 ? a.w0 : a.w_iters + (long)t * a.CKK;
-}
-
-// ----------------------------------------------------------------------------------------------------
-// maps: one workgroup per sample
-// ----------------------------------------------------------------------------------------------------
-__device__ __forceinline__ float pl_lut(const float* __restrict__ w, int bins, float t) {
-    // DistanceMap (ltr/models/layers/distance.py:17-39) followed by a 1x1 conv over the bins is the
-    // piecewise-linear interpolation of the conv weights at t = d / bin_displacement, constant past the last bin.
-    const int k0 = (int)floorf(t);
-    if (k0 >= bins - 1) return w[bins - 1];
-    const float fr = t - (float)k0;
-    return w[k0] * (1.0f - fr) + w[k0 + 1] * fr;
-}
-
-// sums the classification partials, finds the first maximum (torch.max semantics, pytracking/libs/dcf.py:156-164)
-// and re-centres the box of memory slot `cls_slot` on it (inverse of the centre formula of optimizer.py:112-113).
-__device__ void sd_classify_fin(const SdArgs& a) {
-    __shared__ float bv[16];
-    __shared__ int bi[16];
-    float best = -INFINITY;
-    int besti = 0x7fffffff;
-    for (int o = threadIdx.x; o < a.OO; o += blockDim.x) {
-        float s = 0.f;
-        int k = 0;
-        for (; k + 8 <= a.cls_KS; k += 8) {                 // independent loads in flight, fixed summation order
-            float v[8];
-#pragma unroll
-            for (int q = 0; q < 8; ++q) v[q] = a.cls_spart[(long)(k + q) * a.OO + o];
-#pragma unroll
-            for (int q = 0; q < 8; ++q) s += v[q];
-        }
-        for (; k < a.cls_KS; ++k) s += a.cls_spart[(long)k * a.OO + o];
-        a.cls_scores[o] = s;
-        if (s > best) { best = s; besti = o; }
-    }
-#pragma unroll
-    for (int off = 32; off > 0; off >>= 1) {
-        const float ov = __shfl_xor(best, off, 64);
-        const int oi = __shfl_xor(besti, off, 64);
-        if (ov > best || (ov == best && oi < besti)) { best = ov; besti = oi; }
-    }
-    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6, nw = (blockDim.x + 63) >> 6;
-    if (lane == 0) { bv[wave] = best; bi[wave] = besti; }
-    __syncthreads();
-    if (threadIdx.x == 0) {
-        for (int w = 1; w < nw; ++w)
-            if (bv[w] > best || (bv[w] == best && bi[w] < besti)) { best = bv[w]; besti = bi[w]; }
-        const int row = besti / a.OW, col = besti - row * a.OW;
-        a.cls_peak[0] = (float)row;
-        a.cls_peak[1] = (float)col;
-        const float off = (float)(a.K % 2) * 0.5f;
-        float* b = a.cls_bb + 4 * a.cls_slot;
-        b[0] = ((float)col + off) * a.feat_stride - b[2] * 0.5f;
-        b[1] = ((float)row + off) * a.feat_stride - b[3] * 0.5f;
-    }
-    __syncthreads();
-}
 
 __global__ void k_sd_maps(SdArgs a) {
     __shared__ float scratch[16];
     __shared__ int amin[2];
     const int i = blockIdx.x;
     if (a.cls_spart && i == a.cls_slot) sd_classify_fin(a);     // uniform per workgroup
-    const float off = (float)(a.K % 2) * 0.5f;
-    const float* b = a.bb + 4 * i;
-    const float ctr_r = (b[1] + b[3] * 0.5f) / a.feat_stride - off;     // optimizer.py:112-113 (flip -> row first)
-    const float ctr_c = (b[0] + b[2] * 0.5f) / a.feat_stride - off;
-    float* label = a.label + (long)i * a.OO;
-    if (a.kind == PT_SD_DIMP) {
-        float* mask = a.mask + (long)i * a.OO;
-        float* sws = a.sws + (long)i * a.OO;
-        const float swi = a.has_sw ? sqrtf(a.sw[i]) : sqrtf(1.0f / (float)a.n);   // :122-125
-        for (int o = threadIdx.x; o < a.OO; o += blockDim.x) {
-            const int y = o / a.OW, x = o - y * a.OW;
-            const float d0 = (float)y - ctr_r, d1 = (float)x - ctr_c;
-            const float t = sqrtf(d0 * d0 + d1 * d1) / a.bin_disp;
-            label[o] = pl_lut(a.label_lut, a.num_bins, t);
-            float m = pl_lut(a.mask_lut, a.num_bins, t);
-            if (a.mask_act == PT_MASK_SIGMOID) m = 1.0f / (1.0f + expf(-m));
-            mask[o] = m;
-            sws[o] = swi * pl_lut(a.spatial_lut, a.num_bins, t);
-        }
-    } else if (a.kind == PT_SD_DIMP_L2) {
-        float* mask = a.mask + (long)i * a.OO;
-        float* sws = a.sws + (long)i * a.OO;
-        const float swi = a.has_sw ? sqrtf(a.sw[i]) : sqrtf(1.0f / (float)a.n);   // :249-252
-        const float coef = -1.0f / (2.0f * a.gauss_sigma * a.gauss_sigma);
-        for (int o = threadIdx.x; o < a.OO; o += blockDim.x) {
-            const int y = o / a.OW, x = o - y * a.OW;
-            const float d0 = (float)y - ctr_r, d1 = (float)x - ctr_c;
-            const float gss = expf(coef * d0 * d0) * expf(coef * d1 * d1);       // :201-208
-            const float m = gss > a.hinge_thr ? 1.0f : 0.0f;                      // :245
-            label[o] = gss * m;
-            mask[o] = m;
-            sws[o] = swi;
-        }
-    } else {   // PrDiMP label density, optimizer.py:331-353
-        if (a.gauss_sigma == 0.f && threadIdx.x == 0) {
-            int b0 = 0, b1 = 0;
-            float m0 = INFINITY, m1 = INFINITY;
-            for (int y = 0; y < a.OH; ++y) { float d = ((float)y - ctr_r); d *= d; if (d < m0) { m0 = d; b0 = y; } }
-            for (int x = 0; x < a.OW; ++x) { float d = ((float)x - ctr_c); d *= d; if (d < m1) { m1 = d; b1 = x; } }
-            amin[0] = b0; amin[1] = b1;
-        }
-        __syncthreads();
-        const float s2 = a.gauss_sigma * a.gauss_sigma;
-        const float coef = -1.0f / (2.0f * s2);
-        float part = 0.f;
-        for (int o = threadIdx.x; o < a.OO; o += blockDim.x) {
-            const int y = o / a.OW, x = o - y * a.OW;
-            float gss;
-            if (a.gauss_sigma == 0.f) {
-                gss = (y == amin[0] && x == amin[1]) ? 1.0f : 0.0f;
-            } else {
-                const float d0 = (float)y - ctr_r, d1 = (float)x - ctr_c;
-                gss = (expf(coef * d0 * d0) / (2.0f * 3.14159265358979323846f * s2)) * expf(coef * d1 * d1);
-            }
-            gss = gss > a.label_thr ? gss : 0.f;
-            label[o] = gss;
-            part += gss;
-        }
-        const float tot = block_sum(part, scratch);
-        const float inv = a.normalize_label ? 1.0f / (tot + 1e-8f) : 1.0f;
-        const float uni = a.uni_weight / (float)a.OO;
-        for (int o = threadIdx.x; o < a.OO; o += blockDim.x)
-            label[o] = (1.0f - a.label_shrink) * ((1.0f - a.uni_weight) * (label[o] * inv) + uni);
-    }
+    sd_maps_sample(a, i, scratch, amin);
 }
 
 // ----------------------------------------------------------------------------------------------------
 // pointwise stages: one workgroup per sample
 // ----------------------------------------------------------------------------------------------------
-__device__ __forceinline__ void act_pair(int score_act, float bpar, float x, float am, float& act, float& der) {
-    // activation.py:32-66.  score_act 2 = the L2 hinge of optimizer.py:262-263 (mask in {0,1}).
-    if (score_act == PT_ACT_RELU) {
-        const float sgn = (x > 0.f) ? 1.f : ((x < 0.f) ? -1.f : 0.f);
-        act = (1.0f - am) * 0.5f * fabsf(x) + (1.0f + am) * 0.5f * x;
-        der = (1.0f - am) * 0.5f * sgn + (1.0f + am) * 0.5f;
-    } else if (score_act == PT_ACT_BENTPAR) {
-        const float rt = sqrtf(x * x + 4.0f * bpar * bpar);
-        act = (1.0f - am) * 0.5f * (rt - 2.0f * bpar) + (1.0f + am) * 0.5f * x;
-        der = (1.0f - am) * 0.5f * (x / rt) + (1.0f + am) * 0.5f;
-    } else {
-        act = am * x + (1.0f - am) * fmaxf(x, 0.f);
-        der = am + (1.0f - am) * (x > 0.f ? 1.f : 0.f);
-    }
-}
-
 // sum of the KS channel-slice partials of one score element (loads issued together, fixed summation order)
 __device__ __forceinline__ float sd_sum_slices(const SdArgs& a, int i, int o) {
     const float* p = a.spart + (long)i * a.OO + o;
@@ -214,16 +51,6 @@ __device__ __forceinline__ float sd_sum_slices(const SdArgs& a, int i, int o) {
     }
     for (; k < a.KS; ++k) s += p[k * st];
     return s;
-}
-
-__device__ __forceinline__ float sd_alpha_step(const SdArgs& a) {
-    // optimizer.py:155-160 / :425-430: alpha = |g|^2 / max(sum_i q_i + (reg+eps)|g|^2, 1e-8), times the step length
-    float den = 0.f;
-    for (int k = 0; k < a.n; ++k) den += a.qs[k];
-    float a_num = 0.f;
-    for (int k = 0; k < a.KS; ++k) a_num += a.anum[k];
-    den = fmaxf(den + (a.reg + a.alpha_eps) * a_num, 1e-8f);
-    return a.step * (a_num / den);
 }
 
 // stage: PW_INIT (s from correlation partials), PW_SGQ, PW_UPDATE (s_{t} = s_{t-1} - step*alpha*sg).
@@ -375,13 +202,131 @@ static SdCarve sd_carve(const PtPlan& p, int max_iter) {
     return c;
 }
 
+
+// ----------------------------------------------------------------------------------------------------
+// fast path (fast_passes.hip): per iteration  adj2 [update prologue fused] -> corr2 [gradient reduction fused] -> SGQ
+// ----------------------------------------------------------------------------------------------------
+struct FastCarve {
+    size_t label, mask, sws, lms, s0, s1, sg, spart, gpart, g, anum, qs, lossp, total;
+};
+
+static FastCarve fast_carve(const PtFast& f, int max_iter) {
+    FastCarve c;
+    size_t off = 0;
+    auto take = [&](size_t nfl) { size_t o = off; off += pt_align_floats(nfl); return o; };
+    const size_t nOO = (size_t)f.n * f.OO;
+    c.label = take(nOO); c.mask = take(nOO); c.sws = take(nOO); c.lms = take(4 * nOO);
+    c.s0 = take(nOO); c.s1 = take(nOO); c.sg = take(nOO);
+    c.spart = take(pt_fast_spart_floats(f));
+    c.gpart = take(pt_fast_gpart_floats(f));
+    c.g = take((size_t)f.C * f.KK);
+    c.anum = take(64);
+    c.qs = take(f.n);
+    c.lossp = take((size_t)(max_iter + 1) * f.n);
+    c.total = off;
+    return c;
+}
+
+// s_0 = sum of the 8 channel-range slices; classification epilogue of the inserted slot; label/mask/weight maps
+__global__ __launch_bounds__(512) void k_fast_init(SdArgs a) {
+    __shared__ float scratch[16];
+    __shared__ int amin[2];
+    const int i = blockIdx.x;
+    const long base = (long)i * a.OO;
+    for (int o = threadIdx.x; o < a.OO; o += blockDim.x) a.s[base + o] = sd_sum_slices(a, i, o);
+    if (a.cls_spart && i == a.cls_slot) sd_classify_fin(a);     // uniform per workgroup; re-centres bb[slot]
+    sd_maps_sample(a, i, scratch, amin);
+}
+
 #define PT_SD_MAX_ITER 64
 
 extern "C" size_t pt_sd_ws_bytes(int n, int C, int H, int W, int K) {
     if (n <= 0 || C <= 0 || H <= 0 || W <= 0 || K <= 0) return 0;
     const int OH = H + (K + 1) % 2, OW = W + (K + 1) % 2;
     PtPlan p = pt_make_plan(n, C, H, W, K, K, OH, OW);
-    return sd_carve(p, PT_SD_MAX_ITER).total * sizeof(float);
+    size_t tot = sd_carve(p, PT_SD_MAX_ITER).total;
+    PtFast f = pt_fast_plan(n, C, H, W, K, K, OH, OW);
+    if (f.ok) tot = std::max(tot, fast_carve(f, PT_SD_MAX_ITER).total);
+    return tot * sizeof(float);
+}
+
+static void sd_fill_params(SdArgs& a, const pt_sd_params* prm, const float* bb, const float* sample_weight, int n, int C,
+                           int H, int W, int K, int OH, int OW) {
+    a.n = n; a.C = C; a.H = H; a.W = W; a.K = K; a.OH = OH; a.OW = OW; a.OO = OH * OW; a.CKK = C * K * K;
+    a.kind = prm->kind; a.score_act = prm->score_act; a.mask_act = prm->mask_act; a.has_sw = sample_weight != nullptr;
+    a.has_softmax_reg = prm->has_softmax_reg; a.normalize_label = prm->normalize_label; a.num_bins = prm->num_bins;
+    a.step = prm->step_length; a.reg = prm->reg; a.alpha_eps = prm->alpha_eps; a.feat_stride = prm->feat_stride;
+    a.bin_disp = prm->bin_displacement; a.act_param = prm->act_param; a.gauss_sigma = prm->gauss_sigma;
+    a.hinge_thr = prm->hinge_threshold; a.uni_weight = prm->uni_weight; a.label_shrink = prm->label_shrink;
+    a.softmax_reg = prm->softmax_reg; a.label_thr = prm->label_threshold;
+    a.bb = bb; a.sw = sample_weight; a.label_lut = prm->label_lut; a.mask_lut = prm->mask_lut;
+    a.spatial_lut = prm->spatial_lut;
+    a.s_in = nullptr; a.lms = nullptr; a.R = nullptr; a.cls_stride = 0;
+    a.cls_spart = nullptr; a.cls_KS = 0; a.cls_slot = -1; a.cls_scores = nullptr; a.cls_peak = nullptr; a.cls_bb = nullptr;
+}
+
+static int sd_solve_fast(const PtFast& f, const pt_sd_params* prm, const float* w_in, const float* feat, long stride_n,
+                         const float* bb, const float* sample_weight, int num_iter, float* w_iters, float* losses,
+                         void* ws, size_t ws_bytes, hipStream_t st, bool copy_w0, float* w_final, const PtClsFin* cls,
+                         const float* src) {
+    FastCarve cv = fast_carve(f, PT_SD_MAX_ITER);
+    if (ws_bytes < cv.total * sizeof(float) || ((uintptr_t)ws % 256) != 0) return PT_ERR_WORKSPACE;
+    float* base = (float*)ws;
+    const int n = f.n, K = f.KH;
+    SdArgs a;
+    sd_fill_params(a, prm, bb, sample_weight, n, f.C, f.H, f.W, K, f.OH, f.OW);
+    a.KS = 8; a.KSPL = f.KSPL;
+    a.label = base + cv.label; a.mask = base + cv.mask; a.sws = base + cv.sws; a.sg = base + cv.sg;
+    a.lms = base + cv.lms;
+    a.spart = base + cv.spart; a.gpart = base + cv.gpart; a.g = base + cv.g; a.anum = base + cv.anum;
+    a.qs = base + cv.qs; a.lossp = base + cv.lossp; a.w_iters = w_iters; a.w0 = w_in; a.w_final = w_final;
+    float* sbuf[2] = {base + cv.s0, base + cv.s1};
+    a.s = sbuf[0];
+    const int slot = cls ? cls->slot : -1;
+    if (cls) {
+        // the inserted sample's scores under w_in ARE the classification scores of the test frame
+        a.cls_spart = a.spart + (long)slot * a.OO; a.cls_KS = 8; a.cls_stride = (long)n * a.OO; a.cls_slot = slot;
+        a.cls_scores = cls->scores; a.cls_peak = cls->peak; a.cls_bb = cls->mem_bb;
+    }
+    const int want_loss = losses != nullptr;
+    const size_t pw_lds = (size_t)a.OO * sizeof(float) * (a.kind == PT_SD_PRDIMP ? 2 : 1);
+    if (copy_w0 && w_iters != w_in) {
+        if (hipMemcpyAsync(w_iters, w_in, (size_t)a.CKK * sizeof(float), hipMemcpyDeviceToDevice, st) != hipSuccess)
+            return PT_ERR_LAUNCH;
+    }
+    if (num_iter == 0 && !want_loss && !cls) return PT_OK;
+
+    float* copy_dst = src ? const_cast<float*>(feat) + (long)slot * stride_n : nullptr;
+    int rc = pt_launch_corr2(f, feat, stride_n, w_in, a.spart, st, nullptr, src ? slot : -1, src, copy_dst);
+    if (rc) return rc;
+    hipLaunchKernelGGL(k_fast_init, dim3(n), dim3(384), 0, st, a);
+    PT_CHECK_LAUNCH();
+    if (num_iter == 0) {
+        if (!want_loss) return PT_OK;
+        a.R = nullptr;
+        hipLaunchKernelGGL(k_sd_pw, dim3(n), dim3(512), pw_lds, st, a, (int)PW_INIT, 0, 1, 1);
+        PT_CHECK_LAUNCH();
+    }
+    for (int t = 0; t < num_iter; ++t) {
+        a.s_in = sbuf[t == 0 ? 0 : (t - 1) & 1];
+        a.s = sbuf[t & 1];
+        rc = pt_launch_adj2_sd(f, feat, stride_n, a, t, want_loss, st);        // alpha_{t-1}, w_t, s_t, residual maps
+        if (rc) return rc;
+        PtCorrFuse fz = {a.gpart, f.KSPL, t == 0 ? w_in : w_iters + (long)t * a.CKK, a.reg, a.g, a.anum, nullptr};
+        rc = pt_launch_corr2(f, feat, stride_n, nullptr, a.spart, st, &fz);    // g_t, |g_t|^2, F g_t
+        if (rc) return rc;
+        hipLaunchKernelGGL(k_sd_pw, dim3(n), dim3(512), pw_lds, st, a, (int)PW_SGQ, t, 0, 0);
+        PT_CHECK_LAUNCH();
+    }
+    if (num_iter > 0) {
+        hipLaunchKernelGGL(k_sd_pw, dim3(n), dim3(512), pw_lds, st, a, (int)PW_UPDATE, num_iter, 1, want_loss);
+        PT_CHECK_LAUNCH();
+    }
+    if (want_loss) {
+        hipLaunchKernelGGL(k_sd_loss, dim3(num_iter + 1), dim3(256), 0, st, a, losses);
+        PT_CHECK_LAUNCH();
+    }
+    return PT_OK;
 }
 
 // Internal entry shared by pt_sd_solve_f32 and pt_track_frame_f32.
@@ -391,7 +336,7 @@ extern "C" size_t pt_sd_ws_bytes(int n, int C, int H, int W, int K) {
 int pt_sd_solve_impl(const pt_sd_params* prm, const float* w_in, const float* feat, long feat_stride_n, const float* bb,
                      const float* sample_weight, int n, int C, int H, int W, int K, int num_iter, float* w_iters,
                      float* losses, void* ws, size_t ws_bytes, hipStream_t st, bool copy_w0, float* w_final,
-                     const PtClsFin* cls) {
+                     const PtClsFin* cls, const float* src) {
     if (!prm || !w_in || !feat || !bb || !w_iters || !ws) return PT_ERR_NULL;
     if (n <= 0 || C <= 0 || H <= 0 || W <= 0 || K <= 0 || num_iter < 0) return PT_ERR_SHAPE;
     if (K * K > 16 || num_iter > PT_SD_MAX_ITER) return PT_ERR_UNSUPPORTED;
@@ -400,6 +345,13 @@ int pt_sd_solve_impl(const pt_sd_params* prm, const float* w_in, const float* fe
         return PT_ERR_NULL;
     if (prm->kind < PT_SD_DIMP || prm->kind > PT_SD_PRDIMP) return PT_ERR_UNSUPPORTED;
     const int OH = H + (K + 1) % 2, OW = W + (K + 1) % 2;               // optimizer.py:105
+    {
+        PtFast f = pt_fast_plan(n, C, H, W, K, K, OH, OW);
+        if (f.ok && ((uintptr_t)feat % 16) == 0 && (feat_stride_n % 4) == 0 && ((uintptr_t)src % 16) == 0)
+            return sd_solve_fast(f, prm, w_in, feat, feat_stride_n, bb, sample_weight, num_iter, w_iters, losses, ws,
+                                 ws_bytes, st, copy_w0, w_final, cls, src);
+    }
+    if (src) return PT_ERR_UNSUPPORTED;                                 // source override exists on the fast path only
     PtPlan p = pt_make_plan(n, C, H, W, K, K, OH, OW);
     if (p.KS > 64) return PT_ERR_UNSUPPORTED;
     SdCarve cv = sd_carve(p, PT_SD_MAX_ITER);
@@ -421,9 +373,10 @@ int pt_sd_solve_impl(const pt_sd_params* prm, const float* w_in, const float* fe
     a.spart = base + cv.spart; a.R = base + cv.R; a.gpart = base + cv.gpart; a.g = base + cv.g;
     a.anum = base + cv.anum; a.qs = base + cv.qs; a.lossp = base + cv.lossp; a.w_iters = w_iters;
     a.w0 = w_in; a.w_final = w_final;
+    a.s_in = nullptr; a.lms = nullptr; a.cls_stride = 0;
     a.cls_spart = nullptr; a.cls_KS = 0; a.cls_slot = -1; a.cls_scores = nullptr; a.cls_peak = nullptr; a.cls_bb = nullptr;
     if (cls) {
-        a.cls_spart = cls->spart; a.cls_KS = cls->KS; a.cls_slot = cls->slot; a.cls_scores = cls->scores;
+        a.cls_spart = cls->spart; a.cls_KS = cls->KS; a.cls_stride = a.OO; a.cls_slot = cls->slot; a.cls_scores = cls->scores;
         a.cls_peak = cls->peak; a.cls_bb = cls->mem_bb;
     }
 
@@ -467,5 +420,6 @@ extern "C" int pt_sd_solve_f32(const pt_sd_params* prm, const float* w_in, const
                                const float* bb, const float* sample_weight, int n, int C, int H, int W, int K,
                                int num_iter, float* w_iters, float* losses, void* ws, size_t ws_bytes, void* stream) {
     return pt_sd_solve_impl(prm, w_in, feat, feat_stride_n, bb, sample_weight, n, C, H, W, K, num_iter, w_iters, losses,
-                            ws, ws_bytes, (hipStream_t)stream, /*copy_w0=*/true, /*w_final=*/nullptr, /*cls=*/nullptr);
+                            ws, ws_bytes, (hipStream_t)stream, /*copy_w0=*/true, /*w_final=*/nullptr, /*cls=*/nullptr,
+                            /*src=*/nullptr);
 }

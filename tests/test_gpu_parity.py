@@ -54,7 +54,13 @@ def test_apply_filter_two_sequences_and_errors():
 
 
 @pytest.mark.parametrize("n,C,H,W,K", [(1, 512, 18, 18, 4), (50, 512, 18, 18, 4), (7, 64, 22, 22, 4),
-                                       (3, 20, 9, 7, 3), (2, 33, 5, 6, 2), (5, 256, 18, 18, 1)])
+                                       (3, 20, 9, 7, 3), (2, 33, 5, 6, 2), (5, 256, 18, 18, 1),
+                                       # XCD-aligned fast path: trailing-quad trick (rem 1 and 4), no remainder,
+                                       # regular partial tile (22x22: rem 9), every channel count, odd/even K
+                                       (3, 128, 18, 18, 4), (5, 256, 22, 22, 4), (2, 128, 10, 8, 4),
+                                       (2, 128, 16, 16, 4), (3, 256, 12, 12, 3), (2, 128, 20, 20, 4),
+                                       (1, 1024, 18, 18, 4), (4, 128, 14, 14, 2), (9, 128, 18, 16, 4),
+                                       (50, 512, 22, 22, 4), (33, 128, 8, 8, 4)])
 def test_filter_ops_vs_oracle(n, C, H, W, K):
     from pytracking_amd import filter as F
     rng = np.random.default_rng(n * 1000 + C)
@@ -197,6 +203,40 @@ def test_sd_zero_iterations_and_single_sample():
     close(its, ref_its, atol=2e-5)
 
 
+@pytest.mark.parametrize("n,C,H,W", [(7, 128, 18, 18), (3, 256, 22, 22), (20, 128, 16, 16), (2, 128, 10, 8)])
+def test_sd_fast_path_shapes_vs_oracle(n, C, H, W):
+    """XCD-aligned solver path (C in {128,256,512,1024}, H*W % 4 == 0) against the float64 oracle: DiMP, DiMP-L2, PrDiMP."""
+    from pytracking_amd import optimizer
+    w0, feat, bb, sw = synth.dimp_problem(100 + n, n, small=dict(C=C, H=H, W=W))
+    f64 = lambda a: None if a is None else a.astype(np.float64)
+    for weights in (sw, None):
+        ref_its, ref_l = O.dimp_sd(f64(w0), f64(feat), f64(bb), f64(weights), num_iter=4, step_length=0.9, filter_reg=0.1,
+                                   min_filter_reg=1e-3, feat_stride=16, label_w=synth.gauss_lut(100, 0.1, 0.9),
+                                   mask_w=synth.mask_lut(100, 0.1, 3.0), spatial_w=np.ones(100, np.float32),
+                                   bin_displacement=0.1)
+        its, losses = _run(_dimp_module(), w0, feat, bb, weights, 4)
+        close(its, ref_its, atol=2e-5)
+        close(losses, np.array(ref_l), atol=2e-5, rtol=1e-4)
+    its0, l0 = _run(_dimp_module(), w0, feat, bb, sw, 0)
+    close(l0[0], ref_l[0] if False else O.dimp_sd(f64(w0), f64(feat), f64(bb), f64(sw), num_iter=0, step_length=0.9,
+          filter_reg=0.1, min_filter_reg=1e-3, feat_stride=16, label_w=synth.gauss_lut(100, 0.1, 0.9),
+          mask_w=synth.mask_lut(100, 0.1, 3.0), spatial_w=np.ones(100, np.float32), bin_displacement=0.1)[1][0],
+          atol=2e-5, rtol=1e-4)
+    ref_its, ref_l = O.prdimp_sd(f64(w0) * 0, f64(feat), f64(bb), f64(sw), num_iter=4, step_length=1.0, filter_reg=0.05,
+                                 min_filter_reg=0.05, feat_stride=16, gauss_sigma=0.9, alpha_eps=0.05,
+                                 normalize_label=True, softmax_reg_val=0.1)
+    its, losses = _run(_prdimp_module(softmax_reg=0.1), w0 * 0, feat, bb, sw, 4)
+    close(its, ref_its, atol=2e-5)
+    close(losses, np.array(ref_l), atol=2e-5, rtol=1e-4)
+    ref_its, ref_l = O.dimp_l2_sd(f64(w0), f64(feat), f64(bb), f64(sw), num_iter=3, step_length=1.0, filter_reg=0.1,
+                                  min_filter_reg=1e-3, feat_stride=16, gauss_sigma=1.0, hinge_threshold=0.05)
+    mod = optimizer.DiMPL2SteepestDescentGN(num_iter=3, feat_stride=16, init_step_length=1.0, gauss_sigma=1.0,
+                                            hinge_threshold=0.05, init_filter_reg=0.1, min_filter_reg=1e-3).to(DEV).eval()
+    its, losses = _run(mod, w0, feat, bb, sw, 3)
+    close(its, ref_its, atol=2e-5)
+    close(losses, np.array(ref_l), atol=2e-5, rtol=1e-4)
+
+
 # ------------------------------------------------------------------------------------------------------
 # ATOM conjugate gradient
 # ------------------------------------------------------------------------------------------------------
@@ -293,11 +333,11 @@ def test_prroi_consumers_golden():
 # ------------------------------------------------------------------------------------------------------
 # benchmark frame (C ABI pt_track_frame_f32) against a composition of the oracle pieces
 # ------------------------------------------------------------------------------------------------------
-def test_track_frame_matches_oracle_composition():
+@pytest.mark.parametrize("C,n", [(32, 6), (128, 6), (512, 9)])
+def test_track_frame_matches_oracle_composition(C, n):
     from pytracking_amd import bench_frame
     from oracle import frame_port
-    cfg = dict(synth.DIMP50, C=32, H=18, W=18)
-    n = 6
+    cfg = dict(synth.DIMP50, C=C, H=18, W=18)
     st = bench_frame.TrackState(cfg, n, seed=77, device=DEV)
     rng = np.random.default_rng(78)
     x = synth.clf_features(rng, 1, cfg["C"], cfg["H"], cfg["W"], cfg["K"])
