@@ -6,6 +6,7 @@
 #include <vector>
 #include <algorithm>
 #include <hip/hip_runtime.h>
+#define PT_EXPERIMENT 1
 #include "../pytracking_amd/csrc/fast_passes.hip"
 
 void pt_prof_begin(int, hipStream_t) {}
@@ -28,16 +29,16 @@ float time_it(const char* name, F f, int reps = 300, double bytes = 0) {
 }
 
 int main(int argc, char** argv) {
-    const int n = 50, C = 512, H = argc > 1 ? atoi(argv[1]) : 18, W = H, K = 4, OH = H + 1, OW = W + 1;
+    const int n = argc > 2 ? atoi(argv[2]) : 50, C = 512, H = argc > 1 ? atoi(argv[1]) : 18, W = H, K = 4, OH = H + 1, OW = W + 1;
     const size_t nfeat = (size_t)n * C * H * W;
     PtFast f = pt_fast_plan(n, C, H, W, K, K, OH, OW);
-    printf("fast ok=%d tiles=%d left=%d NK=%d corr_lds=%zu | KSPL=%d gper=%d U=%d ns_max=%d adj_lds=%zu E=%d\n", f.ok, f.tiles, f.left, f.NK, f.corr_lds, f.KSPL, f.gper, f.U, f.ns_max, f.adj_lds, f.E);
+    printf("n=%d ", n); printf("fast ok=%d tiles=%d left=%d NK=%d corr_lds=%zu | KSPL=%d gper=%d U=%d ns_max=%d adj_lds=%zu E=%d\n", f.ok, f.tiles, f.left, f.NK, f.corr_lds, f.KSPL, f.gper, f.U, f.ns_max, f.adj_lds, f.E);
     float *feat, *filt, *spart, *gpart, *w, *g, *anum, *maps;
     hipMalloc(&feat, nfeat * 4); hipMalloc(&filt, C * 16 * 4); hipMalloc(&w, C * 16 * 4 * 8); hipMalloc(&g, C * 16 * 4);
     hipMalloc(&spart, pt_fast_spart_floats(f) * 4); hipMalloc(&gpart, pt_fast_gpart_floats(f) * 4); hipMalloc(&anum, 4096);
     const size_t nOO = (size_t)n * OH * OW;
-    hipMalloc(&maps, nOO * 4 * 12);
-    hipMemset(maps, 0, nOO * 4 * 12);
+    hipMalloc(&maps, nOO * 4 * 16);
+    hipMemset(maps, 0, nOO * 4 * 16);
     std::vector<float> h(nfeat);
     for (size_t i = 0; i < nfeat; ++i) h[i] = (float)((i * 2654435761u) % 1000) * 1e-3f - 0.5f;
     hipMemcpy(feat, h.data(), nfeat * 4, hipMemcpyHostToDevice);
@@ -47,7 +48,7 @@ int main(int argc, char** argv) {
     SdArgs sd = SdArgs();
     sd.n = n; sd.C = C; sd.H = H; sd.W = W; sd.K = K; sd.OH = OH; sd.OW = OW; sd.OO = OH * OW; sd.CKK = C * 16; sd.KS = 8; sd.KSPL = f.KSPL;
     sd.kind = PT_SD_DIMP; sd.score_act = PT_ACT_RELU; sd.step = 0.9f; sd.reg = 0.01f;
-    sd.label = maps; sd.mask = maps + nOO; sd.sws = maps + 2 * nOO; sd.s = maps + 3 * nOO; sd.s_in = maps + 4 * nOO; sd.sg = maps + 5 * nOO; sd.lms = maps + 6 * nOO;
+    sd.label = maps; sd.mask = maps + nOO; sd.sws = maps + 2 * nOO; sd.s = maps + 3 * nOO; sd.s_in = maps + 4 * nOO; sd.sg = maps + 5 * nOO; sd.lms = maps + 6 * nOO; sd.pk = maps + 10 * nOO;
     sd.gpart = gpart; sd.g = g; sd.anum = anum; sd.qs = anum + 64; sd.lossp = anum + 256; sd.w_iters = w; sd.w0 = w;
     time_it("corr2 plain", [&] { pt_launch_corr2(f, feat, sn, filt, spart, 0); }, 300, B);
     PtCorrFuse fz = {gpart, f.KSPL, w, 0.01f, g, anum, nullptr};

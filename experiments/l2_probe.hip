@@ -3,6 +3,7 @@
 // (per-XCD L2 = 4 MiB, block b runs on XCD b % 8) and on the workgroup geometry?
 //   hipcc --offload-arch=gfx950 -O3 -std=c++17 experiments/l2_probe.hip -o experiments/l2_probe && ./experiments/l2_probe
 #include <cstdio>
+#include <cstdlib>
 #include <string>
 #include <vector>
 #include <hip/hip_runtime.h>
@@ -29,6 +30,24 @@ __global__ void k_read_xcd(const f32x4* __restrict__ p, size_t per_xcd, int rot,
         }
 #pragma unroll
         for (int u = 0; u < UN; ++u) acc += v[u];
+    }
+    if (acc[0] + acc[1] + acc[2] + acc[3] == 123.456f) out[blockIdx.x] = acc[0];
+}
+
+// strided ownership, as k_corr2/k_adj2 use it: XCD x owns the x-th eighth of EVERY sample (n samples of `svec` vectors)
+__global__ void k_read_xcd_strided(const f32x4* __restrict__ p, int n, size_t svec, int rot, float* out) {
+    const int b = blockIdx.x, xcd = (b + rot) & 7, idx = b >> 3, per = gridDim.x >> 3;
+    const size_t eighth = svec / 8;
+    f32x4 acc = {0, 0, 0, 0};
+    for (int i = idx; i < n; i += per) {
+        const f32x4* q = p + (size_t)i * svec + (size_t)xcd * eighth;
+        for (size_t e = threadIdx.x; e < eighth; e += 8 * blockDim.x) {
+            f32x4 v[8];
+#pragma unroll
+            for (int u = 0; u < 8; ++u) { size_t k = e + (size_t)u * blockDim.x; v[u] = q[k < eighth ? k : 0]; }
+#pragma unroll
+            for (int u = 0; u < 8; ++u) acc += v[u];
+        }
     }
     if (acc[0] + acc[1] + acc[2] + acc[3] == 123.456f) out[blockIdx.x] = acc[0];
 }
@@ -73,6 +92,16 @@ int main() {
     time_it("tiny dependent kernel (50 WG x 64)", [&](int) { hipLaunchKernelGGL(k_tiny, dim3(50), dim3(64), 0, 0, out, out + 4096); });
     time_it("tiny dependent kernel (1 WG x 64)", [&](int) { hipLaunchKernelGGL(k_tiny, dim3(1), dim3(64), 0, 0, out, out + 4096); });
 
+    {
+        const size_t svec = (size_t)512 * 324 / 4;
+        const double B = 50.0 * svec * 16.0;
+        time_it("STRIDED ownership aligned, 400 WGs x 512", [&](int) { hipLaunchKernelGGL(k_read_xcd_strided, dim3(400), dim3(512), 0, 0, (const f32x4*)feat, 50, svec, 0, out); }, 200, B);
+        time_it("STRIDED ownership rotating, 400 WGs x 512", [&](int k) { hipLaunchKernelGGL(k_read_xcd_strided, dim3(400), dim3(512), 0, 0, (const f32x4*)feat, 50, svec, k % 8, out); }, 200, B);
+        const size_t nvec = full / 4, per_xcd = nvec / 8;
+        time_it("CONTIG  ownership aligned, 512 WGs x 256", [&](int) { hipLaunchKernelGGL(k_read_xcd<8>, dim3(512), dim3(256), 0, 0, (const f32x4*)feat, per_xcd, 0, 0, out); }, 200, B);
+        time_it("CONTIG  ownership rotating, 512 WGs x 256", [&](int k) { hipLaunchKernelGGL(k_read_xcd<8>, dim3(512), dim3(256), 0, 0, (const f32x4*)feat, per_xcd, k % 8, 0, out); }, 200, B);
+        if (getenv("L2_PROBE_SHORT")) return 0;
+    }
     for (double frac : {1.0, 0.9, 0.75, 0.5, 2.0}) {
         const size_t nvec = (size_t)(full * frac) / 4 / 8 * 8;
         const size_t per_xcd = nvec / 8;

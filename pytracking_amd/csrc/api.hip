@@ -48,7 +48,7 @@ extern "C" int pt_apply_filter_f32(const float* feat, long feat_stride_n, const 
     hipStream_t st = (hipStream_t)stream;
     float* spart = (float*)ws;
     PtFast f = pt_fast_plan(n, C, H, W, KH, KW, OH, OW);
-    if (f.ok && ((uintptr_t)feat % 16) == 0 && (feat_stride_n % 4) == 0) {
+    if (f.ok && ((uintptr_t)feat % 16) == 0 && (feat_stride_n % 4) == 0 && (long)n * feat_stride_n * 4 < (1L << 31)) {
         rc = pt_launch_corr2(f, feat, feat_stride_n, filt, spart, st);
         if (rc) return rc;
         return pt_launch_sum_slices(spart, scores, 8, (size_t)n * f.OO, st);
@@ -88,7 +88,7 @@ extern "C" int pt_feat_transpose_f32(const float* feat, long feat_stride_n, cons
         return PT_ERR_WORKSPACE;
     hipStream_t st = (hipStream_t)stream;
     PtFast f = pt_fast_plan(n, C, H, W, KH, KW, OH, OW);
-    if (f.ok && ((uintptr_t)feat % 16) == 0 && (feat_stride_n % 4) == 0) {
+    if (f.ok && ((uintptr_t)feat % 16) == 0 && (feat_stride_n % 4) == 0 && (long)n * feat_stride_n * 4 < (1L << 31)) {
         float* gp = (float*)ws;
         rc = pt_launch_adj2_plain(f, feat, feat_stride_n, inp, gp, st);
         if (rc) return rc;

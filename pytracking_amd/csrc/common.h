@@ -6,7 +6,21 @@
 typedef float f32x4 __attribute__((ext_vector_type(4)));
 typedef float f32x2 __attribute__((ext_vector_type(2)));
 
+typedef unsigned int u32x4 __attribute__((ext_vector_type(4)));
+
 #define PT_WAVE 64
+
+// Raw buffer loads: 32-bit byte offsets from one wave-uniform resource descriptor (cheaper address arithmetic than
+// 64-bit flat pointers; out-of-range offsets return 0 instead of faulting).
+__device__ __forceinline__ __amdgpu_buffer_rsrc_t pt_rsrc(const void* base, unsigned bytes) {
+    return __builtin_amdgcn_make_buffer_rsrc(const_cast<void*>(base), 0, bytes, 0x00020000);
+}
+__device__ __forceinline__ f32x4 pt_bload4(__amdgpu_buffer_rsrc_t r, unsigned byte_off) {
+    return __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(r, byte_off, 0, 0));
+}
+__device__ __forceinline__ float pt_bload1(__amdgpu_buffer_rsrc_t r, unsigned byte_off) {
+    return __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(r, byte_off, 0, 0));
+}
 
 // D(16x16) += A(16x4) * B(4x16), exact f32 (fmaf chain in k order).
 // lane l supplies A[i = l&15][k = l>>4] and B[k = l>>4][j = l&15]; holds D[4*(l>>4)+r][l&15], r=0..3.

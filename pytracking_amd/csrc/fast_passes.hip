@@ -16,6 +16,7 @@
 //             wave w owns U contiguous 16-position groups.  G[c][tap] = sum_P feat[c][P] * r[P shifted by tap]; the B
 //             operand is gathered from zero-padded residual maps the workgroup builds in LDS -- there is no im2col
 //             buffer in HBM.  In the solver the maps come from the fused update prologue (alpha, s_{t}, residual).
+#include <stdlib.h>
 #include "common.h"
 #include "pt_internal.h"
 #include "sd_common.h"
@@ -41,6 +42,7 @@ PtFast pt_fast_plan(int n, int C, int H, int W, int KH, int KW, int OH, int OW) 
     if ((p.HW % 4) != 0 || W < 4 || p.KK > 16) return p;
     if (C != 128 && C != 256 && C != 512 && C != 1024) return p;
     if ((long)n * p.HW >= (1L << 20)) return p;
+    if ((long)n * C * p.HW * 4 >= (1L << 31)) return p;             // 32-bit byte offsets of the raw buffer loads
     p.Q = p.HW / 4;
     p.TF = p.Q / 16;
     p.rem = p.Q % 16;
@@ -113,9 +115,9 @@ __device__ __forceinline__ float corr2_filter_elem(const Corr2Args& a, int KK, i
 
 // FUSE = 0: filter operand read from `filt`.  FUSE = 8 / 16 / 32: operand = sum of <= FUSE gradient partials + reg*w
 // (optimizer.py:146-148), every load of the reduction issued before the first wait.
-// Two workgroups (<= 20 waves) per CU need <= 96 VGPRs: 5 waves per SIMD for the common channel counts.
+// Two 10-wave workgroups per CU put up to 6 waves on one SIMD (3+3): <= 80 VGPRs for the common channel counts.
 template <int NK, bool LEFT, int FUSE>
-__global__ __launch_bounds__(1024, (NK <= 8 ? 5 : 4)) void k_corr2(Corr2Args a) {
+__global__ __launch_bounds__(1024, (NK <= 8 ? 6 : 4)) void k_corr2(Corr2Args a) {
     extern __shared__ __attribute__((aligned(16))) float lds[];     // afilt[CX][16] | T[2][KK][HWp]
     __shared__ float scratch[16];
     constexpr int EPT = 2;
@@ -172,22 +174,26 @@ __global__ __launch_bounds__(1024, (NK <= 8 ? 5 : 4)) void k_corr2(Corr2Args a) 
         }
     }
 
-    // ---- this wave's whole feature slice in flight: NK float4 (+ NK scalars for the trailing quads)
+    // ---- feature slice of this wave: NK float4 (+ NK scalars for the trailing quads).  A wave stalls at a load it
+    //      cannot issue (the CU accepts ~45 B/clk), so only the first CD k-steps are requested before the filter is
+    //      staged; the rest are issued CD k-steps ahead of the MFMAs that consume them.
+    constexpr int CD = NK < 4 ? NK : 4;
     const int cbase = cx0 + 4 * (h * NK) + kq;
     const int pos = 64 * t + 4 * j;
     const bool pv = pos < HW;
-    const float* __restrict__ fp = fi + (pv ? pos : 0) + (long)cbase * HW;
-    f32x4 bq[NK];
-#pragma unroll
-    for (int k = 0; k < NK; ++k) bq[k] = *(const f32x4*)(fp + (long)(4 * k) * HW);
-    float bl[NK];
+    const __amdgpu_buffer_rsrc_t fr = pt_rsrc(fi, (unsigned)a.C * HW * 4u);
+    const unsigned fo = ((unsigned)cbase * HW + (pv ? pos : 0)) * 4u;
     const int lpos = 64 * a.TF + j;
     const bool lv = LEFT && t == 0 && j < 4 * a.rem;
-    if (LEFT && t == 0) {
-        const float* __restrict__ lp = fi + (lv ? lpos : 0) + (long)cbase * HW;
+    const unsigned lo = ((unsigned)cbase * HW + (lv ? lpos : 0)) * 4u;
+    f32x4 bq[NK];
+    float bl[NK];
+    auto ldq = [&](int k) {
+        bq[k] = pt_bload4(fr, fo + (unsigned)(4 * k) * HW * 4u);
+        if (LEFT && t == 0) bl[k] = pt_bload1(fr, lo + (unsigned)(4 * k) * HW * 4u);
+    };
 #pragma unroll
-        for (int k = 0; k < NK; ++k) bl[k] = lp[(long)(4 * k) * HW];
-    }
+    for (int k = 0; k < CD; ++k) ldq(k);
 
     PT_STAMP(1);
     // ---- reduce + publish the filter slice
@@ -239,6 +245,18 @@ __global__ __launch_bounds__(1024, (NK <= 8 ? 5 : 4)) void k_corr2(Corr2Args a) 
     __syncthreads();
     PT_STAMP(2);
 
+    f32x4 acc0 = {0, 0, 0, 0}, acc1 = {0, 0, 0, 0}, acc2 = {0, 0, 0, 0}, acc3 = {0, 0, 0, 0}, accL = {0, 0, 0, 0};
+#pragma unroll
+    for (int k = 0; k < NK; ++k) {
+        if (k + CD < NK) ldq(k + CD);
+        const float av = afilt[(4 * (h * NK + k) + kq) * 16 + j];
+        if (PT_ABL & 1) { acc0 += av * bq[k]; continue; }
+        acc0 = mfma16(av, bq[k][0], acc0);
+        acc1 = mfma16(av, bq[k][1], acc1);
+        acc2 = mfma16(av, bq[k][2], acc2);
+        acc3 = mfma16(av, bq[k][3], acc3);
+        if (LEFT && t == 0) accL = mfma16(av, lv ? bl[k] : 0.f, accL);
+    }
     // ---- memory insert rides on the pass (pytracking/tracker/dimp/dimp.py:429-441)
     if (over && a.copy_dst) {
         float* __restrict__ dp = a.copy_dst + pos + (long)cbase * HW;
@@ -253,17 +271,6 @@ __global__ __launch_bounds__(1024, (NK <= 8 ? 5 : 4)) void k_corr2(Corr2Args a) 
         }
     }
 
-    f32x4 acc0 = {0, 0, 0, 0}, acc1 = {0, 0, 0, 0}, acc2 = {0, 0, 0, 0}, acc3 = {0, 0, 0, 0}, accL = {0, 0, 0, 0};
-#pragma unroll
-    for (int k = 0; k < NK; ++k) {
-        const float av = afilt[(4 * (h * NK + k) + kq) * 16 + j];
-        if (PT_ABL & 1) { acc0 += av * bq[k]; continue; }
-        acc0 = mfma16(av, bq[k][0], acc0);
-        acc1 = mfma16(av, bq[k][1], acc1);
-        acc2 = mfma16(av, bq[k][2], acc2);
-        acc3 = mfma16(av, bq[k][3], acc3);
-        if (LEFT && t == 0) accL = mfma16(av, lv ? bl[k] : 0.f, accL);
-    }
     PT_STAMP(3);
 #pragma unroll
     for (int r = 0; r < 4; ++r) {
@@ -336,6 +343,7 @@ int pt_launch_corr2(const PtFast& p, const float* feat, long stride_n, const flo
     if (fuse) { a.gpart = fuse->gpart; a.KSPL = fuse->KSPL; a.w = fuse->w; a.reg = fuse->reg; a.g_out = fuse->g_out; a.anum_part = fuse->anum_part; }
     a.slot = slot; a.src = src; a.copy_dst = copy_dst;
     if (((uintptr_t)feat % 16) || (stride_n % 4) || ((uintptr_t)src % 16) || ((uintptr_t)copy_dst % 16)) return PT_ERR_UNSUPPORTED;
+    if ((long)p.n * stride_n * 4 >= (1L << 31)) return PT_ERR_UNSUPPORTED;
     if (p.KK == 16 && (((uintptr_t)filt % 16) || ((uintptr_t)a.gpart % 16) || ((uintptr_t)a.w % 16) || ((uintptr_t)a.g_out % 16)))
         return PT_ERR_UNSUPPORTED;
     dim3 grid(8 * p.n), block(p.corr_threads);
@@ -376,12 +384,16 @@ struct Adj2Args {
 // residual-map providers of k_adj2
 enum { V_PLAIN = 0, V_DIMP_RELU = 1, V_DIMP_BENT = 2, V_L2 = 3, V_PRDIMP = 4 };
 
-// per-lane inputs of the update stage for one sample: E strided elements per lane
+// per-lane inputs of the update stage for one sample: E strided elements per lane.
+//   pk : packed by k_fast_init / k_fast_sgq, ONE 16-byte load per element:
+//          DiMP relu / L2 : {sws^2 * s, sws^2 * (F g), sws^2 * label, mask}
+//          DiMP bentpar   : {s, F g, label, mask}  (+ sw)          PrDiMP : {s, F g, label, -}
+//   s, sg, lab, msk, sw : raw maps, only loaded by the waves that own the sample (s_t store, loss)
 template <int E>
-struct PReg { float s[E], sg[E], lab[E], msk[E], sw[E]; };
+struct PReg { f32x4 pk[E]; float s[E], sg[E], lab[E], msk[E], sw[E]; };
 
 template <int V, int E>
-__device__ __forceinline__ void sdp_load(const Adj2Args& a, int i, int lane, PReg<E>& r) {
+__device__ __forceinline__ void sdp_load(const Adj2Args& a, int i, int lane, bool home, PReg<E>& r) {
     const int OO = a.OH * a.OW;
     const long base = (long)i * OO;
     // t == 0: there is no F g yet; astep is 0 and any finite operand does
@@ -392,15 +404,21 @@ __device__ __forceinline__ void sdp_load(const Adj2Args& a, int i, int lane, PRe
         if (V == V_PLAIN) {
             r.s[e] = a.inp[q];
         } else {
+            r.pk[e] = ((const f32x4*)a.sd.pk)[q];
+            if (V == V_DIMP_BENT) r.sw[e] = a.sd.sws[q];
+        }
+    }
+    if (V != V_PLAIN && home) {                                     // uniform per wave
+#pragma unroll
+        for (int e = 0; e < E; ++e) {
+            const long q = base + min(lane + 64 * e, OO - 1);
             r.s[e] = a.sd.s_in[q];
             r.sg[e] = sgp[q];
-            if (V != V_PRDIMP) {
-                const f32x4 lm = ((const f32x4*)a.sd.lms)[q];        // {label, mask, sws, -} packed by k_fast_init
+            if (V != V_PRDIMP && a.want_loss) {
+                const f32x4 lm = ((const f32x4*)a.sd.lms)[q];        // {label, mask, sws, -}
                 r.lab[e] = lm[0];
                 r.msk[e] = lm[1];
                 r.sw[e] = lm[2];
-            } else {
-                r.lab[e] = a.sd.label[q];
             }
         }
     }
@@ -416,39 +434,37 @@ __device__ __forceinline__ void sdp_compute(const Adj2Args& a, int i, int lane, 
     const int OO = a.OH * a.OW;
     const long base = (long)i * OO;
     const float inv_ow = 1.0f / (float)a.OW;
-    float sv[E], val[E], aux[E];
+    float val[E], aux[E];
     float lacc = 0.f;
     if (V == V_PLAIN) {
 #pragma unroll
         for (int e = 0; e < E; ++e) val[e] = r.s[e];
-    } else if (V != V_PRDIMP) {
+    } else if (V == V_DIMP_RELU || V == V_L2) {
+        // With u = sws^2 * s_t the residual map entry  der * sws * (sws * (act - label))  of optimizer.py:140,146 is
+        //   s_t > 0 : u - a3        s_t < 0 : m * (m*u - a3)        s_t == 0 : der0 * (0 - a3),   a3 = sws^2 * label,
+        // der0 = (1+m)/2 for LeakyReluPar (sign(0) = 0, activation.py:43-44), m for the L2 hinge (optimizer.py:262-263).
 #pragma unroll
         for (int e = 0; e < E; ++e) {
-            sv[e] = r.s[e] - astep * r.sg[e];
-            float act, der;
-            const float x = sv[e], am = r.msk[e];
-            if (V == V_DIMP_RELU) {                                                 // activation.py:32-46
-                const float sgn = (x > 0.f) ? 1.f : ((x < 0.f) ? -1.f : 0.f);
-                act = (1.0f - am) * 0.5f * fabsf(x) + (1.0f + am) * 0.5f * x;
-                der = (1.0f - am) * 0.5f * sgn + (1.0f + am) * 0.5f;
-            } else if (V == V_DIMP_BENT) {                                          // activation.py:49-66
-                const float bp = sd.act_param, rt = sqrtf(x * x + 4.0f * bp * bp);
-                act = (1.0f - am) * 0.5f * (rt - 2.0f * bp) + (1.0f + am) * 0.5f * x;
-                der = (1.0f - am) * 0.5f * (x / rt) + (1.0f + am) * 0.5f;
-            } else {                                                                // optimizer.py:262-263
-                act = am * x + (1.0f - am) * fmaxf(x, 0.f);
-                der = am + (1.0f - am) * (x > 0.f ? 1.f : 0.f);
-            }
-            const float rr = r.sw[e] * (act - r.lab[e]);                            // :140
-            lacc += (lane + 64 * e < OO) ? rr * rr : 0.f;
-            val[e] = der * (r.sw[e] * rr);                                          // :146
+            const float u = r.pk[e][0] - astep * r.pk[e][1], a3 = r.pk[e][2], m = r.pk[e][3];
+            const float d0 = V == V_DIMP_RELU ? (1.0f + m) * 0.5f : m;
+            val[e] = u > 0.f ? u - a3 : (u < 0.f ? m * (m * u - a3) : d0 * (0.f - a3));
+        }
+    } else if (V == V_DIMP_BENT) {                                  // activation.py:49-66
+#pragma unroll
+        for (int e = 0; e < E; ++e) {
+            const float x = r.pk[e][0] - astep * r.pk[e][1], L = r.pk[e][2], am = r.pk[e][3];
+            const float bp = sd.act_param, rt = sqrtf(x * x + 4.0f * bp * bp);
+            const float act = (1.0f - am) * 0.5f * (rt - 2.0f * bp) + (1.0f + am) * 0.5f * x;
+            const float der = (1.0f - am) * 0.5f * (x / rt) + (1.0f + am) * 0.5f;
+            val[e] = der * (r.sw[e] * (r.sw[e] * (act - L)));
         }
     } else {
         const float swp = sd.has_sw ? sd.sw[i] : 1.0f / (float)sd.n;                // :387-390
+        float sv[E];
         float mx = sd.has_softmax_reg ? sd.softmax_reg : -INFINITY;
 #pragma unroll
         for (int e = 0; e < E; ++e) {
-            sv[e] = r.s[e] - astep * r.sg[e];
+            sv[e] = r.pk[e][0] - astep * r.pk[e][1];
             if (lane + 64 * e < OO) mx = fmaxf(mx, sv[e]);
         }
         mx = wave_max(mx);
@@ -458,7 +474,7 @@ __device__ __forceinline__ void sdp_compute(const Adj2Args& a, int i, int lane, 
             const bool ok = lane + 64 * e < OO;
             aux[e] = ok ? expf(sv[e] - mx) : 0.f;
             es += aux[e];
-            ls += ok ? r.lab[e] * sv[e] : 0.f;
+            ls += ok ? r.pk[e][2] * sv[e] : 0.f;
         }
         es = wave_sum(es);
         ls = wave_sum(ls);
@@ -467,7 +483,7 @@ __device__ __forceinline__ void sdp_compute(const Adj2Args& a, int i, int lane, 
 #pragma unroll
         for (int e = 0; e < E; ++e) {
             aux[e] *= inv;                                                          // softmax P
-            val[e] = swp * (aux[e] - r.lab[e]);                                     // :408
+            val[e] = swp * (aux[e] - r.pk[e][2]);                                   // :408
         }
         lacc = swp * (logf(es) + mx - ls);                                          // :393-396 (same in every lane)
     }
@@ -479,18 +495,28 @@ __device__ __forceinline__ void sdp_compute(const Adj2Args& a, int i, int lane, 
             map[(y + oy) * a.PW + x + ox] = val[e];
         }
     }
-    if (V != V_PLAIN && home) {
+    if (V != V_PLAIN && home) {                                     // uniform per wave
 #pragma unroll
         for (int e = 0; e < E; ++e) {
             const int o = lane + 64 * e;
             if (o < OO) {
-                if (a.t > 0) sd.s[base + o] = sv[e];
+                if (a.t > 0) sd.s[base + o] = r.s[e] - astep * r.sg[e];
                 if (V == V_PRDIMP) sd.mask[base + o] = aux[e];
             }
         }
         if (a.want_loss) {
-            const float tot = V == V_PRDIMP ? lacc : wave_sum(lacc);
-            if (lane == 0) sd.lossp[(long)a.t * sd.n + i] = tot;
+            if (V != V_PRDIMP) {                                    // sum_o (sws*(act - label))^2 from the raw maps (:140-143)
+                const int sact = V == V_L2 ? 2 : (V == V_DIMP_BENT ? PT_ACT_BENTPAR : PT_ACT_RELU);
+#pragma unroll
+                for (int e = 0; e < E; ++e) {
+                    float act, der;
+                    act_pair(sact, sd.act_param, r.s[e] - astep * r.sg[e], r.msk[e], act, der);
+                    const float rr = r.sw[e] * (act - r.lab[e]);
+                    lacc += (lane + 64 * e < OO) ? rr * rr : 0.f;
+                }
+                lacc = wave_sum(lacc);
+            }
+            if (lane == 0) sd.lossp[(long)a.t * sd.n + i] = lacc;
         }
     }
 }
@@ -519,76 +545,70 @@ __global__ __launch_bounds__(512) void k_adj2(Adj2Args a) {
     for (int e = threadIdx.x; e < ns * PHPW; e += blockDim.x) maps[e] = 0.f;
     if (threadIdx.x < 16) maps[ZB + threadIdx.x] = 0.f;
 
-    // ---- update-stage inputs first (they return first) ...
+    // ---- update stage first: its inputs are small and L2/MALL resident, and the MFMA chain cannot start before the
+    //      residual maps exist; the A operand is streamed afterwards so that its loads overlap the MFMAs.
     PReg<E> pr;
     const bool have = wave < ns;
-    sdp_load<V, E>(a, i_lo + min(wave, ns - 1), lane, pr);
-    float q_in = 0.f, an_in = 0.f;                                  // alpha_{t-1} inputs; reduced after the A loads are issued
-    float w_prev = 0.f, g_prev = 0.f;                               // this thread's element of the filter update
+    const int hg0 = ((i_lo + wave) * HW) >> 4;                      // the slice holding a sample's first group owns it
+    const bool home0 = have && cb == 0 && hg0 >= gbeg && hg0 < gend;
+    sdp_load<V, E>(a, i_lo + min(wave, ns - 1), lane, home0, pr);
+    float astep = 0.f;
     const bool wupd = V != V_PLAIN && a.t > 0 && ks == 0;
     const long wge = (long)cb * 16 * KK + min((int)threadIdx.x, 16 * KK - 1);
-    if (V != V_PLAIN && a.t > 0) {
+    if (V != V_PLAIN && a.t > 0) {                                  // optimizer.py:155-160 / :425-430
+        float q_in = 0.f, w_prev = 0.f, g_prev = 0.f;
         for (int k = lane; k < a.sd.n; k += 64) q_in += a.sd.qs[k];
-        an_in = lane < a.sd.KS ? a.sd.anum[lane] : 0.f;
+        const float an_in = lane < a.sd.KS ? a.sd.anum[lane] : 0.f;
         if (wupd) {                                                 // uniform per workgroup
             w_prev = sd_w(a.sd, a.t - 1)[wge];
             g_prev = a.sd.g[wge];
         }
-    }
-    // ---- ... then the A operand: the U contiguous 16-position groups of this wave, all in flight
-    const int c = cb * 16 + j;
-    const float* __restrict__ fc = a.feat + (long)c * HW;
-    const int g0 = gbeg + wave * a.U;
-    f32x4 av[16];
-    int il[16], p0[16];
-#pragma unroll
-    for (int u = 0; u < 16; ++u) {
-        const int g = g0 + u;
-        const int P0 = 16 * g + 4 * kq;
-        const bool okk = u < a.U && g < gend && P0 < total;
-        const int Pc = okk ? P0 : 16 * g0 + 4 * kq < total ? 16 * g0 + 4 * kq : 0;   // masked groups re-read a line already fetched
-        const int i = fdiv(Pc, inv_hw);
-        il[u] = okk ? i - i_lo : -1;
-        p0[u] = Pc - i * HW;
-        av[u] = *(const f32x4*)(fc + (long)i * a.stride_n + p0[u]);
-    }
-
-    PT_STAMP(1);
-    float astep = 0.f;
-    if (V != V_PLAIN && a.t > 0) {                                  // optimizer.py:155-160 / :425-430
         const float a_num = wave_sum(an_in);
         const float den = fmaxf(wave_sum(q_in) + (a.sd.reg + a.sd.alpha_eps) * a_num, 1e-8f);
         astep = a.sd.step * (a_num / den);
+        if (wupd && (int)threadIdx.x < 16 * KK)                     // w_t = w_{t-1} - step*alpha*g   (:160)
+            a.sd.w_iters[(long)a.t * a.sd.CKK + wge] = w_prev - astep * g_prev;
     }
+    PT_STAMP(1);
     __syncthreads();                                                // maps zeroed
     PT_STAMP(2);
-    {
-        const int i = i_lo + wave;
-        const int hg = (i * HW) >> 4;                               // the slice holding the sample's first group owns it
-        const bool home = cb == 0 && hg >= gbeg && hg < gend;
-        if (have && !(PT_ABL & 16)) sdp_compute<V, E>(a, i, lane, pr, astep, maps + wave * PHPW, oy, ox, home);
-    }
+    if (have && !(PT_ABL & 16)) sdp_compute<V, E>(a, i_lo + wave, lane, pr, astep, maps + wave * PHPW, oy, ox, home0);
     for (int sl = wave + 8; sl < ns; sl += 8) {                     // more samples than waves (tiny maps)
         const int i = i_lo + sl;
         const int hg = (i * HW) >> 4;
         const bool home = cb == 0 && hg >= gbeg && hg < gend;
-        sdp_load<V, E>(a, i, lane, pr);
+        sdp_load<V, E>(a, i, lane, home, pr);
         sdp_compute<V, E>(a, i, lane, pr, astep, maps + sl * PHPW, oy, ox, home);
     }
-    if (wupd && (int)threadIdx.x < 16 * KK)                         // w_t = w_{t-1} - step*alpha*g   (:160)
-        a.sd.w_iters[(long)a.t * a.sd.CKK + wge] = w_prev - astep * g_prev;
     PT_STAMP(3);
     __syncthreads();
     PT_STAMP(4);
 
-    // ---- G[c][tap] += feat[c][P] * r[P shifted by tap]
+    // ---- G[c][tap] += feat[c][P] * r[P shifted by tap] over the U contiguous 16-position groups of this wave.
+    //      A wave stalls at a load it cannot issue (the CU's memory pipeline accepts ~20-45 B/clk), so the loads are
+    //      software-pipelined PD groups ahead of the MFMAs that consume them instead of being issued all up front.
+    constexpr int PD = 6;
+    const int c = cb * 16 + j;
+    const __amdgpu_buffer_rsrc_t fr = pt_rsrc(a.feat, (unsigned)(((long)(a.n - 1) * a.stride_n + (long)a.C * HW) * 4));
+    const int g0 = gbeg + wave * a.U;
     const int uj = j / a.KW, vj = j - uj * a.KW;
     const int tapoff = (a.KH - 1 - uj) * a.PW + (a.KW - 1 - vj);
     const bool tapv = j < KK;
-    f32x4 accA = {0, 0, 0, 0}, accB = {0, 0, 0, 0};
+    const int Pm = 16 * g0 + 4 * kq < total ? 16 * g0 + 4 * kq : 0;   // masked groups re-read a line already fetched
+    f32x4 av[16];
     float bv[16][4];
-#pragma unroll
-    for (int u = 0; u < 16; ++u) {                                  // all gathers in flight before the first MFMA
+    int il[16], p0[16];
+    auto issue = [&](int u) {
+        const int g = g0 + u;
+        const int P0 = 16 * g + 4 * kq;
+        const bool okk = u < a.U && g < gend && P0 < total;
+        const int Pc = okk ? P0 : Pm;
+        const int i = fdiv(Pc, inv_hw);
+        il[u] = okk ? i - i_lo : -1;
+        p0[u] = Pc - i * HW;
+        av[u] = pt_bload4(fr, ((unsigned)i * (unsigned)a.stride_n + (unsigned)c * HW + p0[u]) * 4u);
+    };
+    auto gather = [&](int u) {
         const bool okb = il[u] >= 0 && tapv;
         const int y0 = fdiv(p0[u], inv_w), x0 = p0[u] - y0 * a.W;
         // a quad may wrap to the next feature row: one row further in the padded map is PW - W cells more
@@ -598,9 +618,15 @@ __global__ __launch_bounds__(512) void k_adj2(Adj2Args a) {
         bv[u][1] = maps[idx0 + 1 + (x0 + 1 >= a.W ? wr : 0)];
         bv[u][2] = maps[idx0 + 2 + (x0 + 2 >= a.W ? wr : 0)];
         bv[u][3] = maps[idx0 + 3 + (x0 + 3 >= a.W ? wr : 0)];
-    }
+    };
+    f32x4 accA = {0, 0, 0, 0}, accB = {0, 0, 0, 0};
+#pragma unroll
+    for (int u = 0; u < PD; ++u) issue(u);
+    gather(0);
 #pragma unroll
     for (int u = 0; u < 16; ++u) {
+        if (u + PD < 16) issue(u + PD);
+        if (u + 1 < 16) gather(u + 1);
         if (PT_ABL & 8) { accA += av[u]; continue; }
         // masked lanes multiply a finite, re-read feature value by a gathered zero
         accA = mfma16(av[u][0], bv[u][0], accA);
@@ -639,7 +665,7 @@ static void adj2_dispatch(const PtFast& p, const Adj2Args& a, hipStream_t st) {
 
 int pt_launch_adj2_plain(const PtFast& p, const float* feat, long stride_n, const float* inp, float* gpart,
                          hipStream_t st) {
-    if (((uintptr_t)feat % 16) || (stride_n % 4)) return PT_ERR_UNSUPPORTED;
+    if (((uintptr_t)feat % 16) || (stride_n % 4) || (long)p.n * stride_n * 4 >= (1L << 31)) return PT_ERR_UNSUPPORTED;
     Adj2Args a;
     adj2_fill(p, a, feat, stride_n, gpart);
     a.inp = inp;
@@ -653,7 +679,7 @@ int pt_launch_adj2_plain(const PtFast& p, const float* feat, long stride_n, cons
 
 int pt_launch_adj2_sd(const PtFast& p, const float* feat, long stride_n, const SdArgs& sd, int t, int want_loss,
                       hipStream_t st) {
-    if (((uintptr_t)feat % 16) || (stride_n % 4)) return PT_ERR_UNSUPPORTED;
+    if (((uintptr_t)feat % 16) || (stride_n % 4) || (long)p.n * stride_n * 4 >= (1L << 31)) return PT_ERR_UNSUPPORTED;
     Adj2Args a;
     adj2_fill(p, a, feat, stride_n, sd.gpart);
     a.sd = sd;

@@ -16,6 +16,7 @@ struct SdArgs {
     float *s, *sg;               // (n,OO) scores of the current iterate, F g
     const float *s_in;           // fast path: scores of iterate t-1 (ping-pong with s)
     float *lms;                  // fast path: (n,OO,4) packed {label, mask, sws, 0} (one 16-byte load per element)
+    float *pk;                   // fast path: (n,OO,4) packed update-stage operands (see PReg in fast_passes.hip)
     float *spart;                // (KS,n,OO)
     float *R;                    // (NG,256)
     float *gpart, *g;            // (KSPL,CKK), (CKK)

@@ -207,7 +207,7 @@ static SdCarve sd_carve(const PtPlan& p, int max_iter) {
 // fast path (fast_passes.hip): per iteration  adj2 [update prologue fused] -> corr2 [gradient reduction fused] -> SGQ
 // ----------------------------------------------------------------------------------------------------
 struct FastCarve {
-    size_t label, mask, sws, lms, s0, s1, sg, spart, gpart, g, anum, qs, lossp, total;
+    size_t label, mask, sws, lms, pk, s0, s1, sg, spart, gpart, g, anum, qs, lossp, total;
 };
 
 static FastCarve fast_carve(const PtFast& f, int max_iter) {
@@ -215,7 +215,7 @@ static FastCarve fast_carve(const PtFast& f, int max_iter) {
     size_t off = 0;
     auto take = [&](size_t nfl) { size_t o = off; off += pt_align_floats(nfl); return o; };
     const size_t nOO = (size_t)f.n * f.OO;
-    c.label = take(nOO); c.mask = take(nOO); c.sws = take(nOO); c.lms = take(4 * nOO);
+    c.label = take(nOO); c.mask = take(nOO); c.sws = take(nOO); c.lms = take(4 * nOO); c.pk = take(4 * nOO);
     c.s0 = take(nOO); c.s1 = take(nOO); c.sg = take(nOO);
     c.spart = take(pt_fast_spart_floats(f));
     c.gpart = take(pt_fast_gpart_floats(f));
@@ -227,6 +227,19 @@ static FastCarve fast_carve(const PtFast& f, int max_iter) {
     return c;
 }
 
+// packed operands of the update stage that k_adj2 runs as its prologue (PReg in fast_passes.hip)
+__device__ __forceinline__ void fast_pack(const SdArgs& a, long q, float s, float sg) {
+    f32x4 v;
+    if (a.kind == PT_SD_PRDIMP) {
+        v = (f32x4){s, sg, a.label[q], 0.f};
+    } else {
+        const float sw = a.sws[q], m = a.mask[q], L = a.label[q];
+        if (a.kind == PT_SD_DIMP && a.score_act == PT_ACT_BENTPAR) v = (f32x4){s, sg, L, m};
+        else { const float w2 = sw * sw; v = (f32x4){w2 * s, w2 * sg, w2 * L, m}; }
+    }
+    ((f32x4*)a.pk)[q] = v;
+}
+
 // s_0 = sum of the 8 channel-range slices; classification epilogue of the inserted slot; label/mask/weight maps
 __global__ __launch_bounds__(512) void k_fast_init(SdArgs a) {
     __shared__ float scratch[16];
@@ -236,6 +249,48 @@ __global__ __launch_bounds__(512) void k_fast_init(SdArgs a) {
     for (int o = threadIdx.x; o < a.OO; o += blockDim.x) a.s[base + o] = sd_sum_slices(a, i, o);
     if (a.cls_spart && i == a.cls_slot) sd_classify_fin(a);     // uniform per workgroup; re-centres bb[slot]
     sd_maps_sample(a, i, scratch, amin);
+    __syncthreads();                                            // PrDiMP: label is finalised by other threads
+    for (int o = threadIdx.x; o < a.OO; o += blockDim.x) fast_pack(a, base + o, a.s[base + o], 0.f);
+}
+
+// F g = sum of the 8 slices; per-sample curvature term (optimizer.py:151-156 / :416-422); packed operands for k_adj2
+__global__ __launch_bounds__(512) void k_fast_sgq(SdArgs a) {
+    extern __shared__ __attribute__((aligned(16))) float lds[];
+    __shared__ float scratch[16];
+    const int i = blockIdx.x;
+    const long base = (long)i * a.OO;
+    float acc = 0.f;
+    if (a.kind != PT_SD_PRDIMP) {
+        const int sact = a.kind == PT_SD_DIMP_L2 ? 2 : a.score_act;
+        for (int o = threadIdx.x; o < a.OO; o += blockDim.x) {
+            const float sgv = sd_sum_slices(a, i, o), sv = a.s[base + o];
+            a.sg[base + o] = sgv;
+            float act, der;
+            act_pair(sact, a.act_param, sv, a.mask[base + o], act, der);
+            const float q = a.sws[base + o] * (der * sgv);
+            acc += q * q;
+            fast_pack(a, base + o, sv, sgv);
+        }
+        const float tot = block_sum(acc, scratch);
+        if (threadIdx.x == 0) a.qs[i] = tot;
+    } else {
+        const float swp = a.has_sw ? a.sw[i] : 1.0f / (float)a.n;
+        float psum = 0.f;
+        for (int o = threadIdx.x; o < a.OO; o += blockDim.x) {
+            const float sgv = sd_sum_slices(a, i, o);
+            a.sg[base + o] = sgv;
+            lds[o] = sgv;
+            psum += a.mask[base + o] * sgv;                                         // :419
+            fast_pack(a, base + o, a.s[base + o], sgv);
+        }
+        const float tot = block_sum(psum, scratch);
+        for (int o = threadIdx.x; o < a.OO; o += blockDim.x) {
+            const float P = a.mask[base + o], sgv = lds[o];
+            acc += sgv * (P * sgv - P * tot);                                       // :420
+        }
+        const float ghg = block_sum(acc, scratch);
+        if (threadIdx.x == 0) a.qs[i] = swp * fmaxf(ghg, 0.f);                      // :421-422
+    }
 }
 
 #define PT_SD_MAX_ITER 64
@@ -261,7 +316,7 @@ static void sd_fill_params(SdArgs& a, const pt_sd_params* prm, const float* bb, 
     a.softmax_reg = prm->softmax_reg; a.label_thr = prm->label_threshold;
     a.bb = bb; a.sw = sample_weight; a.label_lut = prm->label_lut; a.mask_lut = prm->mask_lut;
     a.spatial_lut = prm->spatial_lut;
-    a.s_in = nullptr; a.lms = nullptr; a.R = nullptr; a.cls_stride = 0;
+    a.s_in = nullptr; a.lms = nullptr; a.pk = nullptr; a.R = nullptr; a.cls_stride = 0;
     a.cls_spart = nullptr; a.cls_KS = 0; a.cls_slot = -1; a.cls_scores = nullptr; a.cls_peak = nullptr; a.cls_bb = nullptr;
 }
 
@@ -277,7 +332,7 @@ static int sd_solve_fast(const PtFast& f, const pt_sd_params* prm, const float* 
     sd_fill_params(a, prm, bb, sample_weight, n, f.C, f.H, f.W, K, f.OH, f.OW);
     a.KS = 8; a.KSPL = f.KSPL;
     a.label = base + cv.label; a.mask = base + cv.mask; a.sws = base + cv.sws; a.sg = base + cv.sg;
-    a.lms = base + cv.lms;
+    a.lms = base + cv.lms; a.pk = base + cv.pk;
     a.spart = base + cv.spart; a.gpart = base + cv.gpart; a.g = base + cv.g; a.anum = base + cv.anum;
     a.qs = base + cv.qs; a.lossp = base + cv.lossp; a.w_iters = w_iters; a.w0 = w_in; a.w_final = w_final;
     float* sbuf[2] = {base + cv.s0, base + cv.s1};
@@ -315,7 +370,7 @@ static int sd_solve_fast(const PtFast& f, const pt_sd_params* prm, const float* 
         PtCorrFuse fz = {a.gpart, f.KSPL, t == 0 ? w_in : w_iters + (long)t * a.CKK, a.reg, a.g, a.anum, nullptr};
         rc = pt_launch_corr2(f, feat, stride_n, nullptr, a.spart, st, &fz);    // g_t, |g_t|^2, F g_t
         if (rc) return rc;
-        hipLaunchKernelGGL(k_sd_pw, dim3(n), dim3(512), pw_lds, st, a, (int)PW_SGQ, t, 0, 0);
+        hipLaunchKernelGGL(k_fast_sgq, dim3(n), dim3(384), pw_lds, st, a);
         PT_CHECK_LAUNCH();
     }
     if (num_iter > 0) {
@@ -347,7 +402,7 @@ int pt_sd_solve_impl(const pt_sd_params* prm, const float* w_in, const float* fe
     const int OH = H + (K + 1) % 2, OW = W + (K + 1) % 2;               // optimizer.py:105
     {
         PtFast f = pt_fast_plan(n, C, H, W, K, K, OH, OW);
-        if (f.ok && ((uintptr_t)feat % 16) == 0 && (feat_stride_n % 4) == 0 && ((uintptr_t)src % 16) == 0)
+        if (f.ok && ((uintptr_t)feat % 16) == 0 && (feat_stride_n % 4) == 0 && (long)n * feat_stride_n * 4 < (1L << 31) && ((uintptr_t)src % 16) == 0)
             return sd_solve_fast(f, prm, w_in, feat, feat_stride_n, bb, sample_weight, num_iter, w_iters, losses, ws,
                                  ws_bytes, st, copy_w0, w_final, cls, src);
     }
@@ -373,7 +428,7 @@ int pt_sd_solve_impl(const pt_sd_params* prm, const float* w_in, const float* fe
     a.spart = base + cv.spart; a.R = base + cv.R; a.gpart = base + cv.gpart; a.g = base + cv.g;
     a.anum = base + cv.anum; a.qs = base + cv.qs; a.lossp = base + cv.lossp; a.w_iters = w_iters;
     a.w0 = w_in; a.w_final = w_final;
-    a.s_in = nullptr; a.lms = nullptr; a.cls_stride = 0;
+    a.s_in = nullptr; a.lms = nullptr; a.pk = nullptr; a.cls_stride = 0;
     a.cls_spart = nullptr; a.cls_KS = 0; a.cls_slot = -1; a.cls_scores = nullptr; a.cls_peak = nullptr; a.cls_bb = nullptr;
     if (cls) {
         a.cls_spart = cls->spart; a.cls_KS = cls->KS; a.cls_stride = a.OO; a.cls_slot = cls->slot; a.cls_scores = cls->scores;
