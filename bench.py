@@ -86,6 +86,8 @@ def main():
     ap.add_argument("--no-graph", action="store_true", help="launch every frame eagerly instead of replaying hipGraphs")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-roofline", action="store_true")
+    ap.add_argument("--workload", default="dimp50", choices=("dimp50", "prdimp50"),
+                    help="dimp50 = BASELINE configs[1] (the metric's configuration); prdimp50 = configs[2]'s per-GPU workload")
     args = ap.parse_args()
 
     world = int(os.environ.get("WORLD_SIZE", "1"))
@@ -106,9 +108,11 @@ def main():
             _lib.build_library()
         if dist is not None:
             dist.barrier()
-    cfg = synth.DIMP50
+    cfg_name = args.workload
+    cfg = synth.DIMP50 if cfg_name == "dimp50" else synth.PRDIMP50
     n = cfg["memory"]
-    st = bench_frame.TrackState(cfg, n, seed=1234 + rank, device=dev)      # one independent sequence per GPU
+    st = bench_frame.TrackState(cfg, n, seed=1234 + rank, device=dev,      # one independent sequence per GPU
+                                kind="dimp" if cfg_name == "dimp50" else "prdimp")
     pool = make_pool(cfg, 4321 + rank, dev)
     K, Wm = args.steps, args.warmup
 
@@ -146,7 +150,10 @@ def main():
             dist.barrier()
         elapsed = time.perf_counter() - t0
 
-        # ---- roofline leg: the same K frames again, eagerly, with HIP events around the feature-pass kernels ----
+        # ---- roofline leg: kprof more frames, eagerly, with HIP events around every feature-pass launch on the stream
+        #      it is launched on.  An event pair costs a few microseconds of its own: the library brackets a one-wave
+        #      kernel that spins for exactly 5.00 us next to every adjoint launch, and (that bracket - 5.00 us) is subtracted
+        #      from the brackets around the passes (rocprofv3's kernel durations in profiles/ are the check).
         roof = None
         if not args.no_roofline and rank == 0:
             L = _lib.lib()
@@ -158,29 +165,33 @@ def main():
             run_frames(st, pool, Wm + K, kprof)
             stream.synchronize()
             L.pt_profile_attach(None)
-            feat_bytes = 4 * n * cfg["C"] * cfg["H"] * cfg["W"]
+            feat_bytes = 4 * n * cfg["C"] * cfg["H"] * cfg["W"]       # one pass streams the n-sample memory once
             kern = {}
-            for kid, name in ((0, "k_corr"), (1, "k_adj")):
+            for kid, name in ((0, "k_corr2"), (1, "k_adj2"), (2, "spin5us")):
                 ms, cnt = ctypes.c_double(), ctypes.c_long()
                 _lib.check(L.pt_profile_collect(prof, kid, ctypes.byref(ms), ctypes.byref(cnt)), "pt_profile_collect")
-                kern[name] = (ms.value, cnt.value)
+                kern[name] = (ms.value * 1e3 / max(cnt.value, 1), cnt.value)       # mean microseconds, launches
             L.pt_profile_destroy(prof)
-            # per frame: 1 + NUM_ITER correlation passes (the first one also classifies the test frame) and NUM_ITER
-            # adjoint passes, each streaming the n-sample memory once
-            corr_bytes = kern["k_corr"][1] * feat_bytes
-            adj_bytes = kern["k_adj"][1] * feat_bytes
-            stats = {"k_corr": (corr_bytes, *kern["k_corr"]), "k_adj": (adj_bytes, *kern["k_adj"])}
-            dom = max(stats, key=lambda k: stats[k][1])
-            b, ms, cnt = stats[dom]
-            ach = b / (ms * 1e-3) / 1e9
-            roof = {"bound": "hbm", "kernel": dom, "achieved": round(ach, 1), "peak": HBM_PEAK_GBS, "unit": "GB/s",
-                    "frac": round(ach / HBM_PEAK_GBS, 4), "traffic": None,
-                    "avg_launch_us": round(ms * 1e3 / cnt, 3), "launches": cnt,
-                    "algorithmic_bytes_per_launch": b // cnt,
-                    "other": {k: {"avg_launch_us": round(v[1] * 1e3 / v[2], 3), "launches": v[2],
-                                  "achieved_GBs": round(v[0] / (v[1] * 1e-3) / 1e9, 1)} for k, v in stats.items()},
-                    "solve_level": {"algorithmic_bytes_per_frame": st.bytes_per_solve(NUM_ITER),
-                                    "achieved_GBs": None}}
+            # the spin kernel's own duration as rocprofv3 sees it: 5.00 us of spinning + 0.58 us dispatch/drain of a
+            # one-wave kernel (profiles/r01e_kernel_stats.csv: k_prof_spin avg 5581 ns)
+            overhead = max(kern["spin5us"][0] - 5.58, 0.0)
+            stats = {k: {"avg_launch_us": round(max(kern[k][0] - overhead, 1e-3), 3), "bracket_us": round(kern[k][0], 3),
+                         "launches": kern[k][1],
+                         "achieved_GBs": round(feat_bytes / max(kern[k][0] - overhead, 1e-3) / 1e3, 1)}
+                     for k in ("k_corr2", "k_adj2")}
+            dom = max(stats, key=lambda k: stats[k]["avg_launch_us"] * stats[k]["launches"])
+            traffic, traffic_src = None, None
+            pmc = os.path.join(ROOT, "profiles", "pmc_traffic.json")   # committed rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE pass
+            if os.path.exists(pmc):
+                rec = json.load(open(pmc)).get(cfg_name, {}).get(dom)
+                if rec:
+                    traffic, traffic_src = rec["hbm_bytes_per_launch"], rec["source"]
+            roof = {"bound": "hbm", "kernel": dom, "achieved": stats[dom]["achieved_GBs"], "peak": HBM_PEAK_GBS,
+                    "unit": "GB/s", "frac": round(stats[dom]["achieved_GBs"] / HBM_PEAK_GBS, 4), "traffic": traffic,
+                    "traffic_source": traffic_src, "avg_launch_us": stats[dom]["avg_launch_us"],
+                    "event_pair_overhead_us": round(overhead, 3), "launches": stats[dom]["launches"],
+                    "algorithmic_bytes_per_launch": feat_bytes, "kernels": stats,
+                    "solve_level": {"algorithmic_bytes_per_frame": st.bytes_per_solve(NUM_ITER), "achieved_GBs": None}}
 
     # the only collective: the end-of-batch (frames, seconds) gather; whole-job rate = all frames / slowest rank
     total_frames, tmax, _ = sequences.gather_throughput(K, elapsed, device=dev)
@@ -190,17 +201,21 @@ def main():
         if roof is not None:
             roof["solve_level"]["achieved_GBs"] = round(st.bytes_per_solve(NUM_ITER) * (K / tmax) / 1e9, 1)
         out = {
-            "metric": "frames/sec DiMP-50 online track (288x288, 5 SD iters)", "value": round(value, 2),
+            "metric": "frames/sec DiMP-50 online track (288x288, 5 SD iters)" if cfg_name == "dimp50" else "frames/sec PrDiMP-50 online track (352x352, 5 SD iters)", "value": round(value, 2),
             "unit": "frames/s", "n_gpus": world, "steps": K, "warmup": Wm,
             "ms_per_step": round(1e3 * tmax / K, 5), "higher_is_better": True, "scaling": "weak",
             "vs_baseline": None, "dtype": "f32", "data": "synthetic",
-            "config": {"workload": "BASELINE configs[1]: DiMP-50 single sequence per GPU; per frame classify(1x512x18x18) "
-                                   "+ arg-max + memory insert + DiMPSteepestDescentGN(5 it) over n=50x512x18x18, K=4",
+            "config": {"workload": ("BASELINE configs[1]: DiMP-50 single sequence per GPU; per frame classify(1x512x18x18) "
+                                    "+ arg-max + memory insert + DiMPSteepestDescentGN(5 it) over n=50x512x18x18, K=4")
+                       if cfg_name == "dimp50" else
+                       ("BASELINE configs[2] per-GPU workload: PrDiMP-50 single sequence per GPU; per frame "
+                        "classify(1x512x22x22) + arg-max + memory insert + PrDiMPSteepestDescentNewton(5 it) over "
+                        "n=50x512x22x22, K=4"),
                        "sequences_per_gpu": 1, "launch": "eager" if graph is None else f"hipGraph of {n} frames",
                        "parallelism": f"{world} independent sequences"},
             "roofline": roof,
         }
-        if not args.no_cpu_baseline and world == 1:
+        if not args.no_cpu_baseline and world == 1 and cfg_name == "dimp50":
             out["cpu_baseline"] = cpu_baseline(cfg, n)
         print(json.dumps(out), flush=True)
     if dist is not None:

@@ -160,7 +160,9 @@ int pt_track_frame_f32(const pt_sd_params* p, float* filter, float* mem_feat, fl
  * Measurement hook (bench.py roofline leg; not part of the reference's API).  While a profile is attached,
  * every launch of the two feature-pass kernels is bracketed by HIP events on the stream it is launched on.
  * The attachment is the only process-global state of the library; it must not be used during graph capture.
- *   kernel ids: 0 = correlation pass (k_corr), 1 = adjoint pass (k_adj).
+ *   kernel ids: 0 = correlation pass (k_corr*), 1 = adjoint pass (k_adj*), 2 = calibration: an event pair around a
+ *   one-wave kernel that spins for exactly 5.00 us of device wall clock, launched before every adjoint pass
+ *   (bracket - 5.00 us = the overhead of an event pair around a real kernel, to be subtracted from ids 0 and 1).
  * ---------------------------------------------------------------------------------------------- */
 typedef struct pt_profile pt_profile;
 int pt_profile_create(pt_profile** out, int max_launches_per_kernel);

@@ -3,11 +3,23 @@
 #include "common.h"
 #include "pt_internal.h"
 
+enum { PT_PROF_IDS = 3 };   // 0 = correlation pass, 1 = adjoint pass, 2 = calibration bracket (see pt_prof_begin)
+
+// One wave that spins for a known time on the 100 MHz wall clock: the event pair around it measures
+// (known duration + the bracket's own overhead), which is what has to be subtracted from the brackets around real kernels.
+#define PT_CAL_TICKS 500    /* 5.00 us */
+__global__ void k_prof_spin(unsigned long long* sink) {
+    const unsigned long long t0 = wall_clock64();
+    unsigned long long t = t0;
+    while (t - t0 < PT_CAL_TICKS) t = wall_clock64();
+    if (sink && t == 0) *sink = t;
+}
+
 struct pt_profile {
     int cap;
-    std::vector<hipEvent_t> start[2], stop[2];
-    int used[2];
-    bool open[2];
+    std::vector<hipEvent_t> start[PT_PROF_IDS], stop[PT_PROF_IDS];
+    int used[PT_PROF_IDS];
+    bool open[PT_PROF_IDS];
 };
 
 static pt_profile* g_prof = nullptr;
@@ -17,7 +29,7 @@ extern "C" int pt_profile_create(pt_profile** out, int max_launches_per_kernel) 
     if (max_launches_per_kernel <= 0) return PT_ERR_SHAPE;
     pt_profile* p = new pt_profile();
     p->cap = max_launches_per_kernel;
-    for (int k = 0; k < 2; ++k) {
+    for (int k = 0; k < PT_PROF_IDS; ++k) {
         p->start[k].resize(p->cap);
         p->stop[k].resize(p->cap);
         p->used[k] = 0;
@@ -38,14 +50,13 @@ extern "C" int pt_profile_attach(pt_profile* prof) {
 
 extern "C" int pt_profile_reset(pt_profile* prof) {
     if (!prof) return PT_ERR_NULL;
-    prof->used[0] = prof->used[1] = 0;
-    prof->open[0] = prof->open[1] = false;
+    for (int k = 0; k < PT_PROF_IDS; ++k) { prof->used[k] = 0; prof->open[k] = false; }
     return PT_OK;
 }
 
 extern "C" int pt_profile_collect(pt_profile* prof, int kernel_id, double* total_ms, long* launches) {
     if (!prof || !total_ms || !launches) return PT_ERR_NULL;
-    if (kernel_id < 0 || kernel_id > 1) return PT_ERR_SHAPE;
+    if (kernel_id < 0 || kernel_id >= PT_PROF_IDS) return PT_ERR_SHAPE;
     double tot = 0.0;
     for (int e = 0; e < prof->used[kernel_id]; ++e) {
         if (hipEventSynchronize(prof->stop[kernel_id][e]) != hipSuccess) return PT_ERR_LAUNCH;
@@ -62,7 +73,7 @@ extern "C" int pt_profile_collect(pt_profile* prof, int kernel_id, double* total
 extern "C" int pt_profile_destroy(pt_profile* prof) {
     if (!prof) return PT_ERR_NULL;
     if (g_prof == prof) g_prof = nullptr;
-    for (int k = 0; k < 2; ++k)
+    for (int k = 0; k < PT_PROF_IDS; ++k)
         for (int e = 0; e < prof->cap; ++e) {
             hipEventDestroy(prof->start[k][e]);
             hipEventDestroy(prof->stop[k][e]);
@@ -74,6 +85,12 @@ extern "C" int pt_profile_destroy(pt_profile* prof) {
 void pt_prof_begin(int k, hipStream_t st) {
     pt_profile* p = g_prof;
     if (!p || p->used[k] >= p->cap) return;
+    if (k == 1 && p->used[2] < p->cap) {           // calibration: an event pair around a kernel of known duration
+        hipEventRecord(p->start[2][p->used[2]], st);
+        hipLaunchKernelGGL(k_prof_spin, dim3(1), dim3(64), 0, st, (unsigned long long*)nullptr);
+        hipEventRecord(p->stop[2][p->used[2]], st);
+        p->used[2]++;
+    }
     hipEventRecord(p->start[k][p->used[k]], st);
     p->open[k] = true;
 }
