@@ -24,6 +24,10 @@
 #ifndef PT_ABL
 #define PT_ABL 0      // experiments/fast_floor.hip only
 #endif
+#ifndef PT_ADJ_WAVES
+#define PT_ADJ_WAVES 8                     // waves per k_adj2 workgroup (16 measured no better at 18x18, worse at 22x22)
+#endif
+#define PT_ADJ_UMAX (128 / PT_ADJ_WAVES)   // 16-position groups per wave (all of a wave's loads are in flight at once)
 #ifdef PT_TRACE       // experiments/fast_floor.hip only: per-workgroup phase time stamps (100 MHz wall clock)
 __device__ unsigned long long* pt_trace_buf;
 #define PT_STAMP(k) do { if (threadIdx.x == 0 && pt_trace_buf) pt_trace_buf[blockIdx.x * 8 + (k)] = wall_clock64(); } while (0)
@@ -48,20 +52,27 @@ PtFast pt_fast_plan(int n, int C, int H, int W, int KH, int KW, int OH, int OW) 
     p.rem = p.Q % 16;
     p.left = (p.rem > 0 && p.rem <= 4) ? 1 : 0;
     p.tiles = p.TF + ((p.rem > 0 && !p.left) ? 1 : 0);
-    if (p.TF < 1 || 2 * p.tiles > 16) return p;
+    if (p.TF < 1 || p.tiles > 16) return p;
+    // k-step halves: two waves per tile when that keeps the workgroup at <= 10 waves (two workgroups per CU, <= 80 VGPRs);
+    // larger maps (22x22: 8 tiles) use one wave per tile with all of the XCD's k-steps
+    p.nh = 2 * p.tiles <= 10 ? 2 : 1;
+#ifdef PT_EXPERIMENT
+    if (getenv("PT_NH")) p.nh = atoi(getenv("PT_NH"));
+#endif
     p.CX = C / 8;
-    p.NK = p.CX / 8;
+    p.NK = p.CX / 4 / p.nh;
+    if (p.NK > 16) return p;
     p.HWp = 64 * (p.TF + (p.rem > 0 ? 1 : 0)) + 4;
-    p.corr_threads = 2 * p.tiles * 64;
-    p.corr_lds = ((size_t)p.CX * 16 + (size_t)2 * p.KK * p.HWp) * sizeof(float);
+    p.corr_threads = p.nh * p.tiles * 64;
+    p.corr_lds = ((size_t)p.CX * 16 + (size_t)p.nh * p.KK * p.HWp) * sizeof(float);
     if (p.corr_lds > 150 * 1024) return p;
     p.CB = C / 16;
     p.bpx = p.CB / 8;
     p.NG = (int)(((long)n * p.HW + 15) / 16);
     p.KSPL = 0;
     for (int ks = 8; ks <= 16; ks *= 2) {
-        const int gper = pt_ceil_div(p.NG, ks), U = pt_ceil_div(gper, 8);
-        if (U <= 16) { p.gper = gper; p.U = U; p.KSPL = pt_ceil_div(p.NG, gper); break; }
+        const int gper = pt_ceil_div(p.NG, ks), U = pt_ceil_div(gper, PT_ADJ_WAVES);
+        if (U <= PT_ADJ_UMAX) { p.gper = gper; p.U = U; p.KSPL = pt_ceil_div(p.NG, gper); break; }
     }
     if (p.KSPL == 0) return p;
     p.PH = H + KH - 1;
@@ -85,7 +96,7 @@ __device__ __forceinline__ int fdiv(int v, float inv_d) { return (int)(((float)v
 // ---------------------------------------------------------------------------------------------------
 struct Corr2Args {
     const float* feat; long stride_n; const float* filt; float* spart;
-    int n, C, H, W, KH, KW, OH, OW, CX, TF, rem, tiles, HWp;
+    int n, C, H, W, KH, KW, OH, OW, CX, TF, rem, tiles, HWp, nh;
     // fused gradient reduction (optimizer.py:146-148): filter operand = sum_k gpart[k] + reg*w
     const float* gpart; int KSPL; const float* w; float reg; float* g_out; float* anum_part;
     // source override: sample `slot` is read from `src` (C,H,W) and stored to copy_dst (the memory slot)
@@ -288,9 +299,9 @@ __global__ __launch_bounds__(1024, (NK <= 8 ? 6 : 4)) void k_corr2(Corr2Args a) 
     const int ph = a.KH / 2, pw = a.KW / 2, OO = a.OH * a.OW;
     const float inv_ow = 1.0f / (float)a.OW;
     const float* __restrict__ T0 = lds + nsl;
-    const float* __restrict__ T1 = T0 + (long)KK * a.HWp;
+    const float* __restrict__ T1 = T0 + (long)KK * a.HWp;          // second k-step half (a.nh == 2)
     float* __restrict__ out = a.spart + ((long)x * a.n + i) * OO;
-    if (PT_ABL & 2) { if (threadIdx.x < 64) out[threadIdx.x] = T0[threadIdx.x * 7] + T1[threadIdx.x]; return; }
+    if (PT_ABL & 2) { if (threadIdx.x < 64) out[threadIdx.x] = T0[threadIdx.x * 7]; return; }
     if (a.KH == 4 && a.KW == 4) {                                   // the trackers' filter size: fully unrolled
         for (int o = threadIdx.x; o < OO; o += blockDim.x) {
             const int y = fdiv(o, inv_ow), xx0 = o - y * a.OW;
@@ -303,7 +314,7 @@ __global__ __launch_bounds__(1024, (NK <= 8 ? 6 : 4)) void k_corr2(Corr2Args a) 
                     const int xx = xx0 + v - 2;
                     const bool ok = (unsigned)yy < (unsigned)a.H && (unsigned)xx < (unsigned)a.W;
                     const int idx = (u * 4 + v) * a.HWp + (ok ? yy * a.W + xx : 0);
-                    const float tsum = T0[idx] + T1[idx];
+                    const float tsum = a.nh == 2 ? T0[idx] + T1[idx] : T0[idx];
                     tv[u * 4 + v] = ok ? tsum : 0.f;
                 }
             }
@@ -325,7 +336,7 @@ __global__ __launch_bounds__(1024, (NK <= 8 ? 6 : 4)) void k_corr2(Corr2Args a) 
                 const int xx = xx0 + v - pw;
                 if ((unsigned)xx < (unsigned)a.W) {
                     const int idx = (u * a.KW + v) * a.HWp + yy * a.W + xx;
-                    s += T0[idx] + T1[idx];
+                    s += a.nh == 2 ? T0[idx] + T1[idx] : T0[idx];
                 }
             }
         }
@@ -338,7 +349,7 @@ int pt_launch_corr2(const PtFast& p, const float* feat, long stride_n, const flo
     Corr2Args a;
     a.feat = feat; a.stride_n = stride_n; a.filt = filt; a.spart = spart;
     a.n = p.n; a.C = p.C; a.H = p.H; a.W = p.W; a.KH = p.KH; a.KW = p.KW; a.OH = p.OH; a.OW = p.OW;
-    a.CX = p.CX; a.TF = p.TF; a.rem = p.rem; a.tiles = p.tiles; a.HWp = p.HWp;
+    a.CX = p.CX; a.TF = p.TF; a.rem = p.rem; a.tiles = p.tiles; a.HWp = p.HWp; a.nh = p.nh;
     a.gpart = nullptr; a.KSPL = 0; a.w = nullptr; a.reg = 0.f; a.g_out = nullptr; a.anum_part = nullptr;
     if (fuse) { a.gpart = fuse->gpart; a.KSPL = fuse->KSPL; a.w = fuse->w; a.reg = fuse->reg; a.g_out = fuse->g_out; a.anum_part = fuse->anum_part; }
     a.slot = slot; a.src = src; a.copy_dst = copy_dst;
@@ -388,9 +399,10 @@ enum { V_PLAIN = 0, V_DIMP_RELU = 1, V_DIMP_BENT = 2, V_L2 = 3, V_PRDIMP = 4 };
 //   pk : packed by k_fast_init / k_fast_sgq, ONE 16-byte load per element:
 //          DiMP relu / L2 : {sws^2 * s, sws^2 * (F g), sws^2 * label, mask}
 //          DiMP bentpar   : {s, F g, label, mask}  (+ sw)          PrDiMP : {s, F g, label, -}
-//   s, sg, lab, msk, sw : raw maps, only loaded by the waves that own the sample (s_t store, loss)
+//   s, sg : raw scores / F g, only loaded by the wave that owns the sample (it stores s_t; the loss needs more raw maps,
+//           which that wave loads late)
 template <int E>
-struct PReg { f32x4 pk[E]; float s[E], sg[E], lab[E], msk[E], sw[E]; };
+struct PReg { f32x4 pk[E]; float s[E], sg[E], sw[E]; };
 
 template <int V, int E>
 __device__ __forceinline__ void sdp_load(const Adj2Args& a, int i, int lane, bool home, PReg<E>& r) {
@@ -414,12 +426,6 @@ __device__ __forceinline__ void sdp_load(const Adj2Args& a, int i, int lane, boo
             const long q = base + min(lane + 64 * e, OO - 1);
             r.s[e] = a.sd.s_in[q];
             r.sg[e] = sgp[q];
-            if (V != V_PRDIMP && a.want_loss) {
-                const f32x4 lm = ((const f32x4*)a.sd.lms)[q];        // {label, mask, sws, -}
-                r.lab[e] = lm[0];
-                r.msk[e] = lm[1];
-                r.sw[e] = lm[2];
-            }
         }
     }
 }
@@ -509,9 +515,10 @@ __device__ __forceinline__ void sdp_compute(const Adj2Args& a, int i, int lane, 
                 const int sact = V == V_L2 ? 2 : (V == V_DIMP_BENT ? PT_ACT_BENTPAR : PT_ACT_RELU);
 #pragma unroll
                 for (int e = 0; e < E; ++e) {
+                    const f32x4 lm = ((const f32x4*)sd.lms)[base + min(lane + 64 * e, OO - 1)];   // {label, mask, sws, -}
                     float act, der;
-                    act_pair(sact, sd.act_param, r.s[e] - astep * r.sg[e], r.msk[e], act, der);
-                    const float rr = r.sw[e] * (act - r.lab[e]);
+                    act_pair(sact, sd.act_param, r.s[e] - astep * r.sg[e], lm[1], act, der);
+                    const float rr = lm[2] * (act - lm[0]);
                     lacc += (lane + 64 * e < OO) ? rr * rr : 0.f;
                 }
                 lacc = wave_sum(lacc);
@@ -522,9 +529,9 @@ __device__ __forceinline__ void sdp_compute(const Adj2Args& a, int i, int lane, 
 }
 
 template <int V, int E>
-__global__ __launch_bounds__(512) void k_adj2(Adj2Args a) {
+__global__ __launch_bounds__(PT_ADJ_WAVES * 64) void k_adj2(Adj2Args a) {
     extern __shared__ __attribute__((aligned(16))) float maps[];    // [ns_max][PH][PW] zero-padded residual maps + 16 zeros
-    __shared__ float red[8][256];
+    __shared__ float red[PT_ADJ_WAVES][256];
     const int b = blockIdx.x, x = b & 7, rr = b >> 3;
     const int cb = a.bpx * x + rr % a.bpx, ks = rr / a.bpx;
     const int HW = a.H * a.W, KK = a.KH * a.KW, PHPW = a.PH * a.PW;
@@ -573,7 +580,7 @@ __global__ __launch_bounds__(512) void k_adj2(Adj2Args a) {
     __syncthreads();                                                // maps zeroed
     PT_STAMP(2);
     if (have && !(PT_ABL & 16)) sdp_compute<V, E>(a, i_lo + wave, lane, pr, astep, maps + wave * PHPW, oy, ox, home0);
-    for (int sl = wave + 8; sl < ns; sl += 8) {                     // more samples than waves (tiny maps)
+    for (int sl = wave + PT_ADJ_WAVES; sl < ns; sl += PT_ADJ_WAVES) {   // more samples than waves (tiny maps)
         const int i = i_lo + sl;
         const int hg = (i * HW) >> 4;
         const bool home = cb == 0 && hg >= gbeg && hg < gend;
@@ -587,7 +594,8 @@ __global__ __launch_bounds__(512) void k_adj2(Adj2Args a) {
     // ---- G[c][tap] += feat[c][P] * r[P shifted by tap] over the U contiguous 16-position groups of this wave.
     //      A wave stalls at a load it cannot issue (the CU's memory pipeline accepts ~20-45 B/clk), so the loads are
     //      software-pipelined PD groups ahead of the MFMAs that consume them instead of being issued all up front.
-    constexpr int PD = 6;
+    constexpr int UM = PT_ADJ_UMAX;
+    constexpr int PD = UM < 8 ? UM : (UM == 8 ? 8 : 6);
     const int c = cb * 16 + j;
     const __amdgpu_buffer_rsrc_t fr = pt_rsrc(a.feat, (unsigned)(((long)(a.n - 1) * a.stride_n + (long)a.C * HW) * 4));
     const int g0 = gbeg + wave * a.U;
@@ -595,9 +603,9 @@ __global__ __launch_bounds__(512) void k_adj2(Adj2Args a) {
     const int tapoff = (a.KH - 1 - uj) * a.PW + (a.KW - 1 - vj);
     const bool tapv = j < KK;
     const int Pm = 16 * g0 + 4 * kq < total ? 16 * g0 + 4 * kq : 0;   // masked groups re-read a line already fetched
-    f32x4 av[16];
-    float bv[16][4];
-    int il[16], p0[16];
+    f32x4 av[UM];
+    float bv[UM][4];
+    int il[UM], p0[UM];
     auto issue = [&](int u) {
         const int g = g0 + u;
         const int P0 = 16 * g + 4 * kq;
@@ -624,9 +632,9 @@ __global__ __launch_bounds__(512) void k_adj2(Adj2Args a) {
     for (int u = 0; u < PD; ++u) issue(u);
     gather(0);
 #pragma unroll
-    for (int u = 0; u < 16; ++u) {
-        if (u + PD < 16) issue(u + PD);
-        if (u + 1 < 16) gather(u + 1);
+    for (int u = 0; u < UM; ++u) {
+        if (u + PD < UM) issue(u + PD);
+        if (u + 1 < UM) gather(u + 1);
         if (PT_ABL & 8) { accA += av[u]; continue; }
         // masked lanes multiply a finite, re-read feature value by a gathered zero
         accA = mfma16(av[u][0], bv[u][0], accA);
@@ -642,7 +650,7 @@ __global__ __launch_bounds__(512) void k_adj2(Adj2Args a) {
         const int e = threadIdx.x, row = e >> 4, tap = e & 15;
         float s = 0.f;
 #pragma unroll
-        for (int w = 0; w < 8; ++w) s += red[w][e];
+        for (int w = 0; w < PT_ADJ_WAVES; ++w) s += red[w][e];
         if (tap < KK) a.gpart[(long)ks * a.C * KK + (long)(cb * 16 + row) * KK + tap] = s;
     }
     PT_STAMP(6);
@@ -657,7 +665,7 @@ static void adj2_fill(const PtFast& p, Adj2Args& a, const float* feat, long stri
 
 template <int V>
 static void adj2_dispatch(const PtFast& p, const Adj2Args& a, hipStream_t st) {
-    dim3 grid(p.CB * p.KSPL), block(512);
+    dim3 grid(p.CB * p.KSPL), block(PT_ADJ_WAVES * 64);
     if (p.E == 6) hipLaunchKernelGGL((k_adj2<V, 6>), grid, block, p.adj_lds, st, a);
     else if (p.E == 9) hipLaunchKernelGGL((k_adj2<V, 9>), grid, block, p.adj_lds, st, a);
     else hipLaunchKernelGGL((k_adj2<V, 16>), grid, block, p.adj_lds, st, a);

@@ -51,7 +51,7 @@ int pt_launch_build_R(const PtPlan& p, const float* inp, float* R, hipStream_t s
 struct PtFast {
     int ok;
     int n, C, H, W, KH, KW, OH, OW, HW, KK, OO, Q;
-    int CX, NK, TF, rem, tiles, left, HWp, corr_threads;   // corr2: grid 8*n, waves = 2 halves x tiles
+    int CX, NK, TF, rem, tiles, left, HWp, corr_threads, nh;   // corr2: grid 8*n, waves = 2 halves x tiles
     size_t corr_lds;
     int CB, bpx, NG, KSPL, gper, U, PH, PW, ns_max, E;     // adj2: grid CB*KSPL, 8 waves x U contiguous groups
     size_t adj_lds;
