@@ -114,6 +114,33 @@ int pt_sd_solve_f32(const pt_sd_params* p, const float* w_in, const float* feat,
                     float* w_iters, float* losses, void* ws, size_t ws_bytes, void* stream);
 
 /* ------------------------------------------------------------------------------------------------
+ * Multi-filter filter layer + LWL few-shot learner -- ltr/models/layers/filter.py (5-D `filter` / `input` branches),
+ * ltr/models/meta/steepestdescent.py, ltr/models/lwl/loss_residual_modules.py
+ *   F <= 16 filters per sequence, K in {1, 3} (zero padding K/2: output H x W), W <= 256, groups = 1, no dilation.
+ * ---------------------------------------------------------------------------------------------- */
+
+/* apply_filter (filter.py:29-34), one sequence, F filters:  filt (F,C,K,K); scores (n,F,H,W) dense
+ *   scores[i,f,y,x] = sum_{c,u,v} filt[f,c,u,v] * feat[i,c,y+u-K/2,x+v-K/2] */
+int pt_apply_filter_mf_f32(const float* feat, long feat_stride_n, const float* filt, float* scores,
+                           int n, int F, int C, int H, int W, int K, void* stream);
+
+/* apply_feat_transpose for a 5-D input (filter.py:158-176):  inp (n,F,H,W) dense; grad (F,C,K,K)
+ *   grad[f,c,u,v] = sum_{i,y,x} feat[i,c,y+u-K/2,x+v-K/2] * inp[i,f,y,x] */
+size_t pt_feat_transpose_mf_ws_bytes(int n, int F, int C, int H, int W, int K);
+int pt_feat_transpose_mf_f32(const float* feat, long feat_stride_n, const float* inp, float* grad,
+                             int n, int F, int C, int H, int W, int K, void* ws, size_t ws_bytes, void* stream);
+
+/* GNSteepestDescent.forward (steepestdescent.py:32-105) on LWTLResidual (loss_residual_modules.py:16-41), one sequence:
+ *   residuals [sw*(apply_filter(feat,w) - label), filter_reg*w]; w_in (F,C,K,K) is not modified; w_iters receives the
+ *   num_iter+1 iterates; losses (num_iter+1 floats) may be NULL; label (n,F,H,W);
+ *   sw_mode 0: sample_weight ignored (sqrt(1/n), :27-28), 1: (n) per image, 2: (n,F,H,W) per element (:29-33). */
+size_t pt_lwl_ws_bytes(int n, int F, int C, int H, int W, int K);
+int pt_lwl_gn_solve_f32(const float* w_in, const float* feat, long feat_stride_n, const float* label,
+                        const float* sample_weight, int sw_mode, float filter_reg, float steplength_reg,
+                        int n, int F, int C, int H, int W, int K, int num_iter,
+                        float* w_iters, float* losses, void* ws, size_t ws_bytes, void* stream);
+
+/* ------------------------------------------------------------------------------------------------
  * ATOM conjugate gradient -- pytracking/libs/optimization.py:72-163,227-289 (ConjugateGradient.run +
  * run_CG) specialised to pytracking/tracker/atom/optim.py:71-99 (ConvProblem) with the MLU response
  * activation (ltr/models/layers/activation.py:20-29).

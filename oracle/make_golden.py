@@ -227,9 +227,49 @@ def gen_prroi_consumers():
          **{"sd_" + k.replace(".", "__"): v for k, v in sd.items()})
 
 
+def gen_lwl():
+    """LWL few-shot learner: the reference's GNSteepestDescent on LWTLResidual (autograd double-backward) on CPU."""
+    from pytracking import TensorList
+    from ltr.models.meta.steepestdescent import GNSteepestDescent
+    from ltr.models.lwl.loss_residual_modules import LWTLResidual
+    rng = np.random.default_rng(41)
+
+    def run(n, F, C, H, W, K, num_iter, sw_mode, reg, slreg, w0_zero):
+        feat = synth.clf_features(rng, n, C, H, W, K)
+        label = rng.uniform(0.0, 1.0, (n, F, H, W)).astype(np.float32)
+        if sw_mode == "full":
+            sw = rng.uniform(0.2, 1.0, (n, F, H, W)).astype(np.float32)
+        elif sw_mode == "per_image":
+            sw = rng.uniform(0.2, 1.0, (n,)).astype(np.float32)
+        else:
+            sw = None
+        w0 = np.zeros((F, C, K, K), np.float32) if w0_zero else \
+            (rng.standard_normal((F, C, K, K), dtype=np.float32) * np.float32(0.02))
+        res = LWTLResidual(init_filter_reg=reg)
+        opt = GNSteepestDescent(residual_module=res, num_iter=num_iter, compute_losses=True, steplength_reg=slreg,
+                                residual_batch_dim=1)          # as ltr/models/lwl/lwl_net.py:192-194 constructs it
+        w, its, losses = opt(TensorList([T(w0)[None]]), feat=T(feat)[:, None], label=T(label)[:, None],
+                             sample_weight=None if sw is None else (T(sw)[:, None] if sw.ndim == 4 else T(sw)))
+        with torch.no_grad():
+            scores = rfilter.apply_filter(T(feat)[:, None], w[0].detach())
+        return dict(feat=feat, label=label, w0=w0, sw=np.zeros(0, np.float32) if sw is None else sw,
+                    iterates=torch.stack([i[0][0].detach() for i in its]).numpy(),
+                    losses=torch.stack([l.detach().reshape(()) for l in losses]).numpy(),
+                    scores=scores[:, 0].numpy(), num_iter=num_iter, filter_reg=reg, steplength_reg=slreg)
+
+    save("lwl_gn_small_full", **run(3, 4, 8, 7, 9, 3, 3, "full", 0.1, 0.0, False))
+    save("lwl_gn_small_img", **run(2, 16, 12, 6, 8, 3, 2, "per_image", 0.05, 0.1, True))
+    save("lwl_gn_small_none", **run(4, 5, 8, 8, 6, 1, 3, "none", 0.1, 0.0, False))
+    # mid size on the MFMA path geometry (C multiple of 16, 16 filters, 3x3), small enough to commit (~120 KiB)
+    g = run(2, 16, 32, 10, 13, 3, 3, "full", 0.05, 0.0, True)
+    save("lwl_gn_mid", **g)
+
+
 if __name__ == "__main__":
     torch.set_num_threads(8)
-    which = sys.argv[1:] or ["filter", "dimp", "l2", "prdimp", "atom", "prroi"]
+    which = sys.argv[1:] or ["filter", "dimp", "l2", "prdimp", "atom", "prroi", "lwl"]
+    if "lwl" in which:
+        gen_lwl()
     if "filter" in which:
         gen_filter_ops()
     if "dimp" in which:

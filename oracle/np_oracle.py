@@ -302,6 +302,52 @@ def prdimp_sd(w0, feat, bb, sample_weight, *, num_iter, step_length, filter_reg,
 
 
 # --------------------------------------------------------------------------------------------
+# LWL few-shot learner: ltr/models/meta/steepestdescent.py + ltr/models/lwl/loss_residual_modules.py
+# --------------------------------------------------------------------------------------------
+
+def lwl_gn_sd(w0, feat, label, sample_weight, *, num_iter, filter_reg, steplength_reg=0.0, compute_losses=True):
+    """`GNSteepestDescent.forward` (steepestdescent.py:32-105) on `LWTLResidual` (loss_residual_modules.py:16-41),
+    one sequence.
+
+    w0 (F,C,K,K); feat (n,C,H,W); label (n,F,H,W); sample_weight None | (n,) | (n,F,H,W).
+    Residuals r = [sw*(apply_filter(feat,w) - label), filter_reg*w]  (:24-41); the autograd calls of the reference
+    (:70-73) are, for this linear residual,  g = J^T r = adj(feat, sw*r_data) + filter_reg*r_reg  and
+    h = J g = [sw*apply_filter(feat,g), filter_reg*g];  alpha = |g|^2 / max(|h|^2 + steplength_reg*|g|^2, 1e-8) (:76-80).
+    Returns (iterates (T+1,F,C,K,K), losses list); loss = sum r^2 / numel(r)  (:28-29).
+    """
+    dt = feat.dtype
+    n = feat.shape[0]
+    K = w0.shape[-1]
+    if sample_weight is None:
+        sw = dt.type(math.sqrt(1.0 / n))                                   # :27-28
+    else:
+        sw = np.asarray(sample_weight, dtype=dt)
+        sw = sw.reshape(label.shape) if sw.size == label.size else sw.reshape(-1, 1, 1, 1)   # :29-33
+    lam = dt.type(filter_reg)
+    w = w0.astype(dt)
+    iterates, losses = [w], []
+
+    def residuals(w):
+        return sw * (apply_filter(feat, w) - label), lam * w
+
+    for _ in range(num_iter):
+        rd, rr = residuals(w)
+        if compute_losses:
+            losses.append(((rd ** 2).sum() + (rr ** 2).sum()) / (rd.size + rr.size))
+        g = apply_feat_transpose(feat, sw * rd, K) + lam * rr
+        hd, hr = sw * apply_filter(feat, g), lam * g
+        ip_gg = (g * g).sum()
+        ip_hh = (hd * hd).sum() + (hr * hr).sum()
+        alpha = ip_gg / max(ip_hh + dt.type(steplength_reg) * ip_gg, dt.type(1e-8))
+        w = w - alpha * g
+        iterates.append(w)
+    if compute_losses:
+        rd, rr = residuals(w)
+        losses.append(((rd ** 2).sum() + (rr ** 2).sum()) / (rd.size + rr.size))
+    return np.stack(iterates), losses
+
+
+# --------------------------------------------------------------------------------------------
 # ATOM: pytracking/libs/optimization.py (CG), pytracking/tracker/atom/optim.py (ConvProblem)
 # --------------------------------------------------------------------------------------------
 

@@ -9,7 +9,7 @@ import subprocess
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.path.join(_HERE, "libpt_hot.so")
-SOURCES = ["filter_kernels.hip", "fast_passes.hip", "sd_solver.hip", "atom_cg.hip", "prroi.hip", "api.hip", "profile.hip"]
+SOURCES = ["filter_kernels.hip", "fast_passes.hip", "sd_solver.hip", "mf_kernels.hip", "lwl_solver.hip", "atom_cg.hip", "prroi.hip", "api.hip", "profile.hip"]
 HEADERS = ["common.h", "pt_internal.h", "rbuild.h", "sd_common.h", os.path.join("..", "..", "include", "pt_hot.h")]
 
 PT_SD_DIMP, PT_SD_DIMP_L2, PT_SD_PRDIMP = 0, 1, 2
@@ -24,6 +24,8 @@ EXPORTS = [
     "pt_atom_cg_ws_bytes", "pt_atom_cg_f32",
     "pt_prroi_fwd_f32", "pt_prroi_bwd_feat_f32", "pt_prroi_bwd_coor_f32",
     "pt_track_frame_ws_bytes", "pt_track_frame_f32",
+    "pt_apply_filter_mf_f32", "pt_feat_transpose_mf_ws_bytes", "pt_feat_transpose_mf_f32",
+    "pt_lwl_ws_bytes", "pt_lwl_gn_solve_f32",
     "pt_profile_create", "pt_profile_attach", "pt_profile_collect", "pt_profile_reset", "pt_profile_destroy",
 ]
 
@@ -108,6 +110,16 @@ def lib():
     L.pt_track_frame_ws_bytes.argtypes = [i] * 5
     L.pt_track_frame_f32.restype = i
     L.pt_track_frame_f32.argtypes = [ctypes.POINTER(SdParams), vp, vp, vp, vp, vp] + [i] * 7 + [vp, vp, vp, sz, vp]
+    L.pt_apply_filter_mf_f32.restype = i
+    L.pt_apply_filter_mf_f32.argtypes = [vp, l, vp, vp] + [i] * 6 + [vp]
+    L.pt_feat_transpose_mf_ws_bytes.restype = sz
+    L.pt_feat_transpose_mf_ws_bytes.argtypes = [i] * 6
+    L.pt_feat_transpose_mf_f32.restype = i
+    L.pt_feat_transpose_mf_f32.argtypes = [vp, l, vp, vp] + [i] * 6 + [vp, sz, vp]
+    L.pt_lwl_ws_bytes.restype = sz
+    L.pt_lwl_ws_bytes.argtypes = [i] * 6
+    L.pt_lwl_gn_solve_f32.restype = i
+    L.pt_lwl_gn_solve_f32.argtypes = [vp, vp, l, vp, vp, i, f, f] + [i] * 7 + [vp, vp, vp, sz, vp]
     L.pt_profile_create.restype = i
     L.pt_profile_create.argtypes = [ctypes.POINTER(vp), i]
     L.pt_profile_attach.restype = i

@@ -1,0 +1,227 @@
+// LWL few-shot learner: `GNSteepestDescent.forward` (ltr/models/meta/steepestdescent.py:32-105) specialised to
+// `LWTLResidual` (ltr/models/lwl/loss_residual_modules.py:16-41), one sequence, F <= 16 filters.
+//
+// The residual  r(w) = [ sw * (apply_filter(feat, w) - label) ,  lambda * w ]  is linear in the filter, so the two
+// autograd passes of the reference (steepestdescent.py:70,73) are explicit:
+//     g = J^T r = apply_feat_transpose(feat, sw * r_data) + lambda^2 * w
+//     h = J g   = [ sw * apply_filter(feat, g) , lambda * g ]
+//     alpha = |g|^2 / max(|h|^2 + steplength_reg * |g|^2, 1e-8) ;   w <- w - alpha * g          (:76-88)
+// and the scores of the next iterate follow without another pass:  s <- s - alpha * apply_filter(feat, g).
+// Per iteration: k_mf_adj -> k_lwl_g -> k_mf_corr -> k_lwl_hh -> k_lwl_upd; no host synchronisation.
+#include <algorithm>
+#include "common.h"
+#include "pt_internal.h"
+
+#define LWL_NBLK 256       // partial sums per reduction (fixed order everywhere)
+#define LWL_MAX_ITER 64
+
+struct LwlArgs {
+    long N;                // n*F*H*W
+    int n, F, C, HW, KK, CKK /* F*C*KK */, NSG, sw_mode;
+    float lam, slreg, sw_scalar;
+    const float *label, *sw;
+    float *s, *sg, *rmap, *gpart, *g, *ggp, *hhp, *lossp, *w_iters;
+    const float* w0;
+};
+
+__device__ __forceinline__ const float* lwl_w(const LwlArgs& a, int t) { return t == 0 ? a.w0 : a.w_iters + (long)t * a.CKK; }
+
+__device__ __forceinline__ float lwl_sw(const LwlArgs& a, long e) {
+    // loss_residual_modules.py:27-33: scalar sqrt(1/n) | per image | per element
+    if (a.sw_mode == 0) return a.sw_scalar;
+    if (a.sw_mode == 1) return a.sw[e / ((long)a.F * a.HW)];
+    return a.sw[e];
+}
+
+__device__ __forceinline__ float lwl_sum_parts(const float* p) {   // every thread: fixed-order sum of LWL_NBLK partials
+    float t = 0.f;
+    for (int k = 0; k < LWL_NBLK; ++k) t += p[k];
+    return t;
+}
+
+// s_t (in place when t > 0: s <- s - alpha*sg), residual, adjoint input, loss partials; t > 0 also w_t = w_{t-1} - alpha*g
+__global__ __launch_bounds__(256) void k_lwl_upd(LwlArgs a, int t, int want_loss, int last) {
+    __shared__ float scratch[16];
+    float alpha = 0.f;
+    if (t > 0) {
+        const float gg = lwl_sum_parts(a.ggp), hh = lwl_sum_parts(a.hhp) + a.lam * a.lam * gg;
+        alpha = gg / fmaxf(hh + a.slreg * gg, 1e-8f);                                   // steepestdescent.py:76-80
+        const float* wp = lwl_w(a, t - 1);
+        float* wn = a.w_iters + (long)t * a.CKK;
+        for (long e = (long)blockIdx.x * 256 + threadIdx.x; e < a.CKK; e += (long)LWL_NBLK * 256)
+            wn[e] = wp[e] - alpha * a.g[e];                                             // :83-88
+    }
+    if (last && !want_loss) return;
+    float lacc = 0.f;
+    for (long e = (long)blockIdx.x * 256 + threadIdx.x; e < a.N; e += (long)LWL_NBLK * 256) {
+        const float sv = t > 0 ? a.s[e] - alpha * a.sg[e] : a.s[e];
+        if (t > 0) a.s[e] = sv;
+        const float sw = lwl_sw(a, e);
+        const float r = sw * (sv - a.label[e]);                                         // loss_residual_modules.py:36
+        lacc += r * r;
+        if (!last) a.rmap[e] = sw * r;
+    }
+    if (want_loss) {
+        const float tot = block_sum(lacc, scratch);
+        if (threadIdx.x == 0) a.lossp[(long)t * LWL_NBLK + blockIdx.x] = tot;
+    }
+}
+
+// g = sum of the sample-group partials + lambda^2 * w_t ; partial |g|^2
+__global__ __launch_bounds__(256) void k_lwl_g(LwlArgs a, int t) {
+    __shared__ float scratch[16];
+    const float* w = lwl_w(a, t);
+    float acc = 0.f;
+    for (long e = (long)blockIdx.x * 256 + threadIdx.x; e < a.CKK; e += (long)LWL_NBLK * 256) {
+        float v = 0.f;
+        for (int k = 0; k < a.NSG; ++k) v += a.gpart[(long)k * a.CKK + e];
+        v += a.lam * a.lam * w[e];
+        a.g[e] = v;
+        acc += v * v;
+    }
+    const float tot = block_sum(acc, scratch);
+    if (threadIdx.x == 0) a.ggp[blockIdx.x] = tot;
+}
+
+// partial |sw * F g|^2
+__global__ __launch_bounds__(256) void k_lwl_hh(LwlArgs a) {
+    __shared__ float scratch[16];
+    float acc = 0.f;
+    for (long e = (long)blockIdx.x * 256 + threadIdx.x; e < a.N; e += (long)LWL_NBLK * 256) {
+        const float h = lwl_sw(a, e) * a.sg[e];
+        acc += h * h;
+    }
+    const float tot = block_sum(acc, scratch);
+    if (threadIdx.x == 0) a.hhp[blockIdx.x] = tot;
+}
+
+// losses[t] = (sum r_data^2 + lambda^2 |w_t|^2) / (N + F*C*KK)      (steepestdescent.py:28-29)
+__global__ __launch_bounds__(256) void k_lwl_loss(LwlArgs a, float* __restrict__ losses) {
+    __shared__ float scratch[16];
+    const int t = blockIdx.x;
+    const float* w = lwl_w(a, t);
+    float acc = 0.f;
+    for (int e = threadIdx.x; e < a.CKK; e += 256) acc += w[e] * w[e];
+    const float ww = block_sum(acc, scratch);
+    if (threadIdx.x == 0) {
+        float l = 0.f;
+        for (int k = 0; k < LWL_NBLK; ++k) l += a.lossp[(long)t * LWL_NBLK + k];
+        losses[t] = (l + a.lam * a.lam * ww) / (float)((double)a.N + (double)a.CKK);
+    }
+}
+
+__global__ void k_mf_sum_groups(const float* __restrict__ gpart, float* __restrict__ out, int groups, long count) {
+    const long e = (long)blockIdx.x * blockDim.x + threadIdx.x;
+    if (e >= count) return;
+    float s = 0.f;
+    for (int k = 0; k < groups; ++k) s += gpart[(long)k * count + e];
+    out[e] = s;
+}
+
+// ---------------------------------------------------------------------------------------------------
+struct LwlCarve { size_t s, sg, rmap, gpart, g, ggp, hhp, lossp, total; };
+
+static LwlCarve lwl_carve(int n, int F, int C, int H, int W, int K) {
+    LwlCarve c;
+    size_t off = 0;
+    auto take = [&](size_t nfl) { size_t o = off; off += pt_align_floats(nfl); return o; };
+    const size_t N = (size_t)n * F * H * W;
+    c.s = take(N); c.sg = take(N); c.rmap = take(N);
+    c.gpart = take(pt_mf_gpart_floats(n, F, C, H, W, K));
+    c.g = take((size_t)F * C * K * K);
+    c.ggp = take(LWL_NBLK); c.hhp = take(LWL_NBLK);
+    c.lossp = take((size_t)(LWL_MAX_ITER + 1) * LWL_NBLK);
+    c.total = off;
+    return c;
+}
+
+static int mf_check(int n, int F, int C, int H, int W, int K) {
+    if (n <= 0 || F <= 0 || C <= 0 || H <= 0 || W <= 0 || K <= 0) return PT_ERR_SHAPE;
+    if (pt_mf_groups(n, F, C, H, W, K) == 0) return PT_ERR_UNSUPPORTED;
+    return PT_OK;
+}
+
+extern "C" size_t pt_lwl_ws_bytes(int n, int F, int C, int H, int W, int K) {
+    if (mf_check(n, F, C, H, W, K)) return 0;
+    return lwl_carve(n, F, C, H, W, K).total * sizeof(float);
+}
+
+extern "C" int pt_apply_filter_mf_f32(const float* feat, long feat_stride_n, const float* filt, float* scores, int n,
+                                      int F, int C, int H, int W, int K, void* stream) {
+    if (!feat || !filt || !scores) return PT_ERR_NULL;
+    int rc = mf_check(n, F, C, H, W, K);
+    if (rc) return rc;
+    if (feat_stride_n < (long)C * H * W) return PT_ERR_SHAPE;
+    return pt_launch_mf_corr(feat, feat_stride_n, filt, scores, n, F, C, H, W, K, (hipStream_t)stream);
+}
+
+extern "C" size_t pt_feat_transpose_mf_ws_bytes(int n, int F, int C, int H, int W, int K) {
+    if (mf_check(n, F, C, H, W, K)) return 0;
+    return pt_align_floats(pt_mf_gpart_floats(n, F, C, H, W, K)) * sizeof(float);
+}
+
+extern "C" int pt_feat_transpose_mf_f32(const float* feat, long feat_stride_n, const float* inp, float* grad, int n,
+                                        int F, int C, int H, int W, int K, void* ws, size_t ws_bytes, void* stream) {
+    if (!feat || !inp || !grad || !ws) return PT_ERR_NULL;
+    int rc = mf_check(n, F, C, H, W, K);
+    if (rc) return rc;
+    if (feat_stride_n < (long)C * H * W) return PT_ERR_SHAPE;
+    if (ws_bytes < pt_feat_transpose_mf_ws_bytes(n, F, C, H, W, K) || ((uintptr_t)ws % 256) != 0) return PT_ERR_WORKSPACE;
+    hipStream_t st = (hipStream_t)stream;
+    rc = pt_launch_mf_adj(feat, feat_stride_n, inp, (float*)ws, n, F, C, H, W, K, st);
+    if (rc) return rc;
+    const long count = (long)F * C * K * K;
+    hipLaunchKernelGGL(k_mf_sum_groups, dim3((unsigned)((count + 255) / 256)), dim3(256), 0, st, (const float*)ws, grad,
+                       pt_mf_groups(n, F, C, H, W, K), count);
+    PT_CHECK_LAUNCH();
+    return PT_OK;
+}
+
+extern "C" int pt_lwl_gn_solve_f32(const float* w_in, const float* feat, long feat_stride_n, const float* label,
+                                   const float* sample_weight, int sw_mode, float filter_reg, float steplength_reg, int n,
+                                   int F, int C, int H, int W, int K, int num_iter, float* w_iters, float* losses,
+                                   void* ws, size_t ws_bytes, void* stream) {
+    if (!w_in || !feat || !label || !w_iters || !ws) return PT_ERR_NULL;
+    int rc = mf_check(n, F, C, H, W, K);
+    if (rc) return rc;
+    if (num_iter < 0 || feat_stride_n < (long)C * H * W) return PT_ERR_SHAPE;
+    if (num_iter > LWL_MAX_ITER || sw_mode < 0 || sw_mode > 2) return PT_ERR_UNSUPPORTED;
+    if (sw_mode != 0 && !sample_weight) return PT_ERR_NULL;
+    LwlCarve cv = lwl_carve(n, F, C, H, W, K);
+    if (ws_bytes < cv.total * sizeof(float) || ((uintptr_t)ws % 256) != 0) return PT_ERR_WORKSPACE;
+    hipStream_t st = (hipStream_t)stream;
+    float* base = (float*)ws;
+    LwlArgs a;
+    a.N = (long)n * F * H * W; a.n = n; a.F = F; a.C = C; a.HW = H * W; a.KK = K * K; a.CKK = F * C * K * K;
+    a.NSG = pt_mf_groups(n, F, C, H, W, K); a.sw_mode = sw_mode;
+    a.lam = filter_reg; a.slreg = steplength_reg; a.sw_scalar = sqrtf(1.0f / (float)n);
+    a.label = label; a.sw = sample_weight;
+    a.s = base + cv.s; a.sg = base + cv.sg; a.rmap = base + cv.rmap; a.gpart = base + cv.gpart; a.g = base + cv.g;
+    a.ggp = base + cv.ggp; a.hhp = base + cv.hhp; a.lossp = base + cv.lossp; a.w_iters = w_iters; a.w0 = w_in;
+    const int want_loss = losses != nullptr;
+    if (w_iters != w_in &&
+        hipMemcpyAsync(w_iters, w_in, (size_t)a.CKK * sizeof(float), hipMemcpyDeviceToDevice, st) != hipSuccess)
+        return PT_ERR_LAUNCH;
+    if (num_iter == 0 && !want_loss) return PT_OK;
+    rc = pt_launch_mf_corr(feat, feat_stride_n, w_in, a.s, n, F, C, H, W, K, st);       // s_0 = F w_0
+    if (rc) return rc;
+    hipLaunchKernelGGL(k_lwl_upd, dim3(LWL_NBLK), dim3(256), 0, st, a, 0, want_loss, (int)(num_iter == 0));
+    PT_CHECK_LAUNCH();
+    for (int t = 0; t < num_iter; ++t) {
+        rc = pt_launch_mf_adj(feat, feat_stride_n, a.rmap, a.gpart, n, F, C, H, W, K, st);
+        if (rc) return rc;
+        hipLaunchKernelGGL(k_lwl_g, dim3(LWL_NBLK), dim3(256), 0, st, a, t);
+        PT_CHECK_LAUNCH();
+        rc = pt_launch_mf_corr(feat, feat_stride_n, a.g, a.sg, n, F, C, H, W, K, st);   // F g
+        if (rc) return rc;
+        hipLaunchKernelGGL(k_lwl_hh, dim3(LWL_NBLK), dim3(256), 0, st, a);
+        PT_CHECK_LAUNCH();
+        hipLaunchKernelGGL(k_lwl_upd, dim3(LWL_NBLK), dim3(256), 0, st, a, t + 1, want_loss, (int)(t + 1 == num_iter));
+        PT_CHECK_LAUNCH();
+    }
+    if (want_loss) {
+        hipLaunchKernelGGL(k_lwl_loss, dim3(num_iter + 1), dim3(256), 0, st, a, losses);
+        PT_CHECK_LAUNCH();
+    }
+    return PT_OK;
+}

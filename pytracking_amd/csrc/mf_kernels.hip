@@ -1,0 +1,356 @@
+// Multi-filter feature passes (reference: ltr/models/layers/filter.py, the 5-D `filter` / `input` branches used by the
+// LWL few-shot learner, ltr/models/lwl/linear_filter.py:70-73, loss_residual_modules.py:16-41):
+//
+//   k_mf_corr : apply_filter(feat (n,C,H,W), filter (F,C,K,K)) -> (n,F,H,W)          filter.py:29-34
+//               scores[i,f,y,x] = sum_{c,u,v} filt[f,c,u,v] * feat[i,c,y+u-p,x+v-p]   (K odd, p = K/2, zero padded)
+//   k_mf_adj  : apply_feat_transpose(feat, input (n,F,H,W), K) -> (F,C,K,K)           filter.py:158-176
+//               grad[f,c,u,v]   = sum_{i,y,x} feat[i,c,y+u-p,x+v-p] * input[i,f,y,x]
+//
+// With F <= 16 filters both are dense contractions with a 16-wide filter dimension -- M = 16 on the f32 matrix cores
+// (v_mfma_f32_16x16x4_f32, exact fp32), the MFMA-bound rows of SURVEY.md section 8 (LWL: 7.4 GFLOP per pass at n = 32,
+// 47 us at the 157 TFLOP/s fp32 matrix peak vs 13 us of HBM time).  Feature tiles are staged in LDS with their zero
+// padding (row band + halo), so the K*K shifted operands are LDS reads at a constant offset instead of global re-reads.
+#include "common.h"
+#include "pt_internal.h"
+
+struct MfGeom {
+    int n, F, C, H, W, K, p, KK;
+    int BR, NB;          // output rows per band, bands per sample
+    int PWs;             // padded row stride in LDS (W + K - 1)
+    int RSmax;           // staged rows per band (BR + K - 1)
+};
+
+__device__ __forceinline__ int mf_fdiv(int v, float inv_d) { return (int)(((float)v + 0.5f) * inv_d); }
+
+// ---------------------------------------------------------------------------------------------------
+// correlation: grid (NB, n), 256 threads.  Channels are streamed in chunks of CK = 8 (two MFMA k-steps); wave w stages
+// channels w and w+4 of the chunk (and a quarter of the weights) while the previous chunk is being multiplied.
+// LDS: fl[CK][CS] zero-padded feature band (channel stride CS == 16 mod 32: conflict-free ds_read_b32 of the B operand),
+//      wl[2][KK][64] weights in MFMA-A order (lane = kq*16 + f).
+// Wave w owns the 16-position tiles w, w+4, ... of the band (<= MF_NT tiles).
+// ---------------------------------------------------------------------------------------------------
+#define MF_CK 8
+#define MF_NT 4        // tiles per wave  -> a band holds <= 256 positions
+#define MF_NL 8        // staged elements per lane per channel (ceil(RS*W/64) <= 8 -> RS*W <= 512)
+
+template <int KK>
+__global__ __launch_bounds__(256) void k_mf_corr(const float* __restrict__ feat, long stride_n,
+                                                 const float* __restrict__ filt, float* __restrict__ scores, MfGeom g,
+                                                 int CS) {
+    extern __shared__ __attribute__((aligned(16))) float lds[];
+    float* __restrict__ fl = lds;                                   // [MF_CK][CS]
+    float* __restrict__ wl = lds + MF_CK * CS;                      // [2][KK][64]
+    const int band = blockIdx.x, i = blockIdx.y;
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const int kq = lane >> 4, j = lane & 15;
+    const int y0 = band * g.BR, rows = min(g.BR, g.H - y0);
+    const int RS = rows + 2 * g.p;                                  // staged rows (image rows y0-p .. y0+rows-1+p)
+    const int HW = g.H * g.W, npos = rows * g.W, ntiles = (npos + 15) >> 4;
+    const float inv_w = 1.0f / (float)g.W;
+    const float* __restrict__ fi = feat + (long)i * stride_n;
+
+    for (int e = threadIdx.x; e < MF_CK * CS; e += 256) fl[e] = 0.f;          // padding columns stay zero for good
+
+    // ---- per-lane staging plan (identical for every channel): element e = lane + 64*q of the RS x W band
+    int s_g[MF_NL], s_l[MF_NL];                                     // global offset inside a channel (-1: outside), LDS offset
+#pragma unroll
+    for (int q = 0; q < MF_NL; ++q) {
+        const int e = lane + 64 * q;
+        const int rr = mf_fdiv(e, inv_w), x = e - rr * g.W;
+        const int y = y0 - g.p + rr;
+        const bool in_band = e < RS * g.W;
+        s_g[q] = (in_band && y >= 0 && y < g.H) ? y * g.W + x : -1;
+        s_l[q] = in_band ? rr * g.PWs + x + g.p : -1;
+    }
+    // weights: element e = tid + 256*q of [2][KK][64]
+    constexpr int WN = (2 * KK * 64 + 255) / 256;
+    long w_g[WN];
+    int w_c[WN];
+    bool w_ok[WN];
+#pragma unroll
+    for (int q = 0; q < WN; ++q) {
+        const int e = threadIdx.x + 256 * q;
+        const int ln = e & 63, tk = e >> 6;                         // tk = ks*KK + tap
+        const int ks = tk / KK, tap = tk - ks * KK;
+        const int f = ln & 15, cq = ln >> 4;
+        w_ok[q] = e < 2 * KK * 64 && f < g.F;
+        w_c[q] = 4 * ks + cq;                                       // channel inside the chunk
+        w_g[q] = ((long)f * g.C + 4 * ks + cq) * KK + tap;          // + c0*KK per chunk
+    }
+
+    // ---- tile geometry of this wave
+    int t_off[MF_NT];
+    bool t_ok[MF_NT];
+#pragma unroll
+    for (int q = 0; q < MF_NT; ++q) {
+        const int pj = 16 * (wave + 4 * q) + j;
+        const int r = mf_fdiv(pj, inv_w), x = pj - r * g.W;
+        t_ok[q] = pj < npos;
+        t_off[q] = t_ok[q] ? r * g.PWs + x : 0;
+    }
+    f32x4 acc[MF_NT];
+#pragma unroll
+    for (int q = 0; q < MF_NT; ++q) acc[q] = (f32x4){0, 0, 0, 0};
+
+    float sv[2][MF_NL], wv[WN];
+    auto fetch = [&](int c0) {
+#pragma unroll
+        for (int cc = 0; cc < 2; ++cc) {
+            const int c = c0 + wave + 4 * cc;
+            const float* __restrict__ fc = fi + (long)min(c, g.C - 1) * HW;
+#pragma unroll
+            for (int q = 0; q < MF_NL; ++q) sv[cc][q] = (s_g[q] >= 0 && c < g.C) ? fc[s_g[q]] : 0.f;
+        }
+#pragma unroll
+        for (int q = 0; q < WN; ++q) wv[q] = (w_ok[q] && c0 + w_c[q] < g.C) ? filt[w_g[q] + (long)c0 * KK] : 0.f;
+    };
+    auto stage = [&]() {
+#pragma unroll
+        for (int cc = 0; cc < 2; ++cc) {
+            float* __restrict__ fc = fl + (wave + 4 * cc) * CS;
+#pragma unroll
+            for (int q = 0; q < MF_NL; ++q)
+                if (s_l[q] >= 0) fc[s_l[q]] = sv[cc][q];
+        }
+#pragma unroll
+        for (int q = 0; q < WN; ++q) {
+            const int e = threadIdx.x + 256 * q;
+            if (e < 2 * KK * 64) wl[e] = wv[q];
+        }
+    };
+
+    fetch(0);
+    __syncthreads();                                                // zero fill done
+    for (int c0 = 0; c0 < g.C; c0 += MF_CK) {
+        stage();
+        __syncthreads();
+        if (c0 + MF_CK < g.C) fetch(c0 + MF_CK);                    // next chunk in flight while this one is multiplied
+#pragma unroll
+        for (int ks = 0; ks < 2; ++ks) {
+            const float* __restrict__ fb = fl + (4 * ks + kq) * CS;
+#pragma unroll
+            for (int tap = 0; tap < KK; ++tap) {
+                const int K = KK == 1 ? 1 : (KK == 9 ? 3 : 5);
+                const int u = tap / K, v = tap - u * K;
+                const float a = wl[(ks * KK + tap) * 64 + lane];
+                const int to = u * g.PWs + v;
+#pragma unroll
+                for (int q = 0; q < MF_NT; ++q) {
+                    if (wave + 4 * q < ntiles) {                    // uniform per wave
+                        const float b = fb[t_off[q] + to];
+                        acc[q] = mfma16(a, t_ok[q] ? b : 0.f, acc[q]);
+                    }
+                }
+            }
+        }
+        __syncthreads();
+    }
+#pragma unroll
+    for (int q = 0; q < MF_NT; ++q) {
+        const int pj = 16 * (wave + 4 * q) + j;
+        if (pj < npos) {
+#pragma unroll
+            for (int r = 0; r < 4; ++r) {
+                const int f = 4 * kq + r;
+                if (f < g.F) scores[((long)i * g.F + f) * HW + (long)y0 * g.W + pj] = acc[q][r];
+            }
+        }
+    }
+}
+
+// ---------------------------------------------------------------------------------------------------
+// adjoint: grid (C/16, NSG), 256 threads.  Workgroup = 16 channels x a group of samples; per (sample, row band) it
+// stages the zero-padded feature band fl[16][CS2] and the input band rl[16][RS2] (strides == 2 mod 32: conflict-free
+// reads with 16 channels/filters x 2 positions per half-wave) and accumulates  D_tap[f][c] += in[f][pos] * feat[c][pos+tap]
+// with K = positions on the matrix cores; wave w takes the 4-position k-steps w, w+4, ...
+// Output: gpart[sg][f][c][tap] (summed over sample groups by the consumer, fixed order).
+// ---------------------------------------------------------------------------------------------------
+#define MF_AL 8        // staged elements per lane per channel / filter row
+
+template <int KK>
+__global__ __launch_bounds__(256) void k_mf_adj(const float* __restrict__ feat, long stride_n,
+                                                const float* __restrict__ inp, float* __restrict__ gpart, MfGeom g,
+                                                int CS2, int RS2, int spg) {
+    extern __shared__ __attribute__((aligned(16))) float lds[];
+    float* __restrict__ fl = lds;                                   // [16][CS2]
+    float* __restrict__ rl = lds + 16 * CS2;                        // [16][RS2]
+    float* __restrict__ red = rl + 16 * RS2;                        // [4][KK][256]
+    const int cb = blockIdx.x, sg = blockIdx.y;
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const int kq = lane >> 4, j = lane & 15;
+    const int HW = g.H * g.W;
+    const float inv_w = 1.0f / (float)g.W;
+    const int i_beg = sg * spg, i_end = min(g.n, i_beg + spg);
+    const int nst = (i_end - i_beg) * g.NB;                         // stages = (sample, band) pairs
+
+    for (int e = threadIdx.x; e < 16 * CS2; e += 256) fl[e] = 0.f;
+
+    f32x4 acc[KK];
+#pragma unroll
+    for (int t = 0; t < KK; ++t) acc[t] = (f32x4){0, 0, 0, 0};
+
+    float sv[4][MF_AL], rv[4][MF_AL];
+    auto fetch = [&](int st) {
+        const int i = i_beg + st / g.NB, band = st - (st / g.NB) * g.NB;
+        const int y0 = band * g.BR, rows = min(g.BR, g.H - y0), RS = rows + 2 * g.p;
+#pragma unroll
+        for (int cc = 0; cc < 4; ++cc) {
+            const int c = cb * 16 + wave + 4 * cc;
+            const bool cok = c < g.C;
+            const float* __restrict__ fc = feat + (long)i * stride_n + (long)min(c, g.C - 1) * HW;
+            const float* __restrict__ rc = inp + ((long)i * g.F + min(wave + 4 * cc, g.F - 1)) * HW + (long)y0 * g.W;
+            const bool fok = wave + 4 * cc < g.F;
+#pragma unroll
+            for (int q = 0; q < MF_AL; ++q) {
+                const int e = lane + 64 * q;
+                const int rr = mf_fdiv(e, inv_w), x = e - rr * g.W;
+                const int y = y0 - g.p + rr;
+                sv[cc][q] = (cok && e < RS * g.W && y >= 0 && y < g.H) ? fc[y * g.W + x] : 0.f;
+                rv[cc][q] = (e < rows * g.W && fok) ? rc[e] : 0.f;
+            }
+        }
+    };
+    auto stage = [&](int st) {
+        const int band = st - (st / g.NB) * g.NB;
+        const int y0 = band * g.BR, rows = min(g.BR, g.H - y0), RS = rows + 2 * g.p;
+#pragma unroll
+        for (int cc = 0; cc < 4; ++cc) {
+            float* __restrict__ fc = fl + (wave + 4 * cc) * CS2;
+            float* __restrict__ rc = rl + (wave + 4 * cc) * RS2;
+#pragma unroll
+            for (int q = 0; q < MF_AL; ++q) {
+                const int e = lane + 64 * q;
+                const int rr = mf_fdiv(e, inv_w), x = e - rr * g.W;
+                if (e < g.RSmax * g.W) fc[rr * g.PWs + x + g.p] = e < RS * g.W ? sv[cc][q] : 0.f;   // short last band: clear
+                if (e < g.BR * g.W) rc[e] = rv[cc][q];
+            }
+        }
+    };
+
+    if (nst > 0) fetch(0);
+    __syncthreads();
+    for (int st = 0; st < nst; ++st) {
+        stage(st);
+        __syncthreads();
+        if (st + 1 < nst) fetch(st + 1);
+        const int band = st - (st / g.NB) * g.NB;
+        const int rows = min(g.BR, g.H - band * g.BR), npos = rows * g.W;
+        const float* __restrict__ fb = fl + j * CS2;
+        const float* __restrict__ rb = rl + j * RS2;
+        for (int s = wave; 4 * s < npos; s += 4) {
+            const int pos = 4 * s + kq;
+            const bool ok = pos < npos;
+            const int pc = ok ? pos : 0;
+            const int r = mf_fdiv(pc, inv_w), x = pc - r * g.W;
+            const float av = rb[pc];
+            const float a = ok ? av : 0.f;
+            const int po = r * g.PWs + x;
+#pragma unroll
+            for (int tap = 0; tap < KK; ++tap) {
+                const int K = KK == 1 ? 1 : (KK == 9 ? 3 : 5);
+                const int u = tap / K, v = tap - u * K;
+                const float b = fb[po + u * g.PWs + v];
+                acc[tap] = mfma16(a, b, acc[tap]);                  // masked k: a = 0, b finite (LDS holds data or zeros)
+            }
+        }
+        __syncthreads();
+    }
+    // ---- cross-wave reduction, fixed order
+#pragma unroll
+    for (int tap = 0; tap < KK; ++tap)
+#pragma unroll
+        for (int r = 0; r < 4; ++r) red[(wave * KK + tap) * 256 + (4 * kq + r) * 16 + j] = acc[tap][r];
+    __syncthreads();
+    for (int e = threadIdx.x; e < KK * 256; e += 256) {
+        const int tap = e >> 8, fc = e & 255, f = fc >> 4, c = fc & 15;
+        float s = 0.f;
+#pragma unroll
+        for (int w = 0; w < 4; ++w) s += red[(w * KK + tap) * 256 + fc];
+        if (f < g.F && cb * 16 + c < g.C) gpart[(((long)sg * g.F + f) * g.C + cb * 16 + c) * KK + tap] = s;
+    }
+}
+
+// ---------------------------------------------------------------------------------------------------
+// host side
+// ---------------------------------------------------------------------------------------------------
+struct MfPlan {
+    int ok;
+    MfGeom g;
+    int CS, CS2, RS2, spg, NSG;
+    size_t corr_lds, adj_lds;
+};
+
+static int mf_pad_to(int v, int mod, int res) {          // smallest x >= v with x % mod == res
+    int x = v;
+    while ((x % mod) != res) ++x;
+    return x;
+}
+
+static MfPlan mf_plan(int n, int F, int C, int H, int W, int K) {
+    MfPlan p;
+    p.ok = 0;
+    if (n <= 0 || F <= 0 || F > 16 || C <= 0 || H <= 0 || W <= 0) return p;
+    if (K != 1 && K != 3) return p;
+    MfGeom& g = p.g;
+    g.n = n; g.F = F; g.C = C; g.H = H; g.W = W; g.K = K; g.p = K / 2; g.KK = K * K;
+    if (W > 256) return p;
+    int BR = 256 / W;                                    // <= MF_NT * 64 positions per band
+    if (BR > H) BR = H;
+    while (BR > 1 && (BR + K - 1) * W > 64 * MF_NL) --BR;  // staged rows must fit the per-lane staging plan
+    if ((BR + K - 1) * W > 64 * MF_NL || BR * W > 256) return p;
+    g.BR = BR;
+    g.NB = (H + BR - 1) / BR;
+    g.PWs = W + K - 1;
+    g.RSmax = BR + K - 1;
+    p.CS = mf_pad_to(g.RSmax * g.PWs, 32, 16);
+    p.CS2 = mf_pad_to(g.RSmax * g.PWs, 32, 2);
+    p.RS2 = mf_pad_to(BR * W, 32, 2);
+    p.corr_lds = ((size_t)MF_CK * p.CS + 2 * g.KK * 64) * sizeof(float);
+    p.adj_lds = ((size_t)16 * p.CS2 + 16 * p.RS2 + 4 * g.KK * 256) * sizeof(float);
+    // sample groups of the adjoint: aim for ~256 workgroups
+    const int CBn = (C + 15) / 16;
+    int NSG = 256 / CBn;
+    if (NSG < 1) NSG = 1;
+    if (NSG > n) NSG = n;
+    if (NSG > 16) NSG = 16;
+    p.spg = (n + NSG - 1) / NSG;
+    p.NSG = (n + p.spg - 1) / p.spg;
+    if (p.corr_lds > 150 * 1024 || p.adj_lds > 150 * 1024) return p;
+    p.ok = 1;
+    return p;
+}
+
+size_t pt_mf_gpart_floats(int n, int F, int C, int H, int W, int K) {
+    MfPlan p = mf_plan(n, F, C, H, W, K);
+    return p.ok ? (size_t)p.NSG * F * C * K * K : 0;
+}
+int pt_mf_groups(int n, int F, int C, int H, int W, int K) {
+    MfPlan p = mf_plan(n, F, C, H, W, K);
+    return p.ok ? p.NSG : 0;
+}
+
+int pt_launch_mf_corr(const float* feat, long stride_n, const float* filt, float* scores, int n, int F, int C, int H,
+                      int W, int K, hipStream_t st) {
+    MfPlan p = mf_plan(n, F, C, H, W, K);
+    if (!p.ok) return PT_ERR_UNSUPPORTED;
+    dim3 grid(p.g.NB, n), block(256);
+    pt_prof_begin(0, st);
+    if (K == 1) hipLaunchKernelGGL((k_mf_corr<1>), grid, block, p.corr_lds, st, feat, stride_n, filt, scores, p.g, p.CS);
+    else hipLaunchKernelGGL((k_mf_corr<9>), grid, block, p.corr_lds, st, feat, stride_n, filt, scores, p.g, p.CS);
+    pt_prof_end(0, st);
+    PT_CHECK_LAUNCH();
+    return PT_OK;
+}
+
+int pt_launch_mf_adj(const float* feat, long stride_n, const float* inp, float* gpart, int n, int F, int C, int H, int W,
+                     int K, hipStream_t st) {
+    MfPlan p = mf_plan(n, F, C, H, W, K);
+    if (!p.ok) return PT_ERR_UNSUPPORTED;
+    dim3 grid((C + 15) / 16, p.NSG), block(256);
+    pt_prof_begin(1, st);
+    if (K == 1) hipLaunchKernelGGL((k_mf_adj<1>), grid, block, p.adj_lds, st, feat, stride_n, inp, gpart, p.g, p.CS2, p.RS2, p.spg);
+    else hipLaunchKernelGGL((k_mf_adj<9>), grid, block, p.adj_lds, st, feat, stride_n, inp, gpart, p.g, p.CS2, p.RS2, p.spg);
+    pt_prof_end(1, st);
+    PT_CHECK_LAUNCH();
+    return PT_OK;
+}

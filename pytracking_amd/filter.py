@@ -88,6 +88,76 @@ def adj_raw(feat4, inp3, ksz):
     return out
 
 
+def corr_mf_raw(feat4, filt4):
+    """feat4 (n,C,H,W), filt4 (F,C,K,K) -> (n,F,H,W)   (multi-filter branch of apply_filter, filter.py:29-34)."""
+    n, C, H, W = feat4.shape
+    Fn, C2, KH, KW = filt4.shape
+    assert C == C2 and KH == KW
+    if feat4.stride()[1:] != (H * W, W, 1):
+        feat4 = feat4.contiguous()
+    filt4 = filt4.contiguous()
+    out = torch.empty((n, Fn, H, W), dtype=torch.float32, device=feat4.device)
+    rc = _lib.lib().pt_apply_filter_mf_f32(_ptr(feat4), feat4.stride(0), _ptr(filt4), _ptr(out), n, Fn, C, H, W, KH,
+                                           _stream())
+    _lib.check(rc, "pt_apply_filter_mf_f32")
+    return out
+
+
+def adj_mf_raw(feat4, inp4, ksz):
+    """feat4 (n,C,H,W), inp4 (n,F,H,W) -> (F,C,K,K)   (5-D input branch of apply_feat_transpose, filter.py:158-176)."""
+    n, C, H, W = feat4.shape
+    Fn = inp4.shape[1]
+    KH, KW = ksz
+    assert KH == KW and inp4.shape[-2:] == (H, W)
+    if feat4.stride()[1:] != (H * W, W, 1):
+        feat4 = feat4.contiguous()
+    inp4 = inp4.contiguous()
+    L = _lib.lib()
+    out = torch.empty((Fn, C, KH, KW), dtype=torch.float32, device=feat4.device)
+    nb = L.pt_feat_transpose_mf_ws_bytes(n, Fn, C, H, W, KH)
+    if nb == 0:
+        raise RuntimeError("multi-filter apply_feat_transpose: configuration not covered by the gfx950 kernels")
+    ws = workspace(nb, feat4.device)
+    rc = L.pt_feat_transpose_mf_f32(_ptr(feat4), feat4.stride(0), _ptr(inp4), _ptr(out), n, Fn, C, H, W, KH, _ptr(ws),
+                                    ws.numel(), _stream())
+    _lib.check(rc, "pt_feat_transpose_mf_f32")
+    return out
+
+
+class _ApplyFilterMF(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, feat, filt):
+        f5 = _as5d(feat)
+        S = f5.shape[1]
+        scores = torch.stack([corr_mf_raw(f5[:, s], filt[s]) for s in range(S)], dim=1)
+        ctx.save_for_backward(feat, filt)
+        return scores
+
+    @staticmethod
+    def backward(ctx, grad):
+        feat, filt = ctx.saved_tensors
+        if ctx.needs_input_grad[0]:
+            raise NotImplementedError("gradient of apply_filter w.r.t. the features (training path) is out of scope")
+        return None, _ApplyFeatTransposeMF.apply(feat, grad, tuple(filt.shape[-2:]))
+
+
+class _ApplyFeatTransposeMF(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, feat, inp, ksz):
+        f5 = _as5d(feat)
+        S = f5.shape[1]
+        out = torch.stack([adj_mf_raw(f5[:, s], inp[:, s], ksz) for s in range(S)], dim=0)
+        ctx.save_for_backward(feat)
+        return out
+
+    @staticmethod
+    def backward(ctx, grad):
+        (feat,) = ctx.saved_tensors
+        if ctx.needs_input_grad[0]:
+            raise NotImplementedError("gradient of apply_feat_transpose w.r.t. the features is out of scope")
+        return None, _ApplyFilterMF.apply(feat, grad), None
+
+
 def _as5d(feat):
     return feat if feat.dim() == 5 else feat.unsqueeze(1)
 
@@ -131,9 +201,12 @@ class _ApplyFeatTranspose(torch.autograd.Function):
 def apply_filter(feat, filter, dilation_factors=None):
     """Cross-correlate each sequence's filter with its features (reference: filter.py:5-57)."""
     _require_device(feat, filter)
-    if filter.dim() == 5 or dilation_factors is not None:
-        raise NotImplementedError("multi-filter / dilated apply_filter (LWL, filter.py:29-52) is a later SURVEY 8 row")
+    if dilation_factors is not None:
+        raise NotImplementedError("dilated apply_filter (filter.py:35-52) is not on the hot path")
     num_sequences = feat.shape[1] if feat.dim() == 5 else 1
+    if filter.dim() == 5:                                   # (sequences, filters, feat_dim, fH, fW), filter.py:29-34
+        assert filter.shape[0] == num_sequences and feat.shape[-3] == filter.shape[-3], "groups != 1 is not covered"
+        return _ApplyFilterMF.apply(feat, filter)
     assert filter.shape[0] == num_sequences and feat.shape[-3] == filter.shape[-3]
     return _ApplyFilter.apply(feat, filter)
 
@@ -144,10 +217,10 @@ def apply_feat_transpose(feat, input, filter_ksz, training=True, groups=1):
     if groups != 1:
         raise NotImplementedError('Not implemented other values of group.')
     _require_device(feat, input)
-    if input.dim() == 5:
-        raise NotImplementedError("multi-filter apply_feat_transpose (filter.py:158-182) is a later SURVEY 8 row")
     if isinstance(filter_ksz, int):
         filter_ksz = (filter_ksz, filter_ksz)
+    if input.dim() == 5:                                    # (images, sequences, filters, H, W), filter.py:158-176
+        return _ApplyFeatTransposeMF.apply(feat, input, tuple(filter_ksz))
     return _ApplyFeatTranspose.apply(feat, input, tuple(filter_ksz))
 
 

@@ -127,3 +127,17 @@ def test_torch_port_matches_reference():
     with torch.no_grad():
         w = tr.solve(tr.filter, tr.mem_feat, tr.mem_bb, tr.sw, 5)
     close(w[0].numpy(), g["iterates"][-1], atol=2e-6)
+
+
+@pytest.mark.parametrize("name", ["lwl_gn_small_full", "lwl_gn_small_img", "lwl_gn_small_none", "lwl_gn_mid"])
+def test_lwl_gn_sd(name):
+    """LWL few-shot learner (GNSteepestDescent on LWTLResidual, steepestdescent.py:32-105) vs the reference run."""
+    g = load_golden(name)
+    sw = g["sw"] if g["sw"].size else None
+    its, losses = O.lwl_gn_sd(g["w0"].astype(np.float64), g["feat"].astype(np.float64), g["label"].astype(np.float64),
+                              None if sw is None else sw.astype(np.float64), num_iter=int(g["num_iter"]),
+                              filter_reg=float(g["filter_reg"]), steplength_reg=float(g["steplength_reg"]))
+    np.testing.assert_allclose(its, g["iterates"], atol=2e-5)
+    np.testing.assert_allclose(np.array(losses), g["losses"], rtol=1e-4, atol=1e-7)
+    s = O.apply_filter(g["feat"].astype(np.float64), its[-1])
+    np.testing.assert_allclose(s, g["scores"], atol=2e-5)
