@@ -23,14 +23,19 @@ struct MfGeom {
 __device__ __forceinline__ int mf_fdiv(int v, float inv_d) { return (int)(((float)v + 0.5f) * inv_d); }
 
 // ---------------------------------------------------------------------------------------------------
-// correlation: grid (NB, n), 256 threads.  Channels are streamed in chunks of CK = 8 (two MFMA k-steps); wave w stages
-// channels w and w+4 of the chunk (and a quarter of the weights) while the previous chunk is being multiplied.
+// correlation: grid (NB, n), 256 threads.  Channels are streamed in chunks of MF_CK (MF_KS MFMA k-steps); wave w stages
+// channels w, w+4, ... of the chunk (and a quarter of the weights) while the previous chunk is being multiplied.
 // LDS: fl[CK][CS] zero-padded feature band (channel stride CS == 16 mod 32: conflict-free ds_read_b32 of the B operand),
-//      wl[2][KK][64] weights in MFMA-A order (lane = kq*16 + f).
+//      wl[MF_KS][KK][64] weights in MFMA-A order (lane = kq*16 + f).
 // Wave w owns the 16-position tiles w, w+4, ... of the band (<= MF_NT tiles).
 // ---------------------------------------------------------------------------------------------------
-#define MF_CK 8
+#define MF_CK 32       // channels per staged chunk (8 MFMA k-steps: ~290 MFMAs per wave hide the next chunk's load latency)
+#define MF_KS (MF_CK / 4)
+#define MF_CW (MF_CK / 4)  // channels staged per wave
 #define MF_NT 4        // tiles per wave  -> a band holds <= 256 positions
+#ifndef PT_MFABL
+#define PT_MFABL 0     // experiments only: 1 = no MFMA, 2 = no B reads from LDS, 4 = no global fetch, 8 = no LDS staging writes
+#endif
 #define MF_NL 8        // staged elements per lane per channel (ceil(RS*W/64) <= 8 -> RS*W <= 512)
 
 template <int KK>
@@ -39,7 +44,7 @@ __global__ __launch_bounds__(256) void k_mf_corr(const float* __restrict__ feat,
                                                  int CS) {
     extern __shared__ __attribute__((aligned(16))) float lds[];
     float* __restrict__ fl = lds;                                   // [MF_CK][CS]
-    float* __restrict__ wl = lds + MF_CK * CS;                      // [2][KK][64]
+    float* __restrict__ wl = lds + MF_CK * CS;                      // [MF_KS][KK][64]
     const int band = blockIdx.x, i = blockIdx.y;
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
     const int kq = lane >> 4, j = lane & 15;
@@ -62,8 +67,8 @@ __global__ __launch_bounds__(256) void k_mf_corr(const float* __restrict__ feat,
         s_g[q] = (in_band && y >= 0 && y < g.H) ? y * g.W + x : -1;
         s_l[q] = in_band ? rr * g.PWs + x + g.p : -1;
     }
-    // weights: element e = tid + 256*q of [2][KK][64]
-    constexpr int WN = (2 * KK * 64 + 255) / 256;
+    // weights: element e = tid + 256*q of [MF_KS][KK][64]
+    constexpr int WN = (MF_KS * KK * 64 + 255) / 256;
     long w_g[WN];
     int w_c[WN];
     bool w_ok[WN];
@@ -73,7 +78,7 @@ __global__ __launch_bounds__(256) void k_mf_corr(const float* __restrict__ feat,
         const int ln = e & 63, tk = e >> 6;                         // tk = ks*KK + tap
         const int ks = tk / KK, tap = tk - ks * KK;
         const int f = ln & 15, cq = ln >> 4;
-        w_ok[q] = e < 2 * KK * 64 && f < g.F;
+        w_ok[q] = e < MF_KS * KK * 64 && f < g.F;
         w_c[q] = 4 * ks + cq;                                       // channel inside the chunk
         w_g[q] = ((long)f * g.C + 4 * ks + cq) * KK + tap;          // + c0*KK per chunk
     }
@@ -92,21 +97,28 @@ __global__ __launch_bounds__(256) void k_mf_corr(const float* __restrict__ feat,
 #pragma unroll
     for (int q = 0; q < MF_NT; ++q) acc[q] = (f32x4){0, 0, 0, 0};
 
-    float sv[2][MF_NL], wv[WN];
+    float sv[MF_CW][MF_NL], wv[WN];
     auto fetch = [&](int c0) {
 #pragma unroll
-        for (int cc = 0; cc < 2; ++cc) {
+        for (int cc = 0; cc < MF_CW; ++cc) {
             const int c = c0 + wave + 4 * cc;
             const float* __restrict__ fc = fi + (long)min(c, g.C - 1) * HW;
 #pragma unroll
-            for (int q = 0; q < MF_NL; ++q) sv[cc][q] = (s_g[q] >= 0 && c < g.C) ? fc[s_g[q]] : 0.f;
+            for (int q = 0; q < MF_NL; ++q) {                       // straight-line: clamped address, select afterwards
+                const float v = fc[max(s_g[q], 0)];
+                sv[cc][q] = (s_g[q] >= 0 && c < g.C) ? v : 0.f;
+            }
         }
 #pragma unroll
-        for (int q = 0; q < WN; ++q) wv[q] = (w_ok[q] && c0 + w_c[q] < g.C) ? filt[w_g[q] + (long)c0 * KK] : 0.f;
+        for (int q = 0; q < WN; ++q) {
+            const bool ok = w_ok[q] && c0 + w_c[q] < g.C;
+            const float v = filt[ok ? w_g[q] + (long)c0 * KK : 0];
+            wv[q] = ok ? v : 0.f;
+        }
     };
     auto stage = [&]() {
 #pragma unroll
-        for (int cc = 0; cc < 2; ++cc) {
+        for (int cc = 0; cc < MF_CW; ++cc) {
             float* __restrict__ fc = fl + (wave + 4 * cc) * CS;
 #pragma unroll
             for (int q = 0; q < MF_NL; ++q)
@@ -115,31 +127,38 @@ __global__ __launch_bounds__(256) void k_mf_corr(const float* __restrict__ feat,
 #pragma unroll
         for (int q = 0; q < WN; ++q) {
             const int e = threadIdx.x + 256 * q;
-            if (e < 2 * KK * 64) wl[e] = wv[q];
+            if (e < MF_KS * KK * 64) wl[e] = wv[q];
         }
     };
 
     fetch(0);
     __syncthreads();                                                // zero fill done
     for (int c0 = 0; c0 < g.C; c0 += MF_CK) {
-        stage();
+        if (!(PT_MFABL & 8) || c0 == 0) stage();
         __syncthreads();
-        if (c0 + MF_CK < g.C) fetch(c0 + MF_CK);                    // next chunk in flight while this one is multiplied
+        if (c0 + MF_CK < g.C && !(PT_MFABL & 4)) fetch(c0 + MF_CK);   // next chunk in flight while this one is multiplied
 #pragma unroll
-        for (int ks = 0; ks < 2; ++ks) {
+        for (int ks = 0; ks < MF_KS; ++ks) {
             const float* __restrict__ fb = fl + (4 * ks + kq) * CS;
+            constexpr int K = KK == 1 ? 1 : (KK == 9 ? 3 : 5);
+            // all LDS operands of this k-step first (KK A values, KK x MF_NT B values), then the MFMAs: one wait per
+            // k-step instead of one per MFMA (a workgroup has a single wave per SIMD, nothing else hides LDS latency)
+            float av[KK], bv[KK][MF_NT];
 #pragma unroll
             for (int tap = 0; tap < KK; ++tap) {
-                const int K = KK == 1 ? 1 : (KK == 9 ? 3 : 5);
                 const int u = tap / K, v = tap - u * K;
-                const float a = wl[(ks * KK + tap) * 64 + lane];
-                const int to = u * g.PWs + v;
+                av[tap] = wl[(ks * KK + tap) * 64 + lane];
+#pragma unroll
+                for (int q = 0; q < MF_NT; ++q) bv[tap][q] = (PT_MFABL & 2) ? av[tap] : fb[t_off[q] + u * g.PWs + v];
+            }
+#pragma unroll
+            for (int tap = 0; tap < KK; ++tap) {
 #pragma unroll
                 for (int q = 0; q < MF_NT; ++q) {
-                    if (wave + 4 * q < ntiles) {                    // uniform per wave
-                        const float b = fb[t_off[q] + to];
-                        acc[q] = mfma16(a, t_ok[q] ? b : 0.f, acc[q]);
-                    }
+                    if (PT_MFABL & 1) { acc[q][0] += av[tap] * bv[tap][q]; continue; }
+                    // no per-tile branch: a tile beyond the band multiplies zeros (t_ok false), which is cheaper than
+                    // putting every MFMA into its own basic block
+                    acc[q] = mfma16(av[tap], t_ok[q] ? bv[tap][q] : 0.f, acc[q]);
                 }
             }
         }
@@ -205,8 +224,10 @@ __global__ __launch_bounds__(256) void k_mf_adj(const float* __restrict__ feat, 
                 const int e = lane + 64 * q;
                 const int rr = mf_fdiv(e, inv_w), x = e - rr * g.W;
                 const int y = y0 - g.p + rr;
-                sv[cc][q] = (cok && e < RS * g.W && y >= 0 && y < g.H) ? fc[y * g.W + x] : 0.f;
-                rv[cc][q] = (e < rows * g.W && fok) ? rc[e] : 0.f;
+                const bool fin = cok && e < RS * g.W && y >= 0 && y < g.H, rin = e < rows * g.W && fok;
+                const float fvv = fc[fin ? y * g.W + x : 0], rvv = rc[rin ? e : 0];    // straight-line loads
+                sv[cc][q] = fin ? fvv : 0.f;
+                rv[cc][q] = rin ? rvv : 0.f;
             }
         }
     };
@@ -237,6 +258,7 @@ __global__ __launch_bounds__(256) void k_mf_adj(const float* __restrict__ feat, 
         const int rows = min(g.BR, g.H - band * g.BR), npos = rows * g.W;
         const float* __restrict__ fb = fl + j * CS2;
         const float* __restrict__ rb = rl + j * RS2;
+#pragma unroll 2
         for (int s = wave; 4 * s < npos; s += 4) {
             const int pos = 4 * s + kq;
             const bool ok = pos < npos;
@@ -245,13 +267,13 @@ __global__ __launch_bounds__(256) void k_mf_adj(const float* __restrict__ feat, 
             const float av = rb[pc];
             const float a = ok ? av : 0.f;
             const int po = r * g.PWs + x;
+            constexpr int K = KK == 1 ? 1 : (KK == 9 ? 3 : 5);
+            float bv[KK];
 #pragma unroll
-            for (int tap = 0; tap < KK; ++tap) {
-                const int K = KK == 1 ? 1 : (KK == 9 ? 3 : 5);
-                const int u = tap / K, v = tap - u * K;
-                const float b = fb[po + u * g.PWs + v];
-                acc[tap] = mfma16(a, b, acc[tap]);                  // masked k: a = 0, b finite (LDS holds data or zeros)
-            }
+            for (int tap = 0; tap < KK; ++tap) bv[tap] = fb[po + (tap / K) * g.PWs + (tap % K)];
+#pragma unroll
+            for (int tap = 0; tap < KK; ++tap)
+                acc[tap] = mfma16(a, bv[tap], acc[tap]);            // masked k: a = 0, b finite (LDS holds data or zeros)
         }
         __syncthreads();
     }
@@ -275,7 +297,8 @@ __global__ __launch_bounds__(256) void k_mf_adj(const float* __restrict__ feat, 
 // ---------------------------------------------------------------------------------------------------
 struct MfPlan {
     int ok;
-    MfGeom g;
+    MfGeom g;            // correlation: band <= 256 positions (MF_NT tiles per wave)
+    MfGeom ga;           // adjoint: band as tall as the staging plan allows (fewer, longer stages)
     int CS, CS2, RS2, spg, NSG;
     size_t corr_lds, adj_lds;
 };
@@ -302,10 +325,16 @@ static MfPlan mf_plan(int n, int F, int C, int H, int W, int K) {
     g.NB = (H + BR - 1) / BR;
     g.PWs = W + K - 1;
     g.RSmax = BR + K - 1;
+    p.ga = g;
+    int BRa = H;
+    while (BRa > 1 && (BRa + K - 1) * W > 64 * MF_AL) --BRa;
+    p.ga.BR = BRa;
+    p.ga.NB = (H + BRa - 1) / BRa;
+    p.ga.RSmax = BRa + K - 1;
     p.CS = mf_pad_to(g.RSmax * g.PWs, 32, 16);
-    p.CS2 = mf_pad_to(g.RSmax * g.PWs, 32, 2);
-    p.RS2 = mf_pad_to(BR * W, 32, 2);
-    p.corr_lds = ((size_t)MF_CK * p.CS + 2 * g.KK * 64) * sizeof(float);
+    p.CS2 = mf_pad_to(p.ga.RSmax * g.PWs, 32, 2);
+    p.RS2 = mf_pad_to(BRa * W, 32, 2);
+    p.corr_lds = ((size_t)MF_CK * p.CS + MF_KS * g.KK * 64) * sizeof(float);
     p.adj_lds = ((size_t)16 * p.CS2 + 16 * p.RS2 + 4 * g.KK * 256) * sizeof(float);
     // sample groups of the adjoint: aim for ~256 workgroups
     const int CBn = (C + 15) / 16;
@@ -348,8 +377,8 @@ int pt_launch_mf_adj(const float* feat, long stride_n, const float* inp, float* 
     if (!p.ok) return PT_ERR_UNSUPPORTED;
     dim3 grid((C + 15) / 16, p.NSG), block(256);
     pt_prof_begin(1, st);
-    if (K == 1) hipLaunchKernelGGL((k_mf_adj<1>), grid, block, p.adj_lds, st, feat, stride_n, inp, gpart, p.g, p.CS2, p.RS2, p.spg);
-    else hipLaunchKernelGGL((k_mf_adj<9>), grid, block, p.adj_lds, st, feat, stride_n, inp, gpart, p.g, p.CS2, p.RS2, p.spg);
+    if (K == 1) hipLaunchKernelGGL((k_mf_adj<1>), grid, block, p.adj_lds, st, feat, stride_n, inp, gpart, p.ga, p.CS2, p.RS2, p.spg);
+    else hipLaunchKernelGGL((k_mf_adj<9>), grid, block, p.adj_lds, st, feat, stride_n, inp, gpart, p.ga, p.CS2, p.RS2, p.spg);
     pt_prof_end(1, st);
     PT_CHECK_LAUNCH();
     return PT_OK;

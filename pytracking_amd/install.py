@@ -12,6 +12,8 @@ What gets rebound (import path = contract; nothing in the reference tree is edit
   ltr.external.PreciseRoIPooling.pytorch.prroi_pool.PrRoIPool2D  (module is CREATED: the submodule is empty)
                                                                                       -> pytracking_amd.prroi_pool
   pytracking.libs.optimization.ConjugateGradient  (ConvProblem + MLU fast path)       -> pytracking_amd.optimization
+  ltr.models.lwl.loss_residual_modules.LWTLResidual, ltr.models.meta.steepestdescent.GNSteepestDescent
+                                                  (LWL few-shot learner)              -> pytracking_amd.steepestdescent
 
 Dispatch rule of the rebound *functions*: device fp32 tensors of a shape the gfx950 kernels cover go to the C ABI;
 everything else (CPU tensors, multi-filter LWL filters, dilations, K*K > 16) is outside SURVEY section 8's scope and
@@ -29,13 +31,19 @@ from . import filter as _filter
 from . import optimization as _optimization
 from . import optimizer as _optimizer
 from . import prroi_pool as _prroi
+from . import steepestdescent as _sd
 
 _state = {"installed": False, "originals": {}}
 
 
 def _covered(feat, filt, dilation_factors=None):
-    return (isinstance(feat, torch.Tensor) and feat.is_cuda and feat.dtype == torch.float32 and filt.is_cuda
-            and filt.dim() == 4 and dilation_factors is None and filt.shape[-1] * filt.shape[-2] <= 16)
+    if not (isinstance(feat, torch.Tensor) and feat.is_cuda and feat.dtype == torch.float32 and filt.is_cuda
+            and dilation_factors is None):
+        return False
+    if filt.dim() == 5:                                  # multi-filter (LWL): <= 16 filters, 1x1 / 3x3, groups == 1
+        return (filt.shape[1] <= 16 and filt.shape[-1] == filt.shape[-2] and filt.shape[-1] in (1, 3)
+                and filt.shape[-3] == feat.shape[-3] and feat.shape[-1] <= 256)
+    return filt.dim() == 4 and filt.shape[-1] * filt.shape[-2] <= 16
 
 
 def _make_dispatchers(orig_mod, strict):
@@ -50,7 +58,8 @@ def _make_dispatchers(orig_mod, strict):
 
     def apply_feat_transpose(feat, input, filter_ksz, training=True, groups=1):
         ksz = (filter_ksz, filter_ksz) if isinstance(filter_ksz, int) else tuple(filter_ksz)
-        if feat.is_cuda and feat.dtype == torch.float32 and input.dim() == 4 and groups == 1 and ksz[0] * ksz[1] <= 16:
+        mf = input.dim() == 5 and input.shape[2] <= 16 and ksz[0] == ksz[1] and ksz[0] in (1, 3) and feat.shape[-1] <= 256
+        if feat.is_cuda and feat.dtype == torch.float32 and groups == 1 and (mf or (input.dim() == 4 and ksz[0] * ksz[1] <= 16)):
             return _filter.apply_feat_transpose(feat, input, ksz, training=training, groups=groups)
         if strict:
             raise NotImplementedError("apply_feat_transpose: configuration outside the gfx950 hot path")
@@ -106,6 +115,27 @@ def install(strict=False, atom_cg=True):
     orig["optimizer"] = tuple(getattr(omod, n) for n in names)
     for n in names:
         setattr(omod, n, getattr(_optimizer, n))
+    # LWL few-shot learner: the residual module is replaced outright (same parameters); the generic optimiser class
+    # dispatches on it so that other residual modules (RTS, dimp_simple) keep the reference implementation
+    try:
+        rmod = importlib.import_module("ltr.models.lwl.loss_residual_modules")
+        smod = importlib.import_module("ltr.models.meta.steepestdescent")
+    except Exception:
+        rmod = smod = None
+    if rmod is not None:
+        orig["lwl"] = (rmod.LWTLResidual, smod.GNSteepestDescent)
+        ref_gn = smod.GNSteepestDescent
+
+        class GNSteepestDescent(ref_gn):
+            """LWTLResidual (gfx950 mirror) -> fused solver; any other residual module -> the reference class."""
+
+            def __new__(cls, residual_module=None, *args, **kw):
+                if isinstance(residual_module, _sd.LWTLResidual) and kw.get("residual_batch_dim", 0) == 1:
+                    return _sd.GNSteepestDescent(residual_module, *args, **kw)
+                return ref_gn.__new__(cls)
+
+        rmod.LWTLResidual = _sd.LWTLResidual
+        smod.GNSteepestDescent = GNSteepestDescent
     if atom_cg:
         try:
             pmod = importlib.import_module("pytracking.libs.optimization")
@@ -148,5 +178,8 @@ def uninstall():
         setattr(omod, n, c)
     if "cg" in orig:
         importlib.import_module("pytracking.libs.optimization").ConjugateGradient = orig["cg"]
+    if "lwl" in orig:
+        importlib.import_module("ltr.models.lwl.loss_residual_modules").LWTLResidual = orig["lwl"][0]
+        importlib.import_module("ltr.models.meta.steepestdescent").GNSteepestDescent = orig["lwl"][1]
     _state["installed"] = False
     orig.clear()
