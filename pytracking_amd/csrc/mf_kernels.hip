@@ -10,6 +10,7 @@
 // (v_mfma_f32_16x16x4_f32, exact fp32), the MFMA-bound rows of SURVEY.md section 8 (LWL: 7.4 GFLOP per pass at n = 32,
 // 47 us at the 157 TFLOP/s fp32 matrix peak vs 13 us of HBM time).  Feature tiles are staged in LDS with their zero
 // padding (row band + halo), so the K*K shifted operands are LDS reads at a constant offset instead of global re-reads.
+#include <algorithm>
 #include "common.h"
 #include "pt_internal.h"
 
@@ -20,99 +21,118 @@ struct MfGeom {
     int RSmax;           // staged rows per band (BR + K - 1)
 };
 
+#ifndef PT_MFABL
+#define PT_MFABL 0     // experiments only: 1 = no MFMA, 4 = no global fetch
+#endif
+
 __device__ __forceinline__ int mf_fdiv(int v, float inv_d) { return (int)(((float)v + 0.5f) * inv_d); }
+
+// Staging plan of one lane for a (rows x W) block that is contiguous in global memory (full-width rows): item q covers
+// VW consecutive floats starting at e = VW*(lane + 64*q).  VW = 4 needs W % 4 == 0 (an item never straddles a row).
+template <int VW, int NQ>
+struct MfStage {
+    int g[NQ];           // float offset inside the channel / filter plane, or -1
+    int l[NQ];           // LDS float offset of the first element
+    __device__ __forceinline__ void plan(int lane, int first_row, int nrows, int W, float inv_w, int lds_row0, int lds_stride,
+                                         int lds_col0) {
+#pragma unroll
+        for (int q = 0; q < NQ; ++q) {
+            const int e = VW * (lane + 64 * q);
+            const int rr = mf_fdiv(e, inv_w), x = e - rr * W;
+            const bool ok = e < nrows * W;
+            g[q] = ok ? (first_row + rr) * W + x : -1;
+            l[q] = (lds_row0 + rr) * lds_stride + x + lds_col0;
+        }
+    }
+};
 
 // ---------------------------------------------------------------------------------------------------
 // correlation: grid (NB, n), 256 threads.  Channels are streamed in chunks of MF_CK (MF_KS MFMA k-steps); wave w stages
 // channels w, w+4, ... of the chunk (and a quarter of the weights) while the previous chunk is being multiplied.
-// LDS: fl[CK][CS] zero-padded feature band (channel stride CS == 16 mod 32: conflict-free ds_read_b32 of the B operand),
+// LDS: fl[MF_CK][CS] zero-padded feature band (channel stride CS == 16 mod 32: conflict-free ds_read_b32 of the B operand),
 //      wl[MF_KS][KK][64] weights in MFMA-A order (lane = kq*16 + f).
-// Wave w owns the 16-position tiles w, w+4, ... of the band (<= MF_NT tiles).
+// Wave w owns the 16-position tiles w, w+4, ... of the band (NT per wave).  The band height is chosen so that the grid
+// holds >= 2 workgroups per CU: a workgroup puts one wave on each SIMD, the second one hides its LDS / barrier latency.
 // ---------------------------------------------------------------------------------------------------
-#define MF_CK 32       // channels per staged chunk (8 MFMA k-steps: ~290 MFMAs per wave hide the next chunk's load latency)
+#define MF_CK 32
 #define MF_KS (MF_CK / 4)
 #define MF_CW (MF_CK / 4)  // channels staged per wave
-#define MF_NT 4        // tiles per wave  -> a band holds <= 256 positions
-#ifndef PT_MFABL
-#define PT_MFABL 0     // experiments only: 1 = no MFMA, 2 = no B reads from LDS, 4 = no global fetch, 8 = no LDS staging writes
-#endif
-#define MF_NL 8        // staged elements per lane per channel (ceil(RS*W/64) <= 8 -> RS*W <= 512)
+#define MF_NQ 8            // scalar staging items per lane per plane: rows*W <= 512
 
-template <int KK>
+template <int KK, int NT, int VW>
 __global__ __launch_bounds__(256) void k_mf_corr(const float* __restrict__ feat, long stride_n,
                                                  const float* __restrict__ filt, float* __restrict__ scores, MfGeom g,
                                                  int CS) {
     extern __shared__ __attribute__((aligned(16))) float lds[];
+    constexpr int NQ = MF_NQ / VW;
+    constexpr int K = KK == 1 ? 1 : 3;
     float* __restrict__ fl = lds;                                   // [MF_CK][CS]
     float* __restrict__ wl = lds + MF_CK * CS;                      // [MF_KS][KK][64]
     const int band = blockIdx.x, i = blockIdx.y;
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
     const int kq = lane >> 4, j = lane & 15;
     const int y0 = band * g.BR, rows = min(g.BR, g.H - y0);
-    const int RS = rows + 2 * g.p;                                  // staged rows (image rows y0-p .. y0+rows-1+p)
-    const int HW = g.H * g.W, npos = rows * g.W, ntiles = (npos + 15) >> 4;
+    const int HW = g.H * g.W, npos = rows * g.W;
     const float inv_w = 1.0f / (float)g.W;
     const float* __restrict__ fi = feat + (long)i * stride_n;
 
-    for (int e = threadIdx.x; e < MF_CK * CS; e += 256) fl[e] = 0.f;          // padding columns stay zero for good
+    for (int e = threadIdx.x; e < MF_CK * CS; e += 256) fl[e] = 0.f;          // padding (and rows outside the image) stay zero
 
-    // ---- per-lane staging plan (identical for every channel): element e = lane + 64*q of the RS x W band
-    int s_g[MF_NL], s_l[MF_NL];                                     // global offset inside a channel (-1: outside), LDS offset
-#pragma unroll
-    for (int q = 0; q < MF_NL; ++q) {
-        const int e = lane + 64 * q;
-        const int rr = mf_fdiv(e, inv_w), x = e - rr * g.W;
-        const int y = y0 - g.p + rr;
-        const bool in_band = e < RS * g.W;
-        s_g[q] = (in_band && y >= 0 && y < g.H) ? y * g.W + x : -1;
-        s_l[q] = in_band ? rr * g.PWs + x + g.p : -1;
-    }
+    // image rows [ys, ye) of the band + halo are contiguous in every channel plane
+    const int ys = max(y0 - g.p, 0), ye = min(y0 + rows + g.p, g.H);
+    MfStage<VW, NQ> sp;
+    sp.plan(lane, ys, ye - ys, g.W, inv_w, ys - (y0 - g.p), g.PWs, g.p);
     // weights: element e = tid + 256*q of [MF_KS][KK][64]
     constexpr int WN = (MF_KS * KK * 64 + 255) / 256;
-    long w_g[WN];
-    int w_c[WN];
-    bool w_ok[WN];
+    int w_g[WN];
 #pragma unroll
     for (int q = 0; q < WN; ++q) {
         const int e = threadIdx.x + 256 * q;
         const int ln = e & 63, tk = e >> 6;                         // tk = ks*KK + tap
         const int ks = tk / KK, tap = tk - ks * KK;
         const int f = ln & 15, cq = ln >> 4;
-        w_ok[q] = e < MF_KS * KK * 64 && f < g.F;
-        w_c[q] = 4 * ks + cq;                                       // channel inside the chunk
-        w_g[q] = ((long)f * g.C + 4 * ks + cq) * KK + tap;          // + c0*KK per chunk
+        // offset for chunk 0 (+ c0*KK per chunk); -1: not a weight (f >= F or beyond the table)
+        w_g[q] = (e < MF_KS * KK * 64 && f < g.F) ? (f * g.C + 4 * ks + cq) * KK + tap : -1;
     }
 
     // ---- tile geometry of this wave
-    int t_off[MF_NT];
-    bool t_ok[MF_NT];
+    int t_off[NT];
+    bool t_ok[NT];
 #pragma unroll
-    for (int q = 0; q < MF_NT; ++q) {
+    for (int q = 0; q < NT; ++q) {
         const int pj = 16 * (wave + 4 * q) + j;
         const int r = mf_fdiv(pj, inv_w), x = pj - r * g.W;
         t_ok[q] = pj < npos;
         t_off[q] = t_ok[q] ? r * g.PWs + x : 0;
     }
-    f32x4 acc[MF_NT];
+    f32x4 acc[NT];
 #pragma unroll
-    for (int q = 0; q < MF_NT; ++q) acc[q] = (f32x4){0, 0, 0, 0};
+    for (int q = 0; q < NT; ++q) acc[q] = (f32x4){0, 0, 0, 0};
 
-    float sv[MF_CW][MF_NL], wv[WN];
-    auto fetch = [&](int c0) {
+    float sv[MF_CW][NQ][VW], wv[WN];
+    auto fetch = [&](int c0) {                                      // straight-line: clamped addresses, select afterwards
 #pragma unroll
         for (int cc = 0; cc < MF_CW; ++cc) {
             const int c = c0 + wave + 4 * cc;
             const float* __restrict__ fc = fi + (long)min(c, g.C - 1) * HW;
 #pragma unroll
-            for (int q = 0; q < MF_NL; ++q) {                       // straight-line: clamped address, select afterwards
-                const float v = fc[max(s_g[q], 0)];
-                sv[cc][q] = (s_g[q] >= 0 && c < g.C) ? v : 0.f;
+            for (int q = 0; q < NQ; ++q) {
+                const bool ok = sp.g[q] >= 0 && c < g.C;
+                if (VW == 4) {
+                    const f32x4 v = *(const f32x4*)(fc + max(sp.g[q], 0));
+#pragma unroll
+                    for (int m = 0; m < 4; ++m) sv[cc][q][m] = ok ? v[m] : 0.f;
+                } else {
+                    const float v = fc[max(sp.g[q], 0)];
+                    sv[cc][q][0] = ok ? v : 0.f;
+                }
             }
         }
 #pragma unroll
         for (int q = 0; q < WN; ++q) {
-            const bool ok = w_ok[q] && c0 + w_c[q] < g.C;
-            const float v = filt[ok ? w_g[q] + (long)c0 * KK : 0];
+            const int ks = (threadIdx.x + 256 * q) / (64 * KK);
+            const bool ok = w_g[q] >= 0 && c0 + 4 * ks + kq < g.C;  // (lane >> 4 of the weight element == kq of this thread)
+            const float v = filt[ok ? (long)w_g[q] + (long)c0 * KK : 0];
             wv[q] = ok ? v : 0.f;
         }
     };
@@ -121,8 +141,11 @@ __global__ __launch_bounds__(256) void k_mf_corr(const float* __restrict__ feat,
         for (int cc = 0; cc < MF_CW; ++cc) {
             float* __restrict__ fc = fl + (wave + 4 * cc) * CS;
 #pragma unroll
-            for (int q = 0; q < MF_NL; ++q)
-                if (s_l[q] >= 0) fc[s_l[q]] = sv[cc][q];
+            for (int q = 0; q < NQ; ++q)
+                if (sp.g[q] >= 0) {
+#pragma unroll
+                    for (int m = 0; m < VW; ++m) fc[sp.l[q] + m] = sv[cc][q][m];
+                }
         }
 #pragma unroll
         for (int q = 0; q < WN; ++q) {
@@ -134,30 +157,28 @@ __global__ __launch_bounds__(256) void k_mf_corr(const float* __restrict__ feat,
     fetch(0);
     __syncthreads();                                                // zero fill done
     for (int c0 = 0; c0 < g.C; c0 += MF_CK) {
-        if (!(PT_MFABL & 8) || c0 == 0) stage();
+        stage();
         __syncthreads();
         if (c0 + MF_CK < g.C && !(PT_MFABL & 4)) fetch(c0 + MF_CK);   // next chunk in flight while this one is multiplied
 #pragma unroll
         for (int ks = 0; ks < MF_KS; ++ks) {
             const float* __restrict__ fb = fl + (4 * ks + kq) * CS;
-            constexpr int K = KK == 1 ? 1 : (KK == 9 ? 3 : 5);
-            // all LDS operands of this k-step first (KK A values, KK x MF_NT B values), then the MFMAs: one wait per
-            // k-step instead of one per MFMA (a workgroup has a single wave per SIMD, nothing else hides LDS latency)
-            float av[KK], bv[KK][MF_NT];
+            // all LDS operands of this k-step first (KK A values, KK x NT B values), then the MFMAs: one wait per k-step
+            // instead of one per MFMA.  No per-tile branch: a tile beyond the band multiplies zeros (t_ok false), which is
+            // far cheaper than putting every MFMA into its own basic block.
+            float av[KK], bv[KK][NT];
 #pragma unroll
             for (int tap = 0; tap < KK; ++tap) {
                 const int u = tap / K, v = tap - u * K;
                 av[tap] = wl[(ks * KK + tap) * 64 + lane];
 #pragma unroll
-                for (int q = 0; q < MF_NT; ++q) bv[tap][q] = (PT_MFABL & 2) ? av[tap] : fb[t_off[q] + u * g.PWs + v];
+                for (int q = 0; q < NT; ++q) bv[tap][q] = fb[t_off[q] + u * g.PWs + v];
             }
 #pragma unroll
             for (int tap = 0; tap < KK; ++tap) {
 #pragma unroll
-                for (int q = 0; q < MF_NT; ++q) {
+                for (int q = 0; q < NT; ++q) {
                     if (PT_MFABL & 1) { acc[q][0] += av[tap] * bv[tap][q]; continue; }
-                    // no per-tile branch: a tile beyond the band multiplies zeros (t_ok false), which is cheaper than
-                    // putting every MFMA into its own basic block
                     acc[q] = mfma16(av[tap], t_ok[q] ? bv[tap][q] : 0.f, acc[q]);
                 }
             }
@@ -165,7 +186,7 @@ __global__ __launch_bounds__(256) void k_mf_corr(const float* __restrict__ feat,
         __syncthreads();
     }
 #pragma unroll
-    for (int q = 0; q < MF_NT; ++q) {
+    for (int q = 0; q < NT; ++q) {
         const int pj = 16 * (wave + 4 * q) + j;
         if (pj < npos) {
 #pragma unroll
@@ -178,22 +199,22 @@ __global__ __launch_bounds__(256) void k_mf_corr(const float* __restrict__ feat,
 }
 
 // ---------------------------------------------------------------------------------------------------
-// adjoint: grid (C/16, NSG), 256 threads.  Workgroup = 16 channels x a group of samples; per (sample, row band) it
+// adjoint: grid (ceil(C/16), NSG), 256 threads.  Workgroup = 16 channels x a group of samples; per (sample, row band) it
 // stages the zero-padded feature band fl[16][CS2] and the input band rl[16][RS2] (strides == 2 mod 32: conflict-free
 // reads with 16 channels/filters x 2 positions per half-wave) and accumulates  D_tap[f][c] += in[f][pos] * feat[c][pos+tap]
 // with K = positions on the matrix cores; wave w takes the 4-position k-steps w, w+4, ...
 // Output: gpart[sg][f][c][tap] (summed over sample groups by the consumer, fixed order).
 // ---------------------------------------------------------------------------------------------------
-#define MF_AL 8        // staged elements per lane per channel / filter row
-
-template <int KK>
+template <int KK, int VW>
 __global__ __launch_bounds__(256) void k_mf_adj(const float* __restrict__ feat, long stride_n,
                                                 const float* __restrict__ inp, float* __restrict__ gpart, MfGeom g,
                                                 int CS2, int RS2, int spg) {
     extern __shared__ __attribute__((aligned(16))) float lds[];
+    constexpr int NQ = MF_NQ / VW;
+    constexpr int K = KK == 1 ? 1 : 3;
     float* __restrict__ fl = lds;                                   // [16][CS2]
     float* __restrict__ rl = lds + 16 * CS2;                        // [16][RS2]
-    float* __restrict__ red = rl + 16 * RS2;                        // [4][KK][256]
+    float* __restrict__ red = lds;                                  // [4][KK][256], reuses the staging area after the loop
     const int cb = blockIdx.x, sg = blockIdx.y;
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
     const int kq = lane >> 4, j = lane & 15;
@@ -202,59 +223,71 @@ __global__ __launch_bounds__(256) void k_mf_adj(const float* __restrict__ feat, 
     const int i_beg = sg * spg, i_end = min(g.n, i_beg + spg);
     const int nst = (i_end - i_beg) * g.NB;                         // stages = (sample, band) pairs
 
-    for (int e = threadIdx.x; e < 16 * CS2; e += 256) fl[e] = 0.f;
-
     f32x4 acc[KK];
 #pragma unroll
     for (int t = 0; t < KK; ++t) acc[t] = (f32x4){0, 0, 0, 0};
 
-    float sv[4][MF_AL], rv[4][MF_AL];
+    float sv[4][NQ][VW], rv[4][NQ][VW];
+    MfStage<VW, NQ> fp, rp;                                         // plans of the stage whose data sits in sv / rv
     auto fetch = [&](int st) {
         const int i = i_beg + st / g.NB, band = st - (st / g.NB) * g.NB;
-        const int y0 = band * g.BR, rows = min(g.BR, g.H - y0), RS = rows + 2 * g.p;
+        const int y0 = band * g.BR, rows = min(g.BR, g.H - y0);
+        const int ys = max(y0 - g.p, 0), ye = min(y0 + rows + g.p, g.H);
+        fp.plan(lane, ys, ye - ys, g.W, inv_w, ys - (y0 - g.p), g.PWs, g.p);
+        rp.plan(lane, y0, rows, g.W, inv_w, 0, g.W, 0);
 #pragma unroll
         for (int cc = 0; cc < 4; ++cc) {
-            const int c = cb * 16 + wave + 4 * cc;
-            const bool cok = c < g.C;
+            const int c = cb * 16 + wave + 4 * cc, f = wave + 4 * cc;
             const float* __restrict__ fc = feat + (long)i * stride_n + (long)min(c, g.C - 1) * HW;
-            const float* __restrict__ rc = inp + ((long)i * g.F + min(wave + 4 * cc, g.F - 1)) * HW + (long)y0 * g.W;
-            const bool fok = wave + 4 * cc < g.F;
+            const float* __restrict__ rc = inp + ((long)i * g.F + min(f, g.F - 1)) * HW;
 #pragma unroll
-            for (int q = 0; q < MF_AL; ++q) {
-                const int e = lane + 64 * q;
-                const int rr = mf_fdiv(e, inv_w), x = e - rr * g.W;
-                const int y = y0 - g.p + rr;
-                const bool fin = cok && e < RS * g.W && y >= 0 && y < g.H, rin = e < rows * g.W && fok;
-                const float fvv = fc[fin ? y * g.W + x : 0], rvv = rc[rin ? e : 0];    // straight-line loads
-                sv[cc][q] = fin ? fvv : 0.f;
-                rv[cc][q] = rin ? rvv : 0.f;
+            for (int q = 0; q < NQ; ++q) {
+                const bool fok = fp.g[q] >= 0 && c < g.C, rok = rp.g[q] >= 0 && f < g.F;
+                if (VW == 4) {
+                    const f32x4 a = *(const f32x4*)(fc + max(fp.g[q], 0)), b = *(const f32x4*)(rc + max(rp.g[q], 0));
+#pragma unroll
+                    for (int m = 0; m < 4; ++m) { sv[cc][q][m] = fok ? a[m] : 0.f; rv[cc][q][m] = rok ? b[m] : 0.f; }
+                } else {
+                    const float a = fc[max(fp.g[q], 0)], b = rc[max(rp.g[q], 0)];
+                    sv[cc][q][0] = fok ? a : 0.f;
+                    rv[cc][q][0] = rok ? b : 0.f;
+                }
             }
         }
     };
-    auto stage = [&](int st) {
-        const int band = st - (st / g.NB) * g.NB;
-        const int y0 = band * g.BR, rows = min(g.BR, g.H - y0), RS = rows + 2 * g.p;
+    auto stage = [&]() {
+        // a band shorter than the previous one (last band of a sample) must not keep stale rows: the whole staging area
+        // was cleared by all threads before (see the loop), only valid items are written here
 #pragma unroll
         for (int cc = 0; cc < 4; ++cc) {
             float* __restrict__ fc = fl + (wave + 4 * cc) * CS2;
             float* __restrict__ rc = rl + (wave + 4 * cc) * RS2;
 #pragma unroll
-            for (int q = 0; q < MF_AL; ++q) {
-                const int e = lane + 64 * q;
-                const int rr = mf_fdiv(e, inv_w), x = e - rr * g.W;
-                if (e < g.RSmax * g.W) fc[rr * g.PWs + x + g.p] = e < RS * g.W ? sv[cc][q] : 0.f;   // short last band: clear
-                if (e < g.BR * g.W) rc[e] = rv[cc][q];
+            for (int q = 0; q < NQ; ++q) {
+                if (fp.g[q] >= 0) {
+#pragma unroll
+                    for (int m = 0; m < VW; ++m) fc[fp.l[q] + m] = sv[cc][q][m];
+                }
+                if (rp.g[q] >= 0) {
+#pragma unroll
+                    for (int m = 0; m < VW; ++m) rc[rp.l[q] + m] = rv[cc][q][m];
+                }
             }
         }
     };
 
     if (nst > 0) fetch(0);
-    __syncthreads();
     for (int st = 0; st < nst; ++st) {
-        stage(st);
+        const int band = st - (st / g.NB) * g.NB;
+        // first / last band of a sample have rows outside the image, and the last band may be short: clear first
+        // (uniform per workgroup; interior bands overwrite every cell they read)
+        if (st == 0 || band == 0 || band == g.NB - 1) {
+            for (int e = threadIdx.x; e < 16 * (CS2 + RS2); e += 256) lds[e] = 0.f;
+            __syncthreads();
+        }
+        stage();
         __syncthreads();
         if (st + 1 < nst) fetch(st + 1);
-        const int band = st - (st / g.NB) * g.NB;
         const int rows = min(g.BR, g.H - band * g.BR), npos = rows * g.W;
         const float* __restrict__ fb = fl + j * CS2;
         const float* __restrict__ rb = rl + j * RS2;
@@ -264,10 +297,9 @@ __global__ __launch_bounds__(256) void k_mf_adj(const float* __restrict__ feat, 
             const bool ok = pos < npos;
             const int pc = ok ? pos : 0;
             const int r = mf_fdiv(pc, inv_w), x = pc - r * g.W;
-            const float av = rb[pc];
-            const float a = ok ? av : 0.f;
+            const float a0 = rb[pc];
+            const float a = ok ? a0 : 0.f;
             const int po = r * g.PWs + x;
-            constexpr int K = KK == 1 ? 1 : (KK == 9 ? 3 : 5);
             float bv[KK];
 #pragma unroll
             for (int tap = 0; tap < KK; ++tap) bv[tap] = fb[po + (tap / K) * g.PWs + (tap % K)];
@@ -297,8 +329,9 @@ __global__ __launch_bounds__(256) void k_mf_adj(const float* __restrict__ feat, 
 // ---------------------------------------------------------------------------------------------------
 struct MfPlan {
     int ok;
-    MfGeom g;            // correlation: band <= 256 positions (MF_NT tiles per wave)
-    MfGeom ga;           // adjoint: band as tall as the staging plan allows (fewer, longer stages)
+    MfGeom g;            // correlation geometry
+    MfGeom ga;           // adjoint geometry
+    int NT;              // correlation: tiles per wave (2 or 4)
     int CS, CS2, RS2, spg, NSG;
     size_t corr_lds, adj_lds;
 };
@@ -314,20 +347,28 @@ static MfPlan mf_plan(int n, int F, int C, int H, int W, int K) {
     p.ok = 0;
     if (n <= 0 || F <= 0 || F > 16 || C <= 0 || H <= 0 || W <= 0) return p;
     if (K != 1 && K != 3) return p;
+    if (W > 256 || (long)n * C * H * W >= (1L << 31) || (long)F * C * K * K >= (1L << 30)) return p;
     MfGeom& g = p.g;
     g.n = n; g.F = F; g.C = C; g.H = H; g.W = W; g.K = K; g.p = K / 2; g.KK = K * K;
-    if (W > 256) return p;
-    int BR = 256 / W;                                    // <= MF_NT * 64 positions per band
+    g.PWs = W + K - 1;
+    // correlation band: <= 256 positions (4 tiles per wave) and <= 512 staged floats per channel; shrink it until the
+    // grid holds ~2 workgroups per CU
+    int BR = 256 / W;
     if (BR > H) BR = H;
-    while (BR > 1 && (BR + K - 1) * W > 64 * MF_NL) --BR;  // staged rows must fit the per-lane staging plan
-    if ((BR + K - 1) * W > 64 * MF_NL || BR * W > 256) return p;
+    while (BR > 1 && ((BR + K - 1) * W > 64 * MF_NQ ||
+                      (n * ((H + BR - 1) / BR) < 512 && (BR - 1) * W >= 96)))      // keep >= 6 of a wave quad's 8 tile slots busy
+        --BR;
+    if ((BR + K - 1) * W > 64 * MF_NQ || BR * W > 256) return p;
     g.BR = BR;
     g.NB = (H + BR - 1) / BR;
-    g.PWs = W + K - 1;
     g.RSmax = BR + K - 1;
+    p.NT = (BR * W + 15) / 16 <= 8 ? 2 : 4;
+    // adjoint band: as above without the grid-size constraint (its grid is channel blocks x sample groups)
     p.ga = g;
-    int BRa = H;
-    while (BRa > 1 && (BRa + K - 1) * W > 64 * MF_AL) --BRa;
+    int BRa = 256 / W;
+    if (BRa > H) BRa = H;
+    while (BRa > 1 && (BRa + K - 1) * W > 64 * MF_NQ) --BRa;
+    if ((BRa + K - 1) * W > 64 * MF_NQ) return p;
     p.ga.BR = BRa;
     p.ga.NB = (H + BRa - 1) / BRa;
     p.ga.RSmax = BRa + K - 1;
@@ -335,13 +376,12 @@ static MfPlan mf_plan(int n, int F, int C, int H, int W, int K) {
     p.CS2 = mf_pad_to(p.ga.RSmax * g.PWs, 32, 2);
     p.RS2 = mf_pad_to(BRa * W, 32, 2);
     p.corr_lds = ((size_t)MF_CK * p.CS + MF_KS * g.KK * 64) * sizeof(float);
-    p.adj_lds = ((size_t)16 * p.CS2 + 16 * p.RS2 + 4 * g.KK * 256) * sizeof(float);
-    // sample groups of the adjoint: aim for ~256 workgroups
+    p.adj_lds = std::max((size_t)16 * (p.CS2 + p.RS2), (size_t)4 * g.KK * 256) * sizeof(float);
     const int CBn = (C + 15) / 16;
-    int NSG = 256 / CBn;
+    int NSG = 512 / CBn;                                 // ~2 workgroups per CU
     if (NSG < 1) NSG = 1;
     if (NSG > n) NSG = n;
-    if (NSG > 16) NSG = 16;
+    if (NSG > 32) NSG = 32;
     p.spg = (n + NSG - 1) / NSG;
     p.NSG = (n + p.spg - 1) / p.spg;
     if (p.corr_lds > 150 * 1024 || p.adj_lds > 150 * 1024) return p;
@@ -358,14 +398,27 @@ int pt_mf_groups(int n, int F, int C, int H, int W, int K) {
     return p.ok ? p.NSG : 0;
 }
 
+static bool mf_vec_ok(const float* a, const float* b, long stride_n, int W) {
+    return (W % 4) == 0 && (stride_n % 4) == 0 && ((uintptr_t)a % 16) == 0 && ((uintptr_t)b % 16) == 0;
+}
+
 int pt_launch_mf_corr(const float* feat, long stride_n, const float* filt, float* scores, int n, int F, int C, int H,
                       int W, int K, hipStream_t st) {
     MfPlan p = mf_plan(n, F, C, H, W, K);
     if (!p.ok) return PT_ERR_UNSUPPORTED;
     dim3 grid(p.g.NB, n), block(256);
+    const bool vec = mf_vec_ok(feat, feat, stride_n, W);
     pt_prof_begin(0, st);
-    if (K == 1) hipLaunchKernelGGL((k_mf_corr<1>), grid, block, p.corr_lds, st, feat, stride_n, filt, scores, p.g, p.CS);
-    else hipLaunchKernelGGL((k_mf_corr<9>), grid, block, p.corr_lds, st, feat, stride_n, filt, scores, p.g, p.CS);
+#define PT_MFC(KKV, NTV, VWV) \
+    hipLaunchKernelGGL((k_mf_corr<KKV, NTV, VWV>), grid, block, p.corr_lds, st, feat, stride_n, filt, scores, p.g, p.CS)
+    if (K == 1) {
+        if (p.NT == 2) { if (vec) PT_MFC(1, 2, 4); else PT_MFC(1, 2, 1); }
+        else { if (vec) PT_MFC(1, 4, 4); else PT_MFC(1, 4, 1); }
+    } else {
+        if (p.NT == 2) { if (vec) PT_MFC(9, 2, 4); else PT_MFC(9, 2, 1); }
+        else { if (vec) PT_MFC(9, 4, 4); else PT_MFC(9, 4, 1); }
+    }
+#undef PT_MFC
     pt_prof_end(0, st);
     PT_CHECK_LAUNCH();
     return PT_OK;
@@ -376,9 +429,13 @@ int pt_launch_mf_adj(const float* feat, long stride_n, const float* inp, float* 
     MfPlan p = mf_plan(n, F, C, H, W, K);
     if (!p.ok) return PT_ERR_UNSUPPORTED;
     dim3 grid((C + 15) / 16, p.NSG), block(256);
+    const bool vec = mf_vec_ok(feat, inp, stride_n, W) && ((H * W) % 4) == 0;
     pt_prof_begin(1, st);
-    if (K == 1) hipLaunchKernelGGL((k_mf_adj<1>), grid, block, p.adj_lds, st, feat, stride_n, inp, gpart, p.ga, p.CS2, p.RS2, p.spg);
-    else hipLaunchKernelGGL((k_mf_adj<9>), grid, block, p.adj_lds, st, feat, stride_n, inp, gpart, p.ga, p.CS2, p.RS2, p.spg);
+#define PT_MFA(KKV, VWV) \
+    hipLaunchKernelGGL((k_mf_adj<KKV, VWV>), grid, block, p.adj_lds, st, feat, stride_n, inp, gpart, p.ga, p.CS2, p.RS2, p.spg)
+    if (K == 1) { if (vec) PT_MFA(1, 4); else PT_MFA(1, 1); }
+    else { if (vec) PT_MFA(9, 4); else PT_MFA(9, 1); }
+#undef PT_MFA
     pt_prof_end(1, st);
     PT_CHECK_LAUNCH();
     return PT_OK;

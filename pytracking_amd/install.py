@@ -16,7 +16,7 @@ What gets rebound (import path = contract; nothing in the reference tree is edit
                                                   (LWL few-shot learner)              -> pytracking_amd.steepestdescent
 
 Dispatch rule of the rebound *functions*: device fp32 tensors of a shape the gfx950 kernels cover go to the C ABI;
-everything else (CPU tensors, multi-filter LWL filters, dilations, K*K > 16) is outside SURVEY section 8's scope and
+everything else (CPU tensors, dilations, grouped filters, K*K > 16, more than 16 filters) is outside the hot path and
 is handed to the reference's ORIGINAL function object -- its own stock-PyTorch code, not a re-implementation --
 unless `strict=True`, in which case it raises.  The rebound *classes* have no such escape: they run the fused
 solver or raise.
