@@ -14,6 +14,7 @@
 // reused 16x (taps) without an LDS round trip.  All loads of a wave's slice are issued before the first
 // MFMA (>= 16 KiB in flight per wave) because at ~1 workgroup per CU there is no other latency hiding.
 #include <stdlib.h>
+#include <algorithm>
 #include "common.h"
 #include "pt_internal.h"
 #include "rbuild.h"
@@ -365,9 +366,14 @@ PtPlan pt_make_plan(int n, int C, int H, int W, int KH, int KW, int OH, int OW) 
     p.corr_lds = ((size_t)p.cper * 16 + (size_t)p.KK * (ntiles * 64 + 4)) * sizeof(float);
     // adj
     p.NG = (int)(((long)n * p.HW + 15) / 16);
+    // position slices: one pass of the 8 waves covers 128 groups; with few channel blocks (ATOM: C = 64) more slices are
+    // needed to put a workgroup on every CU
     int KSPL = p.NG / 64;
+    const int cap = std::max(8, 256 / pt_ceil_div(C, 16));
+    if (KSPL > cap) KSPL = cap;
+    if (KSPL > pt_ceil_div(p.NG, 128)) KSPL = std::max(pt_ceil_div(p.NG, 128), std::min(KSPL, 8));
     if (KSPL < 1) KSPL = 1;
-    if (KSPL > 8) KSPL = 8;
+    if (KSPL > 64) KSPL = 64;
 #if PT_EXPERIMENT
     if (getenv("PT_FORCE_KSPL")) KSPL = atoi(getenv("PT_FORCE_KSPL"));
 #endif
