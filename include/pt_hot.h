@@ -121,8 +121,9 @@ int pt_sd_solve_f32(const pt_sd_params* p, const float* w_in, const float* feat,
 
 /* apply_filter (filter.py:29-34), one sequence, F filters:  filt (F,C,K,K); scores (n,F,H,W) dense
  *   scores[i,f,y,x] = sum_{c,u,v} filt[f,c,u,v] * feat[i,c,y+u-K/2,x+v-K/2] */
+size_t pt_apply_filter_mf_ws_bytes(int n, int F, int C, int H, int W, int K);
 int pt_apply_filter_mf_f32(const float* feat, long feat_stride_n, const float* filt, float* scores,
-                           int n, int F, int C, int H, int W, int K, void* stream);
+                           int n, int F, int C, int H, int W, int K, void* ws, size_t ws_bytes, void* stream);
 
 /* apply_feat_transpose for a 5-D input (filter.py:158-176):  inp (n,F,H,W) dense; grad (F,C,K,K)
  *   grad[f,c,u,v] = sum_{i,y,x} feat[i,c,y+u-K/2,x+v-K/2] * inp[i,f,y,x] */

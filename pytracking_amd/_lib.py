@@ -24,7 +24,7 @@ EXPORTS = [
     "pt_atom_cg_ws_bytes", "pt_atom_cg_f32",
     "pt_prroi_fwd_f32", "pt_prroi_bwd_feat_f32", "pt_prroi_bwd_coor_f32",
     "pt_track_frame_ws_bytes", "pt_track_frame_f32",
-    "pt_apply_filter_mf_f32", "pt_feat_transpose_mf_ws_bytes", "pt_feat_transpose_mf_f32",
+    "pt_apply_filter_mf_ws_bytes", "pt_apply_filter_mf_f32", "pt_feat_transpose_mf_ws_bytes", "pt_feat_transpose_mf_f32",
     "pt_lwl_ws_bytes", "pt_lwl_gn_solve_f32",
     "pt_profile_create", "pt_profile_attach", "pt_profile_collect", "pt_profile_reset", "pt_profile_destroy",
 ]
@@ -110,8 +110,10 @@ def lib():
     L.pt_track_frame_ws_bytes.argtypes = [i] * 5
     L.pt_track_frame_f32.restype = i
     L.pt_track_frame_f32.argtypes = [ctypes.POINTER(SdParams), vp, vp, vp, vp, vp] + [i] * 7 + [vp, vp, vp, sz, vp]
+    L.pt_apply_filter_mf_ws_bytes.restype = sz
+    L.pt_apply_filter_mf_ws_bytes.argtypes = [i] * 6
     L.pt_apply_filter_mf_f32.restype = i
-    L.pt_apply_filter_mf_f32.argtypes = [vp, l, vp, vp] + [i] * 6 + [vp]
+    L.pt_apply_filter_mf_f32.argtypes = [vp, l, vp, vp] + [i] * 6 + [vp, sz, vp]
     L.pt_feat_transpose_mf_ws_bytes.restype = sz
     L.pt_feat_transpose_mf_ws_bytes.argtypes = [i] * 6
     L.pt_feat_transpose_mf_f32.restype = i

@@ -20,7 +20,8 @@ struct LwlArgs {
     int n, F, C, HW, KK, CKK /* F*C*KK */, NSG, sw_mode;
     float lam, slreg, sw_scalar;
     const float *label, *sw;
-    float *s, *sg, *rmap, *gpart, *g, *ggp, *hhp, *lossp, *w_iters;
+    float *s, *sg, *rmap, *gpart, *g, *gT, *ggp, *hhp, *lossp, *w_iters;
+    int C4KK64;            // (C/4)*KK*64: live part of the transposed table
     const float* w0;
 };
 
@@ -77,6 +78,10 @@ __global__ __launch_bounds__(256) void k_lwl_g(LwlArgs a, int t) {
         for (int k = 0; k < a.NSG; ++k) v += a.gpart[(long)k * a.CKK + e];
         v += a.lam * a.lam * w[e];
         a.g[e] = v;
+        {                                                           // the same value in the order k_mf_corr reads it
+            const int tap = (int)(e % a.KK), c = (int)((e / a.KK) % a.C), f = (int)(e / ((long)a.KK * a.C));
+            a.gT[((long)(c >> 2) * a.KK + tap) * 64 + (c & 3) * 16 + f] = v;
+        }
         acc += v * v;
     }
     const float tot = block_sum(acc, scratch);
@@ -119,7 +124,7 @@ __global__ void k_mf_sum_groups(const float* __restrict__ gpart, float* __restri
 }
 
 // ---------------------------------------------------------------------------------------------------
-struct LwlCarve { size_t s, sg, rmap, gpart, g, ggp, hhp, lossp, total; };
+struct LwlCarve { size_t s, sg, rmap, gpart, g, gT, wT, ggp, hhp, lossp, total; };
 
 static LwlCarve lwl_carve(int n, int F, int C, int H, int W, int K) {
     LwlCarve c;
@@ -129,6 +134,7 @@ static LwlCarve lwl_carve(int n, int F, int C, int H, int W, int K) {
     c.s = take(N); c.sg = take(N); c.rmap = take(N);
     c.gpart = take(pt_mf_gpart_floats(n, F, C, H, W, K));
     c.g = take((size_t)F * C * K * K);
+    c.gT = take(pt_mf_wt_floats(C, K)); c.wT = take(pt_mf_wt_floats(C, K));
     c.ggp = take(LWL_NBLK); c.hhp = take(LWL_NBLK);
     c.lossp = take((size_t)(LWL_MAX_ITER + 1) * LWL_NBLK);
     c.total = off;
@@ -146,13 +152,21 @@ extern "C" size_t pt_lwl_ws_bytes(int n, int F, int C, int H, int W, int K) {
     return lwl_carve(n, F, C, H, W, K).total * sizeof(float);
 }
 
+extern "C" size_t pt_apply_filter_mf_ws_bytes(int n, int F, int C, int H, int W, int K) {
+    if (mf_check(n, F, C, H, W, K)) return 0;
+    return pt_align_floats(pt_mf_wt_floats(C, K)) * sizeof(float);
+}
+
 extern "C" int pt_apply_filter_mf_f32(const float* feat, long feat_stride_n, const float* filt, float* scores, int n,
-                                      int F, int C, int H, int W, int K, void* stream) {
-    if (!feat || !filt || !scores) return PT_ERR_NULL;
+                                      int F, int C, int H, int W, int K, void* ws, size_t ws_bytes, void* stream) {
+    if (!feat || !filt || !scores || !ws) return PT_ERR_NULL;
     int rc = mf_check(n, F, C, H, W, K);
     if (rc) return rc;
     if (feat_stride_n < (long)C * H * W) return PT_ERR_SHAPE;
-    return pt_launch_mf_corr(feat, feat_stride_n, filt, scores, n, F, C, H, W, K, (hipStream_t)stream);
+    if (ws_bytes < pt_apply_filter_mf_ws_bytes(n, F, C, H, W, K) || ((uintptr_t)ws % 256) != 0) return PT_ERR_WORKSPACE;
+    rc = pt_launch_mf_wtrans(filt, (float*)ws, F, C, K, (hipStream_t)stream);
+    if (rc) return rc;
+    return pt_launch_mf_corr(feat, feat_stride_n, (const float*)ws, scores, n, F, C, H, W, K, (hipStream_t)stream);
 }
 
 extern "C" size_t pt_feat_transpose_mf_ws_bytes(int n, int F, int C, int H, int W, int K) {
@@ -197,13 +211,18 @@ extern "C" int pt_lwl_gn_solve_f32(const float* w_in, const float* feat, long fe
     a.lam = filter_reg; a.slreg = steplength_reg; a.sw_scalar = sqrtf(1.0f / (float)n);
     a.label = label; a.sw = sample_weight;
     a.s = base + cv.s; a.sg = base + cv.sg; a.rmap = base + cv.rmap; a.gpart = base + cv.gpart; a.g = base + cv.g;
+    a.gT = base + cv.gT;
     a.ggp = base + cv.ggp; a.hhp = base + cv.hhp; a.lossp = base + cv.lossp; a.w_iters = w_iters; a.w0 = w_in;
     const int want_loss = losses != nullptr;
     if (w_iters != w_in &&
         hipMemcpyAsync(w_iters, w_in, (size_t)a.CKK * sizeof(float), hipMemcpyDeviceToDevice, st) != hipSuccess)
         return PT_ERR_LAUNCH;
     if (num_iter == 0 && !want_loss) return PT_OK;
-    rc = pt_launch_mf_corr(feat, feat_stride_n, w_in, a.s, n, F, C, H, W, K, st);       // s_0 = F w_0
+    // the padding of the transposed gradient table is written once (k_lwl_g only touches live entries)
+    if (hipMemsetAsync(a.gT, 0, pt_mf_wt_floats(C, K) * sizeof(float), st) != hipSuccess) return PT_ERR_LAUNCH;
+    rc = pt_launch_mf_wtrans(w_in, base + cv.wT, F, C, K, st);
+    if (rc) return rc;
+    rc = pt_launch_mf_corr(feat, feat_stride_n, base + cv.wT, a.s, n, F, C, H, W, K, st);   // s_0 = F w_0
     if (rc) return rc;
     hipLaunchKernelGGL(k_lwl_upd, dim3(LWL_NBLK), dim3(256), 0, st, a, 0, want_loss, (int)(num_iter == 0));
     PT_CHECK_LAUNCH();
@@ -212,7 +231,7 @@ extern "C" int pt_lwl_gn_solve_f32(const float* w_in, const float* feat, long fe
         if (rc) return rc;
         hipLaunchKernelGGL(k_lwl_g, dim3(LWL_NBLK), dim3(256), 0, st, a, t);
         PT_CHECK_LAUNCH();
-        rc = pt_launch_mf_corr(feat, feat_stride_n, a.g, a.sg, n, F, C, H, W, K, st);   // F g
+        rc = pt_launch_mf_corr(feat, feat_stride_n, a.gT, a.sg, n, F, C, H, W, K, st);  // F g
         if (rc) return rc;
         hipLaunchKernelGGL(k_lwl_hh, dim3(LWL_NBLK), dim3(256), 0, st, a);
         PT_CHECK_LAUNCH();

@@ -10,6 +10,7 @@
 // (v_mfma_f32_16x16x4_f32, exact fp32), the MFMA-bound rows of SURVEY.md section 8 (LWL: 7.4 GFLOP per pass at n = 32,
 // 47 us at the 157 TFLOP/s fp32 matrix peak vs 13 us of HBM time).  Feature tiles are staged in LDS with their zero
 // padding (row band + halo), so the K*K shifted operands are LDS reads at a constant offset instead of global re-reads.
+#include <stdlib.h>
 #include <algorithm>
 #include "common.h"
 #include "pt_internal.h"
@@ -23,6 +24,12 @@ struct MfGeom {
 
 #ifndef PT_MFABL
 #define PT_MFABL 0     // experiments only: 1 = no MFMA, 4 = no global fetch
+#endif
+#ifdef PT_EXPERIMENT   // per-chunk time stamps of k_mf_corr (workgroup-relative), read back by pt_mf_trace_dump()
+static unsigned long long* g_mf_trace = nullptr;
+#define MF_STAMP(slot) do { if (trace && threadIdx.x == 0) trace[((blockIdx.y * gridDim.x + blockIdx.x) * 128) + (slot)] = wall_clock64(); } while (0)
+#else
+#define MF_STAMP(slot) do { } while (0)
 #endif
 
 __device__ __forceinline__ int mf_fdiv(int v, float inv_d) { return (int)(((float)v + 0.5f) * inv_d); }
@@ -61,11 +68,12 @@ struct MfStage {
 
 template <int KK, int NT, int VW>
 __global__ __launch_bounds__(256) void k_mf_corr(const float* __restrict__ feat, long stride_n,
-                                                 const float* __restrict__ filt, float* __restrict__ scores, MfGeom g,
-                                                 int CS) {
+                                                 const float* __restrict__ wT, float* __restrict__ scores, MfGeom g,
+                                                 int CS, unsigned long long* trace) {
     extern __shared__ __attribute__((aligned(16))) float lds[];
     constexpr int NQ = MF_NQ / VW;
     constexpr int K = KK == 1 ? 1 : 3;
+    MF_STAMP(0);
     float* __restrict__ fl = lds;                                   // [MF_CK][CS]
     float* __restrict__ wl = lds + MF_CK * CS;                      // [MF_KS][KK][64]
     const int band = blockIdx.x, i = blockIdx.y;
@@ -82,18 +90,8 @@ __global__ __launch_bounds__(256) void k_mf_corr(const float* __restrict__ feat,
     const int ys = max(y0 - g.p, 0), ye = min(y0 + rows + g.p, g.H);
     MfStage<VW, NQ> sp;
     sp.plan(lane, ys, ye - ys, g.W, inv_w, ys - (y0 - g.p), g.PWs, g.p);
-    // weights: element e = tid + 256*q of [MF_KS][KK][64]
-    constexpr int WN = (MF_KS * KK * 64 + 255) / 256;
-    int w_g[WN];
-#pragma unroll
-    for (int q = 0; q < WN; ++q) {
-        const int e = threadIdx.x + 256 * q;
-        const int ln = e & 63, tk = e >> 6;                         // tk = ks*KK + tap
-        const int ks = tk / KK, tap = tk - ks * KK;
-        const int f = ln & 15, cq = ln >> 4;
-        // offset for chunk 0 (+ c0*KK per chunk); -1: not a weight (f >= F or beyond the table)
-        w_g[q] = (e < MF_KS * KK * 64 && f < g.F) ? (f * g.C + 4 * ks + cq) * KK + tap : -1;
-    }
+    // weights: the chunk's [MF_KS][KK][64] block is contiguous in the pre-transposed table wT (k_mf_wtrans): 16-byte loads
+    constexpr int WN = (MF_KS * KK * 16 + 255) / 256;               // float4 items per thread
 
     // ---- tile geometry of this wave
     int t_off[NT];
@@ -109,80 +107,87 @@ __global__ __launch_bounds__(256) void k_mf_corr(const float* __restrict__ feat,
 #pragma unroll
     for (int q = 0; q < NT; ++q) acc[q] = (f32x4){0, 0, 0, 0};
 
-    float sv[MF_CW][NQ][VW], wv[WN];
-    auto fetch = [&](int c0) {                                      // straight-line: clamped addresses, select afterwards
+    float sv[MF_CW][NQ][VW];
+    f32x4 wv[WN];
+    // fetch: raw loads only (clamped addresses); the validity masks are applied when the values are written to LDS.
+    // A select right behind each load makes the compiler wait for that load before issuing the next one (measured: 26
+    // serialised L2 round trips = 3.6 us of a 7.5 us chunk).
+    auto fetch = [&](int c0) {
 #pragma unroll
         for (int cc = 0; cc < MF_CW; ++cc) {
             const int c = c0 + wave + 4 * cc;
             const float* __restrict__ fc = fi + (long)min(c, g.C - 1) * HW;
 #pragma unroll
             for (int q = 0; q < NQ; ++q) {
-                const bool ok = sp.g[q] >= 0 && c < g.C;
                 if (VW == 4) {
                     const f32x4 v = *(const f32x4*)(fc + max(sp.g[q], 0));
 #pragma unroll
-                    for (int m = 0; m < 4; ++m) sv[cc][q][m] = ok ? v[m] : 0.f;
+                    for (int m = 0; m < 4; ++m) sv[cc][q][m] = v[m];
                 } else {
-                    const float v = fc[max(sp.g[q], 0)];
-                    sv[cc][q][0] = ok ? v : 0.f;
+                    sv[cc][q][0] = fc[max(sp.g[q], 0)];
                 }
             }
         }
+        const f32x4* __restrict__ wc = (const f32x4*)(wT + (long)(c0 >> 2) * KK * 64);
 #pragma unroll
-        for (int q = 0; q < WN; ++q) {
-            const int ks = (threadIdx.x + 256 * q) / (64 * KK);
-            const bool ok = w_g[q] >= 0 && c0 + 4 * ks + kq < g.C;  // (lane >> 4 of the weight element == kq of this thread)
-            const float v = filt[ok ? (long)w_g[q] + (long)c0 * KK : 0];
-            wv[q] = ok ? v : 0.f;
-        }
+        for (int q = 0; q < WN; ++q) wv[q] = wc[min((int)threadIdx.x + 256 * q, MF_KS * KK * 16 - 1)];
     };
-    auto stage = [&]() {
+    auto stage = [&](int c0) {
 #pragma unroll
         for (int cc = 0; cc < MF_CW; ++cc) {
             float* __restrict__ fc = fl + (wave + 4 * cc) * CS;
+            const bool cok = c0 + wave + 4 * cc < g.C;
 #pragma unroll
             for (int q = 0; q < NQ; ++q)
                 if (sp.g[q] >= 0) {
 #pragma unroll
-                    for (int m = 0; m < VW; ++m) fc[sp.l[q] + m] = sv[cc][q][m];
+                    for (int m = 0; m < VW; ++m) fc[sp.l[q] + m] = cok ? sv[cc][q][m] : 0.f;
                 }
         }
 #pragma unroll
         for (int q = 0; q < WN; ++q) {
             const int e = threadIdx.x + 256 * q;
-            if (e < MF_KS * KK * 64) wl[e] = wv[q];
+            if (e < MF_KS * KK * 16) ((f32x4*)wl)[e] = wv[q];
         }
     };
 
     fetch(0);
     __syncthreads();                                                // zero fill done
     for (int c0 = 0; c0 < g.C; c0 += MF_CK) {
-        stage();
+        MF_STAMP(1 + 4 * (c0 / MF_CK));
+        stage(c0);
+        MF_STAMP(2 + 4 * (c0 / MF_CK));
         __syncthreads();
+        MF_STAMP(3 + 4 * (c0 / MF_CK));
         if (c0 + MF_CK < g.C && !(PT_MFABL & 4)) fetch(c0 + MF_CK);   // next chunk in flight while this one is multiplied
-#pragma unroll
-        for (int ks = 0; ks < MF_KS; ++ks) {
+        // LDS operands of k-step ks+1 (KK A values, KK x NT B values) are read while the MFMAs of k-step ks issue: a
+        // workgroup has one wave per SIMD, so nothing else hides the LDS latency.  No per-tile branch: a tile beyond the
+        // band multiplies zeros (t_ok false), far cheaper than putting every MFMA into its own basic block.
+        float av[2][KK], bv[2][KK][NT];
+        auto lds_operands = [&](int ks, int set) {
             const float* __restrict__ fb = fl + (4 * ks + kq) * CS;
-            // all LDS operands of this k-step first (KK A values, KK x NT B values), then the MFMAs: one wait per k-step
-            // instead of one per MFMA.  No per-tile branch: a tile beyond the band multiplies zeros (t_ok false), which is
-            // far cheaper than putting every MFMA into its own basic block.
-            float av[KK], bv[KK][NT];
 #pragma unroll
             for (int tap = 0; tap < KK; ++tap) {
                 const int u = tap / K, v = tap - u * K;
-                av[tap] = wl[(ks * KK + tap) * 64 + lane];
+                av[set][tap] = wl[(ks * KK + tap) * 64 + lane];
 #pragma unroll
-                for (int q = 0; q < NT; ++q) bv[tap][q] = fb[t_off[q] + u * g.PWs + v];
+                for (int q = 0; q < NT; ++q) bv[set][tap][q] = fb[t_off[q] + u * g.PWs + v];
             }
+        };
+        lds_operands(0, 0);
+#pragma unroll
+        for (int ks = 0; ks < MF_KS; ++ks) {
+            if (ks + 1 < MF_KS) lds_operands(ks + 1, (ks + 1) & 1);
 #pragma unroll
             for (int tap = 0; tap < KK; ++tap) {
 #pragma unroll
                 for (int q = 0; q < NT; ++q) {
-                    if (PT_MFABL & 1) { acc[q][0] += av[tap] * bv[tap][q]; continue; }
-                    acc[q] = mfma16(av[tap], t_ok[q] ? bv[tap][q] : 0.f, acc[q]);
+                    if (PT_MFABL & 1) { acc[q][0] += av[ks & 1][tap] * bv[ks & 1][tap][q]; continue; }
+                    acc[q] = mfma16(av[ks & 1][tap], t_ok[q] ? bv[ks & 1][tap][q] : 0.f, acc[q]);
                 }
             }
         }
+        MF_STAMP(4 + 4 * (c0 / MF_CK));
         __syncthreads();
     }
 #pragma unroll
@@ -196,6 +201,17 @@ __global__ __launch_bounds__(256) void k_mf_corr(const float* __restrict__ feat,
             }
         }
     }
+}
+
+// Weights in the order the correlation consumes them: wT[c/4][tap][c%4][16 filters], zero padded to 16 filters and to a
+// multiple of MF_CK channels (one contiguous 16-byte-loadable block per channel chunk).  The old layout makes every lane
+// of a weight load hit its own cache line (filter stride C*K*K floats): 18 such loads per chunk cost more than the MFMAs.
+__global__ void k_mf_wtrans(const float* __restrict__ filt, float* __restrict__ wT, int F, int C, int KK, int Cpad) {
+    const int e = blockIdx.x * blockDim.x + threadIdx.x;
+    if (e >= (Cpad >> 2) * KK * 64) return;
+    const int ln = e & 63, tk = e >> 6, tap = tk % KK, c4 = tk / KK;
+    const int f = ln & 15, c = 4 * c4 + (ln >> 4);
+    wT[e] = (f < F && c < C) ? filt[((long)f * C + c) * KK + tap] : 0.f;
 }
 
 // ---------------------------------------------------------------------------------------------------
@@ -241,16 +257,14 @@ __global__ __launch_bounds__(256) void k_mf_adj(const float* __restrict__ feat, 
             const float* __restrict__ fc = feat + (long)i * stride_n + (long)min(c, g.C - 1) * HW;
             const float* __restrict__ rc = inp + ((long)i * g.F + min(f, g.F - 1)) * HW;
 #pragma unroll
-            for (int q = 0; q < NQ; ++q) {
-                const bool fok = fp.g[q] >= 0 && c < g.C, rok = rp.g[q] >= 0 && f < g.F;
+            for (int q = 0; q < NQ; ++q) {                          // raw loads; masks are applied in stage()
                 if (VW == 4) {
                     const f32x4 a = *(const f32x4*)(fc + max(fp.g[q], 0)), b = *(const f32x4*)(rc + max(rp.g[q], 0));
 #pragma unroll
-                    for (int m = 0; m < 4; ++m) { sv[cc][q][m] = fok ? a[m] : 0.f; rv[cc][q][m] = rok ? b[m] : 0.f; }
+                    for (int m = 0; m < 4; ++m) { sv[cc][q][m] = a[m]; rv[cc][q][m] = b[m]; }
                 } else {
-                    const float a = fc[max(fp.g[q], 0)], b = rc[max(rp.g[q], 0)];
-                    sv[cc][q][0] = fok ? a : 0.f;
-                    rv[cc][q][0] = rok ? b : 0.f;
+                    sv[cc][q][0] = fc[max(fp.g[q], 0)];
+                    rv[cc][q][0] = rc[max(rp.g[q], 0)];
                 }
             }
         }
@@ -262,15 +276,16 @@ __global__ __launch_bounds__(256) void k_mf_adj(const float* __restrict__ feat, 
         for (int cc = 0; cc < 4; ++cc) {
             float* __restrict__ fc = fl + (wave + 4 * cc) * CS2;
             float* __restrict__ rc = rl + (wave + 4 * cc) * RS2;
+            const bool cok = cb * 16 + wave + 4 * cc < g.C, fok = wave + 4 * cc < g.F;
 #pragma unroll
             for (int q = 0; q < NQ; ++q) {
                 if (fp.g[q] >= 0) {
 #pragma unroll
-                    for (int m = 0; m < VW; ++m) fc[fp.l[q] + m] = sv[cc][q][m];
+                    for (int m = 0; m < VW; ++m) fc[fp.l[q] + m] = cok ? sv[cc][q][m] : 0.f;
                 }
                 if (rp.g[q] >= 0) {
 #pragma unroll
-                    for (int m = 0; m < VW; ++m) rc[rp.l[q] + m] = rv[cc][q][m];
+                    for (int m = 0; m < VW; ++m) rc[rp.l[q] + m] = fok ? rv[cc][q][m] : 0.f;
                 }
             }
         }
@@ -358,6 +373,9 @@ static MfPlan mf_plan(int n, int F, int C, int H, int W, int K) {
     while (BR > 1 && ((BR + K - 1) * W > 64 * MF_NQ ||
                       (n * ((H + BR - 1) / BR) < 512 && (BR - 1) * W >= 96)))      // keep >= 6 of a wave quad's 8 tile slots busy
         --BR;
+#ifdef PT_EXPERIMENT
+    if (getenv("PT_MF_BR")) BR = atoi(getenv("PT_MF_BR"));
+#endif
     if ((BR + K - 1) * W > 64 * MF_NQ || BR * W > 256) return p;
     g.BR = BR;
     g.NB = (H + BR - 1) / BR;
@@ -368,6 +386,9 @@ static MfPlan mf_plan(int n, int F, int C, int H, int W, int K) {
     int BRa = 256 / W;
     if (BRa > H) BRa = H;
     while (BRa > 1 && (BRa + K - 1) * W > 64 * MF_NQ) --BRa;
+#ifdef PT_EXPERIMENT
+    if (getenv("PT_MF_BRA")) BRa = atoi(getenv("PT_MF_BRA"));
+#endif
     if ((BRa + K - 1) * W > 64 * MF_NQ) return p;
     p.ga.BR = BRa;
     p.ga.NB = (H + BRa - 1) / BRa;
@@ -379,6 +400,9 @@ static MfPlan mf_plan(int n, int F, int C, int H, int W, int K) {
     p.adj_lds = std::max((size_t)16 * (p.CS2 + p.RS2), (size_t)4 * g.KK * 256) * sizeof(float);
     const int CBn = (C + 15) / 16;
     int NSG = 512 / CBn;                                 // ~2 workgroups per CU
+#ifdef PT_EXPERIMENT
+    if (getenv("PT_MF_NSG")) NSG = atoi(getenv("PT_MF_NSG"));
+#endif
     if (NSG < 1) NSG = 1;
     if (NSG > n) NSG = n;
     if (NSG > 32) NSG = 32;
@@ -387,6 +411,15 @@ static MfPlan mf_plan(int n, int F, int C, int H, int W, int K) {
     if (p.corr_lds > 150 * 1024 || p.adj_lds > 150 * 1024) return p;
     p.ok = 1;
     return p;
+}
+
+size_t pt_mf_wt_floats(int C, int K) { return (size_t)(((C + MF_CK - 1) / MF_CK) * MF_CK / 4) * K * K * 64; }
+
+int pt_launch_mf_wtrans(const float* filt, float* wT, int F, int C, int K, hipStream_t st) {
+    const int Cpad = ((C + MF_CK - 1) / MF_CK) * MF_CK, total = (Cpad >> 2) * K * K * 64;
+    hipLaunchKernelGGL(k_mf_wtrans, dim3((total + 255) / 256), dim3(256), 0, st, filt, wT, F, C, K * K, Cpad);
+    PT_CHECK_LAUNCH();
+    return PT_OK;
 }
 
 size_t pt_mf_gpart_floats(int n, int F, int C, int H, int W, int K) {
@@ -402,15 +435,23 @@ static bool mf_vec_ok(const float* a, const float* b, long stride_n, int W) {
     return (W % 4) == 0 && (stride_n % 4) == 0 && ((uintptr_t)a % 16) == 0 && ((uintptr_t)b % 16) == 0;
 }
 
-int pt_launch_mf_corr(const float* feat, long stride_n, const float* filt, float* scores, int n, int F, int C, int H,
+// wT: weights pre-transposed by pt_launch_mf_wtrans (pt_mf_wt_floats(C, K) floats, 16-byte aligned)
+int pt_launch_mf_corr(const float* feat, long stride_n, const float* wT, float* scores, int n, int F, int C, int H,
                       int W, int K, hipStream_t st) {
     MfPlan p = mf_plan(n, F, C, H, W, K);
     if (!p.ok) return PT_ERR_UNSUPPORTED;
     dim3 grid(p.g.NB, n), block(256);
     const bool vec = mf_vec_ok(feat, feat, stride_n, W);
     pt_prof_begin(0, st);
+    unsigned long long* trace = nullptr;
+#ifdef PT_EXPERIMENT
+    if (getenv("PT_MF_TRACE")) {
+        if (!g_mf_trace) hipMalloc(&g_mf_trace, (size_t)4096 * 128 * 8);
+        trace = g_mf_trace;
+    }
+#endif
 #define PT_MFC(KKV, NTV, VWV) \
-    hipLaunchKernelGGL((k_mf_corr<KKV, NTV, VWV>), grid, block, p.corr_lds, st, feat, stride_n, filt, scores, p.g, p.CS)
+    hipLaunchKernelGGL((k_mf_corr<KKV, NTV, VWV>), grid, block, p.corr_lds, st, feat, stride_n, wT, scores, p.g, p.CS, trace)
     if (K == 1) {
         if (p.NT == 2) { if (vec) PT_MFC(1, 2, 4); else PT_MFC(1, 2, 1); }
         else { if (vec) PT_MFC(1, 4, 4); else PT_MFC(1, 4, 1); }
@@ -440,3 +481,12 @@ int pt_launch_mf_adj(const float* feat, long stride_n, const float* inp, float* 
     PT_CHECK_LAUNCH();
     return PT_OK;
 }
+
+#ifdef PT_EXPERIMENT
+// experiments only: copy the time stamps of the last k_mf_corr launch to the host (slots x workgroups)
+extern "C" int pt_mf_trace_dump(unsigned long long* host, int nwg) {
+    if (!g_mf_trace) return -1;
+    hipDeviceSynchronize();
+    return hipMemcpy(host, g_mf_trace, (size_t)nwg * 128 * 8, hipMemcpyDeviceToHost) == hipSuccess ? 0 : -2;
+}
+#endif

@@ -73,7 +73,9 @@ int pt_launch_adj2_sd(const PtFast& p, const float* feat, long stride_n, const S
 // ---- multi-filter passes (mf_kernels.hip): F <= 16 filters, odd K, C % 16 == 0 -----------------------------
 size_t pt_mf_gpart_floats(int n, int F, int C, int H, int W, int K);     // 0: configuration not covered
 int pt_mf_groups(int n, int F, int C, int H, int W, int K);              // sample groups of the adjoint partials
-int pt_launch_mf_corr(const float* feat, long stride_n, const float* filt, float* scores, int n, int F, int C, int H,
+size_t pt_mf_wt_floats(int C, int K);                                    // pre-transposed weight table
+int pt_launch_mf_wtrans(const float* filt, float* wT, int F, int C, int K, hipStream_t st);
+int pt_launch_mf_corr(const float* feat, long stride_n, const float* wT, float* scores, int n, int F, int C, int H,
                       int W, int K, hipStream_t st);
 int pt_launch_mf_adj(const float* feat, long stride_n, const float* inp, float* gpart, int n, int F, int C, int H, int W,
                      int K, hipStream_t st);

@@ -97,8 +97,13 @@ def corr_mf_raw(feat4, filt4):
         feat4 = feat4.contiguous()
     filt4 = filt4.contiguous()
     out = torch.empty((n, Fn, H, W), dtype=torch.float32, device=feat4.device)
-    rc = _lib.lib().pt_apply_filter_mf_f32(_ptr(feat4), feat4.stride(0), _ptr(filt4), _ptr(out), n, Fn, C, H, W, KH,
-                                           _stream())
+    L = _lib.lib()
+    nb = L.pt_apply_filter_mf_ws_bytes(n, Fn, C, H, W, KH)
+    if nb == 0:
+        raise RuntimeError("multi-filter apply_filter: configuration not covered by the gfx950 kernels")
+    ws = workspace(nb, feat4.device)
+    rc = L.pt_apply_filter_mf_f32(_ptr(feat4), feat4.stride(0), _ptr(filt4), _ptr(out), n, Fn, C, H, W, KH, _ptr(ws),
+                                  ws.numel(), _stream())
     _lib.check(rc, "pt_apply_filter_mf_f32")
     return out
 

@@ -45,6 +45,36 @@ def test_argument_checks_do_not_launch(L):
     assert L.pt_track_frame_ws_bytes(50, 512, 18, 18, 4) > L.pt_sd_ws_bytes(50, 512, 18, 18, 4)
 
 
+def test_multifilter_and_lwl_argument_checks(L):
+    n = None
+    one = ctypes.c_void_p(256)
+    # F > 16 filters, even K, W > 256 are outside the multi-filter kernels: no workspace, UNSUPPORTED
+    assert L.pt_lwl_ws_bytes(4, 16, 512, 30, 52, 3) > 0
+    assert L.pt_lwl_ws_bytes(4, 17, 512, 30, 52, 3) == 0
+    assert L.pt_lwl_ws_bytes(4, 16, 512, 30, 52, 4) == 0
+    assert L.pt_feat_transpose_mf_ws_bytes(4, 16, 512, 30, 300, 3) == 0
+    assert L.pt_apply_filter_mf_f32(n, 0, n, n, 1, 1, 16, 4, 4, 3, n, 0, n) == -1                 # PT_ERR_NULL
+    assert L.pt_apply_filter_mf_f32(one, 16 * 16, one, one, 1, 17, 16, 4, 4, 3, one, 1 << 20, n) == -3   # 17 filters
+    assert L.pt_apply_filter_mf_f32(one, 8, one, one, 1, 4, 16, 4, 4, 3, one, 1 << 20, n) == -2   # sample stride < C*H*W
+    assert L.pt_apply_filter_mf_f32(one, 256, one, one, 1, 4, 16, 4, 4, 3, one, 0, n) == -4        # workspace
+    assert L.pt_feat_transpose_mf_f32(one, 256, one, one, 1, 4, 16, 4, 4, 3, one, 0, n) == -4     # workspace
+    assert L.pt_lwl_gn_solve_f32(one, one, 256, one, n, 2, 0.1, 0.0, 1, 4, 16, 4, 4, 3, 1, one, n, one, 1 << 30, n) == -1
+    assert L.pt_lwl_gn_solve_f32(one, one, 256, one, n, 0, 0.1, 0.0, 1, 4, 16, 4, 4, 3, 65, one, n, one, 1 << 30, n) == -3
+
+
+def test_lwl_mirror_contract():
+    from pytracking_amd import steepestdescent as sd
+    res = sd.LWTLResidual(init_filter_reg=0.05)
+    assert set(res.state_dict().keys()) == {"filter_reg"}                 # loss_residual_modules.py:13
+    opt = sd.GNSteepestDescent(res, num_iter=3, residual_batch_dim=1)
+    assert opt.num_iter == 3 and opt.steplength_reg == 0.0
+    with pytest.raises(RuntimeError, match="MI355X"):                     # no CPU fallback on the product path
+        opt(torch.zeros(1, 2, 16, 3, 3), feat=torch.zeros(1, 1, 16, 4, 4), label=torch.zeros(1, 1, 2, 4, 4))
+    with pytest.raises(NotImplementedError):                              # default residual_batch_dim=0 is not LWL's
+        sd.GNSteepestDescent(res, num_iter=1)(torch.zeros(1, 2, 16, 3, 3), feat=torch.zeros(1, 1, 16, 4, 4),
+                                              label=torch.zeros(1, 1, 2, 4, 4))
+
+
 def test_module_mirror_state_dict_keys():
     from pytracking_amd import optimizer
     m = optimizer.DiMPSteepestDescentGN(num_iter=5, init_step_length=0.9, init_filter_reg=0.1, init_gauss_sigma=0.9,

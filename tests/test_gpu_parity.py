@@ -285,6 +285,24 @@ def test_lwl_gn_golden(name):
     close(losses, g["losses"], atol=1e-7, rtol=1e-4)
 
 
+def test_lwl_edge_cases():
+    """zero iterations (loss only), one filter, one sample, unsupported filter counts raise."""
+    from pytracking_amd import filter as FL
+    rng = np.random.default_rng(91)
+    feat = synth.clf_features(rng, 1, 24, 6, 8, 3)
+    label = rng.uniform(0, 1, (1, 1, 6, 8)).astype(np.float32)
+    w0 = rng.standard_normal((1, 24, 3, 3), dtype=np.float32) * 0.05
+    f64 = lambda a: a.astype(np.float64)
+    its, losses = _lwl_run(w0, feat, label, None, 0, 0.1, 0.0)
+    assert its.shape[0] == 1 and losses.shape[0] == 1
+    ref_its, ref_l = O.lwl_gn_sd(f64(w0), f64(feat), f64(label), None, num_iter=2, filter_reg=0.1)
+    close(losses[0], ref_l[0], atol=1e-7, rtol=1e-4)
+    its, losses = _lwl_run(w0, feat, label, None, 2, 0.1, 0.0)
+    close(its, ref_its, atol=2e-5)
+    with pytest.raises(RuntimeError, match="not covered"):
+        FL.apply_filter(T(feat)[:, None], T(np.zeros((1, 17, 24, 3, 3), np.float32)))   # 17 filters
+
+
 def test_lwl_gn_config5_geometry_vs_oracle():
     """BASELINE configs[4] geometry (16 filters, 3x3, 30x52 maps) at reduced n and C; 3 iterations."""
     rng = np.random.default_rng(55)
