@@ -156,6 +156,18 @@ int pt_atom_cg_f32(float* x, const float* samples, long samples_stride_n, const 
                    float direction_forget_factor, float* cg_state,
                    void* ws, size_t ws_bytes, void* stream);
 
+/* ATOM first-frame joint optimisation -- GaussNewtonCG.run (pytracking/libs/optimization.py:328-421) on
+ * FactorizedConvProblem (pytracking/tracker/atom/optim.py:6-68), identity projection activation, MLU response activation:
+ *   filter (Kc,K,K) and proj (Kc,M) [= the reference's (Kc,M,1,1)] are updated IN PLACE (optimization.py:403-404);
+ *   samples (n,M,H,W) uncompressed features; y (n,H,W); sample_weights (n);
+ *   cg_iters: HOST array of num_gn CG iteration counts, one Gauss-Newton iteration each (optimization.py:340-358);
+ *   CG state is reset at every Gauss-Newton iteration (direction_forget_factor = 0, the tracker's setting). */
+size_t pt_atom_gn_ws_bytes(int n, int M, int Kc, int H, int W, int K);
+int pt_atom_gn_f32(float* filter, float* proj, const float* samples, long samples_stride_n, const float* y,
+                   const float* sample_weights, float filter_reg, float projection_reg, float act_min_val,
+                   int n, int M, int Kc, int H, int W, int K, const int* cg_iters, int num_gn, int fletcher_reeves,
+                   void* ws, size_t ws_bytes, void* stream);
+
 /* ------------------------------------------------------------------------------------------------
  * Precise RoI Pooling -- replaces ltr/external/PreciseRoIPooling (empty git submodule;
  * import sites ltr/models/target_classifier/initializer.py:4,18,45 and

@@ -194,6 +194,37 @@ def gen_atom_cg():
     run("cfg1_n250", 1250, 250, None, 5)
 
 
+def gen_atom_gn():
+    """ATOM first-frame joint optimisation: the reference's GaussNewtonCG on FactorizedConvProblem (CPU, autograd)."""
+    from pytracking import TensorList
+    from pytracking.libs import optimization
+    from pytracking.tracker.atom.optim import FactorizedConvProblem
+    from ltr.models.layers import activation
+    cfg = synth.ATOM18
+
+    def run(tag, seed, n, M, Kc, H, W, cg_iters, fr):
+        rng = np.random.default_rng(seed)
+        samples = (rng.standard_normal((n, M, H, W), dtype=np.float32) * np.float32(0.1))
+        _, _, y, sw = synth.atom_problem(seed, n, cfg, small=dict(C=Kc, H=H, W=W))
+        f0 = rng.standard_normal((Kc, 4, 4), dtype=np.float32) * np.float32(0.05)
+        P0 = rng.standard_normal((Kc, M), dtype=np.float32) * np.float32(1.0 / np.sqrt(M))
+        act = activation.MLU(cfg["act_min_val"])
+        prob = FactorizedConvProblem(TensorList([T(samples)]), TensorList([T(y)[:, None]]), TensorList([cfg["filter_reg"]]),
+                                     TensorList([1e-4]), None, TensorList([T(sw)]), lambda x: x, act)
+        filt = T(f0.copy())[None].clone()
+        proj = T(P0.copy())[:, :, None, None].clone()
+        var = TensorList([filt]).concat(TensorList([proj]))
+        opt = optimization.GaussNewtonCG(prob, var, fletcher_reeves=fr)
+        opt.run(list(cg_iters))
+        save(f"atom_gn_{tag}", samples=samples, y=y, sw=sw, f0=f0, P0=P0, f_out=var[0].detach()[0].numpy(),
+             P_out=var[1].detach()[:, :, 0, 0].numpy(), cg_iters=np.array(cg_iters), fletcher_reeves=int(fr),
+             filter_reg=cfg["filter_reg"], projection_reg=1e-4, act_min_val=cfg["act_min_val"])
+
+    run("small_fr", 61, 4, 12, 8, 10, 10, [3, 3], True)
+    run("small_pr", 62, 3, 16, 8, 9, 11, [2, 2, 2], False)
+    run("mid", 63, 6, 32, 16, 18, 18, [4, 4], True)
+
+
 def gen_prroi_consumers():
     """Reference modules that consume PrRoIPool, executed with the restatement plugged in."""
     from ltr.models.target_classifier.initializer import FilterInitializerLinear
@@ -267,7 +298,9 @@ def gen_lwl():
 
 if __name__ == "__main__":
     torch.set_num_threads(8)
-    which = sys.argv[1:] or ["filter", "dimp", "l2", "prdimp", "atom", "prroi", "lwl"]
+    which = sys.argv[1:] or ["filter", "dimp", "l2", "prdimp", "atom", "prroi", "lwl", "atomgn"]
+    if "atomgn" in which:
+        gen_atom_gn()
     if "lwl" in which:
         gen_lwl()
     if "filter" in which:

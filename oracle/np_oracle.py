@@ -302,6 +302,92 @@ def prdimp_sd(w0, feat, bb, sample_weight, *, num_iter, step_length, filter_reg,
 
 
 # --------------------------------------------------------------------------------------------
+# ATOM first-frame joint optimisation: GaussNewtonCG on FactorizedConvProblem
+#   pytracking/libs/optimization.py:293-421, 72-163;  pytracking/tracker/atom/optim.py:6-68
+# --------------------------------------------------------------------------------------------
+
+def conv1x1(samples, P):
+    """operation.conv1x1 (pytracking/libs/operation.py:35-42): samples (n,M,H,W), P (Kc,M) -> (n,Kc,H,W)."""
+    return np.einsum("nmhw,km->nkhw", samples, P, optimize=True)
+
+
+def conv_same_input_grad(v, filt, H, W):
+    """Gradient of conv2d(c, filt, mode='same') w.r.t. the input c for an output-side map v (n,H,W):
+    gc[i,k,yy,xx] = sum_{u,v} v[i, yy-u+p, xx-v+p] * filt[k,u,v]   (zero outside the HxW output)."""
+    n = v.shape[0]
+    Kc, KH, KW = filt.shape
+    ph, pw = KH // 2, KW // 2
+    vp = np.zeros((n, H + KH, W + KW), dtype=v.dtype)
+    vp[:, KH - 1 - ph + 0:KH - 1 - ph + H, KW - 1 - pw:KW - 1 - pw + W] = v
+    gc = np.zeros((n, Kc, H, W), dtype=v.dtype)
+    for u in range(KH):
+        for w_ in range(KW):
+            # v[yy-u+p] lives at padded row yy - u + p + (KH-1-p) = yy + KH - 1 - u
+            gc += vp[:, None, KH - 1 - u:KH - 1 - u + H, KW - 1 - w_:KW - 1 - w_ + W] * filt[None, :, u, w_, None, None]
+    return gc
+
+
+def atom_gn_cg(filter0, P0, samples, y, sample_weights, *, filter_reg, projection_reg, act_min_val, cg_iters,
+               fletcher_reeves=True):
+    """`GaussNewtonCG.run` (optimization.py:328-407) on `FactorizedConvProblem` (atom/optim.py:6-68), identity
+    projection activation, MLU response activation, explicit Jacobian instead of double autograd.
+
+    filter0 (Kc,K,K); P0 (Kc,M) [= (Kc,M,1,1)]; samples (n,M,H,W); y (n,H,W); cg_iters: list, one entry per GN iteration.
+    Residuals [sqrt(sw)*(MLU(conv_same(conv1x1(S,P), f)) - y), sqrt(lf)*f, sqrt(lP)*P]  (optim.py:19-45);
+    joint inner product over both blocks (:48-65); preconditioner M1 = diag(1/lf, 1/lP) (:67-68, :17).
+    Returns (filter, P)."""
+    dt = samples.dtype
+    n, M, H, W = samples.shape
+    K = filter0.shape[-1]
+    lf, lP = dt.type(filter_reg), dt.type(projection_reg)
+    sqf, sqP = dt.type(math.sqrt(filter_reg)), dt.type(math.sqrt(projection_reg))
+    f, P = filter0.astype(dt), P0.astype(dt)
+    ssw = np.sqrt(sample_weights).reshape(-1, 1, 1).astype(dt)
+    for num_cg in cg_iters:
+        c = conv1x1(samples, P)
+        s = apply_filter(c, f, out_hw=(H, W))
+        d = ssw * mlu_deriv(s, act_min_val)
+        r0 = (ssw * (mlu(s, act_min_val) - y), sqf * f, sqP * P)
+
+        def JT(ud, uf, uP):
+            v = d * ud
+            gf = apply_feat_transpose(c, v, K) + sqf * uf
+            gc = conv_same_input_grad(v, f, H, W)
+            gP = np.einsum("nkhw,nmhw->km", gc, samples, optimize=True) + sqP * uP
+            return gf, gP
+
+        def J(pf, pP):
+            dc = conv1x1(samples, pP)
+            return d * (apply_filter(c, pf, out_hw=(H, W)) + apply_filter(dc, f, out_hw=(H, W))), sqf * pf, sqP * pP
+
+        ip = lambda a, b: (a[0] * b[0]).sum() + (a[1] * b[1]).sum()
+        bf, bP = JT(*r0)
+        r = (-bf, -bP)                                                   # optimization.py:389-392
+        p, rho, r_prev, delta = None, dt.type(1.0), None, None           # direction_forget_factor == 0: reset (:82-83)
+        for ii in range(num_cg):
+            z = (r[0] / lf, r[1] / lP)                                   # M1, M2 = identity
+            rho1, rho = rho, ip(r, z)
+            if rho == 0:
+                break
+            if p is None:
+                p = z
+            else:
+                beta = rho / rho1 if fletcher_reeves else (rho - ip(r_prev, z)) / rho1
+                beta = max(beta, dt.type(0))
+                p = (z[0] + p[0] * beta, z[1] + p[1] * beta)
+            q = JT(*J(*p))
+            alpha = rho / ip(p, q)
+            if not fletcher_reeves:
+                r_prev = r
+            delta = (p[0] * alpha, p[1] * alpha) if delta is None else (delta[0] + p[0] * alpha, delta[1] + p[1] * alpha)
+            if ii < num_cg - 1:
+                r = (r[0] - q[0] * alpha, r[1] - q[1] * alpha)
+        if delta is not None:
+            f, P = f + delta[0], P + delta[1]
+    return f, P
+
+
+# --------------------------------------------------------------------------------------------
 # LWL few-shot learner: ltr/models/meta/steepestdescent.py + ltr/models/lwl/loss_residual_modules.py
 # --------------------------------------------------------------------------------------------
 

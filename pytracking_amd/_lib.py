@@ -9,7 +9,7 @@ import subprocess
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.environ.get("PT_HOT_LIB", os.path.join(_HERE, "libpt_hot.so"))   # override: experiments only
-SOURCES = ["filter_kernels.hip", "fast_passes.hip", "sd_solver.hip", "mf_kernels.hip", "lwl_solver.hip", "atom_cg.hip", "prroi.hip", "api.hip", "profile.hip"]
+SOURCES = ["filter_kernels.hip", "fast_passes.hip", "sd_solver.hip", "mf_kernels.hip", "lwl_solver.hip", "atom_cg.hip", "atom_gn.hip", "prroi.hip", "api.hip", "profile.hip"]
 HEADERS = ["common.h", "pt_internal.h", "rbuild.h", "sd_common.h", os.path.join("..", "..", "include", "pt_hot.h")]
 
 PT_SD_DIMP, PT_SD_DIMP_L2, PT_SD_PRDIMP = 0, 1, 2
@@ -21,7 +21,7 @@ EXPORTS = [
     "pt_apply_filter_ws_bytes", "pt_apply_filter_f32",
     "pt_feat_transpose_ws_bytes", "pt_feat_transpose_f32",
     "pt_sd_ws_bytes", "pt_sd_solve_f32",
-    "pt_atom_cg_ws_bytes", "pt_atom_cg_f32",
+    "pt_atom_cg_ws_bytes", "pt_atom_cg_f32", "pt_atom_gn_ws_bytes", "pt_atom_gn_f32",
     "pt_prroi_fwd_f32", "pt_prroi_bwd_feat_f32", "pt_prroi_bwd_coor_f32",
     "pt_track_frame_ws_bytes", "pt_track_frame_f32",
     "pt_apply_filter_mf_ws_bytes", "pt_apply_filter_mf_f32", "pt_feat_transpose_mf_ws_bytes", "pt_feat_transpose_mf_f32",
@@ -100,6 +100,10 @@ def lib():
     L.pt_atom_cg_ws_bytes.argtypes = [i] * 5
     L.pt_atom_cg_f32.restype = i
     L.pt_atom_cg_f32.argtypes = [vp, vp, l, vp, vp, f, f] + [i] * 7 + [f, vp, vp, sz, vp]
+    L.pt_atom_gn_ws_bytes.restype = sz
+    L.pt_atom_gn_ws_bytes.argtypes = [i] * 6
+    L.pt_atom_gn_f32.restype = i
+    L.pt_atom_gn_f32.argtypes = [vp, vp, vp, l, vp, vp, f, f, f] + [i] * 6 + [ctypes.POINTER(ctypes.c_int), i, i, vp, sz, vp]
     for name in ("pt_prroi_fwd_f32", "pt_prroi_bwd_feat_f32"):
         fn = getattr(L, name)
         fn.restype = i

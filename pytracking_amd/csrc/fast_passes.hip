@@ -528,7 +528,8 @@ __device__ __forceinline__ void sdp_compute(const Adj2Args& a, int i, int lane, 
     }
 }
 
-template <int V, int E>
+// UM: 16-position groups per wave (compile-time trip count of the pipelined loop; 12 for the 22x22 PrDiMP geometry)
+template <int V, int E, int UM>
 __global__ __launch_bounds__(PT_ADJ_WAVES * 64) void k_adj2(Adj2Args a) {
     extern __shared__ __attribute__((aligned(16))) float maps[];    // [ns_max][PH][PW] zero-padded residual maps + 16 zeros
     __shared__ float red[PT_ADJ_WAVES][256];
@@ -594,7 +595,6 @@ __global__ __launch_bounds__(PT_ADJ_WAVES * 64) void k_adj2(Adj2Args a) {
     // ---- G[c][tap] += feat[c][P] * r[P shifted by tap] over the U contiguous 16-position groups of this wave.
     //      A wave stalls at a load it cannot issue (the CU's memory pipeline accepts ~20-45 B/clk), so the loads are
     //      software-pipelined PD groups ahead of the MFMAs that consume them instead of being issued all up front.
-    constexpr int UM = PT_ADJ_UMAX;
     constexpr int PD = UM < 8 ? UM : (UM == 8 ? 8 : 6);
     const int c = cb * 16 + j;
     const __amdgpu_buffer_rsrc_t fr = pt_rsrc(a.feat, (unsigned)(((long)(a.n - 1) * a.stride_n + (long)a.C * HW) * 4));
@@ -666,9 +666,10 @@ static void adj2_fill(const PtFast& p, Adj2Args& a, const float* feat, long stri
 template <int V>
 static void adj2_dispatch(const PtFast& p, const Adj2Args& a, hipStream_t st) {
     dim3 grid(p.CB * p.KSPL), block(PT_ADJ_WAVES * 64);
-    if (p.E == 6) hipLaunchKernelGGL((k_adj2<V, 6>), grid, block, p.adj_lds, st, a);
-    else if (p.E == 9) hipLaunchKernelGGL((k_adj2<V, 9>), grid, block, p.adj_lds, st, a);
-    else hipLaunchKernelGGL((k_adj2<V, 16>), grid, block, p.adj_lds, st, a);
+    if (p.E == 6) hipLaunchKernelGGL((k_adj2<V, 6, 16>), grid, block, p.adj_lds, st, a);
+    else if (p.E == 9 && p.U <= 12) hipLaunchKernelGGL((k_adj2<V, 9, 12>), grid, block, p.adj_lds, st, a);
+    else if (p.E == 9) hipLaunchKernelGGL((k_adj2<V, 9, 16>), grid, block, p.adj_lds, st, a);
+    else hipLaunchKernelGGL((k_adj2<V, 16, 16>), grid, block, p.adj_lds, st, a);
 }
 
 int pt_launch_adj2_plain(const PtFast& p, const float* feat, long stride_n, const float* inp, float* gpart,

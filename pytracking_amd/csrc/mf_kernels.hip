@@ -68,8 +68,8 @@ struct MfStage {
 
 template <int KK, int NT, int VW>
 __global__ __launch_bounds__(256) void k_mf_corr(const float* __restrict__ feat, long stride_n,
-                                                 const float* __restrict__ wT, float* __restrict__ scores, MfGeom g,
-                                                 int CS, unsigned long long* trace) {
+                                                 const float* __restrict__ wT, float* __restrict__ scores,
+                                                 long out_stride_n, MfGeom g, int CS, unsigned long long* trace) {
     extern __shared__ __attribute__((aligned(16))) float lds[];
     constexpr int NQ = MF_NQ / VW;
     constexpr int K = KK == 1 ? 1 : 3;
@@ -197,7 +197,7 @@ __global__ __launch_bounds__(256) void k_mf_corr(const float* __restrict__ feat,
 #pragma unroll
             for (int r = 0; r < 4; ++r) {
                 const int f = 4 * kq + r;
-                if (f < g.F) scores[((long)i * g.F + f) * HW + (long)y0 * g.W + pj] = acc[q][r];
+                if (f < g.F) scores[(long)i * out_stride_n + (long)f * HW + (long)y0 * g.W + pj] = acc[q][r];
             }
         }
     }
@@ -223,8 +223,8 @@ __global__ void k_mf_wtrans(const float* __restrict__ filt, float* __restrict__ 
 // ---------------------------------------------------------------------------------------------------
 template <int KK, int VW>
 __global__ __launch_bounds__(256) void k_mf_adj(const float* __restrict__ feat, long stride_n,
-                                                const float* __restrict__ inp, float* __restrict__ gpart, MfGeom g,
-                                                int CS2, int RS2, int spg) {
+                                                const float* __restrict__ inp, long inp_stride_n,
+                                                float* __restrict__ gpart, MfGeom g, int CS2, int RS2, int spg) {
     extern __shared__ __attribute__((aligned(16))) float lds[];
     constexpr int NQ = MF_NQ / VW;
     constexpr int K = KK == 1 ? 1 : 3;
@@ -255,7 +255,7 @@ __global__ __launch_bounds__(256) void k_mf_adj(const float* __restrict__ feat, 
         for (int cc = 0; cc < 4; ++cc) {
             const int c = cb * 16 + wave + 4 * cc, f = wave + 4 * cc;
             const float* __restrict__ fc = feat + (long)i * stride_n + (long)min(c, g.C - 1) * HW;
-            const float* __restrict__ rc = inp + ((long)i * g.F + min(f, g.F - 1)) * HW;
+            const float* __restrict__ rc = inp + (long)i * inp_stride_n + (long)min(f, g.F - 1) * HW;
 #pragma unroll
             for (int q = 0; q < NQ; ++q) {                          // raw loads; masks are applied in stage()
                 if (VW == 4) {
@@ -437,8 +437,9 @@ static bool mf_vec_ok(const float* a, const float* b, long stride_n, int W) {
 
 // wT: weights pre-transposed by pt_launch_mf_wtrans (pt_mf_wt_floats(C, K) floats, 16-byte aligned)
 int pt_launch_mf_corr(const float* feat, long stride_n, const float* wT, float* scores, int n, int F, int C, int H,
-                      int W, int K, hipStream_t st) {
+                      int W, int K, hipStream_t st, long out_stride_n) {
     MfPlan p = mf_plan(n, F, C, H, W, K);
+    if (out_stride_n == 0) out_stride_n = (long)F * H * W;
     if (!p.ok) return PT_ERR_UNSUPPORTED;
     dim3 grid(p.g.NB, n), block(256);
     const bool vec = mf_vec_ok(feat, feat, stride_n, W);
@@ -451,7 +452,7 @@ int pt_launch_mf_corr(const float* feat, long stride_n, const float* wT, float* 
     }
 #endif
 #define PT_MFC(KKV, NTV, VWV) \
-    hipLaunchKernelGGL((k_mf_corr<KKV, NTV, VWV>), grid, block, p.corr_lds, st, feat, stride_n, wT, scores, p.g, p.CS, trace)
+    hipLaunchKernelGGL((k_mf_corr<KKV, NTV, VWV>), grid, block, p.corr_lds, st, feat, stride_n, wT, scores, out_stride_n, p.g, p.CS, trace)
     if (K == 1) {
         if (p.NT == 2) { if (vec) PT_MFC(1, 2, 4); else PT_MFC(1, 2, 1); }
         else { if (vec) PT_MFC(1, 4, 4); else PT_MFC(1, 4, 1); }
@@ -466,14 +467,15 @@ int pt_launch_mf_corr(const float* feat, long stride_n, const float* wT, float* 
 }
 
 int pt_launch_mf_adj(const float* feat, long stride_n, const float* inp, float* gpart, int n, int F, int C, int H, int W,
-                     int K, hipStream_t st) {
+                     int K, hipStream_t st, long inp_stride_n) {
     MfPlan p = mf_plan(n, F, C, H, W, K);
+    if (inp_stride_n == 0) inp_stride_n = (long)F * H * W;
     if (!p.ok) return PT_ERR_UNSUPPORTED;
     dim3 grid((C + 15) / 16, p.NSG), block(256);
-    const bool vec = mf_vec_ok(feat, inp, stride_n, W) && ((H * W) % 4) == 0;
+    const bool vec = mf_vec_ok(feat, inp, stride_n, W) && ((H * W) % 4) == 0 && (inp_stride_n % 4) == 0;
     pt_prof_begin(1, st);
 #define PT_MFA(KKV, VWV) \
-    hipLaunchKernelGGL((k_mf_adj<KKV, VWV>), grid, block, p.adj_lds, st, feat, stride_n, inp, gpart, p.ga, p.CS2, p.RS2, p.spg)
+    hipLaunchKernelGGL((k_mf_adj<KKV, VWV>), grid, block, p.adj_lds, st, feat, stride_n, inp, inp_stride_n, gpart, p.ga, p.CS2, p.RS2, p.spg)
     if (K == 1) { if (vec) PT_MFA(1, 4); else PT_MFA(1, 1); }
     else { if (vec) PT_MFA(9, 4); else PT_MFA(9, 1); }
 #undef PT_MFA

@@ -12,6 +12,7 @@ What gets rebound (import path = contract; nothing in the reference tree is edit
   ltr.external.PreciseRoIPooling.pytorch.prroi_pool.PrRoIPool2D  (module is CREATED: the submodule is empty)
                                                                                       -> pytracking_amd.prroi_pool
   pytracking.libs.optimization.ConjugateGradient  (ConvProblem + MLU fast path)       -> pytracking_amd.optimization
+  pytracking.libs.optimization.GaussNewtonCG      (FactorizedConvProblem fast path)   -> pytracking_amd.optimization
   ltr.models.lwl.loss_residual_modules.LWTLResidual, ltr.models.meta.steepestdescent.GNSteepestDescent
                                                   (LWL few-shot learner)              -> pytracking_amd.steepestdescent
 
@@ -150,8 +151,8 @@ def install(strict=False, atom_cg=True):
                 """ConvProblem + MLU on device -> fused gfx950 CG; any other problem -> the reference class."""
 
                 def __new__(cls, problem, variable, *args, **kw):
-                    act = getattr(problem, "response_activation", None)
-                    fast = (isinstance(problem, ref_problem) and hasattr(act, "min_val") and len(variable) == 1
+                    kind = _optimization.activation_kind(getattr(problem, "response_activation", None))[0]
+                    fast = (isinstance(problem, ref_problem) and kind == "mlu" and len(variable) == 1
                             and variable[0].is_cuda and not kw.get("debug", False)
                             and kw.get("standard_alpha", True) and kw.get("cg_eps", 0.0) == 0.0)
                     if fast:
@@ -160,10 +161,35 @@ def install(strict=False, atom_cg=True):
                         raise NotImplementedError("ConjugateGradient: problem outside the gfx950 hot path")
                     return ref_cg.__new__(cls)
 
+            orig["gn"] = pmod.GaussNewtonCG
+            ref_gn_cg, ref_fact = pmod.GaussNewtonCG, amod.FactorizedConvProblem
+
+            class GaussNewtonCG(ref_gn_cg):
+                """FactorizedConvProblem, MLU response + identity projection activation, one feature block on device
+                -> fused gfx950 joint Gauss-Newton; any other problem -> the reference class."""
+
+                def __new__(cls, problem, variable, *args, **kw):
+                    ak = _optimization.activation_kind
+                    fast = (isinstance(problem, ref_fact) and len(variable) == 2 and variable[0].is_cuda
+                            and ak(getattr(problem, "response_activation", None))[0] == "mlu"
+                            and ak(getattr(problem, "projection_activation", None))[0] == "identity"
+                            and variable[0].shape[-1] * variable[0].shape[-2] <= 16
+                            and not any(kw.get(k, False) for k in ("debug", "analyze", "plotting"))
+                            and kw.get("standard_alpha", True) and kw.get("cg_eps", 0.0) == 0.0
+                            and kw.get("direction_forget_factor", 0) == 0)
+                    if fast:
+                        return _optimization.GaussNewtonCG(problem, variable, *args, **kw)
+                    if strict:
+                        raise NotImplementedError("GaussNewtonCG: problem outside the gfx950 hot path")
+                    return ref_gn_cg.__new__(cls)
+
             pmod.ConjugateGradient = ConjugateGradient
+            pmod.GaussNewtonCG = GaussNewtonCG
             tmod = sys.modules.get("pytracking.tracker.atom.atom")
             if tmod is not None and hasattr(tmod, "ConjugateGradient"):
                 tmod.ConjugateGradient = ConjugateGradient
+            if tmod is not None and hasattr(tmod, "GaussNewtonCG"):
+                tmod.GaussNewtonCG = GaussNewtonCG
     _state["installed"] = True
 
 
@@ -178,6 +204,8 @@ def uninstall():
         setattr(omod, n, c)
     if "cg" in orig:
         importlib.import_module("pytracking.libs.optimization").ConjugateGradient = orig["cg"]
+    if "gn" in orig:
+        importlib.import_module("pytracking.libs.optimization").GaussNewtonCG = orig["gn"]
     if "lwl" in orig:
         importlib.import_module("ltr.models.lwl.loss_residual_modules").LWTLResidual = orig["lwl"][0]
         importlib.import_module("ltr.models.meta.steepestdescent").GNSteepestDescent = orig["lwl"][1]

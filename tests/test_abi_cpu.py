@@ -62,6 +62,40 @@ def test_multifilter_and_lwl_argument_checks(L):
     assert L.pt_lwl_gn_solve_f32(one, one, 256, one, n, 0, 0.1, 0.0, 1, 4, 16, 4, 4, 3, 65, one, n, one, 1 << 30, n) == -3
 
 
+def test_atom_joint_gn_argument_checks(L):
+    n = None
+    one = ctypes.c_void_p(256)
+    it = (ctypes.c_int * 2)(3, 3)
+    assert L.pt_atom_gn_ws_bytes(30, 256, 64, 18, 18, 4) > 0          # ATOM first frame (atom.py:156-176)
+    assert L.pt_atom_gn_ws_bytes(30, 256, 64, 18, 18, 5) == 0         # 25 taps
+    assert L.pt_atom_gn_ws_bytes(0, 256, 64, 18, 18, 4) == 0
+    assert L.pt_atom_gn_f32(n, one, one, 0, one, one, 0.1, 1e-4, 0.05, 1, 8, 4, 6, 6, 4, it, 2, 1, one, 0, n) == -1
+    assert L.pt_atom_gn_f32(one, one, one, 8 * 36, one, one, 0.1, 1e-4, 0.05, 1, 8, 4, 6, 6, 4, None, 2, 1, one, 0, n) == -1
+    assert L.pt_atom_gn_f32(one, one, one, 8, one, one, 0.1, 1e-4, 0.05, 1, 8, 4, 6, 6, 4, it, 2, 1, one, 1 << 30, n) == -2
+    assert L.pt_atom_gn_f32(one, one, one, 8 * 36, one, one, 0.1, 1e-4, 0.05, 1, 8, 4, 6, 6, 5, it, 2, 1, one, 1 << 30, n) == -3
+    assert L.pt_atom_gn_f32(one, one, one, 8 * 36, one, one, 0.1, 1e-4, 0.05, 1, 8, 4, 6, 6, 4, it, 2, 1, one, 0, n) == -4
+
+
+def test_activation_recognition():
+    """The reference tracker hands its activations over as lambdas (atom.py:444-466); the mirror recognises the two
+    the fused solvers implement and nothing else."""
+    import torch.nn.functional as F
+    from pytracking_amd.optimization import MLU, activation_kind, ConjugateGradient, ConvProblem, GaussNewtonCG, \
+        FactorizedConvProblem
+    assert activation_kind(lambda x: x) == ("identity", None)
+    assert activation_kind(None) == ("identity", None)
+    assert activation_kind(lambda x: F.elu(F.leaky_relu(x, 1 / 0.05), 0.05)) == ("mlu", 0.05)
+    assert activation_kind(MLU(0.05)) == ("mlu", 0.05)
+    assert activation_kind(torch.nn.ReLU(inplace=True)) == (None, None)
+    assert activation_kind(lambda x: x * 2) == (None, None)
+    with pytest.raises(NotImplementedError):
+        ConjugateGradient(ConvProblem([], [], [], [], torch.nn.ReLU()), [])
+    with pytest.raises(NotImplementedError):
+        GaussNewtonCG(FactorizedConvProblem([], [], [], [], None, [], torch.nn.ReLU(), MLU(0.05)), [])
+    with pytest.raises(NotImplementedError):
+        GaussNewtonCG(FactorizedConvProblem([], [], [], [], None, [], None, MLU(0.05)), [], cg_eps=1e-3)
+
+
 def test_lwl_mirror_contract():
     from pytracking_amd import steepestdescent as sd
     res = sd.LWTLResidual(init_filter_reg=0.05)

@@ -351,6 +351,50 @@ def test_atom_cg_golden_config1_size():
     close(out, g["x_out"], atol=1e-4, rtol=1e-3)
 
 
+def _atom_gn_run(f0, P0, samples, y, sw, cg_iters, fr, filter_reg, projection_reg, act_min_val):
+    import torch.nn.functional as F
+    from pytracking_amd.optimization import FactorizedConvProblem, GaussNewtonCG
+    # the activations arrive exactly as the reference tracker builds them (atom.py:444-466): plain lambdas
+    prob = FactorizedConvProblem([T(samples)], [T(y)[:, None]], [filter_reg], [projection_reg], None, [T(sw)],
+                                 lambda x: x, lambda x: F.elu(F.leaky_relu(x, 1 / act_min_val), act_min_val))
+    filt = T(f0.copy())[None].clone()
+    proj = T(P0.copy())[:, :, None, None].clone()
+    opt = GaussNewtonCG(prob, [filt, proj], fletcher_reeves=fr)
+    opt.run(list(cg_iters))
+    return filt[0], proj[:, :, 0, 0]
+
+
+@pytest.mark.parametrize("name", ["atom_gn_small_fr", "atom_gn_small_pr", "atom_gn_mid"])
+def test_atom_joint_gn_golden(name):
+    """ATOM first-frame GaussNewtonCG over (filter, projection matrix): optimization.py:328-421, atom/optim.py:6-68."""
+    g = load_golden(name)
+    f, P = _atom_gn_run(g["f0"], g["P0"], g["samples"], g["y"], g["sw"], [int(v) for v in g["cg_iters"]],
+                        bool(int(g["fletcher_reeves"])), float(g["filter_reg"]), float(g["projection_reg"]),
+                        float(g["act_min_val"]))
+    close(f, g["f_out"], atol=5e-5, rtol=1e-3)
+    close(P, g["P_out"], atol=5e-5, rtol=1e-3)
+
+
+def test_atom_joint_gn_first_frame_size_vs_oracle():
+    """ATOM default first frame (parameter/atom/default.py): 30 augmented samples of 256 x 18 x 18 backbone features,
+    64 compressed channels, 4 x 4 filter, init_CG_iter 60 / init_GN_iter 6 -> 6 x 10 CG iterations (shortened to
+    3 x 4 so the float64 oracle finishes in seconds)."""
+    rng = np.random.default_rng(77)
+    n, M, Kc, H, W, K = 30, 256, 64, 18, 18, 4
+    samples = rng.standard_normal((n, M, H, W), dtype=np.float32) * np.float32(0.1)
+    _, _, y, sw = synth.atom_problem(77, n)
+    f0 = np.zeros((Kc, K, K), np.float32)                               # filter_init_method 'zeros' (atom.py:140-143)
+    P0 = rng.standard_normal((Kc, M), dtype=np.float32) * np.float32(1.0 / np.sqrt(M))
+    cfg = synth.ATOM18
+    f, P = _atom_gn_run(f0, P0, samples, y, sw, [4, 4, 4], True, cfg["filter_reg"], 1e-4, cfg["act_min_val"])
+    f64 = lambda a: a.astype(np.float64)
+    rf, rP = O.atom_gn_cg(f64(f0), f64(P0), f64(samples), f64(y), f64(sw), filter_reg=cfg["filter_reg"],
+                          projection_reg=1e-4, act_min_val=cfg["act_min_val"], cg_iters=[4, 4, 4], fletcher_reeves=True)
+    close(f, rf, atol=1e-4, rtol=2e-3)
+    close(P, rP, atol=1e-4, rtol=2e-3)
+    assert float(np.abs(rf).max()) > 1e-3                               # the solve moved the filter off zero
+
+
 # ------------------------------------------------------------------------------------------------------
 # Precise RoI pooling (oracle self-pinned; see oracle/prroi_torch.py)
 # ------------------------------------------------------------------------------------------------------

@@ -141,3 +141,16 @@ def test_lwl_gn_sd(name):
     np.testing.assert_allclose(np.array(losses), g["losses"], rtol=1e-4, atol=1e-7)
     s = O.apply_filter(g["feat"].astype(np.float64), its[-1])
     np.testing.assert_allclose(s, g["scores"], atol=2e-5)
+
+
+@pytest.mark.parametrize("name", ["atom_gn_small_fr", "atom_gn_small_pr", "atom_gn_mid"])
+def test_atom_joint_gauss_newton(name):
+    """ATOM first-frame GaussNewtonCG on FactorizedConvProblem (optimization.py:328-421, atom/optim.py:6-68)."""
+    g = load_golden(name)
+    f64 = lambda a: a.astype(np.float64)
+    f, P = O.atom_gn_cg(f64(g["f0"]), f64(g["P0"]), f64(g["samples"]), f64(g["y"]), f64(g["sw"]),
+                        filter_reg=float(g["filter_reg"]), projection_reg=float(g["projection_reg"]),
+                        act_min_val=float(g["act_min_val"]), cg_iters=[int(v) for v in g["cg_iters"]],
+                        fletcher_reeves=bool(int(g["fletcher_reeves"])))
+    np.testing.assert_allclose(f, g["f_out"], atol=5e-5)
+    np.testing.assert_allclose(P, g["P_out"], atol=5e-5)
