@@ -14,6 +14,7 @@ Reference entry points executed (all on CPU, fp32, torch.no_grad()):
   pytracking.libs.optimization.ConjugateGradient + atom.optim.ConvProblem (optimization.py:227, optim.py:71)
   ltr.models.target_classifier.initializer.FilterInitializerLinear      (initializer.py:118; PrRoIPool = restatement)
   ltr.models.bbreg.atom_iou_net.AtomIoUNet.predict_iou                  (atom_iou_net.py:96; PrRoIPool = restatement)
+  ltr.models.transformer.filter_predictor.FilterPredictor, heads.{LinearFilterClassifier, DenseBoxRegressor}
 """
 import os
 import sys
@@ -296,9 +297,58 @@ def gen_lwl():
     save("lwl_gn_mid", **g)
 
 
+def build_reference_tomp(cfg, params):
+    """The reference's FilterPredictor + LinearFilterClassifier + DenseBoxRegressor (tompnet.py:106-118) carrying
+    the seeded parameters, in eval mode."""
+    import ltr.models.transformer.transformer as trans
+    import ltr.models.transformer.filter_predictor as fp
+    import ltr.models.transformer.heads as heads
+    D = cfg["D"]
+    tr = trans.Transformer(d_model=D, nhead=cfg["nhead"], num_encoder_layers=cfg["n_enc"],
+                           num_decoder_layers=cfg["n_dec"], dim_feedforward=cfg["ff"])
+    pred = fp.FilterPredictor(tr, feature_sz=cfg["feature_sz"], use_test_frame_encoding=True)
+    cls = heads.LinearFilterClassifier(num_channels=D)
+    reg = heads.DenseBoxRegressor(num_channels=D)
+    for mod, pre in ((pred, "fp."), (cls, "cls."), (reg, "reg.")):
+        sd = {k[len(pre):]: T(v.copy()) for k, v in params.items() if k.startswith(pre)}
+        if pre == "fp.":
+            sd["query_embed_fg_decoder.weight"] = sd["query_embed_fg.weight"]      # same module under two names (:35)
+            for idx in (1, 4):
+                sd[f"box_encoding.{idx}.num_batches_tracked"] = torch.tensor(0)
+        mod.load_state_dict(sd, strict=True)
+        mod.eval()
+    return pred, cls, reg
+
+
+def gen_tomp():
+    """ToMP model predictor (filter_predictor.py:50-150) + heads (heads.py:83-141), reference on CPU."""
+    def run(tag, cfg, seed, store_inputs):
+        params = synth.tomp_params(seed, cfg)
+        train, test, lab, ltrb = synth.tomp_inputs(seed + 1, cfg)
+        pred, cls, reg = build_reference_tomp(cfg, params)
+        with torch.no_grad():
+            cw, bw, cenc, benc = pred.predict_cls_bbreg_filters_parallel(T(train), T(test), T(lab), cfg["num_gth_frames"],
+                                                                         T(ltrb))
+            scores = cls(cenc, cw)
+            boxes = reg(benc, bw)
+            w1, enc1 = pred.predict_filter(T(train), T(test), T(lab), T(ltrb))
+            pos = pred.get_positional_encoding(T(test))
+        out = dict(seed=seed, cls_filter=cw.numpy().reshape(-1), bbreg_filter=bw.numpy().reshape(-1),
+                   cls_enc=cenc.numpy(), bbreg_enc=benc.numpy(), scores=scores.numpy(), ltrb=boxes.numpy(),
+                   single_filter=w1.numpy().reshape(-1), single_enc=enc1.numpy(), pos=pos.numpy()[0, 0])
+        if store_inputs:
+            out.update(train=train, test=test, label=lab, ltrb_target=ltrb)
+        save(f"tomp_{tag}", **out)
+
+    run("small", synth.TOMP_SMALL, 81, True)
+    run("full", synth.TOMP, 83, False)          # BASELINE configs[3] geometry: 256 channels, 8 heads, 6+6 layers, 18x18
+
+
 if __name__ == "__main__":
     torch.set_num_threads(8)
-    which = sys.argv[1:] or ["filter", "dimp", "l2", "prdimp", "atom", "prroi", "lwl", "atomgn"]
+    which = sys.argv[1:] or ["filter", "dimp", "l2", "prdimp", "atom", "prroi", "lwl", "atomgn", "tomp"]
+    if "tomp" in which:
+        gen_tomp()
     if "atomgn" in which:
         gen_atom_gn()
     if "lwl" in which:

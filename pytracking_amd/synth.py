@@ -113,3 +113,103 @@ def atom_problem(seed, n, cfg=ATOM18, small=None):
     sw = decay_weights(n)
     x0 = rng.standard_normal((C, K, K), dtype=np.float32) * np.float32(0.05)
     return x0, samples, y.astype(np.float32), sw
+
+
+# ------------------------------------------------------------------------------------------------------
+# ToMP transformer model predictor (BASELINE configs[3])
+# ------------------------------------------------------------------------------------------------------
+TOMP = dict(  # tompnet50/101 as instantiated by ltr/train_settings/tomp/tomp50.py, tomp101.py (out_feature_dim=256)
+    D=256, nhead=8, ff=2048, n_enc=6, n_dec=6, H=18, W=18, feature_sz=18, n_train=2, num_gth_frames=1)
+TOMP_SMALL = dict(D=64, nhead=2, ff=128, n_enc=2, n_dec=2, H=6, W=6, feature_sz=6, n_train=2, num_gth_frames=1)
+
+
+def _xavier(rng, shape, fan_in, fan_out):
+    a = np.float32(math.sqrt(6.0 / (fan_in + fan_out)))
+    return (rng.random(shape, dtype=np.float32) * 2 - 1) * a
+
+
+def tomp_params(seed, cfg=TOMP):
+    """Seeded parameters of FilterPredictor ('fp.'), LinearFilterClassifier ('cls.') and DenseBoxRegressor ('reg.'),
+    keyed by the reference's state_dict names (filter_predictor.py:19-39, transformer.py:152-190,
+    heads.py:83-117).  Xavier-uniform matrices as `Transformer._reset_parameters` (transformer.py:85-88) draws them;
+    biases, LayerNorm / GroupNorm / BatchNorm affine terms and running statistics are perturbed away from their
+    initial 0/1 so that a dropped term cannot go unnoticed."""
+    rng = np.random.default_rng(seed)
+    D, ff = cfg["D"], cfg["ff"]
+    p = {}
+
+    def vec(n, centre=0.0, spread=0.1):
+        return (np.float32(centre) + np.float32(spread) * rng.standard_normal(n, dtype=np.float32)).astype(np.float32)
+
+    def mha(prefix):
+        p[prefix + "in_proj_weight"] = _xavier(rng, (3 * D, D), D, 3 * D)
+        p[prefix + "in_proj_bias"] = vec(3 * D)
+        p[prefix + "out_proj.weight"] = _xavier(rng, (D, D), D, D)
+        p[prefix + "out_proj.bias"] = vec(D)
+
+    def ffn_norms(prefix, norms):
+        p[prefix + "linear1.weight"] = _xavier(rng, (ff, D), D, ff)
+        p[prefix + "linear1.bias"] = vec(ff)
+        p[prefix + "linear2.weight"] = _xavier(rng, (D, ff), ff, D)
+        p[prefix + "linear2.bias"] = vec(D)
+        for nm in norms:
+            p[prefix + nm + ".weight"] = vec(D, 1.0)
+            p[prefix + nm + ".bias"] = vec(D)
+
+    for i in range(cfg["n_enc"]):
+        pre = f"fp.transformer.encoder.layers.{i}."
+        mha(pre + "self_attn.")
+        ffn_norms(pre, ("norm1", "norm2"))
+    for i in range(cfg["n_dec"]):
+        pre = f"fp.transformer.decoder.layers.{i}."
+        mha(pre + "self_attn.")
+        mha(pre + "multihead_attn.")
+        ffn_norms(pre, ("norm1", "norm2", "norm3"))
+    p["fp.transformer.decoder.norm.weight"] = vec(D, 1.0)
+    p["fp.transformer.decoder.norm.bias"] = vec(D)
+    dims = [4, D // 4, D, D]                                        # MLP([4, d/4, d, d]) (filter_predictor.py:6-17,27)
+    for li, idx in enumerate((0, 3, 6)):
+        p[f"fp.box_encoding.{idx}.weight"] = _xavier(rng, (dims[li + 1], dims[li], 1), dims[li], dims[li + 1])
+        p[f"fp.box_encoding.{idx}.bias"] = vec(dims[li + 1])
+    for li, idx in enumerate((1, 4)):
+        n = dims[li + 1]
+        p[f"fp.box_encoding.{idx}.weight"] = vec(n, 1.0)
+        p[f"fp.box_encoding.{idx}.bias"] = vec(n)
+        p[f"fp.box_encoding.{idx}.running_mean"] = vec(n, 0.0, 0.2)
+        p[f"fp.box_encoding.{idx}.running_var"] = (0.5 + rng.random(n, dtype=np.float32)).astype(np.float32)
+    p["fp.query_embed_fg.weight"] = rng.standard_normal((1, D), dtype=np.float32)
+    p["fp.query_embed_test.weight"] = rng.standard_normal((1, D), dtype=np.float32)
+    p["cls.linear.weight"] = _xavier(rng, (D, D), D, D)
+    p["cls.linear.bias"] = vec(D)
+    p["reg.linear.weight"] = _xavier(rng, (D, D), D, D)
+    p["reg.linear.bias"] = vec(D)
+    for i in range(4):                                              # conv_layer x4 (heads.py:9-16,110-115)
+        p[f"reg.tower.{3 * i}.weight"] = _xavier(rng, (D, D, 3, 3), 9 * D, 9 * D)
+        p[f"reg.tower.{3 * i}.bias"] = vec(D)
+        p[f"reg.tower.{3 * i + 1}.weight"] = vec(D, 1.0)
+        p[f"reg.tower.{3 * i + 1}.bias"] = vec(D)
+    p["reg.bbreg_layer.weight"] = _xavier(rng, (4, D, 3, 3), 9 * D, 9 * 4) * np.float32(0.3)
+    p["reg.bbreg_layer.bias"] = vec(4)
+    return p
+
+
+def tomp_inputs(seed, cfg=TOMP):
+    """Head features of the two memory frames and the test frame, Gaussian train labels and ltrb box maps
+    (tomp.py:282-295, 552-570): shapes (n_train,1,D,H,W), (1,1,D,H,W), (n_train,1,H,W), (n_train,1,4,H,W)."""
+    rng = np.random.default_rng(seed)
+    D, H, W, n = cfg["D"], cfg["H"], cfg["W"], cfg["n_train"]
+    scale = np.float32(1.0 / math.sqrt(D))
+    train = rng.standard_normal((n, 1, D, H, W), dtype=np.float32) * scale * np.float32(4.0)
+    test = rng.standard_normal((1, 1, D, H, W), dtype=np.float32) * scale * np.float32(4.0)
+    ctr = np.stack((H / 2.0 + rng.uniform(-2, 2, n), W / 2.0 + rng.uniform(-2, 2, n)), axis=1)
+    yy = np.arange(H, dtype=np.float64).reshape(1, -1, 1)
+    xx = np.arange(W, dtype=np.float64).reshape(1, 1, -1)
+    lab = np.exp(-0.5 * ((yy - ctr[:, 0].reshape(-1, 1, 1)) ** 2 + (xx - ctr[:, 1].reshape(-1, 1, 1)) ** 2) / 1.5 ** 2)
+    half = rng.uniform(1.5, 4.0, (n, 2))
+    l = (xx - (ctr[:, 1] - half[:, 1]).reshape(-1, 1, 1)) / W + 0 * yy
+    r = ((ctr[:, 1] + half[:, 1]).reshape(-1, 1, 1) - xx) / W + 0 * yy
+    t = (yy - (ctr[:, 0] - half[:, 0]).reshape(-1, 1, 1)) / H + 0 * xx
+    b = ((ctr[:, 0] + half[:, 0]).reshape(-1, 1, 1) - yy) / H + 0 * xx
+    ltrb = np.stack((l, t, r, b), axis=1)
+    return (train.astype(np.float32), test.astype(np.float32), lab.astype(np.float32)[:, None],
+            ltrb.astype(np.float32)[:, None])

@@ -154,3 +154,30 @@ def test_atom_joint_gauss_newton(name):
                         fletcher_reeves=bool(int(g["fletcher_reeves"])))
     np.testing.assert_allclose(f, g["f_out"], atol=5e-5)
     np.testing.assert_allclose(P, g["P_out"], atol=5e-5)
+
+
+@pytest.mark.parametrize("name,cfg", [("tomp_small", "TOMP_SMALL"), ("tomp_full", "TOMP")])
+def test_tomp_model_predictor(name, cfg):
+    """ToMP FilterPredictor (both entry points) + LinearFilterClassifier + DenseBoxRegressor
+    (filter_predictor.py:50-150, transformer.py:66-262, heads.py:83-141)."""
+    from oracle import tomp_oracle as TO
+    g = load_golden(name)
+    cfg = getattr(synth, cfg)
+    p = {k: v.astype(np.float64) for k, v in synth.tomp_params(int(g["seed"]), cfg).items()}
+    train, test, lab, ltrb = [a.astype(np.float64) for a in synth.tomp_inputs(int(g["seed"]) + 1, cfg)]
+    if "train" in g:
+        np.testing.assert_array_equal(g["train"], train.astype(np.float32))
+    a = (cfg["nhead"], cfg["n_enc"], cfg["n_dec"], cfg["feature_sz"])
+    np.testing.assert_allclose(TO.posenc(cfg["H"], cfg["W"], cfg["D"], cfg["feature_sz"]).T.reshape(g["pos"].shape),
+                               g["pos"], atol=2e-6)
+    cw, bw, cenc, benc = TO.predict_cls_bbreg_filters_parallel(p, train, test, lab, cfg["num_gth_frames"], ltrb, *a)
+    np.testing.assert_allclose(cw, g["cls_filter"], atol=2e-5)
+    np.testing.assert_allclose(bw, g["bbreg_filter"], atol=2e-5)
+    np.testing.assert_allclose(cenc, g["cls_enc"], atol=2e-5)
+    np.testing.assert_allclose(benc, g["bbreg_enc"], atol=2e-5)
+    np.testing.assert_allclose(TO.linear_filter_classifier(p, cenc, cw), g["scores"], atol=5e-5)
+    np.testing.assert_allclose(TO.dense_box_regressor(p, benc, bw), g["ltrb"], rtol=1e-4, atol=1e-5)
+    if cfg is synth.TOMP_SMALL:
+        w1, enc1 = TO.predict_filter(p, train, test, lab, ltrb, *a)
+        np.testing.assert_allclose(w1[0], g["single_filter"], atol=2e-5)
+        np.testing.assert_allclose(enc1, g["single_enc"], atol=2e-5)
