@@ -169,6 +169,58 @@ int pt_atom_gn_f32(float* filter, float* proj, const float* samples, long sample
                    void* ws, size_t ws_bytes, void* stream);
 
 /* ------------------------------------------------------------------------------------------------
+ * ToMP transformer model predictor -- replaces, for inference,
+ *   FilterPredictor.predict_filter / predict_cls_bbreg_filters_parallel  (ltr/models/transformer/filter_predictor.py:50-150)
+ *   Transformer.forward, post-norm encoder/decoder layers                (ltr/models/transformer/transformer.py:90-96,172-180,224-238)
+ *   PositionEmbeddingSine('lin_sine', avoid_aliazing=True)               (ltr/models/transformer/position_encoding.py:6-58)
+ *   DenseBoxRegressor.forward and the Linear of LinearFilterClassifier   (ltr/models/transformer/heads.py:93-98,119-141)
+ *
+ * Parameters travel as ONE contiguous fp32 device buffer ("pack"), tensors in the reference's own layouts, in this order
+ * (names = the reference's state_dict keys below `filter_predictor.`):
+ *   for each encoder layer i:  transformer.encoder.layers.i.{self_attn.in_proj_weight (3D,D), self_attn.in_proj_bias (3D),
+ *       self_attn.out_proj.weight (D,D), self_attn.out_proj.bias (D), linear1.weight (F,D), linear1.bias (F),
+ *       linear2.weight (D,F), linear2.bias (D), norm1.weight, norm1.bias, norm2.weight, norm2.bias (D each)}
+ *   for each decoder layer i:  transformer.decoder.layers.i.{self_attn.[4 tensors as above], multihead_attn.[4 tensors],
+ *       linear1.weight, linear1.bias, linear2.weight, linear2.bias, norm1.*, norm2.*, norm3.* (weight, bias)}
+ *   transformer.decoder.norm.{weight, bias}
+ *   box_encoding.0.{weight (D/4,4), bias}, box_encoding.1.{weight, bias, running_mean, running_var} (D/4 each),
+ *   box_encoding.3.{weight (D,D/4), bias}, box_encoding.4.{weight, bias, running_mean, running_var} (D each),
+ *   box_encoding.6.{weight (D,D), bias}, query_embed_fg.weight (D), query_embed_test.weight (D)
+ * pt_tomp_param_floats() returns the length of that buffer (0: configuration not covered).
+ *
+ * Shapes: train_feat (n_train, n_seq, D, H, W); test_feat (1, n_seq, D, H, W); train_label (n_train, n_seq, H, W);
+ * train_ltrb (n_train, n_seq, 4, H, W); pos (H*W, D) from pt_tomp_posenc_f32 (input independent: compute once, keep).
+ *   parallel = 0: predict_filter            -> filters (n_seq, D), enc_feat (n_seq, D, H, W)
+ *   parallel = 1: predict_cls_bbreg_filters_parallel (n_seq must be 1, as the reference's mask row 1 assumes):
+ *                 filters (2, D) = [cls, bbreg], enc_feat (2, D, H, W) = [cls, bbreg]; the memory frames
+ *                 [num_gth_frames, n_train) are masked out as keys for the bbreg row (filter_predictor.py:134-136)
+ * Covered: d_model in {128,256,384,512}, head dim in {16,32,64}, dim_ff % 64 == 0, <= 16 layers each, <= 8 batch rows.
+ * ---------------------------------------------------------------------------------------------- */
+typedef struct pt_tomp_dims {
+    int d_model, nhead, dim_ff, n_enc, n_dec;
+    int H, W;          /* feature map of every frame */
+    int max_res;       /* `feature_sz` of FilterPredictor (anti-aliasing factor of the positional encoding) */
+} pt_tomp_dims;
+size_t pt_tomp_param_floats(const pt_tomp_dims* dims);
+int pt_tomp_posenc_f32(float* pos, int H, int W, int d_model, int max_res, void* stream);
+size_t pt_tomp_predict_ws_bytes(const pt_tomp_dims* dims, int n_train, int n_seq, int parallel);
+int pt_tomp_predict_f32(const pt_tomp_dims* dims, const float* params, const float* pos, const float* train_feat,
+                        const float* test_feat, const float* train_label, const float* train_ltrb,
+                        int n_train, int n_seq, int parallel, int num_gth_frames, float* filters, float* enc_feat,
+                        void* ws, size_t ws_bytes, void* stream);
+/* y (B,N) = [relu](x (B,K) weight(N,K)^T + bias): the Linear applied to the predicted filters (heads.py:95,123), B <= 8 */
+int pt_tomp_linear_f32(const float* weight, const float* bias, const float* x, float* y, int B, int N, int K, int relu,
+                       void* stream);
+/* DenseBoxRegressor.forward (heads.py:119-141): feat (n, D, H, W), filter (D) -> ltrb (n, 4, H, W).
+ * pack: linear.weight (D,D), linear.bias (D), then for tower conv i = 0..3: conv weight in (out, ky, kx, in) order
+ * [= the reference's (out,in,3,3) tensor permuted (0,2,3,1)], conv bias (D), GroupNorm weight (D), GroupNorm bias (D);
+ * then bbreg_layer weight (4, ky, kx, in) and bias (4). */
+size_t pt_tomp_bbreg_param_floats(int d_model);
+size_t pt_tomp_bbreg_ws_bytes(int n, int d_model, int H, int W);
+int pt_tomp_bbreg_f32(const float* params, const float* feat, const float* filter, float* ltrb, int n, int d_model,
+                      int H, int W, void* ws, size_t ws_bytes, void* stream);
+
+/* ------------------------------------------------------------------------------------------------
  * Precise RoI Pooling -- replaces ltr/external/PreciseRoIPooling (empty git submodule;
  * import sites ltr/models/target_classifier/initializer.py:4,18,45 and
  * ltr/models/bbreg/atom_iou_net.py:4,31-32,41-42,126-127,157,160).

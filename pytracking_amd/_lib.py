@@ -9,12 +9,17 @@ import subprocess
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.environ.get("PT_HOT_LIB", os.path.join(_HERE, "libpt_hot.so"))   # override: experiments only
-SOURCES = ["filter_kernels.hip", "fast_passes.hip", "sd_solver.hip", "mf_kernels.hip", "lwl_solver.hip", "atom_cg.hip", "atom_gn.hip", "prroi.hip", "api.hip", "profile.hip"]
+SOURCES = ["filter_kernels.hip", "fast_passes.hip", "sd_solver.hip", "mf_kernels.hip", "lwl_solver.hip", "atom_cg.hip", "atom_gn.hip", "tomp.hip", "prroi.hip", "api.hip", "profile.hip"]
 HEADERS = ["common.h", "pt_internal.h", "rbuild.h", "sd_common.h", os.path.join("..", "..", "include", "pt_hot.h")]
 
 PT_SD_DIMP, PT_SD_DIMP_L2, PT_SD_PRDIMP = 0, 1, 2
 PT_ACT_RELU, PT_ACT_BENTPAR = 0, 1
 PT_MASK_SIGMOID, PT_MASK_LINEAR = 0, 1
+
+class TompDims(ctypes.Structure):
+    """`pt_tomp_dims` of include/pt_hot.h."""
+    _fields_ = [(n, ctypes.c_int) for n in ("d_model", "nhead", "dim_ff", "n_enc", "n_dec", "H", "W", "max_res")]
+
 
 EXPORTS = [
     "pt_strerror", "pt_abi_version",
@@ -26,6 +31,8 @@ EXPORTS = [
     "pt_track_frame_ws_bytes", "pt_track_frame_f32",
     "pt_apply_filter_mf_ws_bytes", "pt_apply_filter_mf_f32", "pt_feat_transpose_mf_ws_bytes", "pt_feat_transpose_mf_f32",
     "pt_lwl_ws_bytes", "pt_lwl_gn_solve_f32",
+    "pt_tomp_param_floats", "pt_tomp_posenc_f32", "pt_tomp_predict_ws_bytes", "pt_tomp_predict_f32", "pt_tomp_linear_f32",
+    "pt_tomp_bbreg_param_floats", "pt_tomp_bbreg_ws_bytes", "pt_tomp_bbreg_f32",
     "pt_profile_create", "pt_profile_attach", "pt_profile_collect", "pt_profile_reset", "pt_profile_destroy",
 ]
 
@@ -126,6 +133,23 @@ def lib():
     L.pt_lwl_ws_bytes.argtypes = [i] * 6
     L.pt_lwl_gn_solve_f32.restype = i
     L.pt_lwl_gn_solve_f32.argtypes = [vp, vp, l, vp, vp, i, f, f] + [i] * 7 + [vp, vp, vp, sz, vp]
+    dp = ctypes.POINTER(TompDims)
+    L.pt_tomp_param_floats.restype = sz
+    L.pt_tomp_param_floats.argtypes = [dp]
+    L.pt_tomp_posenc_f32.restype = i
+    L.pt_tomp_posenc_f32.argtypes = [vp, i, i, i, i, vp]
+    L.pt_tomp_predict_ws_bytes.restype = sz
+    L.pt_tomp_predict_ws_bytes.argtypes = [dp, i, i, i]
+    L.pt_tomp_predict_f32.restype = i
+    L.pt_tomp_predict_f32.argtypes = [dp, vp, vp, vp, vp, vp, vp, i, i, i, i, vp, vp, vp, sz, vp]
+    L.pt_tomp_linear_f32.restype = i
+    L.pt_tomp_linear_f32.argtypes = [vp, vp, vp, vp, i, i, i, i, vp]
+    L.pt_tomp_bbreg_param_floats.restype = sz
+    L.pt_tomp_bbreg_param_floats.argtypes = [i]
+    L.pt_tomp_bbreg_ws_bytes.restype = sz
+    L.pt_tomp_bbreg_ws_bytes.argtypes = [i, i, i, i]
+    L.pt_tomp_bbreg_f32.restype = i
+    L.pt_tomp_bbreg_f32.argtypes = [vp, vp, vp, vp, i, i, i, i, vp, sz, vp]
     L.pt_profile_create.restype = i
     L.pt_profile_create.argtypes = [ctypes.POINTER(vp), i]
     L.pt_profile_attach.restype = i

@@ -1,0 +1,1010 @@
+// ToMP transformer model predictor on gfx950 (BASELINE configs[3]).
+//
+// Replaces, for inference:
+//   FilterPredictor.predict_filter / predict_cls_bbreg_filters_parallel   ltr/models/transformer/filter_predictor.py:50-150
+//   Transformer.forward + post-norm encoder / decoder layers              ltr/models/transformer/transformer.py:90-96,172-180,224-238
+//   PositionEmbeddingSine('lin_sine', avoid_aliazing)                     ltr/models/transformer/position_encoding.py:6-58
+//   DenseBoxRegressor.forward, the Linear of LinearFilterClassifier       ltr/models/transformer/heads.py:93-98,119-141
+//
+// This path is MFMA-bound (45 GFLOP per frame, AI >> 100 flop/B), unlike the solver passes: every dense contraction runs
+// on v_mfma_f32_16x16x4_f32 (exact fp32 products, fp32 accumulation -- the reference computes in fp32 and north_star
+// asks for 1e-4).  Layout: tokens are rows, `(batch row, token) x channel` row-major, so every nn.Linear is an NT GEMM
+// with both operands K-contiguous; the NCHW <-> token-major transposes happen once on the way in and once on the way out.
+//
+//   k_gemm      C = A W^T (+bias, affine, ReLU, residual, exp), LDS-staged 64x64 / 64x32 / 32x32 tiles, register
+//               prefetch of the next K-step, optional "+pos" on the A operand of the q/k column blocks, optional 3x3
+//               gather on the A operand (implicit GEMM for the regression tower)
+//   k_attn      fp32 flash attention: S^T = K Q^T per 16-key tile so that the MFMA accumulator of the score tile IS the
+//               B operand of the PV product (no LDS round trip for P), online softmax per 64-key chunk
+//   decoder     one query token per batch row: the K/V projections of the memory are never formed --
+//               q.(Wk m + bk) = (Wk^T q).m + const and sum_l p_l (Wv m_l + bv) = Wv (sum_l p_l m_l) + bv, so the decoder is a
+//               chain of GEMVs over the weights plus two streaming passes over the memory per layer
+#include "common.h"
+#include "pt_internal.h"
+
+#include <algorithm>
+#include <math.h>
+#include <stdint.h>
+
+namespace {
+
+constexpr unsigned OOB = 0xFFFFFFF0u;      // raw buffer loads past num_records return 0
+
+// ------------------------------------------------------------------------------------------------------------------
+// generic NT GEMM on MFMA
+// ------------------------------------------------------------------------------------------------------------------
+struct GemmArgs {
+    const float* A; long lda; unsigned a_bytes;
+    const float* Wt; unsigned w_bytes;          // (N, K) row-major
+    int M, N, K;
+    const float* bias; const float* scale; const float* shift;
+    const float* R; float* C; long ldc;         // residual shares ldc and the row map of C
+    int c_seg; long c_segstride;                // C/R row of logical row r: (r / c_seg) * c_segstride + r % c_seg
+    int relu, expo, nchw;                       // nchw: C[((r / HW) * N + n) * HW + r % HW]
+    const float* pos; unsigned pos_bytes; int pos_cols, L, HW;   // A[r][k] + pos[(r % L) % HW][k] for column tiles < pos_cols
+    int H, Wd, Cin;                             // MODE 1: 3x3 zero-padded gather, K = 9 * Cin, weights (N, tap, Cin)
+};
+
+template <int BM, int BN, int MODE>
+__global__ __launch_bounds__(256) void k_gemm(GemmArgs g) {
+    constexpr int LS = 36;                      // LDS row stride: 16-byte aligned, conflict-free 128-bit fragment reads
+    constexpr int WM = BM / 2, WN = BN / 2, MT = WM / 16, NT = WN / 16, AL = BM / 32, BL = BN / 32;
+    __shared__ __attribute__((aligned(16))) float As[2][BM * LS];
+    __shared__ __attribute__((aligned(16))) float Bs[2][BN * LS];
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, wm = wave >> 1, wn = wave & 1;
+    const int m0 = blockIdx.y * BM, n0 = blockIdx.x * BN;
+    const int lrow = tid >> 3, lc4 = (tid & 7) * 4;
+    const __amdgpu_buffer_rsrc_t rsA = pt_rsrc(g.A, g.a_bytes), rsW = pt_rsrc(g.Wt, g.w_bytes);
+    const bool addpos = MODE == 0 && g.pos != nullptr && n0 < g.pos_cols;
+    const __amdgpu_buffer_rsrc_t rsP = pt_rsrc(addpos ? g.pos : g.A, addpos ? g.pos_bytes : 16u);
+
+    unsigned aoff[AL], poff[AL], woff[BL];
+    int py[AL], px[AL];
+#pragma unroll
+    for (int i = 0; i < AL; ++i) {
+        const int row = m0 + lrow + 32 * i;
+        const bool ok = row < g.M;
+        if (MODE == 0) {
+            aoff[i] = ok ? (unsigned)(((long)row * g.lda + lc4) * 4) : OOB;
+            poff[i] = (addpos && ok) ? (unsigned)(((long)((row % g.L) % g.HW) * g.K + lc4) * 4) : OOB;
+        } else {
+            const int img = row / g.HW, p = row - img * g.HW;
+            py[i] = ok ? p / g.Wd : -4;                                  // -4: every tap falls outside the map
+            px[i] = p - (p / g.Wd) * g.Wd;
+            aoff[i] = (unsigned)(((long)img * g.HW * g.lda + lc4) * 4);
+            poff[i] = OOB;
+        }
+    }
+#pragma unroll
+    for (int i = 0; i < BL; ++i) {
+        const int n = n0 + lrow + 32 * i;
+        woff[i] = n < g.N ? (unsigned)(((long)n * g.K + lc4) * 4) : OOB;
+    }
+
+    f32x4 ra[AL], rp[AL], rb[BL];
+    auto fetch = [&](int kb) {
+        const unsigned kbytes = (unsigned)kb * 128u;
+        if (MODE == 0) {
+#pragma unroll
+            for (int i = 0; i < AL; ++i) ra[i] = pt_bload4(rsA, aoff[i] == OOB ? OOB : aoff[i] + kbytes);
+            if (addpos) {
+#pragma unroll
+                for (int i = 0; i < AL; ++i) rp[i] = pt_bload4(rsP, poff[i] == OOB ? OOB : poff[i] + kbytes);
+            }
+        } else {
+            const int k0 = kb * 32, tap = k0 / g.Cin, c0 = k0 - tap * g.Cin;
+            const int dy = tap / 3 - 1, dx = tap - (tap / 3) * 3 - 1;
+#pragma unroll
+            for (int i = 0; i < AL; ++i) {
+                const int y = py[i] + dy, x = px[i] + dx;
+                const bool in = y >= 0 && y < g.H && x >= 0 && x < g.Wd;
+                ra[i] = pt_bload4(rsA, in ? aoff[i] + (unsigned)(((long)(y * g.Wd + x) * g.lda + c0) * 4) : OOB);
+            }
+        }
+#pragma unroll
+        for (int i = 0; i < BL; ++i) rb[i] = pt_bload4(rsW, woff[i] == OOB ? OOB : woff[i] + kbytes);
+    };
+    auto stash = [&](int buf) {
+#pragma unroll
+        for (int i = 0; i < AL; ++i) {
+            f32x4 v = ra[i];
+            if (addpos) v += rp[i];
+            *reinterpret_cast<f32x4*>(&As[buf][(lrow + 32 * i) * LS + lc4]) = v;
+        }
+#pragma unroll
+        for (int i = 0; i < BL; ++i) *reinterpret_cast<f32x4*>(&Bs[buf][(lrow + 32 * i) * LS + lc4]) = rb[i];
+    };
+
+    f32x4 acc[MT][NT];
+#pragma unroll
+    for (int a = 0; a < MT; ++a)
+#pragma unroll
+        for (int b = 0; b < NT; ++b) acc[a][b] = f32x4{0.f, 0.f, 0.f, 0.f};
+
+    const int nk = g.K / 32;
+    fetch(0);
+    stash(0);
+    __syncthreads();
+    for (int kb = 0; kb < nk; ++kb) {
+        const int buf = kb & 1;
+        if (kb + 1 < nk) fetch(kb + 1);
+        const float* as = &As[buf][(wm * WM + (lane & 15)) * LS + (lane >> 4) * 4];
+        const float* bs = &Bs[buf][(wn * WN + (lane & 15)) * LS + (lane >> 4) * 4];
+#pragma unroll
+        for (int hh = 0; hh < 2; ++hh) {
+            f32x4 a[MT], b[NT];
+#pragma unroll
+            for (int mt = 0; mt < MT; ++mt) a[mt] = *reinterpret_cast<const f32x4*>(as + mt * 16 * LS + hh * 16);
+#pragma unroll
+            for (int nt = 0; nt < NT; ++nt) b[nt] = *reinterpret_cast<const f32x4*>(bs + nt * 16 * LS + hh * 16);
+#pragma unroll
+            for (int j = 0; j < 4; ++j)
+#pragma unroll
+                for (int mt = 0; mt < MT; ++mt)
+#pragma unroll
+                    for (int nt = 0; nt < NT; ++nt) acc[mt][nt] = mfma16(a[mt][j], b[nt][j], acc[mt][nt]);
+        }
+        if (kb + 1 < nk) stash(buf ^ 1);
+        __syncthreads();
+    }
+
+#pragma unroll
+    for (int mt = 0; mt < MT; ++mt)
+#pragma unroll
+        for (int nt = 0; nt < NT; ++nt) {
+            const int col = n0 + wn * WN + nt * 16 + (lane & 15);
+            if (col >= g.N) continue;
+            const float bv = g.bias ? g.bias[col] : 0.f;
+            const float sc = g.scale ? g.scale[col] : 1.f, sh = g.scale ? g.shift[col] : 0.f;
+#pragma unroll
+            for (int r = 0; r < 4; ++r) {
+                const int row = m0 + wm * WM + mt * 16 + 4 * (lane >> 4) + r;
+                if (row >= g.M) continue;
+                float v = (acc[mt][nt][r] + bv) * sc + sh;
+                if (g.relu) v = fmaxf(v, 0.f);
+                long o;
+                if (g.nchw) {
+                    const int img = row / g.HW;
+                    o = ((long)img * g.N + col) * g.HW + (row - img * g.HW);
+                } else {
+                    const int sg = row / g.c_seg;
+                    o = ((long)sg * g.c_segstride + (row - sg * g.c_seg)) * g.ldc + col;
+                }
+                if (g.R) v += g.R[o];
+                if (g.expo) v = expf(v);
+                g.C[o] = v;
+            }
+        }
+}
+
+GemmArgs gemm_args(const float* A, long lda, long a_rows, const float* Wt, int M, int N, int K, const float* bias,
+                   float* C, long ldc) {
+    GemmArgs g{};
+    g.A = A; g.lda = lda; g.a_bytes = (unsigned)std::min<long>(a_rows * lda * 4, 0xFFFFFFE0L);
+    g.Wt = Wt; g.w_bytes = (unsigned)((long)N * K * 4);
+    g.M = M; g.N = N; g.K = K; g.bias = bias; g.C = C; g.ldc = ldc;
+    g.c_seg = M > 0 ? M : 1; g.c_segstride = 0; g.HW = 1; g.L = 1;
+    return g;
+}
+
+int launch_gemm(const GemmArgs& g, hipStream_t st, bool conv = false) {
+    if (g.K % 32 != 0 || g.M <= 0 || g.N <= 0) return PT_ERR_UNSUPPORTED;
+    if (conv) {
+        if (g.Cin % 32 != 0) return PT_ERR_UNSUPPORTED;
+        hipLaunchKernelGGL((k_gemm<32, 32, 1>), dim3((g.N + 31) / 32, (g.M + 31) / 32), dim3(256), 0, st, g);
+    } else {
+        const long t64 = (long)((g.M + 63) / 64) * ((g.N + 63) / 64), t6432 = (long)((g.M + 63) / 64) * ((g.N + 31) / 32);
+        if (t64 >= 200)
+            hipLaunchKernelGGL((k_gemm<64, 64, 0>), dim3((g.N + 63) / 64, (g.M + 63) / 64), dim3(256), 0, st, g);
+        else if (t6432 >= 200)
+            hipLaunchKernelGGL((k_gemm<64, 32, 0>), dim3((g.N + 31) / 32, (g.M + 63) / 64), dim3(256), 0, st, g);
+        else
+            hipLaunchKernelGGL((k_gemm<32, 32, 0>), dim3((g.N + 31) / 32, (g.M + 31) / 32), dim3(256), 0, st, g);
+    }
+    PT_CHECK_LAUNCH();
+    return PT_OK;
+}
+
+// ------------------------------------------------------------------------------------------------------------------
+// fp32 flash attention over the packed (rows, 3D) q|k|v projections
+// ------------------------------------------------------------------------------------------------------------------
+struct AttnArgs {
+    const float* qkv; unsigned qkv_bytes;
+    float* out;
+    int L, D, nhead;
+    float scale;
+    int mlo[8], mhi[8];                         // keys [mlo[b], mhi[b]) of batch row b are padding (never attended)
+};
+
+template <int HD>
+__global__ __launch_bounds__(256) void k_attn(AttnArgs a) {
+    constexpr int KS = HD + 4, NV = HD / 4, NF4 = HD / 16, DT = HD / 16;   // NV floats of q/k per lane, NF4 float4s
+    __shared__ __attribute__((aligned(16))) float Ks[2][64 * KS];
+    __shared__ __attribute__((aligned(16))) float Vs[2][64 * KS];
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, li = lane & 15, kq = lane >> 4;
+    const int h = blockIdx.y, b = blockIdx.z, q0 = blockIdx.x * 64 + wave * 16;
+    const int ld = 3 * a.D;
+    const __amdgpu_buffer_rsrc_t rs = pt_rsrc(a.qkv, a.qkv_bytes);
+    const long rowbase = (long)b * a.L;
+    const int mlo = a.mlo[b], mhi = a.mhi[b];
+
+    // Q fragment (B operand of S^T = K Q^T): lane (query li, k-slot kq) holds q[query][kq*NV .. +NV), pre-scaled
+    float qf[NV];
+    {
+        const int q = min(q0 + li, a.L - 1);
+        const unsigned off = (unsigned)(((rowbase + q) * ld + h * HD + kq * NV) * 4);
+#pragma unroll
+        for (int v = 0; v < NF4; ++v) {
+            const f32x4 t = pt_bload4(rs, off + 16u * v);
+#pragma unroll
+            for (int e = 0; e < 4; ++e) qf[4 * v + e] = t[e] * a.scale;
+        }
+    }
+    // cooperative K / V chunk loads: 64 keys x HD floats each = 64*HD/4 float4 per operand
+    constexpr int LPT = (64 * HD / 4) / 256;                      // float4 per thread per operand
+    constexpr int F4R = HD / 4;                                   // float4 per row
+    f32x4 rk[LPT], rv[LPT];
+    auto fetch = [&](int c0) {
+#pragma unroll
+        for (int i = 0; i < LPT; ++i) {
+            const int idx = tid + 256 * i, r = idx / F4R, c4 = (idx - r * F4R) * 4, key = c0 + r;
+            const unsigned off = key < a.L ? (unsigned)(((rowbase + key) * ld + a.D + h * HD + c4) * 4) : OOB;
+            rk[i] = pt_bload4(rs, off);
+            rv[i] = pt_bload4(rs, off == OOB ? OOB : off + (unsigned)a.D * 4u);
+        }
+    };
+    auto stash = [&](int buf) {
+#pragma unroll
+        for (int i = 0; i < LPT; ++i) {
+            const int idx = tid + 256 * i, r = idx / F4R, c4 = (idx - r * F4R) * 4;
+            *reinterpret_cast<f32x4*>(&Ks[buf][r * KS + c4]) = rk[i];
+            *reinterpret_cast<f32x4*>(&Vs[buf][r * KS + c4]) = rv[i];
+        }
+    };
+
+    f32x4 ot[DT];
+#pragma unroll
+    for (int d = 0; d < DT; ++d) ot[d] = f32x4{0.f, 0.f, 0.f, 0.f};
+    float m_run = -INFINITY, l_run = 0.f;
+
+    const int nchunk = (a.L + 63) / 64;
+    fetch(0);
+    stash(0);
+    __syncthreads();
+    for (int ch = 0; ch < nchunk; ++ch) {
+        const int buf = ch & 1, c0 = ch * 64;
+        if (ch + 1 < nchunk) fetch(c0 + 64);
+        // ---- S^T tiles: rows = keys, cols = queries
+        f32x4 st[4];
+        float mc = -INFINITY;
+#pragma unroll
+        for (int kt = 0; kt < 4; ++kt) {
+            f32x4 s = f32x4{0.f, 0.f, 0.f, 0.f};
+            const float* kp = &Ks[buf][(kt * 16 + li) * KS + kq * NV];
+#pragma unroll
+            for (int v = 0; v < NF4; ++v) {
+                const f32x4 kk = *reinterpret_cast<const f32x4*>(kp + 4 * v);
+#pragma unroll
+                for (int e = 0; e < 4; ++e) s = mfma16(kk[e], qf[4 * v + e], s);
+            }
+#pragma unroll
+            for (int r = 0; r < 4; ++r) {
+                const int key = c0 + kt * 16 + 4 * kq + r;
+                if (key >= a.L || (key >= mlo && key < mhi)) s[r] = -INFINITY;
+                mc = fmaxf(mc, s[r]);
+            }
+            st[kt] = s;
+        }
+        mc = fmaxf(mc, __shfl_xor(mc, 16, 64));
+        mc = fmaxf(mc, __shfl_xor(mc, 32, 64));
+        const float m_new = fmaxf(m_run, mc);
+        const float m_use = m_new == -INFINITY ? 0.f : m_new;
+        const float alpha = __expf(m_run - m_use);                 // m_run = -inf -> 0
+        l_run *= alpha;
+#pragma unroll
+        for (int d = 0; d < DT; ++d) ot[d] *= alpha;
+        m_run = m_new;
+        // ---- P^T = exp(S^T - m) feeds the PV product straight from the accumulator registers:
+        //      O^T[d][query] += sum_key V[key][d] * P^T[key][query]; k-slot kq of MFMA r <-> key 4*kq + r of the tile
+#pragma unroll
+        for (int kt = 0; kt < 4; ++kt) {
+#pragma unroll
+            for (int r = 0; r < 4; ++r) {
+                const float p = __expf(st[kt][r] - m_use);
+                l_run += p;
+                const float* vp = &Vs[buf][(kt * 16 + 4 * kq + r) * KS + li];
+#pragma unroll
+                for (int d = 0; d < DT; ++d) ot[d] = mfma16(vp[16 * d], p, ot[d]);
+            }
+        }
+        if (ch + 1 < nchunk) stash(buf ^ 1);
+        __syncthreads();
+    }
+    l_run += __shfl_xor(l_run, 16, 64);
+    l_run += __shfl_xor(l_run, 32, 64);
+    const float inv = 1.f / l_run;
+    const int q = q0 + li;
+    if (q < a.L) {
+#pragma unroll
+        for (int d = 0; d < DT; ++d) {
+            f32x4 o = ot[d] * inv;                                 // rows d*16 + 4*kq + r of O^T = 4 consecutive channels
+            *reinterpret_cast<f32x4*>(&a.out[(rowbase + q) * a.D + h * HD + d * 16 + 4 * kq]) = o;
+        }
+    }
+}
+
+// ------------------------------------------------------------------------------------------------------------------
+// row LayerNorm, one wavefront per row (D % 64 == 0, D <= 512); in-place safe
+// ------------------------------------------------------------------------------------------------------------------
+__global__ __launch_bounds__(256) void k_ln_rows(const float* in, float* out, const float* gam, const float* bet,
+                                                 int rows, int D) {
+    const int row = blockIdx.x * 4 + (threadIdx.x >> 6), lane = threadIdx.x & 63;
+    if (row >= rows) return;
+    const int per = D / 64;
+    float v[8];
+    float s = 0.f;
+    for (int i = 0; i < per; ++i) {
+        v[i] = in[(long)row * D + lane * per + i];
+        s += v[i];
+    }
+    const float mean = wave_sum(s) / D;
+    float q = 0.f;
+    for (int i = 0; i < per; ++i) q += (v[i] - mean) * (v[i] - mean);
+    const float rstd = rsqrtf(wave_sum(q) / D + 1e-5f);
+    for (int i = 0; i < per; ++i) {
+        const int c = lane * per + i;
+        out[(long)row * D + c] = (v[i] - mean) * rstd * gam[c] + bet[c];
+    }
+}
+
+// ------------------------------------------------------------------------------------------------------------------
+// token build (filter_predictor.py:113-128)
+// ------------------------------------------------------------------------------------------------------------------
+struct TokArgs {
+    const float *train, *test, *label, *fg, *testtok;
+    float* X;
+    int nf, ns, dup, D, HW, L;
+};
+
+// NCHW feature maps -> token-major rows, + fg_token * label (memory frames) or + test_token (test frame)
+__global__ __launch_bounds__(256) void k_tomp_tokens(TokArgs a) {
+    __shared__ float tile[32][33];
+    const int tx = threadIdx.x & 31, ty = threadIdx.x >> 5;
+    const int p0 = blockIdx.x * 32, c0 = blockIdx.y * 32;
+    const int B = a.dup ? 2 : a.ns;
+    const int fr = blockIdx.z / B, b = blockIdx.z - fr * B, s = a.dup ? 0 : b;
+    const bool train = fr < a.nf;
+    const float* src = train ? a.train + ((long)(fr * a.ns + s) * a.D) * a.HW : a.test + ((long)s * a.D) * a.HW;
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+        const int c = c0 + ty + 8 * i, p = p0 + tx;
+        tile[ty + 8 * i][tx] = (c < a.D && p < a.HW) ? src[(long)c * a.HW + p] : 0.f;
+    }
+    __syncthreads();
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+        const int p = p0 + ty + 8 * i, c = c0 + tx;
+        if (p >= a.HW || c >= a.D) continue;
+        float v = tile[tx][ty + 8 * i];
+        v += train ? a.fg[c] * a.label[(long)(fr * a.ns + s) * a.HW + p] : a.testtok[c];
+        a.X[((long)b * a.L + (long)fr * a.HW + p) * a.D + c] = v;
+    }
+}
+
+struct BoxArgs {
+    const float *ltrb, *w1, *b1, *bn1, *bn2;     // bn: [weight, bias, running_mean, running_var] of D4 / D floats
+    float *E1, *scale2, *shift2;
+    int nf, ns, dup, D, D4, HW;
+};
+
+// first layer of the ltrb MLP (Conv1d 4 -> D/4, BatchNorm1d on running statistics, ReLU) and the folded scale / shift
+// of the second BatchNorm for the epilogue of the next GEMM (filter_predictor.py:6-17)
+__global__ __launch_bounds__(256) void k_tomp_box1(BoxArgs a) {
+    const int B = a.dup ? 2 : a.ns, Ltr = a.nf * a.HW;
+    const long idx = (long)blockIdx.x * 256 + threadIdx.x;
+    if (blockIdx.x == 0) {
+        for (int c = threadIdx.x; c < a.D; c += 256) {
+            const float sc = a.bn2[c] / sqrtf(a.bn2[3 * a.D + c] + 1e-5f);
+            a.scale2[c] = sc;
+            a.shift2[c] = a.bn2[a.D + c] - a.bn2[2 * a.D + c] * sc;
+        }
+    }
+    if (idx >= (long)B * Ltr * a.D4) return;
+    const int j = (int)(idx % a.D4);
+    const long row = idx / a.D4;
+    const int b = (int)(row / Ltr), l = (int)(row - (long)b * Ltr), fr = l / a.HW, p = l - fr * a.HW;
+    const int s = a.dup ? 0 : b;
+    const float* t = a.ltrb + ((long)(fr * a.ns + s) * 4) * a.HW + p;
+    float e = a.b1[j];
+#pragma unroll
+    for (int i = 0; i < 4; ++i) e += a.w1[j * 4 + i] * t[(long)i * a.HW];
+    e = (e - a.bn1[2 * a.D4 + j]) / sqrtf(a.bn1[3 * a.D4 + j] + 1e-5f) * a.bn1[j] + a.bn1[a.D4 + j];
+    a.E1[idx] = fmaxf(e, 0.f);
+}
+
+// token-major rows of the test frame -> NCHW (enc_opt, filter_predictor.py:142-147)
+__global__ __launch_bounds__(256) void k_tokens_to_nchw(const float* X, float* out, int B, int L, int D, int HW,
+                                                        int l0) {
+    __shared__ float tile[32][33];
+    const int tx = threadIdx.x & 31, ty = threadIdx.x >> 5;
+    const int p0 = blockIdx.x * 32, c0 = blockIdx.y * 32, b = blockIdx.z;
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+        const int p = p0 + ty + 8 * i, c = c0 + tx;
+        tile[ty + 8 * i][tx] = (p < HW && c < D) ? X[((long)b * L + l0 + p) * D + c] : 0.f;
+    }
+    __syncthreads();
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+        const int c = c0 + ty + 8 * i, p = p0 + tx;
+        if (c < D && p < HW) out[((long)b * D + c) * HW + p] = tile[tx][ty + 8 * i];
+    }
+}
+
+// ------------------------------------------------------------------------------------------------------------------
+// positional encoding (position_encoding.py:6-58), written once per map size and cached by the caller
+// ------------------------------------------------------------------------------------------------------------------
+__global__ void k_tomp_posenc(float* pos, int H, int W, int D, double factor) {
+    const int idx = blockIdx.x * blockDim.x + threadIdx.x;
+    if (idx >= H * W * D) return;
+    const int p = idx / D, c = idx - p * D, depth = D / 4;
+    const int y = p / W, x = p - y * W;
+    const bool cosine = c >= 2 * depth;
+    const int cc = cosine ? c - 2 * depth : c;
+    const int i = cc / 2 + 1, isy = cc & 1;
+    const float coord = isy ? ((float)(y + 1) - 0.5f) / ((float)H + 1e-6f) : ((float)(x + 1) - 0.5f) / ((float)W + 1e-6f);
+    const float arg = (float)((double)i * factor * 3.14159265358979323846) * coord;   // scalar rounded to fp32, fp32 product
+    pos[idx] = cosine ? cosf(arg) : sinf(arg);
+}
+
+// ------------------------------------------------------------------------------------------------------------------
+// decoder: GEMV family (one wavefront per output feature; B <= 8 batch rows ride along in registers)
+// ------------------------------------------------------------------------------------------------------------------
+struct GemvArgs {
+    const float* Wt; const float* bias; int N, K;
+    const float* x; int x_rows_per_b, x_head_div;   // input row of (b, n): b * x_rows_per_b + (x_head_div ? n / x_head_div : 0)
+    const float *xg, *xb;                           // optional LayerNorm applied to the input rows (K = model width)
+    const float* xadd;                              // optional (K) vector added to every input row after the LayerNorm
+    const float* res; const float *rg, *rb;         // optional residual rows (B, N), optionally LayerNorm'ed
+    int relu, B;
+    float* out;
+};
+
+template <int V>
+__device__ __forceinline__ void ldv(const float* p, float* out) {      // V consecutive floats, 16-byte aligned when V = 4
+    if (V == 4) {
+        const f32x4 t = *reinterpret_cast<const f32x4*>(p);
+        out[0] = t[0]; out[1] = t[1]; out[2] = t[2]; out[3] = t[3];
+    } else {
+        out[0] = p[0];
+    }
+}
+
+template <int V>
+__device__ __forceinline__ void wave_row_stats(const float* x, int K, int lane, float& mean, float& rstd) {
+    float s = 0.f;
+    for (int k = lane * V; k < K; k += 64 * V) {
+        float t[V];
+        ldv<V>(x + k, t);
+#pragma unroll
+        for (int e = 0; e < V; ++e) s += t[e];
+    }
+    mean = wave_sum(s) / K;
+    float q = 0.f;
+    for (int k = lane * V; k < K; k += 64 * V) {
+        float t[V];
+        ldv<V>(x + k, t);
+#pragma unroll
+        for (int e = 0; e < V; ++e) q += (t[e] - mean) * (t[e] - mean);
+    }
+    rstd = rsqrtf(wave_sum(q) / K + 1e-5f);
+}
+
+template <int V>
+__global__ __launch_bounds__(256) void k_gemv(GemvArgs a) {
+    const int lane = threadIdx.x & 63, n = blockIdx.x * 4 + (threadIdx.x >> 6);
+    if (n >= a.N) return;
+    const int xrow0 = a.x_head_div ? n / a.x_head_div : 0;
+    float acc[8], mean[8], rstd[8];
+#pragma unroll
+    for (int b = 0; b < 8; ++b) {
+        acc[b] = 0.f;
+        mean[b] = 0.f;
+        rstd[b] = 1.f;
+    }
+    if (a.xg) {
+#pragma unroll
+        for (int b = 0; b < 8; ++b)
+            if (b < a.B) wave_row_stats<V>(a.x + (long)(b * a.x_rows_per_b + xrow0) * a.K, a.K, lane, mean[b], rstd[b]);
+    }
+    const float* w = a.Wt + (long)n * a.K;
+    for (int k = lane * V; k < a.K; k += 64 * V) {
+        float wv[V], gv[V], bv[V], av[V];
+        ldv<V>(w + k, wv);
+#pragma unroll
+        for (int e = 0; e < V; ++e) gv[e] = 1.f, bv[e] = 0.f, av[e] = 0.f;
+        if (a.xg) {
+            ldv<V>(a.xg + k, gv);
+            ldv<V>(a.xb + k, bv);
+        }
+        if (a.xadd) ldv<V>(a.xadd + k, av);
+#pragma unroll
+        for (int b = 0; b < 8; ++b) {
+            if (b >= a.B) continue;
+            const float* x = a.x + (long)(b * a.x_rows_per_b + xrow0) * a.K;
+            float xr[V];
+            ldv<V>(x + k, xr);
+#pragma unroll
+            for (int e = 0; e < V; ++e) {
+                float xv = (xr[e] - mean[b]) * rstd[b] * gv[e] + bv[e];
+                xv += av[e];
+                acc[b] += wv[e] * xv;
+            }
+        }
+    }
+#pragma unroll
+    for (int b = 0; b < 8; ++b) {
+        if (b >= a.B) continue;
+        float v = wave_sum(acc[b]) + (a.bias ? a.bias[n] : 0.f);
+        if (a.relu) v = fmaxf(v, 0.f);
+        if (a.res) {
+            const float* r = a.res + (long)b * a.N;
+            if (a.rg) {
+                float m, rs;
+                wave_row_stats<V>(r, a.N, lane, m, rs);
+                v += (r[n] - m) * rs * a.rg[n] + a.rb[n];
+            } else {
+                v += r[n];
+            }
+        }
+        if (lane == 0) a.out[(long)b * a.N + n] = v;
+    }
+}
+
+int launch_gemv(const GemvArgs& a, hipStream_t st) {
+    if (a.B > 8 || a.K % 64 != 0 || (a.rg && a.N % 64 != 0)) return PT_ERR_UNSUPPORTED;
+    const bool v4 = a.K % 256 == 0 && (!a.rg || a.N % 256 == 0);
+    if (v4)
+        hipLaunchKernelGGL((k_gemv<4>), dim3((a.N + 3) / 4), dim3(256), 0, st, a);
+    else
+        hipLaunchKernelGGL((k_gemv<1>), dim3((a.N + 3) / 4), dim3(256), 0, st, a);
+    PT_CHECK_LAUNCH();
+    return PT_OK;
+}
+
+// qk[b][h][c] = sum_{j in head h} Wk[h*HD + j][c] * q[b][h*HD + j] / sqrt(HD): the key projection folded onto the query
+__global__ __launch_bounds__(256) void k_dec_qk(const float* Wk, const float* q, float* qk, int B, int D, int nhead,
+                                                float scale) {
+    const int idx = blockIdx.x * 256 + threadIdx.x;
+    if (idx >= nhead * D) return;
+    const int h = idx / D, c = idx - h * D, HD = D / nhead;
+    float acc[8];
+#pragma unroll
+    for (int b = 0; b < 8; ++b) acc[b] = 0.f;
+    for (int j = 0; j < HD; ++j) {
+        const float w = Wk[(long)(h * HD + j) * D + c];
+#pragma unroll
+        for (int b = 0; b < 8; ++b)
+            if (b < B) acc[b] += w * q[(long)b * D + h * HD + j];
+    }
+#pragma unroll
+    for (int b = 0; b < 8; ++b)
+        if (b < B) qk[((long)b * nhead + h) * D + c] = acc[b] * scale;
+}
+
+struct DecAttnArgs {
+    const float *mem, *pos, *qk;
+    float *scores, *ctx;
+    int B, L, D, nhead, HW;
+    int mlo[8], mhi[8];
+};
+
+// scores[b][h][l] = qk[b][h] . (mem[b][l] + pos[l % HW]); one wavefront per 16 memory rows, all heads per row load
+__global__ __launch_bounds__(256) void k_dec_scores(DecAttnArgs a) {
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6, b = blockIdx.y;
+    const int per = a.D / 64;                                    // contiguous channels per lane (<= 8)
+    const int l0 = blockIdx.x * 64 + wave * 16;
+    for (int r = 0; r < 16; ++r) {
+        const int l = l0 + r;
+        if (l >= a.L) return;
+        float mp[8];
+        for (int i = 0; i < per; ++i)
+            mp[i] = a.mem[((long)b * a.L + l) * a.D + lane * per + i] + a.pos[(long)(l % a.HW) * a.D + lane * per + i];
+        const bool masked = l >= a.mlo[b] && l < a.mhi[b];
+        for (int h = 0; h < a.nhead; ++h) {
+            const float* q = a.qk + ((long)b * a.nhead + h) * a.D + lane * per;
+            float s = 0.f;
+            for (int i = 0; i < per; ++i) s += mp[i] * q[i];
+            s = wave_sum(s);
+            if (lane == 0) a.scores[((long)b * a.nhead + h) * a.L + l] = masked ? -INFINITY : s;
+        }
+    }
+}
+
+// ctx[b][h][c] = sum_l softmax(scores[b][h])[l] * mem[b][l][c]; grid (D/64, B*nhead), 4 row partitions per workgroup
+__global__ __launch_bounds__(256) void k_dec_ctx(DecAttnArgs a) {
+    extern __shared__ float sm[];                                // L probabilities + 256 partials + 4 scratch
+    float* p = sm;
+    float* part = sm + a.L;
+    float* scratch = part + 256;
+    const int tid = threadIdx.x, bh = blockIdx.y, b = bh / a.nhead, c = blockIdx.x * 64 + (tid & 63), pr = tid >> 6;
+    const float* s = a.scores + (long)bh * a.L;
+    float mx = -INFINITY;
+    for (int l = tid; l < a.L; l += 256) mx = fmaxf(mx, s[l]);
+    mx = block_max(mx, scratch);
+    float sum = 0.f;
+    for (int l = tid; l < a.L; l += 256) {
+        const float e = __expf(s[l] - mx);
+        p[l] = e;
+        sum += e;
+    }
+    sum = block_sum(sum, scratch);
+    __syncthreads();
+    float acc = 0.f;
+    for (int l = pr; l < a.L; l += 4) acc += p[l] * a.mem[((long)b * a.L + l) * a.D + c];
+    part[tid] = acc;
+    __syncthreads();
+    if (pr == 0) a.ctx[(long)bh * a.D + c] = (part[tid] + part[tid + 64] + part[tid + 128] + part[tid + 192]) / sum;
+}
+
+// ------------------------------------------------------------------------------------------------------------------
+// box-regression head pieces (heads.py:119-141)
+// ------------------------------------------------------------------------------------------------------------------
+// att[p] = feat[:, p] . filt;  T[p][c] = att[p] * feat[c][p] (token-major), one workgroup per (32 positions, image)
+__global__ __launch_bounds__(256) void k_reg_attend(const float* feat, const float* filt, float* T, int D, int HW) {
+    extern __shared__ float sm[];                                // D x 33 tile + 32 attention values
+    float* tile = sm;
+    float* att = sm + (size_t)D * 33;
+    const int tx = threadIdx.x & 31, ty = threadIdx.x >> 5, p0 = blockIdx.x * 32, img = blockIdx.y;
+    const float* src = feat + (long)img * D * HW;
+    float part = 0.f;
+    for (int c = ty; c < D; c += 8) {
+        const float v = (p0 + tx < HW) ? src[(long)c * HW + p0 + tx] : 0.f;
+        tile[c * 33 + tx] = v;
+        part += v * filt[c];
+    }
+    __shared__ float red[8][33];
+    red[ty][tx] = part;
+    __syncthreads();
+    if (ty == 0) {
+        float s = 0.f;
+        for (int i = 0; i < 8; ++i) s += red[i][tx];
+        att[tx] = s;
+    }
+    __syncthreads();
+    for (int i = ty; i < 32; i += 8) {
+        const int p = p0 + i;
+        if (p >= HW) continue;
+        for (int c = tx; c < D; c += 32) T[((long)img * HW + p) * D + c] = att[i] * tile[c * 33 + i];
+    }
+}
+
+// GroupNorm(1, C) + ReLU over one image's (HW, C) token-major block, in place; one workgroup per image
+__global__ __launch_bounds__(1024) void k_groupnorm_relu(float* X, const float* gam, const float* bet, int D, int HW) {
+    __shared__ float scratch[16];
+    float* x = X + (long)blockIdx.x * D * HW;
+    const int n = D * HW;
+    float s = 0.f;
+    for (int i = threadIdx.x; i < n; i += 1024) s += x[i];
+    const float mean = block_sum(s, scratch) / n;
+    float q = 0.f;
+    for (int i = threadIdx.x; i < n; i += 1024) q += (x[i] - mean) * (x[i] - mean);
+    const float rstd = rsqrtf(block_sum(q, scratch) / n + 1e-5f);
+    for (int i = threadIdx.x; i < n; i += 1024) {
+        const int c = i % D;
+        x[i] = fmaxf((x[i] - mean) * rstd * gam[c] + bet[c], 0.f);
+    }
+}
+
+// ------------------------------------------------------------------------------------------------------------------
+// parameter pack layout (documented in include/pt_hot.h)
+// ------------------------------------------------------------------------------------------------------------------
+struct MhaOff { size_t w_in, b_in, w_out, b_out; };
+struct EncOff { MhaOff sa; size_t w1, b1, w2, b2, n1g, n1b, n2g, n2b; };
+struct DecOff { MhaOff sa, ca; size_t w1, b1, w2, b2, n1g, n1b, n2g, n2b, n3g, n3b; };
+struct PackOff {
+    EncOff enc[16];
+    DecOff dec[16];
+    size_t dng, dnb, bw1, bb1, bn1, bw2, bb2, bn2, bw3, bb3, fg, testtok, total;
+};
+
+PackOff pack_layout(int D, int ff, int n_enc, int n_dec) {
+    PackOff o{};
+    size_t c = 0;
+    auto take = [&](size_t n) { size_t r = c; c += n; return r; };
+    auto mha = [&](MhaOff& m) {
+        m.w_in = take((size_t)3 * D * D); m.b_in = take((size_t)3 * D); m.w_out = take((size_t)D * D); m.b_out = take(D);
+    };
+    for (int i = 0; i < n_enc; ++i) {
+        EncOff& e = o.enc[i];
+        mha(e.sa);
+        e.w1 = take((size_t)ff * D); e.b1 = take(ff); e.w2 = take((size_t)D * ff); e.b2 = take(D);
+        e.n1g = take(D); e.n1b = take(D); e.n2g = take(D); e.n2b = take(D);
+    }
+    for (int i = 0; i < n_dec; ++i) {
+        DecOff& d = o.dec[i];
+        mha(d.sa);
+        mha(d.ca);
+        d.w1 = take((size_t)ff * D); d.b1 = take(ff); d.w2 = take((size_t)D * ff); d.b2 = take(D);
+        d.n1g = take(D); d.n1b = take(D); d.n2g = take(D); d.n2b = take(D); d.n3g = take(D); d.n3b = take(D);
+    }
+    o.dng = take(D); o.dnb = take(D);
+    const int D4 = D / 4;
+    o.bw1 = take((size_t)D4 * 4); o.bb1 = take(D4); o.bn1 = take((size_t)4 * D4);
+    o.bw2 = take((size_t)D * D4); o.bb2 = take(D); o.bn2 = take((size_t)4 * D);
+    o.bw3 = take((size_t)D * D); o.bb3 = take(D);
+    o.fg = take(D); o.testtok = take(D);
+    o.total = c;
+    return o;
+}
+
+int dims_check(const pt_tomp_dims* d) {
+    if (!d) return PT_ERR_NULL;
+    if (d->d_model <= 0 || d->nhead <= 0 || d->dim_ff <= 0 || d->n_enc < 0 || d->n_dec < 0 || d->H <= 0 || d->W <= 0 ||
+        d->max_res <= 0)
+        return PT_ERR_SHAPE;
+    if (d->d_model % d->nhead != 0) return PT_ERR_SHAPE;
+    const int hd = d->d_model / d->nhead;
+    if ((hd != 16 && hd != 32 && hd != 64) || d->d_model % 128 != 0 || d->d_model > 512 || d->dim_ff % 64 != 0 ||
+        d->n_enc > 16 || d->n_dec > 16)
+        return PT_ERR_UNSUPPORTED;
+    return PT_OK;
+}
+
+struct WsCarve {
+    size_t X, QKV, AO, Y, Hd, E1, E2, bnsc, bnsh, zero, a, q, qk, scores, ctx, cv, P[2], P1, P2, hdn, total;
+};
+
+WsCarve ws_carve(const pt_tomp_dims* d, int B, int nf) {
+    WsCarve w{};
+    const size_t D = d->d_model, HW = (size_t)d->H * d->W, L = (nf + 1) * HW, rows = B * L;
+    size_t c = 0;
+    auto take = [&](size_t n) { size_t r = c; c += pt_align_floats(n); return r; };
+    w.X = take(rows * D); w.QKV = take(rows * 3 * D); w.AO = take(rows * D); w.Y = take(rows * D);
+    w.Hd = take(rows * d->dim_ff);
+    w.E1 = take((size_t)B * nf * HW * (D / 4)); w.E2 = take((size_t)B * nf * HW * D);
+    w.bnsc = take(D); w.bnsh = take(D);
+    w.zero = take(B * D); w.a = take(B * D); w.q = take(B * D); w.qk = take((size_t)B * d->nhead * D);
+    w.scores = take((size_t)B * d->nhead * L); w.ctx = take((size_t)B * d->nhead * D); w.cv = take(B * D);
+    w.P[0] = take(B * D); w.P[1] = take(B * D); w.P1 = take(B * D); w.P2 = take(B * D); w.hdn = take((size_t)B * d->dim_ff);
+    w.total = c;
+    return w;
+}
+
+}  // namespace
+
+// ==================================================================================================================
+// C ABI
+// ==================================================================================================================
+extern "C" size_t pt_tomp_param_floats(const pt_tomp_dims* d) {
+    if (dims_check(d)) return 0;
+    return pack_layout(d->d_model, d->dim_ff, d->n_enc, d->n_dec).total;
+}
+
+extern "C" int pt_tomp_posenc_f32(float* pos, int H, int W, int d_model, int max_res, void* stream) {
+    if (!pos) return PT_ERR_NULL;
+    if (H <= 0 || W <= 0 || d_model <= 0 || d_model % 4 != 0 || max_res <= 0) return PT_ERR_SHAPE;
+    const int total = H * W * d_model;
+    const double factor = (double)max_res / (double)(d_model / 4);
+    hipLaunchKernelGGL(k_tomp_posenc, dim3((total + 255) / 256), dim3(256), 0, (hipStream_t)stream, pos, H, W, d_model,
+                       factor);
+    PT_CHECK_LAUNCH();
+    return PT_OK;
+}
+
+extern "C" size_t pt_tomp_predict_ws_bytes(const pt_tomp_dims* d, int n_train, int n_seq, int parallel) {
+    if (dims_check(d) || n_train <= 0 || n_seq <= 0) return 0;
+    const int B = parallel ? 2 : n_seq;
+    if (B > 8 || (parallel && n_seq != 1)) return 0;
+    if ((size_t)(n_train + 1) * d->H * d->W > 8192) return 0;
+    return ws_carve(d, B, n_train).total * sizeof(float);
+}
+
+extern "C" int pt_tomp_linear_f32(const float* weight, const float* bias, const float* x, float* y, int B, int N, int K,
+                                  int relu, void* stream) {
+    if (!weight || !x || !y) return PT_ERR_NULL;
+    if (B <= 0 || N <= 0 || K <= 0) return PT_ERR_SHAPE;
+    GemvArgs a{};
+    a.Wt = weight; a.bias = bias; a.N = N; a.K = K; a.x = x; a.x_rows_per_b = 1; a.relu = relu; a.B = B; a.out = y;
+    return launch_gemv(a, (hipStream_t)stream);
+}
+
+extern "C" int pt_tomp_predict_f32(const pt_tomp_dims* d, const float* params, const float* pos, const float* train_feat,
+                                   const float* test_feat, const float* train_label, const float* train_ltrb,
+                                   int n_train, int n_seq, int parallel, int num_gth_frames, float* filters,
+                                   float* enc_feat, void* ws, size_t ws_bytes, void* stream) {
+    if (!params || !pos || !train_feat || !test_feat || !train_label || !train_ltrb || !filters || !enc_feat || !ws)
+        return PT_ERR_NULL;
+    int rc = dims_check(d);
+    if (rc) return rc;
+    if (n_train <= 0 || n_seq <= 0 || num_gth_frames < 0 || num_gth_frames > n_train) return PT_ERR_SHAPE;
+    const int B = parallel ? 2 : n_seq;
+    if (B > 8 || (parallel && n_seq != 1)) return PT_ERR_UNSUPPORTED;
+    const int D = d->d_model, ff = d->dim_ff, NH = d->nhead, HD = D / NH, HW = d->H * d->W, Ltr = n_train * HW,
+              L = Ltr + HW, rows = B * L, D4 = D / 4;
+    if (L > 8192) return PT_ERR_UNSUPPORTED;
+    const WsCarve cv = ws_carve(d, B, n_train);
+    if (ws_bytes < cv.total * sizeof(float) || ((uintptr_t)ws % 256) != 0) return PT_ERR_WORKSPACE;
+    hipStream_t st = (hipStream_t)stream;
+    float* base = (float*)ws;
+    const PackOff po = pack_layout(D, ff, d->n_enc, d->n_dec);
+    const float* P = params;
+    float *X = base + cv.X, *QKV = base + cv.QKV, *AO = base + cv.AO, *Y = base + cv.Y, *Hd = base + cv.Hd;
+
+    // ---- tokens (filter_predictor.py:113-128)
+    {
+        TokArgs t{train_feat, test_feat, train_label, P + po.fg, P + po.testtok, X, n_train, n_seq, parallel ? 1 : 0, D,
+                  HW, L};
+        hipLaunchKernelGGL(k_tomp_tokens, dim3((HW + 31) / 32, (D + 31) / 32, (n_train + 1) * B), dim3(256), 0, st, t);
+        PT_CHECK_LAUNCH();
+        BoxArgs bx{train_ltrb, P + po.bw1, P + po.bb1, P + po.bn1, P + po.bn2, base + cv.E1, base + cv.bnsc,
+                   base + cv.bnsh, n_train, n_seq, parallel ? 1 : 0, D, D4, HW};
+        const long tot = (long)B * Ltr * D4;
+        hipLaunchKernelGGL(k_tomp_box1, dim3((unsigned)((tot + 255) / 256)), dim3(256), 0, st, bx);
+        PT_CHECK_LAUNCH();
+        GemmArgs g = gemm_args(base + cv.E1, D4, (long)B * Ltr, P + po.bw2, B * Ltr, D, D4, P + po.bb2, base + cv.E2, D);
+        g.scale = base + cv.bnsc; g.shift = base + cv.bnsh; g.relu = 1;
+        if ((rc = launch_gemm(g, st))) return rc;
+        g = gemm_args(base + cv.E2, D, (long)B * Ltr, P + po.bw3, B * Ltr, D, D, P + po.bb3, X, D);
+        g.R = X; g.c_seg = Ltr; g.c_segstride = L;
+        if ((rc = launch_gemm(g, st))) return rc;
+    }
+    AttnArgs at{};
+    at.qkv = QKV; at.qkv_bytes = (unsigned)((long)rows * 3 * D * 4); at.out = AO; at.L = L; at.D = D; at.nhead = NH;
+    at.scale = 1.0f / sqrtf((float)HD);
+    for (int b = 0; b < 8; ++b) at.mlo[b] = at.mhi[b] = 0;
+    if (parallel) {                                               // filter_predictor.py:134-136: batch row 1 only
+        at.mlo[1] = num_gth_frames * HW;
+        at.mhi[1] = L - HW;
+    }
+    // ---- encoder (transformer.py:172-180), post-norm
+    for (int i = 0; i < d->n_enc; ++i) {
+        const EncOff& e = po.enc[i];
+        GemmArgs g = gemm_args(X, D, rows, P + e.sa.w_in, rows, 3 * D, D, P + e.sa.b_in, QKV, 3 * D);
+        g.pos = pos; g.pos_bytes = (unsigned)((long)HW * D * 4); g.pos_cols = 2 * D; g.L = L; g.HW = HW;
+        if ((rc = launch_gemm(g, st))) return rc;
+        const dim3 ag((L + 63) / 64, NH, B);
+        if (HD == 32) hipLaunchKernelGGL((k_attn<32>), ag, dim3(256), 0, st, at);
+        else if (HD == 16) hipLaunchKernelGGL((k_attn<16>), ag, dim3(256), 0, st, at);
+        else hipLaunchKernelGGL((k_attn<64>), ag, dim3(256), 0, st, at);
+        PT_CHECK_LAUNCH();
+        g = gemm_args(AO, D, rows, P + e.sa.w_out, rows, D, D, P + e.sa.b_out, Y, D);
+        g.R = X;
+        if ((rc = launch_gemm(g, st))) return rc;
+        hipLaunchKernelGGL(k_ln_rows, dim3((rows + 3) / 4), dim3(256), 0, st, Y, X, P + e.n1g, P + e.n1b, rows, D);
+        PT_CHECK_LAUNCH();
+        g = gemm_args(X, D, rows, P + e.w1, rows, ff, D, P + e.b1, Hd, ff);
+        g.relu = 1;
+        if ((rc = launch_gemm(g, st))) return rc;
+        g = gemm_args(Hd, ff, rows, P + e.w2, rows, D, ff, P + e.b2, Y, D);
+        g.R = X;
+        if ((rc = launch_gemm(g, st))) return rc;
+        hipLaunchKernelGGL(k_ln_rows, dim3((rows + 3) / 4), dim3(256), 0, st, Y, X, P + e.n2g, P + e.n2b, rows, D);
+        PT_CHECK_LAUNCH();
+    }
+    // ---- decoder (transformer.py:224-238), one query per batch row; T = LayerNorm(pre) is applied by the consumers
+    if (hipMemsetAsync(base + cv.zero, 0, (size_t)B * D * sizeof(float), st) != hipSuccess) return PT_ERR_LAUNCH;
+    DecAttnArgs da{};
+    da.mem = X; da.pos = pos; da.qk = base + cv.qk; da.scores = base + cv.scores; da.ctx = base + cv.ctx;
+    da.B = B; da.L = L; da.D = D; da.nhead = NH; da.HW = HW;
+    for (int b = 0; b < 8; ++b) { da.mlo[b] = at.mlo[b]; da.mhi[b] = at.mhi[b]; }
+    const float* qpos = P + po.fg;                                 // query_embed_fg_decoder IS query_embed_fg (:35)
+    const float* tpre = base + cv.zero;                            // pre-LayerNorm state entering the layer
+    const float *tg = nullptr, *tb = nullptr;                      // its LayerNorm (none for the initial zeros)
+    for (int i = 0; i < d->n_dec; ++i) {
+        const DecOff& dc = po.dec[i];
+        float *Pa = base + cv.P1, *Pb = base + cv.P2, *Pc = base + cv.P[i & 1];
+        GemvArgs v{};
+        // self-attention over one token: softmax of a single key is 1 -> out_proj(v_proj(tgt))
+        v.Wt = P + dc.sa.w_in + (size_t)2 * D * D; v.bias = P + dc.sa.b_in + 2 * D; v.N = D; v.K = D;
+        v.x = tpre; v.x_rows_per_b = 1; v.xg = tg; v.xb = tb; v.B = B; v.out = base + cv.a;
+        if ((rc = launch_gemv(v, st))) return rc;
+        v = GemvArgs{};
+        v.Wt = P + dc.sa.w_out; v.bias = P + dc.sa.b_out; v.N = D; v.K = D; v.x = base + cv.a; v.x_rows_per_b = 1;
+        v.res = tpre; v.rg = tg; v.rb = tb; v.B = B; v.out = Pa;
+        if ((rc = launch_gemv(v, st))) return rc;
+        // cross-attention: q = Wq (LN1(Pa) + query_pos) + bq
+        v = GemvArgs{};
+        v.Wt = P + dc.ca.w_in; v.bias = P + dc.ca.b_in; v.N = D; v.K = D; v.x = Pa; v.x_rows_per_b = 1;
+        v.xg = P + dc.n1g; v.xb = P + dc.n1b; v.xadd = qpos; v.B = B; v.out = base + cv.q;   // one query_pos row for all b
+        if ((rc = launch_gemv(v, st))) return rc;
+        hipLaunchKernelGGL(k_dec_qk, dim3((NH * D + 255) / 256), dim3(256), 0, st, P + dc.ca.w_in + (size_t)D * D,
+                           base + cv.q, base + cv.qk, B, D, NH, at.scale);
+        PT_CHECK_LAUNCH();
+        hipLaunchKernelGGL(k_dec_scores, dim3((L + 63) / 64, B), dim3(256), 0, st, da);
+        PT_CHECK_LAUNCH();
+        hipLaunchKernelGGL(k_dec_ctx, dim3(D / 64, B * NH), dim3(256), (size_t)(L + 256 + 8) * sizeof(float), st, da);
+        PT_CHECK_LAUNCH();
+        // value projection per head on the attention-weighted memory, then out_proj + residual LN1(Pa)
+        v = GemvArgs{};
+        v.Wt = P + dc.ca.w_in + (size_t)2 * D * D; v.bias = P + dc.ca.b_in + 2 * D; v.N = D; v.K = D;
+        v.x = base + cv.ctx; v.x_rows_per_b = NH; v.x_head_div = HD; v.B = B; v.out = base + cv.a;
+        if ((rc = launch_gemv(v, st))) return rc;
+        v = GemvArgs{};
+        v.Wt = P + dc.ca.w_out; v.bias = P + dc.ca.b_out; v.N = D; v.K = D; v.x = base + cv.a; v.x_rows_per_b = 1;
+        v.res = Pa; v.rg = P + dc.n1g; v.rb = P + dc.n1b; v.B = B; v.out = Pb;
+        if ((rc = launch_gemv(v, st))) return rc;
+        // feed-forward on LN2(Pb)
+        v = GemvArgs{};
+        v.Wt = P + dc.w1; v.bias = P + dc.b1; v.N = ff; v.K = D; v.x = Pb; v.x_rows_per_b = 1; v.xg = P + dc.n2g;
+        v.xb = P + dc.n2b; v.relu = 1; v.B = B; v.out = base + cv.hdn;
+        if ((rc = launch_gemv(v, st))) return rc;
+        v = GemvArgs{};
+        v.Wt = P + dc.w2; v.bias = P + dc.b2; v.N = D; v.K = ff; v.x = base + cv.hdn; v.x_rows_per_b = 1;
+        v.res = Pb; v.rg = P + dc.n2g; v.rb = P + dc.n2b; v.B = B; v.out = Pc;
+        if ((rc = launch_gemv(v, st))) return rc;
+        tpre = Pc; tg = P + dc.n3g; tb = P + dc.n3b;
+    }
+    // norm3 of the last layer, then the decoder's final norm (transformer.py:141-142)
+    if (d->n_dec > 0) {
+        hipLaunchKernelGGL(k_ln_rows, dim3((B + 3) / 4), dim3(256), 0, st, tpre, base + cv.a, tg, tb, B, D);
+        PT_CHECK_LAUNCH();
+        tpre = base + cv.a;
+    }
+    hipLaunchKernelGGL(k_ln_rows, dim3((B + 3) / 4), dim3(256), 0, st, tpre, filters, P + po.dng, P + po.dnb, B, D);
+    PT_CHECK_LAUNCH();
+    hipLaunchKernelGGL(k_tokens_to_nchw, dim3((HW + 31) / 32, (D + 31) / 32, B), dim3(256), 0, st, X, enc_feat, B, L, D,
+                       HW, Ltr);
+    PT_CHECK_LAUNCH();
+    return PT_OK;
+}
+
+// ---- DenseBoxRegressor (heads.py:119-141) ------------------------------------------------------------------------
+// reg pack: linear.weight (D,D), linear.bias (D), 4 x [conv weight (D, 9, D) tap-major, conv bias (D), GroupNorm weight
+// (D), GroupNorm bias (D)], bbreg_layer weight (4, 9, D), bbreg_layer bias (4)
+namespace {
+struct RegOff { size_t lw, lb, cw[4], cb[4], gg[4], gb[4], fw, fb, total; };
+RegOff reg_layout(int D) {
+    RegOff o{};
+    size_t c = 0;
+    auto take = [&](size_t n) { size_t r = c; c += n; return r; };
+    o.lw = take((size_t)D * D); o.lb = take(D);
+    for (int i = 0; i < 4; ++i) { o.cw[i] = take((size_t)D * 9 * D); o.cb[i] = take(D); o.gg[i] = take(D); o.gb[i] = take(D); }
+    o.fw = take((size_t)4 * 9 * D); o.fb = take(4);
+    o.total = c;
+    return o;
+}
+}  // namespace
+
+extern "C" size_t pt_tomp_bbreg_param_floats(int d_model) {
+    return d_model > 0 && d_model % 32 == 0 ? reg_layout(d_model).total : 0;
+}
+
+extern "C" size_t pt_tomp_bbreg_ws_bytes(int n, int d_model, int H, int W) {
+    if (n <= 0 || d_model <= 0 || d_model % 64 != 0 || d_model > 512 || H <= 0 || W <= 0) return 0;
+    return (pt_align_floats(d_model) + 2 * pt_align_floats((size_t)n * H * W * d_model)) * sizeof(float);
+}
+
+extern "C" int pt_tomp_bbreg_f32(const float* params, const float* feat, const float* filter, float* ltrb, int n,
+                                 int d_model, int H, int W, void* ws, size_t ws_bytes, void* stream) {
+    if (!params || !feat || !filter || !ltrb || !ws) return PT_ERR_NULL;
+    if (n <= 0 || d_model <= 0 || H <= 0 || W <= 0) return PT_ERR_SHAPE;
+    if (d_model % 64 != 0 || d_model > 512) return PT_ERR_UNSUPPORTED;
+    const size_t need = pt_tomp_bbreg_ws_bytes(n, d_model, H, W);
+    if (ws_bytes < need || ((uintptr_t)ws % 256) != 0) return PT_ERR_WORKSPACE;
+    hipStream_t st = (hipStream_t)stream;
+    const int D = d_model, HW = H * W, M = n * HW;
+    const RegOff ro = reg_layout(D);
+    float* fproj = (float*)ws;
+    float* T0 = fproj + pt_align_floats(D);
+    float* T1 = T0 + pt_align_floats((size_t)M * D);
+    GemvArgs v{};
+    v.Wt = params + ro.lw; v.bias = params + ro.lb; v.N = D; v.K = D; v.x = filter; v.x_rows_per_b = 1; v.B = 1; v.out = fproj;
+    int rc = launch_gemv(v, st);
+    if (rc) return rc;
+    hipLaunchKernelGGL(k_reg_attend, dim3((HW + 31) / 32, n), dim3(256), ((size_t)D * 33 + 32) * sizeof(float), st, feat,
+                       fproj, T0, D, HW);
+    PT_CHECK_LAUNCH();
+    float *src = T0, *dst = T1;
+    for (int i = 0; i < 4; ++i) {
+        GemmArgs g = gemm_args(src, D, M, params + ro.cw[i], M, D, 9 * D, params + ro.cb[i], dst, D);
+        g.H = H; g.Wd = W; g.Cin = D; g.HW = HW;
+        if ((rc = launch_gemm(g, st, true))) return rc;
+        hipLaunchKernelGGL(k_groupnorm_relu, dim3(n), dim3(1024), 0, st, dst, params + ro.gg[i], params + ro.gb[i], D, HW);
+        PT_CHECK_LAUNCH();
+        std::swap(src, dst);
+    }
+    GemmArgs g = gemm_args(src, D, M, params + ro.fw, M, 4, 9 * D, params + ro.fb, ltrb, 4);
+    g.H = H; g.Wd = W; g.Cin = D; g.HW = HW; g.expo = 1; g.nchw = 1;
+    return launch_gemm(g, st, true);
+}

@@ -120,7 +120,7 @@ def atom_problem(seed, n, cfg=ATOM18, small=None):
 # ------------------------------------------------------------------------------------------------------
 TOMP = dict(  # tompnet50/101 as instantiated by ltr/train_settings/tomp/tomp50.py, tomp101.py (out_feature_dim=256)
     D=256, nhead=8, ff=2048, n_enc=6, n_dec=6, H=18, W=18, feature_sz=18, n_train=2, num_gth_frames=1)
-TOMP_SMALL = dict(D=64, nhead=2, ff=128, n_enc=2, n_dec=2, H=6, W=6, feature_sz=6, n_train=2, num_gth_frames=1)
+TOMP_SMALL = dict(D=128, nhead=4, ff=256, n_enc=2, n_dec=2, H=6, W=6, feature_sz=6, n_train=2, num_gth_frames=1)
 
 
 def _xavier(rng, shape, fan_in, fan_out):

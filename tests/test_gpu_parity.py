@@ -475,3 +475,83 @@ def test_track_frame_matches_oracle_composition(C, n):
     assert tuple(st.peak.cpu().numpy().astype(int)) == tuple(ref["peak"])
     close(st.mem_bb, ref["bb"], atol=1e-4)
     close(st.filter, ref["filter"], atol=2e-5)
+
+
+# ------------------------------------------------------------------------------------------------------
+# ToMP transformer model predictor
+# ------------------------------------------------------------------------------------------------------
+def build_tomp_modules(cfg, params, device):
+    """The mirrored FilterPredictor / LinearFilterClassifier / DenseBoxRegressor carrying the seeded parameters,
+    loaded through `load_state_dict(strict=True)` with the reference's key names."""
+    from pytracking_amd import transformer as TM
+    D = cfg["D"]
+    tr = TM.Transformer(d_model=D, nhead=cfg["nhead"], num_encoder_layers=cfg["n_enc"],
+                        num_decoder_layers=cfg["n_dec"], dim_feedforward=cfg["ff"])
+    pred = TM.FilterPredictor(tr, feature_sz=cfg["feature_sz"], use_test_frame_encoding=True)
+    cls = TM.LinearFilterClassifier(num_channels=D)
+    reg = TM.DenseBoxRegressor(num_channels=D)
+    for mod, pre in ((pred, "fp."), (cls, "cls."), (reg, "reg.")):
+        sd = {k[len(pre):]: torch.from_numpy(v.copy()) for k, v in params.items() if k.startswith(pre)}
+        if pre == "fp.":
+            sd["query_embed_fg_decoder.weight"] = sd["query_embed_fg.weight"]
+            for idx in (1, 4):
+                sd[f"box_encoding.{idx}.num_batches_tracked"] = torch.tensor(0)
+        mod.load_state_dict(sd, strict=True)
+        mod.to(device).eval()
+    return pred, cls, reg
+
+
+@pytest.mark.parametrize("name,cfg", [("tomp_small", "TOMP_SMALL"), ("tomp_full", "TOMP")])
+def test_tomp_predictor_golden(name, cfg):
+    """predict_cls_bbreg_filters_parallel + classifier + box regressor vs the reference run (tomp.py:282-303)."""
+    g = load_golden(name)
+    cfg = getattr(synth, cfg)
+    pred, cls, reg = build_tomp_modules(cfg, synth.tomp_params(int(g["seed"]), cfg), DEV)
+    train, test, lab, ltrb = [T(a) for a in synth.tomp_inputs(int(g["seed"]) + 1, cfg)]
+    with torch.no_grad():
+        close(pred.get_positional_encoding(test)[0, 0], g["pos"], atol=5e-6, rtol=0)
+        cw, bw, cenc, benc = pred.predict_cls_bbreg_filters_parallel(train, test, lab, cfg["num_gth_frames"], ltrb)
+        assert cw.shape == (1, cfg["D"], 1, 1) and cenc.shape == (1, 1, cfg["D"], cfg["H"], cfg["W"])
+        close(cenc, g["cls_enc"], atol=1e-4, rtol=1e-4)
+        close(benc, g["bbreg_enc"], atol=1e-4, rtol=1e-4)
+        close(cw.reshape(-1), g["cls_filter"], atol=1e-4, rtol=1e-4)
+        close(bw.reshape(-1), g["bbreg_filter"], atol=1e-4, rtol=1e-4)
+        scores = cls(cenc, cw)
+        close(scores, g["scores"], atol=1e-4, rtol=1e-4)
+        boxes = reg(benc, bw)
+        assert boxes.shape == g["ltrb"].shape
+        close(boxes, g["ltrb"], atol=1e-4, rtol=1e-4)
+        # heads alone on the reference's own encoder outputs (isolates them from the transformer's rounding)
+        close(cls(T(g["cls_enc"]), T(g["cls_filter"]).reshape(1, -1, 1, 1)), g["scores"], atol=2e-5, rtol=1e-4)
+        close(reg(T(g["bbreg_enc"]), T(g["bbreg_filter"]).reshape(1, -1, 1, 1)), g["ltrb"], atol=2e-5, rtol=1e-4)
+        w1, enc1 = pred.predict_filter(train, test, lab, ltrb)
+        close(w1.reshape(-1), g["single_filter"], atol=1e-4, rtol=1e-4)
+        close(enc1, g["single_enc"], atol=1e-4, rtol=1e-4)
+
+
+def test_tomp_encoder_blocks_vs_oracle():
+    """Odd sizes against the float64 oracle: 3 memory frames, 5x7 maps (tokens not a multiple of any tile), two
+    sequences through predict_filter, masked keys through the parallel entry point."""
+    from oracle import tomp_oracle as TO
+    cfg = dict(synth.TOMP_SMALL, H=5, W=7, n_train=3, feature_sz=7, num_gth_frames=2)
+    params = synth.tomp_params(91, cfg)
+    pred, cls, reg = build_tomp_modules(cfg, params, DEV)
+    p64 = {k: v.astype(np.float64) for k, v in params.items()}
+    train, test, lab, ltrb = synth.tomp_inputs(92, cfg)
+    train2, test2, lab2, ltrb2 = synth.tomp_inputs(93, cfg)
+    f64 = lambda a: a.astype(np.float64)
+    a = (cfg["nhead"], cfg["n_enc"], cfg["n_dec"], cfg["feature_sz"])
+    with torch.no_grad():
+        cw, bw, cenc, benc = pred.predict_cls_bbreg_filters_parallel(T(train), T(test), T(lab), 2, T(ltrb))
+        rcw, rbw, rcenc, rbenc = TO.predict_cls_bbreg_filters_parallel(p64, f64(train), f64(test), f64(lab), 2, f64(ltrb), *a)
+        close(cw.reshape(-1), rcw, atol=5e-5, rtol=1e-4)
+        close(bw.reshape(-1), rbw, atol=5e-5, rtol=1e-4)
+        close(cenc, rcenc, atol=5e-5, rtol=1e-4)
+        close(benc, rbenc, atol=5e-5, rtol=1e-4)
+        close(reg(benc, bw), TO.dense_box_regressor(p64, rbenc, rbw), atol=5e-5, rtol=2e-4)
+        cat = lambda x, y: np.concatenate((x, y), axis=1)
+        tr, te, lb, lt = cat(train, train2), cat(test, test2), cat(lab, lab2), cat(ltrb, ltrb2)
+        w, enc = pred.predict_filter(T(tr), T(te), T(lb), T(lt))
+        rw, renc = TO.predict_filter(p64, f64(tr), f64(te), f64(lb), f64(lt), *a)
+        close(w.reshape(2, -1), rw, atol=5e-5, rtol=1e-4)
+        close(enc, renc, atol=5e-5, rtol=1e-4)
