@@ -43,6 +43,8 @@ struct GemmArgs {
     int relu, expo, nchw;                       // nchw: C[((r / HW) * N + n) * HW + r % HW]
     const float* pos; unsigned pos_bytes; int pos_cols, L, HW;   // A[r][k] + pos[(r % L) % HW][k] for column tiles < pos_cols
     int H, Wd, Cin;                             // MODE 1: 3x3 zero-padded gather, K = 9 * Cin, weights (N, tap, Cin)
+    int ksteps; long c_zstride;                 // split-K: blockIdx.z owns K-steps [z*ksteps, (z+1)*ksteps) and writes its
+                                                // partial product to C + z*c_zstride (bias on z = 0 only); 0 = no split
 };
 
 template <int BM, int BN, int MODE>
@@ -121,11 +123,12 @@ __global__ __launch_bounds__(256) void k_gemm(GemmArgs g) {
 #pragma unroll
         for (int b = 0; b < NT; ++b) acc[a][b] = f32x4{0.f, 0.f, 0.f, 0.f};
 
-    const int nk = g.K / 32;
-    fetch(0);
-    stash(0);
+    const int kb0 = g.ksteps ? blockIdx.z * g.ksteps : 0;
+    const int nk = g.ksteps ? min(g.K / 32, kb0 + g.ksteps) : g.K / 32;
+    fetch(kb0);
+    stash(kb0 & 1);
     __syncthreads();
-    for (int kb = 0; kb < nk; ++kb) {
+    for (int kb = kb0; kb < nk; ++kb) {
         const int buf = kb & 1;
         if (kb + 1 < nk) fetch(kb + 1);
         const float* as = &As[buf][(wm * WM + (lane & 15)) * LS + (lane >> 4) * 4];
@@ -154,7 +157,7 @@ __global__ __launch_bounds__(256) void k_gemm(GemmArgs g) {
         for (int nt = 0; nt < NT; ++nt) {
             const int col = n0 + wn * WN + nt * 16 + (lane & 15);
             if (col >= g.N) continue;
-            const float bv = g.bias ? g.bias[col] : 0.f;
+            const float bv = (g.bias && blockIdx.z == 0) ? g.bias[col] : 0.f;
             const float sc = g.scale ? g.scale[col] : 1.f, sh = g.scale ? g.shift[col] : 0.f;
 #pragma unroll
             for (int r = 0; r < 4; ++r) {
@@ -172,7 +175,7 @@ __global__ __launch_bounds__(256) void k_gemm(GemmArgs g) {
                 }
                 if (g.R) v += g.R[o];
                 if (g.expo) v = expf(v);
-                g.C[o] = v;
+                g.C[o + (long)blockIdx.z * g.c_zstride] = v;
             }
         }
 }
@@ -191,7 +194,8 @@ int launch_gemm(const GemmArgs& g, hipStream_t st, bool conv = false) {
     if (g.K % 32 != 0 || g.M <= 0 || g.N <= 0) return PT_ERR_UNSUPPORTED;
     if (conv) {
         if (g.Cin % 32 != 0) return PT_ERR_UNSUPPORTED;
-        hipLaunchKernelGGL((k_gemm<32, 32, 1>), dim3((g.N + 31) / 32, (g.M + 31) / 32), dim3(256), 0, st, g);
+        const int nz = g.ksteps ? (g.K / 32 + g.ksteps - 1) / g.ksteps : 1;
+        hipLaunchKernelGGL((k_gemm<32, 32, 1>), dim3((g.N + 31) / 32, (g.M + 31) / 32, nz), dim3(256), 0, st, g);
     } else {
         const long t64 = (long)((g.M + 63) / 64) * ((g.N + 63) / 64), t6432 = (long)((g.M + 63) / 64) * ((g.N + 31) / 32);
         if (t64 >= 200)
@@ -572,24 +576,35 @@ int launch_gemv(const GemvArgs& a, hipStream_t st) {
     return PT_OK;
 }
 
-// qk[b][h][c] = sum_{j in head h} Wk[h*HD + j][c] * q[b][h*HD + j] / sqrt(HD): the key projection folded onto the query
-__global__ __launch_bounds__(256) void k_dec_qk(const float* Wk, const float* q, float* qk, int B, int D, int nhead,
-                                                float scale) {
-    const int idx = blockIdx.x * 256 + threadIdx.x;
-    if (idx >= nhead * D) return;
-    const int h = idx / D, c = idx - h * D, HD = D / nhead;
+// qk[b][h][c] = sum_{j in head h} Wk[h*HD + j][c] * q[b][h*HD + j] / sqrt(HD): the key projection folded onto the query.
+// grid nhead * D / 64; thread = (channel, quarter of the head's rows), quarters reduced through LDS in a fixed order
+__global__ __launch_bounds__(256) void k_dec_qk(const float* __restrict__ Wk, const float* __restrict__ q,
+                                                float* __restrict__ qk, int B, int D, int nhead, float scale) {
+    __shared__ float part[8][256];
+    const int tid = threadIdx.x, cl = tid & 63, jp = tid >> 6;
+    const int idx = blockIdx.x * 64 + cl, h = idx / D, c = idx - h * D, HD = D / nhead, jn = HD / 4;
     float acc[8];
 #pragma unroll
-    for (int b = 0; b < 8; ++b) acc[b] = 0.f;
-    for (int j = 0; j < HD; ++j) {
-        const float w = Wk[(long)(h * HD + j) * D + c];
+    for (int bb = 0; bb < 8; ++bb) acc[bb] = 0.f;
+    const float* w = Wk + (long)(h * HD + jp * jn) * D + c;
+    const float* qq = q + h * HD + jp * jn;
+#pragma unroll 4
+    for (int j = 0; j < jn; ++j) {
+        const float wv = w[(long)j * D];
 #pragma unroll
-        for (int b = 0; b < 8; ++b)
-            if (b < B) acc[b] += w * q[(long)b * D + h * HD + j];
+        for (int bb = 0; bb < 8; ++bb)
+            if (bb < B) acc[bb] += wv * qq[(long)bb * D + j];
     }
 #pragma unroll
-    for (int b = 0; b < 8; ++b)
-        if (b < B) qk[((long)b * nhead + h) * D + c] = acc[b] * scale;
+    for (int bb = 0; bb < 8; ++bb) part[bb][tid] = acc[bb];
+    __syncthreads();
+    if (jp == 0) {
+#pragma unroll
+        for (int bb = 0; bb < 8; ++bb)
+            if (bb < B)
+                qk[((long)bb * nhead + h) * D + c] =
+                    (part[bb][cl] + part[bb][cl + 64] + part[bb][cl + 128] + part[bb][cl + 192]) * scale;
+    }
 }
 
 struct DecAttnArgs {
@@ -599,52 +614,84 @@ struct DecAttnArgs {
     int mlo[8], mhi[8];
 };
 
-// scores[b][h][l] = qk[b][h] . (mem[b][l] + pos[l % HW]); one wavefront per 16 memory rows, all heads per row load
-__global__ __launch_bounds__(256) void k_dec_scores(DecAttnArgs a) {
-    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6, b = blockIdx.y;
-    const int per = a.D / 64;                                    // contiguous channels per lane (<= 8)
-    const int l0 = blockIdx.x * 64 + wave * 16;
-    for (int r = 0; r < 16; ++r) {
-        const int l = l0 + r;
-        if (l >= a.L) return;
-        float mp[8];
-        for (int i = 0; i < per; ++i)
-            mp[i] = a.mem[((long)b * a.L + l) * a.D + lane * per + i] + a.pos[(long)(l % a.HW) * a.D + lane * per + i];
-        const bool masked = l >= a.mlo[b] && l < a.mhi[b];
-        for (int h = 0; h < a.nhead; ++h) {
-            const float* q = a.qk + ((long)b * a.nhead + h) * a.D + lane * per;
-            float s = 0.f;
-            for (int i = 0; i < per; ++i) s += mp[i] * q[i];
-            s = wave_sum(s);
-            if (lane == 0) a.scores[((long)b * a.nhead + h) * a.L + l] = masked ? -INFINITY : s;
+// scores[b][h][l] = qk[b][h] . (mem[b][l] + pos[l % HW]) as a (16 rows x 16 heads) MFMA tile per wavefront:
+// A = 16 memory rows (+pos), B = the folded queries of the (<= 16) heads, K = channels
+__global__ __launch_bounds__(64) void k_dec_scores(DecAttnArgs a) {
+    const int lane = threadIdx.x, li = lane & 15, kq = lane >> 4, b = blockIdx.y, l0 = blockIdx.x * 16;
+    const int l = min(l0 + li, a.L - 1);
+    const __amdgpu_buffer_rsrc_t rm = pt_rsrc(a.mem, (unsigned)((long)a.B * a.L * a.D * 4));
+    const __amdgpu_buffer_rsrc_t rp = pt_rsrc(a.pos, (unsigned)((long)a.HW * a.D * 4));
+    const __amdgpu_buffer_rsrc_t rq = pt_rsrc(a.qk, (unsigned)((long)a.B * a.nhead * a.D * 4));
+    const unsigned om = (unsigned)((((long)b * a.L + l) * a.D + 4 * kq) * 4);
+    const unsigned op = (unsigned)(((long)(l % a.HW) * a.D + 4 * kq) * 4);
+    const unsigned oq = li < a.nhead ? (unsigned)((((long)b * a.nhead + li) * a.D + 4 * kq) * 4) : OOB;
+    f32x4 acc = f32x4{0.f, 0.f, 0.f, 0.f};
+    const int nks = a.D / 16;
+#pragma unroll 8
+    for (int ks = 0; ks < nks; ++ks) {
+        const f32x4 m = pt_bload4(rm, om + 64u * ks), pp = pt_bload4(rp, op + 64u * ks);
+        const f32x4 qv = pt_bload4(rq, oq == OOB ? OOB : oq + 64u * ks);
+#pragma unroll
+        for (int e = 0; e < 4; ++e) acc = mfma16(m[e] + pp[e], qv[e], acc);
+    }
+    if (li < a.nhead) {
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+            const int ll = l0 + 4 * kq + r;
+            if (ll < a.L)
+                a.scores[((long)b * a.nhead + li) * a.L + ll] = (ll >= a.mlo[b] && ll < a.mhi[b]) ? -INFINITY : acc[r];
         }
     }
 }
 
-// ctx[b][h][c] = sum_l softmax(scores[b][h])[l] * mem[b][l][c]; grid (D/64, B*nhead), 4 row partitions per workgroup
-__global__ __launch_bounds__(256) void k_dec_ctx(DecAttnArgs a) {
-    extern __shared__ float sm[];                                // L probabilities + 256 partials + 4 scratch
+// ctx[b][h][c] = sum_l softmax(scores[b][h])[l] * mem[b][l][c]: grid (D/16, B), 16 wavefronts.  Prologue: wavefront h
+// turns scores[b][h] into exp(s - max) in LDS and keeps 1/sum; then every wavefront contracts its share of the memory
+// rows on MFMA (A = probabilities of the <= 16 heads, B = 16 channels of 4 memory rows), partial tiles reduced in LDS
+__global__ __launch_bounds__(1024) void k_dec_ctx(DecAttnArgs a) {
+    extern __shared__ float sm[];                                // nhead * Lp probabilities, 16 inverse sums, 16 x 256 partials
+    const int Lp = (a.L + 3) & ~3;
     float* p = sm;
-    float* part = sm + a.L;
-    float* scratch = part + 256;
-    const int tid = threadIdx.x, bh = blockIdx.y, b = bh / a.nhead, c = blockIdx.x * 64 + (tid & 63), pr = tid >> 6;
-    const float* s = a.scores + (long)bh * a.L;
-    float mx = -INFINITY;
-    for (int l = tid; l < a.L; l += 256) mx = fmaxf(mx, s[l]);
-    mx = block_max(mx, scratch);
-    float sum = 0.f;
-    for (int l = tid; l < a.L; l += 256) {
-        const float e = __expf(s[l] - mx);
-        p[l] = e;
-        sum += e;
+    float* inv = sm + (size_t)a.nhead * Lp;
+    float* part = inv + 16;
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, li = lane & 15, kq = lane >> 4;
+    const int b = blockIdx.y, c0 = blockIdx.x * 16;
+    if (wave < a.nhead) {
+        const float* s = a.scores + ((long)b * a.nhead + wave) * a.L;
+        float mx = -INFINITY;
+        for (int l = lane; l < a.L; l += 64) mx = fmaxf(mx, s[l]);
+        mx = wave_max(mx);
+        float sum = 0.f;
+        for (int l = lane; l < Lp; l += 64) {
+            const float e = l < a.L ? __expf(s[l] - mx) : 0.f;
+            p[(size_t)wave * Lp + l] = e;
+            sum += e;
+        }
+        sum = wave_sum(sum);
+        if (lane == 0) inv[wave] = 1.f / sum;
     }
-    sum = block_sum(sum, scratch);
     __syncthreads();
-    float acc = 0.f;
-    for (int l = pr; l < a.L; l += 4) acc += p[l] * a.mem[((long)b * a.L + l) * a.D + c];
-    part[tid] = acc;
+    const __amdgpu_buffer_rsrc_t rm = pt_rsrc(a.mem, (unsigned)((long)a.B * a.L * a.D * 4));
+    const float hsel = li < a.nhead ? 1.f : 0.f;
+    const float* ph = p + (size_t)min(li, a.nhead - 1) * Lp;
+    f32x4 acc = f32x4{0.f, 0.f, 0.f, 0.f};
+    const int nks = Lp / 4;
+#pragma unroll 4
+    for (int ks = wave; ks < nks; ks += 16) {
+        const int l = 4 * ks + kq;
+        const float mv = pt_bload1(rm, l < a.L ? (unsigned)((((long)b * a.L + l) * a.D + c0 + li) * 4) : OOB);
+        acc = mfma16(ph[l] * hsel, mv, acc);
+    }
+#pragma unroll
+    for (int r = 0; r < 4; ++r) part[wave * 256 + (4 * kq + r) * 16 + li] = acc[r];
     __syncthreads();
-    if (pr == 0) a.ctx[(long)bh * a.D + c] = (part[tid] + part[tid + 64] + part[tid + 128] + part[tid + 192]) / sum;
+    if (tid < 256) {
+        const int h = tid >> 4, c = tid & 15;
+        if (h < a.nhead) {
+            float t = 0.f;
+            for (int w = 0; w < 16; ++w) t += part[w * 256 + tid];
+            a.ctx[((long)b * a.nhead + h) * a.D + c0 + c] = t * inv[h];
+        }
+    }
 }
 
 // ------------------------------------------------------------------------------------------------------------------
@@ -679,21 +726,72 @@ __global__ __launch_bounds__(256) void k_reg_attend(const float* feat, const flo
     }
 }
 
-// GroupNorm(1, C) + ReLU over one image's (HW, C) token-major block, in place; one workgroup per image
-__global__ __launch_bounds__(1024) void k_groupnorm_relu(float* X, const float* gam, const float* bet, int D, int HW) {
-    __shared__ float scratch[16];
-    float* x = X + (long)blockIdx.x * D * HW;
-    const int n = D * HW;
-    float s = 0.f;
-    for (int i = threadIdx.x; i < n; i += 1024) s += x[i];
-    const float mean = block_sum(s, scratch) / n;
-    float q = 0.f;
-    for (int i = threadIdx.x; i < n; i += 1024) q += (x[i] - mean) * (x[i] - mean);
-    const float rstd = rsqrtf(block_sum(q, scratch) / n + 1e-5f);
-    for (int i = threadIdx.x; i < n; i += 1024) {
-        const int c = i % D;
-        x[i] = fmaxf((x[i] - mean) * rstd * gam[c] + bet[c], 0.f);
+// GroupNorm(1, C) + ReLU of the regression tower, fed by the split-K partial products of the 3x3 convolution:
+//   k_gn_reduce: x = sum_z part[z] (fixed order), written once, + per-slice (sum, sum of squares) of one image
+//   k_gn_apply:  mean / variance from the slice sums (double, fixed order), normalise + affine + ReLU in place
+// grid (slices of 4096 elements, images); token-major (HW, C) blocks
+constexpr int GN_SLICE = 4096;
+
+__global__ __launch_bounds__(256) void k_gn_reduce(const float* __restrict__ part, int nz, long zstride,
+                                                   float* __restrict__ x, float* __restrict__ stats, int n_per_img) {
+    __shared__ float scratch[4];
+    const int img = blockIdx.y, i0 = blockIdx.x * GN_SLICE;
+    const long base = (long)img * n_per_img;
+    float s = 0.f, q = 0.f;
+#pragma unroll
+    for (int u = 0; u < GN_SLICE / 1024; ++u) {
+        const int i = i0 + (u * 256 + threadIdx.x) * 4;
+        if (i < n_per_img) {
+            f32x4 v = *reinterpret_cast<const f32x4*>(part + base + i);
+            for (int z = 1; z < nz; ++z) v += *reinterpret_cast<const f32x4*>(part + z * zstride + base + i);
+            *reinterpret_cast<f32x4*>(x + base + i) = v;
+            s += (v[0] + v[1]) + (v[2] + v[3]);
+            q += (v[0] * v[0] + v[1] * v[1]) + (v[2] * v[2] + v[3] * v[3]);
+        }
     }
+    s = block_sum(s, scratch);
+    q = block_sum(q, scratch);
+    if (threadIdx.x == 0) {
+        stats[((long)img * gridDim.x + blockIdx.x) * 2] = s;
+        stats[((long)img * gridDim.x + blockIdx.x) * 2 + 1] = q;
+    }
+}
+
+__global__ __launch_bounds__(256) void k_gn_apply(float* __restrict__ x, const float* __restrict__ stats,
+                                                  const float* __restrict__ gam, const float* __restrict__ bet, int D,
+                                                  int n_per_img) {
+    const int img = blockIdx.y, i0 = blockIdx.x * GN_SLICE;
+    double s = 0.0, q = 0.0;
+    for (unsigned k = 0; k < gridDim.x; ++k) {
+        s += (double)stats[((long)img * gridDim.x + k) * 2];
+        q += (double)stats[((long)img * gridDim.x + k) * 2 + 1];
+    }
+    const double mean_d = s / n_per_img;
+    const float mean = (float)mean_d, rstd = (float)(1.0 / sqrt(fmax(q / n_per_img - mean_d * mean_d, 0.0) + 1e-5));
+    const long base = (long)img * n_per_img;
+#pragma unroll
+    for (int u = 0; u < GN_SLICE / 1024; ++u) {
+        const int i = i0 + (u * 256 + threadIdx.x) * 4;
+        if (i < n_per_img) {
+            const int c = i % D;
+            f32x4 v = *reinterpret_cast<const f32x4*>(x + base + i);
+            const f32x4 g4 = *reinterpret_cast<const f32x4*>(gam + c), b4 = *reinterpret_cast<const f32x4*>(bet + c);
+#pragma unroll
+            for (int e = 0; e < 4; ++e) v[e] = fmaxf((v[e] - mean) * rstd * g4[e] + b4[e], 0.f);
+            *reinterpret_cast<f32x4*>(x + base + i) = v;
+        }
+    }
+}
+
+// ltrb[img][n][p] = exp(sum_z part[z][img*HW + p][n]) (heads.py:134)
+__global__ __launch_bounds__(256) void k_reg_finish(const float* __restrict__ part, int nz, long zstride,
+                                                    float* __restrict__ out, int M, int HW) {
+    const int idx = blockIdx.x * 256 + threadIdx.x;
+    if (idx >= M * 4) return;
+    float v = part[idx];
+    for (int z = 1; z < nz; ++z) v += part[z * zstride + idx];
+    const int row = idx >> 2, n = idx & 3, img = row / HW;
+    out[((long)img * 4 + n) * HW + (row - img * HW)] = expf(v);
 }
 
 // ------------------------------------------------------------------------------------------------------------------
@@ -746,7 +844,7 @@ int dims_check(const pt_tomp_dims* d) {
     if (d->d_model % d->nhead != 0) return PT_ERR_SHAPE;
     const int hd = d->d_model / d->nhead;
     if ((hd != 16 && hd != 32 && hd != 64) || d->d_model % 128 != 0 || d->d_model > 512 || d->dim_ff % 64 != 0 ||
-        d->n_enc > 16 || d->n_dec > 16)
+        d->n_enc > 16 || d->n_dec > 16 || d->nhead > 16)
         return PT_ERR_UNSUPPORTED;
     return PT_OK;
 }
@@ -796,7 +894,7 @@ extern "C" size_t pt_tomp_predict_ws_bytes(const pt_tomp_dims* d, int n_train, i
     if (dims_check(d) || n_train <= 0 || n_seq <= 0) return 0;
     const int B = parallel ? 2 : n_seq;
     if (B > 8 || (parallel && n_seq != 1)) return 0;
-    if ((size_t)(n_train + 1) * d->H * d->W > 8192) return 0;
+    if ((size_t)d->nhead * ((size_t)(n_train + 1) * d->H * d->W + 4) > 11000) return 0;   // LDS of k_dec_ctx
     return ws_carve(d, B, n_train).total * sizeof(float);
 }
 
@@ -822,7 +920,7 @@ extern "C" int pt_tomp_predict_f32(const pt_tomp_dims* d, const float* params, c
     if (B > 8 || (parallel && n_seq != 1)) return PT_ERR_UNSUPPORTED;
     const int D = d->d_model, ff = d->dim_ff, NH = d->nhead, HD = D / NH, HW = d->H * d->W, Ltr = n_train * HW,
               L = Ltr + HW, rows = B * L, D4 = D / 4;
-    if (L > 8192) return PT_ERR_UNSUPPORTED;
+    if ((size_t)NH * (L + 4) > 11000) return PT_ERR_UNSUPPORTED;
     const WsCarve cv = ws_carve(d, B, n_train);
     if (ws_bytes < cv.total * sizeof(float) || ((uintptr_t)ws % 256) != 0) return PT_ERR_WORKSPACE;
     hipStream_t st = (hipStream_t)stream;
@@ -908,12 +1006,13 @@ extern "C" int pt_tomp_predict_f32(const pt_tomp_dims* d, const float* params, c
         v.Wt = P + dc.ca.w_in; v.bias = P + dc.ca.b_in; v.N = D; v.K = D; v.x = Pa; v.x_rows_per_b = 1;
         v.xg = P + dc.n1g; v.xb = P + dc.n1b; v.xadd = qpos; v.B = B; v.out = base + cv.q;   // one query_pos row for all b
         if ((rc = launch_gemv(v, st))) return rc;
-        hipLaunchKernelGGL(k_dec_qk, dim3((NH * D + 255) / 256), dim3(256), 0, st, P + dc.ca.w_in + (size_t)D * D,
+        hipLaunchKernelGGL(k_dec_qk, dim3(NH * D / 64), dim3(256), 0, st, P + dc.ca.w_in + (size_t)D * D,
                            base + cv.q, base + cv.qk, B, D, NH, at.scale);
         PT_CHECK_LAUNCH();
-        hipLaunchKernelGGL(k_dec_scores, dim3((L + 63) / 64, B), dim3(256), 0, st, da);
+        hipLaunchKernelGGL(k_dec_scores, dim3((L + 15) / 16, B), dim3(64), 0, st, da);
         PT_CHECK_LAUNCH();
-        hipLaunchKernelGGL(k_dec_ctx, dim3(D / 64, B * NH), dim3(256), (size_t)(L + 256 + 8) * sizeof(float), st, da);
+        hipLaunchKernelGGL(k_dec_ctx, dim3(D / 16, B), dim3(1024),
+                           ((size_t)NH * ((L + 3) & ~3) + 16 + 16 * 256) * sizeof(float), st, da);
         PT_CHECK_LAUNCH();
         // value projection per head on the attention-weighted memory, then out_proj + residual LN1(Pa)
         v = GemvArgs{};
@@ -970,9 +1069,24 @@ extern "C" size_t pt_tomp_bbreg_param_floats(int d_model) {
     return d_model > 0 && d_model % 32 == 0 ? reg_layout(d_model).total : 0;
 }
 
+namespace {
+struct RegCarve { size_t fproj, T0, T1, part, stats, total; int slices; };
+RegCarve reg_carve(int n, int D, int H, int W) {
+    RegCarve c{};
+    const size_t M = (size_t)n * H * W;
+    size_t o = 0;
+    auto take = [&](size_t k) { size_t r = o; o += pt_align_floats(k); return r; };
+    c.slices = (int)(((size_t)H * W * D + GN_SLICE - 1) / GN_SLICE);
+    c.fproj = take(D); c.T0 = take(M * D); c.T1 = take(M * D); c.part = take(9 * M * D);
+    c.stats = take((size_t)2 * n * c.slices);
+    c.total = o;
+    return c;
+}
+}  // namespace
+
 extern "C" size_t pt_tomp_bbreg_ws_bytes(int n, int d_model, int H, int W) {
     if (n <= 0 || d_model <= 0 || d_model % 64 != 0 || d_model > 512 || H <= 0 || W <= 0) return 0;
-    return (pt_align_floats(d_model) + 2 * pt_align_floats((size_t)n * H * W * d_model)) * sizeof(float);
+    return reg_carve(n, d_model, H, W).total * sizeof(float);
 }
 
 extern "C" int pt_tomp_bbreg_f32(const float* params, const float* feat, const float* filter, float* ltrb, int n,
@@ -980,31 +1094,38 @@ extern "C" int pt_tomp_bbreg_f32(const float* params, const float* feat, const f
     if (!params || !feat || !filter || !ltrb || !ws) return PT_ERR_NULL;
     if (n <= 0 || d_model <= 0 || H <= 0 || W <= 0) return PT_ERR_SHAPE;
     if (d_model % 64 != 0 || d_model > 512) return PT_ERR_UNSUPPORTED;
-    const size_t need = pt_tomp_bbreg_ws_bytes(n, d_model, H, W);
-    if (ws_bytes < need || ((uintptr_t)ws % 256) != 0) return PT_ERR_WORKSPACE;
-    hipStream_t st = (hipStream_t)stream;
     const int D = d_model, HW = H * W, M = n * HW;
+    const RegCarve cv = reg_carve(n, D, H, W);
+    if (ws_bytes < cv.total * sizeof(float) || ((uintptr_t)ws % 256) != 0) return PT_ERR_WORKSPACE;
+    hipStream_t st = (hipStream_t)stream;
     const RegOff ro = reg_layout(D);
-    float* fproj = (float*)ws;
-    float* T0 = fproj + pt_align_floats(D);
-    float* T1 = T0 + pt_align_floats((size_t)M * D);
+    float* base = (float*)ws;
+    float *fproj = base + cv.fproj, *part = base + cv.part, *stats = base + cv.stats;
     GemvArgs v{};
     v.Wt = params + ro.lw; v.bias = params + ro.lb; v.N = D; v.K = D; v.x = filter; v.x_rows_per_b = 1; v.B = 1; v.out = fproj;
     int rc = launch_gemv(v, st);
     if (rc) return rc;
     hipLaunchKernelGGL(k_reg_attend, dim3((HW + 31) / 32, n), dim3(256), ((size_t)D * 33 + 32) * sizeof(float), st, feat,
-                       fproj, T0, D, HW);
+                       fproj, base + cv.T0, D, HW);
     PT_CHECK_LAUNCH();
-    float *src = T0, *dst = T1;
+    // each 3x3 convolution = 9 per-tap partial GEMMs (one K-slice of Cin per tap) reduced by the GroupNorm statistics pass
+    float *src = base + cv.T0, *dst = base + cv.T1;
+    const long zs = (long)M * D;
     for (int i = 0; i < 4; ++i) {
-        GemmArgs g = gemm_args(src, D, M, params + ro.cw[i], M, D, 9 * D, params + ro.cb[i], dst, D);
-        g.H = H; g.Wd = W; g.Cin = D; g.HW = HW;
+        GemmArgs g = gemm_args(src, D, M, params + ro.cw[i], M, D, 9 * D, params + ro.cb[i], part, D);
+        g.H = H; g.Wd = W; g.Cin = D; g.HW = HW; g.ksteps = D / 32; g.c_zstride = zs;
         if ((rc = launch_gemm(g, st, true))) return rc;
-        hipLaunchKernelGGL(k_groupnorm_relu, dim3(n), dim3(1024), 0, st, dst, params + ro.gg[i], params + ro.gb[i], D, HW);
+        hipLaunchKernelGGL(k_gn_reduce, dim3(cv.slices, n), dim3(256), 0, st, part, 9, zs, dst, stats, HW * D);
+        PT_CHECK_LAUNCH();
+        hipLaunchKernelGGL(k_gn_apply, dim3(cv.slices, n), dim3(256), 0, st, dst, stats, params + ro.gg[i],
+                           params + ro.gb[i], D, HW * D);
         PT_CHECK_LAUNCH();
         std::swap(src, dst);
     }
-    GemmArgs g = gemm_args(src, D, M, params + ro.fw, M, 4, 9 * D, params + ro.fb, ltrb, 4);
-    g.H = H; g.Wd = W; g.Cin = D; g.HW = HW; g.expo = 1; g.nchw = 1;
-    return launch_gemm(g, st, true);
+    GemmArgs g = gemm_args(src, D, M, params + ro.fw, M, 4, 9 * D, params + ro.fb, part, 4);
+    g.H = H; g.Wd = W; g.Cin = D; g.HW = HW; g.ksteps = D / 32; g.c_zstride = (long)M * 4;
+    if ((rc = launch_gemm(g, st, true))) return rc;
+    hipLaunchKernelGGL(k_reg_finish, dim3((M * 4 + 255) / 256), dim3(256), 0, st, part, 9, (long)M * 4, ltrb, M, HW);
+    PT_CHECK_LAUNCH();
+    return PT_OK;
 }
