@@ -24,6 +24,7 @@
 
 #include <algorithm>
 #include <math.h>
+#include <stdlib.h>
 #include <stdint.h>
 
 namespace {
@@ -83,15 +84,21 @@ __global__ __launch_bounds__(256) void k_gemm(GemmArgs g) {
         woff[i] = n < g.N ? (unsigned)(((long)n * g.K + lc4) * 4) : OOB;
     }
 
-    f32x4 ra[AL], rp[AL], rb[BL];
-    auto fetch = [&](int kb) {
+    // register ring: K-step k+PD is requested from memory while step k is on the matrix cores (one step of cover is
+    // ~0.2 us of MFMA work against ~0.7 us of L2/fabric latency); LDS is double-buffered one step ahead
+    constexpr int PD = 4;
+    f32x4 ra[PD][AL], rp[PD][AL], rb[PD][BL];
+    // `live` = false turns every request into an out-of-range one (returns zeros, touches nothing): the loads are issued
+    // unconditionally so that the compiler's s_waitcnt vmcnt bookkeeping stays exact -- a fetch inside a branch makes it
+    // wait for ALL outstanding loads before the next LDS store, which collapses the ring to depth 1
+    auto fetch = [&](int kb, int sl, bool live) {
         const unsigned kbytes = (unsigned)kb * 128u;
         if (MODE == 0) {
 #pragma unroll
-            for (int i = 0; i < AL; ++i) ra[i] = pt_bload4(rsA, aoff[i] == OOB ? OOB : aoff[i] + kbytes);
+            for (int i = 0; i < AL; ++i) ra[sl][i] = pt_bload4(rsA, (aoff[i] == OOB || !live) ? OOB : aoff[i] + kbytes);
             if (addpos) {
 #pragma unroll
-                for (int i = 0; i < AL; ++i) rp[i] = pt_bload4(rsP, poff[i] == OOB ? OOB : poff[i] + kbytes);
+                for (int i = 0; i < AL; ++i) rp[sl][i] = pt_bload4(rsP, (poff[i] == OOB || !live) ? OOB : poff[i] + kbytes);
             }
         } else {
             const int k0 = kb * 32, tap = k0 / g.Cin, c0 = k0 - tap * g.Cin;
@@ -99,22 +106,22 @@ __global__ __launch_bounds__(256) void k_gemm(GemmArgs g) {
 #pragma unroll
             for (int i = 0; i < AL; ++i) {
                 const int y = py[i] + dy, x = px[i] + dx;
-                const bool in = y >= 0 && y < g.H && x >= 0 && x < g.Wd;
-                ra[i] = pt_bload4(rsA, in ? aoff[i] + (unsigned)(((long)(y * g.Wd + x) * g.lda + c0) * 4) : OOB);
+                const bool in = live && y >= 0 && y < g.H && x >= 0 && x < g.Wd;
+                ra[sl][i] = pt_bload4(rsA, in ? aoff[i] + (unsigned)(((long)(y * g.Wd + x) * g.lda + c0) * 4) : OOB);
             }
         }
 #pragma unroll
-        for (int i = 0; i < BL; ++i) rb[i] = pt_bload4(rsW, woff[i] == OOB ? OOB : woff[i] + kbytes);
+        for (int i = 0; i < BL; ++i) rb[sl][i] = pt_bload4(rsW, (woff[i] == OOB || !live) ? OOB : woff[i] + kbytes);
     };
-    auto stash = [&](int buf) {
+    auto stash = [&](int sl, int buf) {
 #pragma unroll
         for (int i = 0; i < AL; ++i) {
-            f32x4 v = ra[i];
-            if (addpos) v += rp[i];
+            f32x4 v = ra[sl][i];
+            if (addpos) v += rp[sl][i];
             *reinterpret_cast<f32x4*>(&As[buf][(lrow + 32 * i) * LS + lc4]) = v;
         }
 #pragma unroll
-        for (int i = 0; i < BL; ++i) *reinterpret_cast<f32x4*>(&Bs[buf][(lrow + 32 * i) * LS + lc4]) = rb[i];
+        for (int i = 0; i < BL; ++i) *reinterpret_cast<f32x4*>(&Bs[buf][(lrow + 32 * i) * LS + lc4]) = rb[sl][i];
     };
 
     f32x4 acc[MT][NT];
@@ -123,45 +130,61 @@ __global__ __launch_bounds__(256) void k_gemm(GemmArgs g) {
 #pragma unroll
         for (int b = 0; b < NT; ++b) acc[a][b] = f32x4{0.f, 0.f, 0.f, 0.f};
 
+    // LDS fragment reads without bank conflicts.  ds_read_b128 is serviced in four groups of 16 lanes over 64 banks,
+    // and the groups are not lane-contiguous: {0-3,12-15,20-27}, {4-11,16-19,28-31} and the same +32, i.e. every group
+    // mixes two k-slots (lane >> 4).  With a row stride of 36 words the 16-byte bank group of lane (i, kq) is
+    // (9 * row(i) + quad(kq)) mod 16; it is a permutation inside every hardware group when MFMA row i is tile row
+    // prow(i) (even rows for i in 4..11, odd rows otherwise) and k-slot kq reads k-quad {0,2,1,3}[kq].  Both operands use
+    // the same maps, so the k pairing is intact and the row / column permutation is undone in the epilogue.
+    auto prow = [](int i) { return (i >= 4 && i < 12) ? 2 * (i - 4) : (i < 4 ? 2 * i + 1 : 2 * i - 15); };
+    const int qoff = ((lane >> 4) & 1) * 2 + (lane >> 5);
+
     const int kb0 = g.ksteps ? blockIdx.z * g.ksteps : 0;
     const int nk = g.ksteps ? min(g.K / 32, kb0 + g.ksteps) : g.K / 32;
-    fetch(kb0);
-    stash(kb0 & 1);
+#pragma unroll
+    for (int sl = 0; sl < PD; ++sl) fetch(kb0 + sl, sl, kb0 + sl < nk);
+    stash(0, 0);
     __syncthreads();
-    for (int kb = kb0; kb < nk; ++kb) {
-        const int buf = kb & 1;
-        if (kb + 1 < nk) fetch(kb + 1);
-        const float* as = &As[buf][(wm * WM + (lane & 15)) * LS + (lane >> 4) * 4];
-        const float* bs = &Bs[buf][(wn * WN + (lane & 15)) * LS + (lane >> 4) * 4];
+    for (int t0 = kb0; t0 < nk; t0 += PD) {
 #pragma unroll
-        for (int hh = 0; hh < 2; ++hh) {
-            f32x4 a[MT], b[NT];
+        for (int u = 0; u < PD; ++u) {
+            const int kb = t0 + u;
+            const int buf = u & 1;
+            fetch(kb + PD, u, kb + PD < nk);                             // slot u (step kb) already sits in LDS[buf]
+            if (kb < nk) {                                               // workgroup-uniform; LDS reads + MFMA only
+                const float* as = &As[buf][(wm * WM + prow(lane & 15)) * LS + qoff * 4];
+                const float* bs = &Bs[buf][(wn * WN + prow(lane & 15)) * LS + qoff * 4];
 #pragma unroll
-            for (int mt = 0; mt < MT; ++mt) a[mt] = *reinterpret_cast<const f32x4*>(as + mt * 16 * LS + hh * 16);
+                for (int hh = 0; hh < 2; ++hh) {
+                    f32x4 a[MT], b[NT];
 #pragma unroll
-            for (int nt = 0; nt < NT; ++nt) b[nt] = *reinterpret_cast<const f32x4*>(bs + nt * 16 * LS + hh * 16);
+                    for (int mt = 0; mt < MT; ++mt) a[mt] = *reinterpret_cast<const f32x4*>(as + mt * 16 * LS + hh * 16);
 #pragma unroll
-            for (int j = 0; j < 4; ++j)
+                    for (int nt = 0; nt < NT; ++nt) b[nt] = *reinterpret_cast<const f32x4*>(bs + nt * 16 * LS + hh * 16);
 #pragma unroll
-                for (int mt = 0; mt < MT; ++mt)
+                    for (int j = 0; j < 4; ++j)
 #pragma unroll
-                    for (int nt = 0; nt < NT; ++nt) acc[mt][nt] = mfma16(a[mt][j], b[nt][j], acc[mt][nt]);
+                        for (int mt = 0; mt < MT; ++mt)
+#pragma unroll
+                            for (int nt = 0; nt < NT; ++nt) acc[mt][nt] = mfma16(a[mt][j], b[nt][j], acc[mt][nt]);
+                }
+            }
+            stash((u + 1) % PD, buf ^ 1);                               // step kb+1 (zeros past the end: never read)
+            __syncthreads();
         }
-        if (kb + 1 < nk) stash(buf ^ 1);
-        __syncthreads();
     }
 
 #pragma unroll
     for (int mt = 0; mt < MT; ++mt)
 #pragma unroll
         for (int nt = 0; nt < NT; ++nt) {
-            const int col = n0 + wn * WN + nt * 16 + (lane & 15);
+            const int col = n0 + wn * WN + nt * 16 + prow(lane & 15);
             if (col >= g.N) continue;
             const float bv = (g.bias && blockIdx.z == 0) ? g.bias[col] : 0.f;
             const float sc = g.scale ? g.scale[col] : 1.f, sh = g.scale ? g.shift[col] : 0.f;
 #pragma unroll
             for (int r = 0; r < 4; ++r) {
-                const int row = m0 + wm * WM + mt * 16 + 4 * (lane >> 4) + r;
+                const int row = m0 + wm * WM + mt * 16 + prow(4 * (lane >> 4) + r);
                 if (row >= g.M) continue;
                 float v = (acc[mt][nt][r] + bv) * sc + sh;
                 if (g.relu) v = fmaxf(v, 0.f);
@@ -198,9 +221,10 @@ int launch_gemm(const GemmArgs& g, hipStream_t st, bool conv = false) {
         hipLaunchKernelGGL((k_gemm<32, 32, 1>), dim3((g.N + 31) / 32, (g.M + 31) / 32, nz), dim3(256), 0, st, g);
     } else {
         const long t64 = (long)((g.M + 63) / 64) * ((g.N + 63) / 64), t6432 = (long)((g.M + 63) / 64) * ((g.N + 31) / 32);
-        if (t64 >= 200)
+        static const long T = getenv("PT_TOMP_T") ? atol(getenv("PT_TOMP_T")) : 200;
+        if (t64 >= T)
             hipLaunchKernelGGL((k_gemm<64, 64, 0>), dim3((g.N + 63) / 64, (g.M + 63) / 64), dim3(256), 0, st, g);
-        else if (t6432 >= 200)
+        else if (t6432 >= T)
             hipLaunchKernelGGL((k_gemm<64, 32, 0>), dim3((g.N + 31) / 32, (g.M + 63) / 64), dim3(256), 0, st, g);
         else
             hipLaunchKernelGGL((k_gemm<32, 32, 0>), dim3((g.N + 31) / 32, (g.M + 31) / 32), dim3(256), 0, st, g);
@@ -220,13 +244,21 @@ struct AttnArgs {
     int mlo[8], mhi[8];                         // keys [mlo[b], mhi[b]) of batch row b are padding (never attended)
 };
 
+// Workgroup = 64 queries x 2 key halves: wavefronts 0-3 own the even 64-key chunks, 4-7 the odd ones (two wavefronts per
+// SIMD, so one half's softmax / LDS waits hide behind the other's MFMAs -- B*nhead*L/16 query tiles alone are only one
+// wavefront per SIMD); the halves' (max, sum, O^T) are merged through LDS at the end.
 template <int HD>
-__global__ __launch_bounds__(256) void k_attn(AttnArgs a) {
+__global__ __launch_bounds__(512) void k_attn(AttnArgs a) {
     constexpr int KS = HD + 4, NV = HD / 4, NF4 = HD / 16, DT = HD / 16;   // NV floats of q/k per lane, NF4 float4s
-    __shared__ __attribute__((aligned(16))) float Ks[2][64 * KS];
-    __shared__ __attribute__((aligned(16))) float Vs[2][64 * KS];
+    // LDS strides: K rows 4 mod 64 words, V rows 16 mod 32 words; together with the key permutation prow() below they
+    // make the ds_read_b128 K fragments and the ds_read_b32 V operands bank-conflict free (see k_gemm for the lane
+    // groups of ds_read_b128)
+    constexpr int VS = HD <= 48 ? 48 : 80;
+    __shared__ __attribute__((aligned(16))) float Ks[128 * KS];
+    __shared__ __attribute__((aligned(16))) float Vs[128 * VS];
+    auto prow = [](int i) { return (i >= 4 && i < 12) ? 2 * (i - 4) : (i < 4 ? 2 * i + 1 : 2 * i - 15); };
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, li = lane & 15, kq = lane >> 4;
-    const int h = blockIdx.y, b = blockIdx.z, q0 = blockIdx.x * 64 + wave * 16;
+    const int half = wave >> 2, h = blockIdx.y, b = blockIdx.z, q0 = blockIdx.x * 64 + (wave & 3) * 16;
     const int ld = 3 * a.D;
     const __amdgpu_buffer_rsrc_t rs = pt_rsrc(a.qkv, a.qkv_bytes);
     const long rowbase = (long)b * a.L;
@@ -244,25 +276,25 @@ __global__ __launch_bounds__(256) void k_attn(AttnArgs a) {
             for (int e = 0; e < 4; ++e) qf[4 * v + e] = t[e] * a.scale;
         }
     }
-    // cooperative K / V chunk loads: 64 keys x HD floats each = 64*HD/4 float4 per operand
-    constexpr int LPT = (64 * HD / 4) / 256;                      // float4 per thread per operand
+    // cooperative K / V loads of 128 keys (one chunk per half) per iteration
+    constexpr int LPT = (128 * HD / 4) / 512;                     // float4 per thread per operand
     constexpr int F4R = HD / 4;                                   // float4 per row
     f32x4 rk[LPT], rv[LPT];
     auto fetch = [&](int c0) {
 #pragma unroll
         for (int i = 0; i < LPT; ++i) {
-            const int idx = tid + 256 * i, r = idx / F4R, c4 = (idx - r * F4R) * 4, key = c0 + r;
+            const int idx = tid + 512 * i, r = idx / F4R, c4 = (idx - r * F4R) * 4, key = c0 + r;
             const unsigned off = key < a.L ? (unsigned)(((rowbase + key) * ld + a.D + h * HD + c4) * 4) : OOB;
             rk[i] = pt_bload4(rs, off);
             rv[i] = pt_bload4(rs, off == OOB ? OOB : off + (unsigned)a.D * 4u);
         }
     };
-    auto stash = [&](int buf) {
+    auto stash = [&]() {
 #pragma unroll
         for (int i = 0; i < LPT; ++i) {
-            const int idx = tid + 256 * i, r = idx / F4R, c4 = (idx - r * F4R) * 4;
-            *reinterpret_cast<f32x4*>(&Ks[buf][r * KS + c4]) = rk[i];
-            *reinterpret_cast<f32x4*>(&Vs[buf][r * KS + c4]) = rv[i];
+            const int idx = tid + 512 * i, r = idx / F4R, c4 = (idx - r * F4R) * 4;
+            *reinterpret_cast<f32x4*>(&Ks[r * KS + c4]) = rk[i];
+            *reinterpret_cast<f32x4*>(&Vs[r * VS + c4]) = rv[i];
         }
     };
 
@@ -271,33 +303,36 @@ __global__ __launch_bounds__(256) void k_attn(AttnArgs a) {
     for (int d = 0; d < DT; ++d) ot[d] = f32x4{0.f, 0.f, 0.f, 0.f};
     float m_run = -INFINITY, l_run = 0.f;
 
-    const int nchunk = (a.L + 63) / 64;
+    const int nit = (a.L + 127) / 128;
     fetch(0);
-    stash(0);
-    __syncthreads();
-    for (int ch = 0; ch < nchunk; ++ch) {
-        const int buf = ch & 1, c0 = ch * 64;
-        if (ch + 1 < nchunk) fetch(c0 + 64);
+    for (int it = 0; it < nit; ++it) {
+        __syncthreads();                                          // previous iteration's LDS reads are done
+        stash();
+        __syncthreads();
+        if (it + 1 < nit) fetch((it + 1) * 128);
+        const int c0 = it * 128 + half * 64;
+        const float* Kh = Ks + half * 64 * KS;
+        const float* Vh = Vs + half * 64 * VS;
         // ---- S^T tiles: rows = keys, cols = queries
         f32x4 st[4];
         float mc = -INFINITY;
 #pragma unroll
         for (int kt = 0; kt < 4; ++kt) {
-            f32x4 s = f32x4{0.f, 0.f, 0.f, 0.f};
-            const float* kp = &Ks[buf][(kt * 16 + li) * KS + kq * NV];
+            f32x4 sc = f32x4{0.f, 0.f, 0.f, 0.f};
+            const float* kp = Kh + (kt * 16 + prow(li)) * KS + kq * NV;   // S^T row i of the tile <-> key prow(i)
 #pragma unroll
             for (int v = 0; v < NF4; ++v) {
                 const f32x4 kk = *reinterpret_cast<const f32x4*>(kp + 4 * v);
 #pragma unroll
-                for (int e = 0; e < 4; ++e) s = mfma16(kk[e], qf[4 * v + e], s);
+                for (int e = 0; e < 4; ++e) sc = mfma16(kk[e], qf[4 * v + e], sc);
             }
 #pragma unroll
             for (int r = 0; r < 4; ++r) {
-                const int key = c0 + kt * 16 + 4 * kq + r;
-                if (key >= a.L || (key >= mlo && key < mhi)) s[r] = -INFINITY;
-                mc = fmaxf(mc, s[r]);
+                const int key = c0 + kt * 16 + prow(4 * kq + r);
+                if (key >= a.L || (key >= mlo && key < mhi)) sc[r] = -INFINITY;
+                mc = fmaxf(mc, sc[r]);
             }
-            st[kt] = s;
+            st[kt] = sc;
         }
         mc = fmaxf(mc, __shfl_xor(mc, 16, 64));
         mc = fmaxf(mc, __shfl_xor(mc, 32, 64));
@@ -309,30 +344,47 @@ __global__ __launch_bounds__(256) void k_attn(AttnArgs a) {
         for (int d = 0; d < DT; ++d) ot[d] *= alpha;
         m_run = m_new;
         // ---- P^T = exp(S^T - m) feeds the PV product straight from the accumulator registers:
-        //      O^T[d][query] += sum_key V[key][d] * P^T[key][query]; k-slot kq of MFMA r <-> key 4*kq + r of the tile
+        //      O^T[d][query] += sum_key V[key][d] * P^T[key][query]; k-slot kq of MFMA r <-> key prow(4*kq + r) of the tile
 #pragma unroll
         for (int kt = 0; kt < 4; ++kt) {
 #pragma unroll
             for (int r = 0; r < 4; ++r) {
-                const float p = __expf(st[kt][r] - m_use);
-                l_run += p;
-                const float* vp = &Vs[buf][(kt * 16 + 4 * kq + r) * KS + li];
+                const float pe = __expf(st[kt][r] - m_use);
+                l_run += pe;
+                const float* vp = Vh + (kt * 16 + prow(4 * kq + r)) * VS + li;
 #pragma unroll
-                for (int d = 0; d < DT; ++d) ot[d] = mfma16(vp[16 * d], p, ot[d]);
+                for (int d = 0; d < DT; ++d) ot[d] = mfma16(vp[16 * d], pe, ot[d]);
             }
         }
-        if (ch + 1 < nchunk) stash(buf ^ 1);
-        __syncthreads();
     }
     l_run += __shfl_xor(l_run, 16, 64);
     l_run += __shfl_xor(l_run, 32, 64);
-    const float inv = 1.f / l_run;
-    const int q = q0 + li;
-    if (q < a.L) {
+    // ---- merge the two key halves (the exchange area aliases the K staging buffer)
+    __syncthreads();
+    float* xch = Ks + ((wave & 3) * 64 + lane) * (4 * DT + 2);
+    if (half == 1) {
+        xch[0] = m_run;
+        xch[1] = l_run;
 #pragma unroll
-        for (int d = 0; d < DT; ++d) {
-            f32x4 o = ot[d] * inv;                                 // rows d*16 + 4*kq + r of O^T = 4 consecutive channels
-            *reinterpret_cast<f32x4*>(&a.out[(rowbase + q) * a.D + h * HD + d * 16 + 4 * kq]) = o;
+        for (int d = 0; d < DT; ++d)
+#pragma unroll
+            for (int r = 0; r < 4; ++r) xch[2 + 4 * d + r] = ot[d][r];
+    }
+    __syncthreads();
+    if (half == 0) {
+        const float m1 = xch[0], l1 = xch[1];
+        const float m = fmaxf(m_run, m1);
+        const float a0 = __expf(m_run - m), a1 = m1 == -INFINITY ? 0.f : __expf(m1 - m);
+        const float inv = 1.f / (l_run * a0 + l1 * a1);
+        const int q = q0 + li;
+        if (q < a.L) {
+#pragma unroll
+            for (int d = 0; d < DT; ++d) {
+                f32x4 o;                                           // rows d*16 + 4*kq + r of O^T = 4 consecutive channels
+#pragma unroll
+                for (int r = 0; r < 4; ++r) o[r] = (ot[d][r] * a0 + xch[2 + 4 * d + r] * a1) * inv;
+                *reinterpret_cast<f32x4*>(&a.out[(rowbase + q) * a.D + h * HD + d * 16 + 4 * kq]) = o;
+            }
         }
     }
 }
@@ -516,15 +568,40 @@ __global__ __launch_bounds__(256) void k_gemv(GemvArgs a) {
         mean[b] = 0.f;
         rstd[b] = 1.f;
     }
+    // all weight loads of the row are issued before anything that has to wait (LayerNorm statistics of the input and of
+    // the residual are two dependent reductions each): the chain is latency, not bandwidth
+    constexpr int WCH = 8;
+    const float* w = a.Wt + (long)n * a.K;
+    const int nch = a.K / (64 * V);
+    const bool pre = nch <= WCH;
+    float wreg[WCH][V];
+    if (pre) {
+#pragma unroll
+        for (int ch = 0; ch < WCH; ++ch)
+            if (ch < nch) ldv<V>(w + ch * 64 * V + lane * V, wreg[ch]);
+    }
+    const float bias = a.bias ? a.bias[n] : 0.f;
+    float rterm[8];
+#pragma unroll
+    for (int b = 0; b < 8; ++b) rterm[b] = 0.f;
+    if (a.res) {
+        const float rgn = a.rg ? a.rg[n] : 1.f, rbn = a.rg ? a.rb[n] : 0.f;
+#pragma unroll
+        for (int b = 0; b < 8; ++b) {
+            if (b >= a.B) continue;
+            const float* r = a.res + (long)b * a.N;
+            float m = 0.f, rs = 1.f;
+            if (a.rg) wave_row_stats<V>(r, a.N, lane, m, rs);
+            rterm[b] = (r[n] - m) * rs * rgn + rbn;
+        }
+    }
     if (a.xg) {
 #pragma unroll
         for (int b = 0; b < 8; ++b)
             if (b < a.B) wave_row_stats<V>(a.x + (long)(b * a.x_rows_per_b + xrow0) * a.K, a.K, lane, mean[b], rstd[b]);
     }
-    const float* w = a.Wt + (long)n * a.K;
-    for (int k = lane * V; k < a.K; k += 64 * V) {
-        float wv[V], gv[V], bv[V], av[V];
-        ldv<V>(w + k, wv);
+    auto body = [&](int k, const float* wv) {
+        float gv[V], bv[V], av[V];
 #pragma unroll
         for (int e = 0; e < V; ++e) gv[e] = 1.f, bv[e] = 0.f, av[e] = 0.f;
         if (a.xg) {
@@ -545,22 +622,24 @@ __global__ __launch_bounds__(256) void k_gemv(GemvArgs a) {
                 acc[b] += wv[e] * xv;
             }
         }
+    };
+    if (pre) {
+#pragma unroll
+        for (int ch = 0; ch < WCH; ++ch)
+            if (ch < nch) body(ch * 64 * V + lane * V, wreg[ch]);
+    } else {
+        for (int k = lane * V; k < a.K; k += 64 * V) {
+            float wv[V];
+            ldv<V>(w + k, wv);
+            body(k, wv);
+        }
     }
 #pragma unroll
     for (int b = 0; b < 8; ++b) {
         if (b >= a.B) continue;
-        float v = wave_sum(acc[b]) + (a.bias ? a.bias[n] : 0.f);
+        float v = wave_sum(acc[b]) + bias;
         if (a.relu) v = fmaxf(v, 0.f);
-        if (a.res) {
-            const float* r = a.res + (long)b * a.N;
-            if (a.rg) {
-                float m, rs;
-                wave_row_stats<V>(r, a.N, lane, m, rs);
-                v += (r[n] - m) * rs * a.rg[n] + a.rb[n];
-            } else {
-                v += r[n];
-            }
-        }
+        v += rterm[b];
         if (lane == 0) a.out[(long)b * a.N + n] = v;
     }
 }
@@ -730,7 +809,7 @@ __global__ __launch_bounds__(256) void k_reg_attend(const float* feat, const flo
 //   k_gn_reduce: x = sum_z part[z] (fixed order), written once, + per-slice (sum, sum of squares) of one image
 //   k_gn_apply:  mean / variance from the slice sums (double, fixed order), normalise + affine + ReLU in place
 // grid (slices of 4096 elements, images); token-major (HW, C) blocks
-constexpr int GN_SLICE = 4096;
+constexpr int GN_SLICE = 1024;
 
 __global__ __launch_bounds__(256) void k_gn_reduce(const float* __restrict__ part, int nz, long zstride,
                                                    float* __restrict__ x, float* __restrict__ stats, int n_per_img) {
@@ -962,9 +1041,9 @@ extern "C" int pt_tomp_predict_f32(const pt_tomp_dims* d, const float* params, c
         g.pos = pos; g.pos_bytes = (unsigned)((long)HW * D * 4); g.pos_cols = 2 * D; g.L = L; g.HW = HW;
         if ((rc = launch_gemm(g, st))) return rc;
         const dim3 ag((L + 63) / 64, NH, B);
-        if (HD == 32) hipLaunchKernelGGL((k_attn<32>), ag, dim3(256), 0, st, at);
-        else if (HD == 16) hipLaunchKernelGGL((k_attn<16>), ag, dim3(256), 0, st, at);
-        else hipLaunchKernelGGL((k_attn<64>), ag, dim3(256), 0, st, at);
+        if (HD == 32) hipLaunchKernelGGL((k_attn<32>), ag, dim3(512), 0, st, at);
+        else if (HD == 16) hipLaunchKernelGGL((k_attn<16>), ag, dim3(512), 0, st, at);
+        else hipLaunchKernelGGL((k_attn<64>), ag, dim3(512), 0, st, at);
         PT_CHECK_LAUNCH();
         g = gemm_args(AO, D, rows, P + e.sa.w_out, rows, D, D, P + e.sa.b_out, Y, D);
         g.R = X;

@@ -15,6 +15,9 @@ What gets rebound (import path = contract; nothing in the reference tree is edit
   pytracking.libs.optimization.GaussNewtonCG      (FactorizedConvProblem fast path)   -> pytracking_amd.optimization
   ltr.models.lwl.loss_residual_modules.LWTLResidual, ltr.models.meta.steepestdescent.GNSteepestDescent
                                                   (LWL few-shot learner)              -> pytracking_amd.steepestdescent
+  ltr.models.transformer.transformer.Transformer, ltr.models.transformer.filter_predictor.FilterPredictor,
+  ltr.models.transformer.heads.{LinearFilterClassifier, DenseBoxRegressor}
+                                                  (ToMP model predictor, inference)   -> pytracking_amd.transformer
 
 Dispatch rule of the rebound *functions*: device fp32 tensors of a shape the gfx950 kernels cover go to the C ABI;
 everything else (CPU tensors, dilations, grouped filters, K*K > 16, more than 16 filters) is outside the hot path and
@@ -98,7 +101,59 @@ def provide_prroi_module():
     return pm
 
 
-def install(strict=False, atom_cg=True):
+def _install_tomp(orig, strict):
+    """ToMP model predictor (inference): the reference's tompnet constructors (ltr/models/tracking/tompnet.py:106-118)
+    reach these classes through module attributes, so rebinding the attributes is enough."""
+    from . import transformer as _tm
+    try:
+        tmod = importlib.import_module("ltr.models.transformer.transformer")
+        pmod = importlib.import_module("ltr.models.transformer.filter_predictor")
+        hmod = importlib.import_module("ltr.models.transformer.heads")
+    except Exception:                   # torchvision (heads.py:3) missing: leave the transformer family alone
+        return
+    orig["tomp"] = (tmod.Transformer, pmod.FilterPredictor, hmod.LinearFilterClassifier, hmod.DenseBoxRegressor)
+    ref_tr, ref_fp, ref_cls, ref_reg = orig["tomp"]
+
+    def covered(d_model=512, nhead=8, num_encoder_layers=6, num_decoder_layers=6, dim_feedforward=2048, dropout=0.1,
+                activation="relu", normalize_before=False, return_intermediate_dec=False):
+        hd = d_model // max(nhead, 1)
+        return (activation == "relu" and not normalize_before and not return_intermediate_dec and d_model % 128 == 0
+                and d_model <= 512 and d_model % nhead == 0 and hd in (16, 32, 64) and nhead <= 16
+                and dim_feedforward % 64 == 0 and num_encoder_layers <= 16 and num_decoder_layers <= 16)
+
+    class Transformer(ref_tr):
+        """Covered configuration -> gfx950 parameter container; anything else -> the reference class."""
+
+        def __new__(cls, *args, **kw):
+            if covered(*args, **kw):
+                return _tm.Transformer(*args, **kw)
+            if strict:
+                raise NotImplementedError("Transformer: configuration outside the gfx950 hot path")
+            return ref_tr.__new__(cls)
+
+    class FilterPredictor(ref_fp):
+        def __new__(cls, transformer, *args, **kw):
+            if isinstance(transformer, _tm.Transformer):
+                return _tm.FilterPredictor(transformer, *args, **kw)
+            if strict:
+                raise NotImplementedError("FilterPredictor: transformer outside the gfx950 hot path")
+            return ref_fp.__new__(cls)
+
+    class DenseBoxRegressor(ref_reg):
+        def __new__(cls, num_channels, *args, **kw):
+            if num_channels % 64 == 0 and num_channels <= 512:
+                return _tm.DenseBoxRegressor(num_channels, *args, **kw)
+            if strict:
+                raise NotImplementedError("DenseBoxRegressor: channel count outside the gfx950 hot path")
+            return ref_reg.__new__(cls)
+
+    tmod.Transformer = Transformer
+    pmod.FilterPredictor = FilterPredictor
+    hmod.LinearFilterClassifier = _tm.LinearFilterClassifier
+    hmod.DenseBoxRegressor = DenseBoxRegressor
+
+
+def install(strict=False, atom_cg=True, tomp=True):
     """Rebind the boundary symbols.  Call after the reference is importable (`sys.path`) and before networks or
     trackers are constructed.  Idempotent."""
     if _state["installed"]:
@@ -137,6 +192,8 @@ def install(strict=False, atom_cg=True):
 
         rmod.LWTLResidual = _sd.LWTLResidual
         smod.GNSteepestDescent = GNSteepestDescent
+    if tomp:
+        _install_tomp(orig, strict)
     if atom_cg:
         try:
             pmod = importlib.import_module("pytracking.libs.optimization")
@@ -206,6 +263,11 @@ def uninstall():
         importlib.import_module("pytracking.libs.optimization").ConjugateGradient = orig["cg"]
     if "gn" in orig:
         importlib.import_module("pytracking.libs.optimization").GaussNewtonCG = orig["gn"]
+    if "tomp" in orig:
+        importlib.import_module("ltr.models.transformer.transformer").Transformer = orig["tomp"][0]
+        importlib.import_module("ltr.models.transformer.filter_predictor").FilterPredictor = orig["tomp"][1]
+        hm = importlib.import_module("ltr.models.transformer.heads")
+        hm.LinearFilterClassifier, hm.DenseBoxRegressor = orig["tomp"][2], orig["tomp"][3]
     if "lwl" in orig:
         importlib.import_module("ltr.models.lwl.loss_residual_modules").LWTLResidual = orig["lwl"][0]
         importlib.import_module("ltr.models.meta.steepestdescent").GNSteepestDescent = orig["lwl"][1]

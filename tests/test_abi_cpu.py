@@ -76,6 +76,53 @@ def test_atom_joint_gn_argument_checks(L):
     assert L.pt_atom_gn_f32(one, one, one, 8 * 36, one, one, 0.1, 1e-4, 0.05, 1, 8, 4, 6, 6, 4, it, 2, 1, one, 0, n) == -4
 
 
+def test_tomp_argument_checks(L):
+    n = None
+    one = ctypes.c_void_p(256)
+    d = _lib.TompDims(256, 8, 2048, 6, 6, 18, 18, 18)
+    assert L.pt_tomp_param_floats(ctypes.byref(d)) == 6 * (4 * 256 * 256 + 4 * 256 + 2 * 256 * 2048 + 2048 + 256 + 4 * 256) \
+        + 6 * (8 * 256 * 256 + 8 * 256 + 2 * 256 * 2048 + 2048 + 256 + 6 * 256) + 2 * 256 \
+        + (64 * 4 + 64 + 4 * 64) + (256 * 64 + 256 + 4 * 256) + (256 * 256 + 256) + 2 * 256
+    assert L.pt_tomp_predict_ws_bytes(ctypes.byref(d), 2, 1, 1) > 0
+    assert L.pt_tomp_predict_ws_bytes(ctypes.byref(d), 2, 2, 1) == 0            # the parallel entry point is single-sequence
+    assert L.pt_tomp_predict_ws_bytes(ctypes.byref(d), 2, 9, 0) == 0            # more than 8 batch rows
+    bad = _lib.TompDims(256, 5, 2048, 6, 6, 18, 18, 18)
+    assert L.pt_tomp_param_floats(ctypes.byref(bad)) == 0
+    a = [one] * 5
+    assert L.pt_tomp_predict_f32(ctypes.byref(d), n, *a, 2, 1, 1, 1, one, one, one, 1 << 30, n) == -1
+    assert L.pt_tomp_predict_f32(ctypes.byref(bad), one, *a, 2, 1, 1, 1, one, one, one, 1 << 30, n) == -2
+    assert L.pt_tomp_predict_f32(ctypes.byref(d), one, *a, 2, 1, 1, 3, one, one, one, 1 << 30, n) == -2   # num_gth > n_train
+    assert L.pt_tomp_predict_f32(ctypes.byref(d), one, *a, 2, 2, 1, 1, one, one, one, 1 << 30, n) == -3
+    assert L.pt_tomp_predict_f32(ctypes.byref(d), one, *a, 2, 1, 1, 1, one, one, one, 0, n) == -4
+    assert L.pt_tomp_bbreg_param_floats(256) == 256 * 256 + 256 + 4 * (9 * 256 * 256 + 3 * 256) + 4 * 9 * 256 + 4
+    assert L.pt_tomp_bbreg_ws_bytes(1, 256, 18, 18) > 0 and L.pt_tomp_bbreg_ws_bytes(1, 100, 18, 18) == 0
+    assert L.pt_tomp_bbreg_f32(one, one, one, one, 1, 256, 18, 18, one, 0, n) == -4
+    assert L.pt_tomp_bbreg_f32(one, one, one, one, 1, 100, 18, 18, one, 1 << 30, n) == -3
+    assert L.pt_tomp_linear_f32(one, one, n, one, 1, 256, 256, 0, n) == -1
+    assert L.pt_tomp_posenc_f32(one, 18, 18, 255, 18, n) == -2
+
+
+def test_tomp_mirror_contract():
+    """Constructor signatures and refusals of the ToMP mirror (no device work)."""
+    from pytracking_amd import transformer as TM
+    tr = TM.Transformer(d_model=128, nhead=4, num_encoder_layers=1, num_decoder_layers=1, dim_feedforward=256)
+    pred = TM.FilterPredictor(tr, feature_sz=6)
+    keys = list(pred.state_dict().keys())
+    assert "transformer.encoder.layers.0.self_attn.in_proj_weight" in keys
+    assert "transformer.decoder.layers.0.multihead_attn.out_proj.bias" in keys
+    assert "transformer.decoder.norm.weight" in keys and "box_encoding.4.running_var" in keys
+    assert "query_embed_fg_decoder.weight" in keys and "query_embed_test.weight" in keys
+    with pytest.raises(NotImplementedError):
+        TM.Transformer(normalize_before=True)
+    with pytest.raises(NotImplementedError):
+        TM.Transformer(activation="gelu")
+    x = torch.zeros(2, 1, 128, 6, 6)
+    with pytest.raises(NotImplementedError):                # training mode
+        pred.predict_filter(x, x[:1], torch.zeros(2, 1, 6, 6), torch.zeros(2, 1, 4, 6, 6))
+    with pytest.raises(RuntimeError):                        # CPU tensors
+        pred.eval().predict_filter(x, x[:1], torch.zeros(2, 1, 6, 6), torch.zeros(2, 1, 4, 6, 6))
+
+
 def test_activation_recognition():
     """The reference tracker hands its activations over as lambdas (atom.py:444-466); the mirror recognises the two
     the fused solvers implement and nothing else."""

@@ -529,11 +529,12 @@ def test_tomp_predictor_golden(name, cfg):
         close(enc1, g["single_enc"], atol=1e-4, rtol=1e-4)
 
 
-def test_tomp_encoder_blocks_vs_oracle():
+@pytest.mark.parametrize("nhead", [4, 2, 8])
+def test_tomp_encoder_blocks_vs_oracle(nhead):
     """Odd sizes against the float64 oracle: 3 memory frames, 5x7 maps (tokens not a multiple of any tile), two
-    sequences through predict_filter, masked keys through the parallel entry point."""
+    sequences through predict_filter, masked keys through the parallel entry point; head widths 32 / 64 / 16."""
     from oracle import tomp_oracle as TO
-    cfg = dict(synth.TOMP_SMALL, H=5, W=7, n_train=3, feature_sz=7, num_gth_frames=2)
+    cfg = dict(synth.TOMP_SMALL, H=5, W=7, n_train=3, feature_sz=7, num_gth_frames=2, nhead=nhead)
     params = synth.tomp_params(91, cfg)
     pred, cls, reg = build_tomp_modules(cfg, params, DEV)
     p64 = {k: v.astype(np.float64) for k, v in params.items()}

@@ -41,3 +41,37 @@ def test_install_rebinds_boundary_symbols_and_restores():
         if saved_prroi is not None:
             sys.modules["ltr.external.PreciseRoIPooling.pytorch.prroi_pool"] = saved_prroi
     assert fl.apply_filter is orig_apply and opt.DiMPSteepestDescentGN is orig_cls
+
+
+def test_tomp_mirror_state_dict_matches_reference_and_install_dispatch():
+    """The mirrored ToMP modules expose exactly the reference's state_dict (names and shapes), so a reference checkpoint
+    loads strict; after install() the tompnet constructors build the mirrors for the covered configuration and the
+    reference classes otherwise."""
+    ref_harness.install()
+    import ltr.models.transformer.transformer as rt
+    import ltr.models.transformer.filter_predictor as rf
+    import ltr.models.transformer.heads as rh
+    from pytracking_amd import install as amd, transformer as TM
+    kw = dict(d_model=128, nhead=4, num_encoder_layers=2, num_decoder_layers=2, dim_feedforward=256)
+    ref_pred = rf.FilterPredictor(rt.Transformer(**kw), feature_sz=6)
+    mine = TM.FilterPredictor(TM.Transformer(**kw), feature_sz=6)
+    for a, b in ((ref_pred, mine), (rh.LinearFilterClassifier(128), TM.LinearFilterClassifier(128)),
+                 (rh.DenseBoxRegressor(128), TM.DenseBoxRegressor(128))):
+        sa, sb = a.state_dict(), b.state_dict()
+        assert list(sa.keys()) == list(sb.keys())
+        assert all(sa[k].shape == sb[k].shape for k in sa)
+        b.load_state_dict(sa, strict=True)
+    orig_tr = rt.Transformer
+    amd.install()
+    try:
+        t = rt.Transformer(**kw)
+        assert isinstance(t, TM.Transformer)
+        assert isinstance(rf.FilterPredictor(t, feature_sz=6), TM.FilterPredictor)
+        assert rh.LinearFilterClassifier is TM.LinearFilterClassifier
+        assert isinstance(rh.DenseBoxRegressor(128), TM.DenseBoxRegressor)
+        pre = rt.Transformer(normalize_before=True, **kw)                 # outside the hot path: the reference's class
+        assert isinstance(pre, orig_tr) and not isinstance(pre, TM.Transformer)
+        assert not isinstance(rf.FilterPredictor(pre, feature_sz=6), TM.FilterPredictor)
+    finally:
+        amd.uninstall()
+    assert rt.Transformer is orig_tr
