@@ -48,15 +48,19 @@ struct GemmArgs {
                                                 // partial product to C + z*c_zstride (bias on z = 0 only); 0 = no split
 };
 
-template <int BM, int BN, int MODE>
+template <int BM, int BN, int MODE, int BK = 64>
 __global__ __launch_bounds__(256) void k_gemm(GemmArgs g) {
-    constexpr int LS = 36;                      // LDS row stride: 16-byte aligned, conflict-free 128-bit fragment reads
-    constexpr int WM = BM / 2, WN = BN / 2, MT = WM / 16, NT = WN / 16, AL = BM / 32, BL = BN / 32;
+    // K advances in steps of 64 (one barrier per 4 MFMA sub-steps of 16): with 32-wide steps the counters showed the
+    // wavefronts parked at s_waitcnt / s_barrier for a third of their life and the LDS round trip exposed twice per step
+    // (profiles/r01i_tomp_pmc.txt).  Fragment reads of sub-step h+1 are issued before the MFMAs of sub-step h.
+    constexpr int LS = BK + 4;                  // LDS row stride 68 / 36 words: 16-byte aligned, 4 mod 32 (see prow below)
+    constexpr int RP = 1024 / BK;               // tile rows covered by one pass of the 256 loader threads
+    constexpr int WM = BM / 2, WN = BN / 2, MT = WM / 16, NT = WN / 16, AL = BM / RP, BL = BN / RP;
     __shared__ __attribute__((aligned(16))) float As[2][BM * LS];
     __shared__ __attribute__((aligned(16))) float Bs[2][BN * LS];
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, wm = wave >> 1, wn = wave & 1;
     const int m0 = blockIdx.y * BM, n0 = blockIdx.x * BN;
-    const int lrow = tid >> 3, lc4 = (tid & 7) * 4;
+    const int lrow = tid / (BK / 4), lc4 = (tid % (BK / 4)) * 4;   // loader: BK/4 threads cover one row segment of BK floats
     const __amdgpu_buffer_rsrc_t rsA = pt_rsrc(g.A, g.a_bytes), rsW = pt_rsrc(g.Wt, g.w_bytes);
     const bool addpos = MODE == 0 && g.pos != nullptr && n0 < g.pos_cols;
     const __amdgpu_buffer_rsrc_t rsP = pt_rsrc(addpos ? g.pos : g.A, addpos ? g.pos_bytes : 16u);
@@ -65,7 +69,7 @@ __global__ __launch_bounds__(256) void k_gemm(GemmArgs g) {
     int py[AL], px[AL];
 #pragma unroll
     for (int i = 0; i < AL; ++i) {
-        const int row = m0 + lrow + 32 * i;
+        const int row = m0 + lrow + RP * i;
         const bool ok = row < g.M;
         if (MODE == 0) {
             aoff[i] = ok ? (unsigned)(((long)row * g.lda + lc4) * 4) : OOB;
@@ -80,19 +84,18 @@ __global__ __launch_bounds__(256) void k_gemm(GemmArgs g) {
     }
 #pragma unroll
     for (int i = 0; i < BL; ++i) {
-        const int n = n0 + lrow + 32 * i;
+        const int n = n0 + lrow + RP * i;
         woff[i] = n < g.N ? (unsigned)(((long)n * g.K + lc4) * 4) : OOB;
     }
 
-    // register ring: K-step k+PD is requested from memory while step k is on the matrix cores (one step of cover is
-    // ~0.2 us of MFMA work against ~0.7 us of L2/fabric latency); LDS is double-buffered one step ahead
-    constexpr int PD = 4;
+    // Register ring of depth PD; LDS is double-buffered one step ahead.  The loads are issued unconditionally (`live` =
+    // false turns a request into an out-of-range one: zeros, no memory touched) so that the compiler's s_waitcnt vmcnt
+    // bookkeeping stays exact -- a fetch inside a branch makes it wait for ALL outstanding loads before the LDS store.
+    constexpr int PD = 2;
     f32x4 ra[PD][AL], rp[PD][AL], rb[PD][BL];
-    // `live` = false turns every request into an out-of-range one (returns zeros, touches nothing): the loads are issued
-    // unconditionally so that the compiler's s_waitcnt vmcnt bookkeeping stays exact -- a fetch inside a branch makes it
-    // wait for ALL outstanding loads before the next LDS store, which collapses the ring to depth 1
     auto fetch = [&](int kb, int sl, bool live) {
-        const unsigned kbytes = (unsigned)kb * 128u;
+        live = live && (kb * BK + lc4 < g.K);                            // K % 64 == 32: the last step is half empty
+        const unsigned kbytes = (unsigned)kb * (BK * 4u);
         if (MODE == 0) {
 #pragma unroll
             for (int i = 0; i < AL; ++i) ra[sl][i] = pt_bload4(rsA, (aoff[i] == OOB || !live) ? OOB : aoff[i] + kbytes);
@@ -101,7 +104,7 @@ __global__ __launch_bounds__(256) void k_gemm(GemmArgs g) {
                 for (int i = 0; i < AL; ++i) rp[sl][i] = pt_bload4(rsP, (poff[i] == OOB || !live) ? OOB : poff[i] + kbytes);
             }
         } else {
-            const int k0 = kb * 32, tap = k0 / g.Cin, c0 = k0 - tap * g.Cin;
+            const int k0 = kb * BK, tap = k0 / g.Cin, c0 = k0 - tap * g.Cin;
             const int dy = tap / 3 - 1, dx = tap - (tap / 3) * 3 - 1;
 #pragma unroll
             for (int i = 0; i < AL; ++i) {
@@ -118,10 +121,10 @@ __global__ __launch_bounds__(256) void k_gemm(GemmArgs g) {
         for (int i = 0; i < AL; ++i) {
             f32x4 v = ra[sl][i];
             if (addpos) v += rp[sl][i];
-            *reinterpret_cast<f32x4*>(&As[buf][(lrow + 32 * i) * LS + lc4]) = v;
+            *reinterpret_cast<f32x4*>(&As[buf][(lrow + RP * i) * LS + lc4]) = v;
         }
 #pragma unroll
-        for (int i = 0; i < BL; ++i) *reinterpret_cast<f32x4*>(&Bs[buf][(lrow + 32 * i) * LS + lc4]) = rb[sl][i];
+        for (int i = 0; i < BL; ++i) *reinterpret_cast<f32x4*>(&Bs[buf][(lrow + RP * i) * LS + lc4]) = rb[sl][i];
     };
 
     f32x4 acc[MT][NT];
@@ -132,15 +135,17 @@ __global__ __launch_bounds__(256) void k_gemm(GemmArgs g) {
 
     // LDS fragment reads without bank conflicts.  ds_read_b128 is serviced in four groups of 16 lanes over 64 banks,
     // and the groups are not lane-contiguous: {0-3,12-15,20-27}, {4-11,16-19,28-31} and the same +32, i.e. every group
-    // mixes two k-slots (lane >> 4).  With a row stride of 36 words the 16-byte bank group of lane (i, kq) is
-    // (9 * row(i) + quad(kq)) mod 16; it is a permutation inside every hardware group when MFMA row i is tile row
-    // prow(i) (even rows for i in 4..11, odd rows otherwise) and k-slot kq reads k-quad {0,2,1,3}[kq].  Both operands use
-    // the same maps, so the k pairing is intact and the row / column permutation is undone in the epilogue.
+    // mixes two k-slots (lane >> 4).  With a row stride of 4 mod 64 words the 16-byte bank group of lane (i, kq) is
+    // (s * row(i) + quad(kq)) mod 16 with s odd; it is a permutation inside every hardware group when MFMA row i is
+    // tile row prow(i) (even rows for i in 4..11, odd rows otherwise) and k-slot kq reads k-quad {0,2,1,3}[kq].  Both
+    // operands use the same maps, so the k pairing is intact and the row / column permutation is undone in the epilogue.
     auto prow = [](int i) { return (i >= 4 && i < 12) ? 2 * (i - 4) : (i < 4 ? 2 * i + 1 : 2 * i - 15); };
     const int qoff = ((lane >> 4) & 1) * 2 + (lane >> 5);
+    const int aso = (wm * WM + prow(lane & 15)) * LS + qoff * 4, bso = (wn * WN + prow(lane & 15)) * LS + qoff * 4;
 
+    const int nkt = (g.K + BK - 1) / BK;
     const int kb0 = g.ksteps ? blockIdx.z * g.ksteps : 0;
-    const int nk = g.ksteps ? min(g.K / 32, kb0 + g.ksteps) : g.K / 32;
+    const int nk = g.ksteps ? min(nkt, kb0 + g.ksteps) : nkt;
 #pragma unroll
     for (int sl = 0; sl < PD; ++sl) fetch(kb0 + sl, sl, kb0 + sl < nk);
     stash(0, 0);
@@ -152,21 +157,31 @@ __global__ __launch_bounds__(256) void k_gemm(GemmArgs g) {
             const int buf = u & 1;
             fetch(kb + PD, u, kb + PD < nk);                             // slot u (step kb) already sits in LDS[buf]
             if (kb < nk) {                                               // workgroup-uniform; LDS reads + MFMA only
-                const float* as = &As[buf][(wm * WM + prow(lane & 15)) * LS + qoff * 4];
-                const float* bs = &Bs[buf][(wn * WN + prow(lane & 15)) * LS + qoff * 4];
+                const float* as = &As[buf][aso];
+                const float* bs = &Bs[buf][bso];
+                f32x4 fa[2][MT], fb[2][NT];
 #pragma unroll
-                for (int hh = 0; hh < 2; ++hh) {
-                    f32x4 a[MT], b[NT];
+                for (int mt = 0; mt < MT; ++mt) fa[0][mt] = *reinterpret_cast<const f32x4*>(as + mt * 16 * LS);
 #pragma unroll
-                    for (int mt = 0; mt < MT; ++mt) a[mt] = *reinterpret_cast<const f32x4*>(as + mt * 16 * LS + hh * 16);
+                for (int nt = 0; nt < NT; ++nt) fb[0][nt] = *reinterpret_cast<const f32x4*>(bs + nt * 16 * LS);
 #pragma unroll
-                    for (int nt = 0; nt < NT; ++nt) b[nt] = *reinterpret_cast<const f32x4*>(bs + nt * 16 * LS + hh * 16);
+                for (int hh = 0; hh < BK / 16; ++hh) {
+                    const int c = hh & 1, nx = c ^ 1;
+                    if (hh + 1 < BK / 16) {
+#pragma unroll
+                        for (int mt = 0; mt < MT; ++mt)
+                            fa[nx][mt] = *reinterpret_cast<const f32x4*>(as + mt * 16 * LS + (hh + 1) * 16);
+#pragma unroll
+                        for (int nt = 0; nt < NT; ++nt)
+                            fb[nx][nt] = *reinterpret_cast<const f32x4*>(bs + nt * 16 * LS + (hh + 1) * 16);
+                    }
 #pragma unroll
                     for (int j = 0; j < 4; ++j)
 #pragma unroll
                         for (int mt = 0; mt < MT; ++mt)
 #pragma unroll
-                            for (int nt = 0; nt < NT; ++nt) acc[mt][nt] = mfma16(a[mt][j], b[nt][j], acc[mt][nt]);
+                            for (int nt = 0; nt < NT; ++nt)
+                                acc[mt][nt] = mfma16(fa[c][mt][j], fb[c][nt][j], acc[mt][nt]);
                 }
             }
             stash((u + 1) % PD, buf ^ 1);                               // step kb+1 (zeros past the end: never read)
@@ -174,33 +189,58 @@ __global__ __launch_bounds__(256) void k_gemm(GemmArgs g) {
         }
     }
 
+    // epilogue: the row part of every output address is computed once per accumulator row (the segment / NCHW maps cost
+    // an integer division each -- done per element they were most of the kernel's time: ~120 VALU instructions x 16-64
+    // elements per lane)
+    long rbase[MT][4];
+    const bool plain = !g.nchw && g.c_segstride == 0;
 #pragma unroll
     for (int mt = 0; mt < MT; ++mt)
 #pragma unroll
-        for (int nt = 0; nt < NT; ++nt) {
-            const int col = n0 + wn * WN + nt * 16 + prow(lane & 15);
-            if (col >= g.N) continue;
-            const float bv = (g.bias && blockIdx.z == 0) ? g.bias[col] : 0.f;
-            const float sc = g.scale ? g.scale[col] : 1.f, sh = g.scale ? g.shift[col] : 0.f;
-#pragma unroll
-            for (int r = 0; r < 4; ++r) {
-                const int row = m0 + wm * WM + mt * 16 + prow(4 * (lane >> 4) + r);
-                if (row >= g.M) continue;
-                float v = (acc[mt][nt][r] + bv) * sc + sh;
-                if (g.relu) v = fmaxf(v, 0.f);
-                long o;
-                if (g.nchw) {
+        for (int r = 0; r < 4; ++r) {
+            const int row = m0 + wm * WM + mt * 16 + prow(4 * (lane >> 4) + r);
+            long o = -1;
+            if (row < g.M) {
+                if (plain) {
+                    o = (long)row * g.ldc;
+                } else if (g.nchw) {
                     const int img = row / g.HW;
-                    o = ((long)img * g.N + col) * g.HW + (row - img * g.HW);
+                    o = (long)img * g.N * g.HW + (row - img * g.HW);
                 } else {
                     const int sg = row / g.c_seg;
-                    o = ((long)sg * g.c_segstride + (row - sg * g.c_seg)) * g.ldc + col;
+                    o = ((long)sg * g.c_segstride + (row - sg * g.c_seg)) * g.ldc;
                 }
-                if (g.R) v += g.R[o];
-                if (g.expo) v = expf(v);
-                g.C[o + (long)blockIdx.z * g.c_zstride] = v;
             }
+            rbase[mt][r] = o;
         }
+    const long zoff = (long)blockIdx.z * g.c_zstride;
+    const long cstep = g.nchw ? g.HW : 1;
+#pragma unroll
+    for (int nt = 0; nt < NT; ++nt) {
+        const int col = n0 + wn * WN + nt * 16 + prow(lane & 15);
+        if (col >= g.N) continue;
+        const float bv = (g.bias && blockIdx.z == 0) ? g.bias[col] : 0.f;
+        const float sc = g.scale ? g.scale[col] : 1.f, sh = g.scale ? g.shift[col] : 0.f;
+        const long coff = (long)col * cstep;
+        float res[MT][4];
+        if (g.R) {                                                   // residual loads first, all in flight together
+#pragma unroll
+            for (int mt = 0; mt < MT; ++mt)
+#pragma unroll
+                for (int r = 0; r < 4; ++r) res[mt][r] = rbase[mt][r] >= 0 ? g.R[rbase[mt][r] + coff] : 0.f;
+        }
+#pragma unroll
+        for (int mt = 0; mt < MT; ++mt)
+#pragma unroll
+            for (int r = 0; r < 4; ++r) {
+                if (rbase[mt][r] < 0) continue;
+                float v = (acc[mt][nt][r] + bv) * sc + sh;
+                if (g.relu) v = fmaxf(v, 0.f);
+                if (g.R) v += res[mt][r];
+                if (g.expo) v = expf(v);
+                g.C[rbase[mt][r] + coff + zoff] = v;
+            }
+    }
 }
 
 GemmArgs gemm_args(const float* A, long lda, long a_rows, const float* Wt, int M, int N, int K, const float* bias,
@@ -216,12 +256,12 @@ GemmArgs gemm_args(const float* A, long lda, long a_rows, const float* Wt, int M
 int launch_gemm(const GemmArgs& g, hipStream_t st, bool conv = false) {
     if (g.K % 32 != 0 || g.M <= 0 || g.N <= 0) return PT_ERR_UNSUPPORTED;
     if (conv) {
-        if (g.Cin % 32 != 0) return PT_ERR_UNSUPPORTED;
-        const int nz = g.ksteps ? (g.K / 32 + g.ksteps - 1) / g.ksteps : 1;
+        if (g.Cin % 64 != 0) return PT_ERR_UNSUPPORTED;
+        const int nz = g.ksteps ? (g.K / 64 + g.ksteps - 1) / g.ksteps : 1;
         hipLaunchKernelGGL((k_gemm<32, 32, 1>), dim3((g.N + 31) / 32, (g.M + 31) / 32, nz), dim3(256), 0, st, g);
     } else {
         const long t64 = (long)((g.M + 63) / 64) * ((g.N + 63) / 64), t6432 = (long)((g.M + 63) / 64) * ((g.N + 31) / 32);
-        static const long T = getenv("PT_TOMP_T") ? atol(getenv("PT_TOMP_T")) : 200;
+        static const long T = getenv("PT_TOMP_T") ? atol(getenv("PT_TOMP_T")) : 1L << 40;   // measured: 32x32 tiles win at M = 1944
         if (t64 >= T)
             hipLaunchKernelGGL((k_gemm<64, 64, 0>), dim3((g.N + 63) / 64, (g.M + 63) / 64), dim3(256), 0, st, g);
         else if (t6432 >= T)
@@ -1192,7 +1232,7 @@ extern "C" int pt_tomp_bbreg_f32(const float* params, const float* feat, const f
     const long zs = (long)M * D;
     for (int i = 0; i < 4; ++i) {
         GemmArgs g = gemm_args(src, D, M, params + ro.cw[i], M, D, 9 * D, params + ro.cb[i], part, D);
-        g.H = H; g.Wd = W; g.Cin = D; g.HW = HW; g.ksteps = D / 32; g.c_zstride = zs;
+        g.H = H; g.Wd = W; g.Cin = D; g.HW = HW; g.ksteps = D / 64; g.c_zstride = zs;
         if ((rc = launch_gemm(g, st, true))) return rc;
         hipLaunchKernelGGL(k_gn_reduce, dim3(cv.slices, n), dim3(256), 0, st, part, 9, zs, dst, stats, HW * D);
         PT_CHECK_LAUNCH();
@@ -1202,7 +1242,7 @@ extern "C" int pt_tomp_bbreg_f32(const float* params, const float* feat, const f
         std::swap(src, dst);
     }
     GemmArgs g = gemm_args(src, D, M, params + ro.fw, M, 4, 9 * D, params + ro.fb, part, 4);
-    g.H = H; g.Wd = W; g.Cin = D; g.HW = HW; g.ksteps = D / 32; g.c_zstride = (long)M * 4;
+    g.H = H; g.Wd = W; g.Cin = D; g.HW = HW; g.ksteps = D / 64; g.c_zstride = (long)M * 4;
     if ((rc = launch_gemm(g, st, true))) return rc;
     hipLaunchKernelGGL(k_reg_finish, dim3((M * 4 + 255) / 256), dim3(256), 0, st, part, 9, (long)M * 4, ltrb, M, HW);
     PT_CHECK_LAUNCH();
