@@ -202,9 +202,15 @@ typedef struct pt_tomp_dims {
     int max_res;       /* `feature_sz` of FilterPredictor (anti-aliasing factor of the positional encoding) */
 } pt_tomp_dims;
 size_t pt_tomp_param_floats(const pt_tomp_dims* dims);
+/* Weight-only products of the decoder, folded once per weight update into a second caller-owned buffer of
+ * pt_tomp_prepared_floats() floats (one query token per batch row makes self-attention, the query/key product and
+ * value + out_proj plain matrix-vector products: W_o W_v, W_k,h^T W_q,h / sqrt(d_h), W_o[:,h] W_v,h and their biases). */
+size_t pt_tomp_prepared_floats(const pt_tomp_dims* dims);
+int pt_tomp_prepare_f32(const pt_tomp_dims* dims, const float* params, float* prepared, void* stream);
 int pt_tomp_posenc_f32(float* pos, int H, int W, int d_model, int max_res, void* stream);
 size_t pt_tomp_predict_ws_bytes(const pt_tomp_dims* dims, int n_train, int n_seq, int parallel);
-int pt_tomp_predict_f32(const pt_tomp_dims* dims, const float* params, const float* pos, const float* train_feat,
+int pt_tomp_predict_f32(const pt_tomp_dims* dims, const float* params, const float* prepared, const float* pos,
+                        const float* train_feat,
                         const float* test_feat, const float* train_label, const float* train_ltrb,
                         int n_train, int n_seq, int parallel, int num_gth_frames, float* filters, float* enc_feat,
                         void* ws, size_t ws_bytes, void* stream);

@@ -31,7 +31,7 @@ EXPORTS = [
     "pt_track_frame_ws_bytes", "pt_track_frame_f32",
     "pt_apply_filter_mf_ws_bytes", "pt_apply_filter_mf_f32", "pt_feat_transpose_mf_ws_bytes", "pt_feat_transpose_mf_f32",
     "pt_lwl_ws_bytes", "pt_lwl_gn_solve_f32",
-    "pt_tomp_param_floats", "pt_tomp_posenc_f32", "pt_tomp_predict_ws_bytes", "pt_tomp_predict_f32", "pt_tomp_linear_f32",
+    "pt_tomp_param_floats", "pt_tomp_prepared_floats", "pt_tomp_prepare_f32", "pt_tomp_posenc_f32", "pt_tomp_predict_ws_bytes", "pt_tomp_predict_f32", "pt_tomp_linear_f32",
     "pt_tomp_bbreg_param_floats", "pt_tomp_bbreg_ws_bytes", "pt_tomp_bbreg_f32",
     "pt_profile_create", "pt_profile_attach", "pt_profile_collect", "pt_profile_reset", "pt_profile_destroy",
 ]
@@ -136,12 +136,16 @@ def lib():
     dp = ctypes.POINTER(TompDims)
     L.pt_tomp_param_floats.restype = sz
     L.pt_tomp_param_floats.argtypes = [dp]
+    L.pt_tomp_prepared_floats.restype = sz
+    L.pt_tomp_prepared_floats.argtypes = [dp]
+    L.pt_tomp_prepare_f32.restype = i
+    L.pt_tomp_prepare_f32.argtypes = [dp, vp, vp, vp]
     L.pt_tomp_posenc_f32.restype = i
     L.pt_tomp_posenc_f32.argtypes = [vp, i, i, i, i, vp]
     L.pt_tomp_predict_ws_bytes.restype = sz
     L.pt_tomp_predict_ws_bytes.argtypes = [dp, i, i, i]
     L.pt_tomp_predict_f32.restype = i
-    L.pt_tomp_predict_f32.argtypes = [dp, vp, vp, vp, vp, vp, vp, i, i, i, i, vp, vp, vp, sz, vp]
+    L.pt_tomp_predict_f32.argtypes = [dp, vp, vp, vp, vp, vp, vp, vp, i, i, i, i, vp, vp, vp, sz, vp]
     L.pt_tomp_linear_f32.restype = i
     L.pt_tomp_linear_f32.argtypes = [vp, vp, vp, vp, i, i, i, i, vp]
     L.pt_tomp_bbreg_param_floats.restype = sz

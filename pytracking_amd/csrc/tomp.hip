@@ -17,8 +17,9 @@
 //   k_attn      fp32 flash attention: S^T = K Q^T per 16-key tile so that the MFMA accumulator of the score tile IS the
 //               B operand of the PV product (no LDS round trip for P), online softmax per 64-key chunk
 //   decoder     one query token per batch row: the K/V projections of the memory are never formed --
-//               q.(Wk m + bk) = (Wk^T q).m + const and sum_l p_l (Wv m_l + bv) = Wv (sum_l p_l m_l) + bv, so the decoder is a
-//               chain of GEMVs over the weights plus two streaming passes over the memory per layer
+//               q.(Wk m + bk) = (Wk^T q).m + const and sum_l p_l (Wv m_l + bv) = Wv (sum_l p_l m_l) + bv, and the weight
+//               products this leaves (Wo Wv, Wk_h^T Wq_h, Wo[:,h] Wv_h) are folded once per weight update
+//               (pt_tomp_prepare_f32), so a layer is 5 GEMVs plus two MFMA passes over the memory
 #include "common.h"
 #include "pt_internal.h"
 
@@ -44,6 +45,7 @@ struct GemmArgs {
     int relu, expo, nchw;                       // nchw: C[((r / HW) * N + n) * HW + r % HW]
     const float* pos; unsigned pos_bytes; int pos_cols, L, HW;   // A[r][k] + pos[(r % L) % HW][k] for column tiles < pos_cols
     int H, Wd, Cin;                             // MODE 1: 3x3 zero-padded gather, K = 9 * Cin, weights (N, tap, Cin)
+    int swizzle;                                // XCD-aware workgroup -> tile map (grid.y rounded up to a multiple of 8)
     int ksteps; long c_zstride;                 // split-K: blockIdx.z owns K-steps [z*ksteps, (z+1)*ksteps) and writes its
                                                 // partial product to C + z*c_zstride (bias on z = 0 only); 0 = no split
 };
@@ -59,7 +61,18 @@ __global__ __launch_bounds__(256) void k_gemm(GemmArgs g) {
     __shared__ __attribute__((aligned(16))) float As[2][BM * LS];
     __shared__ __attribute__((aligned(16))) float Bs[2][BN * LS];
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, wm = wave >> 1, wn = wave & 1;
-    const int m0 = blockIdx.y * BM, n0 = blockIdx.x * BN;
+    // Workgroup -> tile map.  Workgroups are dealt to the 8 XCDs round-robin in dispatch order (x fastest), and each XCD
+    // has its own L2: with the natural map and a column-tile count that is a multiple of 8, every XCD walks ALL row tiles
+    // of A (8 x 16 MB over the fabric for the FFN's second GEMM).  Swizzled: XCD c owns the row tiles = c mod 8 and sweeps
+    // the column tiles, so A crosses the fabric once and only the (small) weight matrix is replicated per XCD.
+    int bx = blockIdx.x, by = blockIdx.y;
+    if (g.swizzle) {
+        const int lin = blockIdx.y * gridDim.x + blockIdx.x, xcd = lin & 7, j = lin >> 3;
+        by = xcd + 8 * (j / (int)gridDim.x);
+        bx = j % (int)gridDim.x;
+        if (by * BM >= g.M) return;                              // padding rows of the rounded-up grid
+    }
+    const int m0 = by * BM, n0 = bx * BN;
     const int lrow = tid / (BK / 4), lc4 = (tid % (BK / 4)) * 4;   // loader: BK/4 threads cover one row segment of BK floats
     const __amdgpu_buffer_rsrc_t rsA = pt_rsrc(g.A, g.a_bytes), rsW = pt_rsrc(g.Wt, g.w_bytes);
     const bool addpos = MODE == 0 && g.pos != nullptr && n0 < g.pos_cols;
@@ -266,8 +279,13 @@ int launch_gemm(const GemmArgs& g, hipStream_t st, bool conv = false) {
             hipLaunchKernelGGL((k_gemm<64, 64, 0>), dim3((g.N + 63) / 64, (g.M + 63) / 64), dim3(256), 0, st, g);
         else if (t6432 >= T)
             hipLaunchKernelGGL((k_gemm<64, 32, 0>), dim3((g.N + 31) / 32, (g.M + 63) / 64), dim3(256), 0, st, g);
-        else
-            hipLaunchKernelGGL((k_gemm<32, 32, 0>), dim3((g.N + 31) / 32, (g.M + 31) / 32), dim3(256), 0, st, g);
+        else {
+            GemmArgs gs = g;
+            const int gy = (g.M + 31) / 32;
+            gs.swizzle = gy >= 16;                                   // worth it once every XCD gets >= 2 row tiles
+            hipLaunchKernelGGL((k_gemm<32, 32, 0>), dim3((g.N + 31) / 32, gs.swizzle ? (gy + 7) / 8 * 8 : gy), dim3(256),
+                               0, st, gs);
+        }
     }
     PT_CHECK_LAUNCH();
     return PT_OK;
@@ -558,7 +576,7 @@ __global__ void k_tomp_posenc(float* pos, int H, int W, int D, double factor) {
 // ------------------------------------------------------------------------------------------------------------------
 struct GemvArgs {
     const float* Wt; const float* bias; int N, K;
-    const float* x; int x_rows_per_b, x_head_div;   // input row of (b, n): b * x_rows_per_b + (x_head_div ? n / x_head_div : 0)
+    const float* x;                                 // (B, K) input rows
     const float *xg, *xb;                           // optional LayerNorm applied to the input rows (K = model width)
     const float* xadd;                              // optional (K) vector added to every input row after the LayerNorm
     const float* res; const float *rg, *rb;         // optional residual rows (B, N), optionally LayerNorm'ed
@@ -600,7 +618,6 @@ template <int V>
 __global__ __launch_bounds__(256) void k_gemv(GemvArgs a) {
     const int lane = threadIdx.x & 63, n = blockIdx.x * 4 + (threadIdx.x >> 6);
     if (n >= a.N) return;
-    const int xrow0 = a.x_head_div ? n / a.x_head_div : 0;
     float acc[8], mean[8], rstd[8];
 #pragma unroll
     for (int b = 0; b < 8; ++b) {
@@ -638,7 +655,7 @@ __global__ __launch_bounds__(256) void k_gemv(GemvArgs a) {
     if (a.xg) {
 #pragma unroll
         for (int b = 0; b < 8; ++b)
-            if (b < a.B) wave_row_stats<V>(a.x + (long)(b * a.x_rows_per_b + xrow0) * a.K, a.K, lane, mean[b], rstd[b]);
+            if (b < a.B) wave_row_stats<V>(a.x + (long)b * a.K, a.K, lane, mean[b], rstd[b]);
     }
     auto body = [&](int k, const float* wv) {
         float gv[V], bv[V], av[V];
@@ -652,7 +669,7 @@ __global__ __launch_bounds__(256) void k_gemv(GemvArgs a) {
 #pragma unroll
         for (int b = 0; b < 8; ++b) {
             if (b >= a.B) continue;
-            const float* x = a.x + (long)(b * a.x_rows_per_b + xrow0) * a.K;
+            const float* x = a.x + (long)b * a.K;
             float xr[V];
             ldv<V>(x + k, xr);
 #pragma unroll
@@ -695,34 +712,53 @@ int launch_gemv(const GemvArgs& a, hipStream_t st) {
     return PT_OK;
 }
 
-// qk[b][h][c] = sum_{j in head h} Wk[h*HD + j][c] * q[b][h*HD + j] / sqrt(HD): the key projection folded onto the query.
-// grid nhead * D / 64; thread = (channel, quarter of the head's rows), quarters reduced through LDS in a fixed order
-__global__ __launch_bounds__(256) void k_dec_qk(const float* __restrict__ Wk, const float* __restrict__ q,
-                                                float* __restrict__ qk, int B, int D, int nhead, float scale) {
-    __shared__ float part[8][256];
-    const int tid = threadIdx.x, cl = tid & 63, jp = tid >> 6;
-    const int idx = blockIdx.x * 64 + cl, h = idx / D, c = idx - h * D, HD = D / nhead, jn = HD / 4;
-    float acc[8];
-#pragma unroll
-    for (int bb = 0; bb < 8; ++bb) acc[bb] = 0.f;
-    const float* w = Wk + (long)(h * HD + jp * jn) * D + c;
-    const float* qq = q + h * HD + jp * jn;
-#pragma unroll 4
-    for (int j = 0; j < jn; ++j) {
-        const float wv = w[(long)j * D];
-#pragma unroll
-        for (int bb = 0; bb < 8; ++bb)
-            if (bb < B) acc[bb] += wv * qq[(long)bb * D + j];
+// One-time folding of the decoder's weight products (pt_tomp_prepare_f32).  With a single query token per batch row
+//   self-attention      out_proj(v_proj(t))                  = (Wo Wv) t + (Wo bv + bo)
+//   query . key         q_h . (Wk_h (m + pos))               = (Wk_h^T Wq_h x + Wk_h^T bq_h) . (m + pos)   [+ const in l]
+//   value + out_proj    Wo concat_h(Wv_h ctx_h + bv_h) + bo  = sum_h (Wo[:, h] Wv_h) ctx_h + (Wo bv + bo)
+// so a decoder layer is 5 GEMVs + 2 passes over the memory instead of 8 + 2.  Plain loops: runs once per weight update.
+__global__ void k_prep_sa(const float* Wo, const float* bo, const float* Wv, const float* bv, float* Wsa, float* bsa,
+                          int D) {
+    const int idx = blockIdx.x * blockDim.x + threadIdx.x;
+    if (idx >= D * D) return;
+    const int i = idx / D, j = idx - i * D;
+    float s = 0.f;
+    for (int k = 0; k < D; ++k) s += Wo[i * D + k] * Wv[k * D + j];
+    Wsa[idx] = s;
+    if (j == 0) {
+        float t = bo[i];
+        for (int k = 0; k < D; ++k) t += Wo[i * D + k] * bv[k];
+        bsa[i] = t;
     }
-#pragma unroll
-    for (int bb = 0; bb < 8; ++bb) part[bb][tid] = acc[bb];
-    __syncthreads();
-    if (jp == 0) {
-#pragma unroll
-        for (int bb = 0; bb < 8; ++bb)
-            if (bb < B)
-                qk[((long)bb * nhead + h) * D + c] =
-                    (part[bb][cl] + part[bb][cl + 64] + part[bb][cl + 128] + part[bb][cl + 192]) * scale;
+}
+
+__global__ void k_prep_mq(const float* Wq, const float* bq, const float* Wk, float* Mq, float* cq, int D, int nhead,
+                          float scale) {
+    const long idx = (long)blockIdx.x * blockDim.x + threadIdx.x;
+    if (idx >= (long)nhead * D * D) return;
+    const int HD = D / nhead, h = (int)(idx / ((long)D * D)), c = (int)((idx / D) % D), k = (int)(idx % D);
+    float s = 0.f, t = 0.f;
+    for (int j = 0; j < HD; ++j) {
+        const float wk = Wk[(long)(h * HD + j) * D + c];
+        s += wk * Wq[(long)(h * HD + j) * D + k];
+        t += wk * bq[h * HD + j];
+    }
+    Mq[idx] = s * scale;
+    if (k == 0) cq[h * D + c] = t * scale;
+}
+
+__global__ void k_prep_ov(const float* Wo, const float* bo, const float* Wv, const float* bv, float* Wov, float* bov,
+                          int D, int nhead) {
+    const long idx = (long)blockIdx.x * blockDim.x + threadIdx.x;
+    if (idx >= (long)D * nhead * D) return;
+    const int HD = D / nhead, n = (int)(idx / ((long)nhead * D)), h = (int)((idx / D) % nhead), c = (int)(idx % D);
+    float s = 0.f;
+    for (int j = 0; j < HD; ++j) s += Wo[(long)n * D + h * HD + j] * Wv[(long)(h * HD + j) * D + c];
+    Wov[idx] = s;
+    if (h == 0 && c == 0) {
+        float t = bo[n];
+        for (int j = 0; j < D; ++j) t += Wo[(long)n * D + j] * bv[j];
+        bov[n] = t;
     }
 }
 
@@ -955,6 +991,21 @@ PackOff pack_layout(int D, int ff, int n_enc, int n_dec) {
     return o;
 }
 
+struct PrepOff { size_t wsa, bsa, mq, cq, wov, bov; };
+struct PrepLayout { PrepOff dec[16]; size_t total; };
+PrepLayout prep_layout(int D, int nhead, int n_dec) {
+    PrepLayout o{};
+    size_t c = 0;
+    auto take = [&](size_t n) { size_t r = c; c += pt_align_floats(n); return r; };
+    for (int i = 0; i < n_dec; ++i) {
+        PrepOff& p = o.dec[i];
+        p.wsa = take((size_t)D * D); p.bsa = take(D); p.mq = take((size_t)nhead * D * D); p.cq = take((size_t)nhead * D);
+        p.wov = take((size_t)D * nhead * D); p.bov = take(D);
+    }
+    o.total = c;
+    return o;
+}
+
 int dims_check(const pt_tomp_dims* d) {
     if (!d) return PT_ERR_NULL;
     if (d->d_model <= 0 || d->nhead <= 0 || d->dim_ff <= 0 || d->n_enc < 0 || d->n_dec < 0 || d->H <= 0 || d->W <= 0 ||
@@ -969,7 +1020,7 @@ int dims_check(const pt_tomp_dims* d) {
 }
 
 struct WsCarve {
-    size_t X, QKV, AO, Y, Hd, E1, E2, bnsc, bnsh, zero, a, q, qk, scores, ctx, cv, P[2], P1, P2, hdn, total;
+    size_t X, QKV, AO, Y, Hd, E1, E2, bnsc, bnsh, zero, a, qk, scores, ctx, P[2], P1, P2, hdn, total;
 };
 
 WsCarve ws_carve(const pt_tomp_dims* d, int B, int nf) {
@@ -981,8 +1032,8 @@ WsCarve ws_carve(const pt_tomp_dims* d, int B, int nf) {
     w.Hd = take(rows * d->dim_ff);
     w.E1 = take((size_t)B * nf * HW * (D / 4)); w.E2 = take((size_t)B * nf * HW * D);
     w.bnsc = take(D); w.bnsh = take(D);
-    w.zero = take(B * D); w.a = take(B * D); w.q = take(B * D); w.qk = take((size_t)B * d->nhead * D);
-    w.scores = take((size_t)B * d->nhead * L); w.ctx = take((size_t)B * d->nhead * D); w.cv = take(B * D);
+    w.zero = take(B * D); w.a = take(B * D); w.qk = take((size_t)B * d->nhead * D);
+    w.scores = take((size_t)B * d->nhead * L); w.ctx = take((size_t)B * d->nhead * D);
     w.P[0] = take(B * D); w.P[1] = take(B * D); w.P1 = take(B * D); w.P2 = take(B * D); w.hdn = take((size_t)B * d->dim_ff);
     w.total = c;
     return w;
@@ -1022,15 +1073,49 @@ extern "C" int pt_tomp_linear_f32(const float* weight, const float* bias, const 
     if (!weight || !x || !y) return PT_ERR_NULL;
     if (B <= 0 || N <= 0 || K <= 0) return PT_ERR_SHAPE;
     GemvArgs a{};
-    a.Wt = weight; a.bias = bias; a.N = N; a.K = K; a.x = x; a.x_rows_per_b = 1; a.relu = relu; a.B = B; a.out = y;
+    a.Wt = weight; a.bias = bias; a.N = N; a.K = K; a.x = x; a.relu = relu; a.B = B; a.out = y;
     return launch_gemv(a, (hipStream_t)stream);
 }
 
-extern "C" int pt_tomp_predict_f32(const pt_tomp_dims* d, const float* params, const float* pos, const float* train_feat,
+extern "C" size_t pt_tomp_prepared_floats(const pt_tomp_dims* d) {
+    if (dims_check(d)) return 0;
+    return std::max<size_t>(prep_layout(d->d_model, d->nhead, d->n_dec).total, 64);
+}
+
+extern "C" int pt_tomp_prepare_f32(const pt_tomp_dims* d, const float* params, float* prepared, void* stream) {
+    if (!params || !prepared) return PT_ERR_NULL;
+    int rc = dims_check(d);
+    if (rc) return rc;
+    hipStream_t st = (hipStream_t)stream;
+    const int D = d->d_model, NH = d->nhead;
+    const PackOff po = pack_layout(D, d->dim_ff, d->n_enc, d->n_dec);
+    const PrepLayout pl = prep_layout(D, NH, d->n_dec);
+    const float scale = 1.0f / sqrtf((float)(D / NH));
+    for (int i = 0; i < d->n_dec; ++i) {
+        const DecOff& dc = po.dec[i];
+        const PrepOff& pp = pl.dec[i];
+        const float *sa_w = params + dc.sa.w_in, *sa_b = params + dc.sa.b_in, *ca_w = params + dc.ca.w_in,
+                    *ca_b = params + dc.ca.b_in;
+        hipLaunchKernelGGL(k_prep_sa, dim3((D * D + 255) / 256), dim3(256), 0, st, params + dc.sa.w_out,
+                           params + dc.sa.b_out, sa_w + (size_t)2 * D * D, sa_b + 2 * D, prepared + pp.wsa, prepared + pp.bsa, D);
+        PT_CHECK_LAUNCH();
+        hipLaunchKernelGGL(k_prep_mq, dim3((unsigned)(((long)NH * D * D + 255) / 256)), dim3(256), 0, st, ca_w, ca_b,
+                           ca_w + (size_t)D * D, prepared + pp.mq, prepared + pp.cq, D, NH, scale);
+        PT_CHECK_LAUNCH();
+        hipLaunchKernelGGL(k_prep_ov, dim3((unsigned)(((long)NH * D * D + 255) / 256)), dim3(256), 0, st,
+                           params + dc.ca.w_out, params + dc.ca.b_out, ca_w + (size_t)2 * D * D, ca_b + 2 * D,
+                           prepared + pp.wov, prepared + pp.bov, D, NH);
+        PT_CHECK_LAUNCH();
+    }
+    return PT_OK;
+}
+
+extern "C" int pt_tomp_predict_f32(const pt_tomp_dims* d, const float* params, const float* prepared, const float* pos,
+                                   const float* train_feat,
                                    const float* test_feat, const float* train_label, const float* train_ltrb,
                                    int n_train, int n_seq, int parallel, int num_gth_frames, float* filters,
                                    float* enc_feat, void* ws, size_t ws_bytes, void* stream) {
-    if (!params || !pos || !train_feat || !test_feat || !train_label || !train_ltrb || !filters || !enc_feat || !ws)
+    if (!params || !prepared || !pos || !train_feat || !test_feat || !train_label || !train_ltrb || !filters || !enc_feat || !ws)
         return PT_ERR_NULL;
     int rc = dims_check(d);
     if (rc) return rc;
@@ -1108,47 +1193,38 @@ extern "C" int pt_tomp_predict_f32(const pt_tomp_dims* d, const float* params, c
     const float* qpos = P + po.fg;                                 // query_embed_fg_decoder IS query_embed_fg (:35)
     const float* tpre = base + cv.zero;                            // pre-LayerNorm state entering the layer
     const float *tg = nullptr, *tb = nullptr;                      // its LayerNorm (none for the initial zeros)
+    const PrepLayout pl = prep_layout(D, NH, d->n_dec);
     for (int i = 0; i < d->n_dec; ++i) {
         const DecOff& dc = po.dec[i];
+        const PrepOff& pp = pl.dec[i];
         float *Pa = base + cv.P1, *Pb = base + cv.P2, *Pc = base + cv.P[i & 1];
         GemvArgs v{};
-        // self-attention over one token: softmax of a single key is 1 -> out_proj(v_proj(tgt))
-        v.Wt = P + dc.sa.w_in + (size_t)2 * D * D; v.bias = P + dc.sa.b_in + 2 * D; v.N = D; v.K = D;
-        v.x = tpre; v.x_rows_per_b = 1; v.xg = tg; v.xb = tb; v.B = B; v.out = base + cv.a;
-        if ((rc = launch_gemv(v, st))) return rc;
-        v = GemvArgs{};
-        v.Wt = P + dc.sa.w_out; v.bias = P + dc.sa.b_out; v.N = D; v.K = D; v.x = base + cv.a; v.x_rows_per_b = 1;
+        // self-attention over one token (softmax of a single key is 1), folded: Pa = t + (Wo Wv) t + (Wo bv + bo)
+        v.Wt = prepared + pp.wsa; v.bias = prepared + pp.bsa; v.N = D; v.K = D; v.x = tpre; v.xg = tg; v.xb = tb;
         v.res = tpre; v.rg = tg; v.rb = tb; v.B = B; v.out = Pa;
         if ((rc = launch_gemv(v, st))) return rc;
-        // cross-attention: q = Wq (LN1(Pa) + query_pos) + bq
+        // cross-attention query folded onto the keys: qk[b][h] = Wk_h^T (Wq_h (LN1(Pa) + query_pos) + bq_h) / sqrt(HD)
         v = GemvArgs{};
-        v.Wt = P + dc.ca.w_in; v.bias = P + dc.ca.b_in; v.N = D; v.K = D; v.x = Pa; v.x_rows_per_b = 1;
-        v.xg = P + dc.n1g; v.xb = P + dc.n1b; v.xadd = qpos; v.B = B; v.out = base + cv.q;   // one query_pos row for all b
+        v.Wt = prepared + pp.mq; v.bias = prepared + pp.cq; v.N = NH * D; v.K = D; v.x = Pa; v.xg = P + dc.n1g;
+        v.xb = P + dc.n1b; v.xadd = qpos; v.B = B; v.out = base + cv.qk;     // one query_pos row for all batch rows
         if ((rc = launch_gemv(v, st))) return rc;
-        hipLaunchKernelGGL(k_dec_qk, dim3(NH * D / 64), dim3(256), 0, st, P + dc.ca.w_in + (size_t)D * D,
-                           base + cv.q, base + cv.qk, B, D, NH, at.scale);
-        PT_CHECK_LAUNCH();
         hipLaunchKernelGGL(k_dec_scores, dim3((L + 15) / 16, B), dim3(64), 0, st, da);
         PT_CHECK_LAUNCH();
         hipLaunchKernelGGL(k_dec_ctx, dim3(D / 16, B), dim3(1024),
                            ((size_t)NH * ((L + 3) & ~3) + 16 + 16 * 256) * sizeof(float), st, da);
         PT_CHECK_LAUNCH();
-        // value projection per head on the attention-weighted memory, then out_proj + residual LN1(Pa)
+        // value projection + out_proj folded over the heads' attention-weighted memories, residual LN1(Pa)
         v = GemvArgs{};
-        v.Wt = P + dc.ca.w_in + (size_t)2 * D * D; v.bias = P + dc.ca.b_in + 2 * D; v.N = D; v.K = D;
-        v.x = base + cv.ctx; v.x_rows_per_b = NH; v.x_head_div = HD; v.B = B; v.out = base + cv.a;
-        if ((rc = launch_gemv(v, st))) return rc;
-        v = GemvArgs{};
-        v.Wt = P + dc.ca.w_out; v.bias = P + dc.ca.b_out; v.N = D; v.K = D; v.x = base + cv.a; v.x_rows_per_b = 1;
+        v.Wt = prepared + pp.wov; v.bias = prepared + pp.bov; v.N = D; v.K = NH * D; v.x = base + cv.ctx;
         v.res = Pa; v.rg = P + dc.n1g; v.rb = P + dc.n1b; v.B = B; v.out = Pb;
         if ((rc = launch_gemv(v, st))) return rc;
         // feed-forward on LN2(Pb)
         v = GemvArgs{};
-        v.Wt = P + dc.w1; v.bias = P + dc.b1; v.N = ff; v.K = D; v.x = Pb; v.x_rows_per_b = 1; v.xg = P + dc.n2g;
+        v.Wt = P + dc.w1; v.bias = P + dc.b1; v.N = ff; v.K = D; v.x = Pb; v.xg = P + dc.n2g;
         v.xb = P + dc.n2b; v.relu = 1; v.B = B; v.out = base + cv.hdn;
         if ((rc = launch_gemv(v, st))) return rc;
         v = GemvArgs{};
-        v.Wt = P + dc.w2; v.bias = P + dc.b2; v.N = D; v.K = ff; v.x = base + cv.hdn; v.x_rows_per_b = 1;
+        v.Wt = P + dc.w2; v.bias = P + dc.b2; v.N = D; v.K = ff; v.x = base + cv.hdn;
         v.res = Pb; v.rg = P + dc.n2g; v.rb = P + dc.n2b; v.B = B; v.out = Pc;
         if ((rc = launch_gemv(v, st))) return rc;
         tpre = Pc; tg = P + dc.n3g; tb = P + dc.n3b;
@@ -1221,7 +1297,7 @@ extern "C" int pt_tomp_bbreg_f32(const float* params, const float* feat, const f
     float* base = (float*)ws;
     float *fproj = base + cv.fproj, *part = base + cv.part, *stats = base + cv.stats;
     GemvArgs v{};
-    v.Wt = params + ro.lw; v.bias = params + ro.lb; v.N = D; v.K = D; v.x = filter; v.x_rows_per_b = 1; v.B = 1; v.out = fproj;
+    v.Wt = params + ro.lw; v.bias = params + ro.lb; v.N = D; v.K = D; v.x = filter; v.B = 1; v.out = fproj;
     int rc = launch_gemv(v, st);
     if (rc) return rc;
     hipLaunchKernelGGL(k_reg_attend, dim3((HW + 31) / 32, n), dim3(256), ((size_t)D * 33 + 32) * sizeof(float), st, feat,

@@ -168,6 +168,7 @@ class FilterPredictor(nn.Module):
         self._pack = _Pack()
         self._pos = {}
         self._zero_tok = None
+        self._prep_key, self._prepared = None, None
 
     def forward(self, train_feat, test_feat, train_label, train_ltrb_target, *args, **kwargs):
         return self.predict_filter(train_feat, test_feat, train_label, train_ltrb_target, *args, **kwargs)
@@ -185,7 +186,16 @@ class FilterPredictor(nn.Module):
             be[0].weight, be[0].bias, be[1].weight, be[1].bias, be[1].running_mean, be[1].running_var,
             be[3].weight, be[3].bias, be[4].weight, be[4].bias, be[4].running_mean, be[4].running_var,
             be[6].weight, be[6].bias, self.query_embed_fg.weight, test_tok]
-        return self._pack.get(tensors)
+        pack = self._pack.get(tensors)
+        if self._prep_key != self._pack.key:                # weights changed: fold the decoder's weight products again
+            L = _lib.lib()
+            dims = self._dims(1, 1)
+            self._prepared = torch.empty(L.pt_tomp_prepared_floats(ctypes.byref(dims)), dtype=torch.float32,
+                                         device=pack.device)
+            _lib.check(L.pt_tomp_prepare_f32(ctypes.byref(dims), _ptr(pack), _ptr(self._prepared), _stream()),
+                       "pt_tomp_prepare_f32")
+            self._prep_key = self._pack.key
+        return pack, self._prepared
 
     def _dims(self, H, W):
         t = self.transformer
@@ -236,7 +246,8 @@ class FilterPredictor(nn.Module):
         B = 2 if parallel else ns
         filters = torch.empty(B, D, dtype=torch.float32, device=dev)
         enc = torch.empty(B, D, H, W, dtype=torch.float32, device=dev)
-        rc = L.pt_tomp_predict_f32(ctypes.byref(dims), _ptr(self._params()), _ptr(self._pos_table(H, W, dev)),
+        pack, prepared = self._params()
+        rc = L.pt_tomp_predict_f32(ctypes.byref(dims), _ptr(pack), _ptr(prepared), _ptr(self._pos_table(H, W, dev)),
                                    _ptr(train_feat), _ptr(test_feat), _ptr(train_label), _ptr(train_ltrb_target), nf, ns,
                                    int(parallel), int(num_gth_frames), _ptr(filters), _ptr(enc), _ptr(ws), ws.numel(),
                                    _stream())

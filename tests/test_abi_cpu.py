@@ -88,7 +88,11 @@ def test_tomp_argument_checks(L):
     assert L.pt_tomp_predict_ws_bytes(ctypes.byref(d), 2, 9, 0) == 0            # more than 8 batch rows
     bad = _lib.TompDims(256, 5, 2048, 6, 6, 18, 18, 18)
     assert L.pt_tomp_param_floats(ctypes.byref(bad)) == 0
-    a = [one] * 5
+    a = [one] * 6
+    assert L.pt_tomp_prepared_floats(ctypes.byref(d)) >= 6 * (256 * 256 + 2 * 8 * 256 * 256)
+    assert L.pt_tomp_prepared_floats(ctypes.byref(bad)) == 0
+    assert L.pt_tomp_prepare_f32(ctypes.byref(d), n, one, n) == -1
+    assert L.pt_tomp_prepare_f32(ctypes.byref(bad), one, one, n) == -2
     assert L.pt_tomp_predict_f32(ctypes.byref(d), n, *a, 2, 1, 1, 1, one, one, one, 1 << 30, n) == -1
     assert L.pt_tomp_predict_f32(ctypes.byref(bad), one, *a, 2, 1, 1, 1, one, one, one, 1 << 30, n) == -2
     assert L.pt_tomp_predict_f32(ctypes.byref(d), one, *a, 2, 1, 1, 3, one, one, one, 1 << 30, n) == -2   # num_gth > n_train
