@@ -227,6 +227,19 @@ int pt_tomp_bbreg_f32(const float* params, const float* feat, const float* filte
                       int H, int W, void* ws, size_t ws_bytes, void* stream);
 
 /* ------------------------------------------------------------------------------------------------
+ * Classification-feature head -- `residual_bottleneck(num_blocks=0, final_conv=True, l2norm=True)`
+ * (ltr/models/target_classifier/features.py:49-73): Conv2d(Cin, Cout, 3, padding=1, bias=False) followed by
+ * InstanceL2Norm(size_average=True, eps, scale) (ltr/models/layers/normalization.py:15-20), as DiMP-50 (1024 -> 512,
+ * dimpnet.py:169-172) and ToMP (1024 -> 256, tompnet.py:99-102; run on three frames per tracked frame) build it.
+ *   feat (n, Cin, H, W); weight_tap_major (Cout, ky, kx, Cin) = the reference's (Cout, Cin, 3, 3) tensor permuted
+ *   (0,2,3,1); out (n, Cout, H, W) = conv * norm_scale * sqrt(Cout*H*W / (sum over the image of conv^2 + eps)).
+ * Covered: Cin % 64 == 0, Cout % 4 == 0.
+ * ---------------------------------------------------------------------------------------------- */
+size_t pt_clf_head_ws_bytes(int n, int Cin, int Cout, int H, int W);
+int pt_clf_head_f32(const float* feat, const float* weight_tap_major, float* out, int n, int Cin, int Cout, int H, int W,
+                    float norm_scale, float eps, void* ws, size_t ws_bytes, void* stream);
+
+/* ------------------------------------------------------------------------------------------------
  * Precise RoI Pooling -- replaces ltr/external/PreciseRoIPooling (empty git submodule;
  * import sites ltr/models/target_classifier/initializer.py:4,18,45 and
  * ltr/models/bbreg/atom_iou_net.py:4,31-32,41-42,126-127,157,160).

@@ -344,11 +344,31 @@ def gen_tomp():
     run("full", synth.TOMP, 83, False)          # BASELINE configs[3] geometry: 256 channels, 8 heads, 6+6 layers, 18x18
 
 
+def gen_clf_head():
+    """Classification-feature head: the reference's residual_bottleneck(num_blocks=0, final_conv=True, l2norm=True)
+    (features.py:49-73) on CPU."""
+    import ltr.models.target_classifier.features as rfeat
+    rng = np.random.default_rng(97)
+    out = {}
+    for tag, n, cin, cout, H, W, scale in (("a", 2, 64, 32, 6, 7, 0.0625), ("b", 3, 128, 24, 5, 5, 1.0)):
+        head = rfeat.residual_bottleneck(feature_dim=cin // 4, num_blocks=0, l2norm=True, final_conv=True,
+                                         norm_scale=scale, out_dim=cout).eval()
+        w = (rng.standard_normal((cout, cin, 3, 3), dtype=np.float32) * np.float32(0.05))
+        head[0].weight.data.copy_(T(w))
+        x = rng.standard_normal((n, cin, H, W), dtype=np.float32)
+        with torch.no_grad():
+            y = head(T(x))
+        out.update({f"{tag}_x": x, f"{tag}_w": w, f"{tag}_y": y.numpy(), f"{tag}_scale": scale})
+    save("clf_head", **out)
+
+
 if __name__ == "__main__":
     torch.set_num_threads(8)
-    which = sys.argv[1:] or ["filter", "dimp", "l2", "prdimp", "atom", "prroi", "lwl", "atomgn", "tomp"]
+    which = sys.argv[1:] or ["filter", "dimp", "l2", "prdimp", "atom", "prroi", "lwl", "atomgn", "tomp", "head"]
     if "tomp" in which:
         gen_tomp()
+    if "head" in which:
+        gen_clf_head()
     if "atomgn" in which:
         gen_atom_gn()
     if "lwl" in which:

@@ -608,3 +608,17 @@ def prroi_backward_coor(grad_out, features, rois, PH, PW, scale):
     gr[:, 2] = (g * (d_ys * (1 - p / PH) + d_ye * (1 - (p + 1) / PH))).sum(axis=(1, 2, 3))
     gr[:, 4] = (g * (d_ys * (p / PH) + d_ye * ((p + 1) / PH))).sum(axis=(1, 2, 3))
     return gr * dt.type(scale)
+
+
+# --------------------------------------------------------------------------------------------
+# classification-feature head: ltr/models/target_classifier/features.py:49-73 (num_blocks=0, final_conv, l2norm)
+# --------------------------------------------------------------------------------------------
+
+def clf_head(feat, weight, scale=1.0, eps=1e-5):
+    """Conv2d(Cin, Cout, 3, padding=1, bias=False) (features.py:66) followed by InstanceL2Norm(size_average=True)
+    (normalization.py:15-18): x * scale * sqrt(C*H*W / (sum_{c,h,w} x^2 + eps)) per image.
+      feat (n,Cin,H,W), weight (Cout,Cin,3,3) -> (n,Cout,H,W)."""
+    x = apply_filter(feat, weight)
+    n, C, H, W = x.shape
+    ss = (x * x).reshape(n, -1).sum(axis=1).reshape(n, 1, 1, 1)
+    return x * (scale * np.sqrt((C * H * W) / (ss + eps)))

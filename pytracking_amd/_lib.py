@@ -33,6 +33,7 @@ EXPORTS = [
     "pt_lwl_ws_bytes", "pt_lwl_gn_solve_f32",
     "pt_tomp_param_floats", "pt_tomp_prepared_floats", "pt_tomp_prepare_f32", "pt_tomp_posenc_f32", "pt_tomp_predict_ws_bytes", "pt_tomp_predict_f32", "pt_tomp_linear_f32",
     "pt_tomp_bbreg_param_floats", "pt_tomp_bbreg_ws_bytes", "pt_tomp_bbreg_f32",
+    "pt_clf_head_ws_bytes", "pt_clf_head_f32",
     "pt_profile_create", "pt_profile_attach", "pt_profile_collect", "pt_profile_reset", "pt_profile_destroy",
 ]
 
@@ -154,6 +155,10 @@ def lib():
     L.pt_tomp_bbreg_ws_bytes.argtypes = [i, i, i, i]
     L.pt_tomp_bbreg_f32.restype = i
     L.pt_tomp_bbreg_f32.argtypes = [vp, vp, vp, vp, i, i, i, i, vp, sz, vp]
+    L.pt_clf_head_ws_bytes.restype = sz
+    L.pt_clf_head_ws_bytes.argtypes = [i] * 5
+    L.pt_clf_head_f32.restype = i
+    L.pt_clf_head_f32.argtypes = [vp, vp, vp, i, i, i, i, i, f, f, vp, sz, vp]
     L.pt_profile_create.restype = i
     L.pt_profile_create.argtypes = [ctypes.POINTER(vp), i]
     L.pt_profile_attach.restype = i

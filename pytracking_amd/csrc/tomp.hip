@@ -1324,3 +1324,107 @@ extern "C" int pt_tomp_bbreg_f32(const float* params, const float* feat, const f
     PT_CHECK_LAUNCH();
     return PT_OK;
 }
+
+// ==================================================================================================================
+// Classification-feature head: `residual_bottleneck(num_blocks=0, final_conv=True,
+// l2norm=True)` = Conv2d(Cin, Cout, 3, padding=1, bias=False) + InstanceL2Norm (ltr/models/target_classifier/
+// features.py:49-73, ltr/models/layers/normalization.py:15-20).  DiMP-50 runs it once per frame (1024 -> 512), ToMP on
+// the test frame and on both memory frames every frame (1024 -> 256, tomp.py:289-290).
+//   NCHW -> token-major transpose, 9 per-tap partial GEMMs on the MFMA kernel above (split-K), fixed-order reduction
+//   with the per-image sum of squares, normalise + transpose back to NCHW.
+// ==================================================================================================================
+namespace {
+
+__global__ __launch_bounds__(256) void k_nchw_to_tokens(const float* in, float* X, int C, int HW) {
+    __shared__ float tile[32][33];
+    const int tx = threadIdx.x & 31, ty = threadIdx.x >> 5;
+    const int p0 = blockIdx.x * 32, c0 = blockIdx.y * 32, img = blockIdx.z;
+    const float* src = in + (long)img * C * HW;
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+        const int c = c0 + ty + 8 * i, p = p0 + tx;
+        tile[ty + 8 * i][tx] = (c < C && p < HW) ? src[(long)c * HW + p] : 0.f;
+    }
+    __syncthreads();
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+        const int p = p0 + ty + 8 * i, c = c0 + tx;
+        if (p < HW && c < C) X[((long)img * HW + p) * C + c] = tile[tx][ty + 8 * i];
+    }
+}
+
+// out[img][c][p] = x[img*HW + p][c] * scale * sqrt(C*HW / (sum x^2 + eps)); the per-image sum of squares comes from the
+// slice partials of k_gn_reduce (double, fixed order)
+__global__ __launch_bounds__(256) void k_head_finish(const float* X, const float* stats, int slices, float* out, int C,
+                                                     int HW, float scale, float eps) {
+    __shared__ float tile[32][33];
+    const int tx = threadIdx.x & 31, ty = threadIdx.x >> 5;
+    const int p0 = blockIdx.x * 32, c0 = blockIdx.y * 32, img = blockIdx.z;
+    double q = 0.0;
+    for (int k = 0; k < slices; ++k) q += (double)stats[((long)img * slices + k) * 2 + 1];
+    const float f = scale * (float)sqrt((double)C * HW / (q + (double)eps));
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+        const int p = p0 + ty + 8 * i, c = c0 + tx;
+        tile[ty + 8 * i][tx] = (p < HW && c < C) ? X[((long)img * HW + p) * C + c] * f : 0.f;
+    }
+    __syncthreads();
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+        const int c = c0 + ty + 8 * i, p = p0 + tx;
+        if (c < C && p < HW) out[((long)img * C + c) * HW + p] = tile[tx][ty + 8 * i];
+    }
+}
+
+struct HeadCarve { size_t X, part, Y, stats, total; int slices; };
+HeadCarve head_carve(int n, int Cin, int Cout, int H, int W) {
+    HeadCarve c{};
+    const size_t M = (size_t)n * H * W;
+    size_t o = 0;
+    auto take = [&](size_t k) { size_t r = o; o += pt_align_floats(k); return r; };
+    c.slices = (int)(((size_t)H * W * Cout + GN_SLICE - 1) / GN_SLICE);
+    c.X = take(M * Cin); c.part = take(9 * M * Cout); c.Y = take(M * Cout); c.stats = take((size_t)2 * n * c.slices);
+    c.total = o;
+    return c;
+}
+
+int head_check(int n, int Cin, int Cout, int H, int W) {
+    if (n <= 0 || Cin <= 0 || Cout <= 0 || H <= 0 || W <= 0) return PT_ERR_SHAPE;
+    if (Cin % 64 != 0 || Cout % 4 != 0 || (size_t)n * H * W * Cin * 4 > 0xFFFFFFE0ull ||
+        (size_t)Cout * 9 * Cin * 4 > 0xFFFFFFE0ull)
+        return PT_ERR_UNSUPPORTED;
+    return PT_OK;
+}
+
+}  // namespace
+
+extern "C" size_t pt_clf_head_ws_bytes(int n, int Cin, int Cout, int H, int W) {
+    if (head_check(n, Cin, Cout, H, W)) return 0;
+    return head_carve(n, Cin, Cout, H, W).total * sizeof(float);
+}
+
+extern "C" int pt_clf_head_f32(const float* feat, const float* weight_tap_major, float* out, int n, int Cin, int Cout,
+                               int H, int W, float norm_scale, float eps, void* ws, size_t ws_bytes, void* stream) {
+    if (!feat || !weight_tap_major || !out || !ws) return PT_ERR_NULL;
+    int rc = head_check(n, Cin, Cout, H, W);
+    if (rc) return rc;
+    const HeadCarve cv = head_carve(n, Cin, Cout, H, W);
+    if (ws_bytes < cv.total * sizeof(float) || ((uintptr_t)ws % 256) != 0) return PT_ERR_WORKSPACE;
+    hipStream_t st = (hipStream_t)stream;
+    float* base = (float*)ws;
+    const int HW = H * W, M = n * HW;
+    hipLaunchKernelGGL(k_nchw_to_tokens, dim3((HW + 31) / 32, (Cin + 31) / 32, n), dim3(256), 0, st, feat, base + cv.X, Cin,
+                       HW);
+    PT_CHECK_LAUNCH();
+    const long zs = (long)M * Cout;
+    GemmArgs g = gemm_args(base + cv.X, Cin, M, weight_tap_major, M, Cout, 9 * Cin, nullptr, base + cv.part, Cout);
+    g.H = H; g.Wd = W; g.Cin = Cin; g.HW = HW; g.ksteps = Cin / 64; g.c_zstride = zs;
+    if ((rc = launch_gemm(g, st, true))) return rc;
+    hipLaunchKernelGGL(k_gn_reduce, dim3(cv.slices, n), dim3(256), 0, st, base + cv.part, 9, zs, base + cv.Y,
+                       base + cv.stats, HW * Cout);
+    PT_CHECK_LAUNCH();
+    hipLaunchKernelGGL(k_head_finish, dim3((HW + 31) / 32, (Cout + 31) / 32, n), dim3(256), 0, st, base + cv.Y,
+                       base + cv.stats, cv.slices, out, Cout, HW, norm_scale, eps);
+    PT_CHECK_LAUNCH();
+    return PT_OK;
+}

@@ -18,6 +18,8 @@ What gets rebound (import path = contract; nothing in the reference tree is edit
   ltr.models.transformer.transformer.Transformer, ltr.models.transformer.filter_predictor.FilterPredictor,
   ltr.models.transformer.heads.{LinearFilterClassifier, DenseBoxRegressor}
                                                   (ToMP model predictor, inference)   -> pytracking_amd.transformer
+  ltr.models.target_classifier.features.residual_bottleneck  (final 3x3 conv + InstanceL2Norm, inference)
+                                                                                      -> pytracking_amd.features
 
 Dispatch rule of the rebound *functions*: device fp32 tensors of a shape the gfx950 kernels cover go to the C ABI;
 everything else (CPU tensors, dilations, grouped filters, K*K > 16, more than 16 filters) is outside the hot path and
@@ -153,7 +155,42 @@ def _install_tomp(orig, strict):
     hmod.DenseBoxRegressor = DenseBoxRegressor
 
 
-def install(strict=False, atom_cg=True, tomp=True):
+def _install_clf_head(orig, strict):
+    """Classification-feature head: `clf_features.residual_bottleneck(...)` is reached through the module attribute by
+    every network constructor (dimpnet.py:169, tompnet.py:99).  Covered argument sets build the fused module around the
+    reference's own layer objects; on a CPU tensor / in training it runs those layers as `nn.Sequential` would."""
+    from . import features as _fm
+    try:
+        fmod = importlib.import_module("ltr.models.target_classifier.features")
+    except Exception:                   # torchvision (features.py:4) missing
+        return
+    ref_fn = fmod.residual_bottleneck
+    orig["clf_head"] = ref_fn
+
+    class ClfHead(_fm.ClfHead):
+        def forward(self, x):
+            fused = (x.is_cuda and x.dtype == torch.float32 and not self.training
+                     and not (torch.is_grad_enabled() and (x.requires_grad or self[0].weight.requires_grad)))
+            if fused:
+                return _fm.ClfHead.forward(self, x)
+            if strict:
+                raise NotImplementedError("clf feature head: call outside the gfx950 hot path")
+            return torch.nn.Sequential.forward(self, x)
+
+    def residual_bottleneck(*args, **kw):
+        seq = ref_fn(*args, **kw)
+        if _fm.covered(*args, **kw) and len(seq) == 2:
+            return ClfHead(seq[0], seq[1])                # the reference's Conv2d and InstanceL2Norm objects
+        if strict:
+            raise NotImplementedError("residual_bottleneck: configuration outside the gfx950 hot path")
+        return seq
+
+    residual_bottleneck.__doc__ = ref_fn.__doc__
+    residual_bottleneck.__wrapped__ = ref_fn
+    fmod.residual_bottleneck = residual_bottleneck
+
+
+def install(strict=False, atom_cg=True, tomp=True, clf_head=True):
     """Rebind the boundary symbols.  Call after the reference is importable (`sys.path`) and before networks or
     trackers are constructed.  Idempotent."""
     if _state["installed"]:
@@ -194,6 +231,8 @@ def install(strict=False, atom_cg=True, tomp=True):
         smod.GNSteepestDescent = GNSteepestDescent
     if tomp:
         _install_tomp(orig, strict)
+    if clf_head:
+        _install_clf_head(orig, strict)
     if atom_cg:
         try:
             pmod = importlib.import_module("pytracking.libs.optimization")
@@ -268,6 +307,8 @@ def uninstall():
         importlib.import_module("ltr.models.transformer.filter_predictor").FilterPredictor = orig["tomp"][1]
         hm = importlib.import_module("ltr.models.transformer.heads")
         hm.LinearFilterClassifier, hm.DenseBoxRegressor = orig["tomp"][2], orig["tomp"][3]
+    if "clf_head" in orig:
+        importlib.import_module("ltr.models.target_classifier.features").residual_bottleneck = orig["clf_head"]
     if "lwl" in orig:
         importlib.import_module("ltr.models.lwl.loss_residual_modules").LWTLResidual = orig["lwl"][0]
         importlib.import_module("ltr.models.meta.steepestdescent").GNSteepestDescent = orig["lwl"][1]

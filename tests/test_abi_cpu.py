@@ -106,6 +106,17 @@ def test_tomp_argument_checks(L):
     assert L.pt_tomp_posenc_f32(one, 18, 18, 255, 18, n) == -2
 
 
+def test_clf_head_argument_checks(L):
+    n = None
+    one = ctypes.c_void_p(256)
+    assert L.pt_clf_head_ws_bytes(1, 1024, 512, 18, 18) > 0
+    assert L.pt_clf_head_ws_bytes(1, 1000, 512, 18, 18) == 0
+    assert L.pt_clf_head_f32(n, one, one, 1, 1024, 512, 18, 18, 1.0, 1e-5, one, 1 << 30, n) == -1
+    assert L.pt_clf_head_f32(one, one, one, 0, 1024, 512, 18, 18, 1.0, 1e-5, one, 1 << 30, n) == -2
+    assert L.pt_clf_head_f32(one, one, one, 1, 1000, 512, 18, 18, 1.0, 1e-5, one, 1 << 30, n) == -3
+    assert L.pt_clf_head_f32(one, one, one, 1, 1024, 512, 18, 18, 1.0, 1e-5, one, 0, n) == -4
+
+
 def test_tomp_mirror_contract():
     """Constructor signatures and refusals of the ToMP mirror (no device work)."""
     from pytracking_amd import transformer as TM

@@ -556,3 +556,39 @@ def test_tomp_encoder_blocks_vs_oracle(nhead):
         rw, renc = TO.predict_filter(p64, f64(tr), f64(te), f64(lb), f64(lt), *a)
         close(w.reshape(2, -1), rw, atol=5e-5, rtol=1e-4)
         close(enc, renc, atol=5e-5, rtol=1e-4)
+
+
+# ------------------------------------------------------------------------------------------------------
+# classification-feature head
+# ------------------------------------------------------------------------------------------------------
+def _clf_head(cin, cout, scale, w):
+    from pytracking_amd import features as FM
+    head = FM.residual_bottleneck(feature_dim=cin // 4, num_blocks=0, l2norm=True, final_conv=True, norm_scale=scale,
+                                  out_dim=cout)
+    head.load_state_dict({"0.weight": torch.from_numpy(w.copy())}, strict=True)
+    return head.to(DEV).eval()
+
+
+@pytest.mark.parametrize("tag", ["a", "b"])
+def test_clf_head_golden(tag):
+    g = load_golden("clf_head")
+    x, w = g[f"{tag}_x"], g[f"{tag}_w"]
+    head = _clf_head(w.shape[1], w.shape[0], float(g[f"{tag}_scale"]), w)
+    with torch.no_grad():
+        close(head(T(x)), g[f"{tag}_y"], atol=2e-5, rtol=1e-4)
+        close(head(T(x)[:, None])[:, 0], g[f"{tag}_y"], atol=2e-5, rtol=1e-4)      # leading dims are preserved
+
+
+@pytest.mark.parametrize("n,cout", [(1, 512), (3, 256)])
+def test_clf_head_tracker_sizes_vs_oracle(n, cout):
+    """DiMP-50 (1024 -> 512, one frame) and ToMP (1024 -> 256, test + two memory frames) at 18x18."""
+    rng = np.random.default_rng(33)
+    x = rng.standard_normal((n, 1024, 18, 18), dtype=np.float32)
+    w = rng.standard_normal((cout, 1024, 3, 3), dtype=np.float32) * np.float32(0.02)
+    scale = float(np.sqrt(1.0 / (cout * 16)))
+    head = _clf_head(1024, cout, scale, w)
+    with torch.no_grad():
+        y = head(T(x))
+    ref = O.clf_head(x.astype(np.float64), w.astype(np.float64), scale)
+    close(y, ref, atol=1e-6, rtol=1e-4)
+    assert abs(float((y * y).sum(dim=(1, 2, 3)).mean()) - scale * scale * cout * 324) < 1e-3 * scale * scale * cout * 324

@@ -75,3 +75,31 @@ def test_tomp_mirror_state_dict_matches_reference_and_install_dispatch():
     finally:
         amd.uninstall()
     assert rt.Transformer is orig_tr
+
+
+def test_clf_head_install_dispatch():
+    """After install() `residual_bottleneck` builds the fused head around the reference's own layers for the trackers'
+    configuration (same state_dict, CPU call = the reference's nn.Sequential), the reference module otherwise."""
+    ref_harness.install()
+    import ltr.models.target_classifier.features as rfeat
+    from pytracking_amd import install as amd, features as FM
+    ref_fn = rfeat.residual_bottleneck
+    ref = ref_fn(feature_dim=16, num_blocks=0, l2norm=True, final_conv=True, norm_scale=0.5, out_dim=8)
+    amd.install()
+    try:
+        head = rfeat.residual_bottleneck(feature_dim=16, num_blocks=0, l2norm=True, final_conv=True, norm_scale=0.5, out_dim=8)
+        assert isinstance(head, FM.ClfHead)
+        assert list(head.state_dict().keys()) == list(ref.state_dict().keys()) == ["0.weight"]
+        head.load_state_dict(ref.state_dict(), strict=True)
+        x = torch.randn(2, 64, 5, 5)
+        with torch.no_grad():
+            torch.testing.assert_close(head.eval()(x), ref.eval()(x))                 # CPU tensor -> the reference's layers
+        other = rfeat.residual_bottleneck(feature_dim=16, num_blocks=0, l2norm=False, final_conv=True, out_dim=8)
+        assert not isinstance(other, FM.ClfHead)
+    finally:
+        amd.uninstall()
+    assert rfeat.residual_bottleneck is ref_fn
+    mine = FM.residual_bottleneck(feature_dim=16, num_blocks=0, l2norm=True, final_conv=True, out_dim=8)
+    assert list(mine.state_dict().keys()) == ["0.weight"]
+    with pytest.raises(NotImplementedError):
+        FM.residual_bottleneck(feature_dim=16, num_blocks=1, final_conv=True)

@@ -181,3 +181,11 @@ def test_tomp_model_predictor(name, cfg):
         w1, enc1 = TO.predict_filter(p, train, test, lab, ltrb, *a)
         np.testing.assert_allclose(w1[0], g["single_filter"], atol=2e-5)
         np.testing.assert_allclose(enc1, g["single_enc"], atol=2e-5)
+
+
+@pytest.mark.parametrize("tag", ["a", "b"])
+def test_clf_head(tag):
+    """Conv2d 3x3 (no bias) + InstanceL2Norm as residual_bottleneck builds it (features.py:49-73)."""
+    g = load_golden("clf_head")
+    y = O.clf_head(g[f"{tag}_x"].astype(np.float64), g[f"{tag}_w"].astype(np.float64), float(g[f"{tag}_scale"]))
+    np.testing.assert_allclose(y, g[f"{tag}_y"], atol=2e-6, rtol=2e-5)
