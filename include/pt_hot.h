@@ -240,6 +240,23 @@ int pt_clf_head_f32(const float* feat, const float* weight_tap_major, float* out
                     float norm_scale, float eps, void* ws, size_t ws_bytes, void* stream);
 
 /* ------------------------------------------------------------------------------------------------
+ * Target localisation on the device -- the score-map arithmetic of DiMP/ToMP `localize_advanced`
+ * (pytracking/tracker/dimp/dimp.py:238-303, pytracking/tracker/tomp/tomp.py) and `dcf.max2d`
+ * (pytracking/libs/dcf.py:156-164), one launch, results left on the device for a single copy.
+ *   pt_max2d_f32: a (n, H, W) -> max_val (n), argmax (n, 2) int64 [row, col]; ties: smallest column, then smallest row
+ *     (the order torch.max over rows, then over columns produces).
+ *   pt_localize_f32: scores (S, H, W) [S <= 8 scales], scores_hn (S, H, W) or NULL (= scores): the map the second
+ *     peak is searched in (`perform_hn_without_windowing`, dimp.py:247-250); neigh_rows / neigh_cols: HOST arrays of S
+ *     floats = target_neigh_sz of each scale in score cells (dimp.py:268).
+ *     out8 (device) = [max1, row1, col1, scale_ind, max2, row2, col2, 0]: first peak over all scales (first scale on
+ *     ties), second peak of scores_hn[scale_ind] with rows [round(row1 - nr/2), round(row1 + nr/2 + 1)) x the same in
+ *     columns, clamped to the map, ZEROED (dimp.py:270-278; Python round() = half-to-even).
+ * ---------------------------------------------------------------------------------------------- */
+int pt_max2d_f32(const float* a, float* max_val, long long* argmax, int n, int H, int W, void* stream);
+int pt_localize_f32(const float* scores, const float* scores_hn, const float* neigh_rows, const float* neigh_cols,
+                    float* out8, int S, int H, int W, void* stream);
+
+/* ------------------------------------------------------------------------------------------------
  * Precise RoI Pooling -- replaces ltr/external/PreciseRoIPooling (empty git submodule;
  * import sites ltr/models/target_classifier/initializer.py:4,18,45 and
  * ltr/models/bbreg/atom_iou_net.py:4,31-32,41-42,126-127,157,160).

@@ -344,6 +344,59 @@ def gen_tomp():
     run("full", synth.TOMP, 83, False)          # BASELINE configs[3] geometry: 256 channels, 8 heads, 6+6 layers, 18x18
 
 
+def gen_localize():
+    """`DiMP.localize_advanced` (dimp.py:238-303) of the unmodified reference on CPU, called unbound on a stand-in object
+    that carries exactly the attributes the method reads."""
+    import types
+    from pytracking.tracker.dimp.dimp import DiMP
+    from pytracking.utils import TrackerParams
+    rng = np.random.default_rng(131)
+    cases = []
+    for i in range(48):
+        S = 1 if i % 3 else 2
+        H = W = 19 if i % 2 else 23
+        K = 4 if i % 2 else 5
+        params = TrackerParams()
+        params.target_not_found_threshold = 0.25
+        params.distractor_threshold = 0.8
+        params.hard_negative_threshold = 0.5
+        params.target_neighborhood_scale = 2.2
+        params.dispalcement_scale = 0.8
+        if i % 7 == 3:
+            params.uncertain_threshold = 0.45
+        if i % 11 == 5:
+            params.hard_sample_threshold = 0.5
+        base = rng.standard_normal((S, H, W)).astype(np.float32) * np.float32(0.05)
+        peak = float(rng.choice([0.15, 0.4, 0.7, 1.0]))
+        yy, xx = np.mgrid[0:H, 0:W]
+        r1, c1 = rng.integers(3, H - 3, 2)
+        base[rng.integers(0, S)] += (peak * np.exp(-((yy - r1) ** 2 + (xx - c1) ** 2) / 3.0)).astype(np.float32)
+        if i % 2 == 0:                                           # a distractor of comparable height somewhere else
+            r2, c2 = rng.integers(2, H - 2, 2)
+            base[rng.integers(0, S)] += (peak * float(rng.uniform(0.4, 1.05)) *
+                                         np.exp(-((yy - r2) ** 2 + (xx - c2) ** 2) / 3.0)).astype(np.float32)
+        if i % 13 == 0:                                          # exact ties: the first peak twice
+            base[0, 2, 5] = base[0, 7, 5] = base[0, 7, 3] = np.float32(peak + 0.5)
+        me = types.SimpleNamespace(params=params, kernel_size=torch.Tensor([K, K]), output_window=None,
+                                   img_support_sz=torch.Tensor([288.0, 288.0]) * (22 / 18 if H == 23 else 1),
+                                   target_sz=torch.Tensor(rng.uniform(30, 120, 2).astype(np.float32)),
+                                   pos=torch.Tensor(rng.uniform(100, 200, 2).astype(np.float32)))
+        sample_scales = torch.Tensor(rng.uniform(0.8, 1.3, S).astype(np.float32))
+        sample_pos = me.pos.reshape(1, 2) + torch.Tensor(rng.uniform(-25, 25, (S, 2)).astype(np.float32))
+        tv, scale_ind, _, flag = DiMP.localize_advanced(me, T(base.copy()), sample_pos, sample_scales)
+        cases.append(dict(scores=base, K=K, img_support_sz=me.img_support_sz.numpy(), target_sz=me.target_sz.numpy(),
+                          pos=me.pos.numpy(), sample_scales=sample_scales.numpy(), sample_pos=sample_pos.numpy(),
+                          uncertain=params.get('uncertain_threshold', -np.inf), hard_sample=params.get('hard_sample_threshold', -np.inf),
+                          tv=tv.numpy(), scale_ind=int(scale_ind), flag=flag))
+    flags = sorted(set(c["flag"] for c in cases))
+    print("flags covered:", {f: sum(c["flag"] == f for c in cases) for f in flags})
+    out = {"n": len(cases)}
+    for i, c in enumerate(cases):
+        for k, v in c.items():
+            out[f"c{i}_{k}"] = v
+    save("localize", **out)
+
+
 def gen_clf_head():
     """Classification-feature head: the reference's residual_bottleneck(num_blocks=0, final_conv=True, l2norm=True)
     (features.py:49-73) on CPU."""
@@ -364,11 +417,13 @@ def gen_clf_head():
 
 if __name__ == "__main__":
     torch.set_num_threads(8)
-    which = sys.argv[1:] or ["filter", "dimp", "l2", "prdimp", "atom", "prroi", "lwl", "atomgn", "tomp", "head"]
+    which = sys.argv[1:] or ["filter", "dimp", "l2", "prdimp", "atom", "prroi", "lwl", "atomgn", "tomp", "head", "localize"]
     if "tomp" in which:
         gen_tomp()
     if "head" in which:
         gen_clf_head()
+    if "localize" in which:
+        gen_localize()
     if "atomgn" in which:
         gen_atom_gn()
     if "lwl" in which:

@@ -622,3 +622,31 @@ def clf_head(feat, weight, scale=1.0, eps=1e-5):
     n, C, H, W = x.shape
     ss = (x * x).reshape(n, -1).sum(axis=1).reshape(n, 1, 1, 1)
     return x * (scale * np.sqrt((C * H * W) / (ss + eps)))
+
+
+# --------------------------------------------------------------------------------------------
+# target localisation: pytracking/libs/dcf.py:156-164, pytracking/tracker/dimp/dimp.py:238-303
+# --------------------------------------------------------------------------------------------
+
+def max2d(a):
+    """dcf.max2d for one (H, W) map: maximum over rows, then over columns, first index on ties."""
+    rows = a.argmax(axis=0)                       # numpy argmax returns the first maximum, like torch.max
+    col = int(a.max(axis=0).argmax())
+    return a[rows[col], col], (int(rows[col]), col)
+
+
+def two_peaks(scores, scores_hn, neigh):
+    """The 8 numbers `localize_advanced` derives from the score maps (dimp.py:252-281): scores / scores_hn (S,H,W),
+    neigh (S,2) target neighbourhood in cells.  Python round() (half to even) on doubles for the bounds."""
+    S, H, W = scores.shape
+    peaks = [max2d(scores[s]) for s in range(S)]
+    s1 = int(np.argmax(np.array([p[0] for p in peaks], dtype=np.float32)))
+    m1, (r1, c1) = peaks[s1]
+    top = max(round(float(r1) - float(neigh[s1][0]) / 2), 0)
+    bottom = min(round(float(r1) + float(neigh[s1][0]) / 2 + 1), H)
+    left = max(round(float(c1) - float(neigh[s1][1]) / 2), 0)
+    right = min(round(float(c1) + float(neigh[s1][1]) / 2 + 1), W)
+    masked = np.array(scores_hn[s1], copy=True)
+    masked[top:bottom, left:right] = 0
+    m2, (r2, c2) = max2d(masked)
+    return np.array([m1, r1, c1, s1, m2, r2, c2, 0], dtype=np.float64)

@@ -9,7 +9,7 @@ import subprocess
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.environ.get("PT_HOT_LIB", os.path.join(_HERE, "libpt_hot.so"))   # override: experiments only
-SOURCES = ["filter_kernels.hip", "fast_passes.hip", "sd_solver.hip", "mf_kernels.hip", "lwl_solver.hip", "atom_cg.hip", "atom_gn.hip", "tomp.hip", "prroi.hip", "api.hip", "profile.hip"]
+SOURCES = ["filter_kernels.hip", "fast_passes.hip", "sd_solver.hip", "mf_kernels.hip", "lwl_solver.hip", "atom_cg.hip", "atom_gn.hip", "tomp.hip", "localize.hip", "prroi.hip", "api.hip", "profile.hip"]
 HEADERS = ["common.h", "pt_internal.h", "rbuild.h", "sd_common.h", os.path.join("..", "..", "include", "pt_hot.h")]
 
 PT_SD_DIMP, PT_SD_DIMP_L2, PT_SD_PRDIMP = 0, 1, 2
@@ -33,7 +33,7 @@ EXPORTS = [
     "pt_lwl_ws_bytes", "pt_lwl_gn_solve_f32",
     "pt_tomp_param_floats", "pt_tomp_prepared_floats", "pt_tomp_prepare_f32", "pt_tomp_posenc_f32", "pt_tomp_predict_ws_bytes", "pt_tomp_predict_f32", "pt_tomp_linear_f32",
     "pt_tomp_bbreg_param_floats", "pt_tomp_bbreg_ws_bytes", "pt_tomp_bbreg_f32",
-    "pt_clf_head_ws_bytes", "pt_clf_head_f32",
+    "pt_clf_head_ws_bytes", "pt_clf_head_f32", "pt_max2d_f32", "pt_localize_f32",
     "pt_profile_create", "pt_profile_attach", "pt_profile_collect", "pt_profile_reset", "pt_profile_destroy",
 ]
 
@@ -159,6 +159,11 @@ def lib():
     L.pt_clf_head_ws_bytes.argtypes = [i] * 5
     L.pt_clf_head_f32.restype = i
     L.pt_clf_head_f32.argtypes = [vp, vp, vp, i, i, i, i, i, f, f, vp, sz, vp]
+    L.pt_max2d_f32.restype = i
+    L.pt_max2d_f32.argtypes = [vp, vp, vp, i, i, i, vp]
+    fp = ctypes.POINTER(ctypes.c_float)
+    L.pt_localize_f32.restype = i
+    L.pt_localize_f32.argtypes = [vp, vp, fp, fp, vp, i, i, i, vp]
     L.pt_profile_create.restype = i
     L.pt_profile_create.argtypes = [ctypes.POINTER(vp), i]
     L.pt_profile_attach.restype = i

@@ -20,6 +20,8 @@ What gets rebound (import path = contract; nothing in the reference tree is edit
                                                   (ToMP model predictor, inference)   -> pytracking_amd.transformer
   ltr.models.target_classifier.features.residual_bottleneck  (final 3x3 conv + InstanceL2Norm, inference)
                                                                                       -> pytracking_amd.features
+  pytracking.libs.dcf.max2d, pytracking.tracker.dimp.dimp.DiMP.localize_advanced,
+  pytracking.tracker.tomp.tomp.ToMP.localize_advanced  (score-map localisation)       -> pytracking_amd.localization
 
 Dispatch rule of the rebound *functions*: device fp32 tensors of a shape the gfx950 kernels cover go to the C ABI;
 everything else (CPU tensors, dilations, grouped filters, K*K > 16, more than 16 filters) is outside the hot path and
@@ -190,7 +192,47 @@ def _install_clf_head(orig, strict):
     fmod.residual_bottleneck = residual_bottleneck
 
 
-def install(strict=False, atom_cg=True, tomp=True, clf_head=True):
+def _install_localization(orig, strict):
+    """`dcf.max2d` (function, reached as `dcf.max2d` by the trackers) and the `localize_advanced` methods of DiMP / ToMP:
+    one launch + one 32-byte copy per frame instead of ~10 host synchronisations."""
+    from . import localization as _loc
+    try:
+        dmod = importlib.import_module("pytracking.libs.dcf")
+    except Exception:
+        return
+    ref_max2d = dmod.max2d
+    orig["localization"] = {"max2d": ref_max2d}
+
+    def max2d(a):
+        if a.is_cuda and a.dtype == torch.float32:
+            return _loc.max2d(a)
+        if strict:
+            raise NotImplementedError("max2d: tensor outside the gfx950 hot path")
+        return ref_max2d(a)
+
+    max2d.__doc__, max2d.__wrapped__ = ref_max2d.__doc__, ref_max2d
+    dmod.max2d = max2d
+    for modname, clsname, fn in (("pytracking.tracker.dimp.dimp", "DiMP", _loc.localize_advanced),
+                                 ("pytracking.tracker.tomp.tomp", "ToMP", _loc.localize_advanced_tomp)):
+        try:
+            cls = getattr(importlib.import_module(modname), clsname)
+        except Exception:               # tracker module not importable here (cv2 ...): nothing to patch
+            continue
+        ref_method = cls.localize_advanced
+        orig["localization"][(modname, clsname)] = ref_method
+
+        def method(self, scores, sample_pos, sample_scales, _fast=fn, _ref=ref_method):
+            if scores.is_cuda and scores.dtype == torch.float32 and scores.dim() == 3 and scores.shape[0] <= 8:
+                return _fast(self, scores, sample_pos, sample_scales)
+            if strict:
+                raise NotImplementedError("localize_advanced: scores outside the gfx950 hot path")
+            return _ref(self, scores, sample_pos, sample_scales)
+
+        method.__doc__, method.__wrapped__ = ref_method.__doc__, ref_method
+        cls.localize_advanced = method
+
+
+def install(strict=False, atom_cg=True, tomp=True, clf_head=True, localization=True):
     """Rebind the boundary symbols.  Call after the reference is importable (`sys.path`) and before networks or
     trackers are constructed.  Idempotent."""
     if _state["installed"]:
@@ -233,6 +275,8 @@ def install(strict=False, atom_cg=True, tomp=True, clf_head=True):
         _install_tomp(orig, strict)
     if clf_head:
         _install_clf_head(orig, strict)
+    if localization:
+        _install_localization(orig, strict)
     if atom_cg:
         try:
             pmod = importlib.import_module("pytracking.libs.optimization")
@@ -309,6 +353,12 @@ def uninstall():
         hm.LinearFilterClassifier, hm.DenseBoxRegressor = orig["tomp"][2], orig["tomp"][3]
     if "clf_head" in orig:
         importlib.import_module("ltr.models.target_classifier.features").residual_bottleneck = orig["clf_head"]
+    if "localization" in orig:
+        for key, ref in orig["localization"].items():
+            if key == "max2d":
+                importlib.import_module("pytracking.libs.dcf").max2d = ref
+            else:
+                getattr(importlib.import_module(key[0]), key[1]).localize_advanced = ref
     if "lwl" in orig:
         importlib.import_module("ltr.models.lwl.loss_residual_modules").LWTLResidual = orig["lwl"][0]
         importlib.import_module("ltr.models.meta.steepestdescent").GNSteepestDescent = orig["lwl"][1]

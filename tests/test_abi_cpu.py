@@ -117,6 +117,17 @@ def test_clf_head_argument_checks(L):
     assert L.pt_clf_head_f32(one, one, one, 1, 1024, 512, 18, 18, 1.0, 1e-5, one, 0, n) == -4
 
 
+def test_localize_argument_checks(L):
+    n = None
+    one = ctypes.c_void_p(256)
+    f2 = (ctypes.c_float * 2)(3.0, 3.0)
+    assert L.pt_max2d_f32(n, one, one, 1, 19, 19, n) == -1
+    assert L.pt_max2d_f32(one, one, one, 0, 19, 19, n) == -2
+    assert L.pt_localize_f32(one, n, None, f2, one, 1, 19, 19, n) == -1
+    assert L.pt_localize_f32(one, n, f2, f2, one, 0, 19, 19, n) == -2
+    assert L.pt_localize_f32(one, n, f2, f2, one, 9, 19, 19, n) == -3
+
+
 def test_tomp_mirror_contract():
     """Constructor signatures and refusals of the ToMP mirror (no device work)."""
     from pytracking_amd import transformer as TM

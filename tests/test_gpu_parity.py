@@ -592,3 +592,39 @@ def test_clf_head_tracker_sizes_vs_oracle(n, cout):
     ref = O.clf_head(x.astype(np.float64), w.astype(np.float64), scale)
     close(y, ref, atol=1e-6, rtol=1e-4)
     assert abs(float((y * y).sum(dim=(1, 2, 3)).mean()) - scale * scale * cout * 324) < 1e-3 * scale * scale * cout * 324
+
+
+# ------------------------------------------------------------------------------------------------------
+# target localisation on the device
+# ------------------------------------------------------------------------------------------------------
+def test_localize_advanced_golden():
+    """pt_localize_f32 + the mirrored decision ladder vs the reference's DiMP.localize_advanced on 48 score maps
+    (all four outcomes, two scales, exact ties)."""
+    from pytracking_amd import localization as LM
+    from localize_cases import cases
+    for me, c in cases(load_golden("localize")):
+        scores = T(c["scores"].copy())
+        tv, scale_ind, s_out, flag = LM.localize_advanced(me, scores, torch.from_numpy(c["sample_pos"]),
+                                                          torch.from_numpy(c["sample_scales"]))
+        assert flag == str(c["flag"]) and int(scale_ind) == int(c["scale_ind"]) and s_out is scores
+        np.testing.assert_allclose(tv.numpy(), c["tv"], rtol=1e-6, atol=1e-6)
+        v = LM.two_peaks(scores, None, [np.array([3.3, 4.7], np.float32)] * scores.shape[0]).numpy().astype(np.float64)
+        ref = O.two_peaks(c["scores"], c["scores"], [np.array([3.3, 4.7], np.float32)] * scores.shape[0])
+        np.testing.assert_array_equal(v, ref)                               # bit-exact: values are copied, indices integral
+        tv5 = LM.localize_advanced_tomp(me, scores, torch.from_numpy(c["sample_pos"]), torch.from_numpy(c["sample_scales"]))
+        assert len(tv5) == 5 and tv5[3] == flag
+
+
+def test_max2d_vs_oracle_with_ties():
+    from pytracking_amd import localization as LM
+    rng = np.random.default_rng(8)
+    a = rng.standard_normal((3, 2, 19, 23)).astype(np.float32)
+    a[0, 0, 4, 7] = a[0, 0, 9, 7] = a[0, 0, 9, 2] = 9.0                      # ties: smallest column, then smallest row
+    a[2, 1] = 0.0                                                            # a constant map -> [0, 0]
+    mv, am = LM.max2d(T(a))
+    assert mv.shape == (3, 2) and am.shape == (3, 2, 2) and am.dtype == torch.int64
+    for i in range(3):
+        for j in range(2):
+            v, (r, c) = O.max2d(a[i, j])
+            assert float(mv[i, j]) == float(v) and am[i, j].tolist() == [r, c]
+    assert am[0, 0].tolist() == [9, 2]

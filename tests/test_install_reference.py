@@ -103,3 +103,24 @@ def test_clf_head_install_dispatch():
     assert list(mine.state_dict().keys()) == ["0.weight"]
     with pytest.raises(NotImplementedError):
         FM.residual_bottleneck(feature_dim=16, num_blocks=1, final_conv=True)
+
+
+def test_localization_install_dispatch():
+    """install() rebinds dcf.max2d and the trackers' localize_advanced; CPU tensors still take the reference's code."""
+    ref_harness.install()
+    import pytracking.libs.dcf as dcf
+    from pytracking.tracker.dimp.dimp import DiMP
+    from pytracking.tracker.tomp.tomp import ToMP
+    from pytracking_amd import install as amd
+    ref_max2d, ref_dimp, ref_tomp = dcf.max2d, DiMP.localize_advanced, ToMP.localize_advanced
+    amd.install()
+    try:
+        assert dcf.max2d.__wrapped__ is ref_max2d and DiMP.localize_advanced.__wrapped__ is ref_dimp
+        assert ToMP.localize_advanced.__wrapped__ is ref_tomp
+        a = torch.randn(2, 7, 9)
+        v, i = dcf.max2d(a)
+        rv, ri = ref_max2d(a)
+        assert torch.equal(v, rv) and torch.equal(i, ri)
+    finally:
+        amd.uninstall()
+    assert dcf.max2d is ref_max2d and DiMP.localize_advanced is ref_dimp and ToMP.localize_advanced is ref_tomp

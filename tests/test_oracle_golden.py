@@ -189,3 +189,21 @@ def test_clf_head(tag):
     g = load_golden("clf_head")
     y = O.clf_head(g[f"{tag}_x"].astype(np.float64), g[f"{tag}_w"].astype(np.float64), float(g[f"{tag}_scale"]))
     np.testing.assert_allclose(y, g[f"{tag}_y"], atol=2e-6, rtol=2e-5)
+
+
+def test_localize_decision_ladder_and_two_peaks(monkeypatch):
+    """Host logic of pytracking_amd.localization (the reference's decision ladder) on top of the ORACLE's two-peak search,
+    against DiMP.localize_advanced run by the unmodified reference (tests/golden/localize.npz): flag, scale, translation."""
+    import torch
+    from pytracking_amd import localization as LM
+    from localize_cases import cases
+    monkeypatch.setattr(LM, "two_peaks", lambda s, hn, neigh: torch.from_numpy(
+        O.two_peaks(s.numpy(), (s if hn is None else hn).numpy(), [n.numpy() for n in neigh])).float())
+    seen = set()
+    for me, c in cases(load_golden("localize")):
+        tv, scale_ind, _, flag = LM.localize_advanced(me, torch.from_numpy(c["scores"].copy()), torch.from_numpy(c["sample_pos"]),
+                                                      torch.from_numpy(c["sample_scales"]))
+        assert flag == str(c["flag"]) and int(scale_ind) == int(c["scale_ind"])
+        np.testing.assert_allclose(tv.numpy(), c["tv"], rtol=1e-6, atol=1e-6)
+        seen.add(flag)
+    assert seen == {"normal", "not_found", "uncertain", "hard_negative"}
