@@ -257,6 +257,30 @@ int pt_localize_f32(const float* scores, const float* scores_hn, const float* ne
                     float* out8, int S, int H, int W, void* stream);
 
 /* ------------------------------------------------------------------------------------------------
+ * IoU-guided box refinement -- DiMP.optimize_boxes_default / optimize_boxes_relative
+ * (pytracking/tracker/dimp/dimp.py:725-788) on AtomIoUNet.predict_iou (ltr/models/bbreg/atom_iou_net.py:96-136):
+ * gradient ascent on the predicted IoU w.r.t. the P proposal boxes, all iterations on the device.
+ *   params pack (fp32, the reference's state_dict tensors below `bb_regressor.`, this order): fc3_rt.linear.weight
+ *     (I3, C3*25), fc3_rt.linear.bias, fc3_rt.bn.{weight, bias, running_mean, running_var}, fc4_rt.linear.weight
+ *     (I4, C4*9), fc4_rt.linear.bias, fc4_rt.bn.{...}, iou_predictor.weight (I3+I4), iou_predictor.bias (1).
+ *   prepared: the two Linear weights transposed, written by pt_iou_prepare_f32 once per weight update.
+ *   c3 (C3,H3,W3), c4 (C4,H4,W4): IoU features of ONE test image (get_iou_feat); mod3 (C3), mod4 (C4): modulation
+ *   vectors (get_modulation); init_boxes / boxes_out (P,4) xywh in image coordinates; iou_out (P) = the prediction of the
+ *   last forward pass, as the reference returns it.  step_length4: HOST [s,s,s,s] or [s0,s0,s1,s1] (dimp.py:737-738);
+ *   relative = 1: optimise [cx/sw, cy/sh, log w, log h] with [sw, sh] = size of the first box (dimp.py:767-768).
+ *   Pools are the reference's: 5x5 at 1/8 on c3, 3x3 at 1/16 on c4.  Covered: C3*25, C4*9, I3, I4 multiples of 32, P <= 256.
+ * ---------------------------------------------------------------------------------------------- */
+typedef struct pt_iou_dims { int C3, C4, I3, I4, H3, W3, H4, W4; } pt_iou_dims;
+size_t pt_iou_param_floats(const pt_iou_dims* dims);
+size_t pt_iou_prepared_floats(const pt_iou_dims* dims);
+int pt_iou_prepare_f32(const pt_iou_dims* dims, const float* params, float* prepared, void* stream);
+size_t pt_iou_refine_ws_bytes(const pt_iou_dims* dims, int P);
+int pt_iou_refine_f32(const pt_iou_dims* dims, const float* params, const float* prepared, const float* c3, const float* c4,
+                      const float* mod3, const float* mod4, const float* init_boxes, float* boxes_out, float* iou_out,
+                      int P, int num_iter, const float* step_length4, float step_decay, int relative,
+                      void* ws, size_t ws_bytes, void* stream);
+
+/* ------------------------------------------------------------------------------------------------
  * Precise RoI Pooling -- replaces ltr/external/PreciseRoIPooling (empty git submodule;
  * import sites ltr/models/target_classifier/initializer.py:4,18,45 and
  * ltr/models/bbreg/atom_iou_net.py:4,31-32,41-42,126-127,157,160).

@@ -397,6 +397,47 @@ def gen_localize():
     save("localize", **out)
 
 
+def gen_iou_refine():
+    """IoU-guided box refinement: the reference's DiMP.optimize_boxes_default / optimize_boxes_relative (dimp.py:725-788)
+    driving the reference's AtomIoUNet.predict_iou (atom_iou_net.py:96-136; PrRoIPool = the restatement) on CPU."""
+    import types
+    from pytracking.tracker.dimp.dimp import DiMP
+    from pytracking.utils import TrackerParams
+    from ltr.models.bbreg.atom_iou_net import AtomIoUNet
+    torch.manual_seed(23)
+    rng = np.random.default_rng(71)
+    C, I = 64, 32
+    net = AtomIoUNet(input_dim=(32, 64), pred_input_dim=(C, C), pred_inter_dim=(I, I)).eval()
+    with torch.no_grad():                                      # move BN statistics / biases off their initial values
+        for blk in (net.fc3_rt, net.fc4_rt):
+            blk.bn.running_mean.copy_(torch.randn(I) * 0.1)
+            blk.bn.running_var.copy_(torch.rand(I) + 0.5)
+            blk.bn.bias.copy_(torch.randn(I) * 0.1)
+            blk.linear.bias.copy_(torch.randn(I) * 0.1)
+        net.iou_predictor.bias.fill_(0.3)
+    c3 = T(rng.standard_normal((1, C, 36, 36), dtype=np.float32))
+    c4 = T(rng.standard_normal((1, C, 18, 18), dtype=np.float32))
+    mod3 = T((rng.standard_normal((1, C), dtype=np.float32) * np.float32(0.5) + 1).astype(np.float32))
+    mod4 = T((rng.standard_normal((1, C), dtype=np.float32) * np.float32(0.5) + 1).astype(np.float32))
+    base = np.array([100.0, 90.0, 80.0, 110.0], np.float32)
+    boxes = np.stack([base] + [base + np.concatenate((rng.uniform(-12, 12, 2), rng.uniform(-25, 25, 2))).astype(np.float32)
+                               for _ in range(9)])
+    sd = {k: v.detach().numpy() for k, v in net.state_dict().items()
+          if k.startswith(("fc3_rt", "fc4_rt", "iou_predictor")) and "num_batches" not in k}
+    out = dict(c3=c3.numpy(), c4=c4.numpy(), mod3=mod3.numpy(), mod4=mod4.numpy(), boxes=boxes,
+               **{"w_" + k: v for k, v in sd.items()})
+    for tag, iters, step, decay, method in (("default", 5, 1.0, 1.0, DiMP.optimize_boxes_default),
+                                            ("default_decay", 3, 0.8, 0.5, DiMP.optimize_boxes_default),
+                                            ("relative", 10, 2.5e-3, 1.0, DiMP.optimize_boxes_relative)):
+        params = TrackerParams()
+        params.device = "cpu"
+        params.box_refinement_iter, params.box_refinement_step_length, params.box_refinement_step_decay = iters, step, decay
+        me = types.SimpleNamespace(params=params, net=types.SimpleNamespace(bb_regressor=net), iou_modulation=(mod3, mod4))
+        b, iou = method(me, (c3, c4), T(boxes.copy()))
+        out.update({f"{tag}_boxes": b.numpy(), f"{tag}_iou": iou.numpy(), f"{tag}_cfg": np.array([iters, step, decay])})
+    save("iou_refine", **out)
+
+
 def gen_clf_head():
     """Classification-feature head: the reference's residual_bottleneck(num_blocks=0, final_conv=True, l2norm=True)
     (features.py:49-73) on CPU."""
@@ -417,13 +458,15 @@ def gen_clf_head():
 
 if __name__ == "__main__":
     torch.set_num_threads(8)
-    which = sys.argv[1:] or ["filter", "dimp", "l2", "prdimp", "atom", "prroi", "lwl", "atomgn", "tomp", "head", "localize"]
+    which = sys.argv[1:] or ["filter", "dimp", "l2", "prdimp", "atom", "prroi", "lwl", "atomgn", "tomp", "head", "localize", "iou"]
     if "tomp" in which:
         gen_tomp()
     if "head" in which:
         gen_clf_head()
     if "localize" in which:
         gen_localize()
+    if "iou" in which:
+        gen_iou_refine()
     if "atomgn" in which:
         gen_atom_gn()
     if "lwl" in which:

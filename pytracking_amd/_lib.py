@@ -9,12 +9,17 @@ import subprocess
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.environ.get("PT_HOT_LIB", os.path.join(_HERE, "libpt_hot.so"))   # override: experiments only
-SOURCES = ["filter_kernels.hip", "fast_passes.hip", "sd_solver.hip", "mf_kernels.hip", "lwl_solver.hip", "atom_cg.hip", "atom_gn.hip", "tomp.hip", "localize.hip", "prroi.hip", "api.hip", "profile.hip"]
-HEADERS = ["common.h", "pt_internal.h", "rbuild.h", "sd_common.h", os.path.join("..", "..", "include", "pt_hot.h")]
+SOURCES = ["filter_kernels.hip", "fast_passes.hip", "sd_solver.hip", "mf_kernels.hip", "lwl_solver.hip", "atom_cg.hip", "atom_gn.hip", "tomp.hip", "localize.hip", "iou_refine.hip", "prroi.hip", "api.hip", "profile.hip"]
+HEADERS = ["common.h", "pt_internal.h", "rbuild.h", "sd_common.h", "mfma_gemm.h", os.path.join("..", "..", "include", "pt_hot.h")]
 
 PT_SD_DIMP, PT_SD_DIMP_L2, PT_SD_PRDIMP = 0, 1, 2
 PT_ACT_RELU, PT_ACT_BENTPAR = 0, 1
 PT_MASK_SIGMOID, PT_MASK_LINEAR = 0, 1
+
+class IouDims(ctypes.Structure):
+    """`pt_iou_dims` of include/pt_hot.h."""
+    _fields_ = [(n, ctypes.c_int) for n in ("C3", "C4", "I3", "I4", "H3", "W3", "H4", "W4")]
+
 
 class TompDims(ctypes.Structure):
     """`pt_tomp_dims` of include/pt_hot.h."""
@@ -34,6 +39,7 @@ EXPORTS = [
     "pt_tomp_param_floats", "pt_tomp_prepared_floats", "pt_tomp_prepare_f32", "pt_tomp_posenc_f32", "pt_tomp_predict_ws_bytes", "pt_tomp_predict_f32", "pt_tomp_linear_f32",
     "pt_tomp_bbreg_param_floats", "pt_tomp_bbreg_ws_bytes", "pt_tomp_bbreg_f32",
     "pt_clf_head_ws_bytes", "pt_clf_head_f32", "pt_max2d_f32", "pt_localize_f32",
+    "pt_iou_param_floats", "pt_iou_prepared_floats", "pt_iou_prepare_f32", "pt_iou_refine_ws_bytes", "pt_iou_refine_f32",
     "pt_profile_create", "pt_profile_attach", "pt_profile_collect", "pt_profile_reset", "pt_profile_destroy",
 ]
 
@@ -164,6 +170,17 @@ def lib():
     fp = ctypes.POINTER(ctypes.c_float)
     L.pt_localize_f32.restype = i
     L.pt_localize_f32.argtypes = [vp, vp, fp, fp, vp, i, i, i, vp]
+    ip = ctypes.POINTER(IouDims)
+    L.pt_iou_param_floats.restype = sz
+    L.pt_iou_param_floats.argtypes = [ip]
+    L.pt_iou_prepared_floats.restype = sz
+    L.pt_iou_prepared_floats.argtypes = [ip]
+    L.pt_iou_prepare_f32.restype = i
+    L.pt_iou_prepare_f32.argtypes = [ip, vp, vp, vp]
+    L.pt_iou_refine_ws_bytes.restype = sz
+    L.pt_iou_refine_ws_bytes.argtypes = [ip, i]
+    L.pt_iou_refine_f32.restype = i
+    L.pt_iou_refine_f32.argtypes = [ip, vp, vp, vp, vp, vp, vp, vp, vp, vp, i, i, fp, f, i, vp, sz, vp]
     L.pt_profile_create.restype = i
     L.pt_profile_create.argtypes = [ctypes.POINTER(vp), i]
     L.pt_profile_attach.restype = i

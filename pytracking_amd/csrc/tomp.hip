@@ -22,274 +22,13 @@
 //               (pt_tomp_prepare_f32), so a layer is 5 GEMVs plus two MFMA passes over the memory
 #include "common.h"
 #include "pt_internal.h"
+#include "mfma_gemm.h"
 
 #include <algorithm>
 #include <math.h>
-#include <stdlib.h>
 #include <stdint.h>
 
 namespace {
-
-constexpr unsigned OOB = 0xFFFFFFF0u;      // raw buffer loads past num_records return 0
-
-// ------------------------------------------------------------------------------------------------------------------
-// generic NT GEMM on MFMA
-// ------------------------------------------------------------------------------------------------------------------
-struct GemmArgs {
-    const float* A; long lda; unsigned a_bytes;
-    const float* Wt; unsigned w_bytes;          // (N, K) row-major
-    int M, N, K;
-    const float* bias; const float* scale; const float* shift;
-    const float* R; float* C; long ldc;         // residual shares ldc and the row map of C
-    int c_seg; long c_segstride;                // C/R row of logical row r: (r / c_seg) * c_segstride + r % c_seg
-    int relu, expo, nchw;                       // nchw: C[((r / HW) * N + n) * HW + r % HW]
-    const float* pos; unsigned pos_bytes; int pos_cols, L, HW;   // A[r][k] + pos[(r % L) % HW][k] for column tiles < pos_cols
-    int H, Wd, Cin;                             // MODE 1: 3x3 zero-padded gather, K = 9 * Cin, weights (N, tap, Cin)
-    int swizzle;                                // XCD-aware workgroup -> tile map (grid.y rounded up to a multiple of 8)
-    int ksteps; long c_zstride;                 // split-K: blockIdx.z owns K-steps [z*ksteps, (z+1)*ksteps) and writes its
-                                                // partial product to C + z*c_zstride (bias on z = 0 only); 0 = no split
-};
-
-template <int BM, int BN, int MODE, int BK = 64>
-__global__ __launch_bounds__(256) void k_gemm(GemmArgs g) {
-    // K advances in steps of 64 (one barrier per 4 MFMA sub-steps of 16): with 32-wide steps the counters showed the
-    // wavefronts parked at s_waitcnt / s_barrier for a third of their life and the LDS round trip exposed twice per step
-    // (profiles/r01i_tomp_pmc.txt).  Fragment reads of sub-step h+1 are issued before the MFMAs of sub-step h.
-    constexpr int LS = BK + 4;                  // LDS row stride 68 / 36 words: 16-byte aligned, 4 mod 32 (see prow below)
-    constexpr int RP = 1024 / BK;               // tile rows covered by one pass of the 256 loader threads
-    constexpr int WM = BM / 2, WN = BN / 2, MT = WM / 16, NT = WN / 16, AL = BM / RP, BL = BN / RP;
-    __shared__ __attribute__((aligned(16))) float As[2][BM * LS];
-    __shared__ __attribute__((aligned(16))) float Bs[2][BN * LS];
-    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, wm = wave >> 1, wn = wave & 1;
-    // Workgroup -> tile map.  Workgroups are dealt to the 8 XCDs round-robin in dispatch order (x fastest), and each XCD
-    // has its own L2: with the natural map and a column-tile count that is a multiple of 8, every XCD walks ALL row tiles
-    // of A (8 x 16 MB over the fabric for the FFN's second GEMM).  Swizzled: XCD c owns the row tiles = c mod 8 and sweeps
-    // the column tiles, so A crosses the fabric once and only the (small) weight matrix is replicated per XCD.
-    int bx = blockIdx.x, by = blockIdx.y;
-    if (g.swizzle) {
-        const int lin = blockIdx.y * gridDim.x + blockIdx.x, xcd = lin & 7, j = lin >> 3;
-        by = xcd + 8 * (j / (int)gridDim.x);
-        bx = j % (int)gridDim.x;
-        if (by * BM >= g.M) return;                              // padding rows of the rounded-up grid
-    }
-    const int m0 = by * BM, n0 = bx * BN;
-    const int lrow = tid / (BK / 4), lc4 = (tid % (BK / 4)) * 4;   // loader: BK/4 threads cover one row segment of BK floats
-    const __amdgpu_buffer_rsrc_t rsA = pt_rsrc(g.A, g.a_bytes), rsW = pt_rsrc(g.Wt, g.w_bytes);
-    const bool addpos = MODE == 0 && g.pos != nullptr && n0 < g.pos_cols;
-    const __amdgpu_buffer_rsrc_t rsP = pt_rsrc(addpos ? g.pos : g.A, addpos ? g.pos_bytes : 16u);
-
-    unsigned aoff[AL], poff[AL], woff[BL];
-    int py[AL], px[AL];
-#pragma unroll
-    for (int i = 0; i < AL; ++i) {
-        const int row = m0 + lrow + RP * i;
-        const bool ok = row < g.M;
-        if (MODE == 0) {
-            aoff[i] = ok ? (unsigned)(((long)row * g.lda + lc4) * 4) : OOB;
-            poff[i] = (addpos && ok) ? (unsigned)(((long)((row % g.L) % g.HW) * g.K + lc4) * 4) : OOB;
-        } else {
-            const int img = row / g.HW, p = row - img * g.HW;
-            py[i] = ok ? p / g.Wd : -4;                                  // -4: every tap falls outside the map
-            px[i] = p - (p / g.Wd) * g.Wd;
-            aoff[i] = (unsigned)(((long)img * g.HW * g.lda + lc4) * 4);
-            poff[i] = OOB;
-        }
-    }
-#pragma unroll
-    for (int i = 0; i < BL; ++i) {
-        const int n = n0 + lrow + RP * i;
-        woff[i] = n < g.N ? (unsigned)(((long)n * g.K + lc4) * 4) : OOB;
-    }
-
-    // Register ring of depth PD; LDS is double-buffered one step ahead.  The loads are issued unconditionally (`live` =
-    // false turns a request into an out-of-range one: zeros, no memory touched) so that the compiler's s_waitcnt vmcnt
-    // bookkeeping stays exact -- a fetch inside a branch makes it wait for ALL outstanding loads before the LDS store.
-    constexpr int PD = 2;
-    f32x4 ra[PD][AL], rp[PD][AL], rb[PD][BL];
-    auto fetch = [&](int kb, int sl, bool live) {
-        live = live && (kb * BK + lc4 < g.K);                            // K % 64 == 32: the last step is half empty
-        const unsigned kbytes = (unsigned)kb * (BK * 4u);
-        if (MODE == 0) {
-#pragma unroll
-            for (int i = 0; i < AL; ++i) ra[sl][i] = pt_bload4(rsA, (aoff[i] == OOB || !live) ? OOB : aoff[i] + kbytes);
-            if (addpos) {
-#pragma unroll
-                for (int i = 0; i < AL; ++i) rp[sl][i] = pt_bload4(rsP, (poff[i] == OOB || !live) ? OOB : poff[i] + kbytes);
-            }
-        } else {
-            const int k0 = kb * BK, tap = k0 / g.Cin, c0 = k0 - tap * g.Cin;
-            const int dy = tap / 3 - 1, dx = tap - (tap / 3) * 3 - 1;
-#pragma unroll
-            for (int i = 0; i < AL; ++i) {
-                const int y = py[i] + dy, x = px[i] + dx;
-                const bool in = live && y >= 0 && y < g.H && x >= 0 && x < g.Wd;
-                ra[sl][i] = pt_bload4(rsA, in ? aoff[i] + (unsigned)(((long)(y * g.Wd + x) * g.lda + c0) * 4) : OOB);
-            }
-        }
-#pragma unroll
-        for (int i = 0; i < BL; ++i) rb[sl][i] = pt_bload4(rsW, (woff[i] == OOB || !live) ? OOB : woff[i] + kbytes);
-    };
-    auto stash = [&](int sl, int buf) {
-#pragma unroll
-        for (int i = 0; i < AL; ++i) {
-            f32x4 v = ra[sl][i];
-            if (addpos) v += rp[sl][i];
-            *reinterpret_cast<f32x4*>(&As[buf][(lrow + RP * i) * LS + lc4]) = v;
-        }
-#pragma unroll
-        for (int i = 0; i < BL; ++i) *reinterpret_cast<f32x4*>(&Bs[buf][(lrow + RP * i) * LS + lc4]) = rb[sl][i];
-    };
-
-    f32x4 acc[MT][NT];
-#pragma unroll
-    for (int a = 0; a < MT; ++a)
-#pragma unroll
-        for (int b = 0; b < NT; ++b) acc[a][b] = f32x4{0.f, 0.f, 0.f, 0.f};
-
-    // LDS fragment reads without bank conflicts.  ds_read_b128 is serviced in four groups of 16 lanes over 64 banks,
-    // and the groups are not lane-contiguous: {0-3,12-15,20-27}, {4-11,16-19,28-31} and the same +32, i.e. every group
-    // mixes two k-slots (lane >> 4).  With a row stride of 4 mod 64 words the 16-byte bank group of lane (i, kq) is
-    // (s * row(i) + quad(kq)) mod 16 with s odd; it is a permutation inside every hardware group when MFMA row i is
-    // tile row prow(i) (even rows for i in 4..11, odd rows otherwise) and k-slot kq reads k-quad {0,2,1,3}[kq].  Both
-    // operands use the same maps, so the k pairing is intact and the row / column permutation is undone in the epilogue.
-    auto prow = [](int i) { return (i >= 4 && i < 12) ? 2 * (i - 4) : (i < 4 ? 2 * i + 1 : 2 * i - 15); };
-    const int qoff = ((lane >> 4) & 1) * 2 + (lane >> 5);
-    const int aso = (wm * WM + prow(lane & 15)) * LS + qoff * 4, bso = (wn * WN + prow(lane & 15)) * LS + qoff * 4;
-
-    const int nkt = (g.K + BK - 1) / BK;
-    const int kb0 = g.ksteps ? blockIdx.z * g.ksteps : 0;
-    const int nk = g.ksteps ? min(nkt, kb0 + g.ksteps) : nkt;
-#pragma unroll
-    for (int sl = 0; sl < PD; ++sl) fetch(kb0 + sl, sl, kb0 + sl < nk);
-    stash(0, 0);
-    __syncthreads();
-    for (int t0 = kb0; t0 < nk; t0 += PD) {
-#pragma unroll
-        for (int u = 0; u < PD; ++u) {
-            const int kb = t0 + u;
-            const int buf = u & 1;
-            fetch(kb + PD, u, kb + PD < nk);                             // slot u (step kb) already sits in LDS[buf]
-            if (kb < nk) {                                               // workgroup-uniform; LDS reads + MFMA only
-                const float* as = &As[buf][aso];
-                const float* bs = &Bs[buf][bso];
-                f32x4 fa[2][MT], fb[2][NT];
-#pragma unroll
-                for (int mt = 0; mt < MT; ++mt) fa[0][mt] = *reinterpret_cast<const f32x4*>(as + mt * 16 * LS);
-#pragma unroll
-                for (int nt = 0; nt < NT; ++nt) fb[0][nt] = *reinterpret_cast<const f32x4*>(bs + nt * 16 * LS);
-#pragma unroll
-                for (int hh = 0; hh < BK / 16; ++hh) {
-                    const int c = hh & 1, nx = c ^ 1;
-                    if (hh + 1 < BK / 16) {
-#pragma unroll
-                        for (int mt = 0; mt < MT; ++mt)
-                            fa[nx][mt] = *reinterpret_cast<const f32x4*>(as + mt * 16 * LS + (hh + 1) * 16);
-#pragma unroll
-                        for (int nt = 0; nt < NT; ++nt)
-                            fb[nx][nt] = *reinterpret_cast<const f32x4*>(bs + nt * 16 * LS + (hh + 1) * 16);
-                    }
-#pragma unroll
-                    for (int j = 0; j < 4; ++j)
-#pragma unroll
-                        for (int mt = 0; mt < MT; ++mt)
-#pragma unroll
-                            for (int nt = 0; nt < NT; ++nt)
-                                acc[mt][nt] = mfma16(fa[c][mt][j], fb[c][nt][j], acc[mt][nt]);
-                }
-            }
-            stash((u + 1) % PD, buf ^ 1);                               // step kb+1 (zeros past the end: never read)
-            __syncthreads();
-        }
-    }
-
-    // epilogue: the row part of every output address is computed once per accumulator row (the segment / NCHW maps cost
-    // an integer division each -- done per element they were most of the kernel's time: ~120 VALU instructions x 16-64
-    // elements per lane)
-    long rbase[MT][4];
-    const bool plain = !g.nchw && g.c_segstride == 0;
-#pragma unroll
-    for (int mt = 0; mt < MT; ++mt)
-#pragma unroll
-        for (int r = 0; r < 4; ++r) {
-            const int row = m0 + wm * WM + mt * 16 + prow(4 * (lane >> 4) + r);
-            long o = -1;
-            if (row < g.M) {
-                if (plain) {
-                    o = (long)row * g.ldc;
-                } else if (g.nchw) {
-                    const int img = row / g.HW;
-                    o = (long)img * g.N * g.HW + (row - img * g.HW);
-                } else {
-                    const int sg = row / g.c_seg;
-                    o = ((long)sg * g.c_segstride + (row - sg * g.c_seg)) * g.ldc;
-                }
-            }
-            rbase[mt][r] = o;
-        }
-    const long zoff = (long)blockIdx.z * g.c_zstride;
-    const long cstep = g.nchw ? g.HW : 1;
-#pragma unroll
-    for (int nt = 0; nt < NT; ++nt) {
-        const int col = n0 + wn * WN + nt * 16 + prow(lane & 15);
-        if (col >= g.N) continue;
-        const float bv = (g.bias && blockIdx.z == 0) ? g.bias[col] : 0.f;
-        const float sc = g.scale ? g.scale[col] : 1.f, sh = g.scale ? g.shift[col] : 0.f;
-        const long coff = (long)col * cstep;
-        float res[MT][4];
-        if (g.R) {                                                   // residual loads first, all in flight together
-#pragma unroll
-            for (int mt = 0; mt < MT; ++mt)
-#pragma unroll
-                for (int r = 0; r < 4; ++r) res[mt][r] = rbase[mt][r] >= 0 ? g.R[rbase[mt][r] + coff] : 0.f;
-        }
-#pragma unroll
-        for (int mt = 0; mt < MT; ++mt)
-#pragma unroll
-            for (int r = 0; r < 4; ++r) {
-                if (rbase[mt][r] < 0) continue;
-                float v = (acc[mt][nt][r] + bv) * sc + sh;
-                if (g.relu) v = fmaxf(v, 0.f);
-                if (g.R) v += res[mt][r];
-                if (g.expo) v = expf(v);
-                g.C[rbase[mt][r] + coff + zoff] = v;
-            }
-    }
-}
-
-GemmArgs gemm_args(const float* A, long lda, long a_rows, const float* Wt, int M, int N, int K, const float* bias,
-                   float* C, long ldc) {
-    GemmArgs g{};
-    g.A = A; g.lda = lda; g.a_bytes = (unsigned)std::min<long>(a_rows * lda * 4, 0xFFFFFFE0L);
-    g.Wt = Wt; g.w_bytes = (unsigned)((long)N * K * 4);
-    g.M = M; g.N = N; g.K = K; g.bias = bias; g.C = C; g.ldc = ldc;
-    g.c_seg = M > 0 ? M : 1; g.c_segstride = 0; g.HW = 1; g.L = 1;
-    return g;
-}
-
-int launch_gemm(const GemmArgs& g, hipStream_t st, bool conv = false) {
-    if (g.K % 32 != 0 || g.M <= 0 || g.N <= 0) return PT_ERR_UNSUPPORTED;
-    if (conv) {
-        if (g.Cin % 64 != 0) return PT_ERR_UNSUPPORTED;
-        const int nz = g.ksteps ? (g.K / 64 + g.ksteps - 1) / g.ksteps : 1;
-        hipLaunchKernelGGL((k_gemm<32, 32, 1>), dim3((g.N + 31) / 32, (g.M + 31) / 32, nz), dim3(256), 0, st, g);
-    } else {
-        const long t64 = (long)((g.M + 63) / 64) * ((g.N + 63) / 64), t6432 = (long)((g.M + 63) / 64) * ((g.N + 31) / 32);
-        static const long T = getenv("PT_TOMP_T") ? atol(getenv("PT_TOMP_T")) : 1L << 40;   // measured: 32x32 tiles win at M = 1944
-        if (t64 >= T)
-            hipLaunchKernelGGL((k_gemm<64, 64, 0>), dim3((g.N + 63) / 64, (g.M + 63) / 64), dim3(256), 0, st, g);
-        else if (t6432 >= T)
-            hipLaunchKernelGGL((k_gemm<64, 32, 0>), dim3((g.N + 31) / 32, (g.M + 63) / 64), dim3(256), 0, st, g);
-        else {
-            GemmArgs gs = g;
-            const int gy = (g.M + 31) / 32;
-            gs.swizzle = gy >= 16;                                   // worth it once every XCD gets >= 2 row tiles
-            hipLaunchKernelGGL((k_gemm<32, 32, 0>), dim3((g.N + 31) / 32, gs.swizzle ? (gy + 7) / 8 * 8 : gy), dim3(256),
-                               0, st, gs);
-        }
-    }
-    PT_CHECK_LAUNCH();
-    return PT_OK;
-}
 
 // ------------------------------------------------------------------------------------------------------------------
 // fp32 flash attention over the packed (rows, 3D) q|k|v projections

@@ -22,6 +22,8 @@ What gets rebound (import path = contract; nothing in the reference tree is edit
                                                                                       -> pytracking_amd.features
   pytracking.libs.dcf.max2d, pytracking.tracker.dimp.dimp.DiMP.localize_advanced,
   pytracking.tracker.tomp.tomp.ToMP.localize_advanced  (score-map localisation)       -> pytracking_amd.localization
+  pytracking.tracker.dimp.dimp.DiMP.optimize_boxes_default / optimize_boxes_relative  (IoU-guided box refinement)
+                                                                                      -> pytracking_amd.iou_refine
 
 Dispatch rule of the rebound *functions*: device fp32 tensors of a shape the gfx950 kernels cover go to the C ABI;
 everything else (CPU tensors, dilations, grouped filters, K*K > 16, more than 16 filters) is outside the hot path and
@@ -232,7 +234,38 @@ def _install_localization(orig, strict):
         cls.localize_advanced = method
 
 
-def install(strict=False, atom_cg=True, tomp=True, clf_head=True, localization=True):
+def _install_iou_refine(orig, strict):
+    """`DiMP.optimize_boxes_default` / `optimize_boxes_relative` (dimp.py:725-788): all refinement iterations in one
+    device-side sequence instead of one autograd graph per iteration."""
+    from . import iou_refine as _ir
+    try:
+        cls = importlib.import_module("pytracking.tracker.dimp.dimp").DiMP
+    except Exception:
+        return
+    orig["iou_refine"] = (cls.optimize_boxes_default, cls.optimize_boxes_relative)
+    for name, fast in (("optimize_boxes_default", _ir.optimize_boxes_default),
+                       ("optimize_boxes_relative", _ir.optimize_boxes_relative)):
+        ref_method = getattr(cls, name)
+
+        def method(self, iou_features, init_boxes, _fast=fast, _ref=ref_method):
+            feats = list(iou_features)
+            ok = (len(feats) == 2 and all(f.is_cuda and f.dtype == torch.float32 and f.shape[0] == 1 for f in feats)
+                  and not self.net.bb_regressor.training)
+            if ok:
+                try:
+                    return _fast(self, feats, init_boxes)
+                except NotImplementedError:
+                    if strict:
+                        raise
+            elif strict:
+                raise NotImplementedError(f"{_ref.__name__}: call outside the gfx950 hot path")
+            return _ref(self, iou_features, init_boxes)
+
+        method.__doc__, method.__wrapped__ = ref_method.__doc__, ref_method
+        setattr(cls, name, method)
+
+
+def install(strict=False, atom_cg=True, tomp=True, clf_head=True, localization=True, iou_refine=True):
     """Rebind the boundary symbols.  Call after the reference is importable (`sys.path`) and before networks or
     trackers are constructed.  Idempotent."""
     if _state["installed"]:
@@ -277,6 +310,8 @@ def install(strict=False, atom_cg=True, tomp=True, clf_head=True, localization=T
         _install_clf_head(orig, strict)
     if localization:
         _install_localization(orig, strict)
+    if iou_refine:
+        _install_iou_refine(orig, strict)
     if atom_cg:
         try:
             pmod = importlib.import_module("pytracking.libs.optimization")
@@ -353,6 +388,9 @@ def uninstall():
         hm.LinearFilterClassifier, hm.DenseBoxRegressor = orig["tomp"][2], orig["tomp"][3]
     if "clf_head" in orig:
         importlib.import_module("ltr.models.target_classifier.features").residual_bottleneck = orig["clf_head"]
+    if "iou_refine" in orig:
+        cls = importlib.import_module("pytracking.tracker.dimp.dimp").DiMP
+        cls.optimize_boxes_default, cls.optimize_boxes_relative = orig["iou_refine"]
     if "localization" in orig:
         for key, ref in orig["localization"].items():
             if key == "max2d":

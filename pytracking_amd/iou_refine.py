@@ -1,0 +1,95 @@
+"""Host-side mirror of the IoU-guided box refinement: `DiMP.optimize_boxes_default` / `optimize_boxes_relative`
+(pytracking/tracker/dimp/dimp.py:725-788; ATOM's `optimize_boxes`, atom.py:758-790, has the default body) on
+`AtomIoUNet.predict_iou` (ltr/models/bbreg/atom_iou_net.py:96-136).
+
+The two functions are written to be bound as the tracker's methods: they read `self.net.bb_regressor` (the reference's
+AtomIoUNet instance -- its `fc3_rt`, `fc4_rt`, `iou_predictor` parameters are packed once and re-packed when they change),
+`self.iou_modulation`, `self.params.box_refinement_{iter,step_length,step_decay}` and return the reference's tuple
+`(boxes (P,4) on the CPU, iou (P) on the CPU)`.  All iterations run on the device without a host synchronisation; the
+reference builds and differentiates an autograd graph per iteration.
+"""
+import ctypes
+import weakref
+
+import torch
+
+from . import _lib
+from .filter import _ptr, _require_device, _stream, workspace
+from .transformer import _Pack
+
+_CACHE = weakref.WeakKeyDictionary()          # AtomIoUNet instance -> (pack, prepared buffer, key)
+
+
+def _packs(net, dims):
+    st = _CACHE.get(net)
+    if st is None:
+        st = {"pack": _Pack(), "prepared": None, "key": None}
+        _CACHE[net] = st
+    tensors = []
+    for blk in (net.fc3_rt, net.fc4_rt):
+        tensors += [blk.linear.weight, blk.linear.bias, blk.bn.weight, blk.bn.bias, blk.bn.running_mean, blk.bn.running_var]
+    tensors += [net.iou_predictor.weight, net.iou_predictor.bias]
+    pack = st["pack"].get(tensors)
+    if st["key"] != st["pack"].key:
+        L = _lib.lib()
+        st["prepared"] = torch.empty(L.pt_iou_prepared_floats(ctypes.byref(dims)), dtype=torch.float32, device=pack.device)
+        _lib.check(L.pt_iou_prepare_f32(ctypes.byref(dims), _ptr(pack), _ptr(st["prepared"]), _stream()),
+                   "pt_iou_prepare_f32")
+        st["key"] = st["pack"].key
+    return pack, st["prepared"]
+
+
+def refine_boxes(net, modulation, iou_features, init_boxes, num_iter, step_length, step_decay, relative):
+    """-> (boxes (P,4), iou (P)) device tensors.  net: AtomIoUNet; modulation: (mod3, mod4) of one target;
+    iou_features: (c3_t (1,C3,H3,W3), c4_t (1,C4,H4,W4)); init_boxes (P,4) xywh."""
+    if net.training or net.fc3_rt.bn is None or net.fc3_rt.relu is None:
+        raise NotImplementedError("IoU refinement: eval-mode LinearBlocks with BatchNorm + ReLU (the reference's network)")
+    c3, c4 = [f.contiguous() for f in iou_features]
+    mod3, mod4 = [m.reshape(-1).contiguous() for m in modulation]
+    boxes = init_boxes.reshape(-1, 4).to(c3.device, torch.float32).contiguous()
+    _require_device(c3, c4, mod3, mod4, boxes)
+    if c3.shape[0] != 1 or c4.shape[0] != 1:
+        raise NotImplementedError("IoU refinement runs on one test image (the trackers' call)")
+    for pool, size, scale in ((net.prroi_pool3t, 5, 1 / 8), (net.prroi_pool4t, 3, 1 / 16)):
+        if (getattr(pool, "pooled_height", size), getattr(pool, "pooled_width", size)) != (size, size) or \
+                abs(getattr(pool, "spatial_scale", scale) - scale) > 1e-12:
+            raise NotImplementedError("IoU refinement: pools other than 5x5 @ 1/8 and 3x3 @ 1/16")
+    dims = _lib.IouDims(c3.shape[1], c4.shape[1], net.fc3_rt.linear.out_features, net.fc4_rt.linear.out_features,
+                        c3.shape[2], c3.shape[3], c4.shape[2], c4.shape[3])
+    L = _lib.lib()
+    P = boxes.shape[0]
+    nb = L.pt_iou_refine_ws_bytes(ctypes.byref(dims), P)
+    if nb == 0:
+        raise NotImplementedError("IoU refinement: configuration not covered by the gfx950 kernels")
+    pack, prepared = _packs(net, dims)
+    if pack.numel() != L.pt_iou_param_floats(ctypes.byref(dims)):
+        raise ValueError("AtomIoUNet parameters do not match the feature dimensions")
+    if isinstance(step_length, (tuple, list)):
+        steps = [step_length[0], step_length[0], step_length[1], step_length[1]]
+    else:
+        steps = [float(step_length)] * 4
+    ws = workspace(nb, c3.device)
+    out_boxes = torch.empty_like(boxes)
+    out_iou = torch.empty(P, dtype=torch.float32, device=c3.device)
+    rc = L.pt_iou_refine_f32(ctypes.byref(dims), _ptr(pack), _ptr(prepared), _ptr(c3), _ptr(c4), _ptr(mod3), _ptr(mod4),
+                             _ptr(boxes), _ptr(out_boxes), _ptr(out_iou), P, int(num_iter), (ctypes.c_float * 4)(*steps),
+                             float(step_decay), int(bool(relative)), _ptr(ws), ws.numel(), _stream())
+    _lib.check(rc, "pt_iou_refine_f32")
+    return out_boxes, out_iou
+
+
+def _optimize(self, iou_features, init_boxes, relative):
+    p = self.params
+    boxes, iou = refine_boxes(self.net.bb_regressor, self.iou_modulation, iou_features, init_boxes, p.box_refinement_iter,
+                              p.box_refinement_step_length, p.box_refinement_step_decay, relative)
+    return boxes.view(-1, 4).cpu(), iou.view(-1).cpu()
+
+
+def optimize_boxes_default(self, iou_features, init_boxes):
+    """Drop-in for `DiMP.optimize_boxes_default` (dimp.py:734-759)."""
+    return _optimize(self, iou_features, init_boxes, False)
+
+
+def optimize_boxes_relative(self, iou_features, init_boxes):
+    """Drop-in for `DiMP.optimize_boxes_relative` (dimp.py:762-795)."""
+    return _optimize(self, iou_features, init_boxes, True)

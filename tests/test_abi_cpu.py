@@ -128,6 +128,24 @@ def test_localize_argument_checks(L):
     assert L.pt_localize_f32(one, n, f2, f2, one, 9, 19, 19, n) == -3
 
 
+def test_iou_refine_argument_checks(L):
+    n = None
+    one = ctypes.c_void_p(256)
+    d = _lib.IouDims(256, 256, 256, 256, 36, 36, 18, 18)               # AtomIoUNet defaults (atom_iou_net.py:23)
+    assert L.pt_iou_param_floats(ctypes.byref(d)) == 256 * 6400 + 5 * 256 + 256 * 2304 + 5 * 256 + 512 + 1
+    assert L.pt_iou_prepared_floats(ctypes.byref(d)) >= 256 * (6400 + 2304)
+    assert L.pt_iou_refine_ws_bytes(ctypes.byref(d), 10) > 0
+    bad = _lib.IouDims(250, 256, 256, 256, 36, 36, 18, 18)             # 250 * 25 is not a multiple of 32
+    assert L.pt_iou_param_floats(ctypes.byref(bad)) == 0 and L.pt_iou_refine_ws_bytes(ctypes.byref(bad), 10) == 0
+    f4 = (ctypes.c_float * 4)(1, 1, 1, 1)
+    a = [one] * 9
+    assert L.pt_iou_refine_f32(ctypes.byref(d), n, *a[1:], 10, 5, f4, 1.0, 0, one, 1 << 30, n) == -1
+    assert L.pt_iou_refine_f32(ctypes.byref(d), *a, 0, 5, f4, 1.0, 0, one, 1 << 30, n) == -2
+    assert L.pt_iou_refine_f32(ctypes.byref(bad), *a, 10, 5, f4, 1.0, 0, one, 1 << 30, n) == -3
+    assert L.pt_iou_refine_f32(ctypes.byref(d), *a, 10, 5, f4, 1.0, 0, one, 0, n) == -4
+    assert L.pt_iou_prepare_f32(ctypes.byref(d), one, n, n) == -1
+
+
 def test_tomp_mirror_contract():
     """Constructor signatures and refusals of the ToMP mirror (no device work)."""
     from pytracking_amd import transformer as TM

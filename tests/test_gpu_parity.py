@@ -2,6 +2,8 @@
 vectors on identical seeded inputs.  Tolerance: BASELINE.json north_star asks for 1e-4 abs on score maps /
 filters; 2e-5 is asserted where the arithmetic is smooth, 1e-4 where a sign(s) flip of a near-zero score can
 move an iterate discontinuously (LeakyReluParDeriv, activation.py:43-44)."""
+import types
+
 import numpy as np
 import pytest
 import torch
@@ -628,3 +630,55 @@ def test_max2d_vs_oracle_with_ties():
             v, (r, c) = O.max2d(a[i, j])
             assert float(mv[i, j]) == float(v) and am[i, j].tolist() == [r, c]
     assert am[0, 0].tolist() == [9, 2]
+
+
+# ------------------------------------------------------------------------------------------------------
+# IoU-guided box refinement
+# ------------------------------------------------------------------------------------------------------
+class _IoUNetStandIn(torch.nn.Module):
+    """The attributes of the reference's AtomIoUNet that the refinement reads (atom_iou_net.py:44-49), carrying the golden
+    weights; the reference tree is not available on the GPU box."""
+
+    def __init__(self, g):
+        super().__init__()
+        C, I = g["c3"].shape[1], g["w_fc3_rt.linear.bias"].shape[0]
+
+        def block(k):
+            m = torch.nn.Module()
+            m.linear = torch.nn.Linear(C * k * k, I)
+            m.bn = torch.nn.BatchNorm2d(I)
+            m.relu = torch.nn.ReLU()
+            return m
+        self.fc3_rt, self.fc4_rt = block(5), block(3)
+        self.iou_predictor = torch.nn.Linear(2 * I, 1)
+        sd = {k[2:]: torch.from_numpy(v.copy()) for k, v in g.items() if k.startswith("w_")}
+        for blk in ("fc3_rt", "fc4_rt"):
+            sd[f"{blk}.bn.num_batches_tracked"] = torch.tensor(0)
+        self.load_state_dict(sd, strict=True)
+        self.prroi_pool3t = types.SimpleNamespace(pooled_height=5, pooled_width=5, spatial_scale=1 / 8)
+        self.prroi_pool4t = types.SimpleNamespace(pooled_height=3, pooled_width=3, spatial_scale=1 / 16)
+
+
+@pytest.mark.parametrize("tag,relative", [("default", False), ("default_decay", False), ("relative", True)])
+def test_iou_refinement_golden(tag, relative):
+    """optimize_boxes_default / optimize_boxes_relative (dimp.py:725-788) vs the reference run on CPU."""
+    from pytracking_amd import iou_refine as IR
+    g = load_golden("iou_refine")
+    net = _IoUNetStandIn(g).to(DEV).eval()
+    iters, step, decay = g[f"{tag}_cfg"]
+    params = types.SimpleNamespace(box_refinement_iter=int(iters), box_refinement_step_length=float(step),
+                                   box_refinement_step_decay=float(decay))
+    me = types.SimpleNamespace(params=params, net=types.SimpleNamespace(bb_regressor=net),
+                               iou_modulation=(T(g["mod3"]), T(g["mod4"])))
+    fn = IR.optimize_boxes_relative if relative else IR.optimize_boxes_default
+    boxes, iou = fn(me, (T(g["c3"]), T(g["c4"])), torch.from_numpy(g["boxes"].copy()))
+    assert not boxes.is_cuda and boxes.shape == (10, 4) and iou.shape == (10,)
+    close(iou, g[f"{tag}_iou"], atol=1e-4, rtol=1e-4)
+    close(boxes, g[f"{tag}_boxes"], atol=5e-3, rtol=1e-4)
+    assert float(np.abs(g[f"{tag}_boxes"] - g["boxes"]).max()) > 2.0           # the boxes really moved
+    b2, i2 = fn(me, (T(g["c3"]), T(g["c4"])), torch.from_numpy(g["boxes"].copy()))   # cached pack / prepared buffers
+    assert torch.equal(b2, boxes) and torch.equal(i2, iou)
+    if tag == "default":                                                       # tuple step length (dimp.py:737-738)
+        params.box_refinement_step_length = (float(step), float(step))
+        b3, _ = fn(me, (T(g["c3"]), T(g["c4"])), torch.from_numpy(g["boxes"].copy()))
+        assert torch.equal(b3, boxes)

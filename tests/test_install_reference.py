@@ -124,3 +124,16 @@ def test_localization_install_dispatch():
     finally:
         amd.uninstall()
     assert dcf.max2d is ref_max2d and DiMP.localize_advanced is ref_dimp and ToMP.localize_advanced is ref_tomp
+
+
+def test_iou_refine_install_dispatch():
+    ref_harness.install()
+    from pytracking.tracker.dimp.dimp import DiMP
+    from pytracking_amd import install as amd
+    ref_d, ref_r = DiMP.optimize_boxes_default, DiMP.optimize_boxes_relative
+    amd.install()
+    try:
+        assert DiMP.optimize_boxes_default.__wrapped__ is ref_d and DiMP.optimize_boxes_relative.__wrapped__ is ref_r
+    finally:
+        amd.uninstall()
+    assert DiMP.optimize_boxes_default is ref_d and DiMP.optimize_boxes_relative is ref_r

@@ -207,3 +207,18 @@ def test_localize_decision_ladder_and_two_peaks(monkeypatch):
         np.testing.assert_allclose(tv.numpy(), c["tv"], rtol=1e-6, atol=1e-6)
         seen.add(flag)
     assert seen == {"normal", "not_found", "uncertain", "hard_negative"}
+
+
+@pytest.mark.parametrize("tag,relative", [("default", False), ("default_decay", False), ("relative", True)])
+def test_iou_refinement(tag, relative):
+    """IoU-guided box refinement (dimp.py:725-788 on atom_iou_net.py:96-136): float64 restatement vs the reference run."""
+    import torch
+    from oracle import iou_oracle as IO
+    g = load_golden("iou_refine")
+    t64 = lambda a: torch.from_numpy(a.astype(np.float64))
+    p = {k[2:]: t64(v) for k, v in g.items() if k.startswith("w_")}
+    iters, step, decay = g[f"{tag}_cfg"]
+    boxes, iou = IO.refine(p, (t64(g["mod3"]), t64(g["mod4"])), (t64(g["c3"]), t64(g["c4"])), t64(g["boxes"]), int(iters),
+                           float(step), float(decay), relative)
+    np.testing.assert_allclose(boxes.numpy(), g[f"{tag}_boxes"], rtol=2e-5, atol=2e-4)
+    np.testing.assert_allclose(iou.numpy(), g[f"{tag}_iou"], rtol=2e-5, atol=2e-5)
