@@ -47,6 +47,7 @@ struct IouCarve {
     int nz3, nz4;
 };
 constexpr int KSPLIT = 4;                           // K-steps of 64 per split-K slice of the forward GEMMs
+constexpr int GSL = 16;                             // element slices of the PrRoIPool coordinate gradient per proposal
 IouCarve iou_carve(const pt_iou_dims* d, int P) {
     IouCarve c{};
     const size_t K3 = (size_t)d->C3 * P3 * P3, K4 = (size_t)d->C4 * P4 * P4;
@@ -57,7 +58,7 @@ IouCarve iou_carve(const pt_iou_dims* d, int P) {
     c.rois = take((size_t)P * 5); c.X3 = take(P * K3); c.X4 = take(P * K4);
     c.part3 = take((size_t)c.nz3 * P * d->I3); c.part4 = take((size_t)c.nz4 * P * d->I4);
     c.G3 = take((size_t)P * d->I3); c.G4 = take((size_t)P * d->I4); c.dX3 = take(P * K3); c.dX4 = take(P * K4);
-    c.gr3 = take((size_t)P * 5); c.gr4 = take((size_t)P * 5); c.msc3 = take(K3); c.msc4 = take(K4);
+    c.gr3 = take((size_t)P * GSL * 4); c.gr4 = take((size_t)P * GSL * 4); c.msc3 = take(K3); c.msc4 = take(K4);
     c.state = take((size_t)P * 4); c.szn = take(2);
     c.total = o;
     return c;
@@ -158,8 +159,14 @@ struct UpdArgs {
 __global__ __launch_bounds__(64) void k_iou_update(UpdArgs a) {
     const int p = blockIdx.x * 64 + threadIdx.x;
     if (p >= a.P) return;
-    const float gx0 = a.gr3[5 * p + 1] + a.gr4[5 * p + 1], gy0 = a.gr3[5 * p + 2] + a.gr4[5 * p + 2];
-    const float gx1 = a.gr3[5 * p + 3] + a.gr4[5 * p + 3], gy1 = a.gr3[5 * p + 4] + a.gr4[5 * p + 4];
+    float g3[4] = {0.f, 0.f, 0.f, 0.f}, g4[4] = {0.f, 0.f, 0.f, 0.f};   // slice partials, fixed order
+    for (int sl = 0; sl < GSL; ++sl)
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+            g3[j] += a.gr3[((long)p * GSL + sl) * 4 + j];
+            g4[j] += a.gr4[((long)p * GSL + sl) * 4 + j];
+        }
+    const float gx0 = g3[0] + g4[0], gy0 = g3[1] + g4[1], gx1 = g3[2] + g4[2], gy1 = g3[3] + g4[3];
     const float gx = gx0 + gx1, gy = gy0 + gy1, gw = gx1, gh = gy1;      // [x, y, x + w, y + h]
     float* s = a.state + 4 * p;
     float x, y, w, h;
@@ -264,11 +271,11 @@ extern "C" int pt_iou_refine_f32(const pt_iou_dims* d, const float* params, cons
         g = gemm_args(base + cv.G4, I4, P, W4T, P, K4, I4, nullptr, base + cv.dX4, K4);
         g.scale = base + cv.msc4;
         if ((rc = launch_gemm(g, st))) return rc;
-        if ((rc = pt_prroi_bwd_coor_f32(base + cv.dX3, c3, base + cv.rois, base + cv.gr3, 1, d->C3, d->H3, d->W3, P, P3, P3,
-                                        S3, stream)))
+        if ((rc = pt_launch_prroi_bwd_coor_sliced(base + cv.dX3, c3, base + cv.rois, base + cv.gr3, 1, d->C3, d->H3, d->W3, P,
+                                                  P3, P3, S3, GSL, st)))
             return rc;
-        if ((rc = pt_prroi_bwd_coor_f32(base + cv.dX4, c4, base + cv.rois, base + cv.gr4, 1, d->C4, d->H4, d->W4, P, P4, P4,
-                                        S4, stream)))
+        if ((rc = pt_launch_prroi_bwd_coor_sliced(base + cv.dX4, c4, base + cv.rois, base + cv.gr4, 1, d->C4, d->H4, d->W4, P,
+                                                  P4, P4, S4, GSL, st)))
             return rc;
         UpdArgs ua{base + cv.gr3, base + cv.gr4, base + cv.szn, base + cv.state, base + cv.rois, boxes_out, P, relative,
                    it == num_iter - 1, {step[0], step[1], step[2], step[3]}};

@@ -94,7 +94,9 @@ __global__ void k_prroi_bwd_feat(const float* __restrict__ gout, const float* __
     }
 }
 
-// one workgroup per RoI; threads stride over (c,p,q); fixed-order block reduction of the four coordinate sums
+// workgroup = (RoI, slice of the (c,p,q) elements); threads stride over the slice; fixed-order block reduction of the
+// four coordinate sums.  One slice (gridDim.y == 1): grois (R,5) is written directly.  Several slices: `grois` receives
+// the partial sums (R, slices, 4) and the consumer adds them in slice order (a 10-RoI call would otherwise occupy 10 CUs).
 __global__ __launch_bounds__(256) void k_prroi_bwd_coor(const float* __restrict__ gout, const float* __restrict__ feat,
                                                         const float* __restrict__ rois, float* __restrict__ grois,
                                                         int N, int C, int H, int W, int R, int PH, int PW,
@@ -102,8 +104,9 @@ __global__ __launch_bounds__(256) void k_prroi_bwd_coor(const float* __restrict_
     __shared__ float scratch[16];
     const int r = blockIdx.x;
     const int per = C * PH * PW;
+    const int chunk = (per + gridDim.y - 1) / gridDim.y, e0 = blockIdx.y * chunk, e1 = min(per, e0 + chunk);
     float gx0 = 0.f, gy0 = 0.f, gx1 = 0.f, gy1 = 0.f;
-    for (int e = threadIdx.x; e < per; e += blockDim.x) {
+    for (int e = e0 + threadIdx.x; e < e1; e += blockDim.x) {
         const int q = e % PW, p = (e / PW) % PH, c = e / (PW * PH);
         const Bin k = make_bin(rois + 5 * r, p, q, PH, PW, scale, H, W);
         if (!(k.area > 0.f) || k.b < 0 || k.b >= N) continue;
@@ -142,12 +145,20 @@ __global__ __launch_bounds__(256) void k_prroi_bwd_coor(const float* __restrict_
     gx1 = block_sum(gx1, scratch);
     gy1 = block_sum(gy1, scratch);
     if (threadIdx.x == 0) {
-        float* o = grois + 5 * r;
-        o[0] = 0.f;
-        o[1] = gx0 * scale;
-        o[2] = gy0 * scale;
-        o[3] = gx1 * scale;
-        o[4] = gy1 * scale;
+        if (gridDim.y == 1) {
+            float* o = grois + 5 * r;
+            o[0] = 0.f;
+            o[1] = gx0 * scale;
+            o[2] = gy0 * scale;
+            o[3] = gx1 * scale;
+            o[4] = gy1 * scale;
+        } else {
+            float* o = grois + ((long)r * gridDim.y + blockIdx.y) * 4;
+            o[0] = gx0 * scale;
+            o[1] = gy0 * scale;
+            o[2] = gx1 * scale;
+            o[3] = gy1 * scale;
+        }
     }
 }
 
@@ -188,6 +199,15 @@ extern "C" int pt_prroi_bwd_coor_f32(const float* grad_out, const float* feature
     if (R == 0) return PT_OK;
     hipLaunchKernelGGL(k_prroi_bwd_coor, dim3(R), dim3(256), 0, (hipStream_t)stream, grad_out, features, rois, grad_rois,
                        N, C, H, W, R, PH, PW, spatial_scale);
+    PT_CHECK_LAUNCH();
+    return PT_OK;
+}
+
+int pt_launch_prroi_bwd_coor_sliced(const float* grad_out, const float* features, const float* rois, float* part, int N,
+                                    int C, int H, int W, int R, int PH, int PW, float spatial_scale, int slices,
+                                    hipStream_t st) {
+    hipLaunchKernelGGL(k_prroi_bwd_coor, dim3(R, slices), dim3(256), 0, st, grad_out, features, rois, part, N, C, H, W, R,
+                       PH, PW, spatial_scale);
     PT_CHECK_LAUNCH();
     return PT_OK;
 }

@@ -99,6 +99,11 @@ int pt_sd_solve_impl(const pt_sd_params* prm, const float* w_in, const float* fe
                      float* losses, void* ws, size_t ws_bytes, hipStream_t st, bool copy_w0, float* w_final,
                      const PtClsFin* cls, const float* src);
 
+// PrRoIPool coordinate gradient as partial sums part[(r * slices + s) * 4 + {x0,y0,x1,y1}] (prroi.hip); slices >= 2
+int pt_launch_prroi_bwd_coor_sliced(const float* grad_out, const float* features, const float* rois, float* part, int N,
+                                    int C, int H, int W, int R, int PH, int PW, float spatial_scale, int slices,
+                                    hipStream_t st);
+
 // measurement hook (profile.hip): no-ops unless a pt_profile is attached
 void pt_prof_begin(int kernel_id, hipStream_t st);
 void pt_prof_end(int kernel_id, hipStream_t st);
