@@ -268,6 +268,9 @@ int pt_localize_f32(const float* scores, const float* scores_hn, const float* ne
  *   vectors (get_modulation); init_boxes / boxes_out (P,4) xywh in image coordinates; iou_out (P) = the prediction of the
  *   last forward pass, as the reference returns it.  step_length4: HOST [s,s,s,s] or [s0,s0,s1,s1] (dimp.py:737-738);
  *   relative = 1: optimise [cx/sw, cy/sh, log w, log h] with [sw, sh] = size of the first box (dimp.py:767-768).
+ *   backtrack = 0: DiMP -- one step length for all proposals, multiplied by step_decay after every iteration;
+ *   backtrack = 1: ATOM.optimize_boxes (pytracking/tracker/atom/atom.py:758-836) -- a proposal whose predicted IoU did
+ *     not improve multiplies ITS step length by step_decay and takes its previous step back (no-op when step_decay >= 1).
  *   Pools are the reference's: 5x5 at 1/8 on c3, 3x3 at 1/16 on c4.  Covered: C3*25, C4*9, I3, I4 multiples of 32, P <= 256.
  * ---------------------------------------------------------------------------------------------- */
 typedef struct pt_iou_dims { int C3, C4, I3, I4, H3, W3, H4, W4; } pt_iou_dims;
@@ -277,7 +280,7 @@ int pt_iou_prepare_f32(const pt_iou_dims* dims, const float* params, float* prep
 size_t pt_iou_refine_ws_bytes(const pt_iou_dims* dims, int P);
 int pt_iou_refine_f32(const pt_iou_dims* dims, const float* params, const float* prepared, const float* c3, const float* c4,
                       const float* mod3, const float* mod4, const float* init_boxes, float* boxes_out, float* iou_out,
-                      int P, int num_iter, const float* step_length4, float step_decay, int relative,
+                      int P, int num_iter, const float* step_length4, float step_decay, int relative, int backtrack,
                       void* ws, size_t ws_bytes, void* stream);
 
 /* ------------------------------------------------------------------------------------------------

@@ -2,6 +2,7 @@
   AtomIoUNet.predict_iou                                   ltr/models/bbreg/atom_iou_net.py:96-136
   LinearBlock (Linear -> BatchNorm2d(eval) -> ReLU)        ltr/models/layers/blocks.py:23-36
   DiMP.optimize_boxes_default / optimize_boxes_relative    pytracking/tracker/dimp/dimp.py:725-788
+  ATOM.optimize_boxes                                      pytracking/tracker/atom/atom.py:758-836
   rect_to_rel / rel_to_rect                                ltr/data/bounding_box_utils.py:4-33
 PrRoIPool = oracle/prroi_torch.py ("parity unpinned" upstream, self-pinned there).  A floating-point kernel with a
 gradient: torch autograd supplies d IoU / d box exactly as the reference obtains it.
@@ -63,3 +64,34 @@ def refine(p, modulation, feat, init_boxes, num_iter, step_length, step_decay, r
     if relative:
         boxes = rel_to_rect(rel, sz_norm)
     return boxes.reshape(-1, 4).detach(), out.detach().reshape(-1)
+
+
+def refine_atom(p, modulation, feat, init_boxes, num_iter, step_length, step_decay, relative):
+    """ATOM.optimize_boxes (atom.py:758-836): per-proposal step length; a proposal whose predicted IoU did not improve
+    shrinks its step length and takes the previous step back.  Also returns how many (iteration, proposal) pairs
+    backtracked, so that tests can check the branch was exercised."""
+    boxes = init_boxes.reshape(1, -1, 4).clone()
+    P = boxes.shape[1]
+    slen = step_length * torch.ones(1, P, 1, dtype=boxes.dtype)
+    prev = -99999999 * torch.ones(1, P, dtype=boxes.dtype)
+    step = torch.zeros_like(boxes)
+    if relative:
+        sz_norm = boxes[:, :1, 2:].clone()
+        var0 = rect_to_rel(boxes, sz_norm)
+    else:
+        var0 = boxes
+    out, backtracks = None, 0
+    for _ in range(num_iter):
+        var = var0.clone().detach().requires_grad_(True)
+        out = predict_iou(p, modulation, feat, rel_to_rect(var, sz_norm) if relative else var)
+        out.backward(gradient=torch.ones_like(out))
+        mask = (out.detach() > prev) | (step_decay >= 1)
+        backtracks += int((~mask).sum())
+        mf = mask.reshape(1, -1, 1).to(boxes.dtype)
+        slen[~mask, :] *= step_decay
+        prev = out.detach().clone()
+        direction = var.grad if relative else var.grad * var[:, :, 2:].repeat(1, 1, 2)
+        step = mf * slen * direction - (1.0 - mf) * step
+        var0 = (var + step).detach()
+    boxes = rel_to_rect(var0, sz_norm) if relative else var0
+    return boxes.reshape(-1, 4).detach(), out.detach().reshape(-1), backtracks

@@ -435,6 +435,16 @@ def gen_iou_refine():
         me = types.SimpleNamespace(params=params, net=types.SimpleNamespace(bb_regressor=net), iou_modulation=(mod3, mod4))
         b, iou = method(me, (c3, c4), T(boxes.copy()))
         out.update({f"{tag}_boxes": b.numpy(), f"{tag}_iou": iou.numpy(), f"{tag}_cfg": np.array([iters, step, decay])})
+    from pytracking.tracker.atom.atom import ATOM
+    for tag, iters, step, decay, space in (("atom_default", 6, 3.0, 0.5, "default"), ("atom_relative", 6, 6e-2, 0.5, "relative"),
+                                           ("atom_nodecay", 5, 1.0, 1.0, "default")):
+        params = TrackerParams()
+        params.device = "cpu"
+        params.box_refinement_iter, params.box_refinement_step_length, params.box_refinement_step_decay = iters, step, decay
+        params.box_refinement_space = space
+        me = types.SimpleNamespace(params=params, iou_predictor=net, target_feat=(mod3, mod4))
+        b, iou = ATOM.optimize_boxes(me, (c3, c4), T(boxes.copy()))
+        out.update({f"{tag}_boxes": b.numpy(), f"{tag}_iou": iou.numpy(), f"{tag}_cfg": np.array([iters, step, decay])})
     save("iou_refine", **out)
 
 

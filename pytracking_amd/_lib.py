@@ -180,7 +180,7 @@ def lib():
     L.pt_iou_refine_ws_bytes.restype = sz
     L.pt_iou_refine_ws_bytes.argtypes = [ip, i]
     L.pt_iou_refine_f32.restype = i
-    L.pt_iou_refine_f32.argtypes = [ip, vp, vp, vp, vp, vp, vp, vp, vp, vp, i, i, fp, f, i, vp, sz, vp]
+    L.pt_iou_refine_f32.argtypes = [ip, vp, vp, vp, vp, vp, vp, vp, vp, vp, i, i, fp, f, i, i, vp, sz, vp]
     L.pt_profile_create.restype = i
     L.pt_profile_create.argtypes = [ctypes.POINTER(vp), i]
     L.pt_profile_attach.restype = i

@@ -2,6 +2,7 @@
 //   AtomIoUNet.predict_iou (modulation, PrRoIPool 5x5 @ 1/8 and 3x3 @ 1/16, two LinearBlocks, Linear -> IoU)
 //                                                             ltr/models/bbreg/atom_iou_net.py:96-136, layers/blocks.py:23-36
 //   DiMP.optimize_boxes_default / optimize_boxes_relative     pytracking/tracker/dimp/dimp.py:725-788
+//   ATOM.optimize_boxes (per-proposal backtracking)           pytracking/tracker/atom/atom.py:758-836
 //   rect_to_rel / rel_to_rect                                 ltr/data/bounding_box_utils.py:4-33
 // The reference runs every refinement step as an autograd forward + backward (~60 launches, a host-visible graph per
 // step, 5-10 steps per frame).  Here the gradient of the predicted IoU w.r.t. the box is written out: forward pools ->
@@ -43,7 +44,7 @@ int iou_check(const pt_iou_dims* d) {
 }
 
 struct IouCarve {
-    size_t rois, X3, X4, part3, part4, G3, G4, dX3, dX4, gr3, gr4, msc3, msc4, state, szn, total;
+    size_t rois, X3, X4, part3, part4, G3, G4, dX3, dX4, gr3, gr4, msc3, msc4, state, szn, prev, slen, pstep, total;
     int nz3, nz4;
 };
 constexpr int KSPLIT = 4;                           // K-steps of 64 per split-K slice of the forward GEMMs
@@ -60,6 +61,7 @@ IouCarve iou_carve(const pt_iou_dims* d, int P) {
     c.G3 = take((size_t)P * d->I3); c.G4 = take((size_t)P * d->I4); c.dX3 = take(P * K3); c.dX4 = take(P * K4);
     c.gr3 = take((size_t)P * GSL * 4); c.gr4 = take((size_t)P * GSL * 4); c.msc3 = take(K3); c.msc4 = take(K4);
     c.state = take((size_t)P * 4); c.szn = take(2);
+    c.prev = take(P); c.slen = take((size_t)P * 4); c.pstep = take((size_t)P * 4);
     c.total = o;
     return c;
 }
@@ -83,8 +85,9 @@ __global__ __launch_bounds__(256) void k_transpose(const float* in, float* out, 
 
 struct SetupArgs {
     const float *boxes, *mod3, *mod4;
-    float *state, *szn, *rois, *msc3, *msc4;
+    float *state, *szn, *rois, *msc3, *msc4, *prev, *slen, *pstep;
     int P, K3, K4, relative;
+    float step[4];
 };
 
 // per-column modulation of the pooled features, the optimisation variable (rect or relative) and the first rois
@@ -96,6 +99,9 @@ __global__ __launch_bounds__(256) void k_iou_setup(SetupArgs a) {
         const float x = a.boxes[4 * idx], y = a.boxes[4 * idx + 1], w = a.boxes[4 * idx + 2], h = a.boxes[4 * idx + 3];
         const float sw = a.boxes[2], sh = a.boxes[3];                   // sz_norm = size of the first box (dimp.py:767)
         if (idx == 0) { a.szn[0] = sw; a.szn[1] = sh; }
+        a.prev[idx] = -99999999.f;                                      // outputs_prev (atom.py:769)
+#pragma unroll
+        for (int j = 0; j < 4; ++j) { a.slen[4 * idx + j] = a.step[j]; a.pstep[4 * idx + j] = 0.f; }
         float* s = a.state + 4 * idx;
         if (a.relative) {
             s[0] = (x + 0.5f * w) / sw; s[1] = (y + 0.5f * h) / sh; s[2] = logf(w); s[3] = logf(h);
@@ -149,10 +155,10 @@ __global__ __launch_bounds__(256) void k_iou_head(HeadArgs a) {
 }
 
 struct UpdArgs {
-    const float *gr3, *gr4, *szn;
-    float *state, *rois, *boxes_out;
-    int P, relative, last;
-    float step[4];
+    const float *gr3, *gr4, *szn, *iou;
+    float *state, *rois, *boxes_out, *prev, *slen, *pstep;
+    int P, relative, last, backtrack;
+    float step[4], decay;
 };
 
 // d IoU / d [x0,y0,x1,y1] (both levels) -> gradient in the optimisation variable -> ascent step -> next rois
@@ -169,21 +175,34 @@ __global__ __launch_bounds__(64) void k_iou_update(UpdArgs a) {
     const float gx0 = g3[0] + g4[0], gy0 = g3[1] + g4[1], gx1 = g3[2] + g4[2], gy1 = g3[3] + g4[3];
     const float gx = gx0 + gx1, gy = gy0 + gy1, gw = gx1, gh = gy1;      // [x, y, x + w, y + h]
     float* s = a.state + 4 * p;
-    float x, y, w, h;
+    float dir[4];                                                        // ascent direction in the optimisation variable
     if (a.relative) {
         const float sw = a.szn[0], sh = a.szn[1];
         const float w0 = expf(s[2]), h0 = expf(s[3]);                    // rel_to_rect at the current iterate
-        s[0] += a.step[0] * (gx * sw);
-        s[1] += a.step[1] * (gy * sh);
-        s[2] += a.step[2] * (w0 * (gw - 0.5f * gx));
-        s[3] += a.step[3] * (h0 * (gh - 0.5f * gy));
-        w = expf(s[2]); h = expf(s[3]); x = s[0] * sw - 0.5f * w; y = s[1] * sh - 0.5f * h;
+        dir[0] = gx * sw; dir[1] = gy * sh; dir[2] = w0 * (gw - 0.5f * gx); dir[3] = h0 * (gh - 0.5f * gy);
     } else {
-        const float w0 = s[2], h0 = s[3];
-        s[0] += a.step[0] * gx * w0;
-        s[1] += a.step[1] * gy * h0;
-        s[2] += a.step[2] * gw * w0;
-        s[3] += a.step[3] * gh * h0;
+        dir[0] = gx * s[2]; dir[1] = gy * s[3]; dir[2] = gw * s[2]; dir[3] = gh * s[3];   // grad * [w, h, w, h]
+    }
+    if (a.backtrack) {
+        // ATOM (atom.py:783-795,812-820): a proposal whose predicted IoU did not improve shrinks its own step length and
+        // takes the previous step back; the others ascend with their current step length
+        const bool up = a.iou[p] > a.prev[p] || a.decay >= 1.f;
+        a.prev[p] = a.iou[p];
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+            if (!up) a.slen[4 * p + j] *= a.decay;
+            const float st = up ? a.slen[4 * p + j] * dir[j] : -a.pstep[4 * p + j];
+            a.pstep[4 * p + j] = st;
+            s[j] += st;
+        }
+    } else {
+#pragma unroll
+        for (int j = 0; j < 4; ++j) s[j] += a.step[j] * dir[j];
+    }
+    float x, y, w, h;
+    if (a.relative) {
+        w = expf(s[2]); h = expf(s[3]); x = s[0] * a.szn[0] - 0.5f * w; y = s[1] * a.szn[1] - 0.5f * h;
+    } else {
         x = s[0]; y = s[1]; w = s[2]; h = s[3];
     }
     float* r = a.rois + 5 * p;
@@ -226,7 +245,8 @@ extern "C" size_t pt_iou_refine_ws_bytes(const pt_iou_dims* d, int P) {
 extern "C" int pt_iou_refine_f32(const pt_iou_dims* d, const float* params, const float* prepared, const float* c3,
                                  const float* c4, const float* mod3, const float* mod4, const float* init_boxes,
                                  float* boxes_out, float* iou_out, int P, int num_iter, const float* step_length4,
-                                 float step_decay, int relative, void* ws, size_t ws_bytes, void* stream) {
+                                 float step_decay, int relative, int backtrack, void* ws, size_t ws_bytes,
+                                 void* stream) {
     if (!params || !prepared || !c3 || !c4 || !mod3 || !mod4 || !init_boxes || !boxes_out || !iou_out || !step_length4 || !ws)
         return PT_ERR_NULL;
     int rc = iou_check(d);
@@ -242,7 +262,8 @@ extern "C" int pt_iou_refine_f32(const pt_iou_dims* d, const float* params, cons
     const float* W3T = prepared;
     const float* W4T = prepared + pt_align_floats((size_t)I3 * K3);
     SetupArgs sa{init_boxes, mod3, mod4, base + cv.state, base + cv.szn, base + cv.rois, base + cv.msc3, base + cv.msc4,
-                 P, K3, K4, relative};
+                 base + cv.prev, base + cv.slen, base + cv.pstep, P, K3, K4, relative,
+                 {step_length4[0], step_length4[1], step_length4[2], step_length4[3]}};
     hipLaunchKernelGGL(k_iou_setup, dim3((std::max(std::max(K3, K4), P) + 255) / 256), dim3(256), 0, st, sa);
     PT_CHECK_LAUNCH();
     float step[4] = {step_length4[0], step_length4[1], step_length4[2], step_length4[3]};
@@ -277,11 +298,12 @@ extern "C" int pt_iou_refine_f32(const pt_iou_dims* d, const float* params, cons
         if ((rc = pt_launch_prroi_bwd_coor_sliced(base + cv.dX4, c4, base + cv.rois, base + cv.gr4, 1, d->C4, d->H4, d->W4, P,
                                                   P4, P4, S4, GSL, st)))
             return rc;
-        UpdArgs ua{base + cv.gr3, base + cv.gr4, base + cv.szn, base + cv.state, base + cv.rois, boxes_out, P, relative,
-                   it == num_iter - 1, {step[0], step[1], step[2], step[3]}};
+        UpdArgs ua{base + cv.gr3, base + cv.gr4, base + cv.szn, iou_out, base + cv.state, base + cv.rois, boxes_out,
+                   base + cv.prev, base + cv.slen, base + cv.pstep, P, relative, it == num_iter - 1, backtrack,
+                   {step[0], step[1], step[2], step[3]}, step_decay};
         hipLaunchKernelGGL(k_iou_update, dim3((P + 63) / 64), dim3(64), 0, st, ua);
         PT_CHECK_LAUNCH();
-        for (float& s : step) s *= step_decay;                          // dimp.py:757,783
+        for (float& s : step) s *= step_decay;                          // dimp.py:748,779 (unused when backtracking)
     }
     return PT_OK;
 }

@@ -22,7 +22,8 @@ What gets rebound (import path = contract; nothing in the reference tree is edit
                                                                                       -> pytracking_amd.features
   pytracking.libs.dcf.max2d, pytracking.tracker.dimp.dimp.DiMP.localize_advanced,
   pytracking.tracker.tomp.tomp.ToMP.localize_advanced  (score-map localisation)       -> pytracking_amd.localization
-  pytracking.tracker.dimp.dimp.DiMP.optimize_boxes_default / optimize_boxes_relative  (IoU-guided box refinement)
+  pytracking.tracker.dimp.dimp.DiMP.optimize_boxes_default / optimize_boxes_relative,
+  pytracking.tracker.atom.atom.ATOM.optimize_boxes                                    (IoU-guided box refinement)
                                                                                       -> pytracking_amd.iou_refine
 
 Dispatch rule of the rebound *functions*: device fp32 tensors of a shape the gfx950 kernels cover go to the C ABI;
@@ -242,15 +243,23 @@ def _install_iou_refine(orig, strict):
         cls = importlib.import_module("pytracking.tracker.dimp.dimp").DiMP
     except Exception:
         return
-    orig["iou_refine"] = (cls.optimize_boxes_default, cls.optimize_boxes_relative)
-    for name, fast in (("optimize_boxes_default", _ir.optimize_boxes_default),
-                       ("optimize_boxes_relative", _ir.optimize_boxes_relative)):
+    orig["iou_refine"] = [(cls, "optimize_boxes_default", cls.optimize_boxes_default),
+                          (cls, "optimize_boxes_relative", cls.optimize_boxes_relative)]
+    targets = [(cls, "optimize_boxes_default", _ir.optimize_boxes_default, lambda t: t.net.bb_regressor),
+               (cls, "optimize_boxes_relative", _ir.optimize_boxes_relative, lambda t: t.net.bb_regressor)]
+    try:
+        acls = importlib.import_module("pytracking.tracker.atom.atom").ATOM
+        orig["iou_refine"].append((acls, "optimize_boxes", acls.optimize_boxes))
+        targets.append((acls, "optimize_boxes", _ir.optimize_boxes_atom, lambda t: t.iou_predictor))
+    except Exception:
+        pass
+    for cls, name, fast, get_net in targets:
         ref_method = getattr(cls, name)
 
-        def method(self, iou_features, init_boxes, _fast=fast, _ref=ref_method):
+        def method(self, iou_features, init_boxes, _fast=fast, _ref=ref_method, _net=get_net):
             feats = list(iou_features)
             ok = (len(feats) == 2 and all(f.is_cuda and f.dtype == torch.float32 and f.shape[0] == 1 for f in feats)
-                  and not self.net.bb_regressor.training)
+                  and not _net(self).training)
             if ok:
                 try:
                     return _fast(self, feats, init_boxes)
@@ -389,8 +398,8 @@ def uninstall():
     if "clf_head" in orig:
         importlib.import_module("ltr.models.target_classifier.features").residual_bottleneck = orig["clf_head"]
     if "iou_refine" in orig:
-        cls = importlib.import_module("pytracking.tracker.dimp.dimp").DiMP
-        cls.optimize_boxes_default, cls.optimize_boxes_relative = orig["iou_refine"]
+        for cls, name, ref in orig["iou_refine"]:
+            setattr(cls, name, ref)
     if "localization" in orig:
         for key, ref in orig["localization"].items():
             if key == "max2d":

@@ -1,5 +1,5 @@
 """Host-side mirror of the IoU-guided box refinement: `DiMP.optimize_boxes_default` / `optimize_boxes_relative`
-(pytracking/tracker/dimp/dimp.py:725-788; ATOM's `optimize_boxes`, atom.py:758-790, has the default body) on
+(pytracking/tracker/dimp/dimp.py:725-788) and `ATOM.optimize_boxes` (pytracking/tracker/atom/atom.py:758-836) on
 `AtomIoUNet.predict_iou` (ltr/models/bbreg/atom_iou_net.py:96-136).
 
 The two functions are written to be bound as the tracker's methods: they read `self.net.bb_regressor` (the reference's
@@ -39,7 +39,7 @@ def _packs(net, dims):
     return pack, st["prepared"]
 
 
-def refine_boxes(net, modulation, iou_features, init_boxes, num_iter, step_length, step_decay, relative):
+def refine_boxes(net, modulation, iou_features, init_boxes, num_iter, step_length, step_decay, relative, backtrack=False):
     """-> (boxes (P,4), iou (P)) device tensors.  net: AtomIoUNet; modulation: (mod3, mod4) of one target;
     iou_features: (c3_t (1,C3,H3,W3), c4_t (1,C4,H4,W4)); init_boxes (P,4) xywh."""
     if net.training or net.fc3_rt.bn is None or net.fc3_rt.relu is None:
@@ -73,7 +73,7 @@ def refine_boxes(net, modulation, iou_features, init_boxes, num_iter, step_lengt
     out_iou = torch.empty(P, dtype=torch.float32, device=c3.device)
     rc = L.pt_iou_refine_f32(ctypes.byref(dims), _ptr(pack), _ptr(prepared), _ptr(c3), _ptr(c4), _ptr(mod3), _ptr(mod4),
                              _ptr(boxes), _ptr(out_boxes), _ptr(out_iou), P, int(num_iter), (ctypes.c_float * 4)(*steps),
-                             float(step_decay), int(bool(relative)), _ptr(ws), ws.numel(), _stream())
+                             float(step_decay), int(bool(relative)), int(bool(backtrack)), _ptr(ws), ws.numel(), _stream())
     _lib.check(rc, "pt_iou_refine_f32")
     return out_boxes, out_iou
 
@@ -82,6 +82,18 @@ def _optimize(self, iou_features, init_boxes, relative):
     p = self.params
     boxes, iou = refine_boxes(self.net.bb_regressor, self.iou_modulation, iou_features, init_boxes, p.box_refinement_iter,
                               p.box_refinement_step_length, p.box_refinement_step_decay, relative)
+    return boxes.view(-1, 4).cpu(), iou.view(-1).cpu()
+
+
+def optimize_boxes_atom(self, iou_features, init_boxes):
+    """Drop-in for `ATOM.optimize_boxes` (pytracking/tracker/atom/atom.py:758-836): the network is `self.iou_predictor`, the
+    modulation `self.target_feat`, and every proposal backtracks on its own when its predicted IoU stops improving."""
+    p = self.params
+    space = p.get('box_refinement_space', 'default')
+    if space not in ('default', 'relative'):
+        raise ValueError('Unknown box_refinement_space {}'.format(space))
+    boxes, iou = refine_boxes(self.iou_predictor, self.target_feat, iou_features, init_boxes, p.box_refinement_iter,
+                              p.box_refinement_step_length, p.box_refinement_step_decay, space == 'relative', backtrack=True)
     return boxes.view(-1, 4).cpu(), iou.view(-1).cpu()
 
 

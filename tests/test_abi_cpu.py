@@ -139,10 +139,10 @@ def test_iou_refine_argument_checks(L):
     assert L.pt_iou_param_floats(ctypes.byref(bad)) == 0 and L.pt_iou_refine_ws_bytes(ctypes.byref(bad), 10) == 0
     f4 = (ctypes.c_float * 4)(1, 1, 1, 1)
     a = [one] * 9
-    assert L.pt_iou_refine_f32(ctypes.byref(d), n, *a[1:], 10, 5, f4, 1.0, 0, one, 1 << 30, n) == -1
-    assert L.pt_iou_refine_f32(ctypes.byref(d), *a, 0, 5, f4, 1.0, 0, one, 1 << 30, n) == -2
-    assert L.pt_iou_refine_f32(ctypes.byref(bad), *a, 10, 5, f4, 1.0, 0, one, 1 << 30, n) == -3
-    assert L.pt_iou_refine_f32(ctypes.byref(d), *a, 10, 5, f4, 1.0, 0, one, 0, n) == -4
+    assert L.pt_iou_refine_f32(ctypes.byref(d), n, *a[1:], 10, 5, f4, 1.0, 0, 0, one, 1 << 30, n) == -1
+    assert L.pt_iou_refine_f32(ctypes.byref(d), *a, 0, 5, f4, 1.0, 0, 0, one, 1 << 30, n) == -2
+    assert L.pt_iou_refine_f32(ctypes.byref(bad), *a, 10, 5, f4, 1.0, 0, 0, one, 1 << 30, n) == -3
+    assert L.pt_iou_refine_f32(ctypes.byref(d), *a, 10, 5, f4, 1.0, 0, 0, one, 0, n) == -4
     assert L.pt_iou_prepare_f32(ctypes.byref(d), one, n, n) == -1
 
 

@@ -682,3 +682,23 @@ def test_iou_refinement_golden(tag, relative):
         params.box_refinement_step_length = (float(step), float(step))
         b3, _ = fn(me, (T(g["c3"]), T(g["c4"])), torch.from_numpy(g["boxes"].copy()))
         assert torch.equal(b3, boxes)
+
+
+@pytest.mark.parametrize("tag,space", [("atom_default", "default"), ("atom_relative", "relative"), ("atom_nodecay", "default")])
+def test_iou_refinement_atom_golden(tag, space):
+    """ATOM.optimize_boxes (atom.py:758-836) with per-proposal backtracking vs the reference run on CPU.  Backtracking is
+    a discontinuous decision on `iou > previous iou`; the golden cases keep a margin, the tolerance is the smooth one."""
+    from pytracking_amd import iou_refine as IR
+    g = load_golden("iou_refine")
+    net = _IoUNetStandIn(g).to(DEV).eval()
+    iters, step, decay = g[f"{tag}_cfg"]
+
+    class P(types.SimpleNamespace):
+        def get(self, name, default=None):
+            return getattr(self, name, default)
+    params = P(box_refinement_iter=int(iters), box_refinement_step_length=float(step), box_refinement_step_decay=float(decay),
+               box_refinement_space=space)
+    me = types.SimpleNamespace(params=params, iou_predictor=net, target_feat=(T(g["mod3"]), T(g["mod4"])))
+    boxes, iou = IR.optimize_boxes_atom(me, (T(g["c3"]), T(g["c4"])), torch.from_numpy(g["boxes"].copy()))
+    close(iou, g[f"{tag}_iou"], atol=2e-4, rtol=2e-4)
+    close(boxes, g[f"{tag}_boxes"], atol=1e-2, rtol=1e-4)

@@ -129,11 +129,13 @@ def test_localization_install_dispatch():
 def test_iou_refine_install_dispatch():
     ref_harness.install()
     from pytracking.tracker.dimp.dimp import DiMP
+    from pytracking.tracker.atom.atom import ATOM
     from pytracking_amd import install as amd
-    ref_d, ref_r = DiMP.optimize_boxes_default, DiMP.optimize_boxes_relative
+    ref_d, ref_r, ref_a = DiMP.optimize_boxes_default, DiMP.optimize_boxes_relative, ATOM.optimize_boxes
     amd.install()
     try:
         assert DiMP.optimize_boxes_default.__wrapped__ is ref_d and DiMP.optimize_boxes_relative.__wrapped__ is ref_r
+        assert ATOM.optimize_boxes.__wrapped__ is ref_a
     finally:
         amd.uninstall()
-    assert DiMP.optimize_boxes_default is ref_d and DiMP.optimize_boxes_relative is ref_r
+    assert DiMP.optimize_boxes_default is ref_d and DiMP.optimize_boxes_relative is ref_r and ATOM.optimize_boxes is ref_a

@@ -222,3 +222,19 @@ def test_iou_refinement(tag, relative):
                            float(step), float(decay), relative)
     np.testing.assert_allclose(boxes.numpy(), g[f"{tag}_boxes"], rtol=2e-5, atol=2e-4)
     np.testing.assert_allclose(iou.numpy(), g[f"{tag}_iou"], rtol=2e-5, atol=2e-5)
+
+
+@pytest.mark.parametrize("tag,relative", [("atom_default", False), ("atom_relative", True), ("atom_nodecay", False)])
+def test_iou_refinement_atom_backtracking(tag, relative):
+    """ATOM.optimize_boxes (atom.py:758-836) incl. the per-proposal backtracking, vs the reference run."""
+    import torch
+    from oracle import iou_oracle as IO
+    g = load_golden("iou_refine")
+    t64 = lambda a: torch.from_numpy(a.astype(np.float64))
+    p = {k[2:]: t64(v) for k, v in g.items() if k.startswith("w_")}
+    iters, step, decay = g[f"{tag}_cfg"]
+    boxes, iou, backtracks = IO.refine_atom(p, (t64(g["mod3"]), t64(g["mod4"])), (t64(g["c3"]), t64(g["c4"])), t64(g["boxes"]),
+                                            int(iters), float(step), float(decay), relative)
+    np.testing.assert_allclose(boxes.numpy(), g[f"{tag}_boxes"], rtol=2e-5, atol=5e-4)
+    np.testing.assert_allclose(iou.numpy(), g[f"{tag}_iou"], rtol=2e-5, atol=2e-5)
+    assert (backtracks > 0) == (decay < 1), backtracks
