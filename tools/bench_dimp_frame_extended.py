@@ -1,0 +1,95 @@
+"""DiMP-50 frame with the rows either side of the solver ("hot-path-only fps and end-to-end fps"; the
+ResNet-50 backbone itself is out of scope and absent here):
+
+    layer-3 backbone features 1x1024x18x18  ->  classification-feature head (pt_clf_head_f32)
+    -> classify + arg-max + memory insert + 5 steepest-descent iterations (pt_track_frame_f32)
+    -> localize_advanced on the score map (pt_localize_f32 + one 32-byte copy)
+    -> IoU-guided box refinement, 10 proposals x 5 iterations (pt_iou_refine_f32 + one copy)
+
+Synthetic inputs as section 8(d) prescribes (N(0,1) IoU features 1x256x36x36 / 1x256x18x18).  Host wall time per frame
+incl. the two device->host copies the tracker needs.   python tools/bench_dimp_frame_extended.py [--frames 300]
+"""
+import argparse
+import json
+import os
+import sys
+import time
+import types
+
+import torch
+
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+from pytracking_amd import _lib, bench_frame, synth  # noqa: E402
+from pytracking_amd import features as FM, iou_refine as IR, localization as LM  # noqa: E402
+from pytracking_amd.prroi_pool import PrRoIPool2D  # noqa: E402
+
+
+class Params(types.SimpleNamespace):
+    def get(self, name, default=None):
+        return getattr(self, name, default)
+
+
+def iou_net(dev):
+    net = torch.nn.Module()
+    for name, k in (("fc3_rt", 5), ("fc4_rt", 3)):
+        blk = torch.nn.Module()
+        blk.linear, blk.bn, blk.relu = torch.nn.Linear(256 * k * k, 256), torch.nn.BatchNorm2d(256), torch.nn.ReLU()
+        setattr(net, name, blk)
+    net.iou_predictor = torch.nn.Linear(512, 1)
+    net.prroi_pool3t, net.prroi_pool4t = PrRoIPool2D(5, 5, 1 / 8), PrRoIPool2D(3, 3, 1 / 16)
+    return net.to(dev).eval()
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--frames", type=int, default=300)
+    a = ap.parse_args()
+    if _lib.needs_build():
+        _lib.build_library()
+    dev = torch.device("cuda", 0)
+    torch.manual_seed(1234)
+    cfg = synth.DIMP50
+    st = bench_frame.TrackState(cfg, cfg["memory"], seed=1234, device=dev)
+    head = FM.residual_bottleneck(feature_dim=256, num_blocks=0, l2norm=True, final_conv=True,
+                                  norm_scale=(1.0 / (512 * 16)) ** 0.5, out_dim=512).to(dev).eval()
+    backbone_feat = [torch.randn(1, 1024, 18, 18, device=dev) for _ in range(8)]
+    net = iou_net(dev)
+    iou_feat = (torch.randn(1, 256, 36, 36, device=dev), torch.randn(1, 256, 18, 18, device=dev))
+    params = Params(target_not_found_threshold=0.25, distractor_threshold=0.8, hard_negative_threshold=0.5,
+                    target_neighborhood_scale=2.2, dispalcement_scale=0.8, box_refinement_iter=5,
+                    box_refinement_step_length=1, box_refinement_step_decay=1)
+    me = types.SimpleNamespace(params=params, kernel_size=torch.Tensor([4, 4]), output_window=None,
+                               img_support_sz=torch.Tensor([288.0, 288.0]), target_sz=torch.Tensor([60.0, 70.0]),
+                               pos=torch.Tensor([144.0, 144.0]), net=types.SimpleNamespace(bb_regressor=net),
+                               iou_modulation=(torch.rand(1, 256, device=dev) + 0.5, torch.rand(1, 256, device=dev) + 0.5))
+    sample_pos, sample_scales = torch.Tensor([[144.0, 144.0]]), torch.Tensor([1.0])
+    base = torch.tensor([109.0, 114.0, 70.0, 60.0])
+    boxes = torch.stack([base] + [base + torch.cat((torch.rand(2) * 14 - 7, torch.rand(2) * 30 - 15)) for _ in range(9)])
+
+    def frame(i, parts):
+        with torch.no_grad():
+            x = head(backbone_feat[i % 8])[0]
+        if parts >= 1:
+            st.step(x, slot=i % st.n, num_iter=5)
+        if parts >= 2:
+            LM.localize_advanced(me, st.scores[None], sample_pos, sample_scales)
+        if parts >= 3:
+            IR.optimize_boxes_default(me, iou_feat, boxes)
+
+    out = {}
+    for tag, parts in (("head_only", 0), ("head+solver", 1), ("head+solver+localize", 2), ("head+solver+localize+iou_refine", 3)):
+        for i in range(20):
+            frame(i, parts)
+        torch.cuda.synchronize()
+        t0 = time.perf_counter()
+        for i in range(a.frames):
+            frame(i, parts)
+        torch.cuda.synchronize()
+        dt = (time.perf_counter() - t0) / a.frames
+        out[tag] = {"us_per_frame": round(dt * 1e6, 1), "frames_per_s": round(1 / dt, 1)}
+    out["workload"] = "DiMP-50 frame without the backbone: clf head + classify/insert/5 SD iterations + localisation + IoU refinement"
+    print(json.dumps(out))
+
+
+if __name__ == "__main__":
+    main()
