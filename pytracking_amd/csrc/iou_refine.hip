@@ -117,14 +117,6 @@ __global__ __launch_bounds__(256) void k_iou_setup(SetupArgs a) {
     }
 }
 
-__global__ __launch_bounds__(256) void k_iou_modulate(float* X3, float* X4, const float* msc3, const float* msc4, int P,
-                                                      int K3, int K4) {
-    const long idx = (long)blockIdx.x * 256 + threadIdx.x;
-    const long n3 = (long)P * K3, n4 = (long)P * K4;
-    if (idx < n3) X3[idx] *= msc3[idx % K3];
-    else if (idx < n3 + n4) X4[idx - n3] *= msc4[(idx - n3) % K4];
-}
-
 struct HeadArgs {
     const float *part3, *part4, *b3, *bn3, *b4, *bn4, *wp, *bp;
     float *G3, *G4, *iou;
@@ -267,14 +259,16 @@ extern "C" int pt_iou_refine_f32(const pt_iou_dims* d, const float* params, cons
     hipLaunchKernelGGL(k_iou_setup, dim3((std::max(std::max(K3, K4), P) + 255) / 256), dim3(256), 0, st, sa);
     PT_CHECK_LAUNCH();
     float step[4] = {step_length4[0], step_length4[1], step_length4[2], step_length4[3]};
+    const float* const feats[2] = {c3, c4};
+    const float* const mods[2] = {mod3, mod4};
+    float* const Xs[2] = {base + cv.X3, base + cv.X4};
+    const float* const dXs[2] = {base + cv.dX3, base + cv.dX4};
+    float* const grs[2] = {base + cv.gr3, base + cv.gr4};
+    const int Cs[2] = {d->C3, d->C4}, Hs[2] = {d->H3, d->H4}, Ws[2] = {d->W3, d->W4}, PHs[2] = {P3, P4};
+    const float scales[2] = {S3, S4};
     for (int it = 0; it < num_iter; ++it) {
-        // ---- forward (atom_iou_net.py:108-134)
-        if ((rc = pt_prroi_fwd_f32(c3, base + cv.rois, base + cv.X3, 1, d->C3, d->H3, d->W3, P, P3, P3, S3, stream))) return rc;
-        if ((rc = pt_prroi_fwd_f32(c4, base + cv.rois, base + cv.X4, 1, d->C4, d->H4, d->W4, P, P4, P4, S4, stream))) return rc;
-        const long tot = (long)P * (K3 + K4);
-        hipLaunchKernelGGL(k_iou_modulate, dim3((unsigned)((tot + 255) / 256)), dim3(256), 0, st, base + cv.X3,
-                           base + cv.X4, base + cv.msc3, base + cv.msc4, P, K3, K4);
-        PT_CHECK_LAUNCH();
+        // ---- forward (atom_iou_net.py:108-134): both pools + modulation in one launch
+        if ((rc = pt_launch_prroi_fwd2(feats, mods, Xs, Cs, Hs, Ws, PHs, scales, base + cv.rois, P, st))) return rc;
         GemmArgs g = gemm_args(base + cv.X3, K3, P, params + po.w3, P, I3, K3, nullptr, base + cv.part3, I3);
         g.ksteps = KSPLIT; g.c_zstride = (long)P * I3;
         if ((rc = launch_gemm(g, st))) return rc;
@@ -292,12 +286,7 @@ extern "C" int pt_iou_refine_f32(const pt_iou_dims* d, const float* params, cons
         g = gemm_args(base + cv.G4, I4, P, W4T, P, K4, I4, nullptr, base + cv.dX4, K4);
         g.scale = base + cv.msc4;
         if ((rc = launch_gemm(g, st))) return rc;
-        if ((rc = pt_launch_prroi_bwd_coor_sliced(base + cv.dX3, c3, base + cv.rois, base + cv.gr3, 1, d->C3, d->H3, d->W3, P,
-                                                  P3, P3, S3, GSL, st)))
-            return rc;
-        if ((rc = pt_launch_prroi_bwd_coor_sliced(base + cv.dX4, c4, base + cv.rois, base + cv.gr4, 1, d->C4, d->H4, d->W4, P,
-                                                  P4, P4, S4, GSL, st)))
-            return rc;
+        if ((rc = pt_launch_prroi_bwd_coor2(dXs, feats, grs, Cs, Hs, Ws, PHs, scales, base + cv.rois, P, GSL, st))) return rc;
         UpdArgs ua{base + cv.gr3, base + cv.gr4, base + cv.szn, iou_out, base + cv.state, base + cv.rois, boxes_out,
                    base + cv.prev, base + cv.slen, base + cv.pstep, P, relative, it == num_iter - 1, backtrack,
                    {step[0], step[1], step[2], step[3]}, step_decay};

@@ -46,15 +46,9 @@ __device__ __forceinline__ Bin make_bin(const float* __restrict__ roi, int p, in
     return k;
 }
 
-__global__ void k_prroi_fwd(const float* __restrict__ feat, const float* __restrict__ rois, float* __restrict__ out,
-                            int N, int C, int H, int W, int R, int PH, int PW, float scale) {
-    const long idx = (long)blockIdx.x * blockDim.x + threadIdx.x;
-    const long total = (long)R * C * PH * PW;
-    if (idx >= total) return;
-    const int q = (int)(idx % PW);
-    const int p = (int)((idx / PW) % PH);
-    const int c = (int)((idx / ((long)PW * PH)) % C);
-    const int r = (int)(idx / ((long)PW * PH * C));
+// one output element: bin (p,q) of channel c of RoI r
+__device__ __forceinline__ float prroi_fwd_elem(const float* __restrict__ feat, const float* __restrict__ rois, int r, int c,
+                                                int p, int q, int N, int C, int H, int W, int PH, int PW, float scale) {
     const Bin k = make_bin(rois + 5 * r, p, q, PH, PW, scale, H, W);
     float acc = 0.f;
     if (k.area > 0.f && k.b >= 0 && k.b < N) {
@@ -68,7 +62,44 @@ __global__ void k_prroi_fwd(const float* __restrict__ feat, const float* __restr
         }
         acc /= k.area;
     }
-    out[idx] = acc;
+    return acc;
+}
+
+__global__ void k_prroi_fwd(const float* __restrict__ feat, const float* __restrict__ rois, float* __restrict__ out,
+                            int N, int C, int H, int W, int R, int PH, int PW, float scale) {
+    const long idx = (long)blockIdx.x * blockDim.x + threadIdx.x;
+    const long total = (long)R * C * PH * PW;
+    if (idx >= total) return;
+    const int q = (int)(idx % PW);
+    const int p = (int)((idx / PW) % PH);
+    const int c = (int)((idx / ((long)PW * PH)) % C);
+    const int r = (int)(idx / ((long)PW * PH * C));
+    out[idx] = prroi_fwd_elem(feat, rois, r, c, p, q, N, C, H, W, PH, PW, scale);
+}
+
+// Two pyramid levels of ONE image pooled with the same RoIs in one launch, each output multiplied by a per-channel
+// factor (the IoU head's modulation, atom_iou_net.py:108-110: pool(m * f) = m * pool(f) for a per-channel m).
+struct Prroi2 {
+    const float* feat[2];
+    const float* chan_scale[2];
+    const float* gout[2];          // backward only
+    float* out[2];                 // forward: pooled (R,C,PH,PH); backward: partial sums (R, slices, 4)
+    int C[2], H[2], W[2], PH[2];
+    float scale[2];
+    const float* rois;
+    int R;
+};
+
+__global__ void k_prroi_fwd2(Prroi2 a) {
+    const long idx = (long)blockIdx.x * blockDim.x + threadIdx.x;
+    const long n0 = (long)a.R * a.C[0] * a.PH[0] * a.PH[0], n1 = (long)a.R * a.C[1] * a.PH[1] * a.PH[1];
+    if (idx >= n0 + n1) return;
+    const int l = idx >= n0;
+    const long e = l ? idx - n0 : idx;
+    const int PH = a.PH[l], C = a.C[l];
+    const int q = (int)(e % PH), p = (int)((e / PH) % PH), c = (int)((e / ((long)PH * PH)) % C);
+    const int r = (int)(e / ((long)PH * PH * C));
+    a.out[l][e] = a.chan_scale[l][c] * prroi_fwd_elem(a.feat[l], a.rois, r, c, p, q, 1, C, a.H[l], a.W[l], PH, PH, a.scale[l]);
 }
 
 __global__ void k_prroi_bwd_feat(const float* __restrict__ gout, const float* __restrict__ rois,
@@ -94,17 +125,12 @@ __global__ void k_prroi_bwd_feat(const float* __restrict__ gout, const float* __
     }
 }
 
-// workgroup = (RoI, slice of the (c,p,q) elements); threads stride over the slice; fixed-order block reduction of the
-// four coordinate sums.  One slice (gridDim.y == 1): grois (R,5) is written directly.  Several slices: `grois` receives
-// the partial sums (R, slices, 4) and the consumer adds them in slice order (a 10-RoI call would otherwise occupy 10 CUs).
-__global__ __launch_bounds__(256) void k_prroi_bwd_coor(const float* __restrict__ gout, const float* __restrict__ feat,
-                                                        const float* __restrict__ rois, float* __restrict__ grois,
-                                                        int N, int C, int H, int W, int R, int PH, int PW,
-                                                        float scale) {
-    __shared__ float scratch[16];
-    const int r = blockIdx.x;
+// Four coordinate sums of RoI r over elements [e0, e1) of its (c,p,q) range, block-reduced in a fixed order (every
+// thread returns them).
+__device__ __forceinline__ void prroi_coor_sums(const float* __restrict__ gout, const float* __restrict__ feat,
+                                                const float* __restrict__ rois, int r, int e0, int e1, int N, int C, int H,
+                                                int W, int PH, int PW, float scale, float* scratch, float out[4]) {
     const int per = C * PH * PW;
-    const int chunk = (per + gridDim.y - 1) / gridDim.y, e0 = blockIdx.y * chunk, e1 = min(per, e0 + chunk);
     float gx0 = 0.f, gy0 = 0.f, gx1 = 0.f, gy1 = 0.f;
     for (int e = e0 + threadIdx.x; e < e1; e += blockDim.x) {
         const int q = e % PW, p = (e / PW) % PH, c = e / (PW * PH);
@@ -140,25 +166,39 @@ __global__ __launch_bounds__(256) void k_prroi_bwd_coor(const float* __restrict_
         gy0 += g * (d_ys * (1.f - fp) + d_ye * (1.f - fp1));
         gy1 += g * (d_ys * fp + d_ye * fp1);
     }
-    gx0 = block_sum(gx0, scratch);
-    gy0 = block_sum(gy0, scratch);
-    gx1 = block_sum(gx1, scratch);
-    gy1 = block_sum(gy1, scratch);
+    out[0] = block_sum(gx0, scratch) * scale;
+    out[1] = block_sum(gy0, scratch) * scale;
+    out[2] = block_sum(gx1, scratch) * scale;
+    out[3] = block_sum(gy1, scratch) * scale;
+}
+
+// one workgroup per RoI: grois (R,5), column 0 = 0
+__global__ __launch_bounds__(256) void k_prroi_bwd_coor(const float* __restrict__ gout, const float* __restrict__ feat,
+                                                        const float* __restrict__ rois, float* __restrict__ grois,
+                                                        int N, int C, int H, int W, int R, int PH, int PW,
+                                                        float scale) {
+    __shared__ float scratch[16];
+    const int r = blockIdx.x;
+    float g[4];
+    prroi_coor_sums(gout, feat, rois, r, 0, C * PH * PW, N, C, H, W, PH, PW, scale, scratch, g);
     if (threadIdx.x == 0) {
-        if (gridDim.y == 1) {
-            float* o = grois + 5 * r;
-            o[0] = 0.f;
-            o[1] = gx0 * scale;
-            o[2] = gy0 * scale;
-            o[3] = gx1 * scale;
-            o[4] = gy1 * scale;
-        } else {
-            float* o = grois + ((long)r * gridDim.y + blockIdx.y) * 4;
-            o[0] = gx0 * scale;
-            o[1] = gy0 * scale;
-            o[2] = gx1 * scale;
-            o[3] = gy1 * scale;
-        }
+        float* o = grois + 5 * r;
+        o[0] = 0.f; o[1] = g[0]; o[2] = g[1]; o[3] = g[2]; o[4] = g[3];
+    }
+}
+
+// workgroup = (RoI, element slice, pyramid level): partial sums out[level][(r * slices + s) * 4 + {x0,y0,x1,y1}], added
+// by the consumer in slice order (a 10-RoI call with one workgroup per RoI keeps 10 CUs busy for > 100 us)
+__global__ __launch_bounds__(256) void k_prroi_bwd_coor2(Prroi2 a) {
+    __shared__ float scratch[16];
+    const int r = blockIdx.x, l = blockIdx.z;
+    const int per = a.C[l] * a.PH[l] * a.PH[l];
+    const int chunk = (per + gridDim.y - 1) / gridDim.y, e0 = blockIdx.y * chunk, e1 = min(per, e0 + chunk);
+    float g[4];
+    prroi_coor_sums(a.gout[l], a.feat[l], a.rois, r, e0, e1, 1, a.C[l], a.H[l], a.W[l], a.PH[l], a.PH[l], a.scale[l], scratch, g);
+    if (threadIdx.x == 0) {
+        float* o = a.out[l] + ((long)r * gridDim.y + blockIdx.y) * 4;
+        o[0] = g[0]; o[1] = g[1]; o[2] = g[2]; o[3] = g[3];
     }
 }
 
@@ -203,11 +243,32 @@ extern "C" int pt_prroi_bwd_coor_f32(const float* grad_out, const float* feature
     return PT_OK;
 }
 
-int pt_launch_prroi_bwd_coor_sliced(const float* grad_out, const float* features, const float* rois, float* part, int N,
-                                    int C, int H, int W, int R, int PH, int PW, float spatial_scale, int slices,
-                                    hipStream_t st) {
-    hipLaunchKernelGGL(k_prroi_bwd_coor, dim3(R, slices), dim3(256), 0, st, grad_out, features, rois, part, N, C, H, W, R,
-                       PH, PW, spatial_scale);
+int pt_launch_prroi_fwd2(const float* const feat[2], const float* const chan_scale[2], float* const out[2],
+                         const int C[2], const int H[2], const int W[2], const int PH[2], const float scale[2],
+                         const float* rois, int R, hipStream_t st) {
+    Prroi2 a{};
+    long total = 0;
+    for (int l = 0; l < 2; ++l) {
+        a.feat[l] = feat[l]; a.chan_scale[l] = chan_scale[l]; a.out[l] = out[l];
+        a.C[l] = C[l]; a.H[l] = H[l]; a.W[l] = W[l]; a.PH[l] = PH[l]; a.scale[l] = scale[l];
+        total += (long)R * C[l] * PH[l] * PH[l];
+    }
+    a.rois = rois; a.R = R;
+    hipLaunchKernelGGL(k_prroi_fwd2, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, st, a);
+    PT_CHECK_LAUNCH();
+    return PT_OK;
+}
+
+int pt_launch_prroi_bwd_coor2(const float* const grad_out[2], const float* const feat[2], float* const part[2],
+                              const int C[2], const int H[2], const int W[2], const int PH[2], const float scale[2],
+                              const float* rois, int R, int slices, hipStream_t st) {
+    Prroi2 a{};
+    for (int l = 0; l < 2; ++l) {
+        a.gout[l] = grad_out[l]; a.feat[l] = feat[l]; a.out[l] = part[l];
+        a.C[l] = C[l]; a.H[l] = H[l]; a.W[l] = W[l]; a.PH[l] = PH[l]; a.scale[l] = scale[l];
+    }
+    a.rois = rois; a.R = R;
+    hipLaunchKernelGGL(k_prroi_bwd_coor2, dim3(R, slices, 2), dim3(256), 0, st, a);
     PT_CHECK_LAUNCH();
     return PT_OK;
 }

@@ -99,10 +99,15 @@ int pt_sd_solve_impl(const pt_sd_params* prm, const float* w_in, const float* fe
                      float* losses, void* ws, size_t ws_bytes, hipStream_t st, bool copy_w0, float* w_final,
                      const PtClsFin* cls, const float* src);
 
-// PrRoIPool coordinate gradient as partial sums part[(r * slices + s) * 4 + {x0,y0,x1,y1}] (prroi.hip); slices >= 2
-int pt_launch_prroi_bwd_coor_sliced(const float* grad_out, const float* features, const float* rois, float* part, int N,
-                                    int C, int H, int W, int R, int PH, int PW, float spatial_scale, int slices,
-                                    hipStream_t st);
+// Two pyramid levels of one image, same RoIs, one launch each way (prroi.hip; used by the IoU refinement):
+//   fwd2:      out[l] (R, C[l], PH[l], PH[l]) = chan_scale[l][c] * PrRoIPool(feat[l])
+//   bwd_coor2: part[l][(r * slices + s) * 4 + {x0,y0,x1,y1}] = partial coordinate gradients, summed by the consumer
+int pt_launch_prroi_fwd2(const float* const feat[2], const float* const chan_scale[2], float* const out[2],
+                         const int C[2], const int H[2], const int W[2], const int PH[2], const float scale[2],
+                         const float* rois, int R, hipStream_t st);
+int pt_launch_prroi_bwd_coor2(const float* const grad_out[2], const float* const feat[2], float* const part[2],
+                              const int C[2], const int H[2], const int W[2], const int PH[2], const float scale[2],
+                              const float* rois, int R, int slices, hipStream_t st);
 
 // measurement hook (profile.hip): no-ops unless a pt_profile is attached
 void pt_prof_begin(int kernel_id, hipStream_t st);
