@@ -135,7 +135,8 @@ __global__ __launch_bounds__(256) void k_iou_head(HeadArgs a) {
         const float* part = l3 ? a.part3 : a.part4;
         const float* bn = l3 ? a.bn3 : a.bn4;
         float pre = (l3 ? a.b3 : a.b4)[m];
-        for (int z = 0; z < nz; ++z) pre += part[((long)z * a.P + p) * I + m];
+#pragma unroll 8
+        for (int z = 0; z < nz; ++z) pre += part[((long)z * a.P + p) * I + m];     // independent loads, fixed order
         const float sc = bn[m] / sqrtf(bn[3 * I + m] + 1e-5f);
         const float y = (pre - bn[2 * I + m]) * sc + bn[I + m];
         const float w = a.wp[n];
