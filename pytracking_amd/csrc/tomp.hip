@@ -520,13 +520,19 @@ __global__ __launch_bounds__(64) void k_dec_scores(DecAttnArgs a) {
     const unsigned op = (unsigned)(((long)(l % a.HW) * a.D + 4 * kq) * 4);
     const unsigned oq = li < a.nhead ? (unsigned)((((long)b * a.nhead + li) * a.D + 4 * kq) * 4) : OOB;
     f32x4 acc = f32x4{0.f, 0.f, 0.f, 0.f};
-    const int nks = a.D / 16;
-#pragma unroll 8
-    for (int ks = 0; ks < nks; ++ks) {
-        const f32x4 m = pt_bload4(rm, om + 64u * ks), pp = pt_bload4(rp, op + 64u * ks);
-        const f32x4 qv = pt_bload4(rq, oq == OOB ? OOB : oq + 64u * ks);
+    const int nks = a.D / 16;                                     // D % 64 == 0: whole batches of 4 k-steps
+    for (int k0 = 0; k0 < nks; k0 += 4) {                         // 12 loads in flight, then 16 MFMAs
+        f32x4 m[4], pp[4], qv[4];
 #pragma unroll
-        for (int e = 0; e < 4; ++e) acc = mfma16(m[e] + pp[e], qv[e], acc);
+        for (int u = 0; u < 4; ++u) {
+            m[u] = pt_bload4(rm, om + 64u * (k0 + u));
+            pp[u] = pt_bload4(rp, op + 64u * (k0 + u));
+            qv[u] = pt_bload4(rq, oq == OOB ? OOB : oq + 64u * (k0 + u));
+        }
+#pragma unroll
+        for (int u = 0; u < 4; ++u)
+#pragma unroll
+            for (int e = 0; e < 4; ++e) acc = mfma16(m[u][e] + pp[u][e], qv[u][e], acc);
     }
     if (li < a.nhead) {
 #pragma unroll
@@ -569,11 +575,17 @@ __global__ __launch_bounds__(1024) void k_dec_ctx(DecAttnArgs a) {
     const float* ph = p + (size_t)min(li, a.nhead - 1) * Lp;
     f32x4 acc = f32x4{0.f, 0.f, 0.f, 0.f};
     const int nks = Lp / 4;
-#pragma unroll 4
-    for (int ks = wave; ks < nks; ks += 16) {
-        const int l = 4 * ks + kq;
-        const float mv = pt_bload1(rm, l < a.L ? (unsigned)((((long)b * a.L + l) * a.D + c0 + li) * 4) : OOB);
-        acc = mfma16(ph[l] * hsel, mv, acc);
+    for (int ks = wave; ks < nks; ks += 64) {                     // this wavefront's k-steps ks, ks+16, ks+32, ks+48:
+        float mv[4], pv[4];                                       // four loads in flight, then four MFMAs
+#pragma unroll
+        for (int u = 0; u < 4; ++u) {
+            const int k2 = ks + 16 * u, l = 4 * k2 + kq;
+            const bool live = k2 < nks;
+            mv[u] = pt_bload1(rm, (live && l < a.L) ? (unsigned)((((long)b * a.L + l) * a.D + c0 + li) * 4) : OOB);
+            pv[u] = live ? ph[l] * hsel : 0.f;
+        }
+#pragma unroll
+        for (int u = 0; u < 4; ++u) acc = mfma16(pv[u], mv[u], acc);
     }
 #pragma unroll
     for (int r = 0; r < 4; ++r) part[wave * 256 + (4 * kq + r) * 16 + li] = acc[r];
@@ -637,6 +649,7 @@ __global__ __launch_bounds__(256) void k_gn_reduce(const float* __restrict__ par
         const int i = i0 + (u * 256 + threadIdx.x) * 4;
         if (i < n_per_img) {
             f32x4 v = *reinterpret_cast<const f32x4*>(part + base + i);
+#pragma unroll 8
             for (int z = 1; z < nz; ++z) v += *reinterpret_cast<const f32x4*>(part + z * zstride + base + i);
             *reinterpret_cast<f32x4*>(x + base + i) = v;
             s += (v[0] + v[1]) + (v[2] + v[3]);
