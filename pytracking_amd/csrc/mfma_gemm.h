@@ -154,30 +154,26 @@ __global__ __launch_bounds__(256) void k_gemm(GemmArgs g) {
             if (kb < nk) {                                               // workgroup-uniform; LDS reads + MFMA only
                 const float* as = &As[buf][aso];
                 const float* bs = &Bs[buf][bso];
-                f32x4 fa[2][MT], fb[2][NT];
-#pragma unroll
-                for (int mt = 0; mt < MT; ++mt) fa[0][mt] = *reinterpret_cast<const f32x4*>(as + mt * 16 * LS);
-#pragma unroll
-                for (int nt = 0; nt < NT; ++nt) fb[0][nt] = *reinterpret_cast<const f32x4*>(bs + nt * 16 * LS);
+                // all fragment reads of the K-step are issued up front (straight-line, so the compiler's lgkmcnt waits
+                // are exact and the MFMAs of sub-step h start as soon as ITS fragments have landed): one exposed LDS round
+                // trip per K-step instead of one per 16-k sub-step
+                f32x4 fa[BK / 16][MT], fb[BK / 16][NT];
 #pragma unroll
                 for (int hh = 0; hh < BK / 16; ++hh) {
-                    const int c = hh & 1, nx = c ^ 1;
-                    if (hh + 1 < BK / 16) {
 #pragma unroll
-                        for (int mt = 0; mt < MT; ++mt)
-                            fa[nx][mt] = *reinterpret_cast<const f32x4*>(as + mt * 16 * LS + (hh + 1) * 16);
+                    for (int mt = 0; mt < MT; ++mt) fa[hh][mt] = *reinterpret_cast<const f32x4*>(as + mt * 16 * LS + hh * 16);
 #pragma unroll
-                        for (int nt = 0; nt < NT; ++nt)
-                            fb[nx][nt] = *reinterpret_cast<const f32x4*>(bs + nt * 16 * LS + (hh + 1) * 16);
-                    }
+                    for (int nt = 0; nt < NT; ++nt) fb[hh][nt] = *reinterpret_cast<const f32x4*>(bs + nt * 16 * LS + hh * 16);
+                }
+#pragma unroll
+                for (int hh = 0; hh < BK / 16; ++hh)
 #pragma unroll
                     for (int j = 0; j < 4; ++j)
 #pragma unroll
                         for (int mt = 0; mt < MT; ++mt)
 #pragma unroll
                             for (int nt = 0; nt < NT; ++nt)
-                                acc[mt][nt] = mfma16(fa[c][mt][j], fb[c][nt][j], acc[mt][nt]);
-                }
+                                acc[mt][nt] = mfma16(fa[hh][mt][j], fb[hh][nt][j], acc[mt][nt]);
             }
             stash((u + 1) % PD, buf ^ 1);                               // step kb+1 (zeros past the end: never read)
             __syncthreads();
