@@ -5,18 +5,34 @@ One "step" = one synthetic tracking frame of BASELINE.json configs[1] (SURVEY.md
     of the n=50 sample memory (features + box) -> DiMPSteepestDescentGN, 5 iterations, over the 50x512x18x18 memory.
 Everything is resident in HBM before the timed region; frames are strictly dependent (frame t+1 classifies with the
 filter frame t produced).  One process per GPU, one independent sequence per GPU (weak scaling, no data-path
-collective); RCCL is used only to agree on the slowest rank's time.
+collective); RCCL is used only for the barrier and the end-of-batch (frames, seconds) gather.
 
-    python bench.py [--gpus N] [--steps K] [--warmup W]
+    python bench.py [--gpus N] [--steps K] [--warmup W]          (N > 1: re-executes itself under torch.distributed.run)
     python -m torch.distributed.run --nnodes=1 --nproc-per-node N --master-addr 127.0.0.1 --master-port P bench.py --gpus N ...
 
-Prints ONE JSON line on rank 0 (see README / DESIGN.md for the fields).
+Prints ONE JSON line on rank 0.  Besides the contract fields:
+  roofline        dominant feature-pass kernel: algorithmic bytes per launch / its average launch duration.  The
+                  duration is rocprofv3's (`--kernel-trace --stats` of this very command in a child process, parsed
+                  here -- the same tool that writes profiles/*kernel_stats.csv, so the two agree by construction); next
+                  to it `period_us`: K back-to-back launches of that kernel between ONE HIP event pair on the launch
+                  stream (= duration + one dependent-launch boundary).  When rocprofv3 cannot run, `frac` is computed
+                  from the event period (pessimistic by the boundary) and `timing` says so.
+  cpu_baseline    the reference's CPU execution path (torch-CPU port, oracle/frame_port.py) on this host, pinned threads.
+  gpu_stock_baseline  the same stock-PyTorch op sequence (MIOpen grouped convs) on this GPU: what a user of the reference
+                  gets on ROCm today without these kernels (SURVEY.md section 8d "Stock-GPU baseline").
 """
 import argparse
+import csv
 import ctypes
+import glob
 import json
+import math
 import os
+import shutil
+import socket
+import subprocess
 import sys
+import tempfile
 import time
 
 import numpy as np
@@ -31,6 +47,7 @@ from pytracking_amd import _lib, bench_frame, sequences, synth  # noqa: E402
 HBM_PEAK_GBS = 8000.0      # MI355X_MICROARCH.md: HBM3E 8.0 TB/s spec
 NUM_ITER = 5
 POOL = 50                  # distinct synthetic test features cycled through (one per memory slot)
+CPU_THREADS = 32           # pinned: the oneDNN grouped convs of the CPU path stop scaling (and wander) beyond this
 
 
 def make_pool(cfg, seed, device):
@@ -44,38 +61,144 @@ def run_frames(st, pool, first, count):
         st.step(pool[f % POOL], slot=f % n, num_iter=NUM_ITER)
 
 
-def cpu_baseline(cfg, n, budget_s=12.0, min_frames=10):
-    """Reference CPU path (torch-CPU port, oracle/frame_port.py) on this host, same workload, bounded sample."""
+def stock_baseline(cfg, n, device, budget_s, min_frames=10, max_frames=2000):
+    """The reference's op sequence in stock PyTorch (oracle/frame_port.TorchCpuTracker) on `device`, same workload,
+    bounded sample.  Baseline leg only: nothing measured as the product touches oracle/."""
     from oracle.frame_port import TorchCpuTracker
     host = os.cpu_count() or 1
-    pool = make_pool(cfg, 99, "cpu")
-    # the oneDNN convs of this path stop scaling (and collapse when oversubscribed) well below a 2-socket
-    # host's core count: calibrate the thread count on 2 frames each and keep the fastest
-    best, threads = None, 1
-    for th in sorted({t for t in (8, 16, 32, 64, host) if t <= host}):
-        tr = TorchCpuTracker(cfg, n, seed=1234, threads=th)
-        tr.step(pool[0], 0, NUM_ITER)
-        t0 = time.perf_counter()
-        tr.step(pool[1], 1, NUM_ITER)
-        dt = time.perf_counter() - t0
-        if best is None or dt < best:
-            best, threads = dt, th
-        if dt > 2.0:
-            break
-    tr = TorchCpuTracker(cfg, n, seed=1234, threads=threads)
-    for f in range(2):
+    threads = min(CPU_THREADS, host)
+    pool = make_pool(cfg, 99, device)
+    tr = TorchCpuTracker(cfg, n, seed=1234, threads=threads, device=device)
+    sync = torch.cuda.synchronize if str(device).startswith("cuda") else (lambda: None)
+    for f in range(3):
         tr.step(pool[f % POOL], f % n, NUM_ITER)
+    sync()
     t0 = time.perf_counter()
     frames = 0
     while frames < min_frames or time.perf_counter() - t0 < budget_s:
-        tr.step(pool[(frames + 2) % POOL], (frames + 2) % n, NUM_ITER)
+        tr.step(pool[(frames + 3) % POOL], (frames + 3) % n, NUM_ITER)
         frames += 1
-        if frames >= 2000:
+        if frames >= max_frames:
             break
+    sync()
     dt = time.perf_counter() - t0
-    return {"value": frames / dt, "unit": "frames/s", "cores": torch.get_num_threads(), "kind": "port",
-            "sample": f"{frames} frames of the same workload in {dt:.1f}s (torch-CPU port of the reference path, fp32; "
-                      f"best of 8/16/32/64/all threads on a {host}-core host)"}
+    if str(device).startswith("cuda"):
+        return {"value": round(frames / dt, 2), "unit": "frames/s", "kind": "port",
+                "sample": f"{frames} frames of the same workload in {dt:.1f}s: the reference's op sequence (grouped "
+                          f"F.conv2d apply_filter / feature-as-weights adjoint, 3 passes per iteration, DistanceMap) in "
+                          f"stock PyTorch-ROCm on this GPU, fp32, eager"}
+    return {"value": round(frames / dt, 3), "unit": "frames/s", "cores": threads, "host_cores": host, "kind": "port",
+            "sample": f"{frames} frames of the same workload in {dt:.1f}s (torch-CPU port of the reference path, fp32, "
+                      f"{threads} threads pinned on a {host}-core host)"}
+
+
+# ---------------------------------------------------------------------------------------------------------------------
+# roofline leg
+# ---------------------------------------------------------------------------------------------------------------------
+def event_period_us(st, stream, which, reps=200):
+    """K back-to-back launches of one solver pass between ONE event pair on the launch stream."""
+    L = _lib.lib()
+    c = st.cfg
+    args = (ctypes.byref(st.params), st.filter.data_ptr(), st.mem_feat.data_ptr(), st.mem_bb.data_ptr(),
+            st.sample_weight.data_ptr(), st.n, c["C"], c["H"], c["W"], c["K"], NUM_ITER, st.ws.data_ptr(), st.ws.numel(),
+            which)
+    sp = ctypes.c_void_p(stream.cuda_stream)
+    _lib.check(L.pt_track_frame_replay_pass_f32(*args, 20, sp), "pt_track_frame_replay_pass_f32")
+    e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+    e0.record(stream)
+    _lib.check(L.pt_track_frame_replay_pass_f32(*args, reps, sp), "pt_track_frame_replay_pass_f32")
+    e1.record(stream)
+    e1.synchronize()
+    return e0.elapsed_time(e1) * 1e3 / reps
+
+
+PROF_FRAMES, PROF_WARMUP = 120, 10
+
+
+def rocprof_kernel_stats(workload, frames=PROF_FRAMES):
+    """Run this file's --profile-child leg under `rocprofv3 --kernel-trace --stats` and return {kernel name: (calls,
+    average ns)} from its kernel-stats CSV, or (None, reason)."""
+    exe = shutil.which("rocprofv3") or "/opt/rocm/bin/rocprofv3"
+    if not os.path.exists(exe):
+        return None, "rocprofv3 not found"
+    tmp = tempfile.mkdtemp(prefix="pt_bench_prof_", dir="/tmp")
+    env = dict(os.environ, TMPDIR="/tmp")
+    for k in ("RANK", "LOCAL_RANK", "WORLD_SIZE", "MASTER_ADDR", "MASTER_PORT"):
+        env.pop(k, None)
+    cmd = [exe, "--kernel-trace", "--stats", "--output-format", "csv", "-d", tmp, "-o", "bench", "--",
+           sys.executable, os.path.abspath(__file__), "--profile-child", "--steps", str(frames), "--warmup", str(PROF_WARMUP),
+           "--workload", workload]
+    try:
+        res = subprocess.run(cmd, cwd="/tmp", env=env, capture_output=True, text=True, timeout=600)
+    except Exception as exc:                                  # noqa: BLE001
+        shutil.rmtree(tmp, ignore_errors=True)
+        return None, f"rocprofv3 did not run: {exc}"
+    files = glob.glob(os.path.join(tmp, "**", "*kernel_stats.csv"), recursive=True)
+    dbs = glob.glob(os.path.join(tmp, "**", "*.db"), recursive=True)
+    stats = {}
+    try:
+        if res.returncode == 0 and files:
+            with open(files[0], newline="") as fh:
+                for row in csv.DictReader(fh):
+                    stats[row["Name"]] = (int(row["Calls"]), float(row["AverageNs"]))
+        elif res.returncode == 0 and dbs:                     # rocpd (sqlite) output: the same aggregation
+            import sqlite3
+            con = sqlite3.connect(dbs[0])
+            for name, calls, avg in con.execute("select name, count(*), avg(duration) from kernels group by name"):
+                stats[name] = (int(calls), float(avg))
+            con.close()
+    except Exception as exc:                                  # noqa: BLE001
+        stats, res = {}, type("R", (), {"returncode": -1, "stderr": str(exc), "stdout": ""})()
+    keep = os.environ.get("PT_BENCH_KEEP_STATS")
+    if keep and stats:
+        with open(keep, "w") as fh:
+            fh.write("Name,Calls,AverageNs\n")
+            for nm, (c, a) in sorted(stats.items(), key=lambda kv: -kv[1][0] * kv[1][1]):
+                fh.write(f'"{nm}",{c},{a:.1f}\n')
+    shutil.rmtree(tmp, ignore_errors=True)
+    if not stats:
+        return None, f"rocprofv3 exit {res.returncode}: {(res.stderr or res.stdout)[-300:]}"
+    return stats, None
+
+
+def roofline(st, stream, cfg, cfg_name, n):
+    feat_bytes = 4 * n * cfg["C"] * cfg["H"] * cfg["W"]           # one pass streams the n-sample memory once
+    period = {"k_corr2": event_period_us(st, stream, 0), "k_adj2": event_period_us(st, stream, 1)}
+    stats, why = rocprof_kernel_stats(cfg_name)
+    kern = {}
+    for short in ("k_corr2", "k_adj2"):
+        rec = {"period_us": round(period[short], 3)}
+        if stats:
+            rows = [(nm, c, a) for nm, (c, a) in stats.items() if short in nm]
+            if rows:
+                calls = sum(c for _, c, _ in rows)
+                rec["avg_launch_us"] = round(sum(c * a for _, c, a in rows) / calls / 1e3, 3)    # all instantiations
+                rec["launches"] = calls
+                fused = [(c, a) for nm, c, a in rows if c == max(r[1] for r in rows)]             # the in-iteration one
+                rec["avg_launch_us_in_iteration"] = round(fused[0][1] / 1e3, 3)
+        dur = rec.get("avg_launch_us", rec["period_us"])
+        rec["achieved_GBs"] = round(feat_bytes / dur / 1e3, 1)
+        kern[short] = rec
+    dom = max(kern, key=lambda k: kern[k].get("avg_launch_us", kern[k]["period_us"]) * kern[k].get("launches", 1))
+    traffic, traffic_src = None, None
+    pmc = os.path.join(ROOT, "profiles", "pmc_traffic.json")   # committed rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE pass
+    if os.path.exists(pmc):
+        rec = json.load(open(pmc)).get(cfg_name, {}).get(dom)
+        if rec:
+            traffic, traffic_src = rec["hbm_bytes_per_launch"], rec["source"]
+    timing = ("rocprofv3 --kernel-trace --stats of this command (child process), parsed in-process" if stats and
+              "avg_launch_us" in kern[dom] else f"HIP event pair around 200 back-to-back launches (includes one launch boundary each); {why}")
+    return {"bound": "hbm", "kernel": dom, "achieved": kern[dom]["achieved_GBs"], "peak": HBM_PEAK_GBS, "unit": "GB/s",
+            "frac": round(kern[dom]["achieved_GBs"] / HBM_PEAK_GBS, 4), "traffic": traffic, "traffic_source": traffic_src,
+            "avg_launch_us": kern[dom].get("avg_launch_us", kern[dom]["period_us"]), "timing": timing,
+            "algorithmic_bytes_per_launch": feat_bytes, "kernels": kern,
+            "all_kernels_us_per_frame": None if not stats else round(sum(c * a for c, a in stats.values()) / 1e3 / (PROF_FRAMES + PROF_WARMUP), 2)}
+
+
+def free_port():
+    with socket.socket() as s:
+        s.bind(("127.0.0.1", 0))
+        return s.getsockname()[1]
 
 
 def main():
@@ -85,16 +208,24 @@ def main():
     ap.add_argument("--warmup", type=int, default=50)
     ap.add_argument("--no-graph", action="store_true", help="launch every frame eagerly instead of replaying hipGraphs")
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--no-gpu-baseline", action="store_true")
     ap.add_argument("--no-roofline", action="store_true")
+    ap.add_argument("--profile-child", action="store_true", help=argparse.SUPPRESS)
     ap.add_argument("--workload", default="dimp50", choices=("dimp50", "prdimp50"),
                     help="dimp50 = BASELINE configs[1] (the metric's configuration); prdimp50 = configs[2]'s per-GPU workload")
     args = ap.parse_args()
 
     world = int(os.environ.get("WORLD_SIZE", "1"))
+    if args.gpus > 1 and world != args.gpus:
+        if "WORLD_SIZE" in os.environ:
+            raise SystemExit(f"--gpus {args.gpus} but the launcher started {world} ranks")
+        # started as plain `python bench.py --gpus N`: become the N-rank job (one process per GPU over RCCL)
+        os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+        cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", f"--nproc-per-node={args.gpus}",
+               "--master-addr", "127.0.0.1", "--master-port", str(free_port()), os.path.abspath(__file__)] + sys.argv[1:]
+        os.execv(sys.executable, cmd)
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
-    if args.gpus > 1 and world != args.gpus:
-        raise SystemExit(f"--gpus {args.gpus} needs torch.distributed.run with {args.gpus} ranks (WORLD_SIZE={world})")
     torch.cuda.set_device(local_rank)
     dev = torch.device("cuda", local_rank)
     dist = None
@@ -115,24 +246,36 @@ def main():
                                 kind="dimp" if cfg_name == "dimp50" else "prdimp")
     pool = make_pool(cfg, 4321 + rank, dev)
     K, Wm = args.steps, args.warmup
-
-    # ---- frame launcher: eager, or hipGraphs of one full memory cycle (n frames) --------------------------
     stream = torch.cuda.Stream(device=dev)
-    graph = None
+
+    if args.profile_child:                                     # the leg rocprofv3 traces: eager frames, nothing else
+        with torch.cuda.stream(stream):
+            run_frames(st, pool, 0, Wm + K)
+            stream.synchronize()
+        return
+
+    # ---- frame launcher: hipGraphs of G consecutive frames (G divides the warm-up, the timed steps and the memory size,
+    #      so that the timed region is whole graph replays and every memory slot keeps being overwritten in turn), or
+    #      eager launches when no such G >= 5 exists / --no-graph
+    G = math.gcd(math.gcd(K, n), Wm) if Wm > 0 else math.gcd(K, n)
+    use_graph = (not args.no_graph) and G >= 5
+    graphs = {}
     with torch.cuda.stream(stream):
-        run_frames(st, pool, 0, 2)                         # first-touch / code-object load outside everything
+        run_frames(st, pool, 0, 2)                             # first-touch / code-object load outside everything
         stream.synchronize()
-        if not args.no_graph:
-            graph = torch.cuda.CUDAGraph()
-            with torch.cuda.graph(graph, stream=stream):
-                run_frames(st, pool, 0, n)                 # slots 0..n-1, pool entries 0..n-1
+        if use_graph:
+            for j in range(n // G):                            # graph j = frames [jG, (j+1)G) of a memory cycle
+                g = torch.cuda.CUDAGraph()
+                with torch.cuda.graph(g, stream=stream):
+                    run_frames(st, pool, j * G, G)
+                graphs[j] = g
 
         def advance(first, count):
             f, end = first, first + count
             while f < end:
-                if graph is not None and f % n == 0 and end - f >= n:
-                    graph.replay()
-                    f += n
+                if use_graph and f % G == 0 and end - f >= G:
+                    graphs[(f % n) // G].replay()
+                    f += G
                 else:
                     run_frames(st, pool, f, 1)
                     f += 1
@@ -150,56 +293,23 @@ def main():
             dist.barrier()
         elapsed = time.perf_counter() - t0
 
-        # ---- roofline leg: kprof more frames, eagerly, with HIP events around every feature-pass launch on the stream
-        #      it is launched on.  An event pair costs a few microseconds of its own: the library brackets a one-wave
-        #      kernel that spins for exactly 5.00 us next to every adjoint launch, and (that bracket - 5.00 us) is subtracted
-        #      from the brackets around the passes (rocprofv3's kernel durations in profiles/ are the check).
         roof = None
-        if not args.no_roofline and rank == 0:
-            L = _lib.lib()
-            prof = ctypes.c_void_p()
-            per_frame = 2 * NUM_ITER + 2
-            kprof = min(K, 200)
-            _lib.check(L.pt_profile_create(ctypes.byref(prof), kprof * per_frame), "pt_profile_create")
-            L.pt_profile_attach(prof)
-            run_frames(st, pool, Wm + K, kprof)
-            stream.synchronize()
-            L.pt_profile_attach(None)
-            feat_bytes = 4 * n * cfg["C"] * cfg["H"] * cfg["W"]       # one pass streams the n-sample memory once
-            kern = {}
-            for kid, name in ((0, "k_corr2"), (1, "k_adj2"), (2, "spin5us")):
-                ms, cnt = ctypes.c_double(), ctypes.c_long()
-                _lib.check(L.pt_profile_collect(prof, kid, ctypes.byref(ms), ctypes.byref(cnt)), "pt_profile_collect")
-                kern[name] = (ms.value * 1e3 / max(cnt.value, 1), cnt.value)       # mean microseconds, launches
-            L.pt_profile_destroy(prof)
-            # the spin kernel's own duration as rocprofv3 sees it: 5.00 us of spinning + 0.58 us dispatch/drain of a
-            # one-wave kernel (profiles/r01e_kernel_stats.csv: k_prof_spin avg 5581 ns)
-            overhead = max(kern["spin5us"][0] - 5.58, 0.0)
-            stats = {k: {"avg_launch_us": round(max(kern[k][0] - overhead, 1e-3), 3), "bracket_us": round(kern[k][0], 3),
-                         "launches": kern[k][1],
-                         "achieved_GBs": round(feat_bytes / max(kern[k][0] - overhead, 1e-3) / 1e3, 1)}
-                     for k in ("k_corr2", "k_adj2")}
-            dom = max(stats, key=lambda k: stats[k]["avg_launch_us"] * stats[k]["launches"])
-            traffic, traffic_src = None, None
-            pmc = os.path.join(ROOT, "profiles", "pmc_traffic.json")   # committed rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE pass
-            if os.path.exists(pmc):
-                rec = json.load(open(pmc)).get(cfg_name, {}).get(dom)
-                if rec:
-                    traffic, traffic_src = rec["hbm_bytes_per_launch"], rec["source"]
-            roof = {"bound": "hbm", "kernel": dom, "achieved": stats[dom]["achieved_GBs"], "peak": HBM_PEAK_GBS,
-                    "unit": "GB/s", "frac": round(stats[dom]["achieved_GBs"] / HBM_PEAK_GBS, 4), "traffic": traffic,
-                    "traffic_source": traffic_src, "avg_launch_us": stats[dom]["avg_launch_us"],
-                    "event_pair_overhead_us": round(overhead, 3), "launches": stats[dom]["launches"],
-                    "algorithmic_bytes_per_launch": feat_bytes, "kernels": stats,
-                    "solve_level": {"algorithmic_bytes_per_frame": st.bytes_per_solve(NUM_ITER), "achieved_GBs": None}}
+        if not args.no_roofline and rank == 0 and world == 1:
+            roof = roofline(st, stream, cfg, cfg_name, n)
 
     # the only collective: the end-of-batch (frames, seconds) gather; whole-job rate = all frames / slowest rank
     total_frames, tmax, _ = sequences.gather_throughput(K, elapsed, device=dev)
     value = total_frames / tmax
 
     if rank == 0:
+        solve_bytes = st.bytes_per_solve(NUM_ITER)
         if roof is not None:
-            roof["solve_level"]["achieved_GBs"] = round(st.bytes_per_solve(NUM_ITER) * (K / tmax) / 1e9, 1)
+            gbs = solve_bytes * (K / tmax) / 1e9
+            roof["solve_level"] = {"algorithmic_bytes_per_frame": solve_bytes, "achieved_GBs": round(gbs, 1),
+                                   "frac": round(gbs / HBM_PEAK_GBS, 4),
+                                   "note": "2 feature reads per iteration x 5 iterations (SURVEY 8d) / measured frame time"}
+        launch = (f"hipGraph replay, {G} frames per graph ({n // G} graphs cover the memory cycle)" if use_graph
+                  else "eager (18 launches per frame)")
         out = {
             "metric": "frames/sec DiMP-50 online track (288x288, 5 SD iters)" if cfg_name == "dimp50" else "frames/sec PrDiMP-50 online track (352x352, 5 SD iters)", "value": round(value, 2),
             "unit": "frames/s", "n_gpus": world, "steps": K, "warmup": Wm,
@@ -211,12 +321,14 @@ def main():
                        ("BASELINE configs[2] per-GPU workload: PrDiMP-50 single sequence per GPU; per frame "
                         "classify(1x512x22x22) + arg-max + memory insert + PrDiMPSteepestDescentNewton(5 it) over "
                         "n=50x512x22x22, K=4"),
-                       "sequences_per_gpu": 1, "launch": "eager" if graph is None else f"hipGraph of {n} frames",
-                       "parallelism": f"{world} independent sequences"},
+                       "sequences_per_gpu": 1, "launch": launch, "parallelism": f"{world} independent sequences"},
             "roofline": roof,
         }
-        if not args.no_cpu_baseline and world == 1 and cfg_name == "dimp50":
-            out["cpu_baseline"] = cpu_baseline(cfg, n)
+        if world == 1 and cfg_name == "dimp50":
+            if not args.no_cpu_baseline:
+                out["cpu_baseline"] = stock_baseline(cfg, n, "cpu", budget_s=12.0)
+            if not args.no_gpu_baseline:
+                out["gpu_stock_baseline"] = stock_baseline(cfg, n, dev, budget_s=4.0, min_frames=50)
         print(json.dumps(out), flush=True)
     if dist is not None:
         dist.barrier()

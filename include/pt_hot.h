@@ -312,20 +312,16 @@ int pt_track_frame_f32(const pt_sd_params* p, float* filter, float* mem_feat, fl
                        float* scores_out, float* peak_out, void* ws, size_t ws_bytes, void* stream);
 
 /* ------------------------------------------------------------------------------------------------
- * Measurement hook (bench.py roofline leg; not part of the reference's API).  While a profile is attached,
- * every launch of the two feature-pass kernels is bracketed by HIP events on the stream it is launched on.
- * The attachment is the only process-global state of the library; it must not be used during graph capture.
- *   kernel ids: 0 = correlation pass (k_corr*), 1 = adjoint pass (k_adj*), 2 = calibration: an event pair around a
- *   one-wave kernel that spins for exactly 5.00 us of device wall clock, launched before every adjoint pass
- *   (bracket - 5.00 us = the overhead of an event pair around a real kernel, to be subtracted from ids 0 and 1).
+ * Measurement entry (bench.py roofline leg; not part of the reference's API).  Re-issues ONE feature pass of the
+ * solve that pt_track_frame_f32 last ran on `ws` -- the launch of its last iteration, same kernel instantiation and
+ * operands -- `reps` times back to back on `stream`, so that the caller can bracket the run with ONE HIP event pair
+ * (elapsed / reps = kernel duration + one dependent-launch boundary).  Both passes only read the state they were
+ * launched on, so the replay leaves the sequence's state untouched.  Needs num_iter >= 2 and the XCD-aligned path.
+ *   which = 0: correlation pass with the fused gradient reduction;  which = 1: adjoint pass with the fused update.
  * ---------------------------------------------------------------------------------------------- */
-typedef struct pt_profile pt_profile;
-int pt_profile_create(pt_profile** out, int max_launches_per_kernel);
-int pt_profile_attach(pt_profile* prof);            /* NULL detaches */
-/* Synchronises on the recorded events; returns summed milliseconds and launch count of one kernel id. */
-int pt_profile_collect(pt_profile* prof, int kernel_id, double* total_ms, long* launches);
-int pt_profile_reset(pt_profile* prof);
-int pt_profile_destroy(pt_profile* prof);
+int pt_track_frame_replay_pass_f32(const pt_sd_params* prm, const float* filter, const float* mem_feat,
+                                   const float* mem_bb, const float* sample_weight, int n, int C, int H, int W, int K,
+                                   int num_iter, void* ws, size_t ws_bytes, int which, int reps, void* stream);
 
 #ifdef __cplusplus
 }

@@ -466,9 +466,183 @@ def gen_clf_head():
     save("clf_head", **out)
 
 
+# ------------------------------------------------------------------------------------------------------
+# round 2: full-size / deployed-size cases and the branches that had no reference vector
+# ------------------------------------------------------------------------------------------------------
+def gen_lwl_full():
+    """BASELINE configs[4] size: n=32 samples of 512x30x52, 16 filters 3x3, zero initial filter; 4 GN steepest-descent
+    iterations (BASELINE's wording) -- the reference's per-frame setting of 3 is the prefix of the same run
+    (ltr/models/meta/steepestdescent.py:32-105 is sequential in the iterate).  Inputs are regenerated from the seed."""
+    from pytracking import TensorList
+    from ltr.models.meta.steepestdescent import GNSteepestDescent
+    from ltr.models.lwl.loss_residual_modules import LWTLResidual
+    cfg = synth.LWL
+    seed = 5032
+    w0, feat, label, sw = synth.lwl_problem(seed, cfg)
+    out = dict(seed=seed, filter_reg=cfg["filter_reg"])
+    for it in (3, 4):
+        res = LWTLResidual(init_filter_reg=cfg["filter_reg"])
+        opt = GNSteepestDescent(residual_module=res, num_iter=it, compute_losses=True, steplength_reg=0.0,
+                                residual_batch_dim=1)
+        w, its, losses = opt(TensorList([T(w0)[None]]), feat=T(feat)[:, None], label=T(label)[:, None],
+                             sample_weight=T(sw)[:, None])
+        out[f"losses{it}"] = torch.stack([l.detach().reshape(()) for l in losses]).numpy()
+        out[f"final{it}"] = w[0].detach()[0].numpy()
+        if it == 4:
+            with torch.no_grad():
+                s = rfilter.apply_filter(T(feat[:2])[:, None], w[0].detach())
+            out["scores_first2"] = s[:, 0].numpy()
+            out["iterate1"] = its[1][0][0].detach().numpy()
+    save("lwl_gn_cfg5_n32", **out)
+
+
+def _iou_net(cfg, params):
+    from ltr.models.bbreg.atom_iou_net import AtomIoUNet
+    C, I = cfg["C"], cfg["I"]
+    net = AtomIoUNet(input_dim=(32, 64), pred_input_dim=(C, C), pred_inter_dim=(I, I)).eval()
+    sd = net.state_dict()
+    for k, v in params.items():
+        assert sd[k].shape == v.shape, (k, sd[k].shape, v.shape)
+        sd[k] = T(v.copy())
+    net.load_state_dict(sd, strict=True)
+    return net
+
+
+def gen_iou_refine_full():
+    """IoU-guided refinement at the deployed DiMP-50 / PrDiMP-50 sizes (256-channel IoU features 36x36 / 18x18,
+    256-wide LinearBlocks, 10 proposals): the reference's optimize_boxes_default (5 it), optimize_boxes_relative
+    (10 it) and ATOM.optimize_boxes on CPU.  Weights / inputs are regenerated from the seeds by the tests."""
+    import types
+    from pytracking.tracker.dimp.dimp import DiMP
+    from pytracking.tracker.atom.atom import ATOM
+    from pytracking.utils import TrackerParams
+    cfg = synth.IOU50
+    pseed, iseed = 7301, 7302
+    net = _iou_net(cfg, synth.iou_net_params(pseed, cfg))
+    c3, c4, mod3, mod4, boxes = synth.iou_inputs(iseed, cfg)
+    c3, c4, mod3, mod4 = T(c3), T(c4), T(mod3), T(mod4)
+    out = dict(param_seed=pseed, input_seed=iseed)
+    for tag, iters, step, decay, method in (("default", 5, 1.0, 1.0, DiMP.optimize_boxes_default),
+                                            ("relative", 10, 2.5e-3, 1.0, DiMP.optimize_boxes_relative)):
+        params = TrackerParams()
+        params.device = "cpu"
+        params.box_refinement_iter, params.box_refinement_step_length, params.box_refinement_step_decay = iters, step, decay
+        me = types.SimpleNamespace(params=params, net=types.SimpleNamespace(bb_regressor=net), iou_modulation=(mod3, mod4))
+        b, iou = method(me, (c3, c4), T(boxes.copy()))
+        out.update({f"{tag}_boxes": b.numpy(), f"{tag}_iou": iou.numpy(), f"{tag}_cfg": np.array([iters, step, decay])})
+    params = TrackerParams()
+    params.device = "cpu"
+    params.box_refinement_iter, params.box_refinement_step_length, params.box_refinement_step_decay = 5, 1.0, 1.0
+    params.box_refinement_space = "default"
+    me = types.SimpleNamespace(params=params, iou_predictor=net, target_feat=(mod3, mod4))
+    b, iou = ATOM.optimize_boxes(me, (c3, c4), T(boxes.copy()))
+    out.update(atom_boxes=b.numpy(), atom_iou=iou.numpy(), atom_cfg=np.array([5, 1.0, 1.0]))
+    save("iou_refine_full", **out)
+
+
+def gen_atom_gn_full():
+    """ATOM first frame at the deployed schedule (parameter/atom/default.py:27-28: init_CG_iter 60 / init_GN_iter 6
+    -> six Gauss-Newton iterations of ten CG iterations; Polak-Ribiere, default.py:30) on 30 samples of 256x18x18,
+    64 compressed channels, 4x4 filter.  Reference: GaussNewtonCG on FactorizedConvProblem, CPU autograd."""
+    from pytracking import TensorList
+    from pytracking.libs import optimization
+    from pytracking.tracker.atom.optim import FactorizedConvProblem
+    from ltr.models.layers import activation
+    cfg = synth.ATOM18
+    seed = 9030
+    f0, P0, samples, y, sw = synth.atom_gn_problem(seed)
+    act = activation.MLU(cfg["act_min_val"])
+    out = dict(seed=seed, filter_reg=cfg["filter_reg"], projection_reg=1e-4, act_min_val=cfg["act_min_val"])
+    for tag, fr in (("pr", False), ("fr", True)):
+        prob = FactorizedConvProblem(TensorList([T(samples)]), TensorList([T(y)[:, None]]), TensorList([cfg["filter_reg"]]),
+                                     TensorList([1e-4]), None, TensorList([T(sw)]), lambda x: x, act)
+        filt = T(f0.copy())[None].clone()
+        proj = T(P0.copy())[:, :, None, None].clone()
+        var = TensorList([filt]).concat(TensorList([proj]))
+        opt = optimization.GaussNewtonCG(prob, var, fletcher_reeves=fr)
+        opt.run([10] * 6)
+        out[f"f_out_{tag}"] = var[0].detach()[0].numpy()
+        out[f"P_out_{tag}"] = var[1].detach()[:, :, 0, 0].numpy()
+    save("atom_gn_first_frame", **out)
+
+
+def gen_branches():
+    """Reference vectors for branches no earlier golden touched: score_act='bentpar', mask_act='linear',
+    PrDiMP gauss_sigma=0, two sequences through the optimiser modules, CG direction forgetting across run() calls."""
+    cfg = synth.DIMP50
+    small = dict(C=16, H=10, W=10)
+    # DiMP with BentIdentPar score activation and a linear target mask (activation.py:47-66, optimizer.py:57-66,75-77)
+    for tag, over in (("bentpar", dict(score_act="bentpar", act_param=2.0)), ("linmask", dict(mask_act="linear")),
+                      ("bentpar_linmask", dict(score_act="bentpar", act_param=0.7, mask_act="linear"))):
+        c = dict(cfg, **over)
+        w0, feat, bb, sw = synth.dimp_problem(301, 4, cfg, small=small)
+        m = roptim.DiMPSteepestDescentGN(
+            num_iter=3, feat_stride=c["feat_stride"], init_step_length=c["init_step_length"],
+            init_filter_reg=c["init_filter_reg"], init_gauss_sigma=c["init_gauss_sigma"], num_dist_bins=c["num_dist_bins"],
+            bin_displacement=c["bin_displacement"], mask_init_factor=c["mask_init_factor"], score_act=c["score_act"],
+            act_param=c.get("act_param"), mask_act=c["mask_act"], min_filter_reg=c["min_filter_reg"],
+            alpha_eps=c["alpha_eps"]).eval()
+        its, losses, scores = _run_opt(m, w0, feat, bb, sw, 3)
+        save(f"dimp_sd_{tag}", w0=w0, feat=feat, bb=bb, sw=sw, iterates=its, losses=losses, scores=scores, num_iter=3,
+             score_act=c["score_act"], act_param=c.get("act_param") or 0.0, mask_act=c["mask_act"])
+    # the same branches on the XCD-aligned path geometry (C=128, 18x18): seed + outputs only
+    for tag, over in (("bentpar_c128", dict(score_act="bentpar", act_param=2.0, mask_act="linear")),):
+        c = dict(cfg, **over)
+        w0, feat, bb, sw = synth.dimp_problem(302, 6, cfg, small=dict(C=128, H=18, W=18))
+        m = roptim.DiMPSteepestDescentGN(
+            num_iter=3, feat_stride=c["feat_stride"], init_step_length=c["init_step_length"],
+            init_filter_reg=c["init_filter_reg"], init_gauss_sigma=c["init_gauss_sigma"], num_dist_bins=c["num_dist_bins"],
+            bin_displacement=c["bin_displacement"], mask_init_factor=c["mask_init_factor"], score_act=c["score_act"],
+            act_param=c.get("act_param"), mask_act=c["mask_act"], min_filter_reg=c["min_filter_reg"],
+            alpha_eps=c["alpha_eps"]).eval()
+        its, losses, scores = _run_opt(m, w0, feat, bb, sw, 3)
+        save(f"dimp_sd_{tag}", seed=302, n=6, iterates=its, losses=losses, num_iter=3, act_param=2.0)
+    # PrDiMP with gauss_sigma = 0 (one-hot label at the nearest cell, optimizer.py:334-341)
+    pc = dict(synth.PRDIMP50, gauss_sigma=0.0)
+    w0, feat, bb, sw = synth.dimp_problem(303, 4, synth.PRDIMP50, small=small)
+    its, losses, scores = _run_opt(_prdimp_module(pc), w0 * 0, feat, bb, sw, 3)
+    save("prdimp_sd_sigma0", w0=w0 * 0, feat=feat, bb=bb, sw=sw, iterates=its, losses=losses, scores=scores, num_iter=3)
+    w0, feat, bb, sw = synth.dimp_problem(304, 5, synth.PRDIMP50, small=dict(C=128, H=18, W=18))
+    its, losses, scores = _run_opt(_prdimp_module(pc), w0 * 0, feat, bb, sw, 3)
+    save("prdimp_sd_sigma0_c128", seed=304, n=5, iterates=its, losses=losses, num_iter=3)
+    # two sequences in one call: feat (n,S,C,H,W), weights (S,C,K,K), bb (n,S,4), sample_weight (n,S)
+    rng = np.random.default_rng(305)
+    S, n = 2, 4
+    probs = [synth.dimp_problem(306 + s, n, cfg, small=small) for s in range(S)]
+    w0 = np.stack([p[0] for p in probs])
+    feat = np.stack([p[1] for p in probs], axis=1)
+    bb = np.stack([p[2] for p in probs], axis=1)
+    sw = np.stack([rng.uniform(0.1, 1.0, n).astype(np.float32) for _ in range(S)], axis=1)
+    for tag, mod in (("dimp", _dimp_module(cfg)), ("prdimp", _prdimp_module(synth.PRDIMP50))):
+        with torch.no_grad():
+            w, its, losses = mod(T(w0), T(feat), T(bb), sample_weight=T(sw), num_iter=3, compute_losses=True)
+        save(f"{tag}_sd_two_sequences", w0=w0, feat=feat, bb=bb, sw=sw,
+             iterates=torch.stack(its).numpy(), losses=torch.stack([l.reshape(-1) for l in losses]).numpy(), num_iter=3)
+    # ATOM CG with direction forgetting: state (p, rho, r_prev) carried across three run() calls
+    # (optimization.py:82-85; atom.py:85-89 gives (1 - lr)^CG_forgetting_rate)
+    from pytracking import TensorList
+    from pytracking.libs import optimization
+    from pytracking.tracker.atom.optim import ConvProblem
+    from ltr.models.layers import activation
+    acfg = synth.ATOM18
+    for tag, fr, forget in (("pr", False, 0.75), ("fr", True, 0.5)):
+        x0, samples, y, sw1 = synth.atom_problem(311, 6, acfg, small=dict(C=8, H=10, W=10))
+        prob = ConvProblem(TensorList([T(samples)]), TensorList([T(y)[:, None]]), TensorList([acfg["filter_reg"]]),
+                           TensorList([T(sw1)]), activation.MLU(acfg["act_min_val"]))
+        x = TensorList([T(x0.copy())[None].clone()])
+        opt = optimization.ConjugateGradient(prob, x, fletcher_reeves=fr, direction_forget_factor=forget)
+        outs = []
+        for iters in (3, 2, 3):
+            opt.run(iters)
+            outs.append(x[0].detach()[0].numpy().copy())
+        save(f"atom_cg_forget_{tag}", x0=x0, samples=samples, y=y, sw=sw1, x_out=np.stack(outs), iters=np.array([3, 2, 3]),
+             fletcher_reeves=int(fr), forget=forget)
+
+
 if __name__ == "__main__":
     torch.set_num_threads(8)
-    which = sys.argv[1:] or ["filter", "dimp", "l2", "prdimp", "atom", "prroi", "lwl", "atomgn", "tomp", "head", "localize", "iou"]
+    which = sys.argv[1:] or ["filter", "dimp", "l2", "prdimp", "atom", "prroi", "lwl", "atomgn", "tomp", "head", "localize", "iou",
+                             "branches", "ioufull", "atomgnfull", "lwlfull"]
     if "tomp" in which:
         gen_tomp()
     if "head" in which:
@@ -493,3 +667,11 @@ if __name__ == "__main__":
         gen_atom_cg()
     if "prroi" in which:
         gen_prroi_consumers()
+    if "branches" in which:
+        gen_branches()
+    if "ioufull" in which:
+        gen_iou_refine_full()
+    if "atomgnfull" in which:
+        gen_atom_gn_full()
+    if "lwlfull" in which:
+        gen_lwl_full()

@@ -9,7 +9,7 @@ import subprocess
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.environ.get("PT_HOT_LIB", os.path.join(_HERE, "libpt_hot.so"))   # override: experiments only
-SOURCES = ["filter_kernels.hip", "fast_passes.hip", "sd_solver.hip", "mf_kernels.hip", "lwl_solver.hip", "atom_cg.hip", "atom_gn.hip", "tomp.hip", "localize.hip", "iou_refine.hip", "prroi.hip", "api.hip", "profile.hip"]
+SOURCES = ["filter_kernels.hip", "fast_passes.hip", "sd_solver.hip", "mf_kernels.hip", "lwl_solver.hip", "atom_cg.hip", "atom_gn.hip", "tomp.hip", "localize.hip", "iou_refine.hip", "prroi.hip", "api.hip"]
 HEADERS = ["common.h", "pt_internal.h", "rbuild.h", "sd_common.h", "mfma_gemm.h", os.path.join("..", "..", "include", "pt_hot.h")]
 
 PT_SD_DIMP, PT_SD_DIMP_L2, PT_SD_PRDIMP = 0, 1, 2
@@ -40,7 +40,7 @@ EXPORTS = [
     "pt_tomp_bbreg_param_floats", "pt_tomp_bbreg_ws_bytes", "pt_tomp_bbreg_f32",
     "pt_clf_head_ws_bytes", "pt_clf_head_f32", "pt_max2d_f32", "pt_localize_f32",
     "pt_iou_param_floats", "pt_iou_prepared_floats", "pt_iou_prepare_f32", "pt_iou_refine_ws_bytes", "pt_iou_refine_f32",
-    "pt_profile_create", "pt_profile_attach", "pt_profile_collect", "pt_profile_reset", "pt_profile_destroy",
+    "pt_track_frame_replay_pass_f32",
 ]
 
 
@@ -181,16 +181,8 @@ def lib():
     L.pt_iou_refine_ws_bytes.argtypes = [ip, i]
     L.pt_iou_refine_f32.restype = i
     L.pt_iou_refine_f32.argtypes = [ip, vp, vp, vp, vp, vp, vp, vp, vp, vp, i, i, fp, f, i, i, vp, sz, vp]
-    L.pt_profile_create.restype = i
-    L.pt_profile_create.argtypes = [ctypes.POINTER(vp), i]
-    L.pt_profile_attach.restype = i
-    L.pt_profile_attach.argtypes = [vp]
-    L.pt_profile_collect.restype = i
-    L.pt_profile_collect.argtypes = [vp, i, ctypes.POINTER(ctypes.c_double), ctypes.POINTER(ctypes.c_long)]
-    L.pt_profile_reset.restype = i
-    L.pt_profile_reset.argtypes = [vp]
-    L.pt_profile_destroy.restype = i
-    L.pt_profile_destroy.argtypes = [vp]
+    L.pt_track_frame_replay_pass_f32.restype = i
+    L.pt_track_frame_replay_pass_f32.argtypes = [ctypes.POINTER(SdParams), vp, vp, vp, vp] + [i] * 6 + [vp, sz, i, i, vp]
     _lib = L
     return L
 

@@ -12,7 +12,7 @@ import numpy as np
 import torch
 
 from . import _lib, synth
-from .filter import _ptr, _stream
+from .filter import _ptr, _stream, device_guarded
 
 
 class TrackState:
@@ -62,6 +62,7 @@ class TrackState:
             raise RuntimeError("pt_track_frame_ws_bytes rejected the configuration")
         self.ws = torch.empty(nb, dtype=torch.uint8, device=dev)
 
+    @device_guarded
     def step(self, test_feat, slot, num_iter):
         """test_feat (C,H,W) device tensor.  Asynchronous."""
         c = self.cfg

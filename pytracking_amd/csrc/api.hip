@@ -48,7 +48,7 @@ extern "C" int pt_apply_filter_f32(const float* feat, long feat_stride_n, const 
     hipStream_t st = (hipStream_t)stream;
     float* spart = (float*)ws;
     PtFast f = pt_fast_plan(n, C, H, W, KH, KW, OH, OW);
-    if (f.ok && ((uintptr_t)feat % 16) == 0 && (feat_stride_n % 4) == 0 && (long)n * feat_stride_n * 4 < (1L << 31)) {
+    if (pt_fast_usable(f, feat, feat_stride_n, filt)) {
         rc = pt_launch_corr2(f, feat, feat_stride_n, filt, spart, st);
         if (rc) return rc;
         return pt_launch_sum_slices(spart, scores, 8, (size_t)n * f.OO, st);
@@ -88,7 +88,7 @@ extern "C" int pt_feat_transpose_f32(const float* feat, long feat_stride_n, cons
         return PT_ERR_WORKSPACE;
     hipStream_t st = (hipStream_t)stream;
     PtFast f = pt_fast_plan(n, C, H, W, KH, KW, OH, OW);
-    if (f.ok && ((uintptr_t)feat % 16) == 0 && (feat_stride_n % 4) == 0 && (long)n * feat_stride_n * 4 < (1L << 31)) {
+    if (pt_fast_usable(f, feat, feat_stride_n)) {
         float* gp = (float*)ws;
         rc = pt_launch_adj2_plain(f, feat, feat_stride_n, inp, gp, st);
         if (rc) return rc;
@@ -140,7 +140,7 @@ extern "C" int pt_track_frame_f32(const pt_sd_params* prm, float* filter, float*
     const long CHW = (long)C * H * W;
     float* base = (float*)ws;
     PtFast f = pt_fast_plan(n, C, H, W, K, K, OH, OW);
-    if (f.ok && ((uintptr_t)mem_feat % 16) == 0 && ((uintptr_t)test_feat % 16) == 0) {
+    if (pt_fast_usable(f, mem_feat, CHW, filter, test_feat)) {
         // Fast path: the first correlation of the solve reads sample `slot` from test_feat (and stores it into the
         // memory slot, dimp.py:429-441); its score row under the current filter IS the classification of the test
         // frame (dimp.py:190-194 -> linear_filter.py:75-80).  Localisation runs in the init stage.
@@ -161,4 +161,18 @@ extern "C" int pt_track_frame_f32(const pt_sd_params* prm, float* filter, float*
     return pt_sd_solve_impl(prm, filter, mem_feat, CHW, mem_bb, sample_weight, n, C, H, W, K, num_iter,
                             base + cv.w_iters, nullptr, base + cv.sd, (cv.total - cv.sd) * sizeof(float), st,
                             /*copy_w0=*/false, /*w_final=*/filter, &cls, /*src=*/nullptr);
+}
+
+extern "C" int pt_track_frame_replay_pass_f32(const pt_sd_params* prm, const float* filter, const float* mem_feat,
+                                              const float* mem_bb, const float* sample_weight, int n, int C, int H, int W,
+                                              int K, int num_iter, void* ws, size_t ws_bytes, int which, int reps,
+                                              void* stream) {
+    if (!prm || !filter || !mem_feat || !mem_bb || !ws) return PT_ERR_NULL;
+    if (n <= 0 || C <= 0 || H <= 0 || W <= 0 || K <= 0) return PT_ERR_SHAPE;
+    TfCarve cv = tf_carve(n, C, H, W, K);
+    if (ws_bytes < cv.total * sizeof(float) || ((uintptr_t)ws % 256) != 0) return PT_ERR_WORKSPACE;
+    float* base = (float*)ws;
+    return pt_sd_replay_impl(prm, filter, mem_feat, (long)C * H * W, mem_bb, sample_weight, n, C, H, W, K, num_iter,
+                             base + cv.w_iters, base + cv.sd, (cv.total - cv.sd) * sizeof(float), which, reps,
+                             (hipStream_t)stream);
 }

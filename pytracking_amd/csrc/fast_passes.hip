@@ -16,24 +16,14 @@
 //             wave w owns U contiguous 16-position groups.  G[c][tap] = sum_P feat[c][P] * r[P shifted by tap]; the B
 //             operand is gathered from zero-padded residual maps the workgroup builds in LDS -- there is no im2col
 //             buffer in HBM.  In the solver the maps come from the fused update prologue (alpha, s_{t}, residual).
-#include <stdlib.h>
 #include "common.h"
 #include "pt_internal.h"
 #include "sd_common.h"
 
-#ifndef PT_ABL
-#define PT_ABL 0      // experiments/fast_floor.hip only
-#endif
 #ifndef PT_ADJ_WAVES
 #define PT_ADJ_WAVES 8                     // waves per k_adj2 workgroup (16 measured no better at 18x18, worse at 22x22)
 #endif
 #define PT_ADJ_UMAX (128 / PT_ADJ_WAVES)   // 16-position groups per wave (all of a wave's loads are in flight at once)
-#ifdef PT_TRACE       // experiments/fast_floor.hip only: per-workgroup phase time stamps (100 MHz wall clock)
-__device__ unsigned long long* pt_trace_buf;
-#define PT_STAMP(k) do { if (threadIdx.x == 0 && pt_trace_buf) pt_trace_buf[blockIdx.x * 8 + (k)] = wall_clock64(); } while (0)
-#else
-#define PT_STAMP(k) do { } while (0)
-#endif
 
 // ---------------------------------------------------------------------------------------------------
 // geometry
@@ -56,9 +46,6 @@ PtFast pt_fast_plan(int n, int C, int H, int W, int KH, int KW, int OH, int OW) 
     // k-step halves: two waves per tile when that keeps the workgroup at <= 10 waves (two workgroups per CU, <= 80 VGPRs);
     // larger maps (22x22: 8 tiles) use one wave per tile with all of the XCD's k-steps
     p.nh = 2 * p.tiles <= 10 ? 2 : 1;
-#ifdef PT_EXPERIMENT
-    if (getenv("PT_NH")) p.nh = atoi(getenv("PT_NH"));
-#endif
     p.CX = C / 8;
     p.NK = p.CX / 4 / p.nh;
     if (p.NK > 16) return p;
@@ -145,7 +132,6 @@ __global__ __launch_bounds__(1024, (NK <= 8 ? 6 : 4)) void k_corr2(Corr2Args a) 
     const bool over = a.src != nullptr && i == a.slot;
     const float* __restrict__ fi = over ? a.src : a.feat + (long)i * a.stride_n;
     const bool publish = FUSE > 0 && i == 0;
-    PT_STAMP(0);
 
     // ---- filter operand: straight-line, clamped addresses, all loads in flight together.  With 16 taps the slice
     //      is one contiguous run of CX*16 floats: 16-byte loads, one per thread; otherwise up to EPT scalars.
@@ -206,7 +192,6 @@ __global__ __launch_bounds__(1024, (NK <= 8 ? 6 : 4)) void k_corr2(Corr2Args a) 
 #pragma unroll
     for (int k = 0; k < CD; ++k) ldq(k);
 
-    PT_STAMP(1);
     // ---- reduce + publish the filter slice
     float gsq = 0.f;
     if (k16) {
@@ -254,14 +239,12 @@ __global__ __launch_bounds__(1024, (NK <= 8 ? 6 : 4)) void k_corr2(Corr2Args a) 
         if (threadIdx.x == 0) a.anum_part[x] = tot;
     }
     __syncthreads();
-    PT_STAMP(2);
 
     f32x4 acc0 = {0, 0, 0, 0}, acc1 = {0, 0, 0, 0}, acc2 = {0, 0, 0, 0}, acc3 = {0, 0, 0, 0}, accL = {0, 0, 0, 0};
 #pragma unroll
     for (int k = 0; k < NK; ++k) {
         if (k + CD < NK) ldq(k + CD);
         const float av = afilt[(4 * (h * NK + k) + kq) * 16 + j];
-        if (PT_ABL & 1) { acc0 += av * bq[k]; continue; }
         acc0 = mfma16(av, bq[k][0], acc0);
         acc1 = mfma16(av, bq[k][1], acc1);
         acc2 = mfma16(av, bq[k][2], acc2);
@@ -282,7 +265,6 @@ __global__ __launch_bounds__(1024, (NK <= 8 ? 6 : 4)) void k_corr2(Corr2Args a) 
         }
     }
 
-    PT_STAMP(3);
 #pragma unroll
     for (int r = 0; r < 4; ++r) {
         const int row = 4 * kq + r;
@@ -293,7 +275,6 @@ __global__ __launch_bounds__(1024, (NK <= 8 ? 6 : 4)) void k_corr2(Corr2Args a) 
         }
     }
     __syncthreads();
-    PT_STAMP(4);
 
     // ---- shift-and-add of the tap planes (both halves), fixed order
     const int ph = a.KH / 2, pw = a.KW / 2, OO = a.OH * a.OW;
@@ -301,7 +282,6 @@ __global__ __launch_bounds__(1024, (NK <= 8 ? 6 : 4)) void k_corr2(Corr2Args a) 
     const float* __restrict__ T0 = lds + nsl;
     const float* __restrict__ T1 = T0 + (long)KK * a.HWp;          // second k-step half (a.nh == 2)
     float* __restrict__ out = a.spart + ((long)x * a.n + i) * OO;
-    if (PT_ABL & 2) { if (threadIdx.x < 64) out[threadIdx.x] = T0[threadIdx.x * 7]; return; }
     if (a.KH == 4 && a.KW == 4) {                                   // the trackers' filter size: fully unrolled
         for (int o = threadIdx.x; o < OO; o += blockDim.x) {
             const int y = fdiv(o, inv_ow), xx0 = o - y * a.OW;
@@ -323,7 +303,6 @@ __global__ __launch_bounds__(1024, (NK <= 8 ? 6 : 4)) void k_corr2(Corr2Args a) 
             for (int q = 0; q < 16; ++q) s += tv[q];
             out[o] = s;
         }
-        PT_STAMP(5);
         return;
     }
     for (int o = threadIdx.x; o < OO; o += blockDim.x) {
@@ -358,7 +337,6 @@ int pt_launch_corr2(const PtFast& p, const float* feat, long stride_n, const flo
     if (p.KK == 16 && (((uintptr_t)filt % 16) || ((uintptr_t)a.gpart % 16) || ((uintptr_t)a.w % 16) || ((uintptr_t)a.g_out % 16)))
         return PT_ERR_UNSUPPORTED;
     dim3 grid(8 * p.n), block(p.corr_threads);
-    pt_prof_begin(0, st);
 #define PT_C2F(NKV, LF)                                                                                          \
     do {                                                                                                         \
         if (!a.gpart) hipLaunchKernelGGL((k_corr2<NKV, LF, 0>), grid, block, p.corr_lds, st, a);                 \
@@ -376,7 +354,6 @@ int pt_launch_corr2(const PtFast& p, const float* feat, long stride_n, const flo
     else PT_C2(16);
 #undef PT_C2F
 #undef PT_C2
-    pt_prof_end(0, st);
     PT_CHECK_LAUNCH();
     return PT_OK;
 }
@@ -549,7 +526,6 @@ __global__ __launch_bounds__(PT_ADJ_WAVES * 64) void k_adj2(Adj2Args a) {
     // pixel (yy,xx) sits at (yy + oy, xx + ox)
     const int oy = a.KH - 1 - a.KH / 2, ox = a.KW - 1 - a.KW / 2;
 
-    PT_STAMP(0);
     for (int e = threadIdx.x; e < ns * PHPW; e += blockDim.x) maps[e] = 0.f;
     if (threadIdx.x < 16) maps[ZB + threadIdx.x] = 0.f;
 
@@ -577,10 +553,8 @@ __global__ __launch_bounds__(PT_ADJ_WAVES * 64) void k_adj2(Adj2Args a) {
         if (wupd && (int)threadIdx.x < 16 * KK)                     // w_t = w_{t-1} - step*alpha*g   (:160)
             a.sd.w_iters[(long)a.t * a.sd.CKK + wge] = w_prev - astep * g_prev;
     }
-    PT_STAMP(1);
     __syncthreads();                                                // maps zeroed
-    PT_STAMP(2);
-    if (have && !(PT_ABL & 16)) sdp_compute<V, E>(a, i_lo + wave, lane, pr, astep, maps + wave * PHPW, oy, ox, home0);
+    if (have) sdp_compute<V, E>(a, i_lo + wave, lane, pr, astep, maps + wave * PHPW, oy, ox, home0);
     for (int sl = wave + PT_ADJ_WAVES; sl < ns; sl += PT_ADJ_WAVES) {   // more samples than waves (tiny maps)
         const int i = i_lo + sl;
         const int hg = (i * HW) >> 4;
@@ -588,9 +562,7 @@ __global__ __launch_bounds__(PT_ADJ_WAVES * 64) void k_adj2(Adj2Args a) {
         sdp_load<V, E>(a, i, lane, home, pr);
         sdp_compute<V, E>(a, i, lane, pr, astep, maps + sl * PHPW, oy, ox, home);
     }
-    PT_STAMP(3);
     __syncthreads();
-    PT_STAMP(4);
 
     // ---- G[c][tap] += feat[c][P] * r[P shifted by tap] over the U contiguous 16-position groups of this wave.
     //      A wave stalls at a load it cannot issue (the CU's memory pipeline accepts ~20-45 B/clk), so the loads are
@@ -635,14 +607,12 @@ __global__ __launch_bounds__(PT_ADJ_WAVES * 64) void k_adj2(Adj2Args a) {
     for (int u = 0; u < UM; ++u) {
         if (u + PD < UM) issue(u + PD);
         if (u + 1 < UM) gather(u + 1);
-        if (PT_ABL & 8) { accA += av[u]; continue; }
         // masked lanes multiply a finite, re-read feature value by a gathered zero
         accA = mfma16(av[u][0], bv[u][0], accA);
         accB = mfma16(av[u][1], bv[u][1], accB);
         accA = mfma16(av[u][2], bv[u][2], accA);
         accB = mfma16(av[u][3], bv[u][3], accB);
     }
-    PT_STAMP(5);
 #pragma unroll
     for (int r = 0; r < 4; ++r) red[wave][(4 * kq + r) * 16 + j] = accA[r] + accB[r];
     __syncthreads();
@@ -653,7 +623,6 @@ __global__ __launch_bounds__(PT_ADJ_WAVES * 64) void k_adj2(Adj2Args a) {
         for (int w = 0; w < PT_ADJ_WAVES; ++w) s += red[w][e];
         if (tap < KK) a.gpart[(long)ks * a.C * KK + (long)(cb * 16 + row) * KK + tap] = s;
     }
-    PT_STAMP(6);
 }
 
 static void adj2_fill(const PtFast& p, Adj2Args& a, const float* feat, long stride_n, float* gpart) {
@@ -679,9 +648,7 @@ int pt_launch_adj2_plain(const PtFast& p, const float* feat, long stride_n, cons
     adj2_fill(p, a, feat, stride_n, gpart);
     a.inp = inp;
     a.sd = SdArgs();
-    pt_prof_begin(1, st);
     adj2_dispatch<V_PLAIN>(p, a, st);
-    pt_prof_end(1, st);
     PT_CHECK_LAUNCH();
     return PT_OK;
 }
@@ -694,12 +661,10 @@ int pt_launch_adj2_sd(const PtFast& p, const float* feat, long stride_n, const S
     a.sd = sd;
     a.t = t;
     a.want_loss = want_loss;
-    pt_prof_begin(1, st);
     if (sd.kind == PT_SD_PRDIMP) adj2_dispatch<V_PRDIMP>(p, a, st);
     else if (sd.kind == PT_SD_DIMP_L2) adj2_dispatch<V_L2>(p, a, st);
     else if (sd.score_act == PT_ACT_BENTPAR) adj2_dispatch<V_DIMP_BENT>(p, a, st);
     else adj2_dispatch<V_DIMP_RELU>(p, a, st);
-    pt_prof_end(1, st);
     PT_CHECK_LAUNCH();
     return PT_OK;
 }

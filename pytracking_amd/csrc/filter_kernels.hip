@@ -84,12 +84,6 @@ __device__ __forceinline__ float corr_filter_elem(const float* __restrict__ filt
     return ok ? v : 0.f;
 }
 
-#ifndef PT_EXPERIMENT
-#define PT_EXPERIMENT 0
-#endif
-#ifndef PT_ABL
-#define PT_ABL 0      // experiments/pass_floor.hip only: 1 = no MFMA, 2 = no shift-add epilogue, 4 = no filter staging
-#endif
 
 template <bool VEC, int NK>
 __global__ void k_corr(const float* __restrict__ feat, long stride_n, const float* __restrict__ filt,
@@ -117,7 +111,7 @@ __global__ void k_corr(const float* __restrict__ feat, long stride_n, const floa
 #pragma unroll
     for (int q = 0; q < 4; ++q) {
         const int e = threadIdx.x + q * blockDim.x;
-        if (!(PT_ABL & 4) && e < nsl) fv[q] = corr_filter_elem(filt, fz, C, KK, cbeg, cend, e, publish, gsq);
+        if (e < nsl) fv[q] = corr_filter_elem(filt, fz, C, KK, cbeg, cend, e, publish, gsq);
     }
 
     // ---- first tile's feature loads: the whole channel slice of this wave in flight.  VEC path: addresses are
@@ -185,7 +179,6 @@ __global__ void k_corr(const float* __restrict__ feat, long stride_n, const floa
 #pragma unroll
             for (int k = 0; k < NK; ++k) {
                 const float a = afilt[(4 * k + kq) * 16 + j];
-                if (PT_ABL & 1) { acc0 += a * b[k]; continue; }
                 acc0 = mfma16(a, b[k][0], acc0);
                 acc1 = mfma16(a, b[k][1], acc1);
                 acc2 = mfma16(a, b[k][2], acc2);
@@ -217,7 +210,6 @@ __global__ void k_corr(const float* __restrict__ feat, long stride_n, const floa
 
     const int ph = KH / 2, pw = KW / 2, OO = OH * OW;
     float* __restrict__ out = spart + ((long)cs * n + i) * OO;
-    if (PT_ABL & 2) { if (threadIdx.x < 64) out[threadIdx.x] = Tl[threadIdx.x * 7]; return; }
     for (int o = threadIdx.x; o < OO; o += blockDim.x) {
         const int y = o / OW, x = o - y * OW;
         float s = 0.f;
@@ -269,7 +261,6 @@ __global__ __launch_bounds__(512) void k_adj(const float* __restrict__ feat, lon
                 i += ((long)(i + 1) * HW <= P) ? 1 : 0;
                 const int pos = (int)(P - (long)i * HW);
                 a[u] = *(const f32x4*)(fc + (long)i * stride_n + pos);
-                if (PT_ABL & 16) b[u] = a[u]; else
                 b[u] = *(const f32x4*)(R + (long)g * 256 + lane * 4);
             }
 #pragma unroll
@@ -279,7 +270,6 @@ __global__ __launch_bounds__(512) void k_adj(const float* __restrict__ feat, lon
                 // (lane l carries channel l&15 in A but tap l&15 in B)
                 const bool okk = g < gend && ((long)g * 16 + 4 * kq) < total;
                 const bool oka = okk && cv;
-                if (PT_ABL & 8) { accA += (oka ? a[u] : b[u]) * b[u]; continue; }
                 accA = mfma16(oka ? a[u][0] : 0.f, okk ? b[u][0] : 0.f, accA);
                 accB = mfma16(oka ? a[u][1] : 0.f, okk ? b[u][1] : 0.f, accB);
                 accA = mfma16(oka ? a[u][2] : 0.f, okk ? b[u][2] : 0.f, accA);
@@ -352,16 +342,10 @@ PtPlan pt_make_plan(int n, int C, int H, int W, int KH, int KW, int OH, int OW) 
     int want = pt_ceil_div(512, n);
     int KS = 1;
     while ((KS * 2 <= want || pt_ceil_div(ksteps, KS) > 16) && pt_ceil_div(ksteps, KS * 2) >= 4 && KS < 64) KS *= 2;
-#if PT_EXPERIMENT
-    if (getenv("PT_FORCE_KS")) KS = atoi(getenv("PT_FORCE_KS"));
-#endif
     p.cper = pt_ceil_div(ksteps, KS) * 4;
     p.KS = pt_ceil_div(C, p.cper);                // drop empty slices
     int ntiles = pt_ceil_div(p.HW, 64);
     int nw = ntiles < 16 ? ntiles : 16;
-#if PT_EXPERIMENT
-    if (getenv("PT_FORCE_NW")) nw = atoi(getenv("PT_FORCE_NW"));
-#endif
     p.corr_threads = nw * 64;
     p.corr_lds = ((size_t)p.cper * 16 + (size_t)p.KK * (ntiles * 64 + 4)) * sizeof(float);
     // adj
@@ -374,9 +358,6 @@ PtPlan pt_make_plan(int n, int C, int H, int W, int KH, int KW, int OH, int OW) 
     if (KSPL > pt_ceil_div(p.NG, 128)) KSPL = std::max(pt_ceil_div(p.NG, 128), std::min(KSPL, 8));
     if (KSPL < 1) KSPL = 1;
     if (KSPL > 64) KSPL = 64;
-#if PT_EXPERIMENT
-    if (getenv("PT_FORCE_KSPL")) KSPL = atoi(getenv("PT_FORCE_KSPL"));
-#endif
     p.gper = pt_ceil_div(p.NG, KSPL);
     p.KSPL = pt_ceil_div(p.NG, p.gper);
     return p;
@@ -402,24 +383,20 @@ int pt_launch_corr(const PtPlan& p, const float* feat, long stride_n, const floa
     PtCorrFuse fz = {nullptr, 0, nullptr, 0.f, nullptr, nullptr, nullptr};
     if (fuse) fz = *fuse;
     if (fz.copy_dst && p.n != 1) return PT_ERR_SHAPE;
-    pt_prof_begin(0, st);
     if (p.vec4 && (stride_n % 4) == 0 && ((uintptr_t)feat % 16) == 0 && ((uintptr_t)fz.copy_dst % 16) == 0)
         corr_dispatch<true>(p, grid, block, st, feat, stride_n, filt, spart, fz);
     else
         corr_dispatch<false>(p, grid, block, st, feat, stride_n, filt, spart, fz);
-    pt_prof_end(0, st);
     PT_CHECK_LAUNCH();
     return PT_OK;
 }
 
 int pt_launch_adj(const PtPlan& p, const float* feat, long stride_n, const float* R, float* gpart, hipStream_t st) {
     dim3 grid(pt_ceil_div(p.C, 16), p.KSPL), block(512);
-    pt_prof_begin(1, st);
     if (p.vec4 && (stride_n % 4) == 0 && ((uintptr_t)feat % 16) == 0)
         hipLaunchKernelGGL(k_adj<true>, grid, block, 0, st, feat, stride_n, R, gpart, p.n, p.C, p.HW, p.KK, p.NG, p.gper);
     else
         hipLaunchKernelGGL(k_adj<false>, grid, block, 0, st, feat, stride_n, R, gpart, p.n, p.C, p.HW, p.KK, p.NG, p.gper);
-    pt_prof_end(1, st);
     PT_CHECK_LAUNCH();
     return PT_OK;
 }

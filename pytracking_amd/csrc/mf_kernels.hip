@@ -22,15 +22,6 @@ struct MfGeom {
     int RSmax;           // staged rows per band (BR + K - 1)
 };
 
-#ifndef PT_MFABL
-#define PT_MFABL 0     // experiments only: 1 = no MFMA, 4 = no global fetch
-#endif
-#ifdef PT_EXPERIMENT   // per-chunk time stamps of k_mf_corr (workgroup-relative), read back by pt_mf_trace_dump()
-static unsigned long long* g_mf_trace = nullptr;
-#define MF_STAMP(slot) do { if (trace && threadIdx.x == 0) trace[((blockIdx.y * gridDim.x + blockIdx.x) * 128) + (slot)] = wall_clock64(); } while (0)
-#else
-#define MF_STAMP(slot) do { } while (0)
-#endif
 
 __device__ __forceinline__ int mf_fdiv(int v, float inv_d) { return (int)(((float)v + 0.5f) * inv_d); }
 
@@ -69,11 +60,10 @@ struct MfStage {
 template <int KK, int NT, int VW>
 __global__ __launch_bounds__(256) void k_mf_corr(const float* __restrict__ feat, long stride_n,
                                                  const float* __restrict__ wT, float* __restrict__ scores,
-                                                 long out_stride_n, MfGeom g, int CS, unsigned long long* trace) {
+                                                 long out_stride_n, MfGeom g, int CS) {
     extern __shared__ __attribute__((aligned(16))) float lds[];
     constexpr int NQ = MF_NQ / VW;
     constexpr int K = KK == 1 ? 1 : 3;
-    MF_STAMP(0);
     float* __restrict__ fl = lds;                                   // [MF_CK][CS]
     float* __restrict__ wl = lds + MF_CK * CS;                      // [MF_KS][KK][64]
     const int band = blockIdx.x, i = blockIdx.y;
@@ -154,12 +144,9 @@ __global__ __launch_bounds__(256) void k_mf_corr(const float* __restrict__ feat,
     fetch(0);
     __syncthreads();                                                // zero fill done
     for (int c0 = 0; c0 < g.C; c0 += MF_CK) {
-        MF_STAMP(1 + 4 * (c0 / MF_CK));
         stage(c0);
-        MF_STAMP(2 + 4 * (c0 / MF_CK));
         __syncthreads();
-        MF_STAMP(3 + 4 * (c0 / MF_CK));
-        if (c0 + MF_CK < g.C && !(PT_MFABL & 4)) fetch(c0 + MF_CK);   // next chunk in flight while this one is multiplied
+        if (c0 + MF_CK < g.C) fetch(c0 + MF_CK);   // next chunk in flight while this one is multiplied
         // LDS operands of k-step ks+1 (KK A values, KK x NT B values) are read while the MFMAs of k-step ks issue: a
         // workgroup has one wave per SIMD, so nothing else hides the LDS latency.  No per-tile branch: a tile beyond the
         // band multiplies zeros (t_ok false), far cheaper than putting every MFMA into its own basic block.
@@ -182,12 +169,10 @@ __global__ __launch_bounds__(256) void k_mf_corr(const float* __restrict__ feat,
             for (int tap = 0; tap < KK; ++tap) {
 #pragma unroll
                 for (int q = 0; q < NT; ++q) {
-                    if (PT_MFABL & 1) { acc[q][0] += av[ks & 1][tap] * bv[ks & 1][tap][q]; continue; }
                     acc[q] = mfma16(av[ks & 1][tap], t_ok[q] ? bv[ks & 1][tap][q] : 0.f, acc[q]);
                 }
             }
         }
-        MF_STAMP(4 + 4 * (c0 / MF_CK));
         __syncthreads();
     }
 #pragma unroll
@@ -373,9 +358,6 @@ static MfPlan mf_plan(int n, int F, int C, int H, int W, int K) {
     while (BR > 1 && ((BR + K - 1) * W > 64 * MF_NQ ||
                       (n * ((H + BR - 1) / BR) < 512 && (BR - 1) * W >= 96)))      // keep >= 6 of a wave quad's 8 tile slots busy
         --BR;
-#ifdef PT_EXPERIMENT
-    if (getenv("PT_MF_BR")) BR = atoi(getenv("PT_MF_BR"));
-#endif
     if ((BR + K - 1) * W > 64 * MF_NQ || BR * W > 256) return p;
     g.BR = BR;
     g.NB = (H + BR - 1) / BR;
@@ -386,9 +368,6 @@ static MfPlan mf_plan(int n, int F, int C, int H, int W, int K) {
     int BRa = 256 / W;
     if (BRa > H) BRa = H;
     while (BRa > 1 && (BRa + K - 1) * W > 64 * MF_NQ) --BRa;
-#ifdef PT_EXPERIMENT
-    if (getenv("PT_MF_BRA")) BRa = atoi(getenv("PT_MF_BRA"));
-#endif
     if ((BRa + K - 1) * W > 64 * MF_NQ) return p;
     p.ga.BR = BRa;
     p.ga.NB = (H + BRa - 1) / BRa;
@@ -400,9 +379,6 @@ static MfPlan mf_plan(int n, int F, int C, int H, int W, int K) {
     p.adj_lds = std::max((size_t)16 * (p.CS2 + p.RS2), (size_t)4 * g.KK * 256) * sizeof(float);
     const int CBn = (C + 15) / 16;
     int NSG = 512 / CBn;                                 // ~2 workgroups per CU
-#ifdef PT_EXPERIMENT
-    if (getenv("PT_MF_NSG")) NSG = atoi(getenv("PT_MF_NSG"));
-#endif
     if (NSG < 1) NSG = 1;
     if (NSG > n) NSG = n;
     if (NSG > 32) NSG = 32;
@@ -443,16 +419,8 @@ int pt_launch_mf_corr(const float* feat, long stride_n, const float* wT, float* 
     if (!p.ok) return PT_ERR_UNSUPPORTED;
     dim3 grid(p.g.NB, n), block(256);
     const bool vec = mf_vec_ok(feat, feat, stride_n, W);
-    pt_prof_begin(0, st);
-    unsigned long long* trace = nullptr;
-#ifdef PT_EXPERIMENT
-    if (getenv("PT_MF_TRACE")) {
-        if (!g_mf_trace) hipMalloc(&g_mf_trace, (size_t)4096 * 128 * 8);
-        trace = g_mf_trace;
-    }
-#endif
 #define PT_MFC(KKV, NTV, VWV) \
-    hipLaunchKernelGGL((k_mf_corr<KKV, NTV, VWV>), grid, block, p.corr_lds, st, feat, stride_n, wT, scores, out_stride_n, p.g, p.CS, trace)
+    hipLaunchKernelGGL((k_mf_corr<KKV, NTV, VWV>), grid, block, p.corr_lds, st, feat, stride_n, wT, scores, out_stride_n, p.g, p.CS)
     if (K == 1) {
         if (p.NT == 2) { if (vec) PT_MFC(1, 2, 4); else PT_MFC(1, 2, 1); }
         else { if (vec) PT_MFC(1, 4, 4); else PT_MFC(1, 4, 1); }
@@ -461,7 +429,6 @@ int pt_launch_mf_corr(const float* feat, long stride_n, const float* wT, float* 
         else { if (vec) PT_MFC(9, 4, 4); else PT_MFC(9, 4, 1); }
     }
 #undef PT_MFC
-    pt_prof_end(0, st);
     PT_CHECK_LAUNCH();
     return PT_OK;
 }
@@ -473,22 +440,12 @@ int pt_launch_mf_adj(const float* feat, long stride_n, const float* inp, float* 
     if (!p.ok) return PT_ERR_UNSUPPORTED;
     dim3 grid((C + 15) / 16, p.NSG), block(256);
     const bool vec = mf_vec_ok(feat, inp, stride_n, W) && ((H * W) % 4) == 0 && (inp_stride_n % 4) == 0;
-    pt_prof_begin(1, st);
 #define PT_MFA(KKV, VWV) \
     hipLaunchKernelGGL((k_mf_adj<KKV, VWV>), grid, block, p.adj_lds, st, feat, stride_n, inp, inp_stride_n, gpart, p.ga, p.CS2, p.RS2, p.spg)
     if (K == 1) { if (vec) PT_MFA(1, 4); else PT_MFA(1, 1); }
     else { if (vec) PT_MFA(9, 4); else PT_MFA(9, 1); }
 #undef PT_MFA
-    pt_prof_end(1, st);
     PT_CHECK_LAUNCH();
     return PT_OK;
 }
 
-#ifdef PT_EXPERIMENT
-// experiments only: copy the time stamps of the last k_mf_corr launch to the host (slots x workgroups)
-extern "C" int pt_mf_trace_dump(unsigned long long* host, int nwg) {
-    if (!g_mf_trace) return -1;
-    hipDeviceSynchronize();
-    return hipMemcpy(host, g_mf_trace, (size_t)nwg * 128 * 8, hipMemcpyDeviceToHost) == hipSuccess ? 0 : -2;
-}
-#endif

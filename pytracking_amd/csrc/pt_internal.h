@@ -2,6 +2,7 @@
 #pragma once
 #include <hip/hip_runtime.h>
 #include <stddef.h>
+#include <stdint.h>
 #include "../../include/pt_hot.h"
 
 // Geometry of the two feature passes for one (n, C, H, W, KH, KW) problem.
@@ -57,6 +58,14 @@ struct PtFast {
     size_t adj_lds;
 };
 PtFast pt_fast_plan(int n, int C, int H, int W, int KH, int KW, int OH, int OW);
+// The ONE predicate for "this call can take the XCD-aligned path": the shape plan plus what the raw 16-byte buffer loads
+// need from the pointers (shared by pt_apply_filter_f32, pt_feat_transpose_f32, pt_sd_solve_impl, pt_track_frame_f32;
+// when it is false every caller takes its generic branch).  `filt` / `src` may be null.
+static inline bool pt_fast_usable(const PtFast& f, const void* feat, long stride_n, const void* filt = nullptr,
+                                  const void* src = nullptr) {
+    return f.ok && ((uintptr_t)feat % 16) == 0 && (stride_n % 4) == 0 && (long)f.n * stride_n * 4 < (1L << 31) &&
+           ((uintptr_t)src % 16) == 0 && (f.KK != 16 || ((uintptr_t)filt % 16) == 0);
+}
 static inline size_t pt_fast_spart_floats(const PtFast& p) { return (size_t)8 * p.n * p.OO; }
 static inline size_t pt_fast_gpart_floats(const PtFast& p) { return (size_t)p.KSPL * p.C * p.KK; }
 // spart[x][i][OH*OW], x = XCD channel range (8 slices).  `slot`/`src`/`copy_dst`: sample `slot` is read from `src`
@@ -99,6 +108,10 @@ int pt_sd_solve_impl(const pt_sd_params* prm, const float* w_in, const float* fe
                      float* losses, void* ws, size_t ws_bytes, hipStream_t st, bool copy_w0, float* w_final,
                      const PtClsFin* cls, const float* src);
 
+int pt_sd_replay_impl(const pt_sd_params* prm, const float* w_in, const float* feat, long feat_stride_n, const float* bb,
+                      const float* sample_weight, int n, int C, int H, int W, int K, int num_iter, float* w_iters, void* ws,
+                      size_t ws_bytes, int which, int reps, hipStream_t stream);
+
 // Two pyramid levels of one image, same RoIs, one launch each way (prroi.hip; used by the IoU refinement):
 //   fwd2:      out[l] (R, C[l], PH[l], PH[l]) = chan_scale[l][c] * PrRoIPool(feat[l])
 //   bwd_coor2: part[l][(r * slices + s) * 4 + {x0,y0,x1,y1}] = partial coordinate gradients, summed by the consumer
@@ -109,6 +122,3 @@ int pt_launch_prroi_bwd_coor2(const float* const grad_out[2], const float* const
                               const int C[2], const int H[2], const int W[2], const int PH[2], const float scale[2],
                               const float* rois, int R, int slices, hipStream_t st);
 
-// measurement hook (profile.hip): no-ops unless a pt_profile is attached
-void pt_prof_begin(int kernel_id, hipStream_t st);
-void pt_prof_end(int kernel_id, hipStream_t st);

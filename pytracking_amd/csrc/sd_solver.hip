@@ -320,23 +320,33 @@ static void sd_fill_params(SdArgs& a, const pt_sd_params* prm, const float* bb, 
     a.cls_spart = nullptr; a.cls_KS = 0; a.cls_slot = -1; a.cls_scores = nullptr; a.cls_peak = nullptr; a.cls_bb = nullptr;
 }
 
-static int sd_solve_fast(const PtFast& f, const pt_sd_params* prm, const float* w_in, const float* feat, long stride_n,
-                         const float* bb, const float* sample_weight, int num_iter, float* w_iters, float* losses,
-                         void* ws, size_t ws_bytes, hipStream_t st, bool copy_w0, float* w_final, const PtClsFin* cls,
-                         const float* src) {
+// Solver state of the fast path laid out in the caller's workspace (shared by the solve and by the measurement replay).
+static int sd_fast_setup(const PtFast& f, const pt_sd_params* prm, const float* w_in, const float* bb,
+                         const float* sample_weight, float* w_iters, float* w_final, void* ws, size_t ws_bytes, SdArgs& a,
+                         float* sbuf[2]) {
     FastCarve cv = fast_carve(f, PT_SD_MAX_ITER);
     if (ws_bytes < cv.total * sizeof(float) || ((uintptr_t)ws % 256) != 0) return PT_ERR_WORKSPACE;
     float* base = (float*)ws;
-    const int n = f.n, K = f.KH;
-    SdArgs a;
-    sd_fill_params(a, prm, bb, sample_weight, n, f.C, f.H, f.W, K, f.OH, f.OW);
+    sd_fill_params(a, prm, bb, sample_weight, f.n, f.C, f.H, f.W, f.KH, f.OH, f.OW);
     a.KS = 8; a.KSPL = f.KSPL;
     a.label = base + cv.label; a.mask = base + cv.mask; a.sws = base + cv.sws; a.sg = base + cv.sg;
     a.lms = base + cv.lms; a.pk = base + cv.pk;
     a.spart = base + cv.spart; a.gpart = base + cv.gpart; a.g = base + cv.g; a.anum = base + cv.anum;
     a.qs = base + cv.qs; a.lossp = base + cv.lossp; a.w_iters = w_iters; a.w0 = w_in; a.w_final = w_final;
-    float* sbuf[2] = {base + cv.s0, base + cv.s1};
+    sbuf[0] = base + cv.s0; sbuf[1] = base + cv.s1;
     a.s = sbuf[0];
+    return PT_OK;
+}
+
+static int sd_solve_fast(const PtFast& f, const pt_sd_params* prm, const float* w_in, const float* feat, long stride_n,
+                         const float* bb, const float* sample_weight, int num_iter, float* w_iters, float* losses,
+                         void* ws, size_t ws_bytes, hipStream_t st, bool copy_w0, float* w_final, const PtClsFin* cls,
+                         const float* src) {
+    SdArgs a;
+    float* sbuf[2];
+    int rc = sd_fast_setup(f, prm, w_in, bb, sample_weight, w_iters, w_final, ws, ws_bytes, a, sbuf);
+    if (rc) return rc;
+    const int n = f.n;
     const int slot = cls ? cls->slot : -1;
     if (cls) {
         // the inserted sample's scores under w_in ARE the classification scores of the test frame
@@ -352,7 +362,7 @@ static int sd_solve_fast(const PtFast& f, const pt_sd_params* prm, const float* 
     if (num_iter == 0 && !want_loss && !cls) return PT_OK;
 
     float* copy_dst = src ? const_cast<float*>(feat) + (long)slot * stride_n : nullptr;
-    int rc = pt_launch_corr2(f, feat, stride_n, w_in, a.spart, st, nullptr, src ? slot : -1, src, copy_dst);
+    rc = pt_launch_corr2(f, feat, stride_n, w_in, a.spart, st, nullptr, src ? slot : -1, src, copy_dst);
     if (rc) return rc;
     hipLaunchKernelGGL(k_fast_init, dim3(n), dim3(384), 0, st, a);
     PT_CHECK_LAUNCH();
@@ -402,7 +412,7 @@ int pt_sd_solve_impl(const pt_sd_params* prm, const float* w_in, const float* fe
     const int OH = H + (K + 1) % 2, OW = W + (K + 1) % 2;               // optimizer.py:105
     {
         PtFast f = pt_fast_plan(n, C, H, W, K, K, OH, OW);
-        if (f.ok && ((uintptr_t)feat % 16) == 0 && (feat_stride_n % 4) == 0 && (long)n * feat_stride_n * 4 < (1L << 31) && ((uintptr_t)src % 16) == 0)
+        if (pt_fast_usable(f, feat, feat_stride_n, w_in, src) && ((uintptr_t)w_iters % 16) == 0)
             return sd_solve_fast(f, prm, w_in, feat, feat_stride_n, bb, sample_weight, num_iter, w_iters, losses, ws,
                                  ws_bytes, st, copy_w0, w_final, cls, src);
     }
@@ -477,4 +487,40 @@ extern "C" int pt_sd_solve_f32(const pt_sd_params* prm, const float* w_in, const
     return pt_sd_solve_impl(prm, w_in, feat, feat_stride_n, bb, sample_weight, n, C, H, W, K, num_iter, w_iters, losses,
                             ws, ws_bytes, (hipStream_t)stream, /*copy_w0=*/true, /*w_final=*/nullptr, /*cls=*/nullptr,
                             /*src=*/nullptr);
+}
+
+// ----------------------------------------------------------------------------------------------------
+// Measurement helper behind pt_track_frame_replay_pass_f32 (api.hip; bench.py roofline leg): re-issue ONE feature pass of the solve
+// that last ran on this workspace, `reps` times back to back on `stream`, exactly as iteration t = num_iter - 1 of
+// pt_track_frame_f32 / pt_sd_solve_f32 launched it (same kernel instantiation, same operands; both passes only read
+// the state they were launched on, so re-issuing them is idempotent).  The caller brackets the call with ONE event pair.
+//   which = 0: correlation pass with the fused gradient reduction (k_corr2<..., FUSE>)
+//   which = 1: adjoint pass with the fused update prologue        (k_adj2<V, ...>)
+// ----------------------------------------------------------------------------------------------------
+int pt_sd_replay_impl(const pt_sd_params* prm, const float* w_in, const float* feat, long feat_stride_n, const float* bb,
+                      const float* sample_weight, int n, int C, int H, int W, int K, int num_iter, float* w_iters, void* ws,
+                      size_t ws_bytes, int which, int reps, hipStream_t stream) {
+    if (!prm || !w_in || !feat || !bb || !w_iters || !ws) return PT_ERR_NULL;
+    if (num_iter < 2 || reps < 1 || which < 0 || which > 1) return PT_ERR_SHAPE;
+    const int OH = H + (K + 1) % 2, OW = W + (K + 1) % 2;
+    PtFast f = pt_fast_plan(n, C, H, W, K, K, OH, OW);
+    if (!pt_fast_usable(f, feat, feat_stride_n, w_in)) return PT_ERR_UNSUPPORTED;
+    SdArgs a;
+    float* sbuf[2];
+    int rc = sd_fast_setup(f, prm, w_in, bb, sample_weight, w_iters, nullptr, ws, ws_bytes, a, sbuf);
+    if (rc) return rc;
+    hipStream_t st = (hipStream_t)stream;
+    const int t = num_iter - 1;
+    a.s_in = sbuf[(t - 1) & 1];
+    a.s = sbuf[t & 1];
+    for (int r = 0; r < reps; ++r) {
+        if (which == 1) {
+            rc = pt_launch_adj2_sd(f, feat, feat_stride_n, a, t, 0, st);
+        } else {
+            PtCorrFuse fz = {a.gpart, f.KSPL, w_iters + (long)t * a.CKK, a.reg, a.g, a.anum, nullptr};
+            rc = pt_launch_corr2(f, feat, feat_stride_n, nullptr, a.spart, st, &fz);
+        }
+        if (rc) return rc;
+    }
+    return PT_OK;
 }

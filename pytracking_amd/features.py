@@ -10,7 +10,7 @@ import torch
 import torch.nn as nn
 
 from . import _lib
-from .filter import _ptr, _require_device, _stream, workspace
+from .filter import _ptr, _require_device, _stream, device_guarded, workspace
 
 
 class InstanceL2Norm(nn.Module):
@@ -42,6 +42,7 @@ class ClfHead(nn.Sequential):
             self._key = key
         return self._wt
 
+    @device_guarded
     def forward(self, x):
         if self.training or (torch.is_grad_enabled() and (x.requires_grad or self[0].weight.requires_grad)):
             raise NotImplementedError("ClfHead: the gfx950 path is inference only (eval() under torch.no_grad())")

@@ -12,12 +12,57 @@ stays usable under autograd for filter-space optimisers; gradients w.r.t. the fe
 path that is out of scope and raise NotImplementedError.
 """
 import ctypes
+import functools
 
 import torch
 
 from . import _lib
 
 _WS = {}
+
+
+def _first_device_tensor(objs):
+    for o in objs:
+        if isinstance(o, torch.Tensor):
+            if o.is_cuda:
+                return o
+        elif isinstance(o, (list, tuple)):
+            t = _first_device_tensor(o)
+            if t is not None:
+                return t
+    return None
+
+
+def device_guarded(fn):
+    """The C ABI launches on `torch.cuda.current_stream()` of the CURRENT device.  Stock PyTorch ops guard on the device
+    of their operands; this decorator does the same for the ctypes calls: when the first device tensor among the
+    arguments lives on another GPU than the current one (single-process multi-GPU, `params.device='cuda:1'`), the body
+    runs under `torch.cuda.device(that GPU)` so that stream, workspace and pointers agree."""
+    @functools.wraps(fn)
+    def wrapper(*args, **kw):
+        t = _first_device_tensor(args)
+        if t is None:
+            t = _first_device_tensor(list(kw.values()))
+        if t is None or t.device.index == torch.cuda.current_device():
+            return fn(*args, **kw)
+        with torch.cuda.device(t.device):
+            return fn(*args, **kw)
+    return wrapper
+
+
+class on_device:
+    """`with on_device(t):` -- the same guard for call sites whose tensors are not arguments."""
+
+    def __init__(self, t):
+        self._ctx = None if t.device.index == torch.cuda.current_device() else torch.cuda.device(t.device)
+
+    def __enter__(self):
+        if self._ctx is not None:
+            self._ctx.__enter__()
+
+    def __exit__(self, *exc):
+        if self._ctx is not None:
+            return self._ctx.__exit__(*exc)
 
 
 def workspace(nbytes: int, device) -> torch.Tensor:
@@ -40,18 +85,26 @@ def _ptr(t):
 
 
 def _require_device(*tensors):
+    dev = None
     for t in tensors:
+        if t is None:
+            continue
         if not t.is_cuda:
             raise RuntimeError("pytracking_amd ops run on the MI355X only (got a CPU tensor); "
                                "the CPU restatement lives in oracle/ and is test infrastructure")
         if t.dtype != torch.float32:
             raise RuntimeError(f"pytracking_amd ops are fp32 (got {t.dtype})")
+        if dev is None:
+            dev = t.device
+        elif t.device != dev:
+            raise RuntimeError(f"pytracking_amd ops need all operands on one GPU (got {dev} and {t.device})")
 
 
 def _out_size(H, W, KH, KW):
     return H + 2 * (KH // 2) - KH + 1, W + 2 * (KW // 2) - KW + 1
 
 
+@device_guarded
 def corr_raw(feat4, filt3, out_hw=None):
     """feat4 (n,C,H,W) [sample-strided view allowed], filt3 (C,KH,KW) -> (n,OH,OW)."""
     n, C, H, W = feat4.shape
@@ -70,6 +123,7 @@ def corr_raw(feat4, filt3, out_hw=None):
     return out
 
 
+@device_guarded
 def adj_raw(feat4, inp3, ksz):
     """feat4 (n,C,H,W), inp3 (n,OH,OW) -> (C,KH,KW)."""
     n, C, H, W = feat4.shape
@@ -88,6 +142,7 @@ def adj_raw(feat4, inp3, ksz):
     return out
 
 
+@device_guarded
 def corr_mf_raw(feat4, filt4):
     """feat4 (n,C,H,W), filt4 (F,C,K,K) -> (n,F,H,W)   (multi-filter branch of apply_filter, filter.py:29-34)."""
     n, C, H, W = feat4.shape
@@ -108,6 +163,7 @@ def corr_mf_raw(feat4, filt4):
     return out
 
 
+@device_guarded
 def adj_mf_raw(feat4, inp4, ksz):
     """feat4 (n,C,H,W), inp4 (n,F,H,W) -> (F,C,K,K)   (5-D input branch of apply_feat_transpose, filter.py:158-176)."""
     n, C, H, W = feat4.shape

@@ -51,6 +51,8 @@ def _covered(feat, filt, dilation_factors=None):
     if not (isinstance(feat, torch.Tensor) and feat.is_cuda and feat.dtype == torch.float32 and filt.is_cuda
             and dilation_factors is None):
         return False
+    if torch.is_grad_enabled() and feat.requires_grad:   # feature gradients (offline training): the reference's convs
+        return False
     if filt.dim() == 5:                                  # multi-filter (LWL): <= 16 filters, 1x1 / 3x3, groups == 1
         return (filt.shape[1] <= 16 and filt.shape[-1] == filt.shape[-2] and filt.shape[-1] in (1, 3)
                 and filt.shape[-3] == feat.shape[-3] and feat.shape[-1] <= 256)
@@ -70,7 +72,8 @@ def _make_dispatchers(orig_mod, strict):
     def apply_feat_transpose(feat, input, filter_ksz, training=True, groups=1):
         ksz = (filter_ksz, filter_ksz) if isinstance(filter_ksz, int) else tuple(filter_ksz)
         mf = input.dim() == 5 and input.shape[2] <= 16 and ksz[0] == ksz[1] and ksz[0] in (1, 3) and feat.shape[-1] <= 256
-        if feat.is_cuda and feat.dtype == torch.float32 and groups == 1 and (mf or (input.dim() == 4 and ksz[0] * ksz[1] <= 16)):
+        if feat.is_cuda and feat.dtype == torch.float32 and groups == 1 and (mf or (input.dim() == 4 and ksz[0] * ksz[1] <= 16)) \
+                and not (torch.is_grad_enabled() and feat.requires_grad):
             return _filter.apply_feat_transpose(feat, input, ksz, training=training, groups=groups)
         if strict:
             raise NotImplementedError("apply_feat_transpose: configuration outside the gfx950 hot path")
@@ -87,6 +90,48 @@ def _make_dispatchers(orig_mod, strict):
         fn.__doc__ = o.__doc__
         fn.__wrapped__ = o
     return apply_filter, apply_feat_transpose, filter_gradient
+
+
+def _optimizer_class(fused_cls, ref_cls, strict):
+    """The class bound under the reference's name: the gfx950 module (same parameters, same state_dict keys) whose
+    forward runs the fused solver for device tensors under no_grad and hands every other call (CPU tensors, offline
+    training with requires_grad inputs, K*K > 16) to the reference class's own forward on the same parameters."""
+    import ltr.models.layers.activation as ract
+    import ltr.models.layers.distance as rdist
+
+    class Dispatching(fused_cls):
+        __doc__ = ref_cls.__doc__
+
+        def __init__(self, *args, **kw):
+            super().__init__(*args, **kw)
+            # parameter-free helper modules the reference forward reads (optimizer.py:44,74-82)
+            if hasattr(self, "num_dist_bins"):
+                self.distance_map = rdist.DistanceMap(self.num_dist_bins, self.bin_displacement)
+                if self.score_act == 'bentpar':
+                    self.score_activation = ract.BentIdentPar(self.act_param)
+                    self.score_activation_deriv = ract.BentIdentParDeriv(self.act_param)
+                else:
+                    self.score_activation = ract.LeakyReluPar()
+                    self.score_activation_deriv = ract.LeakyReluParDeriv()
+
+        def forward(self, weights, feat, bb, sample_weight=None, num_iter=None, compute_losses=True):
+            fused = (feat.is_cuda and weights.is_cuda and feat.dtype == torch.float32
+                     and weights.shape[-1] == weights.shape[-2] and weights.shape[-1] ** 2 <= 16
+                     and (sample_weight is None or isinstance(sample_weight, torch.Tensor))
+                     and not (torch.is_grad_enabled() and (weights.requires_grad or feat.requires_grad)))
+            if fused:
+                return fused_cls.forward(self, weights, feat, bb, sample_weight=sample_weight, num_iter=num_iter,
+                                         compute_losses=compute_losses)
+            if strict:
+                raise NotImplementedError(f"{ref_cls.__name__}: call outside the gfx950 hot path")
+            return ref_cls.forward(self, weights, feat, bb, sample_weight=sample_weight, num_iter=num_iter,
+                                   compute_losses=compute_losses)
+
+    for name, member in vars(ref_cls).items():           # helper methods the reference forward calls (get_label_density ...)
+        if callable(member) and not name.startswith("__") and not hasattr(fused_cls, name):
+            setattr(Dispatching, name, member)
+    Dispatching.__name__ = Dispatching.__qualname__ = ref_cls.__name__
+    return Dispatching
 
 
 def provide_prroi_module():
@@ -291,7 +336,7 @@ def install(strict=False, atom_cg=True, tomp=True, clf_head=True, localization=T
     names = ("DiMPSteepestDescentGN", "DiMPL2SteepestDescentGN", "PrDiMPSteepestDescentNewton")
     orig["optimizer"] = tuple(getattr(omod, n) for n in names)
     for n in names:
-        setattr(omod, n, getattr(_optimizer, n))
+        setattr(omod, n, _optimizer_class(getattr(_optimizer, n), getattr(omod, n), strict))
     # LWL few-shot learner: the residual module is replaced outright (same parameters); the generic optimiser class
     # dispatches on it so that other residual modules (RTS, dimp_simple) keep the reference implementation
     try:
@@ -301,17 +346,49 @@ def install(strict=False, atom_cg=True, tomp=True, clf_head=True, localization=T
         rmod = smod = None
     if rmod is not None:
         orig["lwl"] = (rmod.LWTLResidual, smod.GNSteepestDescent)
-        ref_gn = smod.GNSteepestDescent
+        ref_gn, ref_res = smod.GNSteepestDescent, rmod.LWTLResidual
+
+        class LWTLResidual(ref_res):
+            """No dilation factors -> the gfx950 mirror (same parameter); dilated filters -> the reference class."""
+
+            def __new__(cls, init_filter_reg=1e-2, filter_dilation_factors=None):
+                if filter_dilation_factors is None:
+                    return _ResMirror(init_filter_reg, filter_dilation_factors)
+                if strict:
+                    raise NotImplementedError("LWTLResidual: dilated filters are outside the gfx950 hot path")
+                return ref_res.__new__(cls)
+
+        class _ResMirror(_sd.LWTLResidual):
+            # the residual vectors themselves (only the reference's generic forward asks for them): the reference's
+            # own method on the rebound filter layer, so CPU tensors and autograd behave as upstream
+            forward = ref_res.forward
 
         class GNSteepestDescent(ref_gn):
-            """LWTLResidual (gfx950 mirror) -> fused solver; any other residual module -> the reference class."""
+            """LWTLResidual (gfx950 mirror) at inference -> fused solver; any other residual module, a training call
+            (grad-enabled inputs) or CPU tensors -> the reference class / the reference forward."""
 
             def __new__(cls, residual_module=None, *args, **kw):
-                if isinstance(residual_module, _sd.LWTLResidual) and kw.get("residual_batch_dim", 0) == 1:
-                    return _sd.GNSteepestDescent(residual_module, *args, **kw)
+                if (isinstance(residual_module, _sd.LWTLResidual) and residual_module.filter_dilation_factors is None
+                        and kw.get("residual_batch_dim", 0) == 1 and kw.get("parameter_batch_dim", 0) == 0):
+                    return _FusedGN(residual_module, *args, **kw)
                 return ref_gn.__new__(cls)
 
-        rmod.LWTLResidual = _sd.LWTLResidual
+        class _FusedGN(_sd.GNSteepestDescent):
+            _compute_loss = ref_gn._compute_loss
+            _sqr_norm = ref_gn._sqr_norm
+
+            def forward(self, meta_parameter, num_iter=None, *args, **kwargs):
+                w = meta_parameter[0] if isinstance(meta_parameter, (list, tuple)) else meta_parameter
+                feat = kwargs.get("feat")
+                fused = (isinstance(feat, torch.Tensor) and feat.is_cuda and w.is_cuda and not args
+                         and not (torch.is_grad_enabled() and (w.requires_grad or feat.requires_grad)))
+                if fused:
+                    return _sd.GNSteepestDescent.forward(self, meta_parameter, num_iter, **kwargs)
+                if strict:
+                    raise NotImplementedError("GNSteepestDescent: call outside the gfx950 hot path")
+                return ref_gn.forward(self, meta_parameter, num_iter, *args, **kwargs)
+
+        rmod.LWTLResidual = LWTLResidual
         smod.GNSteepestDescent = GNSteepestDescent
     if tomp:
         _install_tomp(orig, strict)
@@ -337,7 +414,8 @@ def install(strict=False, atom_cg=True, tomp=True, clf_head=True, localization=T
                 def __new__(cls, problem, variable, *args, **kw):
                     kind = _optimization.activation_kind(getattr(problem, "response_activation", None))[0]
                     fast = (isinstance(problem, ref_problem) and kind == "mlu" and len(variable) == 1
-                            and variable[0].is_cuda and not kw.get("debug", False)
+                            and variable[0].is_cuda and variable[0].shape[-1] == variable[0].shape[-2]
+                            and variable[0].shape[-1] ** 2 <= 16 and not kw.get("debug", False)
                             and kw.get("standard_alpha", True) and kw.get("cg_eps", 0.0) == 0.0)
                     if fast:
                         return _optimization.ConjugateGradient(problem, variable, *args, **kw)
@@ -357,7 +435,7 @@ def install(strict=False, atom_cg=True, tomp=True, clf_head=True, localization=T
                     fast = (isinstance(problem, ref_fact) and len(variable) == 2 and variable[0].is_cuda
                             and ak(getattr(problem, "response_activation", None))[0] == "mlu"
                             and ak(getattr(problem, "projection_activation", None))[0] == "identity"
-                            and variable[0].shape[-1] * variable[0].shape[-2] <= 16
+                            and variable[0].shape[-1] == variable[0].shape[-2] and variable[0].shape[-1] ** 2 <= 16
                             and not any(kw.get(k, False) for k in ("debug", "analyze", "plotting"))
                             and kw.get("standard_alpha", True) and kw.get("cg_eps", 0.0) == 0.0
                             and kw.get("direction_forget_factor", 0) == 0)

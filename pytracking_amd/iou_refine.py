@@ -14,7 +14,7 @@ import weakref
 import torch
 
 from . import _lib
-from .filter import _ptr, _require_device, _stream, workspace
+from .filter import _ptr, _require_device, _stream, device_guarded, workspace
 from .transformer import _Pack
 
 _CACHE = weakref.WeakKeyDictionary()          # AtomIoUNet instance -> (pack, prepared buffer, key)
@@ -39,6 +39,7 @@ def _packs(net, dims):
     return pack, st["prepared"]
 
 
+@device_guarded
 def refine_boxes(net, modulation, iou_features, init_boxes, num_iter, step_length, step_decay, relative, backtrack=False):
     """-> (boxes (P,4), iou (P)) device tensors.  net: AtomIoUNet; modulation: (mod3, mod4) of one target;
     iou_features: (c3_t (1,C3,H3,W3), c4_t (1,C4,H4,W4)); init_boxes (P,4) xywh."""

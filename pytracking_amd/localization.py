@@ -14,9 +14,10 @@ import math
 import torch
 
 from . import _lib
-from .filter import _ptr, _require_device, _stream
+from .filter import _ptr, _require_device, _stream, device_guarded
 
 
+@device_guarded
 def max2d(a: torch.Tensor):
     """Maximum and [row, col] arg-max over the last two dimensions (dcf.py:156-164); stays on the device."""
     _require_device(a)
@@ -30,6 +31,7 @@ def max2d(a: torch.Tensor):
     return mv.reshape(lead), am.reshape(*lead, 2)
 
 
+@device_guarded
 def two_peaks(scores, scores_hn, neigh):
     """scores (S,H,W); neigh: S pairs (rows, cols) -> CPU float tensor [max1,row1,col1,scale,max2,row2,col2,0]."""
     _require_device(scores)

@@ -12,7 +12,7 @@ import math
 import torch
 
 from . import _lib
-from .filter import _ptr, _require_device, _stream, workspace
+from .filter import _ptr, _require_device, _stream, on_device, workspace
 
 
 class MLU:
@@ -121,18 +121,21 @@ class GaussNewtonCG:
         Kc, K = filt.shape[1], filt.shape[-1]
         assert filt.is_contiguous() and proj.is_contiguous() and samples.stride()[1:] == (H * W, W, 1)
         assert proj.shape[0] == Kc and proj.shape[1] == M
-        y = y.reshape(n, H, W).contiguous()
-        sw = sw.reshape(n).contiguous()
+        if filt.shape[-2] != K or K * K > 16:
+            raise RuntimeError("GaussNewtonCG: square filters with at most 16 taps are covered by the gfx950 kernels")
         L = _lib.lib()
-        nb = L.pt_atom_gn_ws_bytes(n, M, Kc, H, W, K)
-        if nb == 0:
-            raise RuntimeError("GaussNewtonCG: configuration not covered by the gfx950 kernels")
-        ws = workspace(nb, filt.device)
-        iters = (ctypes.c_int * len(num_cg_iter))(*[int(v) for v in num_cg_iter])
-        rc = L.pt_atom_gn_f32(_ptr(filt), _ptr(proj), _ptr(samples), samples.stride(0), _ptr(y), _ptr(sw), lf, lP,
-                              self.act_min_val, n, M, Kc, H, W, K, iters,
-                              len(num_cg_iter), int(bool(self.fletcher_reeves)), _ptr(ws), ws.numel(), _stream())
-        _lib.check(rc, "pt_atom_gn_f32")
+        with on_device(filt):
+            y = y.reshape(n, H, W).contiguous()
+            sw = sw.reshape(n).contiguous()
+            nb = L.pt_atom_gn_ws_bytes(n, M, Kc, H, W, K)
+            if nb == 0:
+                raise RuntimeError("GaussNewtonCG: configuration not covered by the gfx950 kernels")
+            ws = workspace(nb, filt.device)
+            iters = (ctypes.c_int * len(num_cg_iter))(*[int(v) for v in num_cg_iter])
+            rc = L.pt_atom_gn_f32(_ptr(filt), _ptr(proj), _ptr(samples), samples.stride(0), _ptr(y), _ptr(sw), lf, lP,
+                                  self.act_min_val, n, M, Kc, H, W, K, iters,
+                                  len(num_cg_iter), int(bool(self.fletcher_reeves)), _ptr(ws), ws.numel(), _stream())
+            _lib.check(rc, "pt_atom_gn_f32")
         return self.losses, self.residuals
 
 
@@ -167,14 +170,17 @@ class ConjugateGradient:
         n, C, H, W = samples.shape
         K = x.shape[-1]
         assert x.is_contiguous() and samples.stride()[1:] == (H * W, W, 1)
-        y = y.reshape(n, H, W).contiguous()
-        sw = sw.reshape(n).contiguous()
-        if self._state is None or self._state.numel() != 2 * C * K * K + 4:
-            self._state = torch.zeros(2 * C * K * K + 4, dtype=torch.float32, device=x.device)
+        if x.shape[-2] != K or K * K > 16:
+            raise RuntimeError("ConjugateGradient: square filters with at most 16 taps are covered by the gfx950 kernels")
         L = _lib.lib()
-        ws = workspace(L.pt_atom_cg_ws_bytes(n, C, H, W, K), x.device)
-        rc = L.pt_atom_cg_f32(_ptr(x), _ptr(samples), samples.stride(0), _ptr(y), _ptr(sw), lam,
-                              self.act_min_val, n, C, H, W, K, int(num_cg_iter),
-                              int(bool(self.fletcher_reeves)), float(self.direction_forget_factor), _ptr(self._state),
-                              _ptr(ws), ws.numel(), _stream())
-        _lib.check(rc, "pt_atom_cg_f32")
+        with on_device(x):
+            y = y.reshape(n, H, W).contiguous()
+            sw = sw.reshape(n).contiguous()
+            if self._state is None or self._state.numel() != 2 * C * K * K + 4 or self._state.device != x.device:
+                self._state = torch.zeros(2 * C * K * K + 4, dtype=torch.float32, device=x.device)
+            ws = workspace(L.pt_atom_cg_ws_bytes(n, C, H, W, K), x.device)
+            rc = L.pt_atom_cg_f32(_ptr(x), _ptr(samples), samples.stride(0), _ptr(y), _ptr(sw), lam,
+                                  self.act_min_val, n, C, H, W, K, int(num_cg_iter),
+                                  int(bool(self.fletcher_reeves)), float(self.direction_forget_factor), _ptr(self._state),
+                                  _ptr(ws), ws.numel(), _stream())
+            _lib.check(rc, "pt_atom_cg_f32")

@@ -20,9 +20,10 @@ import torch
 import torch.nn as nn
 
 from . import _lib
-from .filter import _ptr, _require_device, _stream, workspace
+from .filter import _ptr, _require_device, _stream, device_guarded, workspace
 
 
+@device_guarded
 def _solve(params: _lib.SdParams, weights, feat, bb, sample_weight, num_iter, compute_losses, keep):
     """Shared driver: loops over sequences (the C ABI solves one sequence per call)."""
     if torch.is_grad_enabled() and (weights.requires_grad or feat.requires_grad):
@@ -59,7 +60,9 @@ def _solve(params: _lib.SdParams, weights, feat, bb, sample_weight, num_iter, co
     loss_list = []
     if compute_losses:
         tot = losses.sum(dim=0) / S                       # optimizer.py:143: (...)/num_sequences
-        loss_list = [tot[t] for t in range(num_iter + 1)]
+        # shape (1,) per iterate like the reference's `(... + reg_weight * ...)/num_sequences` with reg_weight (1,)
+        # (optimizer.py:143,168): the trackers `torch.cat(losses)` in debug mode (dimp.py:583,641)
+        loss_list = [tot[t:t + 1] for t in range(num_iter + 1)]
     return weight_iterates[-1], weight_iterates, loss_list
 
 

@@ -9,11 +9,12 @@ import torch
 import torch.nn as nn
 
 from . import _lib
-from .filter import _ptr, _require_device, _stream
+from .filter import _ptr, _require_device, _stream, device_guarded
 
 
 class _PrRoIPool2DFunction(torch.autograd.Function):
     @staticmethod
+    @device_guarded
     def forward(ctx, features, rois, pooled_height, pooled_width, spatial_scale):
         _require_device(features, rois)
         features = features.contiguous()
@@ -30,6 +31,7 @@ class _PrRoIPool2DFunction(torch.autograd.Function):
         return out
 
     @staticmethod
+    @device_guarded
     def backward(ctx, grad_out):
         features, rois = ctx.saved_tensors
         PH, PW, scale = ctx.params

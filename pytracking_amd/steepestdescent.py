@@ -14,7 +14,7 @@ import torch
 import torch.nn as nn
 
 from . import _lib
-from .filter import _ptr, _require_device, _stream, apply_filter, workspace
+from .filter import _ptr, _require_device, _stream, apply_filter, device_guarded, workspace
 
 
 class LWTLResidual(nn.Module):
@@ -57,6 +57,7 @@ class GNSteepestDescent(nn.Module):
         self._parameter_batch_dim = parameter_batch_dim
         self._residual_batch_dim = residual_batch_dim
 
+    @device_guarded
     def forward(self, meta_parameter, num_iter=None, *args, **kwargs):
         res = self.residual_module
         if not isinstance(res, LWTLResidual) or res.filter_dilation_factors is not None:

@@ -213,3 +213,70 @@ def tomp_inputs(seed, cfg=TOMP):
     ltrb = np.stack((l, t, r, b), axis=1)
     return (train.astype(np.float32), test.astype(np.float32), lab.astype(np.float32)[:, None],
             ltrb.astype(np.float32)[:, None])
+
+
+# ------------------------------------------------------------------------------------------------------
+# LWL few-shot learner and the IoU-guided refinement at deployed sizes
+# ------------------------------------------------------------------------------------------------------
+LWL = dict(n=32, F=16, C=512, H=30, W=52, K=3, filter_reg=0.05)   # lwl_ytvos.py:17,23; lwl_stage2.py:94-100
+
+
+def lwl_problem(seed, cfg=LWL):
+    """(w0, feat, label, sw) of one `GNSteepestDescent(LWTLResidual)` call: zero initial filter, per-element sample
+    weights (`lwl_net` feeds a (n,1,F,H,W) weight tensor), labels in [0,1)."""
+    rng = np.random.default_rng(seed)
+    n, F, C, H, W, K = (cfg[k] for k in ("n", "F", "C", "H", "W", "K"))
+    feat = clf_features(rng, n, C, H, W, K)
+    label = rng.random((n, F, H, W), dtype=np.float32)
+    sw = (np.float32(0.2) + np.float32(0.8) * rng.random((n, F, H, W), dtype=np.float32)).astype(np.float32)
+    w0 = np.zeros((F, C, K, K), np.float32)
+    return w0, feat, label, sw
+
+
+IOU50 = dict(C=256, I=256, H3=36, W3=36, H4=18, W4=18, proposals=10)   # dimpnet50: AtomIoUNet(pred_input_dim=(256,256),
+#                                                                        pred_inter_dim=(256,256)), dimpnet.py:189-190
+
+
+def iou_net_params(seed, cfg=IOU50):
+    """Seeded weights of the IoU predictor's test branch (atom_iou_net.py:44-49) keyed by the reference's state_dict
+    names: two LinearBlocks (Linear + BatchNorm2d + ReLU) and Linear(2I, 1), magnitudes as `kaiming_normal_(fan_in)`
+    (atom_iou_net.py:53-64) with the BatchNorm statistics moved off their initial 0/1."""
+    rng = np.random.default_rng(seed)
+    C, I = cfg["C"], cfg["I"]
+    p = {}
+    for name, k in (("fc3_rt", 5), ("fc4_rt", 3)):
+        fan = C * k * k
+        p[f"{name}.linear.weight"] = rng.standard_normal((I, fan), dtype=np.float32) * np.float32(math.sqrt(2.0 / fan))
+        p[f"{name}.linear.bias"] = rng.standard_normal(I, dtype=np.float32) * np.float32(0.1)
+        p[f"{name}.bn.weight"] = (np.float32(1.0) + np.float32(0.1) * rng.standard_normal(I, dtype=np.float32)).astype(np.float32)
+        p[f"{name}.bn.bias"] = rng.standard_normal(I, dtype=np.float32) * np.float32(0.1)
+        p[f"{name}.bn.running_mean"] = rng.standard_normal(I, dtype=np.float32) * np.float32(0.1)
+        p[f"{name}.bn.running_var"] = (np.float32(0.5) + rng.random(I, dtype=np.float32)).astype(np.float32)
+    p["iou_predictor.weight"] = rng.standard_normal((1, 2 * I), dtype=np.float32) * np.float32(math.sqrt(2.0 / (2 * I)))
+    p["iou_predictor.bias"] = np.full(1, 0.3, np.float32)
+    return p
+
+
+def iou_inputs(seed, cfg=IOU50):
+    """(c3, c4, mod3, mod4, boxes): IoU features of the test frame, modulation vectors, 10 jittered xywh proposals."""
+    rng = np.random.default_rng(seed)
+    C = cfg["C"]
+    c3 = rng.standard_normal((1, C, cfg["H3"], cfg["W3"]), dtype=np.float32)
+    c4 = rng.standard_normal((1, C, cfg["H4"], cfg["W4"]), dtype=np.float32)
+    mod3 = (np.float32(1.0) + np.float32(0.5) * rng.standard_normal((1, C), dtype=np.float32)).astype(np.float32)
+    mod4 = (np.float32(1.0) + np.float32(0.5) * rng.standard_normal((1, C), dtype=np.float32)).astype(np.float32)
+    base = np.array([100.0, 90.0, 80.0, 110.0], np.float32)
+    boxes = np.stack([base] + [base + np.concatenate((rng.uniform(-12, 12, 2), rng.uniform(-25, 25, 2))).astype(np.float32)
+                               for _ in range(cfg["proposals"] - 1)])
+    return c3, c4, mod3, mod4, boxes.astype(np.float32)
+
+
+def atom_gn_problem(seed, n=30, M=256, Kc=64, H=18, W=18, K=4, cfg=ATOM18):
+    """ATOM first frame (parameter/atom/default.py:27-28,40-45; atom.py:140-176): n augmented samples of M backbone
+    channels, zero initial filter, PCA-like projection matrix.  Returns (f0, P0, samples, y, sw)."""
+    rng = np.random.default_rng(seed)
+    samples = rng.standard_normal((n, M, H, W), dtype=np.float32) * np.float32(0.1)
+    _, _, y, sw = atom_problem(seed, n, cfg, small=dict(C=Kc, H=H, W=W))
+    f0 = np.zeros((Kc, K, K), np.float32)
+    P0 = rng.standard_normal((Kc, M), dtype=np.float32) * np.float32(1.0 / math.sqrt(M))
+    return f0, P0, samples, y, sw

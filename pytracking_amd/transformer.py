@@ -21,7 +21,7 @@ import torch.nn as nn
 
 from . import _lib
 from . import filter as filter_layer
-from .filter import _ptr, _require_device, _stream, workspace
+from .filter import _ptr, _require_device, _stream, device_guarded, workspace
 
 
 class _Pack:
@@ -204,6 +204,7 @@ class FilterPredictor(nn.Module):
         return _lib.TompDims(t.d_model, t.nhead, t.dim_feedforward, len(t.encoder.layers), len(t.decoder.layers), H, W,
                              int(fs))
 
+    @device_guarded
     def get_positional_encoding(self, feat):
         """(nframes, nseq, C, h, w) like the reference; the (h*w, C) table is computed once per map size."""
         nframes, nseq, C, h, w = feat.shape
@@ -219,6 +220,7 @@ class FilterPredictor(nn.Module):
             self._pos[key] = pos
         return self._pos[key]
 
+    @device_guarded
     def _run(self, train_feat, test_feat, train_label, train_ltrb_target, parallel, num_gth_frames):
         _inference_only(self)
         if train_feat.dim() == 4:
@@ -269,6 +271,7 @@ class FilterPredictor(nn.Module):
 # ------------------------------------------------------------------------------------------------------------------
 # heads.py
 # ------------------------------------------------------------------------------------------------------------------
+@device_guarded
 def _project(linear, filt, C):
     x = filt.reshape(-1, C).contiguous()
     _require_device(x)
@@ -332,6 +335,7 @@ class DenseBoxRegressor(nn.Module):
         # permute() returns views sharing the parameters' version counters, so the cache key still tracks updates
         return self._pack.get(tensors)
 
+    @device_guarded
     def forward(self, feat, filter):
         _inference_only(self)
         nf, ns, c, h, w = feat.shape

@@ -673,8 +673,8 @@ def test_iou_refinement_golden(tag, relative):
     fn = IR.optimize_boxes_relative if relative else IR.optimize_boxes_default
     boxes, iou = fn(me, (T(g["c3"]), T(g["c4"])), torch.from_numpy(g["boxes"].copy()))
     assert not boxes.is_cuda and boxes.shape == (10, 4) and iou.shape == (10,)
-    close(iou, g[f"{tag}_iou"], atol=1e-4, rtol=1e-4)
-    close(boxes, g[f"{tag}_boxes"], atol=5e-3, rtol=1e-4)
+    close(iou, g[f"{tag}_iou"], atol=1e-4, rtol=0)
+    close(boxes, g[f"{tag}_boxes"], atol=1e-4, rtol=0)
     assert float(np.abs(g[f"{tag}_boxes"] - g["boxes"]).max()) > 2.0           # the boxes really moved
     b2, i2 = fn(me, (T(g["c3"]), T(g["c4"])), torch.from_numpy(g["boxes"].copy()))   # cached pack / prepared buffers
     assert torch.equal(b2, boxes) and torch.equal(i2, iou)
@@ -700,5 +700,155 @@ def test_iou_refinement_atom_golden(tag, space):
                box_refinement_space=space)
     me = types.SimpleNamespace(params=params, iou_predictor=net, target_feat=(T(g["mod3"]), T(g["mod4"])))
     boxes, iou = IR.optimize_boxes_atom(me, (T(g["c3"]), T(g["c4"])), torch.from_numpy(g["boxes"].copy()))
-    close(iou, g[f"{tag}_iou"], atol=2e-4, rtol=2e-4)
-    close(boxes, g[f"{tag}_boxes"], atol=1e-2, rtol=1e-4)
+    close(iou, g[f"{tag}_iou"], atol=1e-4, rtol=0)
+    close(boxes, g[f"{tag}_boxes"], atol=1e-4, rtol=0)
+
+
+# ------------------------------------------------------------------------------------------------------
+# round 2: full-size / deployed-size reference vectors and the branches that had no coverage
+# ------------------------------------------------------------------------------------------------------
+@pytest.mark.parametrize("name", ["dimp_sd_bentpar", "dimp_sd_linmask", "dimp_sd_bentpar_linmask", "dimp_sd_bentpar_c128"])
+def test_dimp_sd_activation_branches_golden(name):
+    """PT_ACT_BENTPAR (activation.py:47-66) and PT_MASK_LINEAR (optimizer.py:57-66) on the generic kernels (C=16) and
+    on the XCD-aligned path (C=128, 18x18), against the reference."""
+    g = load_golden(name)
+    if "feat" in g:
+        w0, feat, bb, sw = g["w0"], g["feat"], g["bb"], g["sw"]
+        over = dict(score_act=str(g["score_act"]), mask_act=str(g["mask_act"]))
+    else:
+        w0, feat, bb, sw = synth.dimp_problem(int(g["seed"]), int(g["n"]), small=dict(C=128, H=18, W=18))
+        over = dict(score_act="bentpar", mask_act="linear")
+    from pytracking_amd import optimizer
+    c = dict(synth.DIMP50, **over)
+    mod = optimizer.DiMPSteepestDescentGN(
+        num_iter=3, feat_stride=c["feat_stride"], init_step_length=c["init_step_length"],
+        init_filter_reg=c["init_filter_reg"], init_gauss_sigma=c["init_gauss_sigma"], num_dist_bins=c["num_dist_bins"],
+        bin_displacement=c["bin_displacement"], mask_init_factor=c["mask_init_factor"], score_act=c["score_act"],
+        act_param=float(g["act_param"]) or None, mask_act=c["mask_act"], min_filter_reg=c["min_filter_reg"],
+        alpha_eps=c["alpha_eps"]).to(DEV).eval()
+    its, losses = _run(mod, w0, feat, bb, sw, int(g["num_iter"]))
+    close(its, g["iterates"], atol=2e-5)
+    close(losses.reshape(-1), g["losses"], atol=2e-5, rtol=1e-4)
+
+
+@pytest.mark.parametrize("name", ["prdimp_sd_sigma0", "prdimp_sd_sigma0_c128"])
+def test_prdimp_one_hot_label_golden(name):
+    """gauss_sigma == 0 (optimizer.py:334-341; sd_common.h one-hot branch), generic and XCD-aligned path."""
+    g = load_golden(name)
+    if "feat" in g:
+        w0, feat, bb, sw = g["w0"], g["feat"], g["bb"], g["sw"]
+    else:
+        w0, feat, bb, sw = synth.dimp_problem(int(g["seed"]), int(g["n"]), synth.PRDIMP50, small=dict(C=128, H=18, W=18))
+        w0 = w0 * 0
+    its, losses = _run(_prdimp_module(gauss_sigma=0.0), w0, feat, bb, sw, int(g["num_iter"]))
+    close(its, g["iterates"], atol=2e-5)
+    close(losses.reshape(-1), g["losses"], atol=2e-5, rtol=1e-4)
+
+
+@pytest.mark.parametrize("name", ["dimp_sd_two_sequences", "prdimp_sd_two_sequences"])
+def test_sd_two_sequences_golden(name):
+    """S = 2 through the optimiser mirror: feat (n,S,C,H,W), weights (S,C,K,K), bb (n,S,4), sample_weight (n,S); the
+    losses keep the reference's shape (1,) so that `torch.cat(losses)` (dimp.py:583,641) works."""
+    g = load_golden(name)
+    mod = _dimp_module() if name.startswith("dimp") else _prdimp_module()
+    with torch.no_grad():
+        w, its, losses = mod(T(g["w0"]), T(g["feat"]), T(g["bb"]), sample_weight=T(g["sw"]), num_iter=int(g["num_iter"]),
+                             compute_losses=True)
+    assert w.shape == g["w0"].shape and len(its) == int(g["num_iter"]) + 1
+    close(torch.stack(its), g["iterates"], atol=2e-5)
+    assert losses[0].shape == (1,)
+    close(torch.cat(losses), g["losses"][:, 0], atol=2e-5, rtol=1e-4)
+
+
+@pytest.mark.parametrize("tag", ["pr", "fr"])
+def test_atom_cg_direction_forgetting_golden(tag):
+    """direction_forget_factor != 0: the CG state (p, rho, r_prev) is carried across run() calls
+    (optimization.py:82-85; atom_cg.hip cg_state)."""
+    from pytracking_amd.optimization import ConjugateGradient, ConvProblem, MLU
+    g = load_golden(f"atom_cg_forget_{tag}")
+    x = [T(g["x0"].copy())[None].clone()]
+    prob = ConvProblem([T(g["samples"])], [T(g["y"])[:, None]], [synth.ATOM18["filter_reg"]], [T(g["sw"])],
+                       MLU(synth.ATOM18["act_min_val"]))
+    opt = ConjugateGradient(prob, x, fletcher_reeves=bool(int(g["fletcher_reeves"])), direction_forget_factor=float(g["forget"]))
+    for call, iters in enumerate(g["iters"]):
+        opt.run(int(iters))
+        close(x[0][0], g["x_out"][call], atol=2e-5, rtol=1e-4)
+
+
+@pytest.mark.parametrize("tag,fr", [("pr", False), ("fr", True)])
+def test_atom_joint_gn_first_frame_schedule_golden(tag, fr):
+    """ATOM first frame at the deployed schedule: 6 Gauss-Newton x 10 CG iterations on 30 x 256 x 18 x 18 samples, 64
+    compressed channels, 4x4 filter (parameter/atom/default.py:27-28,30), against the reference's autograd run."""
+    g = load_golden("atom_gn_first_frame")
+    f0, P0, samples, y, sw = synth.atom_gn_problem(int(g["seed"]))
+    f, P = _atom_gn_run(f0, P0, samples, y, sw, [10] * 6, fr, float(g["filter_reg"]), float(g["projection_reg"]),
+                        float(g["act_min_val"]))
+    close(f, g[f"f_out_{tag}"], atol=1e-4)
+    close(P, g[f"P_out_{tag}"], atol=1e-4)
+
+
+@pytest.mark.parametrize("num_iter", [3, 4])
+def test_lwl_gn_config5_full_size_golden(num_iter):
+    """BASELINE configs[4] at full size: n = 32 samples of 512 x 30 x 52, 16 filters 3x3, 3 iterations (the reference's
+    per-frame setting, lwl_ytvos.py:26) and 4 (BASELINE's wording), against the reference's autograd run on CPU."""
+    from pytracking_amd import filter as FL
+    g = load_golden("lwl_gn_cfg5_n32")
+    w0, feat, label, sw = synth.lwl_problem(int(g["seed"]))
+    its, losses = _lwl_run(w0, feat, label, sw, num_iter, float(g["filter_reg"]), 0.0)
+    close(its[1], g["iterate1"], atol=2e-5)
+    close(its[-1], g[f"final{num_iter}"], atol=1e-4)
+    close(losses, g[f"losses{num_iter}"], atol=1e-7, rtol=1e-4)
+    if num_iter == 4:
+        s = FL.apply_filter(T(feat[:2])[:, None], its[-1][None])[:, 0]
+        close(s, g["scores_first2"], atol=1e-4)
+
+
+class _IoUNetFromParams(torch.nn.Module):
+    """AtomIoUNet's test branch (atom_iou_net.py:44-49) carrying the seeded weights of synth.iou_net_params."""
+
+    def __init__(self, p, C, I):
+        super().__init__()
+
+        def block(k):
+            m = torch.nn.Module()
+            m.linear = torch.nn.Linear(C * k * k, I)
+            m.bn = torch.nn.BatchNorm2d(I)
+            m.relu = torch.nn.ReLU()
+            return m
+        self.fc3_rt, self.fc4_rt = block(5), block(3)
+        self.iou_predictor = torch.nn.Linear(2 * I, 1)
+        sd = {k: torch.from_numpy(v.copy()) for k, v in p.items()}
+        for blk in ("fc3_rt", "fc4_rt"):
+            sd[f"{blk}.bn.num_batches_tracked"] = torch.tensor(0)
+        self.load_state_dict(sd, strict=True)
+        self.prroi_pool3t = types.SimpleNamespace(pooled_height=5, pooled_width=5, spatial_scale=1 / 8)
+        self.prroi_pool4t = types.SimpleNamespace(pooled_height=3, pooled_width=3, spatial_scale=1 / 16)
+
+
+@pytest.mark.parametrize("tag", ["default", "relative", "atom"])
+def test_iou_refinement_deployed_size_golden(tag):
+    """IoU-guided refinement at the deployed sizes (256-channel IoU features 36x36 / 18x18, 256-wide LinearBlocks, 10
+    proposals): DiMP-50 default (5 it), PrDiMP-50 relative (10 it), ATOM backtracking, against the reference on CPU.
+    north_star bound: 1e-4 on IoU and on the boxes (pixels)."""
+    from pytracking_amd import iou_refine as IR
+    g = load_golden("iou_refine_full")
+    cfg = synth.IOU50
+    net = _IoUNetFromParams(synth.iou_net_params(int(g["param_seed"])), cfg["C"], cfg["I"]).to(DEV).eval()
+    c3, c4, m3, m4, boxes = synth.iou_inputs(int(g["input_seed"]))
+    iters, step, decay = g[f"{tag}_cfg"]
+
+    class P(types.SimpleNamespace):
+        def get(self, name, default=None):
+            return getattr(self, name, default)
+    params = P(box_refinement_iter=int(iters), box_refinement_step_length=float(step), box_refinement_step_decay=float(decay),
+               box_refinement_space="default")
+    if tag == "atom":
+        me = types.SimpleNamespace(params=params, iou_predictor=net, target_feat=(T(m3), T(m4)))
+        b, iou = IR.optimize_boxes_atom(me, (T(c3), T(c4)), torch.from_numpy(boxes.copy()))
+    else:
+        me = types.SimpleNamespace(params=params, net=types.SimpleNamespace(bb_regressor=net), iou_modulation=(T(m3), T(m4)))
+        fn = IR.optimize_boxes_relative if tag == "relative" else IR.optimize_boxes_default
+        b, iou = fn(me, (T(c3), T(c4)), torch.from_numpy(boxes.copy()))
+    close(iou, g[f"{tag}_iou"], atol=1e-4)
+    close(b, g[f"{tag}_boxes"], atol=1e-4)
+    assert float(np.abs(g[f"{tag}_boxes"] - boxes).max()) > 2.0

@@ -18,8 +18,9 @@ def test_install_rebinds_boundary_symbols_and_restores():
     from pytracking_amd import install as amd, optimizer as ours, prroi_pool
     amd.install()
     try:
-        assert opt.DiMPSteepestDescentGN is ours.DiMPSteepestDescentGN
-        assert opt.PrDiMPSteepestDescentNewton is ours.PrDiMPSteepestDescentNewton
+        assert issubclass(opt.DiMPSteepestDescentGN, ours.DiMPSteepestDescentGN)
+        assert issubclass(opt.PrDiMPSteepestDescentNewton, ours.PrDiMPSteepestDescentNewton)
+        assert opt.DiMPSteepestDescentGN.__name__ == "DiMPSteepestDescentGN"
         assert fl.apply_filter is not orig_apply and fl.apply_filter.__wrapped__ is orig_apply
         from ltr.external.PreciseRoIPooling.pytorch.prroi_pool import PrRoIPool2D
         assert PrRoIPool2D is prroi_pool.PrRoIPool2D
@@ -139,3 +140,67 @@ def test_iou_refine_install_dispatch():
     finally:
         amd.uninstall()
     assert DiMP.optimize_boxes_default is ref_d and DiMP.optimize_boxes_relative is ref_r and ATOM.optimize_boxes is ref_a
+
+
+def test_installed_optimizers_fall_back_to_the_reference_forward_off_the_hot_path():
+    """install(strict=False): CPU tensors are outside the hot path, so the rebound optimiser classes must run the
+    reference's own forward on their (identically named) parameters -- checked against the reference-generated goldens;
+    the per-iterate losses keep the reference's shape (1,) so that the trackers' `torch.cat(losses)` (dimp.py:583,641)
+    works.  Also covers the LWL learner and ATOM's non-square-kernel gate."""
+    import numpy as np
+    from conftest import load_golden
+    from pytracking_amd import synth
+    ref_harness.install()
+    import ltr.models.target_classifier.optimizer as opt
+    import ltr.models.meta.steepestdescent as smod
+    import ltr.models.lwl.loss_residual_modules as rmod
+    import pytracking.libs.optimization as po
+    from pytracking import TensorList
+    from pytracking_amd import install as amd, steepestdescent as SD
+    T = torch.from_numpy
+    amd.install()
+    try:
+        g = load_golden("dimp_sd_small_w")
+        c = synth.DIMP50
+        mod = opt.DiMPSteepestDescentGN(
+            num_iter=3, feat_stride=c["feat_stride"], init_step_length=c["init_step_length"],
+            init_filter_reg=c["init_filter_reg"], init_gauss_sigma=c["init_gauss_sigma"], num_dist_bins=c["num_dist_bins"],
+            bin_displacement=c["bin_displacement"], mask_init_factor=c["mask_init_factor"], score_act=c["score_act"],
+            mask_act=c["mask_act"], min_filter_reg=c["min_filter_reg"], alpha_eps=c["alpha_eps"]).eval()
+        with torch.no_grad():
+            w, its, losses = mod(T(g["w0"])[None], T(g["feat"]), T(g["bb"]), sample_weight=T(g["sw"]), num_iter=3)
+        np.testing.assert_allclose(torch.stack([i[0] for i in its]).numpy(), g["iterates"], atol=1e-6)
+        assert losses[0].shape == (1,)
+        np.testing.assert_allclose(torch.cat(losses).numpy(), g["losses"], rtol=1e-5)
+        g = load_golden("prdimp_sd_small")
+        c = synth.PRDIMP50
+        mod = opt.PrDiMPSteepestDescentNewton(
+            num_iter=3, feat_stride=c["feat_stride"], init_step_length=c["init_step_length"],
+            init_filter_reg=c["init_filter_reg"], gauss_sigma=c["gauss_sigma"], min_filter_reg=c["min_filter_reg"],
+            alpha_eps=c["alpha_eps"], normalize_label=c["normalize_label"]).eval()
+        with torch.no_grad():
+            w, its, losses = mod(T(g["w0"])[None], T(g["feat"]), T(g["bb"]), sample_weight=T(g["sw"]), num_iter=3)
+        np.testing.assert_allclose(torch.stack([i[0] for i in its]).numpy(), g["iterates"], atol=1e-6)
+        # LWL: the rebound residual module / optimiser on CPU tensors = the reference's autograd formulation
+        g = load_golden("lwl_gn_small_full")
+        res = rmod.LWTLResidual(init_filter_reg=float(g["filter_reg"]))
+        assert isinstance(res, SD.LWTLResidual)
+        o = smod.GNSteepestDescent(residual_module=res, num_iter=int(g["num_iter"]), compute_losses=True,
+                                   steplength_reg=float(g["steplength_reg"]), residual_batch_dim=1)
+        assert isinstance(o, SD.GNSteepestDescent)
+        w, its, losses = o(TensorList([T(g["w0"])[None]]), feat=T(g["feat"])[:, None], label=T(g["label"])[:, None],
+                           sample_weight=T(g["sw"])[:, None])
+        np.testing.assert_allclose(w[0].detach()[0].numpy(), g["iterates"][-1], atol=1e-6)
+        dil = rmod.LWTLResidual(init_filter_reg=0.1, filter_dilation_factors=[1, 2])      # dilated: the reference class
+        assert not isinstance(dil, SD.LWTLResidual)
+        assert not isinstance(smod.GNSteepestDescent(residual_module=dil, residual_batch_dim=1), SD.GNSteepestDescent)
+        # ATOM: a non-square kernel is not covered -> the reference ConjugateGradient object
+        from pytracking.tracker.atom.optim import ConvProblem
+        from ltr.models.layers import activation
+        prob = ConvProblem(TensorList([torch.zeros(2, 4, 6, 6)]), TensorList([torch.zeros(2, 1, 6, 6)]), TensorList([0.1]),
+                           TensorList([torch.ones(2)]), activation.MLU(0.05))
+        cg = po.ConjugateGradient(prob, TensorList([torch.zeros(1, 4, 2, 4)]), fletcher_reeves=False)
+        from pytracking_amd import optimization as OM
+        assert not isinstance(cg, OM.ConjugateGradient) and isinstance(cg, amd._state["originals"]["cg"])
+    finally:
+        amd.uninstall()

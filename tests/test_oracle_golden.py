@@ -238,3 +238,121 @@ def test_iou_refinement_atom_backtracking(tag, relative):
     np.testing.assert_allclose(boxes.numpy(), g[f"{tag}_boxes"], rtol=2e-5, atol=5e-4)
     np.testing.assert_allclose(iou.numpy(), g[f"{tag}_iou"], rtol=2e-5, atol=2e-5)
     assert (backtracks > 0) == (decay < 1), backtracks
+
+
+# ------------------------------------------------------------------------------------------------------
+# round 2: full-size / deployed-size vectors and the branches added by oracle/make_golden.py gen_branches()
+# ------------------------------------------------------------------------------------------------------
+@pytest.mark.parametrize("name", ["dimp_sd_bentpar", "dimp_sd_linmask", "dimp_sd_bentpar_linmask"])
+def test_dimp_sd_activation_branches(name):
+    """score_act='bentpar' (activation.py:47-66) and mask_act='linear' (optimizer.py:57-66)."""
+    g = load_golden(name)
+    f64 = lambda k: g[k].astype(np.float64)
+    mask_act, score_act = str(g["mask_act"]), str(g["score_act"])
+    cfg = synth.DIMP50
+    over = dict(mask_act=mask_act, score_act=score_act, act_param=float(g["act_param"]) or None,
+                mask_w=synth.mask_lut(cfg["num_dist_bins"], cfg["bin_displacement"], cfg["mask_init_factor"], mask_act))
+    its, losses = O.dimp_sd(f64("w0"), f64("feat"), f64("bb"), f64("sw"), num_iter=int(g["num_iter"]),
+                            **_dimp_kwargs(cfg, **over))
+    close(its, g["iterates"])
+    close(losses, g["losses"], atol=1e-5, rtol=1e-4)
+
+
+def test_prdimp_sd_one_hot_label():
+    """gauss_sigma = 0: one-hot label at the nearest cell (optimizer.py:334-341)."""
+    g = load_golden("prdimp_sd_sigma0")
+    f64 = lambda k: g[k].astype(np.float64)
+    c = synth.PRDIMP50
+    its, losses = O.prdimp_sd(f64("w0"), f64("feat"), f64("bb"), f64("sw"), num_iter=int(g["num_iter"]),
+                              step_length=c["init_step_length"], filter_reg=c["init_filter_reg"],
+                              min_filter_reg=c["min_filter_reg"], feat_stride=c["feat_stride"], gauss_sigma=0.0,
+                              alpha_eps=c["alpha_eps"], normalize_label=c["normalize_label"])
+    close(its, g["iterates"])
+    close(losses, g["losses"], atol=1e-5, rtol=1e-4)
+
+
+@pytest.mark.parametrize("name", ["dimp_sd_two_sequences", "prdimp_sd_two_sequences"])
+def test_sd_two_sequences(name):
+    """Two sequences in one call: each sequence is an independent solve; the loss is averaged over sequences
+    (optimizer.py:143, :396)."""
+    g = load_golden(name)
+    S = g["w0"].shape[0]
+    tot = 0.0
+    for s in range(S):
+        a = [g[k].astype(np.float64) for k in ("w0", "feat", "bb", "sw")]
+        args = (a[0][s], a[1][:, s], a[2][:, s], a[3][:, s])
+        if name.startswith("dimp"):
+            its, losses = O.dimp_sd(*args, num_iter=int(g["num_iter"]), **_dimp_kwargs(synth.DIMP50))
+        else:
+            c = synth.PRDIMP50
+            its, losses = O.prdimp_sd(*args, num_iter=int(g["num_iter"]), step_length=c["init_step_length"],
+                                      filter_reg=c["init_filter_reg"], min_filter_reg=c["min_filter_reg"],
+                                      feat_stride=c["feat_stride"], gauss_sigma=c["gauss_sigma"], alpha_eps=c["alpha_eps"],
+                                      normalize_label=c["normalize_label"])
+        close(its, g["iterates"][:, s])
+        tot = tot + np.array(losses)
+    close(tot / S, g["losses"][:, 0], atol=1e-5, rtol=1e-4)
+
+
+@pytest.mark.parametrize("tag", ["pr", "fr"])
+def test_atom_cg_direction_forgetting(tag):
+    """direction_forget_factor != 0: (p, rho, r_prev) carried across three run() calls (optimization.py:82-85)."""
+    g = load_golden(f"atom_cg_forget_{tag}")
+    f64 = lambda k: g[k].astype(np.float64)
+    x, state = f64("x0"), None
+    for call, iters in enumerate(g["iters"]):
+        x, state = O.atom_cg(x, f64("samples"), f64("y"), f64("sw"), filter_reg=synth.ATOM18["filter_reg"],
+                             act_min_val=synth.ATOM18["act_min_val"], num_iter=int(iters),
+                             fletcher_reeves=bool(int(g["fletcher_reeves"])), state=state,
+                             direction_forget_factor=float(g["forget"]))
+        close(x, g["x_out"][call], atol=2e-5, rtol=1e-4)
+    # and the state really mattered: a reset before the second call gives a different iterate
+    x1, _ = O.atom_cg(f64("x0"), f64("samples"), f64("y"), f64("sw"), filter_reg=synth.ATOM18["filter_reg"],
+                      act_min_val=synth.ATOM18["act_min_val"], num_iter=3, fletcher_reeves=bool(int(g["fletcher_reeves"])))
+    x2, _ = O.atom_cg(x1, f64("samples"), f64("y"), f64("sw"), filter_reg=synth.ATOM18["filter_reg"],
+                      act_min_val=synth.ATOM18["act_min_val"], num_iter=2, fletcher_reeves=bool(int(g["fletcher_reeves"])))
+    assert np.abs(x2 - g["x_out"][1]).max() > 1e-4
+
+
+@pytest.mark.parametrize("tag,fr", [("pr", False), ("fr", True)])
+def test_atom_gn_first_frame_schedule(tag, fr):
+    """ATOM first frame at the deployed 6 x 10 schedule (parameter/atom/default.py:27-28), 30 x 256 x 18 x 18."""
+    g = load_golden("atom_gn_first_frame")
+    f0, P0, samples, y, sw = synth.atom_gn_problem(int(g["seed"]))
+    f64 = lambda a: a.astype(np.float64)
+    rf, rP = O.atom_gn_cg(f64(f0), f64(P0), f64(samples), f64(y), f64(sw), filter_reg=float(g["filter_reg"]),
+                          projection_reg=float(g["projection_reg"]), act_min_val=float(g["act_min_val"]),
+                          cg_iters=[10] * 6, fletcher_reeves=fr)
+    close(rf, g[f"f_out_{tag}"], atol=2e-5)
+    close(rP, g[f"P_out_{tag}"], atol=2e-5)
+
+
+def test_lwl_gn_config5_full_size_first_iteration():
+    """BASELINE configs[4] size (n=32, 512x30x52, 16 filters): the first GN iteration and both initial losses; the
+    later iterates are checked on the GPU (the float64 numpy passes take ~10 s each here)."""
+    g = load_golden("lwl_gn_cfg5_n32")
+    w0, feat, label, sw = synth.lwl_problem(int(g["seed"]))
+    f64 = lambda a: a.astype(np.float64)
+    its, losses = O.lwl_gn_sd(f64(w0), f64(feat), f64(label), f64(sw), num_iter=1, filter_reg=float(g["filter_reg"]))
+    close(its[1], g["iterate1"], atol=2e-5)
+    close(losses, g["losses4"][:2], atol=1e-7, rtol=1e-4)
+    np.testing.assert_array_equal(g["losses3"], g["losses4"][:4])          # 3 iterations are the prefix of 4
+
+
+@pytest.mark.parametrize("tag,relative", [("default", False), ("relative", True)])
+def test_iou_refinement_deployed_size(tag, relative):
+    """256-channel IoU features, 256-wide LinearBlocks, 10 proposals (dimpnet.py:189-190): the float64 oracle against
+    the reference's float32 run.  The reference's own rounding at these box magnitudes (100-200 px, ulp 1.5e-5) is
+    what the 2e-4 px bound covers (measured 2.7e-5 / 9.3e-5 px)."""
+    import torch
+    from oracle import iou_oracle as IO
+    g = load_golden("iou_refine_full")
+    p = synth.iou_net_params(int(g["param_seed"]))
+    c3, c4, m3, m4, boxes = synth.iou_inputs(int(g["input_seed"]))
+    t64 = lambda a: torch.from_numpy(a.astype(np.float64))
+    iters, step, decay = g[f"{tag}_cfg"]
+    rb, ri = IO.refine({k: t64(v) for k, v in p.items()}, (t64(m3), t64(m4)), (t64(c3), t64(c4)), t64(boxes), int(iters),
+                       float(step), float(decay), relative)
+    close(ri.numpy(), g[f"{tag}_iou"], atol=2e-5)
+    close(rb.numpy(), g[f"{tag}_boxes"], atol=2e-4, rtol=0)
+    assert np.abs(g[f"{tag}_boxes"] - boxes).max() > 2.0
