@@ -639,10 +639,18 @@ def gen_branches():
              fletcher_reeves=int(fr), forget=forget)
 
 
+def gen_trackers():
+    """Trajectory-level vectors: the unmodified reference DiMP tracker (initialize + 10 x track) on a stubbed backbone,
+    every boundary call recorded (oracle/tracker_harness.py)."""
+    from oracle import tracker_harness as TH
+    outs, rec, _ = TH.run_dimp(**TH.DIMP_RUN)
+    save("tracker_dimp50", **rec.to_npz_dict())
+
+
 if __name__ == "__main__":
     torch.set_num_threads(8)
     which = sys.argv[1:] or ["filter", "dimp", "l2", "prdimp", "atom", "prroi", "lwl", "atomgn", "tomp", "head", "localize", "iou",
-                             "branches", "ioufull", "atomgnfull", "lwlfull"]
+                             "branches", "ioufull", "atomgnfull", "lwlfull", "trackers"]
     if "tomp" in which:
         gen_tomp()
     if "head" in which:
@@ -675,3 +683,5 @@ if __name__ == "__main__":
         gen_atom_gn_full()
     if "lwlfull" in which:
         gen_lwl_full()
+    if "trackers" in which:
+        gen_trackers()

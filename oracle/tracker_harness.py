@@ -1,0 +1,349 @@
+"""TEST INFRASTRUCTURE ONLY -- drive the UNMODIFIED reference tracker classes end to end and record every call that
+crosses the hot-path boundary, for the trajectory-level parity tests.
+
+    python -B oracle/make_golden.py trackers        (build container only: needs /root/reference)
+
+What runs: `pytracking.tracker.dimp.DiMP.initialize()` + `track()` exactly as the reference ships them, with
+`pytracking/parameter/dimp/dimp50.py`'s settings (cadences shortened so that a short sequence reaches every branch), on
+a random-init `dimpnet50` built by the reference's own constructor (no checkpoints exist offline).  Only what
+BASELINE.json's north_star leaves on stock PyTorch is stubbed: the ResNet-50 backbone and the IoU-feature convolutions
+return seeded synthetic feature maps (`StubBackbone`), so the same inputs can be regenerated on the GPU box, where
+neither the reference nor torchvision exists.
+
+The recorder wraps the boundary callables ON THE INSTANCES (nothing in the reference tree is edited) and appends one
+event per call:  head (classification-feature head), get_filter (initialiser + 10 SD iterations), classify, localize,
+refine (IoU-guided box refinement), memory (slot written), optimize (filter_optimizer update).  tests/tracker_replay.py
+replays the event list through any implementation of those ops with the solver state (filter, sample memory, head
+outputs) carried forward closed-loop and the tracker's own glue (positions, scales, schedules) taken from the log.
+"""
+import math
+import os
+import sys
+from collections import OrderedDict
+
+import numpy as np
+import torch
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+ROOT = os.path.dirname(HERE)
+if ROOT not in sys.path:
+    sys.path.insert(0, ROOT)
+
+from oracle import ref_harness  # noqa: E402
+from pytracking_amd import synth  # noqa: E402
+
+
+class StubBackbone:
+    """Seeded stand-in for the stock-PyTorch parts in front of the hot path.  Call k of `backbone(n)` returns the maps
+    drawn from `default_rng(seed + k)`; `iou_feat(n)` likewise with its own counter."""
+
+    def __init__(self, seed, dims):
+        self.seed, self.d = int(seed), dict(dims)
+        self.k_backbone = 0
+        self.k_iou = 0
+
+    def backbone(self, n):
+        out = synth.tracker_backbone(self.seed + self.k_backbone, n, self.d)
+        self.k_backbone += 1
+        return OrderedDict((k, torch.from_numpy(v)) for k, v in out.items())
+
+    def iou_feat(self, n):
+        out = synth.tracker_iou_feat(self.seed + 5000 + self.k_iou, n, self.d)
+        self.k_iou += 1
+        return [torch.from_numpy(v) for v in out]
+
+
+class Recorder:
+    def __init__(self):
+        self.events = []
+
+    def add(self, kind, **kw):
+        ev = {"kind": kind}
+        for k, v in kw.items():
+            if isinstance(v, torch.Tensor):
+                v = v.detach().cpu().numpy().copy()
+            ev[k] = v
+        self.events.append(ev)
+
+    def to_npz_dict(self):
+        out = {"n_events": len(self.events)}
+        for i, ev in enumerate(self.events):
+            for k, v in ev.items():
+                out[f"e{i}_{k}"] = np.asarray(v)
+        return out
+
+
+DIMP50_TEST = dict(C_backbone=1024, C_layer2=512, C=512, H=18, W=18, H2=36, W2=36, C_iou=256, K=4, base_seed=31, noise=0.3)
+# the committed run: 10 frames; the not-found threshold is lowered to the score level a random-init network reaches
+DIMP_RUN = dict(seed=4100, n_frames=10, dims=DIMP50_TEST, thresholds=dict(target_not_found_threshold=0.1))
+
+
+def seed_dimp_net(net, seed, dims):
+    """Overwrite the hot-path parameters of a reference `dimpnet50` with the seeded values of pytracking_amd/synth.py
+    (the same generators rebuild them on the GPU box)."""
+    p = synth.tracker_dimp_params(seed, dims)
+    with torch.no_grad():
+        net.classifier.feature_extractor[0].weight.copy_(torch.from_numpy(p["head.weight"]))
+        net.classifier.filter_initializer.filter_conv.weight.copy_(torch.from_numpy(p["init.weight"]))
+        net.classifier.filter_initializer.filter_conv.bias.copy_(torch.from_numpy(p["init.bias"]))
+        sd = net.bb_regressor.state_dict()
+        for k, v in p.items():
+            if k.startswith("iou."):
+                sd[k[4:]].copy_(torch.from_numpy(v))
+    return p
+
+
+def build_dimp50(seed, dims=DIMP50_TEST):
+    """Random-init network by the reference's constructor with the deployed hyper-parameters
+    (ltr/train_settings/dimp/dimp50.py:91-95), hot-path weights seeded."""
+    ref_harness.install()
+    import ltr.models.tracking.dimpnet as dimpnet
+    torch.manual_seed(seed)
+    net = dimpnet.dimpnet50(filter_size=4, backbone_pretrained=False, optim_iter=5, clf_feat_norm=True,
+                            clf_feat_blocks=0, final_conv=True, out_feature_dim=dims["C"], optim_init_step=0.9,
+                            optim_init_reg=0.1, init_gauss_sigma=0.9, num_dist_bins=100, bin_displacement=0.1,
+                            mask_init_factor=3.0, target_mask_act='sigmoid', score_act='relu')
+    net.eval()
+    seed_dimp_net(net, seed, dims)
+    return net
+
+
+class NetStub:
+    """What `params.net` has to be for the tracker (pytracking/features/net_wrappers.py:NetWithBackbone): attribute
+    access falls through to the network; `initialize()` would load a checkpoint from disk -- there is none offline."""
+
+    def __init__(self, net, stub: StubBackbone):
+        self.net, self._stub = net, stub
+
+    def initialize(self, *a, **k):
+        pass
+
+    def extract_backbone(self, im):
+        return self._stub.backbone(im.shape[0])
+
+    def __getattr__(self, name):
+        return getattr(self.__dict__["net"], name)
+
+
+def dimp50_params(net_stub):
+    """pytracking/parameter/dimp/dimp50.py with the cadences shortened (train_skipping 20 -> 2) and the
+    cv2-only / random augmentations dropped (rotate needs OpenCV; dropout draws from torch's global RNG)."""
+    from pytracking.utils import TrackerParams
+    p = TrackerParams()
+    p.debug = 0
+    p.visualization = False
+    p.use_gpu = False
+    p.device = "cpu"
+    p.image_sample_size = 18 * 16
+    p.search_area_scale = 5
+    p.sample_memory_size = 50
+    p.learning_rate = 0.01
+    p.init_samples_minimum_weight = 0.25
+    p.train_skipping = 2
+    p.update_classifier = True
+    p.net_opt_iter = 10
+    p.net_opt_update_iter = 2
+    p.net_opt_hn_iter = 1
+    p.window_output = False
+    p.use_augmentation = True
+    p.augmentation = {'fliplr': True, 'blur': [(3, 1), (1, 3), (2, 2)],
+                      'relativeshift': [(0.6, 0.6), (-0.6, 0.6), (0.6, -0.6), (-0.6, -0.6)]}
+    p.augmentation_expansion_factor = 2
+    p.random_shift_factor = 1 / 3
+    p.advanced_localization = True
+    p.target_not_found_threshold = 0.25
+    p.distractor_threshold = 0.8
+    p.hard_negative_threshold = 0.5
+    p.target_neighborhood_scale = 2.2
+    p.dispalcement_scale = 0.8
+    p.hard_negative_learning_rate = 0.02
+    p.update_scale_when_uncertain = True
+    p.iounet_augmentation = False
+    p.iounet_use_log_scale = True
+    p.iounet_k = 3
+    p.num_init_random_boxes = 9
+    p.box_jitter_pos = 0.1
+    p.box_jitter_sz = 0.5
+    p.maximal_aspect_ratio = 6
+    p.box_refinement_iter = 5
+    p.box_refinement_step_length = 1
+    p.box_refinement_step_decay = 1
+    p.net = net_stub
+    p.vot_anno_conversion_type = 'preserve_area'
+    return p
+
+
+def synthetic_frame(rng, hw=(360, 480)):
+    return rng.integers(0, 256, size=(hw[0], hw[1], 3), dtype=np.uint8)
+
+
+def run_dimp(seed=4100, n_frames=6, dims=DIMP50_TEST, record=True, score_gain=None, thresholds=None):
+    """initialize() + n_frames x track() of the reference DiMP on a stubbed backbone.  Returns (outputs, recorder)."""
+    ref_harness.install()
+    from pytracking.tracker.dimp.dimp import DiMP
+    net = build_dimp50(seed, dims)
+    stub = StubBackbone(seed, dims)
+    ns = NetStub(net, stub)
+    params = dimp50_params(ns)
+    if thresholds:
+        for k, v in thresholds.items():
+            setattr(params, k, v)
+    tracker = DiMP(params)
+    tracker.visdom = None
+    rec = Recorder()
+    bbreg = net.bb_regressor
+    bbreg.get_iou_feat = lambda feats: stub.iou_feat(feats[0].shape[0])      # stock convs: stubbed like the backbone
+
+    if record:
+        rec.add("config", seed=seed, n_frames=n_frames, memory_size=params.sample_memory_size,
+                **{f"dim_{k}": v for k, v in dims.items()},
+                **{k: getattr(params, k) for k in ("target_not_found_threshold", "distractor_threshold", "hard_negative_threshold",
+                                                   "target_neighborhood_scale", "dispalcement_scale", "box_refinement_iter",
+                                                   "box_refinement_step_length", "box_refinement_step_decay")})
+        # ---- head
+        orig_head = tracker.get_classification_features
+
+        def head(backbone_feat):
+            out = orig_head(backbone_feat)
+            rec.add("head", n=out.shape[0], checksum=float(out.double().abs().sum()))
+            return out
+        tracker.get_classification_features = head
+        # ---- initial filter
+        clf = net.classifier
+        orig_get_filter = clf.get_filter
+
+        def get_filter(feat, bb, *a, **kw):
+            w, its, losses = orig_get_filter(feat, bb, *a, **kw)
+            rec.add("get_filter", bb=bb, num_iter=kw.get("num_iter"), filter=w, n=feat.shape[0])
+            return w, its, losses
+        clf.get_filter = get_filter
+        # ---- filter_optimizer on update frames
+        opt = clf.filter_optimizer
+        orig_fwd = opt.forward
+        state = {"in_get_filter": False}
+
+        def opt_forward(weights, *a, **kw):
+            out = orig_fwd(weights, *a, **kw)
+            if "sample_weight" in kw and kw.get("sample_weight") is not None:      # update call (dimp.py:633-639)
+                rec.add("optimize", bb=kw["bb"], sw=kw["sample_weight"], num_iter=kw["num_iter"], n=kw["feat"].shape[0],
+                        filter=out[0])
+            return out
+        opt.forward = opt_forward
+        # ---- classify
+        orig_cls = tracker.classify_target
+
+        def classify(x):
+            s = orig_cls(x)
+            rec.add("classify", scores=s)
+            return s
+        tracker.classify_target = classify
+        # ---- localisation
+        orig_loc = tracker.localize_advanced
+
+        def localize(scores, sample_pos, sample_scales):
+            st = dict(target_sz=tracker.target_sz.clone(), pos=tracker.pos.clone(), kernel_size=tracker.kernel_size.clone(),
+                      img_support_sz=tracker.img_support_sz.clone())
+            tv, scale_ind, s, flag = orig_loc(scores, sample_pos, sample_scales)
+            rec.add("localize", sample_pos=sample_pos, sample_scales=sample_scales, tv=tv, scale_ind=int(scale_ind),
+                    flag=flag, **st)
+            return tv, scale_ind, s, flag
+        tracker.localize_advanced = localize
+        # ---- IoU refinement
+        for name in ("optimize_boxes_default", "optimize_boxes_relative"):
+            orig = getattr(tracker, name)
+
+            def refine(iou_features, init_boxes, _orig=orig, _name=name):
+                b, iou = _orig(iou_features, init_boxes)
+                rec.add("refine", method=_name, init_boxes=init_boxes, boxes=b, iou=iou,
+                        mod3=tracker.iou_modulation[0], mod4=tracker.iou_modulation[1])
+                return b, iou
+            setattr(tracker, name, refine)
+        # ---- memory
+        orig_mem = tracker.update_memory
+
+        def update_memory(sample_x, target_box, learning_rate=None):
+            orig_mem(sample_x, target_box, learning_rate)
+            rec.add("memory", slot=int(tracker.previous_replace_ind[0]), stored=int(tracker.num_stored_samples[0]))
+        tracker.update_memory = update_memory
+
+    rng = np.random.default_rng(seed + 77)
+    torch.manual_seed(seed)                                    # the tracker draws proposal jitter from torch's RNG
+    outs = []
+    box = [200.0, 140.0, 70.0, 90.0]
+    tracker.initialize(synthetic_frame(rng), {"init_bbox": box})
+    opt_mod = net.classifier.filter_optimizer
+    if record:
+        rec.add("optimizer_params", log_step_length=opt_mod.log_step_length.detach(), filter_reg=opt_mod.filter_reg.detach(),
+                min_filter_reg=float(opt_mod.min_filter_reg), label_lut=opt_mod.label_map_predictor.weight.detach().reshape(-1),
+                mask_lut=opt_mod.target_mask_predictor[0].weight.detach().reshape(-1),
+                spatial_lut=opt_mod.spatial_weight_predictor.weight.detach().reshape(-1))
+    for _ in range(n_frames):
+        if record:
+            rec.add("frame", frame=tracker.frame_num + 1)
+        out = tracker.track(synthetic_frame(rng))
+        outs.append(np.array(out["target_bbox"], dtype=np.float64))
+        if record:
+            rec.add("state", target_bbox=outs[-1], flag=str(tracker.debug_info.get("flag", "")))
+    return np.stack(outs), rec, (tracker, net)
+
+
+class RefOps:
+    """The replay ops (tests/tracker_replay.py) served by the REFERENCE's own modules on CPU: replaying a log through
+    them must reproduce it bit for bit, which validates the log and the player before the gfx950 path is judged by them."""
+
+    def __init__(self, net, tracker):
+        self.net, self.tracker = net, tracker
+
+    def to_numpy(self, t):
+        return t.detach().cpu().numpy() if isinstance(t, torch.Tensor) else np.asarray(t)
+
+    def head(self, l3):
+        with torch.no_grad():
+            return self.net.classifier.extract_classification_feat(torch.from_numpy(l3))
+
+    def get_filter(self, feat, bb, num_iter):
+        from ltr.models.target_classifier.linear_filter import LinearFilter
+        with torch.no_grad():
+            return LinearFilter.get_filter(self.net.classifier, feat, torch.from_numpy(bb), num_iter=num_iter,
+                                           compute_losses=False)[0]
+
+    def set_optimizer_params(self, ev):
+        pass
+
+    def new_memory(self, size, head):
+        mem = head.new_zeros(size, *head.shape[1:])
+        mem[:head.shape[0]] = head
+        return mem
+
+    def store(self, mem, slot, head):
+        mem[slot:slot + 1] = head
+
+    def memory_view(self, mem, n):
+        return mem[:n]
+
+    def optimize(self, filt, feat, bb, sw, num_iter):
+        with torch.no_grad():
+            return type(self.net.classifier.filter_optimizer).forward(
+                self.net.classifier.filter_optimizer, filt, num_iter=num_iter, feat=feat, bb=torch.from_numpy(bb),
+                sample_weight=torch.from_numpy(sw), compute_losses=False)[0]
+
+    def classify(self, filt, feat):
+        with torch.no_grad():
+            return self.net.classifier.classify(filt, feat)
+
+    def localize(self, scores, ev, cfg):
+        import types
+        from pytracking.tracker.dimp.dimp import DiMP
+        me = types.SimpleNamespace(params=self.tracker.params, kernel_size=torch.from_numpy(ev["kernel_size"]),
+                                   output_window=None, img_support_sz=torch.from_numpy(ev["img_support_sz"]),
+                                   target_sz=torch.from_numpy(ev["target_sz"]), pos=torch.from_numpy(ev["pos"]))
+        tv, scale_ind, _, flag = DiMP.localize_advanced(me, scores.squeeze(1).clone(), torch.from_numpy(ev["sample_pos"]),
+                                                        torch.from_numpy(ev["sample_scales"]))
+        return tv, scale_ind, flag
+
+    def refine(self, method, feats, mods, init_boxes, cfg):
+        import types
+        from pytracking.tracker.dimp.dimp import DiMP
+        me = types.SimpleNamespace(params=self.tracker.params, net=self.net,
+                                   iou_modulation=[torch.from_numpy(m) for m in mods])
+        return getattr(DiMP, method)(me, [torch.from_numpy(f) for f in feats], torch.from_numpy(init_boxes))

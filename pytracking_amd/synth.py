@@ -280,3 +280,40 @@ def atom_gn_problem(seed, n=30, M=256, Kc=64, H=18, W=18, K=4, cfg=ATOM18):
     f0 = np.zeros((Kc, K, K), np.float32)
     P0 = rng.standard_normal((Kc, M), dtype=np.float32) * np.float32(1.0 / math.sqrt(M))
     return f0, P0, samples, y, sw
+
+
+# ------------------------------------------------------------------------------------------------------
+# Tracker-level replay (tests/tracker_replay.py): what stays on stock PyTorch in front of the hot path is synthetic
+# ------------------------------------------------------------------------------------------------------
+def tracker_backbone(seed, n, dims):
+    """Backbone feature maps of `n` image patches: {'layer2': (n,C_layer2,H2,W2), 'layer3': (n,C_backbone,H,W)}.
+    Every patch shows the sequence's appearance pattern (drawn from dims['base_seed'], the same in every call) plus
+    per-call noise, so that a filter learnt on the first frame finds the target again in the later ones."""
+    base = np.random.default_rng(dims.get("base_seed", 0))
+    b3 = base.standard_normal((1, dims["C_backbone"], dims["H"], dims["W"]), dtype=np.float32)
+    b2 = base.standard_normal((1, dims["C_layer2"], dims["H2"], dims["W2"]), dtype=np.float32)
+    rng = np.random.default_rng(seed)
+    sg = np.float32(dims.get("noise", 1.0))
+    l3 = b3 + sg * rng.standard_normal((n, dims["C_backbone"], dims["H"], dims["W"]), dtype=np.float32)
+    l2 = b2 + sg * rng.standard_normal((n, dims["C_layer2"], dims["H2"], dims["W2"]), dtype=np.float32)
+    return {"layer2": l2, "layer3": l3}
+
+
+def tracker_iou_feat(seed, n, dims):
+    """IoU features of the test frame (the output of `AtomIoUNet.get_iou_feat`, stock convolutions)."""
+    rng = np.random.default_rng(seed)
+    return (rng.standard_normal((n, dims["C_iou"], dims["H2"], dims["W2"]), dtype=np.float32),
+            rng.standard_normal((n, dims["C_iou"], dims["H"], dims["W"]), dtype=np.float32))
+
+
+def tracker_dimp_params(seed, dims):
+    """Seeded hot-path weights of a DiMP network: classification-feature head conv ('head.weight'), the filter
+    initialiser's conv ('init.weight', 'init.bias') and the IoU predictor's test branch ('iou.*', synth.iou_net_params)."""
+    rng = np.random.default_rng(seed + 900)
+    C, Cb = dims["C"], dims["C_backbone"]
+    p = {"head.weight": rng.standard_normal((C, Cb, 3, 3), dtype=np.float32) * np.float32(math.sqrt(2.0 / (9 * C))),
+         "init.weight": rng.standard_normal((C, C, 3, 3), dtype=np.float32) * np.float32(math.sqrt(2.0 / (9 * C))),
+         "init.bias": rng.standard_normal(C, dtype=np.float32) * np.float32(0.01)}
+    for k, v in iou_net_params(seed + 901, dict(C=dims["C_iou"], I=dims["C_iou"])).items():
+        p["iou." + k] = v
+    return p

@@ -1,0 +1,84 @@
+"""Trajectory-level integration parity: an UNMODIFIED reference tracker -- `pytracking.tracker.dimp.DiMP`
+`initialize()` + 10 x `track()` on a random-init dimpnet50 with the stock-PyTorch parts stubbed by seeded features --
+was run on CPU by oracle/tracker_harness.py and every call across the hot-path boundary recorded
+(tests/golden/tracker_dimp50.npz).
+
+  * CPU, reference mounted:  the log replays bit-exactly through the reference's own modules (validates log + player);
+    the same tracker with `pytracking_amd.install()` active produces the same trajectory (everything off the hot path
+    falls back to the reference: "trackers run unchanged after install()").
+  * GPU:  the log replays through the gfx950 modules in the tracker's call order, solver state (filter, memory, head
+    features) carried closed-loop over all frames, every score map / filter / refined box within 1e-4.
+"""
+import numpy as np
+import pytest
+
+from conftest import load_golden
+import tracker_replay as TR
+
+
+def _events():
+    return TR.events_from_npz(load_golden("tracker_dimp50"))
+
+
+def test_log_covers_every_boundary_call():
+    evs = _events()
+    kinds = [e["kind"] for e in evs]
+    for k in ("head", "get_filter", "classify", "localize", "refine", "memory", "optimize", "state"):
+        assert k in kinds, k
+    flags = {str(e["flag"]) for e in evs if e["kind"] == "localize"}
+    assert {"normal", "hard_negative"} <= flags
+    iters = {int(e["num_iter"]) for e in evs if e["kind"] == "optimize"}
+    assert iters == {1, 2}                                       # hard-negative update and the regular cadence
+    assert int(evs[0]["n_frames"]) == 10 and sum(k == "classify" for k in kinds) == 10
+
+
+def _need_reference():
+    from oracle import ref_harness
+    if not ref_harness.available():
+        pytest.skip("reference tree not mounted")
+
+
+def test_reference_modules_replay_the_log_exactly():
+    _need_reference()
+    from oracle import tracker_harness as TH
+    net = TH.build_dimp50(TH.DIMP_RUN["seed"], TH.DIMP_RUN["dims"])
+    tracker = type("T", (), {})()
+    tracker.params = TH.dimp50_params(None)
+    for k, v in TH.DIMP_RUN["thresholds"].items():
+        setattr(tracker.params, k, v)
+    dev = TR.replay(_events(), TH.RefOps(net, tracker), exact=True)
+    assert set(dev) == {"get_filter", "classify", "localize", "refine_iou", "refine_boxes", "optimize"}
+
+
+def test_reference_tracker_runs_unchanged_after_install():
+    """install() must be transparent for an unmodified tracker whose tensors are off the hot path (CPU): same boxes,
+    same flags, same score maps as the recorded run, through the rebound classes / functions / methods."""
+    _need_reference()
+    from oracle import tracker_harness as TH
+    from pytracking_amd import install as amd
+    TH.ref_harness.install()
+    amd.install()
+    try:
+        outs, rec, (tracker, net) = TH.run_dimp(**TH.DIMP_RUN)
+        from pytracking_amd import optimizer as OM
+        assert isinstance(net.classifier.filter_optimizer, OM.DiMPSteepestDescentGN)     # the rebound class was built
+    finally:
+        amd.uninstall()
+    want = _events()
+    got = rec.events
+    assert [e["kind"] for e in got] == [e["kind"] for e in want]
+    for a, b in zip(got, want):
+        for k in ("scores", "filter", "boxes", "iou", "target_bbox", "tv"):
+            if k in b:
+                np.testing.assert_allclose(np.asarray(a[k], dtype=np.float64), np.asarray(b[k], dtype=np.float64), atol=1e-6,
+                                           err_msg=f"{a['kind']}.{k}")
+        if "flag" in b:
+            assert str(a["flag"]) == str(b["flag"])
+
+
+@pytest.mark.gpu
+def test_gfx950_modules_replay_the_tracker_log():
+    evs = _events()
+    dev = TR.replay(evs, TR.MirrorOps(evs, "cuda"), atol=1e-4)
+    assert set(dev) == {"get_filter", "classify", "localize", "refine_iou", "refine_boxes", "optimize"}
+    print("max deviation per boundary call over the 10-frame trajectory:", {k: f"{v:.2e}" for k, v in dev.items()})

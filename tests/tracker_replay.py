@@ -1,0 +1,215 @@
+"""TEST INFRASTRUCTURE -- replay the boundary-call log of an unmodified reference tracker run (oracle/tracker_harness.py)
+through an implementation of the hot-path ops, in the tracker's own call order.
+
+Closed loop on the solver state: the filter, the sample memory and the classification features come from the
+implementation under test and are carried from call to call exactly as the tracker carries them
+(dimp.py:410-441 init_memory / update_memory, :536-648 init_classifier / update_classifier).  The tracker's glue --
+positions, scales, proposal jitter, schedules -- is taken from the log.  What stays on stock PyTorch in front of the
+path (backbone, IoU-feature convolutions) is regenerated from the seeds of pytracking_amd/synth.py.
+
+`ops` supplies: head(l3) -> (n,C,H,W); get_filter(feat, bb, num_iter) -> (1,C,K,K); optimize(filt, feat, bb, sw, num_iter);
+classify(filt, feat) -> (1,1,O,O); localize(scores (S,O,O), ev, cfg) -> (tv, scale_ind, flag);
+refine(method, (c3, c4), (mod3, mod4), init_boxes, cfg) -> (boxes, iou); to_numpy(t).
+"""
+import numpy as np
+
+from pytracking_amd import synth
+
+
+def events_from_npz(g):
+    n = int(g["n_events"])
+    evs = [dict() for _ in range(n)]
+    for key, v in g.items():
+        if key.startswith("e") and "_" in key and key[1:key.index("_")].isdigit():
+            i = int(key[1:key.index("_")])
+            evs[i][key[key.index("_") + 1:]] = v
+    for ev in evs:
+        ev["kind"] = str(ev["kind"])
+    return evs
+
+
+def replay(events, ops, atol=1e-4, exact=False):
+    """Walk the log; returns a dict of the maximum deviation per event kind.  `exact`: demand bit equality (the ops ARE
+    the reference's own modules: validates the log and this player)."""
+    cfg = events[0]
+    assert cfg["kind"] == "config"
+    dims = {k[4:]: (int(v) if float(v).is_integer() else float(v)) for k, v in cfg.items() if k.startswith("dim_")}
+    seed = int(cfg["seed"])
+    k_backbone = k_iou = 0
+    head = filt = memory = None
+    scores = None
+    dev = {}
+
+    def check(kind, got, want, tol=None):
+        got, want = np.asarray(ops.to_numpy(got), dtype=np.float64), np.asarray(want, dtype=np.float64)
+        assert got.shape == want.shape, (kind, got.shape, want.shape)
+        err = float(np.abs(got - want).max()) if got.size else 0.0
+        dev[kind] = max(dev.get(kind, 0.0), err)
+        if exact:
+            assert err == 0.0, (kind, err)
+        else:
+            assert err <= (atol if tol is None else tol), (kind, err)
+
+    for ev in events[1:]:
+        kind = ev["kind"]
+        if kind == "head":
+            n = int(ev["n"])
+            l3 = synth.tracker_backbone(seed + k_backbone, n, dims)["layer3"]
+            k_backbone += 1
+            head = ops.head(l3)
+            got = float(np.abs(np.asarray(ops.to_numpy(head), dtype=np.float64)).sum())
+            assert abs(got - float(ev["checksum"])) <= 1e-5 * float(ev["checksum"]), ("head", got, float(ev["checksum"]))
+        elif kind == "get_filter":
+            filt = ops.get_filter(head, ev["bb"], int(ev["num_iter"]))
+            check("get_filter", filt, ev["filter"])
+            memory = ops.new_memory(int(cfg["memory_size"]), head)
+        elif kind == "optimizer_params":
+            ops.set_optimizer_params(ev)
+        elif kind == "classify":
+            scores = ops.classify(filt, head)
+            check("classify", scores, ev["scores"])
+        elif kind == "localize":
+            tv, scale_ind, flag = ops.localize(scores, ev, cfg)
+            assert flag == str(ev["flag"]) and int(scale_ind) == int(ev["scale_ind"]), (flag, str(ev["flag"]))
+            check("localize", tv, ev["tv"], tol=1e-3)
+        elif kind == "refine":
+            c3, c4 = synth.tracker_iou_feat(seed + 5000 + k_iou, 1, dims)
+            k_iou += 1
+            boxes, iou = ops.refine(str(ev["method"]), (c3, c4), (ev["mod3"], ev["mod4"]), ev["init_boxes"], cfg)
+            check("refine_iou", iou, ev["iou"])
+            check("refine_boxes", boxes, ev["boxes"], tol=None if exact else 2e-4)
+        elif kind == "memory":
+            ops.store(memory, int(ev["slot"]), head)
+        elif kind == "optimize":
+            filt = ops.optimize(filt, ops.memory_view(memory, int(ev["n"])), ev["bb"], ev["sw"], int(ev["num_iter"]))
+            check("optimize", filt, ev["filter"])
+    return dev
+
+
+class MirrorOps:
+    """The ops served by the gfx950 path: the modules `pytracking_amd.install()` binds under the reference's names, built
+    here directly (the GPU box has no reference tree) with the seeded weights of synth.tracker_dimp_params."""
+
+    def __init__(self, events, device="cuda"):
+        import math
+        import types
+        import torch
+        from pytracking_amd import features, optimizer
+        from pytracking_amd.prroi_pool import PrRoIPool2D
+        self.torch, self.types, self.dev = torch, types, torch.device(device)
+        cfg = events[0]
+        self.dims = dims = {k[4:]: (int(v) if float(v).is_integer() else float(v)) for k, v in cfg.items() if k.startswith("dim_")}
+        p = synth.tracker_dimp_params(int(cfg["seed"]), dims)
+        C, K = dims["C"], dims["K"]
+        self.K = K
+        T = lambda a: torch.from_numpy(np.ascontiguousarray(a)).to(self.dev)
+        self.T = T
+        # classification-feature head as dimpnet50 builds it (dimpnet.py:159-172)
+        self.head_mod = features.residual_bottleneck(feature_dim=dims["C_backbone"] // 4, num_blocks=0, l2norm=True,
+                                                     final_conv=True, norm_scale=math.sqrt(1.0 / (C * K * K)), out_dim=C)
+        self.head_mod.load_state_dict({"0.weight": torch.from_numpy(p["head.weight"])}, strict=True)
+        self.head_mod.to(self.dev).eval()
+        self.init_w, self.init_b = T(p["init.weight"]), T(p["init.bias"])
+        self.pool = PrRoIPool2D(K, K, 1 / 16)
+        self.opt = optimizer.DiMPSteepestDescentGN(num_iter=5, feat_stride=16, init_step_length=0.9, init_filter_reg=0.1,
+                                                   init_gauss_sigma=0.9, num_dist_bins=100, bin_displacement=0.1,
+                                                   mask_init_factor=3.0, score_act='relu', mask_act='sigmoid').to(self.dev).eval()
+        self.iou_params = {k[4:]: v for k, v in p.items() if k.startswith("iou.")}
+        self.iou_net = None
+
+    def to_numpy(self, t):
+        return t.detach().cpu().numpy() if isinstance(t, self.torch.Tensor) else np.asarray(t)
+
+    def head(self, l3):
+        with self.torch.no_grad():
+            return self.head_mod(self.T(l3))
+
+    def set_optimizer_params(self, ev):
+        sd = self.opt.state_dict()
+        sd["log_step_length"] = self.T(ev["log_step_length"])
+        sd["filter_reg"] = self.T(ev["filter_reg"])
+        sd["label_map_predictor.weight"] = self.T(ev["label_lut"]).reshape(1, -1, 1, 1)
+        sd["target_mask_predictor.0.weight"] = self.T(ev["mask_lut"]).reshape(1, -1, 1, 1)
+        sd["spatial_weight_predictor.weight"] = self.T(ev["spatial_lut"]).reshape(1, -1, 1, 1)
+        self.opt.load_state_dict(sd, strict=True)
+        self.opt.min_filter_reg = float(ev["min_filter_reg"])
+
+    def get_filter(self, feat, bb, num_iter):
+        """LinearFilter.get_filter (linear_filter.py:82-103): FilterInitializerLinear (conv -> PrRoIPool(K,K,1/16) -> mean
+        over the images, initializer.py:21-45,151-173) followed by the filter optimiser."""
+        torch = self.torch
+        bb = self.T(bb)
+        n = feat.shape[0]
+        with torch.no_grad():
+            conv = torch.nn.functional.conv2d(feat, self.init_w, self.init_b, padding=1)
+            rois = torch.cat((torch.arange(n, dtype=torch.float32, device=self.dev).reshape(-1, 1), bb[:, :2],
+                              bb[:, :2] + bb[:, 2:]), dim=1)
+            w0 = self.pool(conv, rois).mean(dim=0, keepdim=True)
+            return self.opt(w0, feat=feat, bb=bb, num_iter=num_iter, compute_losses=False)[0]
+
+    def new_memory(self, size, head):
+        mem = head.new_zeros(size, *head.shape[1:])
+        mem[:head.shape[0]] = head
+        return mem
+
+    def store(self, mem, slot, head):
+        mem[slot:slot + 1] = head
+
+    def memory_view(self, mem, n):
+        return mem[:n]
+
+    def optimize(self, filt, feat, bb, sw, num_iter):
+        with self.torch.no_grad():
+            return self.opt(filt, num_iter=num_iter, feat=feat, bb=self.T(bb), sample_weight=self.T(sw),
+                            compute_losses=False)[0]
+
+    def classify(self, filt, feat):
+        from pytracking_amd import filter as F
+        return F.apply_filter(feat, filt)
+
+    class _Params:
+        def __init__(self, **kw):
+            self.__dict__.update(kw)
+
+        def get(self, name, default=None):
+            return getattr(self, name, default)
+
+    def _params(self, cfg):
+        return self._Params(**{k: float(cfg[k]) for k in ("target_not_found_threshold", "distractor_threshold",
+                                                           "hard_negative_threshold", "target_neighborhood_scale",
+                                                           "dispalcement_scale", "box_refinement_step_length",
+                                                           "box_refinement_step_decay")},
+                            box_refinement_iter=int(cfg["box_refinement_iter"]))
+
+    def localize(self, scores, ev, cfg):
+        from pytracking_amd import localization as LM
+        torch = self.torch
+        me = self.types.SimpleNamespace(params=self._params(cfg), kernel_size=torch.from_numpy(ev["kernel_size"]),
+                                        output_window=None, img_support_sz=torch.from_numpy(ev["img_support_sz"]),
+                                        target_sz=torch.from_numpy(ev["target_sz"]), pos=torch.from_numpy(ev["pos"]))
+        tv, scale_ind, _, flag = LM.localize_advanced(me, scores.squeeze(1), torch.from_numpy(ev["sample_pos"]),
+                                                      torch.from_numpy(ev["sample_scales"]))
+        return tv, scale_ind, flag
+
+    def refine(self, method, feats, mods, init_boxes, cfg):
+        from pytracking_amd import iou_refine as IR
+        torch = self.torch
+        if self.iou_net is None:
+            C = self.dims["C_iou"]
+
+            class Net(torch.nn.Module):
+                def __init__(net):
+                    super().__init__()
+                    for name, k in (("fc3_rt", 5), ("fc4_rt", 3)):
+                        blk = torch.nn.Module()
+                        blk.linear, blk.bn, blk.relu = torch.nn.Linear(C * k * k, C), torch.nn.BatchNorm2d(C), torch.nn.ReLU()
+                        setattr(net, name, blk)
+                    net.iou_predictor = torch.nn.Linear(2 * C, 1)
+                    net.prroi_pool3t = self.types.SimpleNamespace(pooled_height=5, pooled_width=5, spatial_scale=1 / 8)
+                    net.prroi_pool4t = self.types.SimpleNamespace(pooled_height=3, pooled_width=3, spatial_scale=1 / 16)
+            net = Net()
+            net.load_state_dict({k: torch.from_numpy(v.copy()) for k, v in self.iou_params.items()}, strict=False)
+            self.iou_net = net.to(self.dev).eval()
+        me = self.types.SimpleNamespace(params=self._params(cfg), net=self.types.SimpleNamespace(bb_regressor=self.iou_net),
+                                        iou_modulation=[self.T(m) for m in mods])
+        return getattr(IR, method)(me, [self.T(f) for f in feats], torch.from_numpy(np.ascontiguousarray(init_boxes)))
