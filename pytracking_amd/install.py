@@ -13,6 +13,8 @@ What gets rebound (import path = contract; nothing in the reference tree is edit
                                                                                       -> pytracking_amd.prroi_pool
   pytracking.libs.optimization.ConjugateGradient  (ConvProblem + MLU fast path)       -> pytracking_amd.optimization
   pytracking.libs.optimization.GaussNewtonCG      (FactorizedConvProblem fast path)   -> pytracking_amd.optimization
+  pytracking.libs.operation.conv2d                (mode='same', one output channel: ATOM's per-frame classification)
+                                                                                      -> pytracking_amd.filter.corr_raw
   ltr.models.lwl.loss_residual_modules.LWTLResidual, ltr.models.meta.steepestdescent.GNSteepestDescent
                                                   (LWL few-shot learner)              -> pytracking_amd.steepestdescent
   ltr.models.transformer.transformer.Transformer, ltr.models.transformer.filter_predictor.FilterPredictor,
@@ -319,6 +321,41 @@ def _install_iou_refine(orig, strict):
         setattr(cls, name, method)
 
 
+def _install_operation(orig, strict):
+    """`pytracking.libs.operation.conv2d` (operation.py:6-33; TensorList-lifted): ATOM classifies every frame with
+    `operation.conv2d(sample_x, self.filter, mode='same')` (atom.py:300-302).  A single-output-channel 'same'
+    correlation on device tensors goes to the gfx950 correlation pass; every other use (full inner products of
+    optim.py:58-99, 1x1 projections, autograd) keeps the reference's function."""
+    try:
+        omod = importlib.import_module("pytracking.libs.operation")
+        tl = importlib.import_module("pytracking.libs.tensorlist")
+    except Exception:
+        return
+    ref_conv2d = omod.conv2d
+    ref_single = getattr(ref_conv2d, "__wrapped__", None)     # functools.wraps keeps the un-lifted function
+    if ref_single is None:
+        return
+    orig["operation"] = ref_conv2d
+
+    def conv2d(input, weight, bias=None, stride=1, padding=0, dilation=1, groups=1, mode=None):
+        fused = (weight is not None and mode == 'same' and bias is None and stride == 1 and dilation == 1 and groups == 1
+                 and padding == 0 and isinstance(input, torch.Tensor) and input.is_cuda and input.dtype == torch.float32
+                 and input.dim() == 4 and weight.dim() == 4 and weight.shape[0] == 1 and weight.shape[1] == input.shape[1]
+                 and weight.shape[2] * weight.shape[3] <= 16 and weight.is_cuda
+                 and not (torch.is_grad_enabled() and (input.requires_grad or weight.requires_grad)))
+        if fused:
+            return _filter.corr_raw(input, weight[0], out_hw=tuple(input.shape[-2:])).unsqueeze(1)
+        if strict and isinstance(input, torch.Tensor) and input.is_cuda and mode == 'same':
+            raise NotImplementedError("operation.conv2d(mode='same'): configuration outside the gfx950 hot path")
+        return ref_single(input, weight, bias=bias, stride=stride, padding=padding, dilation=dilation, groups=groups,
+                          mode=mode)
+
+    conv2d.__doc__ = ref_single.__doc__
+    lifted = tl.tensor_operation(conv2d)
+    lifted.__wrapped_reference__ = ref_conv2d
+    omod.conv2d = lifted
+
+
 def install(strict=False, atom_cg=True, tomp=True, clf_head=True, localization=True, iou_refine=True):
     """Rebind the boundary symbols.  Call after the reference is importable (`sys.path`) and before networks or
     trackers are constructed.  Idempotent."""
@@ -447,6 +484,7 @@ def install(strict=False, atom_cg=True, tomp=True, clf_head=True, localization=T
 
             pmod.ConjugateGradient = ConjugateGradient
             pmod.GaussNewtonCG = GaussNewtonCG
+            _install_operation(orig, strict)
             tmod = sys.modules.get("pytracking.tracker.atom.atom")
             if tmod is not None and hasattr(tmod, "ConjugateGradient"):
                 tmod.ConjugateGradient = ConjugateGradient
@@ -468,6 +506,8 @@ def uninstall():
         importlib.import_module("pytracking.libs.optimization").ConjugateGradient = orig["cg"]
     if "gn" in orig:
         importlib.import_module("pytracking.libs.optimization").GaussNewtonCG = orig["gn"]
+    if "operation" in orig:
+        importlib.import_module("pytracking.libs.operation").conv2d = orig["operation"]
     if "tomp" in orig:
         importlib.import_module("ltr.models.transformer.transformer").Transformer = orig["tomp"][0]
         importlib.import_module("ltr.models.transformer.filter_predictor").FilterPredictor = orig["tomp"][1]

@@ -66,8 +66,22 @@ def _solve(params: _lib.SdParams, weights, feat, bb, sample_weight, num_iter, co
     return weight_iterates[-1], weight_iterates, loss_list
 
 
+def _host_scalar(mod, name):
+    """Host value of a one-element parameter, re-read from the device only when the tensor changed (the trackers
+    overwrite `filter_reg[0]` in place, dimp.py:598-600 -- that bumps `_version`): no device->host synchronisation on
+    the per-frame path."""
+    t = getattr(mod, name)
+    key = (t.data_ptr(), t._version)
+    cache = mod.__dict__.setdefault("_host_scalars", {})
+    hit = cache.get(name)
+    if hit is None or hit[0] != key:
+        hit = (key, float(t.detach().reshape(-1)[0]))
+        cache[name] = hit
+    return hit[1]
+
+
 def _reg_value(mod):
-    fr = float(mod.filter_reg.detach().reshape(-1)[0])
+    fr = _host_scalar(mod, "filter_reg")
     return max(fr * fr, float(mod.min_filter_reg) ** 2)           # optimizer.py:109
 
 
@@ -110,7 +124,7 @@ class DiMPSteepestDescentGN(nn.Module):
                 (self.label_map_predictor, self.target_mask_predictor[0], self.spatial_weight_predictor)]
         p = _lib.SdParams()
         p.kind = _lib.PT_SD_DIMP
-        p.step_length = math.exp(float(self.log_step_length.detach().reshape(-1)[0]))
+        p.step_length = math.exp(_host_scalar(self, "log_step_length"))
         p.reg = _reg_value(self)
         p.alpha_eps = float(self.alpha_eps)
         p.feat_stride = float(self.feat_stride)
@@ -139,7 +153,7 @@ class DiMPL2SteepestDescentGN(nn.Module):
         num_iter = self.num_iter if num_iter is None else num_iter
         p = _lib.SdParams()
         p.kind = _lib.PT_SD_DIMP_L2
-        p.step_length = math.exp(float(self.log_step_length.detach().reshape(-1)[0]))
+        p.step_length = math.exp(_host_scalar(self, "log_step_length"))
         p.reg = _reg_value(self)
         p.alpha_eps = float(self.alpha_eps)
         p.feat_stride = float(self.feat_stride)
@@ -168,7 +182,7 @@ class PrDiMPSteepestDescentNewton(nn.Module):
         num_iter = self.num_iter if num_iter is None else num_iter
         p = _lib.SdParams()
         p.kind = _lib.PT_SD_PRDIMP
-        p.step_length = math.exp(float(self.log_step_length.detach().reshape(-1)[0]))
+        p.step_length = math.exp(_host_scalar(self, "log_step_length"))
         p.reg = _reg_value(self)
         p.alpha_eps = float(self.alpha_eps)
         p.feat_stride = float(self.feat_stride)

@@ -99,7 +99,8 @@ class GNSteepestDescent(nn.Module):
         w_in = weights.detach().contiguous()
         iters = torch.empty((S, num_iter + 1, Fn, C, K, K), dtype=torch.float32, device=feat.device)
         losses = torch.zeros((S, num_iter + 1), dtype=torch.float32, device=feat.device) if self.compute_losses else None
-        lam = float(res.filter_reg.detach().reshape(-1)[0])
+        from .optimizer import _host_scalar
+        lam = _host_scalar(res, "filter_reg")
         keep = []
         for s in range(S):
             fs = f5[:, s]

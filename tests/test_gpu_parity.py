@@ -91,6 +91,12 @@ def test_apply_filter_same_crop_and_autograd_pair():
     filt = rng.standard_normal((16, 4, 4), dtype=np.float32)
     s = F.corr_raw(T(feat), T(filt), out_hw=(18, 18))                     # operation.conv2d(mode='same')
     close(s, O.apply_filter(feat.astype(np.float64), filt.astype(np.float64), out_hw=(18, 18)), atol=1e-4)
+    # ATOM's per-frame classification shape (atom.py:300-302): 64 compressed channels, 4x4 filter, 'same' crop; equals
+    # stock F.conv2d(padding=2)[..., :-1, :-1] (operation.py:17-32)
+    x = T(rng.standard_normal((1, 64, 18, 18), dtype=np.float32))
+    w = T(rng.standard_normal((1, 64, 4, 4), dtype=np.float32) * 0.05)
+    want = torch.nn.functional.conv2d(x, w, padding=2)[:, :, :-1, :-1]
+    close(F.corr_raw(x, w[0], out_hw=(18, 18)).unsqueeze(1), want.cpu().numpy(), atol=2e-5)
     # autograd: d/dfilter <apply_filter(feat, filter), r> = apply_feat_transpose(feat, r)
     w = T(filt[None]).requires_grad_(True)
     r = T(rng.standard_normal((4, 1, 19, 19), dtype=np.float32))
@@ -871,3 +877,29 @@ def test_iou_refinement_deployed_size_golden(tag):
     close(iou, g[f"{tag}_iou"], atol=1e-4)
     close(b, g[f"{tag}_boxes"], atol=1e-4)
     assert float(np.abs(g[f"{tag}_boxes"] - boxes).max()) > 2.0
+
+
+def test_track_frame_is_deterministic_under_repeated_launches():
+    """The pointwise solver stages ride on the correlation launches (last-arriver hand-off between workgroups, agent-scope
+    release / acquire): 300 frames from identical state must give bit-identical filters, scores and boxes every time --
+    a stale read of another workgroup's partial score map would show up as a differing bit pattern."""
+    from pytracking_amd import bench_frame
+    cfg = synth.DIMP50
+    st = bench_frame.TrackState(cfg, 50, seed=321, device=DEV)
+    rng = np.random.default_rng(322)
+    x = T(synth.clf_features(rng, 1, cfg["C"], cfg["H"], cfg["W"], cfg["K"])[0])
+    f0, m0, b0 = st.filter.clone(), st.mem_feat.clone(), st.mem_bb.clone()
+    ref = None
+    junk = torch.empty(64 << 20, dtype=torch.uint8, device=DEV)
+    for rep in range(300):
+        st.filter.copy_(f0); st.mem_feat.copy_(m0); st.mem_bb.copy_(b0)
+        if rep % 3 == 0:
+            junk.fill_(rep & 255)                                   # uneven load / cache churn between the frames
+        st.step(x, slot=rep % 50 if rep % 2 else 7, num_iter=5)
+        if rep % 2 == 0:                                            # same slot -> same result
+            out = (st.filter.clone(), st.scores.clone(), st.mem_bb.clone())
+            if ref is None:
+                ref = out
+            else:
+                assert all(torch.equal(a, b) for a, b in zip(out, ref)), rep
+    torch.cuda.synchronize()

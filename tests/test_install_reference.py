@@ -204,3 +204,25 @@ def test_installed_optimizers_fall_back_to_the_reference_forward_off_the_hot_pat
         assert not isinstance(cg, OM.ConjugateGradient) and isinstance(cg, amd._state["originals"]["cg"])
     finally:
         amd.uninstall()
+
+
+def test_operation_conv2d_rebinding():
+    """`pytracking.libs.operation.conv2d` stays TensorList-lifted and numerically the reference's for everything off the
+    hot path (CPU tensors here); the device route is checked in tests/test_gpu_parity.py."""
+    ref_harness.install()
+    import pytracking.libs.operation as op
+    from pytracking import TensorList
+    from pytracking_amd import install as amd
+    ref = op.conv2d
+    x, w = torch.randn(3, 8, 9, 9), torch.randn(1, 8, 4, 4)
+    want_same, want_valid = ref(x, w, mode='same'), ref(x, w)
+    amd.install()
+    try:
+        assert op.conv2d is not ref
+        assert torch.equal(op.conv2d(x, w, mode='same'), want_same) and torch.equal(op.conv2d(x, w), want_valid)
+        out = op.conv2d(TensorList([x, x]), TensorList([w, w]), mode='same')
+        assert isinstance(out, TensorList) and torch.equal(out[1], want_same)
+        assert op.conv2d(x, None) is x
+    finally:
+        amd.uninstall()
+    assert op.conv2d is ref
