@@ -312,6 +312,20 @@ int pt_track_frame_f32(const pt_sd_params* p, float* filter, float* mem_feat, fl
                        float* scores_out, float* peak_out, void* ws, size_t ws_bytes, void* stream);
 
 /* ------------------------------------------------------------------------------------------------
+ * Image-patch sampling in front of the backbone.
+ * Replaces: pytracking/features/preprocessing.py:54-148 `sample_patch` (strided pre-downsampling, crop with replicate
+ * padding, F.interpolate(mode='bilinear')) and :33-51 `sample_patch_multiscale` (S scales in one launch).
+ *   im   (C, H, W) float image on the device;   out (S, C, OH, OW)
+ *   geom one record per scale, the integers the reference computes on the host (preprocessing.py:83-128):
+ *        df = pre-downsampling stride, (os0, os1) = its row / column offset, (tl0, tl1) = top-left corner of the crop in
+ *        the down-sampled image (may be negative / beyond the border: replicate padding), crop_h x crop_w = crop size.
+ * ---------------------------------------------------------------------------------------------- */
+#define PT_PATCH_MAX_SCALES 8
+typedef struct pt_patch_geom { int df, os0, os1, tl0, tl1, crop_h, crop_w; } pt_patch_geom;
+int pt_sample_patch_f32(const float* im, int C, int H, int W, const pt_patch_geom* geom, int S, float* out, int OH, int OW,
+                        void* stream);
+
+/* ------------------------------------------------------------------------------------------------
  * Measurement entry (bench.py roofline leg; not part of the reference's API).  Re-issues ONE feature pass of the
  * solve that pt_track_frame_f32 last ran on `ws` -- the launch of its last iteration, same kernel instantiation and
  * operands -- `reps` times back to back on `stream`, so that the caller can bracket the run with ONE HIP event pair

@@ -639,6 +639,31 @@ def gen_branches():
              fletcher_reeves=int(fr), forget=forget)
 
 
+def gen_patches():
+    """`sample_patch` / `sample_patch_multiscale` of the unmodified reference (preprocessing.py:33-148) on synthetic images:
+    every border mode, pre-downsampling factors 1..3, crops hanging over each border, up- and down-sampling."""
+    from pytracking.features.preprocessing import sample_patch, sample_patch_multiscale
+    rng = np.random.default_rng(151)
+    im = T(rng.integers(0, 256, size=(1, 3, 70, 90)).astype(np.float32))
+    out = {"im": im.numpy()}
+    cases = []
+    k = 0
+    for mode, msc in (("replicate", None), ("inside", None), ("inside_major", 1.5), ("inside", 1.2)):
+        for pos, ssz, osz in (((35.3, 44.8), (40.0, 40.0), (32, 32)), ((3.0, 5.0), (60.0, 50.0), (24, 24)),
+                              ((66.7, 88.2), (100.0, 120.0), (32, 32)), ((30.0, 40.0), (14.0, 14.0), (32, 32)),
+                              ((20.5, 70.0), (200.0, 260.0), (24, 32)), ((34.0, 45.0), (97.0, 131.0), (32, 32))):
+            p, c = sample_patch(im, torch.Tensor(pos), torch.Tensor(ssz), torch.Tensor(osz), mode=mode, max_scale_change=msc)
+            out.update({f"c{k}_pos": np.array(pos, np.float32), f"c{k}_ssz": np.array(ssz, np.float32),
+                        f"c{k}_osz": np.array(osz, np.int64), f"c{k}_mode": mode, f"c{k}_msc": -1.0 if msc is None else msc,
+                        f"c{k}_patch": p.numpy(), f"c{k}_coord": c.numpy()})
+            k += 1
+    out["n"] = k
+    ps, cs = sample_patch_multiscale(im, torch.Tensor([33.0, 47.0]), torch.Tensor([0.8, 1.0, 1.9]), torch.Tensor([32.0, 32.0]))
+    out.update(ms_pos=np.array([33.0, 47.0], np.float32), ms_scales=np.array([0.8, 1.0, 1.9], np.float32), ms_patches=ps.numpy(),
+               ms_coords=cs.numpy())
+    save("sample_patch", **out)
+
+
 def gen_trackers():
     """Trajectory-level vectors: the unmodified reference DiMP tracker (initialize + 10 x track) on a stubbed backbone,
     every boundary call recorded (oracle/tracker_harness.py)."""
@@ -650,7 +675,7 @@ def gen_trackers():
 if __name__ == "__main__":
     torch.set_num_threads(8)
     which = sys.argv[1:] or ["filter", "dimp", "l2", "prdimp", "atom", "prroi", "lwl", "atomgn", "tomp", "head", "localize", "iou",
-                             "branches", "ioufull", "atomgnfull", "lwlfull", "trackers"]
+                             "branches", "ioufull", "atomgnfull", "lwlfull", "trackers", "patches"]
     if "tomp" in which:
         gen_tomp()
     if "head" in which:
@@ -685,3 +710,5 @@ if __name__ == "__main__":
         gen_lwl_full()
     if "trackers" in which:
         gen_trackers()
+    if "patches" in which:
+        gen_patches()

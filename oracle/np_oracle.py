@@ -650,3 +650,33 @@ def two_peaks(scores, scores_hn, neigh):
     masked[top:bottom, left:right] = 0
     m2, (r2, c2) = max2d(masked)
     return np.array([m1, r1, c1, s1, m2, r2, c2, 0], dtype=np.float64)
+
+
+# --------------------------------------------------------------------------------------------
+# image-patch sampling (pytracking/features/preprocessing.py:54-148), pixel part
+# --------------------------------------------------------------------------------------------
+def sample_patch_pixels(im, df, os0, os1, tl0, tl1, crop_h, crop_w, out_hw):
+    """Strided view `im[..., os0::df, os1::df]`, crop [tl, tl + crop) with replicate padding, bilinear resize with
+    `F.interpolate(mode='bilinear', align_corners=False)` semantics (ATen: scale = in / out in float32,
+    src = scale * (dst + 0.5) - 0.5 clamped at 0, blend of the two column blends).  im (C,H,W) float32 -> (C,oh,ow)."""
+    f32 = np.float32
+    im2 = im[:, os0::df, os1::df]
+    H2, W2 = im2.shape[1:]
+    rows = np.clip(tl0 + np.arange(crop_h), 0, H2 - 1)
+    cols = np.clip(tl1 + np.arange(crop_w), 0, W2 - 1)
+    patch = im2[:, rows][:, :, cols].astype(f32)
+    oh, ow = out_hw
+
+    def axis(n_in, n_out):
+        scale = f32(n_in) / f32(n_out)
+        src = scale * (np.arange(n_out, dtype=f32) + f32(0.5)) - f32(0.5)
+        src = np.maximum(src, f32(0))
+        i0 = src.astype(np.int64)
+        i1 = i0 + (i0 < n_in - 1)
+        l1 = np.clip(src - i0.astype(f32), f32(0), f32(1)).astype(f32)
+        return i0, i1, (f32(1) - l1).astype(f32), l1
+    y0, y1, ly0, ly1 = axis(crop_h, oh)
+    x0, x1, lx0, lx1 = axis(crop_w, ow)
+    top = patch[:, y0][:, :, x0] * lx0 + patch[:, y0][:, :, x1] * lx1
+    bot = patch[:, y1][:, :, x0] * lx0 + patch[:, y1][:, :, x1] * lx1
+    return (top * ly0[None, :, None] + bot * ly1[None, :, None]).astype(f32)

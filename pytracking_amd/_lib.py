@@ -9,7 +9,7 @@ import subprocess
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.environ.get("PT_HOT_LIB", os.path.join(_HERE, "libpt_hot.so"))   # override: experiments only
-SOURCES = ["filter_kernels.hip", "fast_passes.hip", "sd_solver.hip", "mf_kernels.hip", "lwl_solver.hip", "atom_cg.hip", "atom_gn.hip", "tomp.hip", "localize.hip", "iou_refine.hip", "prroi.hip", "api.hip"]
+SOURCES = ["filter_kernels.hip", "fast_passes.hip", "sd_solver.hip", "mf_kernels.hip", "lwl_solver.hip", "atom_cg.hip", "atom_gn.hip", "tomp.hip", "localize.hip", "iou_refine.hip", "prroi.hip", "patch.hip", "api.hip"]
 HEADERS = ["common.h", "pt_internal.h", "rbuild.h", "sd_common.h", "mfma_gemm.h", os.path.join("..", "..", "include", "pt_hot.h")]
 
 PT_SD_DIMP, PT_SD_DIMP_L2, PT_SD_PRDIMP = 0, 1, 2
@@ -19,6 +19,11 @@ PT_MASK_SIGMOID, PT_MASK_LINEAR = 0, 1
 class IouDims(ctypes.Structure):
     """`pt_iou_dims` of include/pt_hot.h."""
     _fields_ = [(n, ctypes.c_int) for n in ("C3", "C4", "I3", "I4", "H3", "W3", "H4", "W4")]
+
+
+class PatchGeom(ctypes.Structure):
+    """`pt_patch_geom` of include/pt_hot.h."""
+    _fields_ = [(n, ctypes.c_int) for n in ("df", "os0", "os1", "tl0", "tl1", "crop_h", "crop_w")]
 
 
 class TompDims(ctypes.Structure):
@@ -40,7 +45,7 @@ EXPORTS = [
     "pt_tomp_bbreg_param_floats", "pt_tomp_bbreg_ws_bytes", "pt_tomp_bbreg_f32",
     "pt_clf_head_ws_bytes", "pt_clf_head_f32", "pt_max2d_f32", "pt_localize_f32",
     "pt_iou_param_floats", "pt_iou_prepared_floats", "pt_iou_prepare_f32", "pt_iou_refine_ws_bytes", "pt_iou_refine_f32",
-    "pt_track_frame_replay_pass_f32",
+    "pt_track_frame_replay_pass_f32", "pt_sample_patch_f32",
 ]
 
 
@@ -183,6 +188,8 @@ def lib():
     L.pt_iou_refine_f32.argtypes = [ip, vp, vp, vp, vp, vp, vp, vp, vp, vp, i, i, fp, f, i, i, vp, sz, vp]
     L.pt_track_frame_replay_pass_f32.restype = i
     L.pt_track_frame_replay_pass_f32.argtypes = [ctypes.POINTER(SdParams), vp, vp, vp, vp] + [i] * 6 + [vp, sz, i, i, vp]
+    L.pt_sample_patch_f32.restype = i
+    L.pt_sample_patch_f32.argtypes = [vp, i, i, i, ctypes.POINTER(PatchGeom), i, vp, i, i, vp]
     _lib = L
     return L
 

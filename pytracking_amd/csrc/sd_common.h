@@ -183,18 +183,8 @@ __device__ __forceinline__ void act_pair(int score_act, float bpar, float x, flo
 }
 
 
-__device__ __forceinline__ float sd_alpha_step(const SdArgs& a) {
-    // optimizer.py:155-160 / :425-430: alpha = |g|^2 / max(sum_i q_i + (reg+eps)|g|^2, 1e-8), times the step length
-    float den = 0.f;
-    for (int k = 0; k < a.n; ++k) den += a.qs[k];
-    float a_num = 0.f;
-    for (int k = 0; k < a.KS; ++k) a_num += a.anum[k];
-    den = fmaxf(den + (a.reg + a.alpha_eps) * a_num, 1e-8f);
-    return a.step * (a_num / den);
-}
-
-
-// The same quantity from one wave (every lane gets it): wave-parallel fixed-order sums, identical in every workgroup.
+// optimizer.py:155-160 / :425-430: alpha = |g|^2 / max(sum_i q_i + (reg+eps)|g|^2, 1e-8), times the step length;
+// from one wave (every lane gets it): wave-parallel fixed-order sums, identical in every workgroup.
 __device__ __forceinline__ float sd_alpha_step_wave(const SdArgs& a, int lane) {
     float den = 0.f;
     for (int k = lane; k < a.n; k += 64) den += a.qs[k];

@@ -99,7 +99,7 @@ __global__ __launch_bounds__(512) void k_sd_pw(SdArgs a, int stage, int t, int l
 
     float astep = 0.f;
     if (stage == PW_UPDATE) {
-        astep = sd_alpha_step(a);
+        astep = sd_alpha_step_wave(a, threadIdx.x & 63);       // wave-parallel, the same fixed order as the k_adj2 prologue
         // this workgroup's slice of the filter update  w_t = w_{t-1} - step*alpha*g   (:160)
         const int chunk = (a.CKK + a.n - 1) / a.n;
         const float* wp = sd_w(a, t - 1);

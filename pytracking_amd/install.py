@@ -15,6 +15,8 @@ What gets rebound (import path = contract; nothing in the reference tree is edit
   pytracking.libs.optimization.GaussNewtonCG      (FactorizedConvProblem fast path)   -> pytracking_amd.optimization
   pytracking.libs.operation.conv2d                (mode='same', one output channel: ATOM's per-frame classification)
                                                                                       -> pytracking_amd.filter.corr_raw
+  pytracking.features.preprocessing.sample_patch / sample_patch_multiscale (device images)
+                                                                                      -> pytracking_amd.preprocessing
   ltr.models.lwl.loss_residual_modules.LWTLResidual, ltr.models.meta.steepestdescent.GNSteepestDescent
                                                   (LWL few-shot learner)              -> pytracking_amd.steepestdescent
   ltr.models.transformer.transformer.Transformer, ltr.models.transformer.filter_predictor.FilterPredictor,
@@ -136,22 +138,45 @@ def _optimizer_class(fused_cls, ref_cls, strict):
     return Dispatching
 
 
-def provide_prroi_module():
+def provide_prroi_module(orig=None):
     """Create `ltr.external.PreciseRoIPooling.pytorch.prroi_pool` (an empty git submodule in the reference) in
     sys.modules so that `from ltr.external.PreciseRoIPooling.pytorch.prroi_pool import PrRoIPool2D`
-    (initializer.py:4, atom_iou_net.py:4) resolves to the HIP implementation."""
+    (initializer.py:4, atom_iou_net.py:4) resolves to the HIP implementation.  If an implementation was already
+    registered under that name (a CPU stand-in in a test harness), CPU tensors keep going to it; modules that imported
+    the class by name before this call are re-pointed."""
     for pkg in ("ltr.external", "ltr.external.PreciseRoIPooling", "ltr.external.PreciseRoIPooling.pytorch"):
         if pkg not in sys.modules:
             m = types.ModuleType(pkg)
             m.__path__ = []
             sys.modules[pkg] = m
     name = "ltr.external.PreciseRoIPooling.pytorch.prroi_pool"
+    prev = sys.modules.get(name)
+    prev_cls = getattr(prev, "PrRoIPool2D", None)
+
+    class PrRoIPool2D(_prroi.PrRoIPool2D):
+        __doc__ = _prroi.PrRoIPool2D.__doc__
+
+        def forward(self, features, rois):
+            if features.is_cuda or prev_cls is None:
+                return _prroi.PrRoIPool2D.forward(self, features, rois)
+            return prev_cls(self.pooled_height, self.pooled_width, self.spatial_scale)(features, rois)
+
     pm = types.ModuleType(name)
-    pm.PrRoIPool2D = _prroi.PrRoIPool2D
+    pm.PrRoIPool2D = PrRoIPool2D
     pm.prroi_pool2d = _prroi.prroi_pool2d
     sys.modules[name] = pm
     parent = sys.modules["ltr.external.PreciseRoIPooling.pytorch"]
+    prev_attr = getattr(parent, "prroi_pool", None)
     parent.prroi_pool = pm
+    importers = []
+    if prev_cls is not None:
+        for modname in ("ltr.models.target_classifier.initializer", "ltr.models.bbreg.atom_iou_net"):
+            mod = sys.modules.get(modname)
+            if mod is not None and getattr(mod, "PrRoIPool2D", None) is prev_cls:
+                mod.PrRoIPool2D = PrRoIPool2D
+                importers.append((mod, prev_cls))
+    if orig is not None:
+        orig["prroi"] = (name, prev, prev_attr, importers)
     return pm
 
 
@@ -356,12 +381,58 @@ def _install_operation(orig, strict):
     omod.conv2d = lifted
 
 
-def install(strict=False, atom_cg=True, tomp=True, clf_head=True, localization=True, iou_refine=True):
+def _install_preprocessing(orig, strict):
+    """`sample_patch` / `sample_patch_multiscale` (pytracking/features/preprocessing.py:33-148): for an image tensor that
+    lives on the device, crop + replicate padding + bilinear resize become one gather launch.  The reference trackers
+    build the image with `numpy_to_torch` on the CPU, so this route is taken when the caller uploads the frame first;
+    CPU images, masks and the first-frame augmentation set keep the reference's functions."""
+    from . import preprocessing as _pp
+    try:
+        pmod = importlib.import_module("pytracking.features.preprocessing")
+    except Exception:
+        return
+    ref_sp, ref_ms = pmod.sample_patch, pmod.sample_patch_multiscale
+    orig["preprocessing"] = {"functions": (ref_sp, ref_ms), "importers": []}
+
+    def sample_patch(im, pos, sample_sz, output_sz=None, mode='replicate', max_scale_change=None, is_mask=False):
+        if im.is_cuda and im.dtype == torch.float32 and not is_mask and im.dim() == 4 and im.shape[0] == 1:
+            return _pp.sample_patch(im, pos, sample_sz, output_sz, mode=mode, max_scale_change=max_scale_change)
+        if strict and im.is_cuda:
+            raise NotImplementedError("sample_patch: call outside the gfx950 hot path")
+        return ref_sp(im, pos, sample_sz, output_sz, mode=mode, max_scale_change=max_scale_change, is_mask=is_mask)
+
+    def sample_patch_multiscale(im, pos, scales, image_sz, mode='replicate', max_scale_change=None):
+        n = 1 if isinstance(scales, (int, float)) else len(scales)
+        if im.is_cuda and im.dtype == torch.float32 and im.dim() == 4 and im.shape[0] == 1 and n <= 8:
+            return _pp.sample_patch_multiscale(im, pos, scales, image_sz, mode=mode, max_scale_change=max_scale_change)
+        if strict and im.is_cuda:
+            raise NotImplementedError("sample_patch_multiscale: call outside the gfx950 hot path")
+        return ref_ms(im, pos, scales, image_sz, mode=mode, max_scale_change=max_scale_change)
+
+    for fn, ref in ((sample_patch, ref_sp), (sample_patch_multiscale, ref_ms)):
+        fn.__doc__, fn.__wrapped__ = ref.__doc__, ref
+    pmod.sample_patch, pmod.sample_patch_multiscale = sample_patch, sample_patch_multiscale
+    # the trackers import the names (`from pytracking.features.preprocessing import sample_patch_multiscale, ...`)
+    for modname in ("pytracking.tracker.dimp.dimp", "pytracking.tracker.atom.atom", "pytracking.tracker.tomp.tomp",
+                    "pytracking.tracker.kys.kys", "pytracking.tracker.lwl.lwl"):
+        tmod = sys.modules.get(modname)
+        if tmod is None:
+            try:
+                tmod = importlib.import_module(modname)
+            except Exception:
+                continue
+        for name, fn, ref in (("sample_patch", sample_patch, ref_sp), ("sample_patch_multiscale", sample_patch_multiscale, ref_ms)):
+            if getattr(tmod, name, None) is ref:
+                setattr(tmod, name, fn)
+                orig["preprocessing"]["importers"].append((tmod, name, ref))
+
+
+def install(strict=False, atom_cg=True, tomp=True, clf_head=True, localization=True, iou_refine=True, preprocessing=True):
     """Rebind the boundary symbols.  Call after the reference is importable (`sys.path`) and before networks or
     trackers are constructed.  Idempotent."""
     if _state["installed"]:
         return
-    provide_prroi_module()                                        # must precede `import ltr.models...`
+    provide_prroi_module(_state["originals"])                     # must precede `import ltr.models...`
     fmod = importlib.import_module("ltr.models.layers.filter")
     omod = importlib.import_module("ltr.models.target_classifier.optimizer")
     orig = _state["originals"]
@@ -435,6 +506,8 @@ def install(strict=False, atom_cg=True, tomp=True, clf_head=True, localization=T
         _install_localization(orig, strict)
     if iou_refine:
         _install_iou_refine(orig, strict)
+    if preprocessing:
+        _install_preprocessing(orig, strict)
     if atom_cg:
         try:
             pmod = importlib.import_module("pytracking.libs.optimization")
@@ -524,6 +597,21 @@ def uninstall():
                 importlib.import_module("pytracking.libs.dcf").max2d = ref
             else:
                 getattr(importlib.import_module(key[0]), key[1]).localize_advanced = ref
+    if "prroi" in orig:
+        name, prev, prev_attr, importers = orig["prroi"]
+        if prev is not None:
+            sys.modules[name] = prev
+        else:
+            sys.modules.pop(name, None)
+        if prev_attr is not None:
+            sys.modules["ltr.external.PreciseRoIPooling.pytorch"].prroi_pool = prev_attr
+        for mod, cls in importers:
+            mod.PrRoIPool2D = cls
+    if "preprocessing" in orig:
+        pm = importlib.import_module("pytracking.features.preprocessing")
+        pm.sample_patch, pm.sample_patch_multiscale = orig["preprocessing"]["functions"]
+        for tmod, name, ref in orig["preprocessing"]["importers"]:
+            setattr(tmod, name, ref)
     if "lwl" in orig:
         importlib.import_module("ltr.models.lwl.loss_residual_modules").LWTLResidual = orig["lwl"][0]
         importlib.import_module("ltr.models.meta.steepestdescent").GNSteepestDescent = orig["lwl"][1]

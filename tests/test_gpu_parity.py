@@ -903,3 +903,38 @@ def test_track_frame_is_deterministic_under_repeated_launches():
             else:
                 assert all(torch.equal(a, b) for a, b in zip(out, ref)), rep
     torch.cuda.synchronize()
+
+
+# ------------------------------------------------------------------------------------------------------
+# image-patch sampling on the device
+# ------------------------------------------------------------------------------------------------------
+def test_sample_patch_golden():
+    """pt_sample_patch_f32 behind the mirrored `sample_patch` / `sample_patch_multiscale` against 24 + 3 reference runs
+    (preprocessing.py:33-148): border modes replicate / inside / inside_major, pre-downsampling strides 1..8, crops
+    over every border.  Pixels are 0..255: 1e-3 is two float32 evaluations of the same bilinear weights apart (the
+    reference's float32 result is itself 5e-4 from its float64 result here); the coordinates are exact."""
+    from pytracking_amd import preprocessing as PP
+    g = load_golden("sample_patch")
+    im = T(g["im"])
+    exact = 0
+    for k in range(int(g["n"])):
+        msc = float(g[f"c{k}_msc"])
+        patch, coord = PP.sample_patch(im, torch.from_numpy(g[f"c{k}_pos"]), torch.from_numpy(g[f"c{k}_ssz"]),
+                                       torch.from_numpy(g[f"c{k}_osz"]).float(), mode=str(g[f"c{k}_mode"]),
+                                       max_scale_change=None if msc < 0 else msc)
+        assert patch.shape == g[f"c{k}_patch"].shape
+        np.testing.assert_array_equal(coord.numpy(), g[f"c{k}_coord"])
+        close(patch, g[f"c{k}_patch"], atol=1e-3)
+        exact += int(np.array_equal(patch.cpu().numpy(), g[f"c{k}_patch"]))
+    assert exact >= 12                                                   # most cases are bit-identical
+    ps, cs = PP.sample_patch_multiscale(im, torch.from_numpy(g["ms_pos"]), torch.from_numpy(g["ms_scales"]),
+                                        torch.Tensor([32.0, 32.0]))
+    np.testing.assert_array_equal(cs.numpy(), g["ms_coords"])
+    close(ps, g["ms_patches"], atol=1e-3)
+    ref = O.sample_patch_pixels(g["im"][0], 1, 0, 0, 5, 7, 20, 30, (20, 30))  # no resize: an exact copy of the crop
+    geom = PP._lib.PatchGeom(1, 0, 0, 5, 7, 20, 30)
+    out = torch.empty(1, 3, 20, 30, device=DEV)
+    from pytracking_amd.filter import _ptr, _stream
+    PP._lib.check(PP._lib.lib().pt_sample_patch_f32(_ptr(im), 3, 70, 90, (PP._lib.PatchGeom * 1)(geom), 1, _ptr(out), 20, 30,
+                                                    _stream()), "pt_sample_patch_f32")
+    assert np.array_equal(out[0].cpu().numpy(), ref) and np.array_equal(ref, g["im"][0][:, 5:25, 7:37])

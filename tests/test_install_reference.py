@@ -23,7 +23,7 @@ def test_install_rebinds_boundary_symbols_and_restores():
         assert opt.DiMPSteepestDescentGN.__name__ == "DiMPSteepestDescentGN"
         assert fl.apply_filter is not orig_apply and fl.apply_filter.__wrapped__ is orig_apply
         from ltr.external.PreciseRoIPooling.pytorch.prroi_pool import PrRoIPool2D
-        assert PrRoIPool2D is prroi_pool.PrRoIPool2D
+        assert issubclass(PrRoIPool2D, prroi_pool.PrRoIPool2D)
         # CPU tensors are outside the hot path: the dispatcher hands them to the reference's own function
         feat, filt = torch.randn(2, 1, 8, 6, 6), torch.randn(1, 8, 4, 4)
         torch.testing.assert_close(fl.apply_filter(feat, filt), orig_apply(feat, filt))
@@ -226,3 +226,22 @@ def test_operation_conv2d_rebinding():
     finally:
         amd.uninstall()
     assert op.conv2d is ref
+
+
+def test_preprocessing_install_dispatch():
+    """CPU images keep the reference's `sample_patch`; the names imported by the tracker modules are rebound and restored."""
+    ref_harness.install()
+    import pytracking.features.preprocessing as pp
+    import pytracking.tracker.dimp.dimp as dimp_mod
+    from pytracking_amd import install as amd
+    ref_sp, ref_ms = pp.sample_patch, pp.sample_patch_multiscale
+    im = torch.rand(1, 3, 40, 50) * 255
+    want, wc = ref_ms(im, torch.Tensor([20.0, 25.0]), torch.Tensor([1.0, 1.5]), torch.Tensor([16.0, 16.0]))
+    amd.install()
+    try:
+        assert pp.sample_patch.__wrapped__ is ref_sp and dimp_mod.sample_patch_multiscale is pp.sample_patch_multiscale
+        got, gc = dimp_mod.sample_patch_multiscale(im, torch.Tensor([20.0, 25.0]), torch.Tensor([1.0, 1.5]), torch.Tensor([16.0, 16.0]))
+        assert torch.equal(got, want) and torch.equal(gc, wc)
+    finally:
+        amd.uninstall()
+    assert pp.sample_patch is ref_sp and dimp_mod.sample_patch_multiscale is ref_ms

@@ -3,7 +3,8 @@
 was run on CPU by oracle/tracker_harness.py and every call across the hot-path boundary recorded
 (tests/golden/tracker_dimp50.npz).
 
-  * CPU, reference mounted:  the log replays bit-exactly through the reference's own modules (validates log + player);
+  * CPU, reference mounted:  the log replays through the reference's own modules to float32 summation order (validates
+    log + player; bit-exact at the recording's thread count);
     the same tracker with `pytracking_amd.install()` active produces the same trajectory (everything off the hot path
     falls back to the reference: "trackers run unchanged after install()").
   * GPU:  the log replays through the gfx950 modules in the tracker's call order, solver state (filter, memory, head
@@ -38,7 +39,9 @@ def _need_reference():
         pytest.skip("reference tree not mounted")
 
 
-def test_reference_modules_replay_the_log_exactly():
+def test_reference_modules_replay_the_log():
+    """Bit-exact when the CPU thread count equals the recording's (oneDNN partitions its sums by thread); 5e-6 covers
+    any other partitioning.  Flags and scale indices must match exactly either way."""
     _need_reference()
     from oracle import tracker_harness as TH
     net = TH.build_dimp50(TH.DIMP_RUN["seed"], TH.DIMP_RUN["dims"])
@@ -46,7 +49,7 @@ def test_reference_modules_replay_the_log_exactly():
     tracker.params = TH.dimp50_params(None)
     for k, v in TH.DIMP_RUN["thresholds"].items():
         setattr(tracker.params, k, v)
-    dev = TR.replay(_events(), TH.RefOps(net, tracker), exact=True)
+    dev = TR.replay(_events(), TH.RefOps(net, tracker), atol=5e-6)
     assert set(dev) == {"get_filter", "classify", "localize", "refine_iou", "refine_boxes", "optimize"}
 
 
