@@ -195,6 +195,37 @@ def roofline(st, stream, cfg, cfg_name, n):
             "all_kernels_us_per_frame": None if not stats else round(sum(c * a for c, a in stats.values()) / 1e3 / (PROF_FRAMES + PROF_WARMUP), 2)}
 
 
+def head_inclusive(cfg, n, dev, stream, frames=200):
+    """Second number: the same frame with the classification-feature head (conv 1024 -> C, 3x3,
+    InstanceL2Norm) in front, its output written straight into the memory slot (pt_track_frame_head_f32); hipGraph of 25
+    frames replayed.  The ResNet-50 backbone is stock PyTorch and not part of either number."""
+    st = bench_frame.TrackState(cfg, n, seed=777, device=dev)
+    rng = np.random.default_rng(778)
+    w = torch.from_numpy(rng.standard_normal((cfg["C"], 1024, 3, 3), dtype=np.float32) * np.float32(0.02)).to(dev)
+    st.attach_head(w, math.sqrt(1.0 / (cfg["C"] * cfg["K"] ** 2)))
+    xb = torch.from_numpy(rng.standard_normal((8, 1024, cfg["H"], cfg["W"]), dtype=np.float32)).to(dev)
+    G = 25
+    with torch.cuda.stream(stream):
+        for f in range(2):
+            st.step_from_backbone(xb[f % 8], f % n, NUM_ITER)
+        stream.synchronize()
+        g = torch.cuda.CUDAGraph()
+        with torch.cuda.graph(g, stream=stream):
+            for f in range(G):
+                st.step_from_backbone(xb[f % 8], f % n, NUM_ITER)
+        g.replay()
+        stream.synchronize()
+        t0 = time.perf_counter()
+        for _ in range(frames // G):
+            g.replay()
+        stream.synchronize()
+        dt = time.perf_counter() - t0
+    fr = (frames // G) * G
+    return {"value": round(fr / dt, 2), "unit": "frames/s", "us_per_frame": round(1e6 * dt / fr, 2),
+            "what": "classification-feature head (1024->%d, 3x3, InstanceL2Norm) writing the memory slot + the frame above; "
+                    "hipGraph replay, 25 frames per graph" % cfg["C"]}
+
+
 def free_port():
     with socket.socket() as s:
         s.bind(("127.0.0.1", 0))
@@ -324,6 +355,8 @@ def main():
                        "sequences_per_gpu": 1, "launch": launch, "parallelism": f"{world} independent sequences"},
             "roofline": roof,
         }
+        if world == 1 and cfg_name == "dimp50" and not args.no_roofline:
+            out["head_inclusive"] = head_inclusive(cfg, n, dev, stream)
         if world == 1 and cfg_name == "dimp50":
             if not args.no_cpu_baseline:
                 out["cpu_baseline"] = stock_baseline(cfg, n, "cpu", budget_s=12.0)

@@ -312,6 +312,20 @@ int pt_track_frame_f32(const pt_sd_params* p, float* filter, float* mem_feat, fl
                        float* scores_out, float* peak_out, void* ws, size_t ws_bytes, void* stream);
 
 /* ------------------------------------------------------------------------------------------------
+ * The tracking frame with the classification-feature head in front.
+ * Replaces: ltr/models/target_classifier/features.py:66-72 (final 3x3 conv + InstanceL2Norm of the test frame) feeding
+ * pytracking/tracker/dimp/dimp.py:190-194, 429-441, 605-648 (classify, memory insert, re-optimisation) in one call: the
+ * head writes the normalised (C,H,W) feature straight into memory slot `slot`, which the first correlation of the solve
+ * then reads like any other sample -- the test feature never exists as a separate tensor.
+ *   backbone_feat (Cin,H,W); head_weight_tap_major (C,3,3,Cin) as for pt_clf_head_f32; everything else as pt_track_frame_f32.
+ * ---------------------------------------------------------------------------------------------- */
+size_t pt_track_frame_head_ws_bytes(int n, int Cin, int C, int H, int W, int K);
+int pt_track_frame_head_f32(const pt_sd_params* prm, float* filter, float* mem_feat, float* mem_bb,
+                            const float* sample_weight, const float* backbone_feat, const float* head_weight_tap_major,
+                            float norm_scale, float norm_eps, int slot, int n, int Cin, int C, int H, int W, int K,
+                            int num_iter, float* scores_out, float* peak_out, void* ws, size_t ws_bytes, void* stream);
+
+/* ------------------------------------------------------------------------------------------------
  * Image-patch sampling in front of the backbone.
  * Replaces: pytracking/features/preprocessing.py:54-148 `sample_patch` (strided pre-downsampling, crop with replicate
  * padding, F.interpolate(mode='bilinear')) and :33-51 `sample_patch_multiscale` (S scales in one launch).

@@ -73,6 +73,30 @@ class TrackState:
             _ptr(self.scores), _ptr(self.peak), _ptr(self.ws), self.ws.numel(), _stream())
         _lib.check(rc, "pt_track_frame_f32")
 
+    def attach_head(self, weight, norm_scale, norm_eps=1e-5):
+        """Classification-feature head in front of the frame: weight (C, Cin, 3, 3) of the final conv
+        (ltr/models/target_classifier/features.py:66-72); enables `step_from_backbone`."""
+        c = self.cfg
+        self.head_w = weight.detach().permute(0, 2, 3, 1).contiguous()        # (C, ky, kx, Cin)
+        self.head_cin = int(weight.shape[1])
+        self.head_scale, self.head_eps = float(norm_scale), float(norm_eps)
+        nb = _lib.lib().pt_track_frame_head_ws_bytes(self.n, self.head_cin, c["C"], c["H"], c["W"], c["K"])
+        if nb == 0:
+            raise RuntimeError("pt_track_frame_head_ws_bytes rejected the configuration")
+        self.ws_head = torch.empty(nb, dtype=torch.uint8, device=self.mem_feat.device)
+
+    @device_guarded
+    def step_from_backbone(self, backbone_feat, slot, num_iter):
+        """backbone_feat (Cin,H,W): head -> memory slot -> classify -> arg-max -> solve, one C-ABI call.  Asynchronous."""
+        c = self.cfg
+        assert backbone_feat.is_contiguous() and backbone_feat.dtype == torch.float32
+        rc = _lib.lib().pt_track_frame_head_f32(
+            ctypes.byref(self.params), _ptr(self.filter), _ptr(self.mem_feat), _ptr(self.mem_bb), _ptr(self.sample_weight),
+            _ptr(backbone_feat), _ptr(self.head_w), self.head_scale, self.head_eps, int(slot), self.n, self.head_cin,
+            c["C"], c["H"], c["W"], c["K"], int(num_iter), _ptr(self.scores), _ptr(self.peak), _ptr(self.ws_head),
+            self.ws_head.numel(), _stream())
+        _lib.check(rc, "pt_track_frame_head_f32")
+
     # algorithmic work of one frame, SURVEY.md section 8(d)
     def bytes_per_solve(self, num_iter):
         c = self.cfg

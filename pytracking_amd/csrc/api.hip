@@ -163,6 +163,67 @@ extern "C" int pt_track_frame_f32(const pt_sd_params* prm, float* filter, float*
                             /*copy_w0=*/false, /*w_final=*/filter, &cls, /*src=*/nullptr);
 }
 
+// ---------------------------------------------------------------------------------------------------
+// the same frame with the classification-feature head in front of it: the head's
+// normalised output is written STRAIGHT into memory slot `slot` (dimp.py:429-441 stores exactly this tensor there), in the
+// (C,H,W) layout the feature passes read, so the test feature never exists as a separate tensor: no copy into the slot,
+// no second read of it by the first correlation.
+// ---------------------------------------------------------------------------------------------------
+struct TfhCarve { size_t head, frame, total; };
+static TfhCarve tfh_carve(int n, int Cin, int C, int H, int W, int K) {
+    TfhCarve c;
+    c.head = 0;
+    c.frame = pt_align_floats(pt_clf_head_ws_bytes(1, Cin, C, H, W) / sizeof(float));
+    c.total = c.frame + pt_track_frame_ws_bytes(n, C, H, W, K) / sizeof(float);
+    return c;
+}
+
+extern "C" size_t pt_track_frame_head_ws_bytes(int n, int Cin, int C, int H, int W, int K) {
+    if (n <= 0 || Cin <= 0 || C <= 0 || H <= 0 || W <= 0 || K <= 0) return 0;
+    if (pt_clf_head_ws_bytes(1, Cin, C, H, W) == 0) return 0;
+    return tfh_carve(n, Cin, C, H, W, K).total * sizeof(float);
+}
+
+extern "C" int pt_track_frame_head_f32(const pt_sd_params* prm, float* filter, float* mem_feat, float* mem_bb,
+                                       const float* sample_weight, const float* backbone_feat,
+                                       const float* head_weight_tap_major, float norm_scale, float norm_eps, int slot, int n,
+                                       int Cin, int C, int H, int W, int K, int num_iter, float* scores_out, float* peak_out,
+                                       void* ws, size_t ws_bytes, void* stream) {
+    if (!prm || !filter || !mem_feat || !mem_bb || !backbone_feat || !head_weight_tap_major || !scores_out || !peak_out || !ws)
+        return PT_ERR_NULL;
+    if (n <= 0 || Cin <= 0 || C <= 0 || H <= 0 || W <= 0 || K <= 0 || num_iter < 0 || slot < 0 || slot >= n) return PT_ERR_SHAPE;
+    if (K * K > 16 || num_iter > 64) return PT_ERR_UNSUPPORTED;
+    const size_t need = pt_track_frame_head_ws_bytes(n, Cin, C, H, W, K);
+    if (need == 0) return PT_ERR_UNSUPPORTED;
+    if (ws_bytes < need || ((uintptr_t)ws % 256) != 0) return PT_ERR_WORKSPACE;
+    const TfhCarve hc = tfh_carve(n, Cin, C, H, W, K);
+    float* base = (float*)ws;
+    const long CHW = (long)C * H * W;
+    // 1. head: conv 3x3 + InstanceL2Norm of the test frame's backbone features -> memory slot (features.py:66-72)
+    int rc = pt_clf_head_f32(backbone_feat, head_weight_tap_major, mem_feat + (long)slot * CHW, 1, Cin, C, H, W, norm_scale,
+                             norm_eps, base + hc.head, hc.frame * sizeof(float), stream);
+    if (rc) return rc;
+    // 2. classification of that sample = its score row of the solve's first correlation; localisation; re-optimisation
+    TfCarve cv = tf_carve(n, C, H, W, K);
+    float* fb = base + hc.frame;
+    PtClsFin cls = {nullptr, 0, slot, scores_out, peak_out, mem_bb};
+    hipStream_t st = (hipStream_t)stream;
+    const int OH = H + (K + 1) % 2, OW = W + (K + 1) % 2;
+    PtFast f = pt_fast_plan(n, C, H, W, K, K, OH, OW);
+    if (pt_fast_usable(f, mem_feat, CHW, filter))
+        return pt_sd_solve_impl(prm, filter, mem_feat, CHW, mem_bb, sample_weight, n, C, H, W, K, num_iter, fb + cv.w_iters,
+                                nullptr, fb + cv.sd, (cv.total - cv.sd) * sizeof(float), st, /*copy_w0=*/false,
+                                /*w_final=*/filter, &cls, /*src=*/nullptr);
+    // generic path: classify the slot's sample on its own, then solve
+    PtPlan p1 = pt_make_plan(1, C, H, W, K, K, OH, OW);
+    rc = pt_launch_corr(p1, mem_feat + (long)slot * CHW, CHW, filter, fb + cv.spart1, st, nullptr);
+    if (rc) return rc;
+    PtClsFin cls2 = {fb + cv.spart1, p1.KS, slot, scores_out, peak_out, mem_bb};
+    return pt_sd_solve_impl(prm, filter, mem_feat, CHW, mem_bb, sample_weight, n, C, H, W, K, num_iter, fb + cv.w_iters, nullptr,
+                            fb + cv.sd, (cv.total - cv.sd) * sizeof(float), st, /*copy_w0=*/false, /*w_final=*/filter, &cls2,
+                            /*src=*/nullptr);
+}
+
 extern "C" int pt_track_frame_replay_pass_f32(const pt_sd_params* prm, const float* filter, const float* mem_feat,
                                               const float* mem_bb, const float* sample_weight, int n, int C, int H, int W,
                                               int K, int num_iter, void* ws, size_t ws_bytes, int which, int reps,

@@ -938,3 +938,25 @@ def test_sample_patch_golden():
     PP._lib.check(PP._lib.lib().pt_sample_patch_f32(_ptr(im), 3, 70, 90, (PP._lib.PatchGeom * 1)(geom), 1, _ptr(out), 20, 30,
                                                     _stream()), "pt_sample_patch_f32")
     assert np.array_equal(out[0].cpu().numpy(), ref) and np.array_equal(ref, g["im"][0][:, 5:25, 7:37])
+
+
+def test_track_frame_with_head_writes_the_memory_slot():
+    """pt_track_frame_head_f32 (second half): head output lands in the memory slot and the frame is
+    bit-identical to head -> pt_track_frame_f32 on the separately materialised test feature."""
+    from pytracking_amd import bench_frame, features as FM
+    cfg = dict(synth.DIMP50)
+    rng = np.random.default_rng(61)
+    w = rng.standard_normal((512, 1024, 3, 3), dtype=np.float32) * np.float32(0.02)
+    scale = float(np.sqrt(1.0 / (512 * 16)))
+    xb = T(rng.standard_normal((1024, 18, 18), dtype=np.float32))
+    a = bench_frame.TrackState(cfg, 12, seed=62, device=DEV)
+    b = bench_frame.TrackState(cfg, 12, seed=62, device=DEV)
+    a.attach_head(T(w), scale)
+    a.step_from_backbone(xb, slot=5, num_iter=5)
+    head = _clf_head(1024, 512, scale, w)
+    with torch.no_grad():
+        feat = head(xb[None])[0].contiguous()
+    b.step(feat, slot=5, num_iter=5)
+    torch.cuda.synchronize()
+    assert torch.equal(a.mem_feat[5], feat) and torch.equal(a.mem_feat, b.mem_feat)
+    assert torch.equal(a.scores, b.scores) and torch.equal(a.filter, b.filter) and torch.equal(a.mem_bb, b.mem_bb)
