@@ -670,6 +670,8 @@ def gen_trackers():
     from oracle import tracker_harness as TH
     outs, rec, _ = TH.run_dimp(**TH.DIMP_RUN)
     save("tracker_dimp50", **rec.to_npz_dict())
+    outs, rec, _ = TH.run_tomp(**TH.TOMP_RUN)
+    save("tracker_tomp50", **rec.to_npz_dict())
 
 
 if __name__ == "__main__":

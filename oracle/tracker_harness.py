@@ -347,3 +347,168 @@ class RefOps:
         me = types.SimpleNamespace(params=self.tracker.params, net=self.net,
                                    iou_modulation=[torch.from_numpy(m) for m in mods])
         return getattr(DiMP, method)(me, [torch.from_numpy(f) for f in feats], torch.from_numpy(init_boxes))
+
+
+# ------------------------------------------------------------------------------------------------------
+# ToMP (pytracking/tracker/tomp/tomp.py): every frame predicts the filters with the transformer model predictor
+# ------------------------------------------------------------------------------------------------------
+TOMP50_TEST = dict(C_backbone=1024, C_layer2=512, C=256, H=18, W=18, H2=36, W2=36, C_iou=256, K=1, base_seed=37, noise=0.3)
+TOMP_RUN = dict(seed=4300, n_frames=6, dims=TOMP50_TEST,
+                thresholds=dict(conf_ths=0.5))   # random-init scores: let the memory update run
+
+
+def build_tomp50(seed, dims=TOMP50_TEST):
+    """tompnet50 as ltr/train_settings/tomp/tomp50.py builds it (filter size 1, 256 channels, 6 + 6 layers), hot-path
+    parameters seeded (synth.tracker_tomp_params)."""
+    ref_harness.install()
+    import ltr.models.tracking.tompnet as tompnet
+    torch.manual_seed(seed)
+    cfg = synth.TOMP
+    net = tompnet.tompnet50(filter_size=1, backbone_pretrained=False, head_feat_blocks=0, head_feat_norm=True, final_conv=True,
+                            out_feature_dim=dims["C"], feature_sz=cfg["feature_sz"], nhead=cfg["nhead"],
+                            num_encoder_layers=cfg["n_enc"], num_decoder_layers=cfg["n_dec"], dim_feedforward=cfg["ff"],
+                            use_test_frame_encoding=True)
+    net.eval()
+    p = synth.tracker_tomp_params(seed, dims)
+    with torch.no_grad():
+        net.head.feature_extractor[0].weight.copy_(torch.from_numpy(p["head.weight"]))
+    for mod, pre in ((net.head.filter_predictor, "fp."), (net.head.classifier, "cls."), (net.head.bb_regressor, "reg.")):
+        sd = {k[len(pre):]: torch.from_numpy(v.copy()) for k, v in p.items() if k.startswith(pre)}
+        if pre == "fp.":
+            sd["query_embed_fg_decoder.weight"] = sd["query_embed_fg.weight"]
+            for idx in (1, 4):
+                sd[f"box_encoding.{idx}.num_batches_tracked"] = torch.tensor(0)
+        mod.load_state_dict(sd, strict=True)
+    return net
+
+
+def tomp50_params(net_stub):
+    """pytracking/parameter/tomp/tomp50.py."""
+    from pytracking.utils import TrackerParams
+    p = TrackerParams()
+    p.debug = 0
+    p.visualization = False
+    p.use_gpu = False
+    p.device = "cpu"
+    p.train_feature_size = 18
+    p.feature_stride = 16
+    p.image_sample_size = p.train_feature_size * p.feature_stride
+    p.search_area_scale = 5
+    p.border_mode = 'inside_major'
+    p.patch_max_scale_change = 1.5
+    p.sample_memory_size = 2
+    p.learning_rate = 0.01
+    p.init_samples_minimum_weight = 0.25
+    p.train_skipping = 20
+    p.update_classifier = True
+    p.net_opt_iter = 10
+    p.net_opt_update_iter = 2
+    p.net_opt_hn_iter = 1
+    p.window_output = False
+    p.use_augmentation = False
+    p.augmentation = {}
+    p.augmentation_expansion_factor = 2
+    p.random_shift_factor = 1 / 3
+    p.advanced_localization = True
+    p.target_not_found_threshold = 0.25
+    p.distractor_threshold = 0.8
+    p.hard_negative_threshold = 0.5
+    p.target_neighborhood_scale = 2.2
+    p.dispalcement_scale = 0.8
+    p.hard_negative_learning_rate = 0.02
+    p.update_scale_when_uncertain = True
+    p.conf_ths = 0.9
+    p.search_area_rescaling_at_occlusion = True
+    p.net = net_stub
+    p.vot_anno_conversion_type = 'preserve_area'
+    return p
+
+
+def run_tomp(seed=4300, n_frames=6, dims=TOMP50_TEST, thresholds=None):
+    """initialize() + n_frames x track() of the reference ToMP on a stubbed backbone; one event per classify_target call
+    (head features of the test frame and of the memory frames, filter prediction, classifier, box regressor)."""
+    ref_harness.install()
+    from pytracking.tracker.tomp.tomp import ToMP
+    net = build_tomp50(seed, dims)
+    stub = StubBackbone(seed, dims)
+    ns = NetStub(net, stub)
+    params = tomp50_params(ns)
+    for k, v in (thresholds or {}).items():
+        setattr(params, k, v)
+    tracker = ToMP(params)
+    tracker.visdom = None
+    rec = Recorder()
+    rec.add("config", seed=seed, n_frames=n_frames, memory_size=params.sample_memory_size,
+            **{f"dim_{k}": v for k, v in dims.items()},
+            **{k: getattr(params, k) for k in ("target_not_found_threshold", "distractor_threshold", "hard_negative_threshold",
+                                               "target_neighborhood_scale", "dispalcement_scale")})
+    slots = {}                                                  # memory slot -> index of the backbone call that filled it
+    orig_cls = tracker.classify_target
+
+    def classify(sample_x):
+        n = min(int(tracker.num_stored_samples[0]), int(params.sample_memory_size))   # the slices `[:num_stored]` clamp
+        scores, bbox = orig_cls(sample_x)
+        rec.add("tomp_classify", n=n, test_call=stub.k_backbone - 1, train_calls=np.array([slots[i] for i in range(n)]),
+                labels=tracker.target_labels[0][:n], ltrb=tracker.encode_bbox(tracker.target_boxes[:n]),
+                num_gth_frames=int(tracker.num_gth_frames), scores=scores, bbox=bbox)
+        return scores, bbox
+    tracker.classify_target = classify
+    orig_loc = tracker.localize_advanced
+
+    def localize(scores, sample_pos, sample_scales):
+        st = dict(target_sz=tracker.target_sz.clone(), pos=tracker.pos.clone(), kernel_size=tracker.kernel_size.clone(),
+                  img_support_sz=tracker.img_support_sz.clone())
+        tv, scale_ind, s, flag, loc = orig_loc(scores, sample_pos, sample_scales)
+        rec.add("tomp_localize", sample_pos=sample_pos, sample_scales=sample_scales, tv=tv, scale_ind=int(scale_ind), flag=flag,
+                score_loc=loc, **st)
+        return tv, scale_ind, s, flag, loc
+    tracker.localize_advanced = localize
+    orig_mem = tracker.update_memory
+
+    def update_memory(sample_x, sample_y, target_box, learning_rate=None):
+        orig_mem(sample_x, sample_y, target_box, learning_rate)
+        slots[int(tracker.previous_replace_ind[0])] = stub.k_backbone - 1
+        rec.add("memory", slot=int(tracker.previous_replace_ind[0]), stored=int(tracker.num_stored_samples[0]))
+    tracker.update_memory = update_memory
+
+    rng = np.random.default_rng(seed + 77)
+    torch.manual_seed(seed)
+    tracker.initialize(synthetic_frame(rng), {"init_bbox": [200.0, 140.0, 70.0, 90.0]})
+    slots[0] = 0                                                # the first-frame sample (no augmentation: one sample)
+    outs = []
+    for _ in range(n_frames):
+        rec.add("frame", frame=tracker.frame_num + 1)
+        out = tracker.track(synthetic_frame(rng))
+        outs.append(np.array(out["target_bbox"], dtype=np.float64))
+        rec.add("state", target_bbox=outs[-1])
+    return np.stack(outs), rec, (tracker, net)
+
+
+class TompRefOps:
+    """tests/tracker_replay.py `replay_tomp` served by the reference's own modules."""
+
+    def __init__(self, net, tracker):
+        self.net, self.tracker = net, tracker
+
+    def to_numpy(self, t):
+        return t.detach().cpu().numpy() if isinstance(t, torch.Tensor) else np.asarray(t)
+
+    def classify(self, test_l3, train_l3, labels, ltrb, num_gth_frames):
+        T = torch.from_numpy
+        h = self.net.head
+        with torch.no_grad():
+            test_feat = h.extract_head_feat(T(test_l3))
+            train_feat = h.extract_head_feat(T(train_l3))
+            cw, bw, cenc, benc = h.get_filter_and_features_in_parallel(train_feat, test_feat, num_gth_frames=num_gth_frames,
+                                                                       train_label=T(labels), train_ltrb_target=T(ltrb))
+            return h.classifier(cenc, cw), h.bb_regressor(benc, bw)
+
+    def localize(self, scores, ev, cfg):
+        import types
+        from pytracking.tracker.tomp.tomp import ToMP
+        me = types.SimpleNamespace(params=self.tracker.params, kernel_size=torch.from_numpy(ev["kernel_size"]),
+                                   output_window=None, img_support_sz=torch.from_numpy(ev["img_support_sz"]),
+                                   target_sz=torch.from_numpy(ev["target_sz"]), pos=torch.from_numpy(ev["pos"]))
+        tv, scale_ind, _, flag, loc = ToMP.localize_advanced(me, scores.squeeze(1).clone(), torch.from_numpy(ev["sample_pos"]),
+                                                             torch.from_numpy(ev["sample_scales"]))
+        return tv, scale_ind, flag, loc

@@ -317,3 +317,17 @@ def tracker_dimp_params(seed, dims):
     for k, v in iou_net_params(seed + 901, dict(C=dims["C_iou"], I=dims["C_iou"])).items():
         p["iou." + k] = v
     return p
+
+
+def tracker_tomp_params(seed, dims, cfg=None):
+    """Seeded hot-path weights of a ToMP network: the head's final conv ('head.weight') + synth.tomp_params."""
+    cfg = cfg or TOMP
+    rng = np.random.default_rng(seed + 910)
+    C, Cb = dims["C"], dims["C_backbone"]
+    p = {"head.weight": rng.standard_normal((C, Cb, 3, 3), dtype=np.float32) * np.float32(math.sqrt(2.0 / (9 * C)))}
+    p.update(tomp_params(seed + 911, cfg))
+    # random-init scores come out negative everywhere, which degenerates the tracker's peak logic (masked cells are 0):
+    # flip the sign of the classifier's filter projection so that the score maps are positive
+    p["cls.linear.weight"] = -p["cls.linear.weight"]
+    p["cls.linear.bias"] = -p["cls.linear.bias"]
+    return p

@@ -85,3 +85,36 @@ def test_gfx950_modules_replay_the_tracker_log():
     dev = TR.replay(evs, TR.MirrorOps(evs, "cuda"), atol=1e-4)
     assert set(dev) == {"get_filter", "classify", "localize", "refine_iou", "refine_boxes", "optimize"}
     print("max deviation per boundary call over the 10-frame trajectory:", {k: f"{v:.2e}" for k, v in dev.items()})
+
+
+# ------------------------------------------------------------------------------------------------------
+# ToMP-50: initialize() + 6 x track() of the unmodified reference tracker (tests/golden/tracker_tomp50.npz)
+# ------------------------------------------------------------------------------------------------------
+def _tomp_events():
+    return TR.events_from_npz(load_golden("tracker_tomp50"))
+
+
+def test_tomp_log_covers_both_memory_sizes():
+    evs = _tomp_events()
+    ns = {int(e["n"]) for e in evs if e["kind"] == "tomp_classify"}
+    assert ns == {1, 2} and sum(e["kind"] == "memory" for e in evs) >= 2
+    assert sum(e["kind"] == "tomp_classify" for e in evs) == int(evs[0]["n_frames"]) == 6
+
+
+def test_reference_tomp_modules_replay_the_log():
+    _need_reference()
+    from oracle import tracker_harness as TH
+    net = TH.build_tomp50(TH.TOMP_RUN["seed"], TH.TOMP_RUN["dims"])
+    tracker = type("T", (), {})()
+    tracker.params = TH.tomp50_params(None)
+    for k, v in TH.TOMP_RUN["thresholds"].items():
+        setattr(tracker.params, k, v)
+    dev = TR.replay_tomp(_tomp_events(), TH.TompRefOps(net, tracker), atol=2e-5)
+    assert set(dev) == {"scores", "log_bbox", "localize", "score_loc"}
+
+
+@pytest.mark.gpu
+def test_gfx950_modules_replay_the_tomp_tracker_log():
+    evs = _tomp_events()
+    dev = TR.replay_tomp(evs, TR.TompMirrorOps(evs, "cuda"), atol=1e-4)
+    print("ToMP: max deviation per boundary call over the 6-frame trajectory:", {k: f"{v:.2e}" for k, v in dev.items()})

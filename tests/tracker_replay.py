@@ -213,3 +213,98 @@ class MirrorOps:
         me = self.types.SimpleNamespace(params=self._params(cfg), net=self.types.SimpleNamespace(bb_regressor=self.iou_net),
                                         iou_modulation=[self.T(m) for m in mods])
         return getattr(IR, method)(me, [self.T(f) for f in feats], torch.from_numpy(np.ascontiguousarray(init_boxes)))
+
+
+# ------------------------------------------------------------------------------------------------------
+# ToMP: every frame = head features of the test frame and of the memory frames -> filter prediction -> classifier and
+# box regressor -> localisation (tomp.py:142-303).  The memory holds BACKBONE features, i.e. seeds here.
+# ------------------------------------------------------------------------------------------------------
+def replay_tomp(events, ops, atol=1e-4):
+    cfg = events[0]
+    dims = {k[4:]: (int(v) if float(v).is_integer() else float(v)) for k, v in cfg.items() if k.startswith("dim_")}
+    seed = int(cfg["seed"])
+    dev = {}
+
+    def check(kind, got, want, tol):
+        got, want = np.asarray(ops.to_numpy(got), dtype=np.float64), np.asarray(want, dtype=np.float64)
+        assert got.shape == want.shape, (kind, got.shape, want.shape)
+        err = float(np.abs(got - want).max())
+        dev[kind] = max(dev.get(kind, 0.0), err)
+        assert err <= tol, (kind, err)
+
+    scores = None
+    for ev in events[1:]:
+        if ev["kind"] == "tomp_classify":
+            l3 = lambda k: synth.tracker_backbone(seed + int(k), 1, dims)["layer3"]
+            test = l3(ev["test_call"])
+            train = np.concatenate([l3(k) for k in np.atleast_1d(ev["train_calls"])], axis=0)
+            scores, bbox = ops.classify(test, train, ev["labels"], ev["ltrb"], int(ev["num_gth_frames"]))
+            check("scores", scores, ev["scores"], atol)
+            # the regressor ends in exp(): compare in the log domain where the 1e-4 bound is meaningful
+            check("log_bbox", np.log(np.maximum(np.asarray(ops.to_numpy(bbox), dtype=np.float64), 1e-30)),
+                  np.log(np.maximum(ev["bbox"].astype(np.float64), 1e-30)), 10 * atol)
+        elif ev["kind"] == "tomp_localize":
+            tv, scale_ind, flag, loc = ops.localize(scores, ev, cfg)
+            assert flag == str(ev["flag"]) and int(scale_ind) == int(ev["scale_ind"]), (flag, str(ev["flag"]))
+            check("localize", tv, ev["tv"], 1e-3)
+            check("score_loc", loc, ev["score_loc"], 0.0)
+    return dev
+
+
+class TompMirrorOps:
+    """`replay_tomp` served by the gfx950 ToMP modules (pytracking_amd.transformer / features / localization)."""
+
+    def __init__(self, events, device="cuda"):
+        import math
+        import types
+        import torch
+        from pytracking_amd import features, transformer as TM
+        self.torch, self.types, self.dev = torch, types, torch.device(device)
+        cfg = events[0]
+        dims = {k[4:]: (int(v) if float(v).is_integer() else float(v)) for k, v in cfg.items() if k.startswith("dim_")}
+        p = synth.tracker_tomp_params(int(cfg["seed"]), dims)
+        c = synth.TOMP
+        C = dims["C"]
+        self.T = lambda a: torch.from_numpy(np.ascontiguousarray(a)).to(self.dev)
+        self.head = features.residual_bottleneck(feature_dim=dims["C_backbone"] // 4, num_blocks=0, l2norm=True, final_conv=True,
+                                                 norm_scale=math.sqrt(1.0 / (C * 1 * 1)), out_dim=C)
+        self.head.load_state_dict({"0.weight": torch.from_numpy(p["head.weight"])}, strict=True)
+        self.head.to(self.dev).eval()
+        tr = TM.Transformer(d_model=C, nhead=c["nhead"], num_encoder_layers=c["n_enc"], num_decoder_layers=c["n_dec"],
+                            dim_feedforward=c["ff"])
+        self.pred = TM.FilterPredictor(tr, feature_sz=c["feature_sz"], use_test_frame_encoding=True)
+        self.cls = TM.LinearFilterClassifier(num_channels=C)
+        self.reg = TM.DenseBoxRegressor(num_channels=C)
+        for mod, pre in ((self.pred, "fp."), (self.cls, "cls."), (self.reg, "reg.")):
+            sd = {k[len(pre):]: torch.from_numpy(v.copy()) for k, v in p.items() if k.startswith(pre)}
+            if pre == "fp.":
+                sd["query_embed_fg_decoder.weight"] = sd["query_embed_fg.weight"]
+                for idx in (1, 4):
+                    sd[f"box_encoding.{idx}.num_batches_tracked"] = torch.tensor(0)
+            mod.load_state_dict(sd, strict=True)
+            mod.to(self.dev).eval()
+
+    def to_numpy(self, t):
+        return t.detach().cpu().numpy() if isinstance(t, self.torch.Tensor) else np.asarray(t)
+
+    def classify(self, test_l3, train_l3, labels, ltrb, num_gth_frames):
+        with self.torch.no_grad():
+            test_feat = self.head(self.T(test_l3))                      # Head.extract_head_feat (heads.py:56-64)
+            train_feat = self.head(self.T(train_l3))
+            cw, bw, cenc, benc = self.pred.predict_cls_bbreg_filters_parallel(train_feat, test_feat, self.T(labels),
+                                                                              num_gth_frames, self.T(ltrb))
+            return self.cls(cenc, cw), self.reg(benc, bw)
+
+    def localize(self, scores, ev, cfg):
+        from pytracking_amd import localization as LM
+        torch = self.torch
+        params = MirrorOps._Params(**{k: float(cfg[k]) for k in ("target_not_found_threshold", "distractor_threshold",
+                                                                 "hard_negative_threshold", "target_neighborhood_scale",
+                                                                 "dispalcement_scale")})
+        me = self.types.SimpleNamespace(params=params, kernel_size=torch.from_numpy(ev["kernel_size"]), output_window=None,
+                                        img_support_sz=torch.from_numpy(ev["img_support_sz"]),
+                                        target_sz=torch.from_numpy(ev["target_sz"]), pos=torch.from_numpy(ev["pos"]))
+        tv, scale_ind, _, flag, loc = LM.localize_advanced_tomp(me, scores.reshape(-1, *scores.shape[-2:]),
+                                                                torch.from_numpy(ev["sample_pos"]),
+                                                                torch.from_numpy(ev["sample_scales"]))
+        return tv, scale_ind, flag, loc
