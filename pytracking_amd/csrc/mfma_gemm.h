@@ -139,8 +139,9 @@ __global__ __launch_bounds__(256) void k_gemm(GemmArgs g) {
     const int aso = (wm * WM + prow(lane & 15)) * LS + qoff * 4, bso = (wn * WN + prow(lane & 15)) * LS + qoff * 4;
 
     const int nkt = (g.K + BK - 1) / BK;
-    const int kb0 = g.ksteps ? blockIdx.z * g.ksteps : 0;
-    const int nk = g.ksteps ? min(nkt, kb0 + g.ksteps) : nkt;
+    constexpr int KSU = 64 / BK;                                         // g.ksteps counts 64-wide steps whatever BK is
+    const int kb0 = g.ksteps ? blockIdx.z * g.ksteps * KSU : 0;
+    const int nk = g.ksteps ? min(nkt, kb0 + g.ksteps * KSU) : nkt;
 #pragma unroll
     for (int sl = 0; sl < PD; ++sl) fetch(kb0 + sl, sl, kb0 + sl < nk);
     stash(0, 0);
@@ -180,57 +181,79 @@ __global__ __launch_bounds__(256) void k_gemm(GemmArgs g) {
         }
     }
 
-    // epilogue: the row part of every output address is computed once per accumulator row (the segment / NCHW maps cost
-    // an integer division each -- done per element they were most of the kernel's time: ~120 VALU instructions x 16-64
-    // elements per lane)
-    long rbase[MT][4];
+    // epilogue: straight-line.  The row part of every output address is computed once per accumulator row (the segment /
+    // NCHW maps cost an integer division each) as a 32-bit BYTE offset for raw buffer accesses: rows / columns outside the
+    // matrix get an out-of-range offset, which the hardware drops (stores) or answers with 0 (loads) -- no per-element
+    // branches, so the compiler keeps all residual loads and all stores in flight (with `if (row < M)` around every
+    // element it put an s_waitcnt vmcnt(0) in front of every store: 0.23 us per element per lane, 18 us for a 128x128
+    // tile).  exp() only under a workgroup-uniform branch.
+    const __amdgpu_buffer_rsrc_t rsC = pt_rsrc(g.C, 0xFFFFFFE0u), rsR = pt_rsrc(g.R ? g.R : g.C, 0xFFFFFFE0u);
+    unsigned rbase[MT][4];
     const bool plain = !g.nchw && g.c_segstride == 0;
 #pragma unroll
     for (int mt = 0; mt < MT; ++mt)
 #pragma unroll
         for (int r = 0; r < 4; ++r) {
             const int row = m0 + wm * WM + mt * 16 + prow(4 * (lane >> 4) + r);
-            long o = -1;
-            if (row < g.M) {
-                if (plain) {
-                    o = (long)row * g.ldc;
-                } else if (g.nchw) {
-                    const int img = row / g.HW;
-                    o = (long)img * g.N * g.HW + (row - img * g.HW);
-                } else {
-                    const int sg = row / g.c_seg;
-                    o = ((long)sg * g.c_segstride + (row - sg * g.c_seg)) * g.ldc;
-                }
+            const int rc = min(row, g.M - 1);
+            long o;
+            if (plain) {
+                o = (long)rc * g.ldc;
+            } else if (g.nchw) {
+                const int img = rc / g.HW;
+                o = (long)img * g.N * g.HW + (rc - img * g.HW);
+            } else {
+                const int sg = rc / g.c_seg;
+                o = ((long)sg * g.c_segstride + (rc - sg * g.c_seg)) * g.ldc;
             }
-            rbase[mt][r] = o;
+            rbase[mt][r] = row < g.M ? (unsigned)(o * 4) : OOB;
         }
-    const long zoff = (long)blockIdx.z * g.c_zstride;
-    const long cstep = g.nchw ? g.HW : 1;
+    const unsigned zoff = (unsigned)((long)blockIdx.z * g.c_zstride * 4);
+    const unsigned cstep = (unsigned)(g.nchw ? g.HW : 1) * 4u;
 #pragma unroll
     for (int nt = 0; nt < NT; ++nt) {
         const int col = n0 + wn * WN + nt * 16 + prow(lane & 15);
-        if (col >= g.N) continue;
-        const float bv = (g.bias && blockIdx.z == 0) ? g.bias[col] : 0.f;
-        const float sc = g.scale ? g.scale[col] : 1.f, sh = g.shift ? g.shift[col] : 0.f;
-        const long coff = (long)col * cstep;
-        float res[MT][4];
-        if (g.R) {                                                   // residual loads first, all in flight together
+        const bool cok = col < g.N;
+        const int cc = cok ? col : 0;
+        const float bv = (g.bias && blockIdx.z == 0) ? g.bias[cc] : 0.f;
+        const float sc = g.scale ? g.scale[cc] : 1.f, sh = g.shift ? g.shift[cc] : 0.f;
+        const unsigned coff = (unsigned)cc * cstep;
+        unsigned off[MT][4];
 #pragma unroll
-            for (int mt = 0; mt < MT; ++mt)
+        for (int mt = 0; mt < MT; ++mt)
 #pragma unroll
-                for (int r = 0; r < 4; ++r) res[mt][r] = rbase[mt][r] >= 0 ? g.R[rbase[mt][r] + coff] : 0.f;
-        }
+            for (int r = 0; r < 4; ++r) off[mt][r] = (cok && rbase[mt][r] != OOB) ? rbase[mt][r] + coff : OOB;
+        float v[MT][4];
 #pragma unroll
         for (int mt = 0; mt < MT; ++mt)
 #pragma unroll
             for (int r = 0; r < 4; ++r) {
-                if (rbase[mt][r] < 0) continue;
-                float v = (acc[mt][nt][r] + bv) * sc + sh;
-                if (g.relu) v = fmaxf(v, 0.f);
-                if (g.R) v += res[mt][r];
-                if (g.expo) v = expf(v);
-                g.C[rbase[mt][r] + coff + zoff] = v;
+                const float t = (acc[mt][nt][r] + bv) * sc + sh;
+                v[mt][r] = g.relu ? fmaxf(t, 0.f) : t;
             }
+        if (g.R) {                                                   // uniform: residual loads all in flight together
+            float res[MT][4];
+#pragma unroll
+            for (int mt = 0; mt < MT; ++mt)
+#pragma unroll
+                for (int r = 0; r < 4; ++r) res[mt][r] = pt_bload1(rsR, off[mt][r]);
+#pragma unroll
+            for (int mt = 0; mt < MT; ++mt)
+#pragma unroll
+                for (int r = 0; r < 4; ++r) v[mt][r] += res[mt][r];
+        }
+        if (g.expo) {                                                // uniform
+#pragma unroll
+            for (int mt = 0; mt < MT; ++mt)
+#pragma unroll
+                for (int r = 0; r < 4; ++r) v[mt][r] = expf(v[mt][r]);
+        }
+#pragma unroll
+        for (int mt = 0; mt < MT; ++mt)
+#pragma unroll
+            for (int r = 0; r < 4; ++r)
+                __builtin_amdgcn_raw_buffer_store_b32(__builtin_bit_cast(unsigned, v[mt][r]), rsC,
+                                                      off[mt][r] == OOB ? OOB : off[mt][r] + zoff, 0, 0);
     }
 }
 
@@ -244,14 +267,26 @@ GemmArgs gemm_args(const float* A, long lda, long a_rows, const float* Wt, int M
     return g;
 }
 
-// 32x32 workgroup tiles throughout: at the row counts of this path (324..1944) the 64x64 / 64x32 / 128x128 tilings were
-// measured slower
+// Workgroup tile by shape (experiments/gemm_tiles.hip, profiles/r02e_gemm_tiles.txt; M = 1944 rows of the ToMP encoder):
+// 32x32x64 everywhere except wide outputs (N >= 1024, many rows), where 64x64 tiles with 32-wide K steps halve the operand
+// traffic per flop and two workgroups still fit a CU: FFN first GEMM 36.3 -> 28.0 us.  Larger tiles (128x64, 128x128) run
+// their K steps at 67-74 % of the MFMA rate but leave too few workgroups at these sizes.
 int launch_gemm(const GemmArgs& g, hipStream_t st, bool conv = false) {
     if (g.K % 32 != 0 || g.M <= 0 || g.N <= 0) return PT_ERR_UNSUPPORTED;
+    // the epilogue addresses C (and R) with 32-bit byte offsets through a raw buffer descriptor
     const int nz = g.ksteps ? ((g.K + 63) / 64 + g.ksteps - 1) / g.ksteps : 1;
+    const long rows = g.nchw ? (long)g.M * g.N : (g.c_segstride ? ((long)(g.M / g.c_seg) + 1) * g.c_segstride * g.ldc
+                                                                   : (long)g.M * g.ldc);
+    if ((rows + (long)(nz - 1) * g.c_zstride) * 4 >= 0xFFFFFFE0L) return PT_ERR_UNSUPPORTED;
     if (conv) {
         if (g.Cin % 64 != 0) return PT_ERR_UNSUPPORTED;
         hipLaunchKernelGGL((k_gemm<32, 32, 1>), dim3((g.N + 31) / 32, (g.M + 31) / 32, nz), dim3(256), 0, st, g);
+    } else if (g.N >= 1024 && g.M >= 1024 && nz == 1) {
+        GemmArgs gs = g;
+        const int gy = (g.M + 63) / 64;
+        gs.swizzle = gy >= 16;
+        hipLaunchKernelGGL((k_gemm<64, 64, 0, 32>), dim3((g.N + 63) / 64, gs.swizzle ? (gy + 7) / 8 * 8 : gy, 1), dim3(256), 0,
+                           st, gs);
     } else {
         GemmArgs gs = g;
         const int gy = (g.M + 31) / 32;
