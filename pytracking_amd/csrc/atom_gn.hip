@@ -33,6 +33,7 @@ struct GnArgs {
     float *c, *dc, *gc;                 // (n,Kc,HW) compressed samples, their direction, their gradient
     float *r, *p, *q, *delta, *rprev;   // (NV) CG vectors: [filter block | projection block]
     float *scal;                        // [0] rho, [1] stop, [2] has_p
+    float *pqpart;                      // (ceil(NV/256)) per-workgroup partial sums of <p, q> (k_gn_gather)
 };
 
 __device__ __forceinline__ float gn_mlu(float x, float mn) {
@@ -136,16 +137,37 @@ __device__ void gn_direction(const GnArgs& a, float* scratch) {
     if (threadIdx.x == 0) { a.scal[0] = rho; a.scal[2] = 1.f; }
 }
 
-// phase 0: b = -J^T f0 (regularisation residuals sqrt(l)*x enter as l*x), state reset (:82-83), first direction
-// phase 1: q = J^T J p, alpha, delta, residual (:127-146); then the next direction, or x += delta after the last one
+// Assembling J^T(.) from the pass partials is the wide part of a CG step (NV = Kc*K*K + Kc*M elements, each the sum of up
+// to NSG partial slabs): one workgroup per 256 elements.  As a single workgroup (round 1) this was 146 us per step, 86 %
+// of the first-frame solve.
+//   phase 0: r = -(J^T f0 + reg * x), delta = 0        phase 1: q = J^T J p (+ reg * p), per-workgroup partial of <p, q>
+__global__ __launch_bounds__(256) void k_gn_gather(GnArgs a, int phase) {
+    __shared__ float scratch[16];
+    const int e = blockIdx.x * 256 + threadIdx.x;
+    float acc = 0.f;
+    if (e < a.NV) {
+        if (phase == 0) {
+            a.r[e] = -gn_gather(a, e, e < a.NF ? a.f : a.P - a.NF);
+            a.delta[e] = 0.f;
+        } else {
+            const float qv = gn_gather(a, e, a.p);
+            a.q[e] = qv;
+            acc = a.p[e] * qv;
+        }
+    }
+    if (phase == 1) {
+        const float tot = block_sum(acc, scratch);
+        if (threadIdx.x == 0) a.pqpart[blockIdx.x] = tot;
+    }
+}
+
+// The recurrences of a CG step on the assembled vectors (one workgroup; fixed summation order):
+// phase 0: state reset (:82-83), first direction
+// phase 1: alpha, delta, residual (:127-146); then the next direction, or x += delta after the last one
 __global__ __launch_bounds__(1024) void k_gn_vec(GnArgs a, int phase, int ii, int num_iter) {
     __shared__ float scratch[16];
     if (phase == 0) {
         if (threadIdx.x == 0) { a.scal[0] = 1.f; a.scal[1] = 0.f; a.scal[2] = 0.f; }
-        for (int e = threadIdx.x; e < a.NV; e += blockDim.x) {
-            a.r[e] = -gn_gather(a, e, e < a.NF ? a.f : a.P - a.NF);
-            a.delta[e] = 0.f;
-        }
         __syncthreads();
         gn_direction(a, scratch);
         return;
@@ -155,12 +177,9 @@ __global__ __launch_bounds__(1024) void k_gn_vec(GnArgs a, int phase, int ii, in
             for (int e = threadIdx.x; e < a.NV; e += blockDim.x) (e < a.NF ? a.f[e] : a.P[e - a.NF]) += a.delta[e];
         return;
     }
+    const int nparts = (a.NV + 255) / 256;
     float acc = 0.f;
-    for (int e = threadIdx.x; e < a.NV; e += blockDim.x) {
-        const float qv = gn_gather(a, e, a.p);
-        a.q[e] = qv;
-        acc += a.p[e] * qv;
-    }
+    for (int k = threadIdx.x; k < nparts; k += blockDim.x) acc += a.pqpart[k];
     const float pq = block_sum(acc, scratch);
     const float alpha = a.scal[0] / pq;                                 // :131
     const bool more = ii < num_iter - 1;
@@ -179,7 +198,7 @@ __global__ __launch_bounds__(1024) void k_gn_vec(GnArgs a, int phase, int ii, in
 }
 
 // ---------------------------------------------------------------------------------------------------
-struct GnCarve { size_t d, v, sp1, sp2, R, gpf, gpP, c, dc, gc, wT, r, p, q, delta, rprev, scal, total; };
+struct GnCarve { size_t d, v, sp1, sp2, R, gpf, gpP, c, dc, gc, wT, r, p, q, delta, rprev, scal, pqpart, total; };
 
 static GnCarve gn_carve(const PtPlan& pl, int n, int M, int Kc, int H, int W, int K) {
     GnCarve c;
@@ -193,9 +212,10 @@ static GnCarve gn_carve(const PtPlan& pl, int n, int M, int Kc, int H, int W, in
     c.gpf = take(pt_gpart_floats(pl));
     c.gpP = take((size_t)ngrp * pt_mf_gpart_floats(n, 16, M, H, W, 1));
     c.c = take(n * Kc * HW); c.dc = take(n * Kc * HW); c.gc = take(n * Kc * HW);
-    c.wT = take(pt_mf_wt_floats(M, 1));
+    c.wT = take((size_t)ngrp * pt_mf_wt_floats(M, 1));
     c.r = take(NV); c.p = take(NV); c.q = take(NV); c.delta = take(NV); c.rprev = take(NV);
     c.scal = take(64);
+    c.pqpart = take((NV + 255) / 256);
     c.total = off;
     return c;
 }
@@ -216,6 +236,11 @@ extern "C" size_t pt_atom_gn_ws_bytes(int n, int M, int Kc, int H, int W, int K)
 // conv1x1(S, rows of `proj`) -> out (n,Kc,H,W), 16 projection rows per launch
 static int gn_project(const GnArgs& a, const float* samples, long stride_n, const float* proj, float* out, float* wT,
                       hipStream_t st) {
+    if (a.Kc % 16 == 0) {                                           // all banks of 16 projection rows in one launch each
+        int rc = pt_launch_mf_wtrans(proj, wT, 16, a.M, 1, st, a.NGRP);
+        if (rc) return rc;
+        return pt_launch_mf_corr(samples, stride_n, wT, out, a.n, 16, a.M, a.H, a.W, 1, st, (long)a.Kc * a.HW, a.NGRP);
+    }
     for (int g = 0; g < a.NGRP; ++g) {
         const int Fg = std::min(16, a.Kc - 16 * g);
         int rc = pt_launch_mf_wtrans(proj + (long)16 * g * a.M, wT, Fg, a.M, 1, st);
@@ -234,6 +259,8 @@ static int gn_jt(const GnArgs& a, const PtPlan& pl, const float* samples, long s
     const long total = (long)a.n * a.Kc * a.HW;
     hipLaunchKernelGGL(k_gn_backproject, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, st, a);
     PT_CHECK_LAUNCH();
+    if (a.Kc % 16 == 0)
+        return pt_launch_mf_adj(samples, stride_n, a.gc, a.gpP, a.n, 16, a.M, a.H, a.W, 1, st, (long)a.Kc * a.HW, a.NGRP);
     for (int g = 0; g < a.NGRP; ++g) {
         const int Fg = std::min(16, a.Kc - 16 * g);
         rc = pt_launch_mf_adj(samples, stride_n, a.gc + (long)16 * g * a.HW, a.gpP + (long)g * a.NSG * 16 * a.M, a.n, Fg,
@@ -265,7 +292,7 @@ extern "C" int pt_atom_gn_f32(float* filter, float* proj, const float* samples, 
     a.d = base + cv.d; a.v = base + cv.v; a.sp1 = base + cv.sp1; a.sp2 = base + cv.sp2; a.R = base + cv.R;
     a.gpf = base + cv.gpf; a.gpP = base + cv.gpP; a.c = base + cv.c; a.dc = base + cv.dc; a.gc = base + cv.gc;
     a.r = base + cv.r; a.p = base + cv.p; a.q = base + cv.q; a.delta = base + cv.delta; a.rprev = base + cv.rprev;
-    a.scal = base + cv.scal;
+    a.scal = base + cv.scal; a.pqpart = base + cv.pqpart;
     float* wT = base + cv.wT;
     const size_t pw_lds = (size_t)a.HW * sizeof(float);
     const long cs = (long)Kc * a.HW;
@@ -281,6 +308,9 @@ extern "C" int pt_atom_gn_f32(float* filter, float* proj, const float* samples, 
         PT_CHECK_LAUNCH();
         rc = gn_jt(a, pl, samples, samples_stride_n, st);
         if (rc) return rc;
+        const unsigned ngw = (unsigned)((a.NV + 255) / 256);
+        hipLaunchKernelGGL(k_gn_gather, dim3(ngw), dim3(256), 0, st, a, 0);
+        PT_CHECK_LAUNCH();
         hipLaunchKernelGGL(k_gn_vec, dim3(1), dim3(1024), 0, st, a, 0, 0, ncg);
         PT_CHECK_LAUNCH();
         // ---- conjugate gradient on J^T J delta = b                                          optimization.py:72-163
@@ -295,6 +325,8 @@ extern "C" int pt_atom_gn_f32(float* filter, float* proj, const float* samples, 
             PT_CHECK_LAUNCH();
             rc = gn_jt(a, pl, samples, samples_stride_n, st);
             if (rc) return rc;
+            hipLaunchKernelGGL(k_gn_gather, dim3(ngw), dim3(256), 0, st, a, 1);
+            PT_CHECK_LAUNCH();
             hipLaunchKernelGGL(k_gn_vec, dim3(1), dim3(1024), 0, st, a, 1, ii, ncg);
             PT_CHECK_LAUNCH();
         }

@@ -60,8 +60,10 @@ struct MfStage {
 template <int KK, int NT, int VW>
 __global__ __launch_bounds__(256) void k_mf_corr(const float* __restrict__ feat, long stride_n,
                                                  const float* __restrict__ wT, float* __restrict__ scores,
-                                                 long out_stride_n, MfGeom g, int CS) {
+                                                 long out_stride_n, MfGeom g, int CS, long wt_zstride, long out_zstride) {
     extern __shared__ __attribute__((aligned(16))) float lds[];
+    wT += (long)blockIdx.z * wt_zstride;                            // blockIdx.z: group of <= 16 filters of a wider bank
+    scores += (long)blockIdx.z * out_zstride;
     constexpr int NQ = MF_NQ / VW;
     constexpr int K = KK == 1 ? 1 : 3;
     float* __restrict__ fl = lds;                                   // [MF_CK][CS]
@@ -191,7 +193,10 @@ __global__ __launch_bounds__(256) void k_mf_corr(const float* __restrict__ feat,
 // Weights in the order the correlation consumes them: wT[c/4][tap][c%4][16 filters], zero padded to 16 filters and to a
 // multiple of MF_CK channels (one contiguous 16-byte-loadable block per channel chunk).  The old layout makes every lane
 // of a weight load hit its own cache line (filter stride C*K*K floats): 18 such loads per chunk cost more than the MFMAs.
-__global__ void k_mf_wtrans(const float* __restrict__ filt, float* __restrict__ wT, int F, int C, int KK, int Cpad) {
+__global__ void k_mf_wtrans(const float* __restrict__ filt, float* __restrict__ wT, int F, int C, int KK, int Cpad,
+                            long filt_zstride, long wt_zstride) {
+    filt += (long)blockIdx.y * filt_zstride;
+    wT += (long)blockIdx.y * wt_zstride;
     const int e = blockIdx.x * blockDim.x + threadIdx.x;
     if (e >= (Cpad >> 2) * KK * 64) return;
     const int ln = e & 63, tk = e >> 6, tap = tk % KK, c4 = tk / KK;
@@ -209,8 +214,11 @@ __global__ void k_mf_wtrans(const float* __restrict__ filt, float* __restrict__ 
 template <int KK, int VW>
 __global__ __launch_bounds__(256) void k_mf_adj(const float* __restrict__ feat, long stride_n,
                                                 const float* __restrict__ inp, long inp_stride_n,
-                                                float* __restrict__ gpart, MfGeom g, int CS2, int RS2, int spg) {
+                                                float* __restrict__ gpart, MfGeom g, int CS2, int RS2, int spg,
+                                                long inp_zstride, long gp_zstride) {
     extern __shared__ __attribute__((aligned(16))) float lds[];
+    inp += (long)blockIdx.z * inp_zstride;                          // blockIdx.z: group of <= 16 filters of a wider bank
+    gpart += (long)blockIdx.z * gp_zstride;
     constexpr int NQ = MF_NQ / VW;
     constexpr int K = KK == 1 ? 1 : 3;
     float* __restrict__ fl = lds;                                   // [16][CS2]
@@ -391,9 +399,10 @@ static MfPlan mf_plan(int n, int F, int C, int H, int W, int K) {
 
 size_t pt_mf_wt_floats(int C, int K) { return (size_t)(((C + MF_CK - 1) / MF_CK) * MF_CK / 4) * K * K * 64; }
 
-int pt_launch_mf_wtrans(const float* filt, float* wT, int F, int C, int K, hipStream_t st) {
+int pt_launch_mf_wtrans(const float* filt, float* wT, int F, int C, int K, hipStream_t st, int groups) {
     const int Cpad = ((C + MF_CK - 1) / MF_CK) * MF_CK, total = (Cpad >> 2) * K * K * 64;
-    hipLaunchKernelGGL(k_mf_wtrans, dim3((total + 255) / 256), dim3(256), 0, st, filt, wT, F, C, K * K, Cpad);
+    hipLaunchKernelGGL(k_mf_wtrans, dim3((total + 255) / 256, groups), dim3(256), 0, st, filt, wT, F, C, K * K, Cpad,
+                       (long)F * C * K * K, (long)pt_mf_wt_floats(C, K));
     PT_CHECK_LAUNCH();
     return PT_OK;
 }
@@ -413,14 +422,16 @@ static bool mf_vec_ok(const float* a, const float* b, long stride_n, int W) {
 
 // wT: weights pre-transposed by pt_launch_mf_wtrans (pt_mf_wt_floats(C, K) floats, 16-byte aligned)
 int pt_launch_mf_corr(const float* feat, long stride_n, const float* wT, float* scores, int n, int F, int C, int H,
-                      int W, int K, hipStream_t st, long out_stride_n) {
+                      int W, int K, hipStream_t st, long out_stride_n, int groups) {
     MfPlan p = mf_plan(n, F, C, H, W, K);
     if (out_stride_n == 0) out_stride_n = (long)F * H * W;
-    if (!p.ok) return PT_ERR_UNSUPPORTED;
-    dim3 grid(p.g.NB, n), block(256);
+    if (!p.ok || groups < 1) return PT_ERR_UNSUPPORTED;
+    // groups > 1: `groups` banks of F filters each (weight tables back to back, outputs F*H*W apart inside a sample)
+    const long wt_zs = (long)pt_mf_wt_floats(C, K), out_zs = (long)F * H * W;
+    dim3 grid(p.g.NB, n, groups), block(256);
     const bool vec = mf_vec_ok(feat, feat, stride_n, W);
 #define PT_MFC(KKV, NTV, VWV) \
-    hipLaunchKernelGGL((k_mf_corr<KKV, NTV, VWV>), grid, block, p.corr_lds, st, feat, stride_n, wT, scores, out_stride_n, p.g, p.CS)
+    hipLaunchKernelGGL((k_mf_corr<KKV, NTV, VWV>), grid, block, p.corr_lds, st, feat, stride_n, wT, scores, out_stride_n, p.g, p.CS, wt_zs, out_zs)
     if (K == 1) {
         if (p.NT == 2) { if (vec) PT_MFC(1, 2, 4); else PT_MFC(1, 2, 1); }
         else { if (vec) PT_MFC(1, 4, 4); else PT_MFC(1, 4, 1); }
@@ -434,14 +445,16 @@ int pt_launch_mf_corr(const float* feat, long stride_n, const float* wT, float* 
 }
 
 int pt_launch_mf_adj(const float* feat, long stride_n, const float* inp, float* gpart, int n, int F, int C, int H, int W,
-                     int K, hipStream_t st, long inp_stride_n) {
+                     int K, hipStream_t st, long inp_stride_n, int groups) {
     MfPlan p = mf_plan(n, F, C, H, W, K);
     if (inp_stride_n == 0) inp_stride_n = (long)F * H * W;
-    if (!p.ok) return PT_ERR_UNSUPPORTED;
-    dim3 grid((C + 15) / 16, p.NSG), block(256);
+    if (!p.ok || groups < 1) return PT_ERR_UNSUPPORTED;
+    // groups > 1: banks of F filter maps F*H*W apart inside a sample, partials of a bank NSG*F*C*K*K floats apart
+    const long inp_zs = (long)F * H * W, gp_zs = (long)p.NSG * F * C * K * K;
+    dim3 grid((C + 15) / 16, p.NSG, groups), block(256);
     const bool vec = mf_vec_ok(feat, inp, stride_n, W) && ((H * W) % 4) == 0 && (inp_stride_n % 4) == 0;
 #define PT_MFA(KKV, VWV) \
-    hipLaunchKernelGGL((k_mf_adj<KKV, VWV>), grid, block, p.adj_lds, st, feat, stride_n, inp, inp_stride_n, gpart, p.ga, p.CS2, p.RS2, p.spg)
+    hipLaunchKernelGGL((k_mf_adj<KKV, VWV>), grid, block, p.adj_lds, st, feat, stride_n, inp, inp_stride_n, gpart, p.ga, p.CS2, p.RS2, p.spg, inp_zs, gp_zs)
     if (K == 1) { if (vec) PT_MFA(1, 4); else PT_MFA(1, 1); }
     else { if (vec) PT_MFA(9, 4); else PT_MFA(9, 1); }
 #undef PT_MFA

@@ -102,27 +102,42 @@ __global__ void k_prroi_fwd2(Prroi2 a) {
     a.out[l][e] = a.chan_scale[l][c] * prroi_fwd_elem(a.feat[l], a.rois, r, c, p, q, 1, C, a.H[l], a.W[l], PH, PH, a.scale[l]);
 }
 
+// Gradient w.r.t. the features as a GATHER: one thread per feature element (b, c, j, i) walks the RoIs and bins that
+// cover it in a fixed (r, p, q) order and adds its own sum to grad_features -- deterministic (the scatter form needed
+// atomicAdd: run-to-run different sums).  d out[r,c,p,q] / d F[b,c,j,i] = wy_j * wx_i / area.
 __global__ void k_prroi_bwd_feat(const float* __restrict__ gout, const float* __restrict__ rois,
                                  float* __restrict__ gfeat, int N, int C, int H, int W, int R, int PH, int PW,
                                  float scale) {
     const long idx = (long)blockIdx.x * blockDim.x + threadIdx.x;
-    const long total = (long)R * C * PH * PW;
+    const long total = (long)N * C * H * W;
     if (idx >= total) return;
-    const int q = (int)(idx % PW);
-    const int p = (int)((idx / PW) % PH);
-    const int c = (int)((idx / ((long)PW * PH)) % C);
-    const int r = (int)(idx / ((long)PW * PH * C));
-    const Bin k = make_bin(rois + 5 * r, p, q, PH, PW, scale, H, W);
-    if (!(k.area > 0.f) || k.b < 0 || k.b >= N) return;
-    const float g = gout[idx] / k.area;
-    float* __restrict__ f = gfeat + ((long)k.b * C + c) * H * W;
-    for (int j = k.j0; j <= k.j1; ++j) {
-        const float wy = hat_cdf(k.ye - (float)j) - hat_cdf(k.ys - (float)j);
-        for (int i = k.i0; i <= k.i1; ++i) {
-            const float w = wy * (hat_cdf(k.xe - (float)i) - hat_cdf(k.xs - (float)i));
-            if (w != 0.f) atomicAdd(f + j * W + i, g * w);
+    const int i = (int)(idx % W);
+    const int j = (int)((idx / W) % H);
+    const int c = (int)((idx / ((long)W * H)) % C);
+    const int b = (int)(idx / ((long)W * H * C));
+    float acc = 0.f;
+    for (int r = 0; r < R; ++r) {
+        const float* __restrict__ roi = rois + 5 * r;
+        if ((int)roi[0] != b) continue;
+        const float X0 = roi[1] * scale, Y0 = roi[2] * scale, X1 = roi[3] * scale, Y1 = roi[4] * scale;
+        // the pixel's hat function reaches [i-1, i+1] x [j-1, j+1]: RoIs that do not touch it contribute nothing
+        if (X1 <= (float)i - 1.f || X0 >= (float)i + 1.f || Y1 <= (float)j - 1.f || Y0 >= (float)j + 1.f) continue;
+        const float bw = fmaxf(X1 - X0, 0.f) / (float)PW, bh = fmaxf(Y1 - Y0, 0.f) / (float)PH;
+        const float area = bw * bh;
+        if (!(area > 0.f)) continue;
+        const float* __restrict__ g = gout + ((long)r * C + c) * PH * PW;
+        for (int p = 0; p < PH; ++p) {
+            const float ys = Y0 + (float)p * bh, ye = ys + bh;
+            const float wy = hat_cdf(ye - (float)j) - hat_cdf(ys - (float)j);
+            if (wy == 0.f) continue;
+            for (int q = 0; q < PW; ++q) {
+                const float xs = X0 + (float)q * bw, xe = xs + bw;
+                const float w = wy * (hat_cdf(xe - (float)i) - hat_cdf(xs - (float)i));
+                if (w != 0.f) acc += (g[p * PW + q] / area) * w;
+            }
         }
     }
+    if (acc != 0.f) gfeat[idx] += acc;
 }
 
 // Four coordinate sums of RoI r over elements [e0, e1) of its (c,p,q) range, block-reduced in a fixed order (every
@@ -223,7 +238,7 @@ extern "C" int pt_prroi_bwd_feat_f32(const float* grad_out, const float* rois, f
                                      int W, int R, int PH, int PW, float spatial_scale, void* stream) {
     int rc = prroi_check(grad_out, rois, grad_features, N, C, H, W, R, PH, PW);
     if (rc || R == 0) return rc;
-    const long total = (long)R * C * PH * PW;
+    const long total = (long)N * C * H * W;
     hipLaunchKernelGGL(k_prroi_bwd_feat, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, (hipStream_t)stream,
                        grad_out, rois, grad_features, N, C, H, W, R, PH, PW, spatial_scale);
     PT_CHECK_LAUNCH();

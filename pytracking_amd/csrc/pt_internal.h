@@ -83,13 +83,15 @@ int pt_launch_adj2_sd(const PtFast& p, const float* feat, long stride_n, const S
 size_t pt_mf_gpart_floats(int n, int F, int C, int H, int W, int K);     // 0: configuration not covered
 int pt_mf_groups(int n, int F, int C, int H, int W, int K);              // sample groups of the adjoint partials
 size_t pt_mf_wt_floats(int C, int K);                                    // pre-transposed weight table
-int pt_launch_mf_wtrans(const float* filt, float* wT, int F, int C, int K, hipStream_t st);
+int pt_launch_mf_wtrans(const float* filt, float* wT, int F, int C, int K, hipStream_t st, int groups = 1);
 // out_stride_n / inp_stride_n: floats between consecutive samples of scores / inp (0 = dense F*H*W); lets a group of
-// <= 16 filters be a slice of a wider (n, Ftotal, H, W) tensor
+// <= 16 filters be a slice of a wider (n, Ftotal, H, W) tensor; groups > 1: `groups` consecutive banks of F filters in ONE
+// launch (grid.z) -- weight tables pt_mf_wt_floats apart, maps F*H*W apart inside a sample, adjoint partials
+// pt_mf_gpart_floats apart
 int pt_launch_mf_corr(const float* feat, long stride_n, const float* wT, float* scores, int n, int F, int C, int H,
-                      int W, int K, hipStream_t st, long out_stride_n = 0);
+                      int W, int K, hipStream_t st, long out_stride_n = 0, int groups = 1);
 int pt_launch_mf_adj(const float* feat, long stride_n, const float* inp, float* gpart, int n, int F, int C, int H, int W,
-                     int K, hipStream_t st, long inp_stride_n = 0);
+                     int K, hipStream_t st, long inp_stride_n = 0, int groups = 1);
 
 #define PT_CHECK_LAUNCH()                                    \
     do {                                                     \

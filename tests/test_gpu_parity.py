@@ -431,6 +431,11 @@ def test_prroi_forward_backward_vs_oracle(PH, PW, scale, H, W):
     refc = O.prroi_backward_coor(gout.astype(np.float64), feat.astype(np.float64), rois.astype(np.float64), PH, PW, scale)
     close(r.grad, refc, atol=2e-4 * max(1.0, np.abs(refc).max()))
     assert float(r.grad[:, 0].abs().max()) == 0.0
+    g1 = f.grad.clone()                                          # the feature gradient is a fixed-order gather: bit-reproducible
+    f.grad = None
+    r.grad = None
+    PrRoIPool2D(PH, PW, scale)(f, r).backward(T(gout))
+    assert torch.equal(f.grad, g1)
 
 
 def test_prroi_consumers_golden():

@@ -202,6 +202,12 @@ def test_installed_optimizers_fall_back_to_the_reference_forward_off_the_hot_pat
         cg = po.ConjugateGradient(prob, TensorList([torch.zeros(1, 4, 2, 4)]), fletcher_reeves=False)
         from pytracking_amd import optimization as OM
         assert not isinstance(cg, OM.ConjugateGradient) and isinstance(cg, amd._state["originals"]["cg"])
+        # TensorList with more than one feature block (multi-resolution ATOM): the fused path takes single-block
+        # problems only, so such a variable gets the reference class
+        prob2 = ConvProblem(TensorList([torch.zeros(2, 4, 6, 6)] * 2), TensorList([torch.zeros(2, 1, 6, 6)] * 2),
+                            TensorList([0.1, 0.1]), TensorList([torch.ones(2)] * 2), activation.MLU(0.05))
+        cg2 = po.ConjugateGradient(prob2, TensorList([torch.zeros(1, 4, 4, 4), torch.zeros(1, 4, 4, 4)]), fletcher_reeves=False)
+        assert not isinstance(cg2, OM.ConjugateGradient)
     finally:
         amd.uninstall()
 
