@@ -121,6 +121,8 @@ def rocprof_kernel_stats(workload, frames=PROF_FRAMES):
     exe = shutil.which("rocprofv3") or "/opt/rocm/bin/rocprofv3"
     if not os.path.exists(exe):
         return None, "rocprofv3 not found"
+    if any(k.startswith(("ROCPROF", "ROCPROFILER")) for k in os.environ) or "rocprofiler" in os.environ.get("LD_PRELOAD", ""):
+        return None, "this process is itself running under a profiler (its own trace has the kernel durations)"
     tmp = tempfile.mkdtemp(prefix="pt_bench_prof_", dir="/tmp")
     env = dict(os.environ, TMPDIR="/tmp")
     for k in ("RANK", "LOCAL_RANK", "WORLD_SIZE", "MASTER_ADDR", "MASTER_PORT"):
@@ -129,7 +131,7 @@ def rocprof_kernel_stats(workload, frames=PROF_FRAMES):
            sys.executable, os.path.abspath(__file__), "--profile-child", "--steps", str(frames), "--warmup", str(PROF_WARMUP),
            "--workload", workload]
     try:
-        res = subprocess.run(cmd, cwd="/tmp", env=env, capture_output=True, text=True, timeout=600)
+        res = subprocess.run(cmd, cwd="/tmp", env=env, capture_output=True, text=True, timeout=300)
     except Exception as exc:                                  # noqa: BLE001
         shutil.rmtree(tmp, ignore_errors=True)
         return None, f"rocprofv3 did not run: {exc}"
