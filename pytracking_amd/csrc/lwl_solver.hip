@@ -80,7 +80,7 @@ __global__ __launch_bounds__(256) void k_lwl_g(LwlArgs a, int t) {
         a.g[e] = v;
         {                                                           // the same value in the order k_mf_corr reads it
             const int tap = (int)(e % a.KK), c = (int)((e / a.KK) % a.C), f = (int)(e / ((long)a.KK * a.C));
-            a.gT[((long)(c >> 2) * a.KK + tap) * 64 + (c & 3) * 16 + f] = v;
+            a.gT[pt_mf_wt_index(c, f, tap, a.KK)] = v;
         }
         acc += v * v;
     }

@@ -18,8 +18,10 @@
 struct MfGeom {
     int n, F, C, H, W, K, p, KK;
     int BR, NB;          // output rows per band, bands per sample
-    int PWs;             // padded row stride in LDS (W + K - 1)
+    int PWs;             // padded row stride in LDS (W + K - 1): adjoint
     int RSmax;           // staged rows per band (BR + K - 1)
+    int Wp, PS;          // correlation: row length the positions are counted on (roundup4(W)), LDS row stride (Wp + 4)
+    int out_vec;         // correlation: 16-byte stores of the scores are legal
 };
 
 
@@ -45,163 +47,263 @@ struct MfStage {
 };
 
 // ---------------------------------------------------------------------------------------------------
-// correlation: grid (NB, n), 256 threads.  Channels are streamed in chunks of MF_CK (MF_KS MFMA k-steps); wave w stages
-// channels w, w+4, ... of the chunk (and a quarter of the weights) while the previous chunk is being multiplied.
-// LDS: fl[MF_CK][CS] zero-padded feature band (channel stride CS == 16 mod 32: conflict-free ds_read_b32 of the B operand),
-//      wl[MF_KS][KK][64] weights in MFMA-A order (lane = kq*16 + f).
-// Wave w owns the 16-position tiles w, w+4, ... of the band (NT per wave).  The band height is chosen so that the grid
-// holds >= 2 workgroups per CU: a workgroup puts one wave on each SIMD, the second one hides its LDS / barrier latency.
+// correlation: grid (NB, n), 512 threads, one band of BR output rows per workgroup.
+//
+// What bounds it (experiments/mfma_issue.hip, profiles/r02i_mfma_issue_microbench.json): on this chip nothing issues in
+// the shadow of a v_mfma_f32_16x16x4_f32 -- every other VALU instruction of the wavefront costs ~5 cycles on top of the
+// MFMA's 32, every LDS instruction ~4-8.  So the kernel is laid out for FEW instructions per MFMA, not for overlap:
+//   * positions are counted on rows padded to Wp = roundup4(W); lane (kq, j) of wave w owns the 4 CONSECUTIVE positions
+//     64w + 4j + q, q = 0..3 (its 4 MFMA tiles).  One ds_read_b128 and two ds_read_b32 of the padded row (6 floats) hold
+//     the B operands of all 4 tiles x 3 horizontal taps: 9 LDS reads per 36 MFMAs of a k-step (was 29);
+//   * the weights sit in LDS as [k-step][lane][12] (9 taps + pad): 3 ds_read_b128 per k-step, conflict-free (lane stride
+//     12 dwords); k_mf_wtrans writes the table in exactly this order, staging it is a straight 16-byte copy;
+//   * no masks on the operands: lanes beyond the band read offset 0 and only feed output columns that are never stored.
+// Channels are streamed in chunks of MF_CK (MF_KS k-steps) through two LDS buffers:
+//      fl[MF_CK][CS]   zero-padded band: 4 floats, then rows of PS = Wp + 4 floats with the data at column x -- the zero
+//                      tail of a row is the left padding of the next one, and a float4 of the image lands 16-byte aligned
+//                      (at column p + x every lane's 4 ds_write_b32 hit 16 banks: the staging stores alone took 1500 of
+//                      a chunk's 6800 cycles, profiles/r02i_lwl_kernel_ablation.txt)
+//      wl[MF_KS][64][TP]
+// 8 waves: wave w owns position group w & 3 (64 positions) and k-steps 2(w>>2), 2(w>>2)+1 of every chunk -- two waves per
+// SIMD, because a wave's LDS / global / barrier time does not overlap its own MFMAs either (measured: with one wave per
+// SIMD every component adds linearly, profiles/r02i_lwl_kernel_ablation.txt); the two halves are summed through LDS at
+// the end.  Wave w stages channels w and w+8 of a chunk.  Per wave, while chunk c is multiplied out of buffer c&1, chunk
+// c+1 goes from registers into the other buffer and the global loads of chunk c+2 are issued.  The chunk's barrier sits in
+// front of the wave's second k-step (see the loop).
 // ---------------------------------------------------------------------------------------------------
-#define MF_CK 32
+#define MF_CK 16
 #define MF_KS (MF_CK / 4)
-#define MF_CW (MF_CK / 4)  // channels staged per wave
 #define MF_NQ 8            // scalar staging items per lane per plane: rows*W <= 512
+#define MF_TP(KK) ((KK) == 1 ? 1 : 12)   // weight floats per lane per k-step (pt_mf_wt_index)
+#define MF_CT 512          // threads of the correlation workgroup
 
-template <int KK, int NT, int VW>
-__global__ __launch_bounds__(256) void k_mf_corr(const float* __restrict__ feat, long stride_n,
-                                                 const float* __restrict__ wT, float* __restrict__ scores,
-                                                 long out_stride_n, MfGeom g, int CS, long wt_zstride, long out_zstride) {
+template <int KK, int VW>
+__global__ __launch_bounds__(MF_CT) void k_mf_corr(const float* __restrict__ feat, long stride_n,
+                                                   const float* __restrict__ wT, float* __restrict__ scores,
+                                                   long out_stride_n, MfGeom g, int CS, long wt_zstride, long out_zstride) {
     extern __shared__ __attribute__((aligned(16))) float lds[];
     wT += (long)blockIdx.z * wt_zstride;                            // blockIdx.z: group of <= 16 filters of a wider bank
     scores += (long)blockIdx.z * out_zstride;
     constexpr int NQ = MF_NQ / VW;
     constexpr int K = KK == 1 ? 1 : 3;
-    float* __restrict__ fl = lds;                                   // [MF_CK][CS]
-    float* __restrict__ wl = lds + MF_CK * CS;                      // [MF_KS][KK][64]
+    constexpr int TP = MF_TP(KK);
+    constexpr int NB6 = K == 1 ? 4 : 6;                             // floats of a padded row one lane reads per (k-step, u)
+    constexpr int WITEMS = MF_KS * 64 * TP / 4;                     // float4 items of a chunk's weight block
+    constexpr int WN = (WITEMS + MF_CT - 1) / MF_CT;
+    static_assert(MF_KS == 4 && MF_CK == 16 && WN <= 2, "two k-steps and two staging pieces per wave and chunk");
+    const int BUF = MF_CK * CS + MF_KS * 64 * TP;                   // floats per buffer
     const int band = blockIdx.x, i = blockIdx.y;
-    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const int lane = threadIdx.x & 63, wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+    const int pg = wave & 3, kh = wave >> 2;
     const int kq = lane >> 4, j = lane & 15;
     const int y0 = band * g.BR, rows = min(g.BR, g.H - y0);
-    const int HW = g.H * g.W, npos = rows * g.W;
+    const int HW = g.H * g.W;
     const float inv_w = 1.0f / (float)g.W;
     const float* __restrict__ fi = feat + (long)i * stride_n;
 
-    for (int e = threadIdx.x; e < MF_CK * CS; e += 256) fl[e] = 0.f;          // padding (and rows outside the image) stay zero
+    for (int e = threadIdx.x; e < 2 * BUF; e += MF_CT) lds[e] = 0.f;   // padding (and rows outside the image) stay zero
 
     // image rows [ys, ye) of the band + halo are contiguous in every channel plane
     const int ys = max(y0 - g.p, 0), ye = min(y0 + rows + g.p, g.H);
     MfStage<VW, NQ> sp;
-    sp.plan(lane, ys, ye - ys, g.W, inv_w, ys - (y0 - g.p), g.PWs, g.p);
-    // weights: the chunk's [MF_KS][KK][64] block is contiguous in the pre-transposed table wT (k_mf_wtrans): 16-byte loads
-    constexpr int WN = (MF_KS * KK * 16 + 255) / 256;               // float4 items per thread
+    sp.plan(lane, ys, ye - ys, g.W, inv_w, ys - (y0 - g.p), g.PS, 4);
+    const int nchunks = (g.C + MF_CK - 1) / MF_CK;
 
-    // ---- tile geometry of this wave
-    int t_off[NT];
-    bool t_ok[NT];
+    // ---- the 4 positions of this lane: P0 .. P0 + 3 on rows of Wp
+    const int P0 = 64 * pg + 4 * j;
+    const int pr = P0 / g.Wp, px = P0 - pr * g.Wp;
+    const int t_off = 4 + (pr < rows ? pr * g.PS + px : 0);
+    f32x4 acc[4];
 #pragma unroll
-    for (int q = 0; q < NT; ++q) {
-        const int pj = 16 * (wave + 4 * q) + j;
-        const int r = mf_fdiv(pj, inv_w), x = pj - r * g.W;
-        t_ok[q] = pj < npos;
-        t_off[q] = t_ok[q] ? r * g.PWs + x : 0;
-    }
-    f32x4 acc[NT];
-#pragma unroll
-    for (int q = 0; q < NT; ++q) acc[q] = (f32x4){0, 0, 0, 0};
+    for (int q = 0; q < 4; ++q) acc[q] = (f32x4){0, 0, 0, 0};
 
-    float sv[MF_CW][NQ][VW];
+    float sv[2][NQ][VW];
     f32x4 wv[WN];
-    // fetch: raw loads only (clamped addresses); the validity masks are applied when the values are written to LDS.
-    // A select right behind each load makes the compiler wait for that load before issuing the next one (measured: 26
-    // serialised L2 round trips = 3.6 us of a 7.5 us chunk).
-    auto fetch = [&](int c0) {
+    // piece cc (0, 1) of a chunk = channel wave + 8 cc (NQ loads) and weight item cc.  Buffer loads: SGPR base (channel
+    // plane / chunk block) + invariant VGPR offset, no address arithmetic on the VALU; an item without a source has an
+    // out-of-range offset (reads 0) and goes to the thread's dump slot.  A chunk index beyond the last one re-fetches
+    // the last chunk; a channel >= C (channel count not a multiple of MF_CK) reads channel C - 1 against zero weights.
+    const __amdgpu_buffer_rsrc_t rsF = pt_rsrc(fi, (unsigned)g.C * (unsigned)HW * 4u);
+    const __amdgpu_buffer_rsrc_t rsW = pt_rsrc(wT, (unsigned)nchunks * (unsigned)(MF_KS * 64 * TP) * 4u);
+    const int dump = 2 * BUF + 4 * threadIdx.x;
+    unsigned goff[NQ], woff[WN];
+    int lrow[NQ], lwt[WN];
 #pragma unroll
-        for (int cc = 0; cc < MF_CW; ++cc) {
-            const int c = c0 + wave + 4 * cc;
-            const float* __restrict__ fc = fi + (long)min(c, g.C - 1) * HW;
-#pragma unroll
-            for (int q = 0; q < NQ; ++q) {
-                if (VW == 4) {
-                    const f32x4 v = *(const f32x4*)(fc + max(sp.g[q], 0));
-#pragma unroll
-                    for (int m = 0; m < 4; ++m) sv[cc][q][m] = v[m];
-                } else {
-                    sv[cc][q][0] = fc[max(sp.g[q], 0)];
-                }
-            }
-        }
-        const f32x4* __restrict__ wc = (const f32x4*)(wT + (long)(c0 >> 2) * KK * 64);
-#pragma unroll
-        for (int q = 0; q < WN; ++q) wv[q] = wc[min((int)threadIdx.x + 256 * q, MF_KS * KK * 16 - 1)];
-    };
-    auto stage = [&](int c0) {
-#pragma unroll
-        for (int cc = 0; cc < MF_CW; ++cc) {
-            float* __restrict__ fc = fl + (wave + 4 * cc) * CS;
-            const bool cok = c0 + wave + 4 * cc < g.C;
-#pragma unroll
-            for (int q = 0; q < NQ; ++q)
-                if (sp.g[q] >= 0) {
-#pragma unroll
-                    for (int m = 0; m < VW; ++m) fc[sp.l[q] + m] = cok ? sv[cc][q][m] : 0.f;
-                }
-        }
-#pragma unroll
-        for (int q = 0; q < WN; ++q) {
-            const int e = threadIdx.x + 256 * q;
-            if (e < MF_KS * KK * 16) ((f32x4*)wl)[e] = wv[q];
-        }
-    };
-
-    fetch(0);
-    __syncthreads();                                                // zero fill done
-    for (int c0 = 0; c0 < g.C; c0 += MF_CK) {
-        stage(c0);
-        __syncthreads();
-        if (c0 + MF_CK < g.C) fetch(c0 + MF_CK);   // next chunk in flight while this one is multiplied
-        // LDS operands of k-step ks+1 (KK A values, KK x NT B values) are read while the MFMAs of k-step ks issue: a
-        // workgroup has one wave per SIMD, so nothing else hides the LDS latency.  No per-tile branch: a tile beyond the
-        // band multiplies zeros (t_ok false), far cheaper than putting every MFMA into its own basic block.
-        float av[2][KK], bv[2][KK][NT];
-        auto lds_operands = [&](int ks, int set) {
-            const float* __restrict__ fb = fl + (4 * ks + kq) * CS;
-#pragma unroll
-            for (int tap = 0; tap < KK; ++tap) {
-                const int u = tap / K, v = tap - u * K;
-                av[set][tap] = wl[(ks * KK + tap) * 64 + lane];
-#pragma unroll
-                for (int q = 0; q < NT; ++q) bv[set][tap][q] = fb[t_off[q] + u * g.PWs + v];
-            }
-        };
-        lds_operands(0, 0);
-#pragma unroll
-        for (int ks = 0; ks < MF_KS; ++ks) {
-            if (ks + 1 < MF_KS) lds_operands(ks + 1, (ks + 1) & 1);
-#pragma unroll
-            for (int tap = 0; tap < KK; ++tap) {
-#pragma unroll
-                for (int q = 0; q < NT; ++q) {
-                    acc[q] = mfma16(av[ks & 1][tap], t_ok[q] ? bv[ks & 1][tap][q] : 0.f, acc[q]);
-                }
-            }
-        }
-        __syncthreads();
+    for (int q = 0; q < NQ; ++q) {
+        goff[q] = sp.g[q] >= 0 ? 4u * (unsigned)sp.g[q] : 0x80000000u;
+        lrow[q] = sp.g[q] >= 0 ? sp.l[q] : -1;
     }
 #pragma unroll
-    for (int q = 0; q < NT; ++q) {
-        const int pj = 16 * (wave + 4 * q) + j;
-        if (pj < npos) {
+    for (int cc = 0; cc < WN; ++cc) {
+        const int e = threadIdx.x + MF_CT * cc;
+        woff[cc] = e < WITEMS ? 16u * e : 0x80000000u;
+        lwt[cc] = e < WITEMS ? MF_CK * CS + 4 * e : -1;
+    }
+    auto fetch_piece = [&](int ci, int cc) {
+        const int c0 = min(ci, nchunks - 1) * MF_CK;
+        const unsigned soff = (unsigned)min(c0 + wave + 8 * cc, g.C - 1) * (unsigned)HW * 4u;
 #pragma unroll
-            for (int r = 0; r < 4; ++r) {
-                const int f = 4 * kq + r;
-                if (f < g.F) scores[(long)i * out_stride_n + (long)f * HW + (long)y0 * g.W + pj] = acc[q][r];
+        for (int q = 0; q < NQ; ++q) {
+            if (VW == 4) {
+                const f32x4 v = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(rsF, goff[q], soff, 0));
+#pragma unroll
+                for (int m = 0; m < 4; ++m) sv[cc][q][m] = v[m];
+            } else {
+                sv[cc][q][0] = __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(rsF, goff[q], soff, 0));
+            }
+        }
+        if (cc < WN)
+            wv[cc] = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(rsW, woff[cc], (unsigned)(c0 >> 2) * (64 * TP * 4), 0));
+    };
+    auto stage_piece = [&](int buf, int cc) {
+        const int row = buf * BUF + (wave + 8 * cc) * CS;
+#pragma unroll
+        for (int q = 0; q < NQ; ++q) {
+            const int at = lrow[q] >= 0 ? row + lrow[q] : dump;
+            if (VW == 4) *(f32x4*)(lds + at) = (f32x4){sv[cc][q][0], sv[cc][q][1], sv[cc][q][2], sv[cc][q][3]};
+            else lds[at] = sv[cc][q][0];
+        }
+        if (cc < WN) *(f32x4*)(lds + (lwt[cc] >= 0 ? buf * BUF + lwt[cc] : dump)) = wv[cc];
+    };
+    // LDS operands of one k-step: the lane's weights of all taps, and per vertical tap NB6 floats of the padded row --
+    // NRD single read instructions (read_op), so that they can be placed one by one between the MFMAs.
+    float av[2][KK], bv[2][K][NB6];
+    constexpr int NRD = KK == 1 ? 2 : 12;
+    auto read_op = [&](int buf, int ks, int set, int k) {
+        const float* __restrict__ fb = lds + buf * BUF + (4 * ks + kq) * CS + t_off;
+        const float* __restrict__ wl = lds + buf * BUF + MF_CK * CS + (ks * 64 + lane) * TP;
+        if (KK == 1) {
+            if (k == 0) av[set][0] = wl[0];
+            if (k == 1) {
+                const f32x4 v = *(const f32x4*)fb;
+#pragma unroll
+                for (int e = 0; e < 4; ++e) bv[set][0][e] = v[e];
+            }
+            return;
+        }
+        if (k < 2) {                                                // 9 of the 12 floats: a register that is loaded but
+            const f32x4 v = *(const f32x4*)(wl + 4 * k);            // never read gets reused while the load is in flight
+#pragma unroll
+            for (int e = 0; e < 4; ++e) av[set][4 * k + e] = v[e];
+        } else if (k == 2) {
+            av[set][8] = wl[8];
+        } else {                                                    // columns px - 1 .. px + 4 of row pr + u
+            const int u = (k - 3) / 3, part = (k - 3) % 3;
+            if (part == 0) {
+                const f32x4 v = *(const f32x4*)(fb + u * g.PS);
+#pragma unroll
+                for (int e = 0; e < 4; ++e) bv[set][u][e + 1] = v[e];
+            } else if (part == 1) {
+                bv[set][u][0] = fb[u * g.PS - 1];
+            } else {
+                bv[set][u][5] = fb[u * g.PS + 4];
+            }
+        }
+    };
+    auto lds_operands = [&](int buf, int ks, int set) {
+#pragma unroll
+        for (int k = 0; k < NRD; ++k) read_op(buf, ks, set, k);
+    };
+    // One k-step: the MFMAs on operand set `set`, and behind the first ones, one each and pinned there (left alone the
+    // scheduler sinks every read to its first use), the memory instructions that go with it: the operand reads of the
+    // wave's next k-step (rbuf, rks -> the other set; they need the rest of this k-step to land), the LDS stores of
+    // staging piece cc into sbuf, the loads that refill its registers from chunk fci.
+    auto kstep = [&](int set, int rbuf, int rks, int sbuf, int cc, int fci) {
+        constexpr int NMF = KK * 4;
+#pragma unroll
+        for (int m = 0; m < NMF; ++m) {
+            const int tap = m / 4, q = m - 4 * tap, u = tap / K, v = tap - u * K;
+            acc[q] = mfma16(av[set][tap], bv[set][u][q + v], acc[q]);
+            if (KK > 1) {
+                __builtin_amdgcn_sched_barrier(0);
+                if (m < NRD) read_op(rbuf, rks, set ^ 1, m);
+                if (m == NRD) stage_piece(sbuf, cc);
+                if (m == NRD + 3) fetch_piece(fci, cc);
+                __builtin_amdgcn_sched_barrier(0);
+            }
+        }
+        if (KK == 1) {
+            lds_operands(rbuf, rks, set ^ 1);
+            stage_piece(sbuf, cc);
+            fetch_piece(fci, cc);
+        }
+        __builtin_amdgcn_sched_barrier(0);
+    };
+
+    fetch_piece(0, 0);
+    fetch_piece(0, 1);
+    __syncthreads();                                                // zero fill done
+    stage_piece(0, 0);
+    stage_piece(0, 1);
+    fetch_piece(1, 0);
+    fetch_piece(1, 1);
+    stage_piece(1, 0);
+    fetch_piece(2, 0);
+    __syncthreads();
+    lds_operands(0, 2 * kh, 0);
+    __builtin_amdgcn_sched_barrier(0);
+    // Registers hold chunk c+1 piece 1 and chunk c+2 piece 0 when chunk c starts.  With a k-step's MFMAs go: the reads of
+    // the wave's NEXT k-step, one staging piece (registers -> LDS) and the loads that refill those registers.
+    //   first k-step : reads of the second one; piece 1 of chunk c+1 -> other buffer; loads piece 1 of chunk c+2
+    //   second k-step: reads of chunk c+1's first one from the other buffer; piece 0 of chunk c+2 -> this buffer (nobody
+    //                  reads it any more); loads piece 0 of chunk c+3
+    // so the chunk's barrier sits between the two.
+    const int k0 = 2 * kh, k1 = 2 * kh + 1;
+    for (int ci = 0; ci < nchunks; ci += 2) {
+        kstep(0, 0, k1, 1, 1, ci + 2);
+        __syncthreads();
+        kstep(1, 1, k0, 0, 0, ci + 3);
+        if (ci + 1 < nchunks) {
+            kstep(0, 1, k1, 0, 1, ci + 3);
+            __syncthreads();
+            kstep(1, 0, k0, 1, 0, ci + 4);
+        }
+    }
+    // sum of the two k halves: waves 4..7 hand their accumulators to waves 0..3 through LDS ([pg][q][r][lane])
+    __syncthreads();
+    if (kh == 1) {
+#pragma unroll
+        for (int q = 0; q < 4; ++q)
+#pragma unroll
+            for (int r = 0; r < 4; ++r) lds[((pg * 4 + q) * 4 + r) * 64 + lane] = acc[q][r];
+    }
+    __syncthreads();
+    if (kh == 1) return;
+#pragma unroll
+    for (int q = 0; q < 4; ++q)
+#pragma unroll
+        for (int r = 0; r < 4; ++r) acc[q][r] += lds[((pg * 4 + q) * 4 + r) * 64 + lane];
+    // lane (kq, j), tile q, register r: filter 4 kq + r at position P0 + q
+    if (pr < rows) {
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+            const int f = 4 * kq + r;
+            float* __restrict__ o = scores + (long)i * out_stride_n + (long)f * HW + (long)(y0 + pr) * g.W + px;
+            if (f < g.F) {
+                if (VW == 4 && g.out_vec) {
+                    if (px < g.W) *(f32x4*)o = (f32x4){acc[0][r], acc[1][r], acc[2][r], acc[3][r]};
+                } else {
+#pragma unroll
+                    for (int q = 0; q < 4; ++q)
+                        if (px + q < g.W) o[q] = acc[q][r];
+                }
             }
         }
     }
 }
 
-// Weights in the order the correlation consumes them: wT[c/4][tap][c%4][16 filters], zero padded to 16 filters and to a
-// multiple of MF_CK channels (one contiguous 16-byte-loadable block per channel chunk).  The old layout makes every lane
-// of a weight load hit its own cache line (filter stride C*K*K floats): 18 such loads per chunk cost more than the MFMAs.
+// Weights in the order the correlation consumes them: wT[c/4][lane = (c%4)*16 + filter][MF_TP taps], zero padded to 16
+// filters, to 12 taps and to a multiple of MF_CK channels (one contiguous 16-byte-loadable block per channel chunk).
 __global__ void k_mf_wtrans(const float* __restrict__ filt, float* __restrict__ wT, int F, int C, int KK, int Cpad,
                             long filt_zstride, long wt_zstride) {
     filt += (long)blockIdx.y * filt_zstride;
     wT += (long)blockIdx.y * wt_zstride;
+    const int TP = MF_TP(KK);
     const int e = blockIdx.x * blockDim.x + threadIdx.x;
-    if (e >= (Cpad >> 2) * KK * 64) return;
-    const int ln = e & 63, tk = e >> 6, tap = tk % KK, c4 = tk / KK;
+    if (e >= (Cpad >> 2) * 64 * TP) return;
+    const int tap = e % TP, ln = (e / TP) & 63, c4 = e / (TP * 64);
     const int f = ln & 15, c = 4 * c4 + (ln >> 4);
-    wT[e] = (f < F && c < C) ? filt[((long)f * C + c) * KK + tap] : 0.f;
+    wT[e] = (tap < KK && f < F && c < C) ? filt[((long)f * C + c) * KK + tap] : 0.f;
 }
 
 // ---------------------------------------------------------------------------------------------------
@@ -299,21 +401,45 @@ __global__ __launch_bounds__(256) void k_mf_adj(const float* __restrict__ feat, 
         const int rows = min(g.BR, g.H - band * g.BR), npos = rows * g.W;
         const float* __restrict__ fb = fl + j * CS2;
         const float* __restrict__ rb = rl + j * RS2;
+        // one k-step of LDS operands is read ahead of the MFMAs that consume it (a workgroup has one wave per SIMD; left to
+        // the scheduler the reads sit right in front of their first use: 2-3 exposed LDS round trips per 9 MFMAs)
+        float a_n, b_n[KK];
+        bool ok_n, ok_a;
+        int pc_a, po_a;                                             // LDS offsets of the k-step after the one in a_n / b_n
+        auto address = [&](int s) {
+            const int pos = 4 * s + kq;
+            ok_a = pos < npos;
+            pc_a = ok_a ? pos : 0;                                  // beyond the band: position 0, multiplied by a = 0
+            const int r = mf_fdiv(pc_a, inv_w), x = pc_a - r * g.W;
+            po_a = r * g.PWs + x;
+        };
+        auto operands = [&]() {
+            ok_n = ok_a;
+            a_n = rb[pc_a];
+#pragma unroll
+            for (int tap = 0; tap < KK; ++tap) b_n[tap] = fb[po_a + (tap / K) * g.PWs + (tap % K)];
+        };
+        address(wave);
+        operands();
+        address(wave + 4);
 #pragma unroll 2
         for (int s = wave; 4 * s < npos; s += 4) {
-            const int pos = 4 * s + kq;
-            const bool ok = pos < npos;
-            const int pc = ok ? pos : 0;
-            const int r = mf_fdiv(pc, inv_w), x = pc - r * g.W;
-            const float a0 = rb[pc];
-            const float a = ok ? a0 : 0.f;
-            const int po = r * g.PWs + x;
+            const float a = ok_n ? a_n : 0.f;                       // masked k: a = 0, b finite (LDS holds data or zeros)
             float bv[KK];
 #pragma unroll
-            for (int tap = 0; tap < KK; ++tap) bv[tap] = fb[po + (tap / K) * g.PWs + (tap % K)];
+            for (int tap = 0; tap < KK; ++tap) bv[tap] = b_n[tap];
+            operands();                                             // k-step s + 4: reads first, a full k-step to land
+            address(s + 8);
 #pragma unroll
-            for (int tap = 0; tap < KK; ++tap)
-                acc[tap] = mfma16(a, bv[tap], acc[tap]);            // masked k: a = 0, b finite (LDS holds data or zeros)
+            for (int tap = 0; tap < KK; ++tap) acc[tap] = mfma16(a, bv[tap], acc[tap]);
+            // issue order: the reads and the address arithmetic go into the shadows of these MFMAs
+#pragma unroll
+            for (int tap = 0; tap < KK; ++tap) {
+                __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);  // 1 MFMA
+                __builtin_amdgcn_sched_group_barrier(0x100, 3, 0);  // <= 3 LDS reads
+                __builtin_amdgcn_sched_group_barrier(0x002, 3, 0);  // <= 3 VALU
+            }
+            __builtin_amdgcn_sched_barrier(0);
         }
         __syncthreads();
     }
@@ -339,7 +465,6 @@ struct MfPlan {
     int ok;
     MfGeom g;            // correlation geometry
     MfGeom ga;           // adjoint geometry
-    int NT;              // correlation: tiles per wave (2 or 4)
     int CS, CS2, RS2, spg, NSG;
     size_t corr_lds, adj_lds;
 };
@@ -355,22 +480,22 @@ static MfPlan mf_plan(int n, int F, int C, int H, int W, int K) {
     p.ok = 0;
     if (n <= 0 || F <= 0 || F > 16 || C <= 0 || H <= 0 || W <= 0) return p;
     if (K != 1 && K != 3) return p;
-    if (W > 256 || (long)n * C * H * W >= (1L << 31) || (long)F * C * K * K >= (1L << 30)) return p;
+    if (W > 256 || (long)n * C * H * W >= (1L << 31) || (long)C * H * W >= (1L << 30) || (long)F * C * K * K >= (1L << 30)) return p;
     MfGeom& g = p.g;
     g.n = n; g.F = F; g.C = C; g.H = H; g.W = W; g.K = K; g.p = K / 2; g.KK = K * K;
     g.PWs = W + K - 1;
-    // correlation band: <= 256 positions (4 tiles per wave) and <= 512 staged floats per channel; shrink it until the
-    // grid holds ~2 workgroups per CU
-    int BR = 256 / W;
+    // correlation band: <= 256 positions counted on rows of Wp (4 consecutive positions per lane) and <= 512 staged floats
+    // per channel; a small problem gets shorter bands until the grid covers the CUs, as long as half the lanes stay busy
+    g.Wp = (W + 3) & ~3;
+    g.PS = g.Wp + 4;
+    g.out_vec = 0;
+    int BR = 256 / g.Wp;
     if (BR > H) BR = H;
-    while (BR > 1 && ((BR + K - 1) * W > 64 * MF_NQ ||
-                      (n * ((H + BR - 1) / BR) < 512 && (BR - 1) * W >= 96)))      // keep >= 6 of a wave quad's 8 tile slots busy
-        --BR;
-    if ((BR + K - 1) * W > 64 * MF_NQ || BR * W > 256) return p;
+    while (BR > 1 && ((BR + K - 1) * W > 64 * MF_NQ || (n * ((H + BR - 1) / BR) < 256 && (BR - 1) * g.Wp >= 128))) --BR;
+    if (BR < 1 || (BR + K - 1) * W > 64 * MF_NQ || BR * g.Wp > 256) return p;
     g.BR = BR;
     g.NB = (H + BR - 1) / BR;
     g.RSmax = BR + K - 1;
-    p.NT = (BR * W + 15) / 16 <= 8 ? 2 : 4;
     // adjoint band: as above without the grid-size constraint (its grid is channel blocks x sample groups)
     p.ga = g;
     int BRa = 256 / W;
@@ -380,10 +505,10 @@ static MfPlan mf_plan(int n, int F, int C, int H, int W, int K) {
     p.ga.BR = BRa;
     p.ga.NB = (H + BRa - 1) / BRa;
     p.ga.RSmax = BRa + K - 1;
-    p.CS = mf_pad_to(g.RSmax * g.PWs, 32, 16);
+    p.CS = 4 + g.RSmax * g.PS;
     p.CS2 = mf_pad_to(p.ga.RSmax * g.PWs, 32, 2);
     p.RS2 = mf_pad_to(BRa * W, 32, 2);
-    p.corr_lds = ((size_t)MF_CK * p.CS + MF_KS * g.KK * 64) * sizeof(float);
+    p.corr_lds = std::max(2 * ((size_t)MF_CK * p.CS + MF_KS * 64 * MF_TP(g.KK)) + 4 * MF_CT, (size_t)4096) * sizeof(float);   // two buffers + dump slots | k-half sum
     p.adj_lds = std::max((size_t)16 * (p.CS2 + p.RS2), (size_t)4 * g.KK * 256) * sizeof(float);
     const int CBn = (C + 15) / 16;
     int NSG = 512 / CBn;                                 // ~2 workgroups per CU
@@ -397,10 +522,10 @@ static MfPlan mf_plan(int n, int F, int C, int H, int W, int K) {
     return p;
 }
 
-size_t pt_mf_wt_floats(int C, int K) { return (size_t)(((C + MF_CK - 1) / MF_CK) * MF_CK / 4) * K * K * 64; }
+size_t pt_mf_wt_floats(int C, int K) { return (size_t)(((C + MF_CK - 1) / MF_CK) * MF_CK / 4) * 64 * MF_TP(K * K); }
 
 int pt_launch_mf_wtrans(const float* filt, float* wT, int F, int C, int K, hipStream_t st, int groups) {
-    const int Cpad = ((C + MF_CK - 1) / MF_CK) * MF_CK, total = (Cpad >> 2) * K * K * 64;
+    const int Cpad = ((C + MF_CK - 1) / MF_CK) * MF_CK, total = (Cpad >> 2) * 64 * MF_TP(K * K);
     hipLaunchKernelGGL(k_mf_wtrans, dim3((total + 255) / 256, groups), dim3(256), 0, st, filt, wT, F, C, K * K, Cpad,
                        (long)F * C * K * K, (long)pt_mf_wt_floats(C, K));
     PT_CHECK_LAUNCH();
@@ -428,17 +553,13 @@ int pt_launch_mf_corr(const float* feat, long stride_n, const float* wT, float* 
     if (!p.ok || groups < 1) return PT_ERR_UNSUPPORTED;
     // groups > 1: `groups` banks of F filters each (weight tables back to back, outputs F*H*W apart inside a sample)
     const long wt_zs = (long)pt_mf_wt_floats(C, K), out_zs = (long)F * H * W;
-    dim3 grid(p.g.NB, n, groups), block(256);
+    dim3 grid(p.g.NB, n, groups), block(MF_CT);
     const bool vec = mf_vec_ok(feat, feat, stride_n, W);
-#define PT_MFC(KKV, NTV, VWV) \
-    hipLaunchKernelGGL((k_mf_corr<KKV, NTV, VWV>), grid, block, p.corr_lds, st, feat, stride_n, wT, scores, out_stride_n, p.g, p.CS, wt_zs, out_zs)
-    if (K == 1) {
-        if (p.NT == 2) { if (vec) PT_MFC(1, 2, 4); else PT_MFC(1, 2, 1); }
-        else { if (vec) PT_MFC(1, 4, 4); else PT_MFC(1, 4, 1); }
-    } else {
-        if (p.NT == 2) { if (vec) PT_MFC(9, 2, 4); else PT_MFC(9, 2, 1); }
-        else { if (vec) PT_MFC(9, 4, 4); else PT_MFC(9, 4, 1); }
-    }
+    p.g.out_vec = vec && ((uintptr_t)scores % 16) == 0 && (out_stride_n % 4) == 0 && ((H * W) % 4) == 0;
+#define PT_MFC(KKV, VWV) \
+    hipLaunchKernelGGL((k_mf_corr<KKV, VWV>), grid, block, p.corr_lds, st, feat, stride_n, wT, scores, out_stride_n, p.g, p.CS, wt_zs, out_zs)
+    if (K == 1) { if (vec) PT_MFC(1, 4); else PT_MFC(1, 1); }
+    else { if (vec) PT_MFC(9, 4); else PT_MFC(9, 1); }
 #undef PT_MFC
     PT_CHECK_LAUNCH();
     return PT_OK;

@@ -83,6 +83,10 @@ int pt_launch_adj2_sd(const PtFast& p, const float* feat, long stride_n, const S
 size_t pt_mf_gpart_floats(int n, int F, int C, int H, int W, int K);     // 0: configuration not covered
 int pt_mf_groups(int n, int F, int C, int H, int W, int K);              // sample groups of the adjoint partials
 size_t pt_mf_wt_floats(int C, int K);                                    // pre-transposed weight table
+// position of weight (filter f, channel c, tap) in that table: [c/4][lane = (c%4)*16 + f][12 taps (9 used) | 1 tap]
+__host__ __device__ inline long pt_mf_wt_index(int c, int f, int tap, int KK) {
+    return ((long)(c >> 2) * 64 + (c & 3) * 16 + f) * (KK == 1 ? 1 : 12) + tap;
+}
 int pt_launch_mf_wtrans(const float* filt, float* wT, int F, int C, int K, hipStream_t st, int groups = 1);
 // out_stride_n / inp_stride_n: floats between consecutive samples of scores / inp (0 = dense F*H*W); lets a group of
 // <= 16 filters be a slice of a wider (n, Ftotal, H, W) tensor; groups > 1: `groups` consecutive banks of F filters in ONE
