@@ -27,6 +27,11 @@ struct MfGeom {
 
 __device__ __forceinline__ int mf_fdiv(int v, float inv_d) { return (int)(((float)v + 0.5f) * inv_d); }
 
+// 16-byte LDS accesses.  Through a plain cast of `lds + offset` clang derives the alignment from the array (4 bytes for an
+// unknown offset) and the backend splits the access into two ds_read2_b32 / ds_write2_b32.
+__device__ __forceinline__ f32x4 mf_lds_ld4(const float* p) { return *(const f32x4*)__builtin_assume_aligned(p, 16); }
+__device__ __forceinline__ void mf_lds_st4(float* p, f32x4 v) { *(f32x4*)__builtin_assume_aligned(p, 16) = v; }
+
 // Staging plan of one lane for a (rows x W) block that is contiguous in global memory (full-width rows): item q covers
 // VW consecutive floats starting at e = VW*(lane + 64*q).  VW = 4 needs W % 4 == 0 (an item never straddles a row).
 template <int VW, int NQ>
@@ -160,10 +165,10 @@ __global__ __launch_bounds__(MF_CT) void k_mf_corr(const float* __restrict__ fea
 #pragma unroll
         for (int q = 0; q < NQ; ++q) {
             const int at = lrow[q] >= 0 ? row + lrow[q] : dump;
-            if (VW == 4) *(f32x4*)(lds + at) = (f32x4){sv[cc][q][0], sv[cc][q][1], sv[cc][q][2], sv[cc][q][3]};
+            if (VW == 4) mf_lds_st4(lds + at, (f32x4){sv[cc][q][0], sv[cc][q][1], sv[cc][q][2], sv[cc][q][3]});
             else lds[at] = sv[cc][q][0];
         }
-        if (cc < WN) *(f32x4*)(lds + (lwt[cc] >= 0 ? buf * BUF + lwt[cc] : dump)) = wv[cc];
+        if (cc < WN) mf_lds_st4(lds + (lwt[cc] >= 0 ? buf * BUF + lwt[cc] : dump), wv[cc]);
     };
     // LDS operands of one k-step: the lane's weights of all taps, and per vertical tap NB6 floats of the padded row --
     // NRD single read instructions (read_op), so that they can be placed one by one between the MFMAs.
@@ -175,14 +180,14 @@ __global__ __launch_bounds__(MF_CT) void k_mf_corr(const float* __restrict__ fea
         if (KK == 1) {
             if (k == 0) av[set][0] = wl[0];
             if (k == 1) {
-                const f32x4 v = *(const f32x4*)fb;
+                const f32x4 v = mf_lds_ld4(fb);
 #pragma unroll
                 for (int e = 0; e < 4; ++e) bv[set][0][e] = v[e];
             }
             return;
         }
         if (k < 2) {                                                // 9 of the 12 floats: a register that is loaded but
-            const f32x4 v = *(const f32x4*)(wl + 4 * k);            // never read gets reused while the load is in flight
+            const f32x4 v = mf_lds_ld4(wl + 4 * k);            // never read gets reused while the load is in flight
 #pragma unroll
             for (int e = 0; e < 4; ++e) av[set][4 * k + e] = v[e];
         } else if (k == 2) {
@@ -190,7 +195,7 @@ __global__ __launch_bounds__(MF_CT) void k_mf_corr(const float* __restrict__ fea
         } else {                                                    // columns px - 1 .. px + 4 of row pr + u
             const int u = (k - 3) / 3, part = (k - 3) % 3;
             if (part == 0) {
-                const f32x4 v = *(const f32x4*)(fb + u * g.PS);
+                const f32x4 v = mf_lds_ld4(fb + u * g.PS);
 #pragma unroll
                 for (int e = 0; e < 4; ++e) bv[set][u][e + 1] = v[e];
             } else if (part == 1) {
@@ -307,10 +312,20 @@ __global__ void k_mf_wtrans(const float* __restrict__ filt, float* __restrict__ 
 }
 
 // ---------------------------------------------------------------------------------------------------
-// adjoint: grid (ceil(C/16), NSG), 256 threads.  Workgroup = 16 channels x a group of samples; per (sample, row band) it
-// stages the zero-padded feature band fl[16][CS2] and the input band rl[16][RS2] (strides == 2 mod 32: conflict-free
-// reads with 16 channels/filters x 2 positions per half-wave) and accumulates  D_tap[f][c] += in[f][pos] * feat[c][pos+tap]
-// with K = positions on the matrix cores; wave w takes the 4-position k-steps w, w+4, ...
+// adjoint: grid (ceil(C/16), NSG), 256 threads.  Workgroup = 16 channels x a group of samples; a stage = one (sample, row
+// band): the zero-padded feature band fl[16][CS2] (layout of the correlation: 4 floats, rows of PS = Wp + 4, data at column
+// x) and the input band rl[16][RS2] (rows of Wp) in LDS, and  D_tap[f][c] += in[f][pos] * feat[c][pos+tap]  with K =
+// positions on the matrix cores.  Same issue model as the correlation (few instructions per MFMA, see there):
+//   * positions are counted on rows of Wp and taken in groups of 16; lane kq owns the 4 CONSECUTIVE positions 16g + 4kq + m
+//     and feeds them to 4 MFMAs: one ds_read_b128 of the input row, and per vertical tap one ds_read_b128 + one
+//     ds_read2_b32 of the feature row (6 floats = 4 positions x 3 horizontal taps): 7 LDS reads per 36 MFMAs (was 8 per 9,
+//     plus a division per k-step);
+//   * wave w takes the groups 4 s + (w + stage) % 4 -- rotating, so that a band of 13 groups costs every SIMD 3.25 slots
+//     on average; a slot without a group skips its MFMAs;
+//   * two LDS buffers; while stage t is multiplied, stage t+1 goes from registers to the other buffer and the buffer loads
+//     of stage t+2 are issued, one piece (channel wave + 4k, filter wave + 4k) per slot, pinned behind the slot's first
+//     MFMAs.  The loads are range checked against the channel plane: rows above / below the image arrive as zeros, so no
+//     buffer is ever cleared.  The stage's barrier sits in front of its last slot (as in the correlation).
 // Output: gpart[sg][f][c][tap] (summed over sample groups by the consumer, fixed order).
 // ---------------------------------------------------------------------------------------------------
 template <int KK, int VW>
@@ -321,129 +336,199 @@ __global__ __launch_bounds__(256) void k_mf_adj(const float* __restrict__ feat, 
     extern __shared__ __attribute__((aligned(16))) float lds[];
     inp += (long)blockIdx.z * inp_zstride;                          // blockIdx.z: group of <= 16 filters of a wider bank
     gpart += (long)blockIdx.z * gp_zstride;
-    constexpr int NQ = MF_NQ / VW;
     constexpr int K = KK == 1 ? 1 : 3;
-    float* __restrict__ fl = lds;                                   // [16][CS2]
-    float* __restrict__ rl = lds + 16 * CS2;                        // [16][RS2]
-    float* __restrict__ red = lds;                                  // [4][KK][256], reuses the staging area after the loop
+    constexpr int NQF = 8 / VW, NQI = 4 / VW;                       // staging items per lane: feature channel / input plane
+    constexpr int NB6 = K == 1 ? 4 : 6;
+    constexpr int NRD = K == 1 ? 2 : 7;
+    constexpr int NWR = NQF + NQI;
+    static_assert(NRD + 2 * NWR <= 4 * KK || KK == 1, "memory instructions of a slot fit behind its MFMAs");
+    const int BUF = 16 * (CS2 + RS2);
+    float* __restrict__ red = lds;                                  // [4][KK][256], reuses the buffers after the loop
     const int cb = blockIdx.x, sg = blockIdx.y;
-    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const int lane = threadIdx.x & 63, wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
     const int kq = lane >> 4, j = lane & 15;
     const int HW = g.H * g.W;
-    const float inv_w = 1.0f / (float)g.W;
+    const float inv_w = 1.0f / (float)g.W, inv_wp = 1.0f / (float)g.Wp;
     const int i_beg = sg * spg, i_end = min(g.n, i_beg + spg);
     const int nst = (i_end - i_beg) * g.NB;                         // stages = (sample, band) pairs
+    const int dump = 2 * BUF + 4 * threadIdx.x;
 
     f32x4 acc[KK];
 #pragma unroll
     for (int t = 0; t < KK; ++t) acc[t] = (f32x4){0, 0, 0, 0};
+    for (int e = threadIdx.x; e < 2 * BUF; e += 256) lds[e] = 0.f;  // the padding stays zero
 
-    float sv[4][NQ][VW], rv[4][NQ][VW];
-    MfStage<VW, NQ> fp, rp;                                         // plans of the stage whose data sits in sv / rv
-    auto fetch = [&](int st) {
-        const int i = i_beg + st / g.NB, band = st - (st / g.NB) * g.NB;
-        const int y0 = band * g.BR, rows = min(g.BR, g.H - y0);
-        const int ys = max(y0 - g.p, 0), ye = min(y0 + rows + g.p, g.H);
-        fp.plan(lane, ys, ye - ys, g.W, inv_w, ys - (y0 - g.p), g.PWs, g.p);
-        rp.plan(lane, y0, rows, g.W, inv_w, 0, g.W, 0);
+    // staging items: item q of a plane covers VW floats from e = VW (lane + 64 q) of the staged rows (full width, contiguous)
+    unsigned fsrc[NQF], isrc[NQI];                                  // byte offset in the plane relative to the first staged row
+    int fdst[NQF], idst[NQI];                                       // LDS offset inside the channel / filter row, or -1
 #pragma unroll
-        for (int cc = 0; cc < 4; ++cc) {
-            const int c = cb * 16 + wave + 4 * cc, f = wave + 4 * cc;
-            const float* __restrict__ fc = feat + (long)i * stride_n + (long)min(c, g.C - 1) * HW;
-            const float* __restrict__ rc = inp + (long)i * inp_stride_n + (long)min(f, g.F - 1) * HW;
+    for (int q = 0; q < NQF; ++q) {
+        const int e = VW * (lane + 64 * q);
+        const int rr = mf_fdiv(e, inv_w), x = e - rr * g.W;
+        const bool ok = e < g.RSmax * g.W;
+        fsrc[q] = ok ? 4u * e : 0x40000000u;
+        fdst[q] = ok ? 4 + rr * g.PS + x : -1;
+    }
 #pragma unroll
-            for (int q = 0; q < NQ; ++q) {                          // raw loads; masks are applied in stage()
-                if (VW == 4) {
-                    const f32x4 a = *(const f32x4*)(fc + max(fp.g[q], 0)), b = *(const f32x4*)(rc + max(rp.g[q], 0));
+    for (int q = 0; q < NQI; ++q) {
+        const int e = VW * (lane + 64 * q);
+        const int rr = mf_fdiv(e, inv_w), x = e - rr * g.W;
+        const bool ok = e < g.BR * g.W;
+        isrc[q] = ok ? 4u * e : 0x40000000u;
+        idst[q] = ok ? rr * g.Wp + x : -1;
+    }
+    float sv[4][NQF][VW], rv[4][NQI][VW];
+    // piece cc of stage st: channel cb*16 + wave + 4 cc and filter wave + 4 cc.  One buffer resource per plane: a row
+    // offset below 0 or beyond H*W is out of range and reads 0.  A stage index beyond the last re-fetches the last stage.
+    auto fetch_piece = [&](int st, int cc) {
+        const int sc = min(st, nst - 1);
+        const int si = sc / g.NB, band = sc - si * g.NB;
+        const int i = i_beg + si, y0 = band * g.BR;
+        const int c = min(cb * 16 + wave + 4 * cc, g.C - 1), f = min(wave + 4 * cc, g.F - 1);
+        const __amdgpu_buffer_rsrc_t rsF = pt_rsrc(feat + (long)i * stride_n + (long)c * HW, (unsigned)HW * 4u);
+        const __amdgpu_buffer_rsrc_t rsI = pt_rsrc(inp + (long)i * inp_stride_n + (long)f * HW, (unsigned)HW * 4u);
+        const unsigned frow = (unsigned)((y0 - g.p) * g.W * 4), irow = (unsigned)(y0 * g.W * 4);
 #pragma unroll
-                    for (int m = 0; m < 4; ++m) { sv[cc][q][m] = a[m]; rv[cc][q][m] = b[m]; }
-                } else {
-                    sv[cc][q][0] = fc[max(fp.g[q], 0)];
-                    rv[cc][q][0] = rc[max(rp.g[q], 0)];
-                }
+        for (int q = 0; q < NQF; ++q) {
+            if (VW == 4) {
+                const f32x4 v = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(rsF, fsrc[q] + frow, 0, 0));
+#pragma unroll
+                for (int m = 0; m < 4; ++m) sv[cc][q][m] = v[m];
+            } else {
+                sv[cc][q][0] = __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(rsF, fsrc[q] + frow, 0, 0));
+            }
+        }
+#pragma unroll
+        for (int q = 0; q < NQI; ++q) {
+            if (VW == 4) {
+                const f32x4 v = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(rsI, isrc[q] + irow, 0, 0));
+#pragma unroll
+                for (int m = 0; m < 4; ++m) rv[cc][q][m] = v[m];
+            } else {
+                rv[cc][q][0] = __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(rsI, isrc[q] + irow, 0, 0));
             }
         }
     };
-    auto stage = [&]() {
-        // a band shorter than the previous one (last band of a sample) must not keep stale rows: the whole staging area
-        // was cleared by all threads before (see the loop), only valid items are written here
+    auto stage_piece = [&](int buf, int cc) {
+        const int frw = buf * BUF + (wave + 4 * cc) * CS2, irw = buf * BUF + 16 * CS2 + (wave + 4 * cc) * RS2;
 #pragma unroll
-        for (int cc = 0; cc < 4; ++cc) {
-            float* __restrict__ fc = fl + (wave + 4 * cc) * CS2;
-            float* __restrict__ rc = rl + (wave + 4 * cc) * RS2;
-            const bool cok = cb * 16 + wave + 4 * cc < g.C, fok = wave + 4 * cc < g.F;
+        for (int q = 0; q < NQF; ++q) {
+            const int at = fdst[q] >= 0 ? frw + fdst[q] : dump;
+            if (VW == 4) mf_lds_st4(lds + at, (f32x4){sv[cc][q][0], sv[cc][q][1], sv[cc][q][2], sv[cc][q][3]});
+            else lds[at] = sv[cc][q][0];
+        }
 #pragma unroll
-            for (int q = 0; q < NQ; ++q) {
-                if (fp.g[q] >= 0) {
+        for (int q = 0; q < NQI; ++q) {
+            const int at = idst[q] >= 0 ? irw + idst[q] : dump;
+            if (VW == 4) mf_lds_st4(lds + at, (f32x4){rv[cc][q][0], rv[cc][q][1], rv[cc][q][2], rv[cc][q][3]});
+            else lds[at] = rv[cc][q][0];
+        }
+    };
+    // slot s of stage st: group 4 s + (wave + st) % 4, positions 16 g + 4 kq + m; operands of its 4 k-steps
+    float av[2][4], bv[2][K][NB6];
+    int a_at, b_at;                                                 // LDS offsets of the slot whose reads are being issued
+    auto slot_address = [&](int buf, int st, int sl) {
+        const int gi = 4 * sl + ((wave + st) & 3);
+        const int P = 16 * gi < g.BR * g.Wp ? 16 * gi + 4 * kq : 4 * kq;       // beyond the band: group 0 (never multiplied)
+        const int r = mf_fdiv(P, inv_wp);
+        a_at = buf * BUF + 16 * CS2 + j * RS2 + P;
+        b_at = buf * BUF + j * CS2 + 4 + P + 4 * r;                 // 4 + r PS + x, PS = Wp + 4
+    };
+    auto slot_valid = [&](int st, int sl) {                         // wave uniform
+        const int sc = min(st, nst - 1), band = sc - (sc / g.NB) * g.NB;
+        const int rows = min(g.BR, g.H - band * g.BR);
+        return st < nst && 16 * (4 * sl + ((wave + st) & 3)) < rows * g.Wp;
+    };
+    auto read_op = [&](int set, int k) {
+        if (k == 0) {
+            const f32x4 v = mf_lds_ld4(lds + a_at);
 #pragma unroll
-                    for (int m = 0; m < VW; ++m) fc[fp.l[q] + m] = cok ? sv[cc][q][m] : 0.f;
-                }
-                if (rp.g[q] >= 0) {
+            for (int e = 0; e < 4; ++e) av[set][e] = v[e];
+        } else if (K == 1) {
+            const f32x4 v = mf_lds_ld4(lds + b_at);
 #pragma unroll
-                    for (int m = 0; m < VW; ++m) rc[rp.l[q] + m] = fok ? rv[cc][q][m] : 0.f;
-                }
+            for (int e = 0; e < 4; ++e) bv[set][0][e] = v[e];
+        } else {
+            const int u = (k - 1) >> 1;
+            if ((k - 1) & 1) {                                      // columns x - 1 and x + 4: one ds_read2_b32
+                bv[set][u][0] = lds[b_at + u * g.PS - 1];
+                bv[set][u][5] = lds[b_at + u * g.PS + 4];
+            } else {
+                const f32x4 v = mf_lds_ld4(lds + b_at + u * g.PS);
+#pragma unroll
+                for (int e = 0; e < 4; ++e) bv[set][u][e + 1] = v[e];
             }
         }
     };
-
-    if (nst > 0) fetch(0);
-    for (int st = 0; st < nst; ++st) {
-        const int band = st - (st / g.NB) * g.NB;
-        // first / last band of a sample have rows outside the image, and the last band may be short: clear first
-        // (uniform per workgroup; interior bands overwrite every cell they read)
-        if (st == 0 || band == 0 || band == g.NB - 1) {
-            for (int e = threadIdx.x; e < 16 * (CS2 + RS2); e += 256) lds[e] = 0.f;
-            __syncthreads();
-        }
-        stage();
-        __syncthreads();
-        if (st + 1 < nst) fetch(st + 1);
-        const int rows = min(g.BR, g.H - band * g.BR), npos = rows * g.W;
-        const float* __restrict__ fb = fl + j * CS2;
-        const float* __restrict__ rb = rl + j * RS2;
-        // one k-step of LDS operands is read ahead of the MFMAs that consume it (a workgroup has one wave per SIMD; left to
-        // the scheduler the reads sit right in front of their first use: 2-3 exposed LDS round trips per 9 MFMAs)
-        float a_n, b_n[KK];
-        bool ok_n, ok_a;
-        int pc_a, po_a;                                             // LDS offsets of the k-step after the one in a_n / b_n
-        auto address = [&](int s) {
-            const int pos = 4 * s + kq;
-            ok_a = pos < npos;
-            pc_a = ok_a ? pos : 0;                                  // beyond the band: position 0, multiplied by a = 0
-            const int r = mf_fdiv(pc_a, inv_w), x = pc_a - r * g.W;
-            po_a = r * g.PWs + x;
-        };
-        auto operands = [&]() {
-            ok_n = ok_a;
-            a_n = rb[pc_a];
+    // One slot: 4 k-steps x KK taps of MFMAs on operand set `set` (if the slot has a group), and pinned behind the first
+    // ones the memory instructions that go with it: the reads of the wave's next slot (addresses in a_at / b_at), the LDS
+    // stores of staging piece cc into sbuf, the loads that refill its registers from stage fst.
+    auto memory_op = [&](int set, int k, int sbuf, int cc, int fst) {
+        if (k < NRD) read_op(set ^ 1, k);
+        if (k == NRD) stage_piece(sbuf, cc);
+        if (k == NRD + NWR) fetch_piece(fst, cc);
+    };
+    auto slot = [&](bool valid, int set, int sbuf, int cc, int fst) {
+        if (valid && KK > 1) {
 #pragma unroll
-            for (int tap = 0; tap < KK; ++tap) b_n[tap] = fb[po_a + (tap / K) * g.PWs + (tap % K)];
-        };
-        address(wave);
-        operands();
-        address(wave + 4);
-#pragma unroll 2
-        for (int s = wave; 4 * s < npos; s += 4) {
-            const float a = ok_n ? a_n : 0.f;                       // masked k: a = 0, b finite (LDS holds data or zeros)
-            float bv[KK];
+            for (int m = 0; m < 4; ++m) {
 #pragma unroll
-            for (int tap = 0; tap < KK; ++tap) bv[tap] = b_n[tap];
-            operands();                                             // k-step s + 4: reads first, a full k-step to land
-            address(s + 8);
-#pragma unroll
-            for (int tap = 0; tap < KK; ++tap) acc[tap] = mfma16(a, bv[tap], acc[tap]);
-            // issue order: the reads and the address arithmetic go into the shadows of these MFMAs
-#pragma unroll
-            for (int tap = 0; tap < KK; ++tap) {
-                __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);  // 1 MFMA
-                __builtin_amdgcn_sched_group_barrier(0x100, 3, 0);  // <= 3 LDS reads
-                __builtin_amdgcn_sched_group_barrier(0x002, 3, 0);  // <= 3 VALU
+                for (int tap = 0; tap < KK; ++tap) {
+                    const int u = tap / K, v = tap - u * K;
+                    acc[tap] = mfma16(av[set][m], bv[set][u][m + v], acc[tap]);
+                    __builtin_amdgcn_sched_barrier(0);
+                    memory_op(set, m * KK + tap, sbuf, cc, fst);
+                    __builtin_amdgcn_sched_barrier(0);
+                }
             }
-            __builtin_amdgcn_sched_barrier(0);
+        } else {
+            if (valid) {
+#pragma unroll
+                for (int m = 0; m < 4; ++m) acc[0] = mfma16(av[set][m], bv[set][0][m], acc[0]);
+            }
+#pragma unroll
+            for (int k = 0; k <= NRD + NWR; ++k) memory_op(set, k, sbuf, cc, fst);
         }
+        __builtin_amdgcn_sched_barrier(0);
+    };
+
+    if (nst > 0) {
+#pragma unroll
+        for (int cc = 0; cc < 4; ++cc) fetch_piece(0, cc);
+        __syncthreads();                                            // zero fill done
+#pragma unroll
+        for (int cc = 0; cc < 4; ++cc) stage_piece(0, cc);
+#pragma unroll
+        for (int cc = 0; cc < 4; ++cc) fetch_piece(1, cc);
+        stage_piece(1, 0);
+        fetch_piece(2, 0);
         __syncthreads();
+        slot_address(0, 0, 0);
+#pragma unroll
+        for (int k = 0; k < NRD; ++k) read_op(0, k);
+        __builtin_amdgcn_sched_barrier(0);
+    }
+    // Registers hold pieces 1..3 of stage t+1 and piece 0 of stage t+2 when stage t starts (piece 0 of stage t+1 is in the
+    // other buffer already).  Slots 0..2 write pieces 1..3 of stage t+1 into the other buffer; then the barrier; slot 3
+    // reads the first operands of stage t+1 there and writes piece 0 of stage t+2 into this buffer, which nobody reads any
+    // more.  (Two stages per iteration so that the buffer index is a literal.)
+    for (int st = 0; st < nst; st += 2) {
+#pragma unroll
+        for (int h = 0; h < 2; ++h) {
+            const int t = st + h;
+            if (h == 1 && t >= nst) break;
+#pragma unroll
+            for (int sl = 0; sl < 4; ++sl) {
+                if (sl == 3) __syncthreads();
+                if (sl < 3) slot_address(h, t, sl + 1);
+                else slot_address(h ^ 1, t + 1, 0);
+                if (sl < 3) slot(slot_valid(t, sl), sl & 1, h ^ 1, sl + 1, t + 2);
+                else slot(slot_valid(t, sl), sl & 1, h, 0, t + 3);
+            }
+        }
     }
     // ---- cross-wave reduction, fixed order
+    __syncthreads();
 #pragma unroll
     for (int tap = 0; tap < KK; ++tap)
 #pragma unroll
@@ -496,20 +581,20 @@ static MfPlan mf_plan(int n, int F, int C, int H, int W, int K) {
     g.BR = BR;
     g.NB = (H + BR - 1) / BR;
     g.RSmax = BR + K - 1;
-    // adjoint band: as above without the grid-size constraint (its grid is channel blocks x sample groups)
+    // adjoint band: <= 256 positions on rows of Wp, <= 512 staged feature floats per channel
     p.ga = g;
-    int BRa = 256 / W;
+    int BRa = 256 / g.Wp;
     if (BRa > H) BRa = H;
     while (BRa > 1 && (BRa + K - 1) * W > 64 * MF_NQ) --BRa;
-    if ((BRa + K - 1) * W > 64 * MF_NQ) return p;
+    if (BRa < 1 || (BRa + K - 1) * W > 64 * MF_NQ) return p;
     p.ga.BR = BRa;
     p.ga.NB = (H + BRa - 1) / BRa;
     p.ga.RSmax = BRa + K - 1;
     p.CS = 4 + g.RSmax * g.PS;
-    p.CS2 = mf_pad_to(p.ga.RSmax * g.PWs, 32, 2);
-    p.RS2 = mf_pad_to(BRa * W, 32, 2);
+    p.CS2 = mf_pad_to(4 + p.ga.RSmax * g.PS, 8, 4);     // == 4 mod 8: the 16 rows of a b128 read hit 16 different bank quads
+    p.RS2 = mf_pad_to((BRa * g.Wp + 15) & ~15, 8, 4);   // whole groups of 16 positions; the tail of a row stays zero
     p.corr_lds = std::max(2 * ((size_t)MF_CK * p.CS + MF_KS * 64 * MF_TP(g.KK)) + 4 * MF_CT, (size_t)4096) * sizeof(float);   // two buffers + dump slots | k-half sum
-    p.adj_lds = std::max((size_t)16 * (p.CS2 + p.RS2), (size_t)4 * g.KK * 256) * sizeof(float);
+    p.adj_lds = std::max((size_t)2 * 16 * (p.CS2 + p.RS2) + 4 * 256, (size_t)4 * g.KK * 256) * sizeof(float);   // two buffers + dump slots | reduction
     const int CBn = (C + 15) / 16;
     int NSG = 512 / CBn;                                 // ~2 workgroups per CU
     if (NSG < 1) NSG = 1;
