@@ -17,6 +17,7 @@
 #include "common.h"
 #include "pt_internal.h"
 #include "rbuild.h"
+#include "mfma_gemm.h"
 
 struct GnArgs {
     int n, M, Kc, H, W, K, HW, KK, NF /* Kc*KK */, NP /* Kc*M */, NV;
@@ -259,6 +260,15 @@ static int gn_jt(const GnArgs& a, const PtPlan& pl, const float* samples, long s
     const long total = (long)a.n * a.Kc * a.HW;
     hipLaunchKernelGGL(k_gn_backproject, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, st, a);
     PT_CHECK_LAUNCH();
+    if (a.Kc % 16 == 0 && a.NSG == a.n && a.HW % 4 == 0 && stride_n % 4 == 0 && ((uintptr_t)samples % 16) == 0) {
+        // one partial per sample: a batch of n small NT GEMMs  gpP[., i][f][m] = sum_pos gc[i][f][pos] * S[i][m][pos]
+        // (K = H*W contiguous in both operands) instead of the banded LDS kernel, whose fixed cost per workgroup
+        // dominates on an 18x18 map (50 us vs 6)
+        GemmArgs ga = gemm_args(a.gc, a.HW, a.Kc, samples, a.Kc, a.M, a.HW, nullptr, a.gpP, a.M);
+        ga.batch = a.n; ga.a_zstride = (long)a.Kc * a.HW; ga.w_zstride = stride_n;
+        ga.c_seg = 16; ga.c_segstride = (long)a.NSG * 16; ga.c_zstride = (long)16 * a.M;
+        return launch_gemm(ga, st);
+    }
     if (a.Kc % 16 == 0)
         return pt_launch_mf_adj(samples, stride_n, a.gc, a.gpP, a.n, 16, a.M, a.H, a.W, 1, st, (long)a.Kc * a.HW, a.NGRP);
     for (int g = 0; g < a.NGRP; ++g) {

@@ -566,6 +566,18 @@ static MfPlan mf_plan(int n, int F, int C, int H, int W, int K) {
     if (n <= 0 || F <= 0 || F > 16 || C <= 0 || H <= 0 || W <= 0) return p;
     if (K != 1 && K != 3) return p;
     if (W > 256 || (long)n * C * H * W >= (1L << 31) || (long)C * H * W >= (1L << 30) || (long)F * C * K * K >= (1L << 30)) return p;
+    if (K == 1 && ((H * W) % 4) == 0) {
+        // 1x1: the map is a flat list of H*W positions.  Count it on rows whose length is a multiple of 4 (float4 staging
+        // and stores; 18x18 -> 9 rows of 36), the one that fills the 256-position bands best.
+        const int HW = H * W;
+        int best = 0, fill = -1;
+        for (int d = 4; d <= 256 && d <= HW; d += 4) {
+            if (HW % d) continue;
+            const int br = std::min(HW / d, 256 / d), fl = br * d;
+            if (fl >= fill) { fill = fl; best = d; }
+        }
+        if (best) { W = best; H = HW / best; }
+    }
     MfGeom& g = p.g;
     g.n = n; g.F = F; g.C = C; g.H = H; g.W = W; g.K = K; g.p = K / 2; g.KK = K * K;
     g.PWs = W + K - 1;
@@ -639,7 +651,7 @@ int pt_launch_mf_corr(const float* feat, long stride_n, const float* wT, float* 
     // groups > 1: `groups` banks of F filters each (weight tables back to back, outputs F*H*W apart inside a sample)
     const long wt_zs = (long)pt_mf_wt_floats(C, K), out_zs = (long)F * H * W;
     dim3 grid(p.g.NB, n, groups), block(MF_CT);
-    const bool vec = mf_vec_ok(feat, feat, stride_n, W);
+    const bool vec = mf_vec_ok(feat, feat, stride_n, p.g.W);            // the plan's W (a 1x1 map is re-rowed)
     p.g.out_vec = vec && ((uintptr_t)scores % 16) == 0 && (out_stride_n % 4) == 0 && ((H * W) % 4) == 0;
 #define PT_MFC(KKV, VWV) \
     hipLaunchKernelGGL((k_mf_corr<KKV, VWV>), grid, block, p.corr_lds, st, feat, stride_n, wT, scores, out_stride_n, p.g, p.CS, wt_zs, out_zs)
@@ -658,7 +670,7 @@ int pt_launch_mf_adj(const float* feat, long stride_n, const float* inp, float* 
     // groups > 1: banks of F filter maps F*H*W apart inside a sample, partials of a bank NSG*F*C*K*K floats apart
     const long inp_zs = (long)F * H * W, gp_zs = (long)p.NSG * F * C * K * K;
     dim3 grid((C + 15) / 16, p.NSG, groups), block(256);
-    const bool vec = mf_vec_ok(feat, inp, stride_n, W) && ((H * W) % 4) == 0 && (inp_stride_n % 4) == 0;
+    const bool vec = mf_vec_ok(feat, inp, stride_n, p.ga.W) && ((H * W) % 4) == 0 && (inp_stride_n % 4) == 0;
 #define PT_MFA(KKV, VWV) \
     hipLaunchKernelGGL((k_mf_adj<KKV, VWV>), grid, block, p.adj_lds, st, feat, stride_n, inp, inp_stride_n, gpart, p.ga, p.CS2, p.RS2, p.spg, inp_zs, gp_zs)
     if (K == 1) { if (vec) PT_MFA(1, 4); else PT_MFA(1, 1); }

@@ -30,6 +30,8 @@ struct GemmArgs {
     int swizzle;                                // XCD-aware workgroup -> tile map (grid.y rounded up to a multiple of 8)
     int ksteps; long c_zstride;                 // split-K: blockIdx.z owns K-steps [z*ksteps, (z+1)*ksteps) and writes its
                                                 // partial product to C + z*c_zstride (bias on z = 0 only); 0 = no split
+    int batch; long a_zstride, w_zstride;       // batch > 0 (no split-K): blockIdx.z is an independent problem, operands
+                                                // a_zstride / w_zstride floats apart, output at C + z*c_zstride
 };
 
 template <int BM, int BN, int MODE, int BK = 64>
@@ -56,7 +58,8 @@ __global__ __launch_bounds__(256) void k_gemm(GemmArgs g) {
     }
     const int m0 = by * BM, n0 = bx * BN;
     const int lrow = tid / (BK / 4), lc4 = (tid % (BK / 4)) * 4;   // loader: BK/4 threads cover one row segment of BK floats
-    const __amdgpu_buffer_rsrc_t rsA = pt_rsrc(g.A, g.a_bytes), rsW = pt_rsrc(g.Wt, g.w_bytes);
+    const long zb = g.batch ? (long)blockIdx.z : 0;
+    const __amdgpu_buffer_rsrc_t rsA = pt_rsrc(g.A + zb * g.a_zstride, g.a_bytes), rsW = pt_rsrc(g.Wt + zb * g.w_zstride, g.w_bytes);
     const bool addpos = MODE == 0 && g.pos != nullptr && n0 < g.pos_cols;
     const __amdgpu_buffer_rsrc_t rsP = pt_rsrc(addpos ? g.pos : g.A, addpos ? g.pos_bytes : 16u);
 
@@ -215,7 +218,7 @@ __global__ __launch_bounds__(256) void k_gemm(GemmArgs g) {
         const int col = n0 + wn * WN + nt * 16 + prow(lane & 15);
         const bool cok = col < g.N;
         const int cc = cok ? col : 0;
-        const float bv = (g.bias && blockIdx.z == 0) ? g.bias[cc] : 0.f;
+        const float bv = (g.bias && (g.batch || blockIdx.z == 0)) ? g.bias[cc] : 0.f;
         const float sc = g.scale ? g.scale[cc] : 1.f, sh = g.shift ? g.shift[cc] : 0.f;
         const unsigned coff = (unsigned)cc * cstep;
         unsigned off[MT][4];
@@ -272,16 +275,17 @@ GemmArgs gemm_args(const float* A, long lda, long a_rows, const float* Wt, int M
 // traffic per flop and two workgroups still fit a CU: FFN first GEMM 36.3 -> 28.0 us.  Larger tiles (128x64, 128x128) run
 // their K steps at 67-74 % of the MFMA rate but leave too few workgroups at these sizes.
 int launch_gemm(const GemmArgs& g, hipStream_t st, bool conv = false) {
-    if (g.K % 32 != 0 || g.M <= 0 || g.N <= 0) return PT_ERR_UNSUPPORTED;
+    // K % 4: a loader thread fetches 4 consecutive k (16 bytes); quads past K are not requested at all (zeros)
+    if (g.K % 4 != 0 || (conv && g.K % 32 != 0) || g.M <= 0 || g.N <= 0 || (g.batch && g.ksteps)) return PT_ERR_UNSUPPORTED;
     // the epilogue addresses C (and R) with 32-bit byte offsets through a raw buffer descriptor
-    const int nz = g.ksteps ? ((g.K + 63) / 64 + g.ksteps - 1) / g.ksteps : 1;
+    const int nz = g.batch ? g.batch : g.ksteps ? ((g.K + 63) / 64 + g.ksteps - 1) / g.ksteps : 1;
     const long rows = g.nchw ? (long)g.M * g.N : (g.c_segstride ? ((long)(g.M / g.c_seg) + 1) * g.c_segstride * g.ldc
                                                                    : (long)g.M * g.ldc);
     if ((rows + (long)(nz - 1) * g.c_zstride) * 4 >= 0xFFFFFFE0L) return PT_ERR_UNSUPPORTED;
     if (conv) {
         if (g.Cin % 64 != 0) return PT_ERR_UNSUPPORTED;
         hipLaunchKernelGGL((k_gemm<32, 32, 1>), dim3((g.N + 31) / 32, (g.M + 31) / 32, nz), dim3(256), 0, st, g);
-    } else if (g.N >= 1024 && g.M >= 1024 && nz == 1) {
+    } else if (g.N >= 1024 && g.M >= 1024 && nz == 1 && g.K % 32 == 0) {
         GemmArgs gs = g;
         const int gy = (g.M + 63) / 64;
         gs.swizzle = gy >= 16;
@@ -291,6 +295,7 @@ int launch_gemm(const GemmArgs& g, hipStream_t st, bool conv = false) {
         GemmArgs gs = g;
         const int gy = (g.M + 31) / 32;
         gs.swizzle = nz == 1 && gy >= 16;                            // worth it once every XCD gets >= 2 row tiles
+        if (g.batch) gs.ksteps = 0;
         hipLaunchKernelGGL((k_gemm<32, 32, 0>), dim3((g.N + 31) / 32, gs.swizzle ? (gy + 7) / 8 * 8 : gy, nz), dim3(256), 0,
                            st, gs);
     }
