@@ -297,6 +297,118 @@ __global__ __launch_bounds__(MF_CT) void k_mf_corr(const float* __restrict__ fea
     }
 }
 
+// ---------------------------------------------------------------------------------------------------
+// 1x1 correlation without LDS staging (ATOM's projection: 256 -> 64 channels on 18x18 maps).  With a single tap nothing is
+// reused between positions, so the B operand goes straight from global memory to the lane that multiplies it: lane
+// (kq, j) of every wave owns the 4 consecutive positions P0 + q (P0 = 64 blockIdx.x + 4 j) and loads them per channel
+// with one 16-byte load (a wave load = 4 rows of 256 contiguous bytes).  The A operand comes from the transposed table
+// ([c/4][lane], one coalesced dword per k-step and bank) or, DIRECT, from the (F, C) weight matrix itself (16 bytes per
+// lane and bank for 4 k-steps: no transposition launch in front).  A workgroup serves NBK banks of 16 filters with the same B
+// registers; its 4 waves split the channels and are summed through LDS.  No barrier in the loop; the banded LDS kernel
+// spent 17 us on this (16 chunks x (barrier + exposed load latency)) for 10 MB of input.
+// grid (ceil(HW/64), n, ceil(groups/NBK)), 256 threads.  HW % 4 == 0.
+// ---------------------------------------------------------------------------------------------------
+template <int NBK, bool DIRECT>
+__global__ __launch_bounds__(256) void k_mf_corr1(const float* __restrict__ feat, long stride_n, const float* __restrict__ wT,
+                                                  float* __restrict__ scores, long out_stride_n, int F, int C, int HW,
+                                                  int groups, long wt_zstride, long out_zstride, int out_vec) {
+    __shared__ __attribute__((aligned(16))) float red[3][NBK * 16][64];
+    constexpr int PD = 2;                                           // 16-channel blocks in flight
+    const int lane = threadIdx.x & 63, wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+    const int kq = lane >> 4, j = lane & 15;
+    const int i = blockIdx.y, b0 = blockIdx.z * NBK;
+    const int P0 = 64 * blockIdx.x + 4 * j;
+    const bool pok = P0 < HW;
+    const int nblk = (C + MF_CK - 1) / MF_CK;                       // the table is zero padded to whole blocks
+    const int per = (nblk + 3) / 4, cb0 = wave * per, cb1 = min(nblk, cb0 + per);
+    const __amdgpu_buffer_rsrc_t rsF = pt_rsrc(feat + (long)i * stride_n, (unsigned)C * (unsigned)HW * 4u);
+    const unsigned boff = pok ? 4u * P0 : 0x80000000u;              // beyond the map: reads 0, never stored
+    f32x4 acc[NBK][4];
+#pragma unroll
+    for (int b = 0; b < NBK; ++b)
+#pragma unroll
+        for (int q = 0; q < 4; ++q) acc[b][q] = (f32x4){0, 0, 0, 0};
+    // k-step m of block cb multiplies channel 16 cb + 4 m + kq (table order), or 16 cb + 4 kq + m when the weights are
+    // read DIRECTly from the (F, C) matrix: then a lane's 4 k-steps are 4 consecutive floats of its filter row (C % 16 == 0)
+    f32x4 bq[PD][4];
+    float aq[PD][NBK][4];
+    auto fetch = [&](int cb, int sl) {
+        const int cbc = min(cb, nblk - 1);
+#pragma unroll
+        for (int m = 0; m < 4; ++m) {
+            const int c = min(16 * cbc + (DIRECT ? 4 * kq + m : 4 * m + kq), C - 1);      // a channel >= C meets zero weights
+            bq[sl][m] = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(rsF, boff + (unsigned)c * (unsigned)HW * 4u, 0, 0));
+        }
+#pragma unroll
+        for (int b = 0; b < NBK; ++b) {
+            const int bank = min(b0 + b, groups - 1);
+            if (DIRECT) {
+                const f32x4 v = *(const f32x4*)(wT + ((long)bank * 16 + j) * C + 16 * cbc + 4 * kq);
+#pragma unroll
+                for (int m = 0; m < 4; ++m) aq[sl][b][m] = v[m];
+            } else {
+#pragma unroll
+                for (int m = 0; m < 4; ++m) aq[sl][b][m] = wT[(long)bank * wt_zstride + (long)(4 * cbc + m) * 64 + lane];
+            }
+        }
+    };
+#pragma unroll
+    for (int sl = 0; sl < PD; ++sl) fetch(cb0 + sl, sl);
+    for (int cb = cb0; cb < cb1; cb += PD) {
+#pragma unroll
+        for (int sl = 0; sl < PD; ++sl) {
+            if (cb + sl < cb1) {
+                f32x4 bv[4];
+                float av[NBK][4];
+#pragma unroll
+                for (int m = 0; m < 4; ++m) {
+                    bv[m] = bq[sl][m];
+#pragma unroll
+                    for (int b = 0; b < NBK; ++b) av[b][m] = aq[sl][b][m];
+                }
+                fetch(cb + sl + PD, sl);                            // past the range: clamped, unused
+#pragma unroll
+                for (int m = 0; m < 4; ++m)
+#pragma unroll
+                    for (int b = 0; b < NBK; ++b)
+#pragma unroll
+                        for (int q = 0; q < 4; ++q) acc[b][q] = mfma16(av[b][m], bv[m][q], acc[b][q]);
+            }
+        }
+    }
+    // sum of the 4 channel ranges, fixed order; lane (kq, j), register r: filter 4 kq + r at positions P0 + q
+    if (wave > 0) {
+#pragma unroll
+        for (int b = 0; b < NBK; ++b)
+#pragma unroll
+            for (int q = 0; q < 4; ++q)
+#pragma unroll
+                for (int r = 0; r < 4; ++r) red[wave - 1][(b * 4 + q) * 4 + r][lane] = acc[b][q][r];
+    }
+    __syncthreads();
+    if (wave > 0 || !pok) return;
+#pragma unroll
+    for (int b = 0; b < NBK; ++b) {
+        if (b0 + b >= groups) break;
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+            float v[4];
+#pragma unroll
+            for (int q = 0; q < 4; ++q) {
+                v[q] = acc[b][q][r];
+#pragma unroll
+                for (int w = 0; w < 3; ++w) v[q] += red[w][(b * 4 + q) * 4 + r][lane];
+            }
+            const int f = 4 * kq + r;
+            if (f < F) {
+                float* __restrict__ o = scores + (long)(b0 + b) * out_zstride + (long)i * out_stride_n + (long)f * HW + P0;
+                if (out_vec) *(f32x4*)o = (f32x4){v[0], v[1], v[2], v[3]};
+                else { o[0] = v[0]; o[1] = v[1]; o[2] = v[2]; o[3] = v[3]; }
+            }
+        }
+    }
+}
+
 // Weights in the order the correlation consumes them: wT[c/4][lane = (c%4)*16 + filter][MF_TP taps], zero padded to 16
 // filters, to 12 taps and to a multiple of MF_CK channels (one contiguous 16-byte-loadable block per channel chunk).
 __global__ void k_mf_wtrans(const float* __restrict__ filt, float* __restrict__ wT, int F, int C, int KK, int Cpad,
@@ -642,6 +754,32 @@ static bool mf_vec_ok(const float* a, const float* b, long stride_n, int W) {
     return (W % 4) == 0 && (stride_n % 4) == 0 && ((uintptr_t)a % 16) == 0 && ((uintptr_t)b % 16) == 0;
 }
 
+// no LDS staging for a single tap; as many banks per workgroup (shared B registers) as keep the grid >= 256
+static int mf_launch_corr1(const float* feat, long stride_n, const float* w, bool direct, float* scores, long out_stride_n,
+                           int n, int F, int C, int HW, int groups, long wt_zs, long out_zs, int out_vec, hipStream_t st) {
+    const int gx = (HW + 63) / 64;
+    int nbk = groups >= 4 ? 4 : groups >= 2 ? 2 : 1;
+    while (nbk > 1 && (long)gx * n * ((groups + nbk - 1) / nbk) < 256) nbk >>= 1;
+    dim3 g1(gx, n, (groups + nbk - 1) / nbk);
+#define PT_MFC1(NBKV, DV) \
+    hipLaunchKernelGGL((k_mf_corr1<NBKV, DV>), g1, dim3(256), 0, st, feat, stride_n, w, scores, out_stride_n, F, C, HW, groups, wt_zs, out_zs, out_vec)
+    if (direct) { if (nbk == 4) PT_MFC1(4, true); else if (nbk == 2) PT_MFC1(2, true); else PT_MFC1(1, true); }
+    else { if (nbk == 4) PT_MFC1(4, false); else if (nbk == 2) PT_MFC1(2, false); else PT_MFC1(1, false); }
+#undef PT_MFC1
+    PT_CHECK_LAUNCH();
+    return PT_OK;
+}
+
+// conv1x1 with the weights read from the (Ftot, C) matrix itself, Ftot = 16 * groups rows (no pt_launch_mf_wtrans in front).
+// PT_ERR_UNSUPPORTED when the shapes / alignments do not allow it: the caller falls back to wtrans + pt_launch_mf_corr.
+int pt_launch_mf_corr1_direct(const float* feat, long stride_n, const float* filt, float* scores, int n, int Ftot, int C,
+                              int H, int W, hipStream_t st, long out_stride_n) {
+    const int HW = H * W;
+    if (n <= 0 || Ftot <= 0 || Ftot % 16 || C % 16 || HW % 4 || stride_n % 4 || out_stride_n % 4) return PT_ERR_UNSUPPORTED;
+    if (((uintptr_t)feat % 16) || ((uintptr_t)filt % 16) || ((uintptr_t)scores % 16) || (long)C * HW >= (1L << 30)) return PT_ERR_UNSUPPORTED;
+    return mf_launch_corr1(feat, stride_n, filt, true, scores, out_stride_n, n, 16, C, HW, Ftot / 16, 0, (long)16 * HW, 1, st);
+}
+
 // wT: weights pre-transposed by pt_launch_mf_wtrans (pt_mf_wt_floats(C, K) floats, 16-byte aligned)
 int pt_launch_mf_corr(const float* feat, long stride_n, const float* wT, float* scores, int n, int F, int C, int H,
                       int W, int K, hipStream_t st, long out_stride_n, int groups) {
@@ -655,7 +793,8 @@ int pt_launch_mf_corr(const float* feat, long stride_n, const float* wT, float* 
     p.g.out_vec = vec && ((uintptr_t)scores % 16) == 0 && (out_stride_n % 4) == 0 && ((H * W) % 4) == 0;
 #define PT_MFC(KKV, VWV) \
     hipLaunchKernelGGL((k_mf_corr<KKV, VWV>), grid, block, p.corr_lds, st, feat, stride_n, wT, scores, out_stride_n, p.g, p.CS, wt_zs, out_zs)
-    if (K == 1) { if (vec) PT_MFC(1, 4); else PT_MFC(1, 1); }
+    if (K == 1 && vec) return mf_launch_corr1(feat, stride_n, wT, false, scores, out_stride_n, n, F, C, H * W, groups, wt_zs, out_zs, p.g.out_vec, st);
+    if (K == 1) { PT_MFC(1, 1); }
     else { if (vec) PT_MFC(9, 4); else PT_MFC(9, 1); }
 #undef PT_MFC
     PT_CHECK_LAUNCH();

@@ -92,6 +92,8 @@ int pt_launch_mf_wtrans(const float* filt, float* wT, int F, int C, int K, hipSt
 // <= 16 filters be a slice of a wider (n, Ftotal, H, W) tensor; groups > 1: `groups` consecutive banks of F filters in ONE
 // launch (grid.z) -- weight tables pt_mf_wt_floats apart, maps F*H*W apart inside a sample, adjoint partials
 // pt_mf_gpart_floats apart
+int pt_launch_mf_corr1_direct(const float* feat, long stride_n, const float* filt, float* scores, int n, int Ftot, int C,
+                              int H, int W, hipStream_t st, long out_stride_n);     // 1x1, weights (Ftot, C) untransposed
 int pt_launch_mf_corr(const float* feat, long stride_n, const float* wT, float* scores, int n, int F, int C, int H,
                       int W, int K, hipStream_t st, long out_stride_n = 0, int groups = 1);
 int pt_launch_mf_adj(const float* feat, long stride_n, const float* inp, float* gpart, int n, int F, int C, int H, int W,
