@@ -252,7 +252,13 @@ def test_sd_fast_path_shapes_vs_oracle(n, C, H, W):
 # multi-filter filter layer + LWL few-shot learner
 # ------------------------------------------------------------------------------------------------------
 @pytest.mark.parametrize("n,F,C,H,W,K", [(3, 16, 64, 30, 52, 3), (2, 16, 512, 30, 52, 3), (5, 7, 40, 9, 11, 3),
-                                         (2, 16, 32, 30, 52, 1), (4, 3, 20, 17, 120, 3), (1, 1, 16, 5, 5, 3)])
+                                         (2, 16, 32, 30, 52, 1), (4, 3, 20, 17, 120, 3), (1, 1, 16, 5, 5, 3),
+                                         # two samples per adjoint workgroup, short last band, few filters
+                                         (35, 5, 48, 9, 16, 3),
+                                         # 1x1: re-rowed float4 path with a ragged channel count / odd map (banded kernel)
+                                         (2, 16, 24, 18, 18, 1), (3, 9, 33, 7, 9, 1),
+                                         # several full bands per sample; one-row bands (3 staged rows of 168 floats: the widest map a 3x3 pass stages)
+                                         (2, 16, 16, 64, 64, 3), (1, 16, 20, 3, 168, 3)])
 def test_multifilter_ops_vs_oracle(n, F, C, H, W, K):
     from pytracking_amd import filter as FL
     rng = np.random.default_rng(7 * n + C)
