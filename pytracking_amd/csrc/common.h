@@ -5,6 +5,7 @@
 
 typedef float f32x4 __attribute__((ext_vector_type(4)));
 typedef float f32x2 __attribute__((ext_vector_type(2)));
+typedef int i32x4 __attribute__((ext_vector_type(4)));
 
 typedef unsigned int u32x4 __attribute__((ext_vector_type(4)));
 

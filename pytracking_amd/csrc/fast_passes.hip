@@ -68,7 +68,11 @@ PtFast pt_fast_plan(int n, int C, int H, int W, int KH, int KW, int OH, int OW) 
     p.PW = W + KW - 1;
     while ((p.PW % 16) != 8) ++p.PW;
     p.ns_max = (p.gper * 16 + p.HW - 1) / p.HW + 1;
-    p.adj_lds = ((size_t)p.ns_max * p.PH * p.PW + 16) * sizeof(float);
+    // zero block behind the maps: a masked quad gathers zeros for every tap offset; sized so that the quad table that
+    // follows is 16-byte aligned
+    p.zn = (KH - 1) * p.PW + KW + 4;
+    while (((p.ns_max * p.PH * p.PW + p.zn) % 4) != 0) ++p.zn;
+    p.adj_lds = ((size_t)p.ns_max * p.PH * p.PW + p.zn + (size_t)5 * 4 * PT_ADJ_WAVES * PT_ADJ_UMAX) * sizeof(float);
     if (p.adj_lds > 96 * 1024 || p.OO > 1024) return p;
     p.E = p.OO <= 384 ? 6 : (p.OO <= 576 ? 9 : 16);
     p.ok = 1;
@@ -363,7 +367,7 @@ int pt_launch_corr2(const PtFast& p, const float* feat, long stride_n, const flo
 // ---------------------------------------------------------------------------------------------------
 struct Adj2Args {
     const float* feat; long stride_n; float* gpart;
-    int n, C, H, W, KH, KW, OH, OW, NG, gper, U, bpx, PH, PW, ns_max;
+    int n, C, H, W, KH, KW, OH, OW, NG, gper, U, bpx, PH, PW, ns_max, zn;
     const float* inp;        // V_PLAIN: residual maps (n, OH, OW)
     SdArgs sd;               // solver variants: solver state
     int t, want_loss;        //                  iterate index of the maps this launch builds
@@ -508,7 +512,7 @@ __device__ __forceinline__ void sdp_compute(const Adj2Args& a, int i, int lane, 
 // UM: 16-position groups per wave (compile-time trip count of the pipelined loop; 12 for the 22x22 PrDiMP geometry)
 template <int V, int E, int UM>
 __global__ __launch_bounds__(PT_ADJ_WAVES * 64) void k_adj2(Adj2Args a) {
-    extern __shared__ __attribute__((aligned(16))) float maps[];    // [ns_max][PH][PW] zero-padded residual maps + 16 zeros
+    extern __shared__ __attribute__((aligned(16))) float maps[];    // [ns_max][PH][PW] zero-padded residual maps, zn zeros, quad table
     __shared__ float red[PT_ADJ_WAVES][256];
     const int b = blockIdx.x, x = b & 7, rr = b >> 3;
     const int cb = a.bpx * x + rr % a.bpx, ks = rr / a.bpx;
@@ -521,13 +525,13 @@ __global__ __launch_bounds__(PT_ADJ_WAVES * 64) void k_adj2(Adj2Args a) {
     const int i_lo = fdiv(gbeg * 16, inv_hw);
     const int i_hi = min(a.n - 1, fdiv(gend * 16 - 1, inv_hw));
     const int ns = i_hi - i_lo + 1;
-    const int ZB = a.ns_max * PHPW;                                 // 16 zeros: what masked lanes gather
+    const int ZB = a.ns_max * PHPW;                                 // a.zn zeros: what masked quads gather (any tap)
     // residual coordinate of (position (y,x), tap (u,v)) is (y-u+KH/2, x-v+KW/2); in the padded map the residual
     // pixel (yy,xx) sits at (yy + oy, xx + ox)
     const int oy = a.KH - 1 - a.KH / 2, ox = a.KW - 1 - a.KW / 2;
 
     for (int e = threadIdx.x; e < ns * PHPW; e += blockDim.x) maps[e] = 0.f;
-    if (threadIdx.x < 16) maps[ZB + threadIdx.x] = 0.f;
+    for (int e = threadIdx.x; e < a.zn; e += blockDim.x) maps[ZB + e] = 0.f;
 
     // ---- update stage first: its inputs are small and L2/MALL resident, and the MFMA chain cannot start before the
     //      residual maps exist; the A operand is streamed afterwards so that its loads overlap the MFMAs.
@@ -570,44 +574,64 @@ __global__ __launch_bounds__(PT_ADJ_WAVES * 64) void k_adj2(Adj2Args a) {
     constexpr int PD = UM < 8 ? UM : (UM == 8 ? 8 : 6);
     const int c = cb * 16 + j;
     const __amdgpu_buffer_rsrc_t fr = pt_rsrc(a.feat, (unsigned)(((long)(a.n - 1) * a.stride_n + (long)a.C * HW) * 4));
-    const int g0 = gbeg + wave * a.U;
     const int uj = j / a.KW, vj = j - uj * a.KW;
-    const int tapoff = (a.KH - 1 - uj) * a.PW + (a.KW - 1 - vj);
-    const bool tapv = j < KK;
-    const int Pm = 16 * g0 + 4 * kq < total ? 16 * g0 + 4 * kq : 0;   // masked groups re-read a line already fetched
+    // lanes j >= K*K feed accumulator columns that are never stored: any in-range tap offset does
+    const unsigned tapoff4 = j < KK ? 4u * (unsigned)((a.KH - 1 - uj) * a.PW + (a.KW - 1 - vj)) : 0u;
+    const unsigned chw4 = 4u * (unsigned)c * (unsigned)HW;
+    // Where a quad of positions lives does not depend on the channel or the tap: the workgroup computes it once per quad
+    // (sample, feature offset, the 4 residual-map cells incl. the row wrap inside the quad) into an LDS table instead of
+    // every lane redoing two divisions and the wrap selects per group -- the pass is bound by VALU issue, not by memory
+    // (rocprofv3 counters, profiles/r02j_solver_instruction_mix.txt: 1020 VALU instructions per wave around 64 MFMAs).
+    //   tabA[kq][wave][u]   byte offset of the quad in the feature tensor (channel 0)
+    //   tabI[kq][wave][u]   byte offsets of its 4 cells in `maps` for tap (KH-1, KW-1); + tapoff4 per lane.  A masked quad
+    //                       re-reads a line already fetched and points at the zero block behind the maps.
+    int* __restrict__ tabA = (int*)(maps + ZB + a.zn);
+    int* __restrict__ tabI = tabA + 4 * PT_ADJ_WAVES * UM;
+    const int Pm = 16 * gbeg < total ? 16 * gbeg : 0;
+    for (int e = threadIdx.x; e < 4 * PT_ADJ_WAVES * UM; e += blockDim.x) {
+        const int tu = e % UM, tw = (e / UM) % PT_ADJ_WAVES, tk = e / (UM * PT_ADJ_WAVES);
+        const int g = gbeg + tw * a.U + tu;
+        const int P0 = 16 * g + 4 * tk;
+        const bool okk = tu < a.U && g < gend && P0 < total;
+        const int Pc = okk ? P0 : Pm + 4 * tk;
+        const int i = fdiv(Pc, inv_hw), p0 = Pc - i * HW;
+        tabA[e] = (int)(((unsigned)i * (unsigned)a.stride_n + (unsigned)p0) * 4u);
+        const int y0 = fdiv(p0, inv_w), x0 = p0 - y0 * a.W;
+        // a quad may wrap to the next feature row: one row further in the padded map is PW - W cells more
+        const int base = (i - i_lo) * PHPW + y0 * a.PW + x0, wr = a.PW - a.W;
+#pragma unroll
+        for (int k = 0; k < 4; ++k) tabI[4 * e + k] = 4 * (okk ? base + k + (x0 + k >= a.W ? wr : 0) : ZB);
+    }
+    __syncthreads();
+    const int tq = (kq * PT_ADJ_WAVES + wave) * UM;
+    int foff[UM];
+#pragma unroll
+    for (int u = 0; u < UM; u += 4) {
+        const i32x4 v = *(const i32x4*)__builtin_assume_aligned(tabA + tq + u, 16);
+#pragma unroll
+        for (int k = 0; k < 4; ++k) foff[u + k] = v[k];
+    }
     f32x4 av[UM];
     float bv[UM][4];
-    int il[UM], p0[UM];
-    auto issue = [&](int u) {
-        const int g = g0 + u;
-        const int P0 = 16 * g + 4 * kq;
-        const bool okk = u < a.U && g < gend && P0 < total;
-        const int Pc = okk ? P0 : Pm;
-        const int i = fdiv(Pc, inv_hw);
-        il[u] = okk ? i - i_lo : -1;
-        p0[u] = Pc - i * HW;
-        av[u] = pt_bload4(fr, ((unsigned)i * (unsigned)a.stride_n + (unsigned)c * HW + p0[u]) * 4u);
-    };
+    i32x4 cell[UM];
+    auto issue = [&](int u) { av[u] = pt_bload4(fr, (unsigned)foff[u] + chw4); };
+    auto cells = [&](int u) { cell[u] = *(const i32x4*)__builtin_assume_aligned(tabI + 4 * (tq + u), 16); };
     auto gather = [&](int u) {
-        const bool okb = il[u] >= 0 && tapv;
-        const int y0 = fdiv(p0[u], inv_w), x0 = p0[u] - y0 * a.W;
-        // a quad may wrap to the next feature row: one row further in the padded map is PW - W cells more
-        const int idx0 = okb ? il[u] * PHPW + tapoff + y0 * a.PW + x0 : ZB;
-        const int wr = okb ? a.PW - a.W : 0;
-        bv[u][0] = maps[idx0];
-        bv[u][1] = maps[idx0 + 1 + (x0 + 1 >= a.W ? wr : 0)];
-        bv[u][2] = maps[idx0 + 2 + (x0 + 2 >= a.W ? wr : 0)];
-        bv[u][3] = maps[idx0 + 3 + (x0 + 3 >= a.W ? wr : 0)];
+#pragma unroll
+        for (int k = 0; k < 4; ++k) bv[u][k] = *(const float*)((const char*)maps + ((unsigned)cell[u][k] + tapoff4));
     };
     f32x4 accA = {0, 0, 0, 0}, accB = {0, 0, 0, 0};
 #pragma unroll
     for (int u = 0; u < PD; ++u) issue(u);
+    cells(0);
+    if (UM > 1) cells(1);
     gather(0);
 #pragma unroll
     for (int u = 0; u < UM; ++u) {
         if (u + PD < UM) issue(u + PD);
+        if (u + 2 < UM) cells(u + 2);
         if (u + 1 < UM) gather(u + 1);
-        // masked lanes multiply a finite, re-read feature value by a gathered zero
+        // masked quads multiply a finite, re-read feature value by a gathered zero
         accA = mfma16(av[u][0], bv[u][0], accA);
         accB = mfma16(av[u][1], bv[u][1], accB);
         accA = mfma16(av[u][2], bv[u][2], accA);
@@ -628,7 +652,7 @@ __global__ __launch_bounds__(PT_ADJ_WAVES * 64) void k_adj2(Adj2Args a) {
 static void adj2_fill(const PtFast& p, Adj2Args& a, const float* feat, long stride_n, float* gpart) {
     a.feat = feat; a.stride_n = stride_n; a.gpart = gpart;
     a.n = p.n; a.C = p.C; a.H = p.H; a.W = p.W; a.KH = p.KH; a.KW = p.KW; a.OH = p.OH; a.OW = p.OW;
-    a.NG = p.NG; a.gper = p.gper; a.U = p.U; a.bpx = p.bpx; a.PH = p.PH; a.PW = p.PW; a.ns_max = p.ns_max;
+    a.NG = p.NG; a.gper = p.gper; a.U = p.U; a.bpx = p.bpx; a.PH = p.PH; a.PW = p.PW; a.ns_max = p.ns_max; a.zn = p.zn;
     a.inp = nullptr; a.t = 0; a.want_loss = 0;
 }
 

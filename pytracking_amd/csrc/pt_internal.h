@@ -54,7 +54,7 @@ struct PtFast {
     int n, C, H, W, KH, KW, OH, OW, HW, KK, OO, Q;
     int CX, NK, TF, rem, tiles, left, HWp, corr_threads, nh;   // corr2: grid 8*n, waves = 2 halves x tiles
     size_t corr_lds;
-    int CB, bpx, NG, KSPL, gper, U, PH, PW, ns_max, E;     // adj2: grid CB*KSPL, 8 waves x U contiguous groups
+    int CB, bpx, NG, KSPL, gper, U, PH, PW, ns_max, E, zn; // adj2: grid CB*KSPL, 8 waves x U contiguous groups; zero block
     size_t adj_lds;
 };
 PtFast pt_fast_plan(int n, int C, int H, int W, int KH, int KW, int OH, int OW);
