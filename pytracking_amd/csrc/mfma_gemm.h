@@ -91,28 +91,44 @@ __global__ __launch_bounds__(256) void k_gemm(GemmArgs g) {
     // bookkeeping stays exact -- a fetch inside a branch makes it wait for ALL outstanding loads before the LDS store.
     constexpr int PD = 2;
     f32x4 ra[PD][AL], rp[PD][AL], rb[PD][BL];
+    // Addressing without VALU work per load (the vector instructions of a K-step are issue time taken from the MFMAs:
+    // experiments/mfma_issue.hip): the row part of an address is a loop-invariant VGPR (out-of-range for rows outside
+    // the matrix), the K-step part goes into the scalar offset of the buffer instruction.  A step past the end re-fetches
+    // the last one (never consumed); only a ragged last step (K % BK != 0) needs per-lane offsets, prepared once.
+    const int nkt_all = (g.K + BK - 1) / BK;
+    const bool tail_live = (nkt_all - 1) * BK + lc4 < g.K;          // this lane's quad of the last K-step is inside K
+    unsigned aoffT[AL], poffT[AL], woffT[BL];
+#pragma unroll
+    for (int i = 0; i < AL; ++i) { aoffT[i] = tail_live ? aoff[i] : OOB; poffT[i] = tail_live ? poff[i] : OOB; }
+#pragma unroll
+    for (int i = 0; i < BL; ++i) woffT[i] = tail_live ? woff[i] : OOB;
     auto fetch = [&](int kb, int sl, bool live) {
-        live = live && (kb * BK + lc4 < g.K);                            // K % 64 == 32: the last step is half empty
-        const unsigned kbytes = (unsigned)kb * (BK * 4u);
+        const int kc = min(kb, nkt_all - 1);
+        const bool last = kc == nkt_all - 1;                            // uniform
+        const unsigned kbytes = (unsigned)kc * (BK * 4u);
+        (void)live;
         if (MODE == 0) {
 #pragma unroll
-            for (int i = 0; i < AL; ++i) ra[sl][i] = pt_bload4(rsA, (aoff[i] == OOB || !live) ? OOB : aoff[i] + kbytes);
+            for (int i = 0; i < AL; ++i)
+                ra[sl][i] = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(rsA, last ? aoffT[i] : aoff[i], kbytes, 0));
             if (addpos) {
 #pragma unroll
-                for (int i = 0; i < AL; ++i) rp[sl][i] = pt_bload4(rsP, (poff[i] == OOB || !live) ? OOB : poff[i] + kbytes);
+                for (int i = 0; i < AL; ++i)
+                    rp[sl][i] = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(rsP, last ? poffT[i] : poff[i], kbytes, 0));
             }
         } else {
-            const int k0 = kb * BK, tap = k0 / g.Cin, c0 = k0 - tap * g.Cin;
+            const int k0 = kc * BK, tap = k0 / g.Cin, c0 = k0 - tap * g.Cin;
             const int dy = tap / 3 - 1, dx = tap - (tap / 3) * 3 - 1;
 #pragma unroll
             for (int i = 0; i < AL; ++i) {
                 const int y = py[i] + dy, x = px[i] + dx;
-                const bool in = live && y >= 0 && y < g.H && x >= 0 && x < g.Wd;
+                const bool in = y >= 0 && y < g.H && x >= 0 && x < g.Wd;
                 ra[sl][i] = pt_bload4(rsA, in ? aoff[i] + (unsigned)(((long)(y * g.Wd + x) * g.lda + c0) * 4) : OOB);
             }
         }
 #pragma unroll
-        for (int i = 0; i < BL; ++i) rb[sl][i] = pt_bload4(rsW, (woff[i] == OOB || !live) ? OOB : woff[i] + kbytes);
+        for (int i = 0; i < BL; ++i)
+            rb[sl][i] = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(rsW, last ? woffT[i] : woff[i], kbytes, 0));
     };
     auto stash = [&](int sl, int buf) {
 #pragma unroll
