@@ -110,18 +110,38 @@ __global__ __launch_bounds__(512) void k_attn(AttnArgs a) {
         const int c0 = it * 128 + half * 64;
         const float* Kh = Ks + half * 64 * KS;
         const float* Vh = Vs + half * 64 * VS;
-        // ---- S^T tiles: rows = keys, cols = queries
+        // ---- S^T tiles: rows = keys, cols = queries.  The K fragments of tile kt+1 (and the V operands of the first PV
+        //      tile) are read while tile kt is multiplied; the sched_barriers keep the scheduler from sinking the reads to
+        //      their first use (it did: one exposed LDS round trip per 2 PV MFMAs, per 8 S MFMAs).
         f32x4 st[4];
         float mc = -INFINITY;
-#pragma unroll
-        for (int kt = 0; kt < 4; ++kt) {
-            f32x4 sc = f32x4{0.f, 0.f, 0.f, 0.f};
+        f32x4 kf[2][NF4];
+        float vf[2][4][DT];
+        auto read_k = [&](int kt, int set) {
             const float* kp = Kh + (kt * 16 + prow(li)) * KS + kq * NV;   // S^T row i of the tile <-> key prow(i)
 #pragma unroll
-            for (int v = 0; v < NF4; ++v) {
-                const f32x4 kk = *reinterpret_cast<const f32x4*>(kp + 4 * v);
+            for (int v = 0; v < NF4; ++v) kf[set][v] = *reinterpret_cast<const f32x4*>(kp + 4 * v);
+        };
+        auto read_v = [&](int kt, int set) {
 #pragma unroll
-                for (int e = 0; e < 4; ++e) sc = mfma16(kk[e], qf[4 * v + e], sc);
+            for (int r = 0; r < 4; ++r) {
+                const float* vp = Vh + (kt * 16 + prow(4 * kq + r)) * VS + li;
+#pragma unroll
+                for (int d = 0; d < DT; ++d) vf[set][r][d] = vp[16 * d];
+            }
+        };
+        read_k(0, 0);
+        __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+        for (int kt = 0; kt < 4; ++kt) {
+            if (kt < 3) read_k(kt + 1, (kt + 1) & 1);
+            else read_v(0, 0);
+            __builtin_amdgcn_sched_barrier(0);
+            f32x4 sc = f32x4{0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+            for (int v = 0; v < NF4; ++v) {
+#pragma unroll
+                for (int e = 0; e < 4; ++e) sc = mfma16(kf[kt & 1][v][e], qf[4 * v + e], sc);
             }
 #pragma unroll
             for (int r = 0; r < 4; ++r) {
@@ -130,6 +150,7 @@ __global__ __launch_bounds__(512) void k_attn(AttnArgs a) {
                 mc = fmaxf(mc, sc[r]);
             }
             st[kt] = sc;
+            __builtin_amdgcn_sched_barrier(0);
         }
         mc = fmaxf(mc, __shfl_xor(mc, 16, 64));
         mc = fmaxf(mc, __shfl_xor(mc, 32, 64));
@@ -142,16 +163,19 @@ __global__ __launch_bounds__(512) void k_attn(AttnArgs a) {
         m_run = m_new;
         // ---- P^T = exp(S^T - m) feeds the PV product straight from the accumulator registers:
         //      O^T[d][query] += sum_key V[key][d] * P^T[key][query]; k-slot kq of MFMA r <-> key prow(4*kq + r) of the tile
+        __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
         for (int kt = 0; kt < 4; ++kt) {
+            if (kt < 3) read_v(kt + 1, (kt + 1) & 1);
+            __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
             for (int r = 0; r < 4; ++r) {
                 const float pe = __expf(st[kt][r] - m_use);
                 l_run += pe;
-                const float* vp = Vh + (kt * 16 + prow(4 * kq + r)) * VS + li;
 #pragma unroll
-                for (int d = 0; d < DT; ++d) ot[d] = mfma16(vp[16 * d], pe, ot[d]);
+                for (int d = 0; d < DT; ++d) ot[d] = mfma16(vf[kt & 1][r][d], pe, ot[d]);
             }
+            __builtin_amdgcn_sched_barrier(0);
         }
     }
     l_run += __shfl_xor(l_run, 16, 64);
