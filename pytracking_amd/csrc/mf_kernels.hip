@@ -32,6 +32,27 @@ __device__ __forceinline__ int mf_fdiv(int v, float inv_d) { return (int)(((floa
 __device__ __forceinline__ f32x4 mf_lds_ld4(const float* p) { return *(const f32x4*)__builtin_assume_aligned(p, 16); }
 __device__ __forceinline__ void mf_lds_st4(float* p, f32x4 v) { *(f32x4*)__builtin_assume_aligned(p, 16) = v; }
 
+// VW (1, 2, 4) consecutive floats: range-checked buffer load / LDS store (VW*4-byte aligned)
+template <int VW>
+__device__ __forceinline__ void mf_bload(__amdgpu_buffer_rsrc_t rs, unsigned voff, unsigned soff, float* out) {
+    if (VW == 4) {
+        const f32x4 v = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(rs, voff, soff, 0));
+#pragma unroll
+        for (int m = 0; m < 4; ++m) out[m] = v[m];
+    } else if (VW == 2) {
+        const f32x2 v = __builtin_bit_cast(f32x2, __builtin_amdgcn_raw_buffer_load_b64(rs, voff, soff, 0));
+        out[0] = v[0]; out[1] = v[1];
+    } else {
+        out[0] = __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(rs, voff, soff, 0));
+    }
+}
+template <int VW>
+__device__ __forceinline__ void mf_lds_store(float* p, const float* v) {
+    if (VW == 4) mf_lds_st4(p, (f32x4){v[0], v[1], v[2], v[3]});
+    else if (VW == 2) *(f32x2*)__builtin_assume_aligned(p, 8) = (f32x2){v[0], v[1]};
+    else p[0] = v[0];
+}
+
 // Staging plan of one lane for a (rows x W) block that is contiguous in global memory (full-width rows): item q covers
 // VW consecutive floats starting at e = VW*(lane + 64*q).  VW = 4 needs W % 4 == 0 (an item never straddles a row).
 template <int VW, int NQ>
@@ -82,22 +103,29 @@ struct MfStage {
 #define MF_TP(KK) ((KK) == 1 ? 1 : 12)   // weight floats per lane per k-step (pt_mf_wt_index)
 #define MF_CT 512          // threads of the correlation workgroup
 
-template <int KK, int VW>
+// WTM: the weights come tap-major, (filters, 9, C) -- the layout the classification-feature head keeps its 3x3 weights in --
+//      and are transposed into the [k-step][lane][12] order on their way into LDS (C % 16 == 0, 16 filters per bank).
+// ksplit > 1: blockIdx.y = sample + n * split; split s multiplies its share of the channel chunks and writes its partial map
+//      to scores + s * part_zstride (summed by the caller in fixed order): a single frame has too few bands to fill the chip.
+template <int KK, int VW, bool WTM>
 __global__ __launch_bounds__(MF_CT) void k_mf_corr(const float* __restrict__ feat, long stride_n,
                                                    const float* __restrict__ wT, float* __restrict__ scores,
-                                                   long out_stride_n, MfGeom g, int CS, long wt_zstride, long out_zstride) {
+                                                   long out_stride_n, MfGeom g, int CS, long wt_zstride, long out_zstride,
+                                                   int ksplit, long part_zstride) {
     extern __shared__ __attribute__((aligned(16))) float lds[];
+    static_assert(!WTM || KK == 9, "tap-major weights: 3x3 only");
     wT += (long)blockIdx.z * wt_zstride;                            // blockIdx.z: group of <= 16 filters of a wider bank
     scores += (long)blockIdx.z * out_zstride;
     constexpr int NQ = MF_NQ / VW;
     constexpr int K = KK == 1 ? 1 : 3;
     constexpr int TP = MF_TP(KK);
     constexpr int NB6 = K == 1 ? 4 : 6;                             // floats of a padded row one lane reads per (k-step, u)
-    constexpr int WITEMS = MF_KS * 64 * TP / 4;                     // float4 items of a chunk's weight block
+    constexpr int WITEMS = WTM ? 16 * 9 * MF_KS : MF_KS * 64 * TP / 4;   // 16-byte items of a chunk's weight block
     constexpr int WN = (WITEMS + MF_CT - 1) / MF_CT;
     static_assert(MF_KS == 4 && MF_CK == 16 && WN <= 2, "two k-steps and two staging pieces per wave and chunk");
     const int BUF = MF_CK * CS + MF_KS * 64 * TP;                   // floats per buffer
-    const int band = blockIdx.x, i = blockIdx.y;
+    const int band = blockIdx.x, i = blockIdx.y % g.n, ksp = blockIdx.y / g.n;
+    scores += (long)ksp * part_zstride;
     const int lane = threadIdx.x & 63, wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
     const int pg = wave & 3, kh = wave >> 2;
     const int kq = lane >> 4, j = lane & 15;
@@ -112,7 +140,8 @@ __global__ __launch_bounds__(MF_CT) void k_mf_corr(const float* __restrict__ fea
     const int ys = max(y0 - g.p, 0), ye = min(y0 + rows + g.p, g.H);
     MfStage<VW, NQ> sp;
     sp.plan(lane, ys, ye - ys, g.W, inv_w, ys - (y0 - g.p), g.PS, 4);
-    const int nchunks = (g.C + MF_CK - 1) / MF_CK;
+    const int nch_all = (g.C + MF_CK - 1) / MF_CK, cps = (nch_all + ksplit - 1) / ksplit;
+    const int cbeg = ksp * cps, nchunks = min(nch_all, cbeg + cps) - cbeg;   // >= 1 (the launcher sees to it)
 
     // ---- the 4 positions of this lane: P0 .. P0 + 3 on rows of Wp
     const int P0 = 64 * pg + 4 * j;
@@ -129,7 +158,8 @@ __global__ __launch_bounds__(MF_CT) void k_mf_corr(const float* __restrict__ fea
     // out-of-range offset (reads 0) and goes to the thread's dump slot.  A chunk index beyond the last one re-fetches
     // the last chunk; a channel >= C (channel count not a multiple of MF_CK) reads channel C - 1 against zero weights.
     const __amdgpu_buffer_rsrc_t rsF = pt_rsrc(fi, (unsigned)g.C * (unsigned)HW * 4u);
-    const __amdgpu_buffer_rsrc_t rsW = pt_rsrc(wT, (unsigned)nchunks * (unsigned)(MF_KS * 64 * TP) * 4u);
+    const __amdgpu_buffer_rsrc_t rsW = pt_rsrc(wT, WTM ? (unsigned)g.F * 9u * (unsigned)g.C * 4u
+                                                       : (unsigned)nch_all * (unsigned)(MF_KS * 64 * TP) * 4u);
     const int dump = 2 * BUF + 4 * threadIdx.x;
     unsigned goff[NQ], woff[WN];
     int lrow[NQ], lwt[WN];
@@ -141,34 +171,39 @@ __global__ __launch_bounds__(MF_CT) void k_mf_corr(const float* __restrict__ fea
 #pragma unroll
     for (int cc = 0; cc < WN; ++cc) {
         const int e = threadIdx.x + MF_CT * cc;
-        woff[cc] = e < WITEMS ? 16u * e : 0x80000000u;
-        lwt[cc] = e < WITEMS ? MF_CK * CS + 4 * e : -1;
+        if (WTM) {                                                  // item = (filter f, tap, k-step): channels 4 ks .. + 3
+            const int ks = e & 3, ft = e >> 2, f = ft / 9, tap = ft - 9 * f;
+            woff[cc] = e < WITEMS ? 4u * (unsigned)((f * 9 + tap) * g.C + 4 * ks) : 0x80000000u;
+            lwt[cc] = e < WITEMS ? MF_CK * CS + (ks * 64 + f) * TP + tap : -1;
+        } else {
+            woff[cc] = e < WITEMS ? 16u * e : 0x80000000u;
+            lwt[cc] = e < WITEMS ? MF_CK * CS + 4 * e : -1;
+        }
     }
     auto fetch_piece = [&](int ci, int cc) {
-        const int c0 = min(ci, nchunks - 1) * MF_CK;
+        const int c0 = (cbeg + min(ci, nchunks - 1)) * MF_CK;
         const unsigned soff = (unsigned)min(c0 + wave + 8 * cc, g.C - 1) * (unsigned)HW * 4u;
 #pragma unroll
-        for (int q = 0; q < NQ; ++q) {
-            if (VW == 4) {
-                const f32x4 v = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(rsF, goff[q], soff, 0));
-#pragma unroll
-                for (int m = 0; m < 4; ++m) sv[cc][q][m] = v[m];
-            } else {
-                sv[cc][q][0] = __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(rsF, goff[q], soff, 0));
-            }
-        }
+        for (int q = 0; q < NQ; ++q) mf_bload<VW>(rsF, goff[q], soff, sv[cc][q]);
         if (cc < WN)
-            wv[cc] = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(rsW, woff[cc], (unsigned)(c0 >> 2) * (64 * TP * 4), 0));
+            wv[cc] = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(
+                rsW, woff[cc], WTM ? (unsigned)c0 * 4u : (unsigned)(c0 >> 2) * (64 * TP * 4), 0));
     };
     auto stage_piece = [&](int buf, int cc) {
         const int row = buf * BUF + (wave + 8 * cc) * CS;
 #pragma unroll
         for (int q = 0; q < NQ; ++q) {
             const int at = lrow[q] >= 0 ? row + lrow[q] : dump;
-            if (VW == 4) mf_lds_st4(lds + at, (f32x4){sv[cc][q][0], sv[cc][q][1], sv[cc][q][2], sv[cc][q][3]});
-            else lds[at] = sv[cc][q][0];
+            mf_lds_store<VW>(lds + at, sv[cc][q]);
         }
-        if (cc < WN) mf_lds_st4(lds + (lwt[cc] >= 0 ? buf * BUF + lwt[cc] : dump), wv[cc]);
+        if (cc < WN) {
+            if (WTM) {                                              // 4 channels of one (filter, tap): lanes kq = 0..3
+#pragma unroll
+                for (int m = 0; m < 4; ++m) lds[lwt[cc] >= 0 ? buf * BUF + lwt[cc] + m * 16 * TP : dump + m] = wv[cc][m];
+            } else {
+                mf_lds_st4(lds + (lwt[cc] >= 0 ? buf * BUF + lwt[cc] : dump), wv[cc]);
+            }
+        }
     };
     // LDS operands of one k-step: the lane's weights of all taps, and per vertical tap NB6 floats of the padded row --
     // NRD single read instructions (read_op), so that they can be placed one by one between the MFMAs.
@@ -501,39 +536,21 @@ __global__ __launch_bounds__(256) void k_mf_adj(const float* __restrict__ feat, 
         const __amdgpu_buffer_rsrc_t rsI = pt_rsrc(inp + (long)i * inp_stride_n + (long)f * HW, (unsigned)HW * 4u);
         const unsigned frow = (unsigned)((y0 - g.p) * g.W * 4), irow = (unsigned)(y0 * g.W * 4);
 #pragma unroll
-        for (int q = 0; q < NQF; ++q) {
-            if (VW == 4) {
-                const f32x4 v = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(rsF, fsrc[q] + frow, 0, 0));
+        for (int q = 0; q < NQF; ++q) mf_bload<VW>(rsF, fsrc[q] + frow, 0, sv[cc][q]);
 #pragma unroll
-                for (int m = 0; m < 4; ++m) sv[cc][q][m] = v[m];
-            } else {
-                sv[cc][q][0] = __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(rsF, fsrc[q] + frow, 0, 0));
-            }
-        }
-#pragma unroll
-        for (int q = 0; q < NQI; ++q) {
-            if (VW == 4) {
-                const f32x4 v = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(rsI, isrc[q] + irow, 0, 0));
-#pragma unroll
-                for (int m = 0; m < 4; ++m) rv[cc][q][m] = v[m];
-            } else {
-                rv[cc][q][0] = __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(rsI, isrc[q] + irow, 0, 0));
-            }
-        }
+        for (int q = 0; q < NQI; ++q) mf_bload<VW>(rsI, isrc[q] + irow, 0, rv[cc][q]);
     };
     auto stage_piece = [&](int buf, int cc) {
         const int frw = buf * BUF + (wave + 4 * cc) * CS2, irw = buf * BUF + 16 * CS2 + (wave + 4 * cc) * RS2;
 #pragma unroll
         for (int q = 0; q < NQF; ++q) {
             const int at = fdst[q] >= 0 ? frw + fdst[q] : dump;
-            if (VW == 4) mf_lds_st4(lds + at, (f32x4){sv[cc][q][0], sv[cc][q][1], sv[cc][q][2], sv[cc][q][3]});
-            else lds[at] = sv[cc][q][0];
+            mf_lds_store<VW>(lds + at, sv[cc][q]);
         }
 #pragma unroll
         for (int q = 0; q < NQI; ++q) {
             const int at = idst[q] >= 0 ? irw + idst[q] : dump;
-            if (VW == 4) mf_lds_st4(lds + at, (f32x4){rv[cc][q][0], rv[cc][q][1], rv[cc][q][2], rv[cc][q][3]});
-            else lds[at] = rv[cc][q][0];
+            mf_lds_store<VW>(lds + at, rv[cc][q]);
         }
     };
     // slot s of stage st: group 4 s + (wave + st) % 4, positions 16 g + 4 kq + m; operands of its 4 k-steps
@@ -672,7 +689,7 @@ static int mf_pad_to(int v, int mod, int res) {          // smallest x >= v with
     return x;
 }
 
-static MfPlan mf_plan(int n, int F, int C, int H, int W, int K) {
+static MfPlan mf_plan(int n, int F, int C, int H, int W, int K, int br_force = 0) {   // br_force: rows per correlation band
     MfPlan p;
     p.ok = 0;
     if (n <= 0 || F <= 0 || F > 16 || C <= 0 || H <= 0 || W <= 0) return p;
@@ -700,7 +717,13 @@ static MfPlan mf_plan(int n, int F, int C, int H, int W, int K) {
     g.out_vec = 0;
     int BR = 256 / g.Wp;
     if (BR > H) BR = H;
-    while (BR > 1 && ((BR + K - 1) * W > 64 * MF_NQ || (n * ((H + BR - 1) / BR) < 256 && (BR - 1) * g.Wp >= 128))) --BR;
+    while (BR > 1 && (BR + K - 1) * W > 64 * MF_NQ) --BR;            // what fits
+    if (br_force > 0) {
+        if (br_force > BR) return p;
+        BR = br_force;
+    } else {
+        while (BR > 1 && n * ((H + BR - 1) / BR) < 256 && (BR - 1) * g.Wp >= 128) --BR;
+    }
     if (BR < 1 || (BR + K - 1) * W > 64 * MF_NQ || BR * g.Wp > 256) return p;
     g.BR = BR;
     g.NB = (H + BR - 1) / BR;
@@ -753,6 +776,12 @@ int pt_mf_groups(int n, int F, int C, int H, int W, int K) {
 static bool mf_vec_ok(const float* a, const float* b, long stride_n, int W) {
     return (W % 4) == 0 && (stride_n % 4) == 0 && ((uintptr_t)a % 16) == 0 && ((uintptr_t)b % 16) == 0;
 }
+// widest staging item: 4 floats, or 2 for an even map width such as 18 (rows and planes 8-byte aligned), else 1
+static int mf_vec_width(const float* a, long stride_n, int H, int W) {
+    if (mf_vec_ok(a, a, stride_n, W)) return 4;
+    if ((W % 2) == 0 && (stride_n % 2) == 0 && ((uintptr_t)a % 8) == 0) return 2;
+    return 1;
+}
 
 // no LDS staging for a single tap; as many banks per workgroup (shared B registers) as keep the grid >= 256
 static int mf_launch_corr1(const float* feat, long stride_n, const float* w, bool direct, float* scores, long out_stride_n,
@@ -792,11 +821,72 @@ int pt_launch_mf_corr(const float* feat, long stride_n, const float* wT, float* 
     const bool vec = mf_vec_ok(feat, feat, stride_n, p.g.W);            // the plan's W (a 1x1 map is re-rowed)
     p.g.out_vec = vec && ((uintptr_t)scores % 16) == 0 && (out_stride_n % 4) == 0 && ((H * W) % 4) == 0;
 #define PT_MFC(KKV, VWV) \
-    hipLaunchKernelGGL((k_mf_corr<KKV, VWV>), grid, block, p.corr_lds, st, feat, stride_n, wT, scores, out_stride_n, p.g, p.CS, wt_zs, out_zs)
+    hipLaunchKernelGGL((k_mf_corr<KKV, VWV, false>), grid, block, p.corr_lds, st, feat, stride_n, wT, scores, out_stride_n, p.g, p.CS, wt_zs, out_zs, 1, 0L)
     if (K == 1 && vec) return mf_launch_corr1(feat, stride_n, wT, false, scores, out_stride_n, n, F, C, H * W, groups, wt_zs, out_zs, p.g.out_vec, st);
+    const int vw = mf_vec_width(feat, stride_n, p.g.H, p.g.W);
     if (K == 1) { PT_MFC(1, 1); }
-    else { if (vec) PT_MFC(9, 4); else PT_MFC(9, 1); }
+    else { if (vw == 4) PT_MFC(9, 4); else if (vw == 2) PT_MFC(9, 2); else PT_MFC(9, 1); }
 #undef PT_MFC
+    PT_CHECK_LAUNCH();
+    return PT_OK;
+}
+
+// 3x3 correlation with a bank of Ftot = 16 * groups filters kept tap-major, (Ftot, 9, C), split `ksplit` ways over the
+// channels: partial maps part[s][n][Ftot][H][W] (the caller sums them in fixed order).  pt_mf_corr_tm_splits() says how
+// many splits fill the chip (0: shape not covered).
+// Band height and channel splits for a bank of filters on few samples: the cheapest of (rounds of 256 workgroups) x (chunks
+// per workgroup + ~4 chunks of fixed cost), balanced bands on a tie.
+static int mf_tm_config(int n, int Ftot, int C, int H, int W, int* br_out) {
+    if (Ftot <= 0 || Ftot % 16 || C <= 0 || C % 16 || H <= 0 || W <= 0) return 0;
+    const int Wp = (W + 3) & ~3, nch = C / MF_CK, groups = Ftot / 16;
+    int best_ks = 0, best_br = 0;
+    long best_cost = -1;
+    for (int br = std::min(H, 256 / std::max(Wp, 1)); br >= 1; --br) {
+        if ((br + 2) * W > 64 * MF_NQ) continue;
+        const int nb = (H + br - 1) / br;
+        if (br != (H + nb - 1) / nb) continue;                      // only the balanced height of each band count
+        for (int ks = 1; ks <= 8 && ks <= nch; ks *= 2) {
+            const long wgs = (long)n * nb * groups * ks, cost = ((wgs + 255) / 256) * ((nch + ks - 1) / ks + 4);
+            if (best_cost < 0 || cost < best_cost) { best_cost = cost; best_ks = ks; best_br = br; }
+        }
+    }
+    if (br_out) *br_out = best_br;
+    return best_ks;
+}
+
+// 3x3 correlation with a bank of Ftot = 16 * groups filters kept tap-major, (Ftot, 9, C), split `ksplit` ways over the
+// channels: partial maps part[s][n][Ftot][H][W] (the caller sums them in fixed order).  pt_mf_corr_tm_splits() says how
+// many splits this launcher will use (0: shape not covered).
+int pt_mf_corr_tm_splits(int n, int Ftot, int C, int H, int W) {
+    int br = 0;
+    const int ks = mf_tm_config(n, Ftot, C, H, W, &br);
+    if (ks == 0 || br == 0 || !mf_plan(n, 16, C, H, W, 3, br).ok) return 0;
+    return ks;
+}
+// chunk times (~2.7 us each on an 18x18 map) this launcher needs for the shape: rounds of 256 workgroups x chunks per split
+int pt_mf_corr_tm_cost(int n, int Ftot, int C, int H, int W) {
+    int br = 0;
+    const int ks = mf_tm_config(n, Ftot, C, H, W, &br);
+    if (ks == 0 || br == 0) return 1 << 30;
+    const long wgs = (long)n * ((H + br - 1) / br) * (Ftot / 16) * ks;
+    return (int)(((wgs + 255) / 256) * ((C / MF_CK + ks - 1) / ks));
+}
+int pt_launch_mf_corr_tm(const float* feat, long stride_n, const float* w_tap_major, float* part, int n, int Ftot, int C,
+                         int H, int W, int ksplit, hipStream_t st) {
+    int br = 0;
+    if (mf_tm_config(n, Ftot, C, H, W, &br) != ksplit || ksplit < 1) return PT_ERR_UNSUPPORTED;
+    if (((uintptr_t)w_tap_major % 16) || ((uintptr_t)part % 16) || (long)Ftot * 9 * C >= (1L << 30)) return PT_ERR_UNSUPPORTED;
+    const int groups = Ftot / 16;
+    MfPlan p = mf_plan(n, 16, C, H, W, 3, br);
+    if (!p.ok) return PT_ERR_UNSUPPORTED;
+    const long out_stride_n = (long)Ftot * H * W, wt_zs = (long)16 * 9 * C, out_zs = (long)16 * H * W;
+    dim3 grid(p.g.NB, n * ksplit, groups), block(MF_CT);
+    const int vw = mf_vec_width(feat, stride_n, H, W);
+    p.g.out_vec = vw == 4 && ((H * W) % 4) == 0;
+#define PT_MFT(VWV) \
+    hipLaunchKernelGGL((k_mf_corr<9, VWV, true>), grid, block, p.corr_lds, st, feat, stride_n, w_tap_major, part, out_stride_n, p.g, p.CS, wt_zs, out_zs, ksplit, (long)n * out_stride_n)
+    if (vw == 4) PT_MFT(4); else if (vw == 2) PT_MFT(2); else PT_MFT(1);
+#undef PT_MFT
     PT_CHECK_LAUNCH();
     return PT_OK;
 }
@@ -810,10 +900,12 @@ int pt_launch_mf_adj(const float* feat, long stride_n, const float* inp, float* 
     const long inp_zs = (long)F * H * W, gp_zs = (long)p.NSG * F * C * K * K;
     dim3 grid((C + 15) / 16, p.NSG, groups), block(256);
     const bool vec = mf_vec_ok(feat, inp, stride_n, p.ga.W) && ((H * W) % 4) == 0 && (inp_stride_n % 4) == 0;
+    const bool vec2 = !vec && (p.ga.W % 2) == 0 && (stride_n % 2) == 0 && (inp_stride_n % 2) == 0 &&
+                      ((uintptr_t)feat % 8) == 0 && ((uintptr_t)inp % 8) == 0;
 #define PT_MFA(KKV, VWV) \
     hipLaunchKernelGGL((k_mf_adj<KKV, VWV>), grid, block, p.adj_lds, st, feat, stride_n, inp, inp_stride_n, gpart, p.ga, p.CS2, p.RS2, p.spg, inp_zs, gp_zs)
     if (K == 1) { if (vec) PT_MFA(1, 4); else PT_MFA(1, 1); }
-    else { if (vec) PT_MFA(9, 4); else PT_MFA(9, 1); }
+    else { if (vec) PT_MFA(9, 4); else if (vec2) PT_MFA(9, 2); else PT_MFA(9, 1); }
 #undef PT_MFA
     PT_CHECK_LAUNCH();
     return PT_OK;

@@ -92,6 +92,10 @@ int pt_launch_mf_wtrans(const float* filt, float* wT, int F, int C, int K, hipSt
 // <= 16 filters be a slice of a wider (n, Ftotal, H, W) tensor; groups > 1: `groups` consecutive banks of F filters in ONE
 // launch (grid.z) -- weight tables pt_mf_wt_floats apart, maps F*H*W apart inside a sample, adjoint partials
 // pt_mf_gpart_floats apart
+int pt_mf_corr_tm_splits(int n, int Ftot, int C, int H, int W);             // channel splits that fill the chip; 0: not covered
+int pt_mf_corr_tm_cost(int n, int Ftot, int C, int H, int W);               // rounds x channel chunks per workgroup
+int pt_launch_mf_corr_tm(const float* feat, long stride_n, const float* w_tap_major, float* part, int n, int Ftot, int C,
+                         int H, int W, int ksplit, hipStream_t st);          // 3x3, weights (Ftot, 9, C); partial maps
 int pt_launch_mf_corr1_direct(const float* feat, long stride_n, const float* filt, float* scores, int n, int Ftot, int C,
                               int H, int W, hipStream_t st, long out_stride_n);     // 1x1, weights (Ftot, C) untransposed
 int pt_launch_mf_corr(const float* feat, long stride_n, const float* wT, float* scores, int n, int F, int C, int H,

@@ -1136,9 +1136,16 @@ __global__ __launch_bounds__(256) void k_head_finish(const float* X, const float
     __shared__ float tile[32][33];
     const int tx = threadIdx.x & 31, ty = threadIdx.x >> 5;
     const int p0 = blockIdx.x * 32, c0 = blockIdx.y * 32, img = blockIdx.z;
-    double q = 0.0;
-    for (int k = 0; k < slices; ++k) q += (double)stats[((long)img * slices + k) * 2 + 1];
-    const float f = scale * (float)sqrt((double)C * HW / (q + (double)eps));
+    __shared__ double sh[256];
+    double q = 0.0;                                                 // fixed order: thread t sums slices t, t+256, ...; then a tree
+    for (int k = threadIdx.x; k < slices; k += 256) q += (double)stats[((long)img * slices + k) * 2 + 1];
+    sh[threadIdx.x] = q;
+    __syncthreads();
+    for (int w = 128; w > 0; w >>= 1) {
+        if ((int)threadIdx.x < w) sh[threadIdx.x] += sh[threadIdx.x + w];
+        __syncthreads();
+    }
+    const float f = scale * (float)sqrt((double)C * HW / (sh[0] + (double)eps));
 #pragma unroll
     for (int i = 0; i < 4; ++i) {
         const int p = p0 + ty + 8 * i, c = c0 + tx;
@@ -1149,6 +1156,27 @@ __global__ __launch_bounds__(256) void k_head_finish(const float* X, const float
     for (int i = 0; i < 4; ++i) {
         const int c = c0 + ty + 8 * i, p = p0 + tx;
         if (c < C && p < HW) out[((long)img * C + c) * HW + p] = tile[tx][ty + 8 * i];
+    }
+}
+
+// out = y * scale * sqrt(C*HW / (sum y^2 + eps)) for maps that already are (n, C, H, W)
+__global__ __launch_bounds__(256) void k_head_scale(const float* __restrict__ Y, const float* __restrict__ stats, int slices,
+                                                    float* __restrict__ out, int C, int HW, float scale, float eps) {
+    __shared__ double sh[256];
+    const int img = blockIdx.y;
+    double q = 0.0;                                                 // fixed order: thread t sums slices t, t+256, ...; then a tree
+    for (int k = threadIdx.x; k < slices; k += 256) q += (double)stats[((long)img * slices + k) * 2 + 1];
+    sh[threadIdx.x] = q;
+    __syncthreads();
+    for (int w = 128; w > 0; w >>= 1) {
+        if ((int)threadIdx.x < w) sh[threadIdx.x] += sh[threadIdx.x + w];
+        __syncthreads();
+    }
+    const float f = scale * (float)sqrt((double)C * HW / (sh[0] + (double)eps));
+    const long base = (long)img * C * HW, i = ((long)blockIdx.x * 256 + threadIdx.x) * 4;
+    if (i < (long)C * HW) {
+        f32x4 v = *reinterpret_cast<const f32x4*>(Y + base + i);
+        *reinterpret_cast<f32x4*>(out + base + i) = v * f;
     }
 }
 
@@ -1189,6 +1217,24 @@ extern "C" int pt_clf_head_f32(const float* feat, const float* weight_tap_major,
     hipStream_t st = (hipStream_t)stream;
     float* base = (float*)ws;
     const int HW = H * W, M = n * HW;
+    // The maps stay (n, C, H, W) end to end when the banded correlation kernel covers the shape (csrc/mf_kernels.hip: 16 output
+    // channels per workgroup, weights transposed on their way into LDS, channel splits summed here): no token transposes,
+    // 3 launches instead of 4, and the MFMA loop built on the issue model (66.6 -> 4x us on the DiMP-50 head).
+    // (one frame of DiMP-50: 256 workgroups x 16 chunks; ToMP's three frames would need 32 chunk times and stay on the
+    // GEMM path below, 76 vs 90 us)
+    const int ks = ((Cout * HW) % 4 == 0 && ((uintptr_t)out % 16) == 0 && pt_mf_corr_tm_cost(n, Cout, Cin, H, W) <= 18)
+                       ? pt_mf_corr_tm_splits(n, Cout, Cin, H, W) : 0;
+    if (ks > 0 && ks <= 9) {
+        if ((rc = pt_launch_mf_corr_tm(feat, (long)Cin * HW, weight_tap_major, base + cv.part, n, Cout, Cin, H, W, ks, st)) == PT_OK) {
+            hipLaunchKernelGGL(k_gn_reduce, dim3(cv.slices, n), dim3(256), 0, st, base + cv.part, ks, (long)M * Cout, base + cv.Y,
+                               base + cv.stats, HW * Cout);
+            PT_CHECK_LAUNCH();
+            hipLaunchKernelGGL(k_head_scale, dim3((Cout * HW / 4 + 255) / 256, n), dim3(256), 0, st, base + cv.Y, base + cv.stats,
+                               cv.slices, out, Cout, HW, norm_scale, eps);
+            PT_CHECK_LAUNCH();
+            return PT_OK;
+        }
+    }
     hipLaunchKernelGGL(k_nchw_to_tokens, dim3((HW + 31) / 32, (Cin + 31) / 32, n), dim3(256), 0, st, feat, base + cv.X, Cin,
                        HW);
     PT_CHECK_LAUNCH();
