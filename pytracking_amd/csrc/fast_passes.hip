@@ -149,9 +149,12 @@ __global__ __launch_bounds__(1024, (NK <= 8 ? 6 : 4)) void k_corr2(Corr2Args a) 
     if (k16) {
         const long g4 = ((long)cx0 * 16 >> 1) + e4;
         if (FUSE > 0) {
-            const long CKK4 = (long)a.C * 8;
+            // partial k in the scalar offset of the buffer load: no 64-bit address arithmetic per load on the VALU
+            const unsigned ckk_b = (unsigned)a.C * 16u * 4u;
+            const __amdgpu_buffer_rsrc_t rg = pt_rsrc(a.gpart, (unsigned)a.KSPL * ckk_b);
 #pragma unroll
-            for (int k = 0; k < FP; ++k) part4[k] = ((const f32x2*)a.gpart)[(long)min(k, a.KSPL - 1) * CKK4 + g4];
+            for (int k = 0; k < FP; ++k)
+                part4[k] = __builtin_bit_cast(f32x2, __builtin_amdgcn_raw_buffer_load_b64(rg, (unsigned)g4 * 8u, (unsigned)min(k, a.KSPL - 1) * ckk_b, 0));
             wv4 = ((const f32x2*)a.w)[g4];
         } else {
             part4[0] = ((const f32x2*)a.filt)[g4];
@@ -186,7 +189,7 @@ __global__ __launch_bounds__(1024, (NK <= 8 ? 6 : 4)) void k_corr2(Corr2Args a) 
     const unsigned fo = ((unsigned)cbase * HW + (pv ? pos : 0)) * 4u;
     const int lpos = 64 * a.TF + j;
     const bool lv = LEFT && t == 0 && j < 4 * a.rem;
-    const unsigned lo = ((unsigned)cbase * HW + (lv ? lpos : 0)) * 4u;
+    const unsigned lo = lv ? ((unsigned)cbase * HW + lpos) * 4u : 0xFFFFFFF0u - 64u * (unsigned)HW * 4u;   // no position: reads 0
     f32x4 bq[NK];
     float bl[NK];
     auto ldq = [&](int k) {
@@ -253,7 +256,7 @@ __global__ __launch_bounds__(1024, (NK <= 8 ? 6 : 4)) void k_corr2(Corr2Args a) 
         acc1 = mfma16(av, bq[k][1], acc1);
         acc2 = mfma16(av, bq[k][2], acc2);
         acc3 = mfma16(av, bq[k][3], acc3);
-        if (LEFT && t == 0) accL = mfma16(av, lv ? bl[k] : 0.f, accL);
+        if (LEFT && t == 0) accL = mfma16(av, bl[k], accL);
     }
     // ---- memory insert rides on the pass (pytracking/tracker/dimp/dimp.py:429-441)
     if (over && a.copy_dst) {
