@@ -258,7 +258,9 @@ def test_sd_fast_path_shapes_vs_oracle(n, C, H, W):
                                          # 1x1: re-rowed float4 path with a ragged channel count / odd map (banded kernel)
                                          (2, 16, 24, 18, 18, 1), (3, 9, 33, 7, 9, 1),
                                          # several full bands per sample; one-row bands (3 staged rows of 168 floats: the widest map a 3x3 pass stages)
-                                         (2, 16, 16, 64, 64, 3), (1, 16, 20, 3, 168, 3)])
+                                         (2, 16, 16, 64, 64, 3), (1, 16, 20, 3, 168, 3),
+                                         # even width that is not a multiple of 4 (480x854 frames: 30x54 maps): float2 staging
+                                         (2, 16, 32, 30, 54, 3), (3, 6, 24, 18, 18, 3)])
 def test_multifilter_ops_vs_oracle(n, F, C, H, W, K):
     from pytracking_amd import filter as FL
     rng = np.random.default_rng(7 * n + C)
