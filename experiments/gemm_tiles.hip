@@ -53,6 +53,39 @@ static float run(const char* tag, int M, int N, int K, int ksteps_per_z, const f
     return us;
 }
 
+// the 8-wave 128x128x32 kernel with the pinned schedule (k_gemm_big)
+static float run_big(const char* tag, int M, int N, int K, int ksteps_per_z, const float* A, const float* W, float* C, const float* ref,
+                     int reps) {
+    GemmArgs g = gemm_args(A, K, M, W, M, N, K, nullptr, C, N);
+    const int nk64 = (K + 63) / 64;
+    int nz = 1;
+    if (ksteps_per_z > 0) { g.ksteps = ksteps_per_z; g.c_zstride = (long)M * N; nz = (nk64 + ksteps_per_z - 1) / ksteps_per_z; }
+    dim3 grid((N + 127) / 128, (M + 127) / 128, nz), block(512);
+    const size_t lds = 2 * GB_STAGE * sizeof(float);
+    hipEvent_t e0, e1;
+    hipEventCreate(&e0); hipEventCreate(&e1);
+    for (int i = 0; i < 3; ++i) hipLaunchKernelGGL(k_gemm_big, grid, block, lds, 0, g);
+    if (hipDeviceSynchronize() != hipSuccess) { printf("%-28s big: launch failed\n", tag); return -1.f; }
+    hipEventRecord(e0, 0);
+    for (int i = 0; i < reps; ++i) hipLaunchKernelGGL(k_gemm_big, grid, block, lds, 0, g);
+    hipEventRecord(e1, 0);
+    hipEventSynchronize(e1);
+    float ms;
+    hipEventElapsedTime(&ms, e0, e1);
+    const float us = ms * 1e3f / reps;
+    std::vector<float> h((size_t)M * N * nz);
+    hipMemcpy(h.data(), C, h.size() * 4, hipMemcpyDeviceToHost);
+    double err = 0;
+    for (size_t i = 0; i < (size_t)M * N; i += 97) {
+        double s = 0;
+        for (int z = 0; z < nz; ++z) s += h[(size_t)z * M * N + i];
+        err = fmax(err, fabs(s - ref[i]));
+    }
+    printf("%-28s BIG  128x128x32 8 waves z=%d grid %4d  %7.2f us  %6.1f TFLOP/s  err %.1e\n", tag, nz,
+           (int)(grid.x * grid.y * grid.z), us, 2.0 * M * N * K / us / 1e6, err);
+    return us;
+}
+
 int main() {
     struct Shape { const char* name; int M, N, K; } shapes[] = {{"qkv 1944x768x256", 1944, 768, 256}, {"out 1944x256x256", 1944, 256, 256},
         {"ffn1 1944x2048x256", 1944, 2048, 256}, {"ffn2 1944x256x2048", 1944, 256, 2048}, {"head 324x512x9216", 324, 512, 9216},
@@ -82,6 +115,9 @@ int main() {
         run<128, 128, 32>(s.name, s.M, s.N, s.K, 0, A, W, C, ref.data(), R);
         if (deepk) run<128, 128, 32>(s.name, s.M, s.N, s.K, s.K / 64 / 8, A, W, C, ref.data(), R);
         if (deepk) run<128, 128, 32>(s.name, s.M, s.N, s.K, s.K / 64 / 16, A, W, C, ref.data(), R);
+        run_big(s.name, s.M, s.N, s.K, 0, A, W, C, ref.data(), R);
+        if (deepk) run_big(s.name, s.M, s.N, s.K, s.K / 64 / 8, A, W, C, ref.data(), R);
+        if (deepk) run_big(s.name, s.M, s.N, s.K, s.K / 64 / 16, A, W, C, ref.data(), R);
         hipFree(A); hipFree(W); hipFree(C);
     }
     return 0;

@@ -34,6 +34,91 @@ struct GemmArgs {
                                                 // a_zstride / w_zstride floats apart, output at C + z*c_zstride
 };
 
+// ------------------------------------------------------------------------------------------------------------------
+// epilogue shared by the GEMM kernels: accumulator tile (MT x NT fragments of 16x16, rows / columns permuted by prow) of
+// the wave whose first row / column is (mrow0, ncol0)
+// ------------------------------------------------------------------------------------------------------------------
+__device__ __forceinline__ int gemm_prow(int i) { return (i >= 4 && i < 12) ? 2 * (i - 4) : (i < 4 ? 2 * i + 1 : 2 * i - 15); }
+
+template <int MT, int NT>
+__device__ __forceinline__ void gemm_store(const GemmArgs& g, f32x4 (&acc)[MT][NT], int mrow0, int ncol0, int lane) {
+    auto prow = [](int i) { return gemm_prow(i); };
+    // epilogue: straight-line.  The row part of every output address is computed once per accumulator row (the segment /
+    // NCHW maps cost an integer division each) as a 32-bit BYTE offset for raw buffer accesses: rows / columns outside the
+    // matrix get an out-of-range offset, which the hardware drops (stores) or answers with 0 (loads) -- no per-element
+    // branches, so the compiler keeps all residual loads and all stores in flight (with `if (row < M)` around every
+    // element it put an s_waitcnt vmcnt(0) in front of every store: 0.23 us per element per lane, 18 us for a 128x128
+    // tile).  exp() only under a workgroup-uniform branch.
+    const __amdgpu_buffer_rsrc_t rsC = pt_rsrc(g.C, 0xFFFFFFE0u), rsR = pt_rsrc(g.R ? g.R : g.C, 0xFFFFFFE0u);
+    unsigned rbase[MT][4];
+    const bool plain = !g.nchw && g.c_segstride == 0;
+#pragma unroll
+    for (int mt = 0; mt < MT; ++mt)
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+            const int row = mrow0 + mt * 16 + prow(4 * (lane >> 4) + r);
+            const int rc = min(row, g.M - 1);
+            long o;
+            if (plain) {
+                o = (long)rc * g.ldc;
+            } else if (g.nchw) {
+                const int img = rc / g.HW;
+                o = (long)img * g.N * g.HW + (rc - img * g.HW);
+            } else {
+                const int sg = rc / g.c_seg;
+                o = ((long)sg * g.c_segstride + (rc - sg * g.c_seg)) * g.ldc;
+            }
+            rbase[mt][r] = row < g.M ? (unsigned)(o * 4) : OOB;
+        }
+    const unsigned zoff = (unsigned)((long)blockIdx.z * g.c_zstride * 4);
+    const unsigned cstep = (unsigned)(g.nchw ? g.HW : 1) * 4u;
+#pragma unroll
+    for (int nt = 0; nt < NT; ++nt) {
+        const int col = ncol0 + nt * 16 + prow(lane & 15);
+        const bool cok = col < g.N;
+        const int cc = cok ? col : 0;
+        const float bv = (g.bias && (g.batch || blockIdx.z == 0)) ? g.bias[cc] : 0.f;
+        const float sc = g.scale ? g.scale[cc] : 1.f, sh = g.shift ? g.shift[cc] : 0.f;
+        const unsigned coff = (unsigned)cc * cstep;
+        unsigned off[MT][4];
+#pragma unroll
+        for (int mt = 0; mt < MT; ++mt)
+#pragma unroll
+            for (int r = 0; r < 4; ++r) off[mt][r] = (cok && rbase[mt][r] != OOB) ? rbase[mt][r] + coff : OOB;
+        float v[MT][4];
+#pragma unroll
+        for (int mt = 0; mt < MT; ++mt)
+#pragma unroll
+            for (int r = 0; r < 4; ++r) {
+                const float t = (acc[mt][nt][r] + bv) * sc + sh;
+                v[mt][r] = g.relu ? fmaxf(t, 0.f) : t;
+            }
+        if (g.R) {                                                   // uniform: residual loads all in flight together
+            float res[MT][4];
+#pragma unroll
+            for (int mt = 0; mt < MT; ++mt)
+#pragma unroll
+                for (int r = 0; r < 4; ++r) res[mt][r] = pt_bload1(rsR, off[mt][r]);
+#pragma unroll
+            for (int mt = 0; mt < MT; ++mt)
+#pragma unroll
+                for (int r = 0; r < 4; ++r) v[mt][r] += res[mt][r];
+        }
+        if (g.expo) {                                                // uniform
+#pragma unroll
+            for (int mt = 0; mt < MT; ++mt)
+#pragma unroll
+                for (int r = 0; r < 4; ++r) v[mt][r] = expf(v[mt][r]);
+        }
+#pragma unroll
+        for (int mt = 0; mt < MT; ++mt)
+#pragma unroll
+            for (int r = 0; r < 4; ++r)
+                __builtin_amdgcn_raw_buffer_store_b32(__builtin_bit_cast(unsigned, v[mt][r]), rsC,
+                                                      off[mt][r] == OOB ? OOB : off[mt][r] + zoff, 0, 0);
+    }
+}
+
 template <int BM, int BN, int MODE, int BK = 64>
 __global__ __launch_bounds__(256) void k_gemm(GemmArgs g) {
     // K advances in steps of 64 (one barrier per 4 MFMA sub-steps of 16): with 32-wide steps the counters showed the
@@ -200,80 +285,125 @@ __global__ __launch_bounds__(256) void k_gemm(GemmArgs g) {
         }
     }
 
-    // epilogue: straight-line.  The row part of every output address is computed once per accumulator row (the segment /
-    // NCHW maps cost an integer division each) as a 32-bit BYTE offset for raw buffer accesses: rows / columns outside the
-    // matrix get an out-of-range offset, which the hardware drops (stores) or answers with 0 (loads) -- no per-element
-    // branches, so the compiler keeps all residual loads and all stores in flight (with `if (row < M)` around every
-    // element it put an s_waitcnt vmcnt(0) in front of every store: 0.23 us per element per lane, 18 us for a 128x128
-    // tile).  exp() only under a workgroup-uniform branch.
-    const __amdgpu_buffer_rsrc_t rsC = pt_rsrc(g.C, 0xFFFFFFE0u), rsR = pt_rsrc(g.R ? g.R : g.C, 0xFFFFFFE0u);
-    unsigned rbase[MT][4];
-    const bool plain = !g.nchw && g.c_segstride == 0;
+    gemm_store<MT, NT>(g, acc, m0 + wm * WM, n0 + wn * WN, lane);
+}
+
+// ------------------------------------------------------------------------------------------------------------------
+// 128 x 128 x 32 tiles, 8 wavefronts (2 x 4, each 64 x 32 = 4 x 2 MFMA fragments), for the wide GEMMs (M, N in the
+// thousands).  Built on what bounds the fp32 MFMA kernels here (experiments/mfma_issue.hip: nothing but SALU issues behind
+// a v_mfma_f32_16x16x4_f32; phases in which all waves touch LDS / wait on a barrier at once are pure loss):
+//   * 6 ds_read_b128 fragment reads per 32 MFMAs (4 A + 2 B fragments per 16-k sub-step), no address VALU in the loop (K
+//     advances through the scalar offset of the buffer loads);
+//   * two LDS stages; while stage s is multiplied, stage s+1 goes from registers into the other buffer and the loads of
+//     stage s+2 are issued; ONE barrier per stage, in front of its second sub-step (by then every wave has read its last
+//     fragments of the current buffer and written its share of the next), so that sub-step already reads stage s+1;
+//   * every memory instruction pinned behind one of the sub-step's first MFMAs (sched_barrier; left alone the scheduler
+//     sinks the reads to their first use);
+//   * two waves per SIMD.
+// MODE 0 only (plain A).  K % 32 == 0.  Same LDS layout / fragment permutation / epilogue as k_gemm.
+// ------------------------------------------------------------------------------------------------------------------
+constexpr int GB_LS = 36, GB_STAGE = 2 * 128 * GB_LS;               // floats per stage: A tile then W tile
+
+__global__ __launch_bounds__(512) void k_gemm_big(GemmArgs g) {
+    extern __shared__ __attribute__((aligned(16))) float gb_lds[];  // [2][GB_STAGE]
+    constexpr int MT = 4, NT = 2, WM = 64, WN = 32;
+    const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6), wm = wave >> 2, wn = wave & 3;
+    const int m0 = blockIdx.y * 128, n0 = blockIdx.x * 128;
+    const long zb = g.batch ? (long)blockIdx.z : 0;
+    const __amdgpu_buffer_rsrc_t rsA = pt_rsrc(g.A + zb * g.a_zstride, g.a_bytes), rsW = pt_rsrc(g.Wt + zb * g.w_zstride, g.w_bytes);
+    // loader: thread t covers 16 bytes of rows t/8 and t/8 + 64 of both tiles
+    const int lrow = tid >> 3, lc4 = (tid & 7) * 4;
+    unsigned aoff[2], woff[2];
+    int lds_at[2];
 #pragma unroll
-    for (int mt = 0; mt < MT; ++mt)
-#pragma unroll
-        for (int r = 0; r < 4; ++r) {
-            const int row = m0 + wm * WM + mt * 16 + prow(4 * (lane >> 4) + r);
-            const int rc = min(row, g.M - 1);
-            long o;
-            if (plain) {
-                o = (long)rc * g.ldc;
-            } else if (g.nchw) {
-                const int img = rc / g.HW;
-                o = (long)img * g.N * g.HW + (rc - img * g.HW);
-            } else {
-                const int sg = rc / g.c_seg;
-                o = ((long)sg * g.c_segstride + (rc - sg * g.c_seg)) * g.ldc;
-            }
-            rbase[mt][r] = row < g.M ? (unsigned)(o * 4) : OOB;
-        }
-    const unsigned zoff = (unsigned)((long)blockIdx.z * g.c_zstride * 4);
-    const unsigned cstep = (unsigned)(g.nchw ? g.HW : 1) * 4u;
-#pragma unroll
-    for (int nt = 0; nt < NT; ++nt) {
-        const int col = n0 + wn * WN + nt * 16 + prow(lane & 15);
-        const bool cok = col < g.N;
-        const int cc = cok ? col : 0;
-        const float bv = (g.bias && (g.batch || blockIdx.z == 0)) ? g.bias[cc] : 0.f;
-        const float sc = g.scale ? g.scale[cc] : 1.f, sh = g.shift ? g.shift[cc] : 0.f;
-        const unsigned coff = (unsigned)cc * cstep;
-        unsigned off[MT][4];
-#pragma unroll
-        for (int mt = 0; mt < MT; ++mt)
-#pragma unroll
-            for (int r = 0; r < 4; ++r) off[mt][r] = (cok && rbase[mt][r] != OOB) ? rbase[mt][r] + coff : OOB;
-        float v[MT][4];
-#pragma unroll
-        for (int mt = 0; mt < MT; ++mt)
-#pragma unroll
-            for (int r = 0; r < 4; ++r) {
-                const float t = (acc[mt][nt][r] + bv) * sc + sh;
-                v[mt][r] = g.relu ? fmaxf(t, 0.f) : t;
-            }
-        if (g.R) {                                                   // uniform: residual loads all in flight together
-            float res[MT][4];
-#pragma unroll
-            for (int mt = 0; mt < MT; ++mt)
-#pragma unroll
-                for (int r = 0; r < 4; ++r) res[mt][r] = pt_bload1(rsR, off[mt][r]);
-#pragma unroll
-            for (int mt = 0; mt < MT; ++mt)
-#pragma unroll
-                for (int r = 0; r < 4; ++r) v[mt][r] += res[mt][r];
-        }
-        if (g.expo) {                                                // uniform
-#pragma unroll
-            for (int mt = 0; mt < MT; ++mt)
-#pragma unroll
-                for (int r = 0; r < 4; ++r) v[mt][r] = expf(v[mt][r]);
-        }
-#pragma unroll
-        for (int mt = 0; mt < MT; ++mt)
-#pragma unroll
-            for (int r = 0; r < 4; ++r)
-                __builtin_amdgcn_raw_buffer_store_b32(__builtin_bit_cast(unsigned, v[mt][r]), rsC,
-                                                      off[mt][r] == OOB ? OOB : off[mt][r] + zoff, 0, 0);
+    for (int i = 0; i < 2; ++i) {
+        const int row = m0 + lrow + 64 * i, n = n0 + lrow + 64 * i;
+        aoff[i] = row < g.M ? (unsigned)(((long)row * g.lda + lc4) * 4) : OOB;
+        woff[i] = n < g.N ? (unsigned)(((long)n * g.K + lc4) * 4) : OOB;
+        lds_at[i] = (lrow + 64 * i) * GB_LS + lc4;
     }
+    const int nst_all = g.K / 32;
+    const int s0 = g.ksteps ? blockIdx.z * g.ksteps * 2 : 0;       // g.ksteps counts 64-wide steps
+    const int nst = (g.ksteps ? min(nst_all, s0 + g.ksteps * 2) : nst_all) - s0;
+    f32x4 ra[2], rb[2];
+    auto fetch_one = [&](int st, int k) {                           // k = 0, 1: A rows; 2, 3: W rows.  Past the end: last stage
+        const unsigned kbytes = (unsigned)(s0 + min(st, nst - 1)) * 128u;
+        if (k < 2) ra[k] = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(rsA, aoff[k], kbytes, 0));
+        else rb[k - 2] = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(rsW, woff[k - 2], kbytes, 0));
+    };
+    auto stash_one = [&](int buf, int k) {
+        float* base = gb_lds + buf * GB_STAGE;
+        if (k < 2) *reinterpret_cast<f32x4*>(__builtin_assume_aligned(base + lds_at[k], 16)) = ra[k];
+        else *reinterpret_cast<f32x4*>(__builtin_assume_aligned(base + 128 * GB_LS + lds_at[k - 2], 16)) = rb[k - 2];
+    };
+    // fragment addresses (k_gemm's conflict-free maps: MFMA row i <-> tile row prow(i), k-slot kq <-> k-quad {0,2,1,3}[kq])
+    const int qoff = ((lane >> 4) & 1) * 2 + (lane >> 5);
+    const int aso = (wm * WM + gemm_prow(lane & 15)) * GB_LS + qoff * 4;
+    const int bso = 128 * GB_LS + (wn * WN + gemm_prow(lane & 15)) * GB_LS + qoff * 4;
+    f32x4 fa[2][MT], fb[2][NT];
+    auto frag_one = [&](int buf, int hh, int set, int k) {          // k < MT: A fragment k, else W fragment k - MT
+        const float* base = gb_lds + buf * GB_STAGE + hh * 16;
+        if (k < MT) fa[set][k] = *reinterpret_cast<const f32x4*>(__builtin_assume_aligned(base + aso + k * 16 * GB_LS, 16));
+        else fb[set][k - MT] = *reinterpret_cast<const f32x4*>(__builtin_assume_aligned(base + bso + (k - MT) * 16 * GB_LS, 16));
+    };
+    f32x4 acc[MT][NT];
+#pragma unroll
+    for (int a = 0; a < MT; ++a)
+#pragma unroll
+        for (int b = 0; b < NT; ++b) acc[a][b] = f32x4{0.f, 0.f, 0.f, 0.f};
+    // one 16-k sub-step on fragment set `set`; `mem(i)` is issued behind MFMA i and pinned there
+    auto substep = [&](int set, auto&& mem) {
+#pragma unroll
+        for (int j = 0; j < 4; ++j)
+#pragma unroll
+            for (int mt = 0; mt < MT; ++mt)
+#pragma unroll
+                for (int nt = 0; nt < NT; ++nt) {
+                    acc[mt][nt] = mfma16(fa[set][mt][j], fb[set][nt][j], acc[mt][nt]);
+                    __builtin_amdgcn_sched_barrier(0);
+                    mem((j * MT + mt) * NT + nt);
+                    __builtin_amdgcn_sched_barrier(0);
+                }
+    };
+    if (nst > 0) {
+        {   // stages 0 and 1 requested together: one exposed memory round trip in front of the first MFMA, not two
+            f32x4 pa[2], pb[2];
+#pragma unroll
+            for (int k = 0; k < 4; ++k) fetch_one(0, k);
+#pragma unroll
+            for (int k = 0; k < 2; ++k) { pa[k] = ra[k]; pb[k] = rb[k]; }
+#pragma unroll
+            for (int k = 0; k < 4; ++k) fetch_one(1, k);
+            float* base = gb_lds;
+#pragma unroll
+            for (int k = 0; k < 2; ++k) {
+                *reinterpret_cast<f32x4*>(__builtin_assume_aligned(base + lds_at[k], 16)) = pa[k];
+                *reinterpret_cast<f32x4*>(__builtin_assume_aligned(base + 128 * GB_LS + lds_at[k], 16)) = pb[k];
+            }
+        }
+        __syncthreads();
+#pragma unroll
+        for (int k = 0; k < MT + NT; ++k) frag_one(0, 0, 0, k);
+        __builtin_amdgcn_sched_barrier(0);
+        // registers hold stage s+1 when stage s starts
+        for (int st = 0; st < nst; st += 2) {
+#pragma unroll
+            for (int h = 0; h < 2; ++h) {
+                const int s = st + h;                               // buffer h
+                if (h == 1 && s >= nst) break;
+                substep(0, [&](int i) {
+                    if (i < MT + NT) frag_one(h, 1, 1, i);                          // fragments of this stage's second sub-step
+                    else if (i < MT + NT + 4) stash_one(h ^ 1, i - (MT + NT));      // stage s+1 -> the other buffer
+                    else if (i < MT + NT + 8) fetch_one(s + 2, i - (MT + NT + 4));  // stage s+2 -> registers
+                });
+                __syncthreads();
+                substep(1, [&](int i) {
+                    if (i < MT + NT) frag_one(h ^ 1, 0, 0, i);                      // first fragments of stage s+1
+                });
+            }
+        }
+    }
+    gemm_store<MT, NT>(g, acc, m0 + wm * WM, n0 + wn * WN, lane);
 }
 
 GemmArgs gemm_args(const float* A, long lda, long a_rows, const float* Wt, int M, int N, int K, const float* bias,
@@ -286,7 +416,10 @@ GemmArgs gemm_args(const float* A, long lda, long a_rows, const float* Wt, int M
     return g;
 }
 
-// Workgroup tile by shape (experiments/gemm_tiles.hip, profiles/r02e_gemm_tiles.txt; M = 1944 rows of the ToMP encoder):
+// Workgroup tile by shape (experiments/gemm_tiles.hip, profiles/r02e_gemm_tiles.txt, r02m_gemm_tiles.txt; M = 1944 rows of the ToMP
+// encoder).  Wide outputs (N >= 1024, many rows) go to k_gemm_big: its K loop runs at 91 % of the fp32 MFMA peak (ffn2 shape,
+// one workgroup per 64 K-stages), but at K = 256 a workgroup has only 8 stages and prologue + epilogue weigh as much as they
+// do for the small tiles: 24.1 vs 27.8 us on ffn1.  Below that:
 // 32x32x64 everywhere except wide outputs (N >= 1024, many rows), where 64x64 tiles with 32-wide K steps halve the operand
 // traffic per flop and two workgroups still fit a CU: FFN first GEMM 36.3 -> 28.0 us.  Larger tiles (128x64, 128x128) run
 // their K steps at 67-74 % of the MFMA rate but leave too few workgroups at these sizes.
@@ -298,6 +431,12 @@ int launch_gemm(const GemmArgs& g, hipStream_t st, bool conv = false) {
     const long rows = g.nchw ? (long)g.M * g.N : (g.c_segstride ? ((long)(g.M / g.c_seg) + 1) * g.c_segstride * g.ldc
                                                                    : (long)g.M * g.ldc);
     if ((rows + (long)(nz - 1) * g.c_zstride) * 4 >= 0xFFFFFFE0L) return PT_ERR_UNSUPPORTED;
+    if (!conv && g.N >= 1024 && g.M >= 1024 && g.K % 32 == 0 && !g.pos && !g.batch) {
+        hipLaunchKernelGGL(k_gemm_big, dim3((g.N + 127) / 128, (g.M + 127) / 128, nz), dim3(512), 2 * GB_STAGE * sizeof(float),
+                           st, g);
+        PT_CHECK_LAUNCH();
+        return PT_OK;
+    }
     if (conv) {
         if (g.Cin % 64 != 0) return PT_ERR_UNSUPPORTED;
         hipLaunchKernelGGL((k_gemm<32, 32, 1>), dim3((g.N + 31) / 32, (g.M + 31) / 32, nz), dim3(256), 0, st, g);
