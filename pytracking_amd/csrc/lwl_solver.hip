@@ -34,10 +34,11 @@ __device__ __forceinline__ float lwl_sw(const LwlArgs& a, long e) {
     return a.sw[e];
 }
 
-__device__ __forceinline__ float lwl_sum_parts(const float* p) {   // every thread: fixed-order sum of LWL_NBLK partials
-    float t = 0.f;
-    for (int k = 0; k < LWL_NBLK; ++k) t += p[k];
-    return t;
+// every thread: the sum of the LWL_NBLK partials, fixed order (thread k holds partial k; wave sums, then the waves in order).
+// As a serial loop in every thread this was 2 x 256 dependent loads in front of the update kernel.
+__device__ __forceinline__ float lwl_sum_parts(const float* p, float* scratch) {
+    static_assert(LWL_NBLK == 256, "one partial per thread of the 256-thread block");
+    return block_sum(p[threadIdx.x], scratch);
 }
 
 // s_t (in place when t > 0: s <- s - alpha*sg), residual, adjoint input, loss partials; t > 0 also w_t = w_{t-1} - alpha*g
@@ -45,7 +46,7 @@ __global__ __launch_bounds__(256) void k_lwl_upd(LwlArgs a, int t, int want_loss
     __shared__ float scratch[16];
     float alpha = 0.f;
     if (t > 0) {
-        const float gg = lwl_sum_parts(a.ggp), hh = lwl_sum_parts(a.hhp) + a.lam * a.lam * gg;
+        const float gg = lwl_sum_parts(a.ggp, scratch), hh = lwl_sum_parts(a.hhp, scratch) + a.lam * a.lam * gg;
         alpha = gg / fmaxf(hh + a.slreg * gg, 1e-8f);                                   // steepestdescent.py:76-80
         const float* wp = lwl_w(a, t - 1);
         float* wn = a.w_iters + (long)t * a.CKK;
@@ -54,13 +55,31 @@ __global__ __launch_bounds__(256) void k_lwl_upd(LwlArgs a, int t, int want_loss
     }
     if (last && !want_loss) return;
     float lacc = 0.f;
-    for (long e = (long)blockIdx.x * 256 + threadIdx.x; e < a.N; e += (long)LWL_NBLK * 256) {
-        const float sv = t > 0 ? a.s[e] - alpha * a.sg[e] : a.s[e];
-        if (t > 0) a.s[e] = sv;
-        const float sw = lwl_sw(a, e);
-        const float r = sw * (sv - a.label[e]);                                         // loss_residual_modules.py:36
-        lacc += r * r;
-        if (!last) a.rmap[e] = sw * r;
+    // LWL_U strided elements per round: all loads of a round are issued before the first store (one element per round left
+    // every round waiting for its own loads: 12 dependent round trips)
+    constexpr int LWL_U = 4;
+    const long stride = (long)LWL_NBLK * 256;
+    for (long e0 = (long)blockIdx.x * 256 + threadIdx.x; e0 < a.N; e0 += LWL_U * stride) {
+        float sv[LWL_U], gv[LWL_U], lb[LWL_U], sw[LWL_U];
+#pragma unroll
+        for (int u = 0; u < LWL_U; ++u) {
+            const long e = min(e0 + u * stride, a.N - 1);
+            sv[u] = a.s[e];
+            gv[u] = t > 0 ? a.sg[e] : 0.f;
+            lb[u] = a.label[e];
+            sw[u] = lwl_sw(a, e);
+        }
+#pragma unroll
+        for (int u = 0; u < LWL_U; ++u) {
+            const long e = e0 + u * stride;
+            if (e < a.N) {
+                const float v = t > 0 ? sv[u] - alpha * gv[u] : sv[u];
+                if (t > 0) a.s[e] = v;
+                const float r = sw[u] * (v - lb[u]);                                    // loss_residual_modules.py:36
+                lacc += r * r;
+                if (!last) a.rmap[e] = sw[u] * r;
+            }
+        }
     }
     if (want_loss) {
         const float tot = block_sum(lacc, scratch);
@@ -75,7 +94,8 @@ __global__ __launch_bounds__(256) void k_lwl_g(LwlArgs a, int t) {
     float acc = 0.f;
     for (long e = (long)blockIdx.x * 256 + threadIdx.x; e < a.CKK; e += (long)LWL_NBLK * 256) {
         float v = 0.f;
-        for (int k = 0; k < a.NSG; ++k) v += a.gpart[(long)k * a.CKK + e];
+#pragma unroll 8
+        for (int k = 0; k < a.NSG; ++k) v += a.gpart[(long)k * a.CKK + e];       // unrolled: the loads of 8 partials in flight
         v += a.lam * a.lam * w[e];
         a.g[e] = v;
         {                                                           // the same value in the order k_mf_corr reads it
@@ -92,6 +112,7 @@ __global__ __launch_bounds__(256) void k_lwl_g(LwlArgs a, int t) {
 __global__ __launch_bounds__(256) void k_lwl_hh(LwlArgs a) {
     __shared__ float scratch[16];
     float acc = 0.f;
+#pragma unroll 4
     for (long e = (long)blockIdx.x * 256 + threadIdx.x; e < a.N; e += (long)LWL_NBLK * 256) {
         const float h = lwl_sw(a, e) * a.sg[e];
         acc += h * h;
