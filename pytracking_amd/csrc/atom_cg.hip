@@ -39,6 +39,7 @@ __global__ __launch_bounds__(512) void k_atom_pw(CgArgs a, int mode) {
     const float sq = sqrtf(a.sw[i]);
     for (int o = threadIdx.x; o < a.HW; o += blockDim.x) {
         float sv = 0.f;
+#pragma unroll 8
         for (int k = 0; k < a.KS; ++k) sv += a.spart[((long)k * a.n + i) * a.HW + o];
         if (mode == 0) {
             const float dv = sq * mlu_d(sv, a.act_min);
@@ -93,7 +94,8 @@ __global__ __launch_bounds__(1024) void k_atom_vec(CgArgs a, int phase, int ii) 
         }
         for (int e = threadIdx.x; e < a.CKK; e += blockDim.x) {
             float v = 0.f;
-            for (int k = 0; k < a.KSPL; ++k) v += a.gpart[(long)k * a.CKK + e];
+#pragma unroll 8
+            for (int k = 0; k < a.KSPL; ++k) v += a.gpart[(long)k * a.CKK + e];   // unrolled: 8 partial loads in flight
             a.r[e] = -(v + a.lambda * a.x[e]);
             a.delta[e] = 0.f;
         }
@@ -106,6 +108,7 @@ __global__ __launch_bounds__(1024) void k_atom_vec(CgArgs a, int phase, int ii) 
     float acc = 0.f;
     for (int e = threadIdx.x; e < a.CKK; e += blockDim.x) {
         float v = 0.f;
+#pragma unroll 8
         for (int k = 0; k < a.KSPL; ++k) v += a.gpart[(long)k * a.CKK + e];
         v += a.lambda * a.p[e];
         a.gpart[e] = v;                       // slice 0 now holds q (each thread only rewrites what it read)

@@ -52,6 +52,7 @@ __global__ __launch_bounds__(512) void k_gn_pw(GnArgs a, int mode) {
     const float sq = sqrtf(a.sw[i]);
     for (int o = threadIdx.x; o < a.HW; o += blockDim.x) {
         float t = 0.f;
+#pragma unroll 8
         for (int k = 0; k < a.KS; ++k) t += a.sp1[((long)k * a.n + i) * a.HW + o];
         float val;
         if (mode == 0) {
@@ -60,6 +61,7 @@ __global__ __launch_bounds__(512) void k_gn_pw(GnArgs a, int mode) {
             val = dv * (sq * (gn_mlu(t, a.act_min) - a.y[base + o]));
         } else {
             float t2 = 0.f;
+#pragma unroll 8
             for (int k = 0; k < a.KS; ++k) t2 += a.sp2[((long)k * a.n + i) * a.HW + o];
             const float dv = a.d[base + o];
             val = dv * (dv * (t + t2));
@@ -102,12 +104,14 @@ __device__ float gn_dot2(const float* u, const float* v, int n, float* scratch) 
 __device__ __forceinline__ float gn_gather(const GnArgs& a, int e, const float* vec) {
     float s = 0.f;
     if (e < a.NF) {
-        for (int k = 0; k < a.KSPL; ++k) s += a.gpf[(long)k * a.NF + e];
+#pragma unroll 8
+        for (int k = 0; k < a.KSPL; ++k) s += a.gpf[(long)k * a.NF + e];       // unrolled: 8 partial loads in flight
         return s + a.lf * vec[e];
     }
     const int ep = e - a.NF, row = ep / a.M, m = ep - row * a.M, grp = row >> 4, rl = row & 15;
     const int Fg = min(16, a.Kc - 16 * grp);
     const float* gp = a.gpP + (long)grp * a.NSG * 16 * a.M;
+#pragma unroll 8
     for (int k = 0; k < a.NSG; ++k) s += gp[((long)k * Fg + rl) * a.M + m];
     return s + a.lP * vec[e];
 }
