@@ -319,6 +319,7 @@ __global__ void k_sum_slices(const float* __restrict__ part, float* __restrict__
     const size_t e = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
     if (e >= count) return;
     float s = 0.f;
+#pragma unroll 8
     for (int k = 0; k < slices; ++k) s += part[(size_t)k * count + e];
     out[e] = s;
 }

@@ -140,6 +140,7 @@ __global__ void k_mf_sum_groups(const float* __restrict__ gpart, float* __restri
     const long e = (long)blockIdx.x * blockDim.x + threadIdx.x;
     if (e >= count) return;
     float s = 0.f;
+#pragma unroll 8
     for (int k = 0; k < groups; ++k) s += gpart[(long)k * count + e];
     out[e] = s;
 }
