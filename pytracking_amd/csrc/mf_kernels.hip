@@ -107,8 +107,10 @@ struct MfStage {
 //      and are transposed into the [k-step][lane][12] order on their way into LDS (C % 16 == 0, 16 filters per bank).
 // ksplit > 1: blockIdx.y = sample + n * split; split s multiplies its share of the channel chunks and writes its partial map
 //      to scores + s * part_zstride (summed by the caller in fixed order): a single frame has too few bands to fill the chip.
-template <int KK, int VW, bool WTM>
-__global__ __launch_bounds__(MF_CT) void k_mf_corr(const float* __restrict__ feat, long stride_n,
+// NPG: position groups of 64 per workgroup (4, or 6 = 12 waves for a whole 18x18 map as one band: 360 of 384 slots instead of
+//      2 bands of 180 of 256).  Waves = 2 NPG (two k halves), 128 NPG threads.
+template <int KK, int VW, bool WTM, int NPG = 4>
+__global__ __launch_bounds__(128 * NPG) void k_mf_corr(const float* __restrict__ feat, long stride_n,
                                                    const float* __restrict__ wT, float* __restrict__ scores,
                                                    long out_stride_n, MfGeom g, int CS, long wt_zstride, long out_zstride,
                                                    int ksplit, long part_zstride) {
@@ -121,20 +123,21 @@ __global__ __launch_bounds__(MF_CT) void k_mf_corr(const float* __restrict__ fea
     constexpr int TP = MF_TP(KK);
     constexpr int NB6 = K == 1 ? 4 : 6;                             // floats of a padded row one lane reads per (k-step, u)
     constexpr int WITEMS = WTM ? 16 * 9 * MF_KS : MF_KS * 64 * TP / 4;   // 16-byte items of a chunk's weight block
-    constexpr int WN = (WITEMS + MF_CT - 1) / MF_CT;
-    static_assert(MF_KS == 4 && MF_CK == 16 && WN <= 2, "two k-steps and two staging pieces per wave and chunk");
+    constexpr int NT = 128 * NPG, NWV = 2 * NPG;                    // threads, waves
+    constexpr int WN = (WITEMS + NT - 1) / NT;
+    static_assert(MF_KS == 4 && MF_CK == 16 && WN <= 2 && 2 * NWV >= MF_CK, "two k-steps and two staging pieces per wave and chunk");
     const int BUF = MF_CK * CS + MF_KS * 64 * TP;                   // floats per buffer
     const int band = blockIdx.x, i = blockIdx.y % g.n, ksp = blockIdx.y / g.n;
     scores += (long)ksp * part_zstride;
     const int lane = threadIdx.x & 63, wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
-    const int pg = wave & 3, kh = wave >> 2;
+    const int pg = wave % NPG, kh = wave / NPG;
     const int kq = lane >> 4, j = lane & 15;
     const int y0 = band * g.BR, rows = min(g.BR, g.H - y0);
     const int HW = g.H * g.W;
     const float inv_w = 1.0f / (float)g.W;
     const float* __restrict__ fi = feat + (long)i * stride_n;
 
-    for (int e = threadIdx.x; e < 2 * BUF; e += MF_CT) lds[e] = 0.f;   // padding (and rows outside the image) stay zero
+    for (int e = threadIdx.x; e < 2 * BUF; e += NT) lds[e] = 0.f;   // padding (and rows outside the image) stay zero
 
     // image rows [ys, ye) of the band + halo are contiguous in every channel plane
     const int ys = max(y0 - g.p, 0), ye = min(y0 + rows + g.p, g.H);
@@ -170,7 +173,7 @@ __global__ __launch_bounds__(MF_CT) void k_mf_corr(const float* __restrict__ fea
     }
 #pragma unroll
     for (int cc = 0; cc < WN; ++cc) {
-        const int e = threadIdx.x + MF_CT * cc;
+        const int e = threadIdx.x + NT * cc;
         if (WTM) {                                                  // item = (filter f, tap, k-step): channels 4 ks .. + 3
             const int ks = e & 3, ft = e >> 2, f = ft / 9, tap = ft - 9 * f;
             woff[cc] = e < WITEMS ? 4u * (unsigned)((f * 9 + tap) * g.C + 4 * ks) : 0x80000000u;
@@ -182,7 +185,7 @@ __global__ __launch_bounds__(MF_CT) void k_mf_corr(const float* __restrict__ fea
     }
     auto fetch_piece = [&](int ci, int cc) {
         const int c0 = (cbeg + min(ci, nchunks - 1)) * MF_CK;
-        const unsigned soff = (unsigned)min(c0 + wave + 8 * cc, g.C - 1) * (unsigned)HW * 4u;
+        const unsigned soff = (unsigned)min(c0 + min(wave + NWV * cc, MF_CK - 1), g.C - 1) * (unsigned)HW * 4u;
 #pragma unroll
         for (int q = 0; q < NQ; ++q) mf_bload<VW>(rsF, goff[q], soff, sv[cc][q]);
         if (cc < WN)
@@ -190,11 +193,13 @@ __global__ __launch_bounds__(MF_CT) void k_mf_corr(const float* __restrict__ fea
                 rsW, woff[cc], WTM ? (unsigned)c0 * 4u : (unsigned)(c0 >> 2) * (64 * TP * 4), 0));
     };
     auto stage_piece = [&](int buf, int cc) {
-        const int row = buf * BUF + (wave + 8 * cc) * CS;
+        const int row = buf * BUF + (wave + NWV * cc) * CS;
+        if (wave + NWV * cc < MF_CK) {                              // (12 waves: the second piece exists for waves 0..3 only)
 #pragma unroll
-        for (int q = 0; q < NQ; ++q) {
-            const int at = lrow[q] >= 0 ? row + lrow[q] : dump;
-            mf_lds_store<VW>(lds + at, sv[cc][q]);
+            for (int q = 0; q < NQ; ++q) {
+                const int at = lrow[q] >= 0 ? row + lrow[q] : dump;
+                mf_lds_store<VW>(lds + at, sv[cc][q]);
+            }
         }
         if (cc < WN) {
             if (WTM) {                                              // 4 channels of one (filter, tap): lanes kq = 0..3
@@ -305,7 +310,7 @@ __global__ __launch_bounds__(MF_CT) void k_mf_corr(const float* __restrict__ fea
 #pragma unroll
         for (int q = 0; q < 4; ++q)
 #pragma unroll
-            for (int r = 0; r < 4; ++r) lds[((pg * 4 + q) * 4 + r) * 64 + lane] = acc[q][r];
+            for (int r = 0; r < 4; ++r) lds[((pg * 4 + q) * 4 + r) * 64 + lane] = acc[q][r];   // NPG x 16 x 64 floats
     }
     __syncthreads();
     if (kh == 1) return;
@@ -689,7 +694,7 @@ static int mf_pad_to(int v, int mod, int res) {          // smallest x >= v with
     return x;
 }
 
-static MfPlan mf_plan(int n, int F, int C, int H, int W, int K, int br_force = 0) {   // br_force: rows per correlation band
+static MfPlan mf_plan(int n, int F, int C, int H, int W, int K, int br_force = 0, int npg = 4) {   // br_force: rows per correlation band; npg: 64-position groups per band
     MfPlan p;
     p.ok = 0;
     if (n <= 0 || F <= 0 || F > 16 || C <= 0 || H <= 0 || W <= 0) return p;
@@ -715,7 +720,7 @@ static MfPlan mf_plan(int n, int F, int C, int H, int W, int K, int br_force = 0
     g.Wp = (W + 3) & ~3;
     g.PS = g.Wp + 4;
     g.out_vec = 0;
-    int BR = 256 / g.Wp;
+    int BR = 64 * npg / g.Wp;
     if (BR > H) BR = H;
     while (BR > 1 && (BR + K - 1) * W > 64 * MF_NQ) --BR;            // what fits
     if (br_force > 0) {
@@ -724,7 +729,7 @@ static MfPlan mf_plan(int n, int F, int C, int H, int W, int K, int br_force = 0
     } else {
         while (BR > 1 && n * ((H + BR - 1) / BR) < 256 && (BR - 1) * g.Wp >= 128) --BR;
     }
-    if (BR < 1 || (BR + K - 1) * W > 64 * MF_NQ || BR * g.Wp > 256) return p;
+    if (BR < 1 || (BR + K - 1) * W > 64 * MF_NQ || BR * g.Wp > 64 * npg) return p;
     g.BR = BR;
     g.NB = (H + BR - 1) / BR;
     g.RSmax = BR + K - 1;
@@ -740,7 +745,7 @@ static MfPlan mf_plan(int n, int F, int C, int H, int W, int K, int br_force = 0
     p.CS = 4 + g.RSmax * g.PS;
     p.CS2 = mf_pad_to(4 + p.ga.RSmax * g.PS, 8, 4);     // == 4 mod 8: the 16 rows of a b128 read hit 16 different bank quads
     p.RS2 = mf_pad_to((BRa * g.Wp + 15) & ~15, 8, 4);   // whole groups of 16 positions; the tail of a row stays zero
-    p.corr_lds = std::max(2 * ((size_t)MF_CK * p.CS + MF_KS * 64 * MF_TP(g.KK)) + 4 * MF_CT, (size_t)4096) * sizeof(float);   // two buffers + dump slots | k-half sum
+    p.corr_lds = std::max(2 * ((size_t)MF_CK * p.CS + MF_KS * 64 * MF_TP(g.KK)) + 4 * 128 * npg, (size_t)1024 * npg) * sizeof(float);   // two buffers + dump slots | k-half sum
     p.adj_lds = std::max((size_t)2 * 16 * (p.CS2 + p.RS2) + 4 * 256, (size_t)4 * g.KK * 256) * sizeof(float);   // two buffers + dump slots | reduction
     const int CBn = (C + 15) / 16;
     int NSG = 512 / CBn;                                 // ~2 workgroups per CU
@@ -831,26 +836,27 @@ int pt_launch_mf_corr(const float* feat, long stride_n, const float* wT, float* 
     return PT_OK;
 }
 
-// 3x3 correlation with a bank of Ftot = 16 * groups filters kept tap-major, (Ftot, 9, C), split `ksplit` ways over the
-// channels: partial maps part[s][n][Ftot][H][W] (the caller sums them in fixed order).  pt_mf_corr_tm_splits() says how
-// many splits fill the chip (0: shape not covered).
-// Band height and channel splits for a bank of filters on few samples: the cheapest of (rounds of 256 workgroups) x (chunks
-// per workgroup + ~4 chunks of fixed cost), balanced bands on a tie.
-static int mf_tm_config(int n, int Ftot, int C, int H, int W, int* br_out) {
+// Band height, position groups (8 or 12 waves) and channel splits for a bank of filters on few samples: the cheapest of
+// (rounds of 256 workgroups) x (chunks per workgroup + ~4 chunks of fixed cost) x (waves / 8), balanced bands on a tie.
+static int mf_tm_config(int n, int Ftot, int C, int H, int W, int* br_out, int* npg_out, long* cost_out = nullptr) {
     if (Ftot <= 0 || Ftot % 16 || C <= 0 || C % 16 || H <= 0 || W <= 0) return 0;
     const int Wp = (W + 3) & ~3, nch = C / MF_CK, groups = Ftot / 16;
-    int best_ks = 0, best_br = 0;
+    int best_ks = 0, best_br = 0, best_npg = 4;
     long best_cost = -1;
-    for (int br = std::min(H, 256 / std::max(Wp, 1)); br >= 1; --br) {
-        if ((br + 2) * W > 64 * MF_NQ) continue;
-        const int nb = (H + br - 1) / br;
-        if (br != (H + nb - 1) / nb) continue;                      // only the balanced height of each band count
-        for (int ks = 1; ks <= 8 && ks <= nch; ks *= 2) {
-            const long wgs = (long)n * nb * groups * ks, cost = ((wgs + 255) / 256) * ((nch + ks - 1) / ks + 4);
-            if (best_cost < 0 || cost < best_cost) { best_cost = cost; best_ks = ks; best_br = br; }
+    for (int npg = 4; npg <= 6; npg += 2) {                         // a chunk costs a SIMD npg/4 as much
+        for (int br = std::min(H, 64 * npg / std::max(Wp, 1)); br >= 1; --br) {
+            if ((br + 2) * W > 64 * MF_NQ) continue;
+            const int nb = (H + br - 1) / br;
+            if (br != (H + nb - 1) / nb) continue;                  // only the balanced height of each band count
+            for (int ks = 1; ks <= 8 && ks <= nch; ks *= 2) {
+                const long wgs = (long)n * nb * groups * ks, cost = ((wgs + 255) / 256) * ((nch + ks - 1) / ks + 4) * npg;
+                if (best_cost < 0 || cost < best_cost) { best_cost = cost; best_ks = ks; best_br = br; best_npg = npg; }
+            }
         }
     }
     if (br_out) *br_out = best_br;
+    if (npg_out) *npg_out = best_npg;
+    if (cost_out) *cost_out = best_cost;
     return best_ks;
 }
 
@@ -858,34 +864,35 @@ static int mf_tm_config(int n, int Ftot, int C, int H, int W, int* br_out) {
 // channels: partial maps part[s][n][Ftot][H][W] (the caller sums them in fixed order).  pt_mf_corr_tm_splits() says how
 // many splits this launcher will use (0: shape not covered).
 int pt_mf_corr_tm_splits(int n, int Ftot, int C, int H, int W) {
-    int br = 0;
-    const int ks = mf_tm_config(n, Ftot, C, H, W, &br);
-    if (ks == 0 || br == 0 || !mf_plan(n, 16, C, H, W, 3, br).ok) return 0;
+    int br = 0, npg = 4;
+    const int ks = mf_tm_config(n, Ftot, C, H, W, &br, &npg);
+    if (ks == 0 || br == 0 || !mf_plan(n, 16, C, H, W, 3, br, npg).ok) return 0;
     return ks;
 }
-// chunk times (~2.7 us each on an 18x18 map) this launcher needs for the shape: rounds of 256 workgroups x chunks per split
+// what the shape costs on this launcher, in chunk times of the 8-wave kernel (~2.7 us each on an 18x18 map), fixed part included
 int pt_mf_corr_tm_cost(int n, int Ftot, int C, int H, int W) {
-    int br = 0;
-    const int ks = mf_tm_config(n, Ftot, C, H, W, &br);
+    int br = 0, npg = 4;
+    long cost = 0;
+    const int ks = mf_tm_config(n, Ftot, C, H, W, &br, &npg, &cost);
     if (ks == 0 || br == 0) return 1 << 30;
-    const long wgs = (long)n * ((H + br - 1) / br) * (Ftot / 16) * ks;
-    return (int)(((wgs + 255) / 256) * ((C / MF_CK + ks - 1) / ks));
+    return (int)(cost / 4);
 }
 int pt_launch_mf_corr_tm(const float* feat, long stride_n, const float* w_tap_major, float* part, int n, int Ftot, int C,
                          int H, int W, int ksplit, hipStream_t st) {
-    int br = 0;
-    if (mf_tm_config(n, Ftot, C, H, W, &br) != ksplit || ksplit < 1) return PT_ERR_UNSUPPORTED;
+    int br = 0, npg = 4;
+    if (mf_tm_config(n, Ftot, C, H, W, &br, &npg) != ksplit || ksplit < 1) return PT_ERR_UNSUPPORTED;
     if (((uintptr_t)w_tap_major % 16) || ((uintptr_t)part % 16) || (long)Ftot * 9 * C >= (1L << 30)) return PT_ERR_UNSUPPORTED;
     const int groups = Ftot / 16;
-    MfPlan p = mf_plan(n, 16, C, H, W, 3, br);
+    MfPlan p = mf_plan(n, 16, C, H, W, 3, br, npg);
     if (!p.ok) return PT_ERR_UNSUPPORTED;
     const long out_stride_n = (long)Ftot * H * W, wt_zs = (long)16 * 9 * C, out_zs = (long)16 * H * W;
-    dim3 grid(p.g.NB, n * ksplit, groups), block(MF_CT);
+    dim3 grid(p.g.NB, n * ksplit, groups), block(128 * npg);
     const int vw = mf_vec_width(feat, stride_n, H, W);
     p.g.out_vec = vw == 4 && ((H * W) % 4) == 0;
-#define PT_MFT(VWV) \
-    hipLaunchKernelGGL((k_mf_corr<9, VWV, true>), grid, block, p.corr_lds, st, feat, stride_n, w_tap_major, part, out_stride_n, p.g, p.CS, wt_zs, out_zs, ksplit, (long)n * out_stride_n)
-    if (vw == 4) PT_MFT(4); else if (vw == 2) PT_MFT(2); else PT_MFT(1);
+#define PT_MFT(VWV, NPGV) \
+    hipLaunchKernelGGL((k_mf_corr<9, VWV, true, NPGV>), grid, block, p.corr_lds, st, feat, stride_n, w_tap_major, part, out_stride_n, p.g, p.CS, wt_zs, out_zs, ksplit, (long)n * out_stride_n)
+    if (npg == 6) { if (vw == 4) PT_MFT(4, 6); else if (vw == 2) PT_MFT(2, 6); else PT_MFT(1, 6); }
+    else { if (vw == 4) PT_MFT(4, 4); else if (vw == 2) PT_MFT(2, 4); else PT_MFT(1, 4); }
 #undef PT_MFT
     PT_CHECK_LAUNCH();
     return PT_OK;

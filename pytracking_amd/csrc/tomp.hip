@@ -1222,7 +1222,7 @@ extern "C" int pt_clf_head_f32(const float* feat, const float* weight_tap_major,
     // 3 launches instead of 4, and the MFMA loop built on the issue model (66.6 -> 4x us on the DiMP-50 head).
     // (one frame of DiMP-50: 256 workgroups x 16 chunks; ToMP's three frames would need 32 chunk times and stay on the
     // GEMM path below, 76 vs 90 us)
-    const int ks = ((Cout * HW) % 4 == 0 && ((uintptr_t)out % 16) == 0 && pt_mf_corr_tm_cost(n, Cout, Cin, H, W) <= 18)
+    const int ks = ((Cout * HW) % 4 == 0 && ((uintptr_t)out % 16) == 0 && pt_mf_corr_tm_cost(n, Cout, Cin, H, W) <= 22)
                        ? pt_mf_corr_tm_splits(n, Cout, Cin, H, W) : 0;
     if (ks > 0 && ks <= 9) {
         if ((rc = pt_launch_mf_corr_tm(feat, (long)Cin * HW, weight_tap_major, base + cv.part, n, Cout, Cin, H, W, ks, st)) == PT_OK) {
