@@ -9,8 +9,8 @@
 // non-zero only for i in [floor(xs), ceil(xe)].  The gradient w.r.t. the bin edges is the boundary line integral
 // (Lx, Ly below) minus the mean-value term; RoI coordinates get it through xs = X0 + q*bw etc.
 //
-// The op is tiny (10 RoIs x 256 ch x 25 bins per IoUNet refine step): it is launch-latency bound, so each kernel
-// is a single flat launch; no LDS staging is needed because a bin touches <= ~4x4 pixels that stay in L1/L2.
+// The op is tiny (10 RoIs x 256 ch x 25 bins per IoUNet refine step): it is latency bound, so each kernel is a single flat
+// launch and a bin's <= 4 x 4 pixels are requested together (fixed window); no LDS staging is needed, they stay in L1/L2.
 #include "common.h"
 #include "pt_internal.h"
 
@@ -21,6 +21,8 @@ __device__ __forceinline__ float hat_cdf(float u) {
     return 1.f;
 }
 __device__ __forceinline__ float hat(float u) { return fmaxf(0.f, 1.f - fabsf(u)); }
+
+#define PRROI_WIN 4        // pixels per side of the fixed-window fast path
 
 struct Bin {
     float xs, xe, ys, ye, bw, bh, area;
@@ -53,12 +55,37 @@ __device__ __forceinline__ float prroi_fwd_elem(const float* __restrict__ feat, 
     float acc = 0.f;
     if (k.area > 0.f && k.b >= 0 && k.b < N) {
         const float* __restrict__ f = feat + ((long)k.b * C + c) * H * W;
-        for (int j = k.j0; j <= k.j1; ++j) {
-            const float wy = hat_cdf(k.ye - (float)j) - hat_cdf(k.ys - (float)j);
-            float row = 0.f;
-            for (int i = k.i0; i <= k.i1; ++i)
-                row += f[j * W + i] * (hat_cdf(k.xe - (float)i) - hat_cdf(k.xs - (float)i));
-            acc += wy * row;
+        const int nj = k.j1 - k.j0 + 1, ni = k.i1 - k.i0 + 1;
+        if (nj <= PRROI_WIN && ni <= PRROI_WIN) {
+            // the usual case (bins of 1-2 pixels touch <= 4 x 4): a fixed window, so that all loads are issued before the
+            // first wait -- the runtime-bounded loops below make every pixel its own dependent round trip
+            float v[PRROI_WIN][PRROI_WIN], wx[PRROI_WIN];
+#pragma unroll
+            for (int jj = 0; jj < PRROI_WIN; ++jj)
+#pragma unroll
+                for (int ii = 0; ii < PRROI_WIN; ++ii) v[jj][ii] = f[min(k.j0 + jj, k.j1) * W + min(k.i0 + ii, k.i1)];
+#pragma unroll
+            for (int ii = 0; ii < PRROI_WIN; ++ii) {
+                const float i = (float)(k.i0 + ii);
+                wx[ii] = ii < ni ? hat_cdf(k.xe - i) - hat_cdf(k.xs - i) : 0.f;
+            }
+#pragma unroll
+            for (int jj = 0; jj < PRROI_WIN; ++jj) {
+                const float j = (float)(k.j0 + jj);
+                const float wy = jj < nj ? hat_cdf(k.ye - j) - hat_cdf(k.ys - j) : 0.f;
+                float row = 0.f;
+#pragma unroll
+                for (int ii = 0; ii < PRROI_WIN; ++ii) row += v[jj][ii] * wx[ii];
+                acc += wy * row;
+            }
+        } else {
+            for (int j = k.j0; j <= k.j1; ++j) {
+                const float wy = hat_cdf(k.ye - (float)j) - hat_cdf(k.ys - (float)j);
+                float row = 0.f;
+                for (int i = k.i0; i <= k.i1; ++i)
+                    row += f[j * W + i] * (hat_cdf(k.xe - (float)i) - hat_cdf(k.xs - (float)i));
+                acc += wy * row;
+            }
         }
         acc /= k.area;
     }
@@ -153,21 +180,57 @@ __device__ __forceinline__ void prroi_coor_sums(const float* __restrict__ gout, 
         if (!(k.area > 0.f) || k.b < 0 || k.b >= N) continue;
         const float* __restrict__ f = feat + ((long)k.b * C + c) * H * W;
         float integ = 0.f, lxs = 0.f, lxe = 0.f, lys = 0.f, lye = 0.f;
-        for (int j = k.j0; j <= k.j1; ++j) {
-            const float wy = hat_cdf(k.ye - (float)j) - hat_cdf(k.ys - (float)j);
-            const float hys = hat(k.ys - (float)j), hye = hat(k.ye - (float)j);
-            float row = 0.f, rxs = 0.f, rxe = 0.f;
-            for (int i = k.i0; i <= k.i1; ++i) {
-                const float v = f[j * W + i];
-                row += v * (hat_cdf(k.xe - (float)i) - hat_cdf(k.xs - (float)i));
-                rxs += v * hat(k.xs - (float)i);
-                rxe += v * hat(k.xe - (float)i);
+        const int nj = k.j1 - k.j0 + 1, ni = k.i1 - k.i0 + 1;
+        if (nj <= PRROI_WIN && ni <= PRROI_WIN) {                   // fixed window: all loads in flight together (see forward)
+            float v[PRROI_WIN][PRROI_WIN], wx[PRROI_WIN], hxs[PRROI_WIN], hxe[PRROI_WIN];
+#pragma unroll
+            for (int jj = 0; jj < PRROI_WIN; ++jj)
+#pragma unroll
+                for (int ii = 0; ii < PRROI_WIN; ++ii) v[jj][ii] = f[min(k.j0 + jj, k.j1) * W + min(k.i0 + ii, k.i1)];
+#pragma unroll
+            for (int ii = 0; ii < PRROI_WIN; ++ii) {
+                const float i = (float)(k.i0 + ii);
+                const bool in = ii < ni;
+                wx[ii] = in ? hat_cdf(k.xe - i) - hat_cdf(k.xs - i) : 0.f;
+                hxs[ii] = in ? hat(k.xs - i) : 0.f;
+                hxe[ii] = in ? hat(k.xe - i) : 0.f;
             }
-            integ += wy * row;
-            lxs += wy * rxs;
-            lxe += wy * rxe;
-            lys += hys * row;
-            lye += hye * row;
+#pragma unroll
+            for (int jj = 0; jj < PRROI_WIN; ++jj) {
+                const float j = (float)(k.j0 + jj);
+                const bool in = jj < nj;
+                const float wy = in ? hat_cdf(k.ye - j) - hat_cdf(k.ys - j) : 0.f;
+                const float hys = in ? hat(k.ys - j) : 0.f, hye = in ? hat(k.ye - j) : 0.f;
+                float row = 0.f, rxs = 0.f, rxe = 0.f;
+#pragma unroll
+                for (int ii = 0; ii < PRROI_WIN; ++ii) {
+                    row += v[jj][ii] * wx[ii];
+                    rxs += v[jj][ii] * hxs[ii];
+                    rxe += v[jj][ii] * hxe[ii];
+                }
+                integ += wy * row;
+                lxs += wy * rxs;
+                lxe += wy * rxe;
+                lys += hys * row;
+                lye += hye * row;
+            }
+        } else {
+            for (int j = k.j0; j <= k.j1; ++j) {
+                const float wy = hat_cdf(k.ye - (float)j) - hat_cdf(k.ys - (float)j);
+                const float hys = hat(k.ys - (float)j), hye = hat(k.ye - (float)j);
+                float row = 0.f, rxs = 0.f, rxe = 0.f;
+                for (int i = k.i0; i <= k.i1; ++i) {
+                    const float v = f[j * W + i];
+                    row += v * (hat_cdf(k.xe - (float)i) - hat_cdf(k.xs - (float)i));
+                    rxs += v * hat(k.xs - (float)i);
+                    rxe += v * hat(k.xe - (float)i);
+                }
+                integ += wy * row;
+                lxs += wy * rxs;
+                lxe += wy * rxe;
+                lys += hys * row;
+                lye += hye * row;
+            }
         }
         const float inv = 1.f / k.area;
         const float o = integ * inv;
