@@ -22,8 +22,6 @@ __device__ __forceinline__ float hat_cdf(float u) {
 }
 __device__ __forceinline__ float hat(float u) { return fmaxf(0.f, 1.f - fabsf(u)); }
 
-#define PRROI_WIN 4        // pixels per side of the fixed-window fast path
-
 struct Bin {
     float xs, xe, ys, ye, bw, bh, area;
     int b, i0, i1, j0, j1;
@@ -48,6 +46,72 @@ __device__ __forceinline__ Bin make_bin(const float* __restrict__ roi, int p, in
     return k;
 }
 
+// Integral of one bin over a fixed WIN x WIN pixel window (the bin touches nj x ni <= WIN x WIN pixels): all loads are
+// issued before the first wait -- the runtime-bounded loops of the general form make every pixel its own dependent round
+// trip (k_prroi_bwd_coor2 18 -> 11 us, k_prroi_fwd2 9.3 -> 8.2 us at 2-3 pixel bins).  Same terms in the same order.
+template <int WIN>
+__device__ __forceinline__ float prroi_fwd_window(const float* __restrict__ f, const Bin& k, int W, int nj, int ni) {
+    float v[WIN][WIN], wx[WIN];
+#pragma unroll
+    for (int jj = 0; jj < WIN; ++jj)
+#pragma unroll
+        for (int ii = 0; ii < WIN; ++ii) v[jj][ii] = f[min(k.j0 + jj, k.j1) * W + min(k.i0 + ii, k.i1)];
+#pragma unroll
+    for (int ii = 0; ii < WIN; ++ii) {
+        const float i = (float)(k.i0 + ii);
+        wx[ii] = ii < ni ? hat_cdf(k.xe - i) - hat_cdf(k.xs - i) : 0.f;
+    }
+    float acc = 0.f;
+#pragma unroll
+    for (int jj = 0; jj < WIN; ++jj) {
+        const float j = (float)(k.j0 + jj);
+        const float wy = jj < nj ? hat_cdf(k.ye - j) - hat_cdf(k.ys - j) : 0.f;
+        float row = 0.f;
+#pragma unroll
+        for (int ii = 0; ii < WIN; ++ii) row += v[jj][ii] * wx[ii];
+        acc += wy * row;
+    }
+    return acc;
+}
+
+// the five sums of the coordinate gradient over the same window
+template <int WIN>
+__device__ __forceinline__ void prroi_coor_window(const float* __restrict__ f, const Bin& k, int W, int nj, int ni, float& integ,
+                                                  float& lxs, float& lxe, float& lys, float& lye) {
+    float v[WIN][WIN], wx[WIN], hxs[WIN], hxe[WIN];
+#pragma unroll
+    for (int jj = 0; jj < WIN; ++jj)
+#pragma unroll
+        for (int ii = 0; ii < WIN; ++ii) v[jj][ii] = f[min(k.j0 + jj, k.j1) * W + min(k.i0 + ii, k.i1)];
+#pragma unroll
+    for (int ii = 0; ii < WIN; ++ii) {
+        const float i = (float)(k.i0 + ii);
+        const bool in = ii < ni;
+        wx[ii] = in ? hat_cdf(k.xe - i) - hat_cdf(k.xs - i) : 0.f;
+        hxs[ii] = in ? hat(k.xs - i) : 0.f;
+        hxe[ii] = in ? hat(k.xe - i) : 0.f;
+    }
+#pragma unroll
+    for (int jj = 0; jj < WIN; ++jj) {
+        const float j = (float)(k.j0 + jj);
+        const bool in = jj < nj;
+        const float wy = in ? hat_cdf(k.ye - j) - hat_cdf(k.ys - j) : 0.f;
+        const float hys = in ? hat(k.ys - j) : 0.f, hye = in ? hat(k.ye - j) : 0.f;
+        float row = 0.f, rxs = 0.f, rxe = 0.f;
+#pragma unroll
+        for (int ii = 0; ii < WIN; ++ii) {
+            row += v[jj][ii] * wx[ii];
+            rxs += v[jj][ii] * hxs[ii];
+            rxe += v[jj][ii] * hxe[ii];
+        }
+        integ += wy * row;
+        lxs += wy * rxs;
+        lxe += wy * rxe;
+        lys += hys * row;
+        lye += hye * row;
+    }
+}
+
 // one output element: bin (p,q) of channel c of RoI r
 __device__ __forceinline__ float prroi_fwd_elem(const float* __restrict__ feat, const float* __restrict__ rois, int r, int c,
                                                 int p, int q, int N, int C, int H, int W, int PH, int PW, float scale) {
@@ -56,29 +120,9 @@ __device__ __forceinline__ float prroi_fwd_elem(const float* __restrict__ feat, 
     if (k.area > 0.f && k.b >= 0 && k.b < N) {
         const float* __restrict__ f = feat + ((long)k.b * C + c) * H * W;
         const int nj = k.j1 - k.j0 + 1, ni = k.i1 - k.i0 + 1;
-        if (nj <= PRROI_WIN && ni <= PRROI_WIN) {
-            // the usual case (bins of 1-2 pixels touch <= 4 x 4): a fixed window, so that all loads are issued before the
-            // first wait -- the runtime-bounded loops below make every pixel its own dependent round trip
-            float v[PRROI_WIN][PRROI_WIN], wx[PRROI_WIN];
-#pragma unroll
-            for (int jj = 0; jj < PRROI_WIN; ++jj)
-#pragma unroll
-                for (int ii = 0; ii < PRROI_WIN; ++ii) v[jj][ii] = f[min(k.j0 + jj, k.j1) * W + min(k.i0 + ii, k.i1)];
-#pragma unroll
-            for (int ii = 0; ii < PRROI_WIN; ++ii) {
-                const float i = (float)(k.i0 + ii);
-                wx[ii] = ii < ni ? hat_cdf(k.xe - i) - hat_cdf(k.xs - i) : 0.f;
-            }
-#pragma unroll
-            for (int jj = 0; jj < PRROI_WIN; ++jj) {
-                const float j = (float)(k.j0 + jj);
-                const float wy = jj < nj ? hat_cdf(k.ye - j) - hat_cdf(k.ys - j) : 0.f;
-                float row = 0.f;
-#pragma unroll
-                for (int ii = 0; ii < PRROI_WIN; ++ii) row += v[jj][ii] * wx[ii];
-                acc += wy * row;
-            }
-        } else {
+        if (nj <= 4 && ni <= 4) acc = prroi_fwd_window<4>(f, k, W, nj, ni);
+        else if (nj <= 6 && ni <= 6) acc = prroi_fwd_window<6>(f, k, W, nj, ni);
+        else {
             for (int j = k.j0; j <= k.j1; ++j) {
                 const float wy = hat_cdf(k.ye - (float)j) - hat_cdf(k.ys - (float)j);
                 float row = 0.f;
@@ -181,40 +225,9 @@ __device__ __forceinline__ void prroi_coor_sums(const float* __restrict__ gout, 
         const float* __restrict__ f = feat + ((long)k.b * C + c) * H * W;
         float integ = 0.f, lxs = 0.f, lxe = 0.f, lys = 0.f, lye = 0.f;
         const int nj = k.j1 - k.j0 + 1, ni = k.i1 - k.i0 + 1;
-        if (nj <= PRROI_WIN && ni <= PRROI_WIN) {                   // fixed window: all loads in flight together (see forward)
-            float v[PRROI_WIN][PRROI_WIN], wx[PRROI_WIN], hxs[PRROI_WIN], hxe[PRROI_WIN];
-#pragma unroll
-            for (int jj = 0; jj < PRROI_WIN; ++jj)
-#pragma unroll
-                for (int ii = 0; ii < PRROI_WIN; ++ii) v[jj][ii] = f[min(k.j0 + jj, k.j1) * W + min(k.i0 + ii, k.i1)];
-#pragma unroll
-            for (int ii = 0; ii < PRROI_WIN; ++ii) {
-                const float i = (float)(k.i0 + ii);
-                const bool in = ii < ni;
-                wx[ii] = in ? hat_cdf(k.xe - i) - hat_cdf(k.xs - i) : 0.f;
-                hxs[ii] = in ? hat(k.xs - i) : 0.f;
-                hxe[ii] = in ? hat(k.xe - i) : 0.f;
-            }
-#pragma unroll
-            for (int jj = 0; jj < PRROI_WIN; ++jj) {
-                const float j = (float)(k.j0 + jj);
-                const bool in = jj < nj;
-                const float wy = in ? hat_cdf(k.ye - j) - hat_cdf(k.ys - j) : 0.f;
-                const float hys = in ? hat(k.ys - j) : 0.f, hye = in ? hat(k.ye - j) : 0.f;
-                float row = 0.f, rxs = 0.f, rxe = 0.f;
-#pragma unroll
-                for (int ii = 0; ii < PRROI_WIN; ++ii) {
-                    row += v[jj][ii] * wx[ii];
-                    rxs += v[jj][ii] * hxs[ii];
-                    rxe += v[jj][ii] * hxe[ii];
-                }
-                integ += wy * row;
-                lxs += wy * rxs;
-                lxe += wy * rxe;
-                lys += hys * row;
-                lye += hye * row;
-            }
-        } else {
+        if (nj <= 4 && ni <= 4) prroi_coor_window<4>(f, k, W, nj, ni, integ, lxs, lxe, lys, lye);
+        else if (nj <= 6 && ni <= 6) prroi_coor_window<6>(f, k, W, nj, ni, integ, lxs, lxe, lys, lye);
+        else {
             for (int j = k.j0; j <= k.j1; ++j) {
                 const float wy = hat_cdf(k.ye - (float)j) - hat_cdf(k.ys - (float)j);
                 const float hys = hat(k.ys - (float)j), hye = hat(k.ye - (float)j);
