@@ -272,10 +272,9 @@ extern "C" int pt_iou_refine_f32(const pt_iou_dims* d, const float* params, cons
         if ((rc = pt_launch_prroi_fwd2(feats, mods, Xs, Cs, Hs, Ws, PHs, scales, base + cv.rois, P, st))) return rc;
         GemmArgs g = gemm_args(base + cv.X3, K3, P, params + po.w3, P, I3, K3, nullptr, base + cv.part3, I3);
         g.ksteps = KSPLIT; g.c_zstride = (long)P * I3;
-        if ((rc = launch_gemm(g, st))) return rc;
-        g = gemm_args(base + cv.X4, K4, P, params + po.w4, P, I4, K4, nullptr, base + cv.part4, I4);
-        g.ksteps = KSPLIT; g.c_zstride = (long)P * I4;
-        if ((rc = launch_gemm(g, st))) return rc;
+        GemmArgs g2 = gemm_args(base + cv.X4, K4, P, params + po.w4, P, I4, K4, nullptr, base + cv.part4, I4);
+        g2.ksteps = KSPLIT; g2.c_zstride = (long)P * I4;
+        if ((rc = launch_gemm_pair(g, g2, st))) return rc;              // both FC layers in one launch
         HeadArgs ha{base + cv.part3, base + cv.part4, params + po.b3, params + po.bn3, params + po.b4, params + po.bn4,
                     params + po.wp, params + po.bp, base + cv.G3, base + cv.G4, iou_out, P, I3, I4, cv.nz3, cv.nz4};
         hipLaunchKernelGGL(k_iou_head, dim3(P), dim3(256), 0, st, ha);
@@ -283,10 +282,9 @@ extern "C" int pt_iou_refine_f32(const pt_iou_dims* d, const float* params, cons
         // ---- backward to the box: d pooled = (G W) * modulation, then the PrRoIPool coordinate gradient
         g = gemm_args(base + cv.G3, I3, P, W3T, P, K3, I3, nullptr, base + cv.dX3, K3);
         g.scale = base + cv.msc3;
-        if ((rc = launch_gemm(g, st))) return rc;
-        g = gemm_args(base + cv.G4, I4, P, W4T, P, K4, I4, nullptr, base + cv.dX4, K4);
-        g.scale = base + cv.msc4;
-        if ((rc = launch_gemm(g, st))) return rc;
+        g2 = gemm_args(base + cv.G4, I4, P, W4T, P, K4, I4, nullptr, base + cv.dX4, K4);
+        g2.scale = base + cv.msc4;
+        if ((rc = launch_gemm_pair(g, g2, st))) return rc;
         if ((rc = pt_launch_prroi_bwd_coor2(dXs, feats, grs, Cs, Hs, Ws, PHs, scales, base + cv.rois, P, GSL, st))) return rc;
         UpdArgs ua{base + cv.gr3, base + cv.gr4, base + cv.szn, iou_out, base + cv.state, base + cv.rois, boxes_out,
                    base + cv.prev, base + cv.slen, base + cv.pstep, P, relative, it == num_iter - 1, backtrack,

@@ -41,7 +41,7 @@ struct GemmArgs {
 __device__ __forceinline__ int gemm_prow(int i) { return (i >= 4 && i < 12) ? 2 * (i - 4) : (i < 4 ? 2 * i + 1 : 2 * i - 15); }
 
 template <int MT, int NT>
-__device__ __forceinline__ void gemm_store(const GemmArgs& g, f32x4 (&acc)[MT][NT], int mrow0, int ncol0, int lane) {
+__device__ __forceinline__ void gemm_store(const GemmArgs& g, f32x4 (&acc)[MT][NT], int mrow0, int ncol0, int lane, int bz) {
     auto prow = [](int i) { return gemm_prow(i); };
     // epilogue: straight-line.  The row part of every output address is computed once per accumulator row (the segment /
     // NCHW maps cost an integer division each) as a 32-bit BYTE offset for raw buffer accesses: rows / columns outside the
@@ -70,14 +70,14 @@ __device__ __forceinline__ void gemm_store(const GemmArgs& g, f32x4 (&acc)[MT][N
             }
             rbase[mt][r] = row < g.M ? (unsigned)(o * 4) : OOB;
         }
-    const unsigned zoff = (unsigned)((long)blockIdx.z * g.c_zstride * 4);
+    const unsigned zoff = (unsigned)((long)bz * g.c_zstride * 4);
     const unsigned cstep = (unsigned)(g.nchw ? g.HW : 1) * 4u;
 #pragma unroll
     for (int nt = 0; nt < NT; ++nt) {
         const int col = ncol0 + nt * 16 + prow(lane & 15);
         const bool cok = col < g.N;
         const int cc = cok ? col : 0;
-        const float bv = (g.bias && (g.batch || blockIdx.z == 0)) ? g.bias[cc] : 0.f;
+        const float bv = (g.bias && (g.batch || bz == 0)) ? g.bias[cc] : 0.f;
         const float sc = g.scale ? g.scale[cc] : 1.f, sh = g.shift ? g.shift[cc] : 0.f;
         const unsigned coff = (unsigned)cc * cstep;
         unsigned off[MT][4];
@@ -119,8 +119,9 @@ __device__ __forceinline__ void gemm_store(const GemmArgs& g, f32x4 (&acc)[MT][N
     }
 }
 
+// one workgroup tile of the problem `g`: (bxi, byi) tile coordinates in a grid of gx column tiles, bzi the split / batch index
 template <int BM, int BN, int MODE, int BK = 64>
-__global__ __launch_bounds__(256) void k_gemm(GemmArgs g) {
+__device__ __forceinline__ void gemm_tile(const GemmArgs& g, const int bxi, const int byi, const int bzi, const int gx) {
     // K advances in steps of 64 (one barrier per 4 MFMA sub-steps of 16): with 32-wide steps the counters showed the
     // wavefronts parked at s_waitcnt / s_barrier for a third of their life and the LDS round trip exposed twice per step
     // (profiles/r01i_tomp_pmc.txt).  Fragment reads of sub-step h+1 are issued before the MFMAs of sub-step h.
@@ -134,16 +135,16 @@ __global__ __launch_bounds__(256) void k_gemm(GemmArgs g) {
     // has its own L2: with the natural map and a column-tile count that is a multiple of 8, every XCD walks ALL row tiles
     // of A (8 x 16 MB over the fabric for the FFN's second GEMM).  Swizzled: XCD c owns the row tiles = c mod 8 and sweeps
     // the column tiles, so A crosses the fabric once and only the (small) weight matrix is replicated per XCD.
-    int bx = blockIdx.x, by = blockIdx.y;
+    int bx = bxi, by = byi;
     if (g.swizzle) {
-        const int lin = blockIdx.y * gridDim.x + blockIdx.x, xcd = lin & 7, j = lin >> 3;
-        by = xcd + 8 * (j / (int)gridDim.x);
-        bx = j % (int)gridDim.x;
+        const int lin = byi * gx + bxi, xcd = lin & 7, j = lin >> 3;
+        by = xcd + 8 * (j / gx);
+        bx = j % gx;
         if (by * BM >= g.M) return;                              // padding rows of the rounded-up grid
     }
     const int m0 = by * BM, n0 = bx * BN;
     const int lrow = tid / (BK / 4), lc4 = (tid % (BK / 4)) * 4;   // loader: BK/4 threads cover one row segment of BK floats
-    const long zb = g.batch ? (long)blockIdx.z : 0;
+    const long zb = g.batch ? (long)bzi : 0;
     const __amdgpu_buffer_rsrc_t rsA = pt_rsrc(g.A + zb * g.a_zstride, g.a_bytes), rsW = pt_rsrc(g.Wt + zb * g.w_zstride, g.w_bytes);
     const bool addpos = MODE == 0 && g.pos != nullptr && n0 < g.pos_cols;
     const __amdgpu_buffer_rsrc_t rsP = pt_rsrc(addpos ? g.pos : g.A, addpos ? g.pos_bytes : 16u);
@@ -244,7 +245,7 @@ __global__ __launch_bounds__(256) void k_gemm(GemmArgs g) {
 
     const int nkt = (g.K + BK - 1) / BK;
     constexpr int KSU = 64 / BK;                                         // g.ksteps counts 64-wide steps whatever BK is
-    const int kb0 = g.ksteps ? blockIdx.z * g.ksteps * KSU : 0;
+    const int kb0 = g.ksteps ? bzi * g.ksteps * KSU : 0;
     const int nk = g.ksteps ? min(nkt, kb0 + g.ksteps * KSU) : nkt;
 #pragma unroll
     for (int sl = 0; sl < PD; ++sl) fetch(kb0 + sl, sl, kb0 + sl < nk);
@@ -285,7 +286,25 @@ __global__ __launch_bounds__(256) void k_gemm(GemmArgs g) {
         }
     }
 
-    gemm_store<MT, NT>(g, acc, m0 + wm * WM, n0 + wn * WN, lane);
+    gemm_store<MT, NT>(g, acc, m0 + wm * WM, n0 + wn * WN, lane, bzi);
+}
+
+template <int BM, int BN, int MODE, int BK = 64>
+__global__ __launch_bounds__(256) void k_gemm(GemmArgs g) {
+    gemm_tile<BM, BN, MODE, BK>(g, blockIdx.x, blockIdx.y, blockIdx.z, gridDim.x);
+}
+
+// Two independent small problems in one launch (the IoU head's two FC layers, forward and backward: 4 launches -> 2 per
+// refinement iteration; each is launch bound at M = 10): column tiles [0, nx0) belong to g0, the rest to g1; a workgroup
+// outside its problem's own row / split range leaves.
+template <int BM, int BN>
+__global__ __launch_bounds__(256) void k_gemm_pair(GemmArgs g0, GemmArgs g1, int nx0, int nx1) {
+    const bool first = (int)blockIdx.x < nx0;
+    const GemmArgs& g = first ? g0 : g1;
+    const int nz = g.ksteps ? ((g.K + 63) / 64 + g.ksteps - 1) / g.ksteps : 1;
+    if ((int)blockIdx.y * BM >= g.M || (int)blockIdx.z >= nz) return;
+    if (first) gemm_tile<BM, BN, 0, 64>(g0, blockIdx.x, blockIdx.y, blockIdx.z, nx0);
+    else gemm_tile<BM, BN, 0, 64>(g1, blockIdx.x - nx0, blockIdx.y, blockIdx.z, nx1);
 }
 
 // ------------------------------------------------------------------------------------------------------------------
@@ -403,7 +422,7 @@ __global__ __launch_bounds__(512) void k_gemm_big(GemmArgs g) {
             }
         }
     }
-    gemm_store<MT, NT>(g, acc, m0 + wm * WM, n0 + wn * WN, lane);
+    gemm_store<MT, NT>(g, acc, m0 + wm * WM, n0 + wn * WN, lane, blockIdx.z);
 }
 
 GemmArgs gemm_args(const float* A, long lda, long a_rows, const float* Wt, int M, int N, int K, const float* bias,
@@ -454,6 +473,18 @@ int launch_gemm(const GemmArgs& g, hipStream_t st, bool conv = false) {
         hipLaunchKernelGGL((k_gemm<32, 32, 0>), dim3((g.N + 31) / 32, gs.swizzle ? (gy + 7) / 8 * 8 : gy, nz), dim3(256), 0,
                            st, gs);
     }
+    PT_CHECK_LAUNCH();
+    return PT_OK;
+}
+
+// two plain GEMMs (no swizzle, no conv, no batch) as one launch of 32 x 32 tiles
+int launch_gemm_pair(const GemmArgs& g0, const GemmArgs& g1, hipStream_t st) {
+    for (const GemmArgs* g : {&g0, &g1})
+        if (g->K % 4 != 0 || g->M <= 0 || g->N <= 0 || g->batch || g->pos || g->swizzle) return PT_ERR_UNSUPPORTED;
+    auto nzf = [](const GemmArgs& g) { return g.ksteps ? ((g.K + 63) / 64 + g.ksteps - 1) / g.ksteps : 1; };
+    const int nx0 = (g0.N + 31) / 32, nx1 = (g1.N + 31) / 32;
+    const int gy = std::max((g0.M + 31) / 32, (g1.M + 31) / 32), nz = std::max(nzf(g0), nzf(g1));
+    hipLaunchKernelGGL((k_gemm_pair<32, 32>), dim3(nx0 + nx1, gy, nz), dim3(256), 0, st, g0, g1, nx0, nx1);
     PT_CHECK_LAUNCH();
     return PT_OK;
 }
