@@ -404,23 +404,81 @@ __global__ __launch_bounds__(256) void k_gemv(GemvArgs a) {
     float rterm[8];
 #pragma unroll
     for (int b = 0; b < 8; ++b) rterm[b] = 0.f;
-    if (a.res) {
-        const float rgn = a.rg ? a.rg[n] : 1.f, rbn = a.rg ? a.rb[n] : 0.f;
+    // <= 2 batch rows of <= 64*V*WCH elements (the decoder's shapes): the input rows and the residual rows are read ONCE,
+    // together with the weights, and their LayerNorm statistics come from registers -- otherwise every statistic is two
+    // dependent sweeps through memory and the dot product a third
+    const bool cached = pre && a.B <= 2 && (!a.rg || a.N <= 64 * V * WCH);
+    float xc[2][WCH][V];
+    if (cached) {
+        float rc[2][WCH][V];
+        const int nrc = a.rg ? a.N / (64 * V) : 0;
 #pragma unroll
-        for (int b = 0; b < 8; ++b) {
+        for (int b = 0; b < 2; ++b) {
             if (b >= a.B) continue;
-            const float* r = a.res + (long)b * a.N;
-            float m = 0.f, rs = 1.f;
-            if (a.rg) wave_row_stats<V>(r, a.N, lane, m, rs);
-            rterm[b] = (r[n] - m) * rs * rgn + rbn;
+#pragma unroll
+            for (int ch = 0; ch < WCH; ++ch) {
+                if (ch < nch) ldv<V>(a.x + (long)b * a.K + ch * 64 * V + lane * V, xc[b][ch]);
+                if (ch < nrc) ldv<V>(a.res + (long)b * a.N + ch * 64 * V + lane * V, rc[b][ch]);
+            }
+        }
+        float rn[2] = {0.f, 0.f};
+        if (a.res) {
+#pragma unroll
+            for (int b = 0; b < 2; ++b)
+                if (b < a.B) rn[b] = a.res[(long)b * a.N + n];
+        }
+        auto stats = [&](float (&v)[WCH][V], int nc, int len, float& m, float& rs) {     // same two-pass formula, from registers
+            float s = 0.f;
+#pragma unroll
+            for (int ch = 0; ch < WCH; ++ch)
+                if (ch < nc) {
+#pragma unroll
+                    for (int e = 0; e < V; ++e) s += v[ch][e];
+                }
+            m = wave_sum(s) / len;
+            float q = 0.f;
+#pragma unroll
+            for (int ch = 0; ch < WCH; ++ch)
+                if (ch < nc) {
+#pragma unroll
+                    for (int e = 0; e < V; ++e) q += (v[ch][e] - m) * (v[ch][e] - m);
+                }
+            rs = rsqrtf(wave_sum(q) / len + 1e-5f);
+        };
+        if (a.res) {
+            const float rgn = a.rg ? a.rg[n] : 1.f, rbn = a.rg ? a.rb[n] : 0.f;
+#pragma unroll
+            for (int b = 0; b < 2; ++b) {
+                if (b >= a.B) continue;
+                float m = 0.f, rs = 1.f;
+                if (a.rg) stats(rc[b], nrc, a.N, m, rs);
+                rterm[b] = (rn[b] - m) * rs * rgn + rbn;
+            }
+        }
+        if (a.xg) {
+#pragma unroll
+            for (int b = 0; b < 2; ++b)
+                if (b < a.B) stats(xc[b], nch, a.K, mean[b], rstd[b]);
+        }
+    } else {
+        if (a.res) {
+            const float rgn = a.rg ? a.rg[n] : 1.f, rbn = a.rg ? a.rb[n] : 0.f;
+#pragma unroll
+            for (int b = 0; b < 8; ++b) {
+                if (b >= a.B) continue;
+                const float* r = a.res + (long)b * a.N;
+                float m = 0.f, rs = 1.f;
+                if (a.rg) wave_row_stats<V>(r, a.N, lane, m, rs);
+                rterm[b] = (r[n] - m) * rs * rgn + rbn;
+            }
+        }
+        if (a.xg) {
+#pragma unroll
+            for (int b = 0; b < 8; ++b)
+                if (b < a.B) wave_row_stats<V>(a.x + (long)b * a.K, a.K, lane, mean[b], rstd[b]);
         }
     }
-    if (a.xg) {
-#pragma unroll
-        for (int b = 0; b < 8; ++b)
-            if (b < a.B) wave_row_stats<V>(a.x + (long)b * a.K, a.K, lane, mean[b], rstd[b]);
-    }
-    auto body = [&](int k, const float* wv) {
+    auto body = [&](int k, const float* wv, int ch) {
         float gv[V], bv[V], av[V];
 #pragma unroll
         for (int e = 0; e < V; ++e) gv[e] = 1.f, bv[e] = 0.f, av[e] = 0.f;
@@ -432,9 +490,13 @@ __global__ __launch_bounds__(256) void k_gemv(GemvArgs a) {
 #pragma unroll
         for (int b = 0; b < 8; ++b) {
             if (b >= a.B) continue;
-            const float* x = a.x + (long)b * a.K;
             float xr[V];
-            ldv<V>(x + k, xr);
+            if (cached && b < 2 && ch >= 0) {
+#pragma unroll
+                for (int e = 0; e < V; ++e) xr[e] = xc[b][ch][e];
+            } else {
+                ldv<V>(a.x + (long)b * a.K + k, xr);
+            }
 #pragma unroll
             for (int e = 0; e < V; ++e) {
                 float xv = (xr[e] - mean[b]) * rstd[b] * gv[e] + bv[e];
@@ -446,12 +508,12 @@ __global__ __launch_bounds__(256) void k_gemv(GemvArgs a) {
     if (pre) {
 #pragma unroll
         for (int ch = 0; ch < WCH; ++ch)
-            if (ch < nch) body(ch * 64 * V + lane * V, wreg[ch]);
+            if (ch < nch) body(ch * 64 * V + lane * V, wreg[ch], ch);
     } else {
         for (int k = lane * V; k < a.K; k += 64 * V) {
             float wv[V];
             ldv<V>(w + k, wv);
-            body(k, wv);
+            body(k, wv, -1);
         }
     }
 #pragma unroll
