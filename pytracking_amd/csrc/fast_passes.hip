@@ -536,44 +536,6 @@ __global__ __launch_bounds__(PT_ADJ_WAVES * 64) void k_adj2(Adj2Args a) {
     for (int e = threadIdx.x; e < ns * PHPW; e += blockDim.x) maps[e] = 0.f;
     for (int e = threadIdx.x; e < a.zn; e += blockDim.x) maps[ZB + e] = 0.f;
 
-    // ---- update stage first: its inputs are small and L2/MALL resident, and the MFMA chain cannot start before the
-    //      residual maps exist; the A operand is streamed afterwards so that its loads overlap the MFMAs.
-    PReg<E> pr;
-    const bool have = wave < ns;
-    const int hg0 = ((i_lo + wave) * HW) >> 4;                      // the slice holding a sample's first group owns it
-    const bool home0 = have && cb == 0 && hg0 >= gbeg && hg0 < gend;
-    sdp_load<V, E>(a, i_lo + min(wave, ns - 1), lane, home0, pr);
-    float astep = 0.f;
-    const bool wupd = V != V_PLAIN && a.t > 0 && ks == 0;
-    const long wge = (long)cb * 16 * KK + min((int)threadIdx.x, 16 * KK - 1);
-    if (V != V_PLAIN && a.t > 0) {                                  // optimizer.py:155-160 / :425-430
-        float q_in = 0.f, w_prev = 0.f, g_prev = 0.f;
-        for (int k = lane; k < a.sd.n; k += 64) q_in += a.sd.qs[k];
-        const float an_in = lane < a.sd.KS ? a.sd.anum[lane] : 0.f;
-        if (wupd) {                                                 // uniform per workgroup
-            w_prev = sd_w(a.sd, a.t - 1)[wge];
-            g_prev = a.sd.g[wge];
-        }
-        const float a_num = wave_sum(an_in);
-        const float den = fmaxf(wave_sum(q_in) + (a.sd.reg + a.sd.alpha_eps) * a_num, 1e-8f);
-        astep = a.sd.step * (a_num / den);
-        if (wupd && (int)threadIdx.x < 16 * KK)                     // w_t = w_{t-1} - step*alpha*g   (:160)
-            a.sd.w_iters[(long)a.t * a.sd.CKK + wge] = w_prev - astep * g_prev;
-    }
-    __syncthreads();                                                // maps zeroed
-    if (have) sdp_compute<V, E>(a, i_lo + wave, lane, pr, astep, maps + wave * PHPW, oy, ox, home0);
-    for (int sl = wave + PT_ADJ_WAVES; sl < ns; sl += PT_ADJ_WAVES) {   // more samples than waves (tiny maps)
-        const int i = i_lo + sl;
-        const int hg = (i * HW) >> 4;
-        const bool home = cb == 0 && hg >= gbeg && hg < gend;
-        sdp_load<V, E>(a, i, lane, home, pr);
-        sdp_compute<V, E>(a, i, lane, pr, astep, maps + sl * PHPW, oy, ox, home);
-    }
-    __syncthreads();
-
-    // ---- G[c][tap] += feat[c][P] * r[P shifted by tap] over the U contiguous 16-position groups of this wave.
-    //      A wave stalls at a load it cannot issue (the CU's memory pipeline accepts ~20-45 B/clk), so the loads are
-    //      software-pipelined PD groups ahead of the MFMAs that consume them instead of being issued all up front.
     constexpr int PD = UM < 8 ? UM : (UM == 8 ? 8 : 6);
     const int c = cb * 16 + j;
     const __amdgpu_buffer_rsrc_t fr = pt_rsrc(a.feat, (unsigned)(((long)(a.n - 1) * a.stride_n + (long)a.C * HW) * 4));
@@ -605,7 +567,34 @@ __global__ __launch_bounds__(PT_ADJ_WAVES * 64) void k_adj2(Adj2Args a) {
 #pragma unroll
         for (int k = 0; k < 4; ++k) tabI[4 * e + k] = 4 * (okk ? base + k + (x0 + k >= a.W ? wr : 0) : ZB);
     }
-    __syncthreads();
+
+    // ---- update stage: its inputs are small and L2/MALL resident, and the MFMA chain cannot start before the residual
+    //      maps exist.  The quad table above does not depend on it, so the first PD feature loads are issued in front of
+    //      it (after the barrier that publishes the table) and fly while the stage waits for its own inputs.
+    PReg<E> pr;
+    const bool have = wave < ns;
+    const int hg0 = ((i_lo + wave) * HW) >> 4;                      // the slice holding a sample's first group owns it
+    const bool home0 = have && cb == 0 && hg0 >= gbeg && hg0 < gend;
+    sdp_load<V, E>(a, i_lo + min(wave, ns - 1), lane, home0, pr);
+    float astep = 0.f;
+    const bool wupd = V != V_PLAIN && a.t > 0 && ks == 0;
+    const long wge = (long)cb * 16 * KK + min((int)threadIdx.x, 16 * KK - 1);
+    if (V != V_PLAIN && a.t > 0) {                                  // optimizer.py:155-160 / :425-430
+        float q_in = 0.f, w_prev = 0.f, g_prev = 0.f;
+        for (int k = lane; k < a.sd.n; k += 64) q_in += a.sd.qs[k];
+        const float an_in = lane < a.sd.KS ? a.sd.anum[lane] : 0.f;
+        if (wupd) {                                                 // uniform per workgroup
+            w_prev = sd_w(a.sd, a.t - 1)[wge];
+            g_prev = a.sd.g[wge];
+        }
+        const float a_num = wave_sum(an_in);
+        const float den = fmaxf(wave_sum(q_in) + (a.sd.reg + a.sd.alpha_eps) * a_num, 1e-8f);
+        astep = a.sd.step * (a_num / den);
+        if (wupd && (int)threadIdx.x < 16 * KK)                     // w_t = w_{t-1} - step*alpha*g   (:160)
+            a.sd.w_iters[(long)a.t * a.sd.CKK + wge] = w_prev - astep * g_prev;
+    }
+    __syncthreads();                                                // maps zeroed, quad table written
+    // the first feature loads go out now: they fly while the update stage below waits for its own (small) inputs
     const int tq = (kq * PT_ADJ_WAVES + wave) * UM;
     int foff[UM];
 #pragma unroll
@@ -623,9 +612,22 @@ __global__ __launch_bounds__(PT_ADJ_WAVES * 64) void k_adj2(Adj2Args a) {
 #pragma unroll
         for (int k = 0; k < 4; ++k) bv[u][k] = *(const float*)((const char*)maps + ((unsigned)cell[u][k] + tapoff4));
     };
-    f32x4 accA = {0, 0, 0, 0}, accB = {0, 0, 0, 0};
 #pragma unroll
     for (int u = 0; u < PD; ++u) issue(u);
+    if (have) sdp_compute<V, E>(a, i_lo + wave, lane, pr, astep, maps + wave * PHPW, oy, ox, home0);
+    for (int sl = wave + PT_ADJ_WAVES; sl < ns; sl += PT_ADJ_WAVES) {   // more samples than waves (tiny maps)
+        const int i = i_lo + sl;
+        const int hg = (i * HW) >> 4;
+        const bool home = cb == 0 && hg >= gbeg && hg < gend;
+        sdp_load<V, E>(a, i, lane, home, pr);
+        sdp_compute<V, E>(a, i, lane, pr, astep, maps + sl * PHPW, oy, ox, home);
+    }
+    __syncthreads();
+
+    // ---- G[c][tap] += feat[c][P] * r[P shifted by tap] over the U contiguous 16-position groups of this wave.
+    //      A wave stalls at a load it cannot issue (the CU's memory pipeline accepts ~20-45 B/clk), so the loads are
+    //      software-pipelined PD groups ahead of the MFMAs that consume them instead of being issued all up front.
+    f32x4 accA = {0, 0, 0, 0}, accB = {0, 0, 0, 0};
     cells(0);
     if (UM > 1) cells(1);
     gather(0);
