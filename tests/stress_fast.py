@@ -1,5 +1,5 @@
 """One-off randomized check of the single-filter passes (k_corr2 / k_adj2 and the generic k_corr / k_adj) against the float64
-oracle on many shapes.  python tools/stress_fast.py"""
+oracle on many shapes.  python tests/stress_fast.py"""
 import sys, numpy as np, torch
 sys.path.insert(0, '.')
 from pytracking_amd import filter as F

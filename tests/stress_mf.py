@@ -1,5 +1,5 @@
 """One-off randomized check of the multi-filter passes (k_mf_corr / k_mf_adj / k_mf_corr1) against the float64 oracle on 160
-random shapes.  python tools/stress_mf.py"""
+random shapes.  python tests/stress_mf.py"""
 import sys, numpy as np, torch
 sys.path.insert(0, '.')
 from pytracking_amd import filter as FL
