@@ -146,7 +146,7 @@ __global__ void k_mf_sum_groups(const float* __restrict__ gpart, float* __restri
 }
 
 // ---------------------------------------------------------------------------------------------------
-struct LwlCarve { size_t s, sg, rmap, gpart, g, gT, wT, ggp, hhp, lossp, total; };
+struct LwlCarve { size_t s, sg, rmap, gpart, g, gT, wT, ggp, hhp, lossp, cpart, total; };
 
 static LwlCarve lwl_carve(int n, int F, int C, int H, int W, int K) {
     LwlCarve c;
@@ -159,6 +159,7 @@ static LwlCarve lwl_carve(int n, int F, int C, int H, int W, int K) {
     c.gT = take(pt_mf_wt_floats(C, K)); c.wT = take(pt_mf_wt_floats(C, K));
     c.ggp = take(LWL_NBLK); c.hhp = take(LWL_NBLK);
     c.lossp = take((size_t)(LWL_MAX_ITER + 1) * LWL_NBLK);
+    c.cpart = take(pt_mf_corr_part_floats(n, F, C, H, W, K));       // channel-split partial maps of the correlation (few samples)
     c.total = off;
     return c;
 }
@@ -176,7 +177,7 @@ extern "C" size_t pt_lwl_ws_bytes(int n, int F, int C, int H, int W, int K) {
 
 extern "C" size_t pt_apply_filter_mf_ws_bytes(int n, int F, int C, int H, int W, int K) {
     if (mf_check(n, F, C, H, W, K)) return 0;
-    return pt_align_floats(pt_mf_wt_floats(C, K)) * sizeof(float);
+    return (pt_align_floats(pt_mf_wt_floats(C, K)) + pt_align_floats(pt_mf_corr_part_floats(n, F, C, H, W, K))) * sizeof(float);
 }
 
 extern "C" int pt_apply_filter_mf_f32(const float* feat, long feat_stride_n, const float* filt, float* scores, int n,
@@ -188,7 +189,8 @@ extern "C" int pt_apply_filter_mf_f32(const float* feat, long feat_stride_n, con
     if (ws_bytes < pt_apply_filter_mf_ws_bytes(n, F, C, H, W, K) || ((uintptr_t)ws % 256) != 0) return PT_ERR_WORKSPACE;
     rc = pt_launch_mf_wtrans(filt, (float*)ws, F, C, K, (hipStream_t)stream);
     if (rc) return rc;
-    return pt_launch_mf_corr(feat, feat_stride_n, (const float*)ws, scores, n, F, C, H, W, K, (hipStream_t)stream);
+    float* part = pt_mf_corr_part_floats(n, F, C, H, W, K) ? (float*)ws + pt_align_floats(pt_mf_wt_floats(C, K)) : nullptr;
+    return pt_launch_mf_corr(feat, feat_stride_n, (const float*)ws, scores, n, F, C, H, W, K, (hipStream_t)stream, 0, 1, part);
 }
 
 extern "C" size_t pt_feat_transpose_mf_ws_bytes(int n, int F, int C, int H, int W, int K) {
@@ -244,7 +246,8 @@ extern "C" int pt_lwl_gn_solve_f32(const float* w_in, const float* feat, long fe
     if (hipMemsetAsync(a.gT, 0, pt_mf_wt_floats(C, K) * sizeof(float), st) != hipSuccess) return PT_ERR_LAUNCH;
     rc = pt_launch_mf_wtrans(w_in, base + cv.wT, F, C, K, st);
     if (rc) return rc;
-    rc = pt_launch_mf_corr(feat, feat_stride_n, base + cv.wT, a.s, n, F, C, H, W, K, st);   // s_0 = F w_0
+    float* cpart = pt_mf_corr_part_floats(n, F, C, H, W, K) ? base + cv.cpart : nullptr;
+    rc = pt_launch_mf_corr(feat, feat_stride_n, base + cv.wT, a.s, n, F, C, H, W, K, st, 0, 1, cpart);   // s_0 = F w_0
     if (rc) return rc;
     hipLaunchKernelGGL(k_lwl_upd, dim3(LWL_NBLK), dim3(256), 0, st, a, 0, want_loss, (int)(num_iter == 0));
     PT_CHECK_LAUNCH();
@@ -253,7 +256,7 @@ extern "C" int pt_lwl_gn_solve_f32(const float* w_in, const float* feat, long fe
         if (rc) return rc;
         hipLaunchKernelGGL(k_lwl_g, dim3(LWL_NBLK), dim3(256), 0, st, a, t);
         PT_CHECK_LAUNCH();
-        rc = pt_launch_mf_corr(feat, feat_stride_n, a.gT, a.sg, n, F, C, H, W, K, st);  // F g
+        rc = pt_launch_mf_corr(feat, feat_stride_n, a.gT, a.sg, n, F, C, H, W, K, st, 0, 1, cpart);  // F g
         if (rc) return rc;
         hipLaunchKernelGGL(k_lwl_hh, dim3(LWL_NBLK), dim3(256), 0, st, a);
         PT_CHECK_LAUNCH();

@@ -814,25 +814,58 @@ int pt_launch_mf_corr1_direct(const float* feat, long stride_n, const float* fil
     return mf_launch_corr1(feat, stride_n, filt, true, scores, out_stride_n, n, 16, C, HW, Ftot / 16, 0, (long)16 * HW, 1, st);
 }
 
+// Few samples leave the 3x3 correlation too few bands for the chip (n = 1: the test frame of the few-shot learner, n < 16: the
+// first frames of a sequence): with a partial-map workspace the channels are split over `pt_mf_corr_splits` workgroups per band
+// and summed in fixed order.  1 = no split.
+int pt_mf_corr_splits(int n, int F, int C, int H, int W, int K) {
+    MfPlan p = mf_plan(n, F, C, H, W, K);
+    if (!p.ok || K != 3) return 1;
+    const int nch = (C + MF_CK - 1) / MF_CK;
+    int ks = 1;
+    while (ks < 8 && 2 * ks <= nch / 2 && (long)n * p.g.NB * ks < 192) ks *= 2;
+    while (ks > 1 && (ks - 1) * ((nch + ks - 1) / ks) >= nch) ks /= 2;     // every split owns at least one chunk
+    return ks;
+}
+size_t pt_mf_corr_part_floats(int n, int F, int C, int H, int W, int K) {
+    const int ks = pt_mf_corr_splits(n, F, C, H, W, K);
+    return ks > 1 ? (size_t)ks * n * F * H * W : 0;
+}
+__global__ void k_mf_sum_parts(const float* __restrict__ part, float* __restrict__ out, int parts, long count) {
+    const long e = ((long)blockIdx.x * blockDim.x + threadIdx.x) * 4;
+    if (e >= count) return;
+    f32x4 s = *(const f32x4*)(part + e);
+    for (int k = 1; k < parts; ++k) s += *(const f32x4*)(part + (long)k * count + e);
+    *(f32x4*)(out + e) = s;
+}
+
 // wT: weights pre-transposed by pt_launch_mf_wtrans (pt_mf_wt_floats(C, K) floats, 16-byte aligned)
 int pt_launch_mf_corr(const float* feat, long stride_n, const float* wT, float* scores, int n, int F, int C, int H,
-                      int W, int K, hipStream_t st, long out_stride_n, int groups) {
+                      int W, int K, hipStream_t st, long out_stride_n, int groups, float* part) {
     MfPlan p = mf_plan(n, F, C, H, W, K);
     if (out_stride_n == 0) out_stride_n = (long)F * H * W;
     if (!p.ok || groups < 1) return PT_ERR_UNSUPPORTED;
+    // channel splits into the caller's partial-map workspace (pt_mf_corr_part_floats), then the fixed-order sum
+    const int ksp = (part && groups == 1 && out_stride_n == (long)F * H * W && ((F * H * W) % 4) == 0 &&
+                     ((uintptr_t)part % 16) == 0 && ((uintptr_t)scores % 16) == 0) ? pt_mf_corr_splits(n, F, C, H, W, K) : 1;
     // groups > 1: `groups` banks of F filters each (weight tables back to back, outputs F*H*W apart inside a sample)
     const long wt_zs = (long)pt_mf_wt_floats(C, K), out_zs = (long)F * H * W;
-    dim3 grid(p.g.NB, n, groups), block(MF_CT);
+    dim3 grid(p.g.NB, n * ksp, groups), block(MF_CT);
     const bool vec = mf_vec_ok(feat, feat, stride_n, p.g.W);            // the plan's W (a 1x1 map is re-rowed)
-    p.g.out_vec = vec && ((uintptr_t)scores % 16) == 0 && (out_stride_n % 4) == 0 && ((H * W) % 4) == 0;
+    float* dst = ksp > 1 ? part : scores;
+    p.g.out_vec = vec && ((uintptr_t)dst % 16) == 0 && (out_stride_n % 4) == 0 && ((H * W) % 4) == 0;
 #define PT_MFC(KKV, VWV) \
-    hipLaunchKernelGGL((k_mf_corr<KKV, VWV, false>), grid, block, p.corr_lds, st, feat, stride_n, wT, scores, out_stride_n, p.g, p.CS, wt_zs, out_zs, 1, 0L)
+    hipLaunchKernelGGL((k_mf_corr<KKV, VWV, false>), grid, block, p.corr_lds, st, feat, stride_n, wT, dst, out_stride_n, p.g, p.CS, wt_zs, out_zs, ksp, (long)n * out_stride_n)
     if (K == 1 && vec) return mf_launch_corr1(feat, stride_n, wT, false, scores, out_stride_n, n, F, C, H * W, groups, wt_zs, out_zs, p.g.out_vec, st);
     const int vw = mf_vec_width(feat, stride_n, p.g.H, p.g.W);
     if (K == 1) { PT_MFC(1, 1); }
     else { if (vw == 4) PT_MFC(9, 4); else if (vw == 2) PT_MFC(9, 2); else PT_MFC(9, 1); }
 #undef PT_MFC
     PT_CHECK_LAUNCH();
+    if (ksp > 1) {
+        const long count = (long)n * out_stride_n;
+        hipLaunchKernelGGL(k_mf_sum_parts, dim3((unsigned)((count / 4 + 255) / 256)), dim3(256), 0, st, part, scores, ksp, count);
+        PT_CHECK_LAUNCH();
+    }
     return PT_OK;
 }
 
@@ -849,6 +882,7 @@ static int mf_tm_config(int n, int Ftot, int C, int H, int W, int* br_out, int* 
             const int nb = (H + br - 1) / br;
             if (br != (H + nb - 1) / nb) continue;                  // only the balanced height of each band count
             for (int ks = 1; ks <= 8 && ks <= nch; ks *= 2) {
+                if (ks > 1 && (ks - 1) * ((nch + ks - 1) / ks) >= nch) continue;    // every split owns at least one chunk
                 const long wgs = (long)n * nb * groups * ks, cost = ((wgs + 255) / 256) * ((nch + ks - 1) / ks + 4) * npg;
                 if (best_cost < 0 || cost < best_cost) { best_cost = cost; best_ks = ks; best_br = br; best_npg = npg; }
             }

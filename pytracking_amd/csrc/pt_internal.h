@@ -98,8 +98,10 @@ int pt_launch_mf_corr_tm(const float* feat, long stride_n, const float* w_tap_ma
                          int H, int W, int ksplit, hipStream_t st);          // 3x3, weights (Ftot, 9, C); partial maps
 int pt_launch_mf_corr1_direct(const float* feat, long stride_n, const float* filt, float* scores, int n, int Ftot, int C,
                               int H, int W, hipStream_t st, long out_stride_n);     // 1x1, weights (Ftot, C) untransposed
+int pt_mf_corr_splits(int n, int F, int C, int H, int W, int K);               // channel splits used with a partial workspace
+size_t pt_mf_corr_part_floats(int n, int F, int C, int H, int W, int K);         // its size (0: no split for this shape)
 int pt_launch_mf_corr(const float* feat, long stride_n, const float* wT, float* scores, int n, int F, int C, int H,
-                      int W, int K, hipStream_t st, long out_stride_n = 0, int groups = 1);
+                      int W, int K, hipStream_t st, long out_stride_n = 0, int groups = 1, float* part = nullptr);
 int pt_launch_mf_adj(const float* feat, long stride_n, const float* inp, float* gpart, int n, int F, int C, int H, int W,
                      int K, hipStream_t st, long inp_stride_n = 0, int groups = 1);
 
