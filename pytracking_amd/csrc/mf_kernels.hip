@@ -483,7 +483,7 @@ __global__ void k_mf_wtrans(const float* __restrict__ filt, float* __restrict__ 
 template <int KK, int VW>
 __global__ __launch_bounds__(256) void k_mf_adj(const float* __restrict__ feat, long stride_n,
                                                 const float* __restrict__ inp, long inp_stride_n,
-                                                float* __restrict__ gpart, MfGeom g, int CS2, int RS2, int spg,
+                                                float* __restrict__ gpart, MfGeom g, int CS2, int RS2, int spg, int bps,
                                                 long inp_zstride, long gp_zstride) {
     extern __shared__ __attribute__((aligned(16))) float lds[];
     inp += (long)blockIdx.z * inp_zstride;                          // blockIdx.z: group of <= 16 filters of a wider bank
@@ -501,8 +501,11 @@ __global__ __launch_bounds__(256) void k_mf_adj(const float* __restrict__ feat, 
     const int kq = lane >> 4, j = lane & 15;
     const int HW = g.H * g.W;
     const float inv_w = 1.0f / (float)g.W, inv_wp = 1.0f / (float)g.Wp;
-    const int i_beg = sg * spg, i_end = min(g.n, i_beg + spg);
-    const int nst = (i_end - i_beg) * g.NB;                         // stages = (sample, band) pairs
+    // group sg: spg samples with all their bands, or (bps > 1, few samples) one sample's share of the bands
+    const int bpg = (g.NB + bps - 1) / bps;
+    const int i_beg = bps > 1 ? sg / bps : sg * spg, i_end = bps > 1 ? i_beg + 1 : min(g.n, i_beg + spg);
+    const int b_beg = bps > 1 ? (sg % bps) * bpg : 0, b_cnt = bps > 1 ? max(0, min(g.NB, b_beg + bpg) - b_beg) : g.NB;
+    const int nst = (i_end - i_beg) * b_cnt;                        // stages = (sample, band) pairs
     const int dump = 2 * BUF + 4 * threadIdx.x;
 
     f32x4 acc[KK];
@@ -534,7 +537,7 @@ __global__ __launch_bounds__(256) void k_mf_adj(const float* __restrict__ feat, 
     // offset below 0 or beyond H*W is out of range and reads 0.  A stage index beyond the last re-fetches the last stage.
     auto fetch_piece = [&](int st, int cc) {
         const int sc = min(st, nst - 1);
-        const int si = sc / g.NB, band = sc - si * g.NB;
+        const int si = sc / b_cnt, band = b_beg + sc - si * b_cnt;
         const int i = i_beg + si, y0 = band * g.BR;
         const int c = min(cb * 16 + wave + 4 * cc, g.C - 1), f = min(wave + 4 * cc, g.F - 1);
         const __amdgpu_buffer_rsrc_t rsF = pt_rsrc(feat + (long)i * stride_n + (long)c * HW, (unsigned)HW * 4u);
@@ -569,7 +572,7 @@ __global__ __launch_bounds__(256) void k_mf_adj(const float* __restrict__ feat, 
         b_at = buf * BUF + j * CS2 + 4 + P + 4 * r;                 // 4 + r PS + x, PS = Wp + 4
     };
     auto slot_valid = [&](int st, int sl) {                         // wave uniform
-        const int sc = min(st, nst - 1), band = sc - (sc / g.NB) * g.NB;
+        const int sc = min(st, nst - 1), band = b_beg + sc - (sc / b_cnt) * b_cnt;
         const int rows = min(g.BR, g.H - band * g.BR);
         return st < nst && 16 * (4 * sl + ((wave + st) & 3)) < rows * g.Wp;
     };
@@ -684,7 +687,7 @@ struct MfPlan {
     int ok;
     MfGeom g;            // correlation geometry
     MfGeom ga;           // adjoint geometry
-    int CS, CS2, RS2, spg, NSG;
+    int CS, CS2, RS2, spg, NSG, bps;
     size_t corr_lds, adj_lds;
 };
 
@@ -754,6 +757,14 @@ static MfPlan mf_plan(int n, int F, int C, int H, int W, int K, int br_force = 0
     if (NSG > 32) NSG = 32;
     p.spg = (n + NSG - 1) / NSG;
     p.NSG = (n + p.spg - 1) / p.spg;
+    p.bps = 1;
+    if (p.spg == 1 && (long)n * CBn < 256 && p.ga.NB > 1) {         // few samples: a sample's bands over several workgroups
+        int bps = std::min(p.ga.NB, (int)((256 + (long)n * CBn - 1) / ((long)n * CBn)));
+        while (bps > 1 && n * bps > 32) --bps;
+        const int bpg = (p.ga.NB + bps - 1) / bps;
+        bps = (p.ga.NB + bpg - 1) / bpg;                            // no empty share
+        if (bps > 1) { p.bps = bps; p.NSG = n * bps; }
+    }
     if (p.corr_lds > 150 * 1024 || p.adj_lds > 150 * 1024) return p;
     p.ok = 1;
     return p;
@@ -944,7 +955,7 @@ int pt_launch_mf_adj(const float* feat, long stride_n, const float* inp, float* 
     const bool vec2 = !vec && (p.ga.W % 2) == 0 && (stride_n % 2) == 0 && (inp_stride_n % 2) == 0 &&
                       ((uintptr_t)feat % 8) == 0 && ((uintptr_t)inp % 8) == 0;
 #define PT_MFA(KKV, VWV) \
-    hipLaunchKernelGGL((k_mf_adj<KKV, VWV>), grid, block, p.adj_lds, st, feat, stride_n, inp, inp_stride_n, gpart, p.ga, p.CS2, p.RS2, p.spg, inp_zs, gp_zs)
+    hipLaunchKernelGGL((k_mf_adj<KKV, VWV>), grid, block, p.adj_lds, st, feat, stride_n, inp, inp_stride_n, gpart, p.ga, p.CS2, p.RS2, p.spg, p.bps, inp_zs, gp_zs)
     if (K == 1) { if (vec) PT_MFA(1, 4); else PT_MFA(1, 1); }
     else { if (vec) PT_MFA(9, 4); else if (vec2) PT_MFA(9, 2); else PT_MFA(9, 1); }
 #undef PT_MFA
