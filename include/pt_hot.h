@@ -256,6 +256,28 @@ int pt_max2d_f32(const float* a, float* max_val, long long* argmax, int n, int H
 int pt_localize_f32(const float* scores, const float* scores_hn, const float* neigh_rows, const float* neigh_cols,
                     float* out8, int S, int H, int W, void* stream);
 
+/* pt_localize_decide_f32: the whole of `localize_advanced` in one launch -- both peaks
+ * as pt_localize_f32 finds them, then the outcome of dimp.py:258-303 decided on the device.  The caller supplies the
+ * per-frame constants below (plain host arithmetic on the tracker's state; no device data is needed to form them):
+ *   thresholds on the first peak are compared as doubles (`max_score1.item() < threshold`), the remaining tests are the
+ *   reference's float32 tensor expressions (`python float * float32 tensor`, `float32 tensor > python float`);
+ *   center = (score_sz - 1) / 2, ratio = img_support_sz / output_sz (dimp.py:241-244), per scale s: scale[s] =
+ *   sample_scales[s], neigh = target_neigh_sz (dimp.py:268), prev = prev_target_vec (dimp.py:285), disp_threshold =
+ *   dispalcement_scale * sqrt(H * W) / 2 (dimp.py:291).  Absent optional thresholds are passed as -infinity.
+ * out16 (device memory OR device-visible pinned host memory; the kernel writes it directly) =
+ *   [code, scale_ind, row, col, translation_row, translation_col, max1, row1, col1, max2, row2, col2, peak_chosen, 0, 0, 0]
+ *   with code = PT_LOC_*, (row, col) the displacement (`max_disp`) of the chosen peak and translation =
+ *   (disp - center) * ratio * scale[scale_ind] in float32 (dimp.py:256,282). */
+enum { PT_LOC_NORMAL = 0, PT_LOC_HARD_NEGATIVE = 1, PT_LOC_UNCERTAIN = 2, PT_LOC_NOT_FOUND = 3 };
+typedef struct {
+    double target_not_found_threshold, uncertain_threshold, hard_sample_threshold;
+    float distractor_threshold, hard_negative_threshold, target_not_found_f32, disp_threshold;
+    float center_r, center_c, ratio_r, ratio_c;
+    float scale[8], neigh_r[8], neigh_c[8], prev_r[8], prev_c[8];
+} pt_localize_params;
+int pt_localize_decide_f32(const float* scores, const float* scores_hn, const pt_localize_params* prm, float* out16,
+                           int S, int H, int W, void* stream);
+
 /* ------------------------------------------------------------------------------------------------
  * IoU-guided box refinement -- DiMP.optimize_boxes_default / optimize_boxes_relative
  * (pytracking/tracker/dimp/dimp.py:725-788) on AtomIoUNet.predict_iou (ltr/models/bbreg/atom_iou_net.py:96-136):

@@ -652,6 +652,50 @@ def two_peaks(scores, scores_hn, neigh):
     return np.array([m1, r1, c1, s1, m2, r2, c2, 0], dtype=np.float64)
 
 
+LOC_FLAGS = ("normal", "hard_negative", "uncertain", "not_found")
+
+
+def localize_decide(scores, scores_hn, q):
+    """Outcome of `DiMP.localize_advanced` (pytracking/tracker/dimp/dimp.py:252-303) from the two peaks, as the 16 floats
+    `pt_localize_decide_f32` leaves: [code, scale, row, col, translation_row, translation_col, max1, row1, col1, max2,
+    row2, col2, pick, 0, 0, 0].  `q`: the fields of `pt_localize_params` (include/pt_hot.h) -- thresholds, map centre,
+    support / output ratio and per scale: sample scale, neighbourhood (dimp.py:268), previous target offset (dimp.py:285).
+    Types as the reference's expressions evaluate under torch: `.item() < float` in double (dimp.py:258-263), everything
+    else float32 with Python scalars rounded to float32 first (dimp.py:288-301)."""
+    f32 = np.float32
+    v = two_peaks(scores, scores_hn, list(zip(q["neigh_r"], q["neigh_c"])))
+    m1, r1, c1, s1, m2, r2, c2 = f32(v[0]), int(v[1]), int(v[2]), int(v[3]), f32(v[4]), int(v[5]), int(v[6])
+    ctr = (f32(q["center_r"]), f32(q["center_c"]))
+    d1 = (f32(r1) - ctr[0], f32(c1) - ctr[1])                                  # target_disp1, dimp.py:255
+    d2 = (f32(r2) - ctr[0], f32(c2) - ctr[1])                                  # target_disp2, dimp.py:281
+    pick = 1
+    if float(m1) < q["target_not_found_threshold"]:
+        code = 3
+    elif float(m1) < q["uncertain_threshold"]:
+        code = 2
+    elif float(m1) < q["hard_sample_threshold"]:
+        code = 1
+    elif m2 > f32(q["distractor_threshold"]) * m1:                             # dimp.py:288
+        prev = (f32(q["prev_r"][s1]), f32(q["prev_c"][s1]))
+        n1 = np.sqrt((d1[0] - prev[0]) ** 2 + (d1[1] - prev[1]) ** 2, dtype=f32)
+        n2 = np.sqrt((d2[0] - prev[0]) ** 2 + (d2[1] - prev[1]) ** 2, dtype=f32)
+        thr = f32(q["disp_threshold"])
+        if n2 > thr and n1 < thr:
+            code = 1
+        elif n2 < thr and n1 > thr:
+            code, pick = 1, 2
+        else:
+            code = 2
+    elif m2 > f32(q["hard_negative_threshold"]) * m1 and m2 > f32(q["target_not_found_f32"]):
+        code = 1
+    else:
+        code = 0
+    d, rc = (d1, (r1, c1)) if pick == 1 else (d2, (r2, c2))
+    sc = f32(q["scale"][s1])
+    tv = (d[0] * f32(q["ratio_r"]) * sc, d[1] * f32(q["ratio_c"]) * sc)       # dimp.py:256 / :282
+    return np.array([code, s1, rc[0], rc[1], tv[0], tv[1], m1, r1, c1, m2, r2, c2, pick, 0, 0, 0], dtype=np.float64)
+
+
 # --------------------------------------------------------------------------------------------
 # image-patch sampling (pytracking/features/preprocessing.py:54-148), pixel part
 # --------------------------------------------------------------------------------------------

@@ -26,6 +26,17 @@ class PatchGeom(ctypes.Structure):
     _fields_ = [(n, ctypes.c_int) for n in ("df", "os0", "os1", "tl0", "tl1", "crop_h", "crop_w")]
 
 
+class LocalizeParams(ctypes.Structure):
+    """`pt_localize_params` of include/pt_hot.h."""
+    _fields_ = ([(n, ctypes.c_double) for n in ("target_not_found_threshold", "uncertain_threshold", "hard_sample_threshold")]
+                + [(n, ctypes.c_float) for n in ("distractor_threshold", "hard_negative_threshold", "target_not_found_f32",
+                                                 "disp_threshold", "center_r", "center_c", "ratio_r", "ratio_c")]
+                + [(n, ctypes.c_float * 8) for n in ("scale", "neigh_r", "neigh_c", "prev_r", "prev_c")])
+
+
+PT_LOC_FLAGS = ("normal", "hard_negative", "uncertain", "not_found")      # PT_LOC_* of include/pt_hot.h
+
+
 class TompDims(ctypes.Structure):
     """`pt_tomp_dims` of include/pt_hot.h."""
     _fields_ = [(n, ctypes.c_int) for n in ("d_model", "nhead", "dim_ff", "n_enc", "n_dec", "H", "W", "max_res")]
@@ -43,7 +54,7 @@ EXPORTS = [
     "pt_lwl_ws_bytes", "pt_lwl_gn_solve_f32",
     "pt_tomp_param_floats", "pt_tomp_prepared_floats", "pt_tomp_prepare_f32", "pt_tomp_posenc_f32", "pt_tomp_predict_ws_bytes", "pt_tomp_predict_f32", "pt_tomp_linear_f32",
     "pt_tomp_bbreg_param_floats", "pt_tomp_bbreg_ws_bytes", "pt_tomp_bbreg_f32",
-    "pt_clf_head_ws_bytes", "pt_clf_head_f32", "pt_max2d_f32", "pt_localize_f32",
+    "pt_clf_head_ws_bytes", "pt_clf_head_f32", "pt_max2d_f32", "pt_localize_f32", "pt_localize_decide_f32",
     "pt_iou_param_floats", "pt_iou_prepared_floats", "pt_iou_prepare_f32", "pt_iou_refine_ws_bytes", "pt_iou_refine_f32",
     "pt_track_frame_replay_pass_f32", "pt_sample_patch_f32", "pt_track_frame_head_ws_bytes", "pt_track_frame_head_f32",
 ]
@@ -175,6 +186,8 @@ def lib():
     fp = ctypes.POINTER(ctypes.c_float)
     L.pt_localize_f32.restype = i
     L.pt_localize_f32.argtypes = [vp, vp, fp, fp, vp, i, i, i, vp]
+    L.pt_localize_decide_f32.restype = i
+    L.pt_localize_decide_f32.argtypes = [vp, vp, ctypes.POINTER(LocalizeParams), vp, i, i, i, vp]
     ip = ctypes.POINTER(IouDims)
     L.pt_iou_param_floats.restype = sz
     L.pt_iou_param_floats.argtypes = [ip]

@@ -120,7 +120,10 @@ __device__ __forceinline__ float prroi_fwd_elem(const float* __restrict__ feat, 
     if (k.area > 0.f && k.b >= 0 && k.b < N) {
         const float* __restrict__ f = feat + ((long)k.b * C + c) * H * W;
         const int nj = k.j1 - k.j0 + 1, ni = k.i1 - k.i0 + 1;
-        if (nj <= 4 && ni <= 4) acc = prroi_fwd_window<4>(f, k, W, nj, ni);
+        // a bin more than one pixel above / left of (or below / right of) the map touches no pixel: j1 < j0 or i1 < i0,
+        // and j1 / i1 may be negative -- the window paths clamp to them, so they must not run (the integral is 0)
+        if (nj <= 0 || ni <= 0) acc = 0.f;
+        else if (nj <= 4 && ni <= 4) acc = prroi_fwd_window<4>(f, k, W, nj, ni);
         else if (nj <= 6 && ni <= 6) acc = prroi_fwd_window<6>(f, k, W, nj, ni);
         else {
             for (int j = k.j0; j <= k.j1; ++j) {
@@ -225,6 +228,7 @@ __device__ __forceinline__ void prroi_coor_sums(const float* __restrict__ gout, 
         const float* __restrict__ f = feat + ((long)k.b * C + c) * H * W;
         float integ = 0.f, lxs = 0.f, lxe = 0.f, lys = 0.f, lye = 0.f;
         const int nj = k.j1 - k.j0 + 1, ni = k.i1 - k.i0 + 1;
+        if (nj <= 0 || ni <= 0) continue;          // bin entirely outside the map: every sum is 0 (see prroi_fwd_elem)
         if (nj <= 4 && ni <= 4) prroi_coor_window<4>(f, k, W, nj, ni, integ, lxs, lxe, lys, lye);
         else if (nj <= 6 && ni <= 6) prroi_coor_window<6>(f, k, W, nj, ni, integ, lxs, lxe, lys, lye);
         else {

@@ -66,11 +66,16 @@ class on_device:
 
 
 def workspace(nbytes: int, device) -> torch.Tensor:
-    """Caller-owned scratch for the C ABI (the library never allocates).  One growing buffer per device;
-    reuse across calls is safe because every call is ordered on the current stream."""
-    key = (device.type, device.index)
+    """Caller-owned scratch for the C ABI (the library never allocates).  One growing buffer per (device, stream):
+    calls on one stream are ordered, so they may share scratch; two streams of one device (a tracker per stream) get
+    separate buffers and cannot alias.  A buffer that is outgrown is not handed back to the allocator while kernels of
+    earlier calls may still use it: `record_stream` defers its reuse until the work queued on this stream has run."""
+    stream = torch.cuda.current_stream(device)
+    key = (device.type, device.index, stream.cuda_stream)
     buf = _WS.get(key)
     if buf is None or buf.numel() < nbytes:
+        if buf is not None:
+            buf.record_stream(stream)
         buf = torch.empty(max(int(nbytes), 1 << 20), dtype=torch.uint8, device=device)
         _WS[key] = buf
     return buf

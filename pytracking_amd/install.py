@@ -413,8 +413,10 @@ def _install_preprocessing(orig, strict):
         fn.__doc__, fn.__wrapped__ = ref.__doc__, ref
     pmod.sample_patch, pmod.sample_patch_multiscale = sample_patch, sample_patch_multiscale
     # the trackers import the names (`from pytracking.features.preprocessing import sample_patch_multiscale, ...`)
+    # ... and ATOM reaches them through its feature extractors (`pytracking/features/extractor.py:3,112`)
     for modname in ("pytracking.tracker.dimp.dimp", "pytracking.tracker.atom.atom", "pytracking.tracker.tomp.tomp",
-                    "pytracking.tracker.kys.kys", "pytracking.tracker.lwl.lwl"):
+                    "pytracking.tracker.kys.kys", "pytracking.tracker.lwl.lwl", "pytracking.features.extractor",
+                    "pytracking.features.featurebase"):
         tmod = sys.modules.get(modname)
         if tmod is None:
             try:

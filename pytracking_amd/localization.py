@@ -3,14 +3,17 @@
 
 `localize_advanced(self, scores, sample_pos, sample_scales)` is written to be bound as the tracker's method: it reads
 the same attributes (`params`, `kernel_size`, `img_support_sz`, `target_sz`, `pos`, `output_window`) and returns the same
-tuple, but finds both peaks in ONE device launch and makes ONE device-to-host copy of 8 floats, where the reference
-issues two max2d's, a clone, a masked fill and about ten `.item()` / `.cpu()` synchronisations.  The decision ladder
-(not_found / uncertain / hard_negative / normal) is the reference's, evaluated on those 8 numbers with the same
-float32 tensor arithmetic.
+tuple.  The whole routine is ONE launch (`pt_localize_decide_f32`, csrc/localize.hip): both peaks, the outcome
+(normal / hard_negative / uncertain / not_found), the displacement of the peak that outcome selects and its translation
+vector are decided on the device and written into a pinned host buffer; the host forms the per-frame constants the
+kernel needs (float32 scalar arithmetic on the tracker's CPU state -- numpy float32 rounds like torch's CPU kernels)
+and waits for the stream once.  The reference issues two max2d's, a clone, a masked fill and about ten `.item()` /
+`.cpu()` synchronisations for the same result.
 """
 import ctypes
 import math
 
+import numpy as np
 import torch
 
 from . import _lib
@@ -46,61 +49,90 @@ def two_peaks(scores, scores_hn, neigh):
     return out.cpu()                                         # the one synchronisation of the localisation step
 
 
-def _localize(self, scores, sample_pos, sample_scales):
-    sz = scores.shape[-2:]
-    score_sz = torch.Tensor(list(sz))
-    output_sz = score_sz - (self.kernel_size + 1) % 2
-    score_center = (score_sz - 1) / 2
+_F = np.float32
+_HOST_OUT = {}
 
+
+def _host_out(device):
+    """16 floats of pinned host memory per device that the localisation kernel writes directly (no copy launch)."""
+    buf = _HOST_OUT.get(device.index)
+    if buf is None:
+        t = torch.zeros(16, dtype=torch.float32).pin_memory()
+        buf = (t, t.numpy(), ctypes.c_void_p(t.data_ptr()))
+        _HOST_OUT[device.index] = buf
+    return buf
+
+
+def _f32_pair(t):
+    """A two-element CPU tensor (or sequence) as two numpy float32 scalars."""
+    a, b = t.tolist() if isinstance(t, torch.Tensor) else t
+    return _F(a), _F(b)
+
+
+def _frame_constants(self, shape, sample_pos, sample_scales):
+    """`pt_localize_params` for this frame.  Every product / quotient below is a float32 operation in the reference
+    (float32 CPU tensors; Python scalars are rounded to float32 by torch's binary ops): numpy float32 scalars round
+    identically.  Optional thresholds the parameter file does not define are -inf (the test can never fire)."""
+    S, H, W = shape
+    prm = self.params
+    q = _lib.LocalizeParams()
+    q.target_not_found_threshold = float(prm.target_not_found_threshold)
+    q.uncertain_threshold = float(prm.get('uncertain_threshold', -float('inf')))
+    q.hard_sample_threshold = float(prm.get('hard_sample_threshold', -float('inf')))
+    q.distractor_threshold = float(prm.distractor_threshold)
+    q.hard_negative_threshold = float(prm.hard_negative_threshold)
+    q.target_not_found_f32 = float(prm.target_not_found_threshold)
+    q.disp_threshold = prm.dispalcement_scale * math.sqrt(H * W) / 2
+    kr, kc = _f32_pair(self.kernel_size)
+    out_r, out_c = _F(H) - (kr + _F(1)) % _F(2), _F(W) - (kc + _F(1)) % _F(2)      # output_sz
+    q.center_r, q.center_c = (_F(H) - _F(1)) / _F(2), (_F(W) - _F(1)) / _F(2)
+    sup_r, sup_c = _f32_pair(self.img_support_sz)
+    ratio_r, ratio_c = sup_r / out_r, sup_c / out_c
+    q.ratio_r, q.ratio_c = ratio_r, ratio_c
+    tns = _F(prm.target_neighborhood_scale)
+    tgt_r, tgt_c = _f32_pair(self.target_sz)
+    pos_r, pos_c = _f32_pair(self.pos)
+    scales = sample_scales.tolist() if isinstance(sample_scales, torch.Tensor) else list(sample_scales)
+    centres = sample_pos.tolist()
+    for s in range(S):
+        sc = _F(scales[s])
+        q.scale[s] = sc
+        q.neigh_r[s] = tns * (tgt_r / sc) * (out_r / sup_r)
+        q.neigh_c[s] = tns * (tgt_c / sc) * (out_c / sup_c)
+        q.prev_r[s] = (pos_r - _F(centres[s][0])) / (ratio_r * sc)
+        q.prev_c[s] = (pos_c - _F(centres[s][1])) / (ratio_c * sc)
+    return q
+
+
+@device_guarded
+def _localize(self, scores, sample_pos, sample_scales):
+    _require_device(scores)
     scores_hn = scores
     if self.output_window is not None and self.params.get('perform_hn_without_windowing', False):
-        scores_hn = scores.clone()                           # dimp.py:247-250, verbatim (device elementwise)
+        scores_hn = scores.clone()                           # the second peak is searched in the un-windowed map
         scores *= self.output_window
-
-    S = scores.shape[0]
-    scale_of = lambda s: sample_scales[s]
-    neigh = [self.params.target_neighborhood_scale * (self.target_sz / scale_of(s)) * (output_sz / self.img_support_sz)
-             for s in range(S)]                              # dimp.py:268 for every candidate scale
-    v = two_peaks(scores, scores_hn, neigh)
-
-    scale_ind = v[3].long()
-    sample_scale = sample_scales[scale_ind]
-    max_score1 = v[0]
-    max_disp1 = v[1:3].clone()
-    target_disp1 = max_disp1 - score_center
-    translation_vec1 = target_disp1 * (self.img_support_sz / output_sz) * sample_scale
-
-    if max_score1.item() < self.params.target_not_found_threshold:
-        return translation_vec1, scale_ind, scores_hn, 'not_found', max_disp1
-    if max_score1.item() < self.params.get('uncertain_threshold', -float('inf')):
-        return translation_vec1, scale_ind, scores_hn, 'uncertain', max_disp1
-    if max_score1.item() < self.params.get('hard_sample_threshold', -float('inf')):
-        return translation_vec1, scale_ind, scores_hn, 'hard_negative', max_disp1
-
-    max_score2 = v[4]
-    max_disp2 = v[5:7].clone()
-    target_disp2 = max_disp2 - score_center
-    translation_vec2 = target_disp2 * (self.img_support_sz / output_sz) * sample_scale
-
-    prev_target_vec = (self.pos - sample_pos[scale_ind, :]) / ((self.img_support_sz / output_sz) * sample_scale)
-
-    if max_score2 > self.params.distractor_threshold * max_score1:
-        disp_norm1 = torch.sqrt(torch.sum((target_disp1 - prev_target_vec) ** 2))
-        disp_norm2 = torch.sqrt(torch.sum((target_disp2 - prev_target_vec) ** 2))
-        disp_threshold = self.params.dispalcement_scale * math.sqrt(sz[0] * sz[1]) / 2
-
-        if disp_norm2 > disp_threshold and disp_norm1 < disp_threshold:
-            return translation_vec1, scale_ind, scores_hn, 'hard_negative', max_disp1
-        if disp_norm2 < disp_threshold and disp_norm1 > disp_threshold:
-            return translation_vec2, scale_ind, scores_hn, 'hard_negative', max_disp2
-        if disp_norm2 > disp_threshold and disp_norm1 > disp_threshold:
-            return translation_vec1, scale_ind, scores_hn, 'uncertain', max_disp1
-        return translation_vec1, scale_ind, scores_hn, 'uncertain', max_disp1
-
-    if max_score2 > self.params.hard_negative_threshold * max_score1 and max_score2 > self.params.target_not_found_threshold:
-        return translation_vec1, scale_ind, scores_hn, 'hard_negative', max_disp1
-
-    return translation_vec1, scale_ind, scores_hn, 'normal', max_disp1
+    H, W = scores.shape[-2:]
+    sc3 = scores.reshape(-1, H, W)
+    S = sc3.shape[0]
+    if S > 8:
+        raise NotImplementedError("more than 8 scales per call")
+    if not sc3.is_contiguous():
+        sc3 = sc3.contiguous()
+    hn3 = None
+    if scores_hn is not scores:
+        hn3 = scores_hn.reshape(-1, H, W)
+        hn3 = hn3 if hn3.is_contiguous() else hn3.contiguous()
+    q = _frame_constants(self, (S, H, W), sample_pos, sample_scales)
+    _, host, host_ptr = _host_out(scores.device)
+    stream = torch.cuda.current_stream()
+    rc = _lib.lib().pt_localize_decide_f32(_ptr(sc3), None if hn3 is None else _ptr(hn3), ctypes.byref(q), host_ptr, S, H, W,
+                                           ctypes.c_void_p(stream.cuda_stream))
+    _lib.check(rc, "pt_localize_decide_f32")
+    stream.synchronize()                                     # the one synchronisation of the localisation step
+    r = host.tolist()
+    translation_vec = torch.tensor(r[4:6], dtype=torch.float32)
+    max_disp = torch.tensor(r[2:4], dtype=torch.float32)
+    return translation_vec, torch.tensor(int(r[1])), scores_hn, _lib.PT_LOC_FLAGS[int(r[0])], max_disp
 
 
 def localize_advanced(self, scores, sample_pos, sample_scales):

@@ -69,9 +69,15 @@ def _solve(params: _lib.SdParams, weights, feat, bb, sample_weight, num_iter, co
 def _host_scalar(mod, name):
     """Host value of a one-element parameter, re-read from the device only when the tensor changed (the trackers
     overwrite `filter_reg[0]` in place, dimp.py:598-600 -- that bumps `_version`): no device->host synchronisation on
-    the per-frame path."""
+    the per-frame path.  The reference re-reads the parameter on every call; what the version counter cannot see is
+    covered explicitly: `load_state_dict` and `.to()/.cuda()/.float()` drop the cache (`_ScalarCacheMixin`),
+    tensors without a version counter (built under `torch.inference_mode`) are read directly every time, and a write
+    through `.data` (which does not bump the version) needs `refresh_host_scalars(module)`."""
     t = getattr(mod, name)
-    key = (t.data_ptr(), t._version)
+    try:
+        key = (t.data_ptr(), t._version)
+    except RuntimeError:                                   # inference tensors do not track versions
+        return float(t.detach().reshape(-1)[0])
     cache = mod.__dict__.setdefault("_host_scalars", {})
     hit = cache.get(name)
     if hit is None or hit[0] != key:
@@ -80,12 +86,31 @@ def _host_scalar(mod, name):
     return hit[1]
 
 
+def refresh_host_scalars(mod):
+    """Drop the cached host copies of the one-element parameters of `mod` and its sub-modules (call after writing a
+    parameter through `.data`, e.g. `opt.filter_reg.data.fill_(x)`)."""
+    for m in mod.modules():
+        m.__dict__.pop("_host_scalars", None)
+
+
+class _ScalarCacheMixin:
+    """Invalidate the host-scalar cache wherever parameters are replaced wholesale."""
+
+    def _load_from_state_dict(self, *args, **kw):
+        self.__dict__.pop("_host_scalars", None)
+        return super()._load_from_state_dict(*args, **kw)
+
+    def _apply(self, fn, *args, **kw):
+        self.__dict__.pop("_host_scalars", None)
+        return super()._apply(fn, *args, **kw)
+
+
 def _reg_value(mod):
     fr = _host_scalar(mod, "filter_reg")
     return max(fr * fr, float(mod.min_filter_reg) ** 2)           # optimizer.py:109
 
 
-class DiMPSteepestDescentGN(nn.Module):
+class DiMPSteepestDescentGN(_ScalarCacheMixin, nn.Module):
     """reference: optimizer.py:11-170."""
 
     def __init__(self, num_iter=1, feat_stride=16, init_step_length=1.0, init_filter_reg=1e-2, init_gauss_sigma=1.0,
@@ -137,7 +162,7 @@ class DiMPSteepestDescentGN(nn.Module):
         return _solve(p, weights, feat, bb, sample_weight, num_iter, compute_losses, keep=luts)
 
 
-class DiMPL2SteepestDescentGN(nn.Module):
+class DiMPL2SteepestDescentGN(_ScalarCacheMixin, nn.Module):
     """reference: optimizer.py:174-291."""
 
     def __init__(self, num_iter=1, feat_stride=16, init_step_length=1.0, gauss_sigma=1.0, hinge_threshold=-999,
@@ -162,7 +187,7 @@ class DiMPL2SteepestDescentGN(nn.Module):
         return _solve(p, weights, feat, bb, sample_weight, num_iter, compute_losses, keep=[])
 
 
-class PrDiMPSteepestDescentNewton(nn.Module):
+class PrDiMPSteepestDescentNewton(_ScalarCacheMixin, nn.Module):
     """reference: optimizer.py:294-439."""
 
     def __init__(self, num_iter=1, feat_stride=16, init_step_length=1.0, init_filter_reg=1e-2, gauss_sigma=1.0,

@@ -101,17 +101,19 @@ def sample_patch_multiscale(im, pos, scales, image_sz, mode='replicate', max_sca
     return out, torch.tensor(coords, dtype=torch.float32)
 
 
+@device_guarded
 def sample_patch(im, pos, sample_sz, output_sz=None, mode='replicate', max_scale_change=None, is_mask=False):
     """preprocessing.py:54-148 for a device image: (im_patch (1,C,oh,ow), patch_coord (1,4))."""
     if is_mask:
         raise NotImplementedError("mask patches (nearest resampling) are not on the per-frame path")
     _require_device(im)
+    if im.dim() != 4 or im.shape[0] != 1:
+        raise NotImplementedError("sample_patch takes one image (1, C, H, W)")
     g, c = patch_geometry(im.shape[-2:], pos, sample_sz, output_sz, mode, max_scale_change)
     oh, ow = (g.crop_h, g.crop_w) if output_sz is None else (int(output_sz[0]), int(output_sz[1]))
     im = im.contiguous()
     C, H, W = im.shape[1:]
     out = torch.empty((1, C, oh, ow), dtype=torch.float32, device=im.device)
-    with torch.cuda.device(im.device):
-        rc = _lib.lib().pt_sample_patch_f32(_ptr(im), C, H, W, (_lib.PatchGeom * 1)(g), 1, _ptr(out), oh, ow, _stream())
+    rc = _lib.lib().pt_sample_patch_f32(_ptr(im), C, H, W, (_lib.PatchGeom * 1)(g), 1, _ptr(out), oh, ow, _stream())
     _lib.check(rc, "pt_sample_patch_f32")
     return out, torch.tensor([c], dtype=torch.float32)

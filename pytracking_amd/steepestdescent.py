@@ -15,9 +15,10 @@ import torch.nn as nn
 
 from . import _lib
 from .filter import _ptr, _require_device, _stream, apply_filter, device_guarded, workspace
+from .optimizer import _ScalarCacheMixin, _host_scalar
 
 
-class LWTLResidual(nn.Module):
+class LWTLResidual(_ScalarCacheMixin, nn.Module):
     """reference: loss_residual_modules.py:8-41 (residuals W*(T(x) - E(y)) and lambda*tau of the few-shot loss)."""
 
     def __init__(self, init_filter_reg=1e-2, filter_dilation_factors=None):
@@ -99,7 +100,6 @@ class GNSteepestDescent(nn.Module):
         w_in = weights.detach().contiguous()
         iters = torch.empty((S, num_iter + 1, Fn, C, K, K), dtype=torch.float32, device=feat.device)
         losses = torch.zeros((S, num_iter + 1), dtype=torch.float32, device=feat.device) if self.compute_losses else None
-        from .optimizer import _host_scalar
         lam = _host_scalar(res, "filter_reg")
         keep = []
         for s in range(S):

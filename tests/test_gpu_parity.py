@@ -446,6 +446,42 @@ def test_prroi_forward_backward_vs_oracle(PH, PW, scale, H, W):
     assert torch.equal(f.grad, g1)
 
 
+@pytest.mark.parametrize("PH,PW,scale,H,W", [(5, 5, 1 / 8, 36, 36), (3, 3, 1 / 16, 18, 18), (4, 4, 1 / 16, 18, 18)])
+def test_prroi_rois_at_negative_coordinates(PH, PW, scale, H, W):
+    """RoIs that drift above / left of the search crop (IoU refinement, jittered proposals): bins more than one pixel
+    outside the map touch no pixel (j1 < 0 or i1 < 0) -- outputs and gradients must be the oracle's finite values
+    (zeros where nothing is touched), not reads in front of the tensor."""
+    from pytracking_amd.prroi_pool import PrRoIPool2D
+    rng = np.random.default_rng(77 + PH)
+    N, C = 1, 16
+    # b = 0, c = 0 is the tensor base: a negative index there reads in front of the allocation
+    feat = rng.standard_normal((N, C, H, W), dtype=np.float32)
+    ex, ey = W / scale, H / scale
+    rois = np.array([
+        [0, -0.9 * ex, -0.9 * ey, -0.2 * ex, -0.2 * ey],       # fully above-left, far outside
+        [0, -0.6 * ex, 0.1 * ey, 0.3 * ex, 0.5 * ey],          # left part outside: the first bins' i1 < 0
+        [0, 0.2 * ex, -0.7 * ey, 0.6 * ex, 0.2 * ey],          # top part outside: the first bins' j1 < 0
+        [0, -0.4 * ex, -0.4 * ey, 1.3 * ex, 1.3 * ey],         # covers the map and sticks out on every side (wide bins)
+        [0, -3.0 / scale, -3.0 / scale, 2.0 / scale, 2.0 / scale],   # a few pixels over the corner
+        [0, 0.9 * ex, 0.9 * ey, 1.8 * ex, 1.8 * ey],           # bottom-right overhang
+    ], dtype=np.float32)
+    f = T(feat).requires_grad_(True)
+    r = T(rois).requires_grad_(True)
+    out = PrRoIPool2D(PH, PW, scale)(f, r)
+    ref = O.prroi_forward(feat.astype(np.float64), rois.astype(np.float64), PH, PW, scale)
+    assert torch.isfinite(out).all()
+    close(out, ref, atol=2e-5)
+    assert float(out[0].abs().max()) == 0.0
+    gout = rng.standard_normal(ref.shape).astype(np.float32)
+    out.backward(T(gout))
+    assert torch.isfinite(f.grad).all() and torch.isfinite(r.grad).all()
+    close(f.grad, O.prroi_backward_feat(gout.astype(np.float64), feat.shape, rois.astype(np.float64), PH, PW, scale),
+          atol=1e-4)
+    refc = O.prroi_backward_coor(gout.astype(np.float64), feat.astype(np.float64), rois.astype(np.float64), PH, PW, scale)
+    close(r.grad, refc, atol=2e-4 * max(1.0, np.abs(refc).max()))
+    assert float(r.grad[0].abs().max()) == 0.0
+
+
 def test_prroi_consumers_golden():
     """Reference FilterInitializerLinear pooling and the IoU-predictor proposal gradient (golden produced by the
     reference modules with the PrRoIPool restatement plugged in)."""
@@ -619,21 +655,62 @@ def test_clf_head_tracker_sizes_vs_oracle(n, cout):
 # target localisation on the device
 # ------------------------------------------------------------------------------------------------------
 def test_localize_advanced_golden():
-    """pt_localize_f32 + the mirrored decision ladder vs the reference's DiMP.localize_advanced on 48 score maps
-    (all four outcomes, two scales, exact ties)."""
+    """pt_localize_decide_f32 (peaks AND outcome decided on the device) vs the reference's DiMP.localize_advanced on 48
+    score maps (all four outcomes, the second-peak pick, two scales, exact ties): flag, scale and the float32 translation
+    vector bit-exact; the 16 numbers the kernel leaves equal the oracle's restatement."""
+    import ctypes
     from pytracking_amd import localization as LM
     from localize_cases import cases
     for me, c in cases(load_golden("localize")):
         scores = T(c["scores"].copy())
-        tv, scale_ind, s_out, flag = LM.localize_advanced(me, scores, torch.from_numpy(c["sample_pos"]),
-                                                          torch.from_numpy(c["sample_scales"]))
+        spos, sscl = torch.from_numpy(c["sample_pos"]), torch.from_numpy(c["sample_scales"])
+        tv, scale_ind, s_out, flag = LM.localize_advanced(me, scores, spos, sscl)
         assert flag == str(c["flag"]) and int(scale_ind) == int(c["scale_ind"]) and s_out is scores
-        np.testing.assert_allclose(tv.numpy(), c["tv"], rtol=1e-6, atol=1e-6)
+        assert not tv.is_cuda and tv.dtype == torch.float32
+        np.testing.assert_array_equal(tv.numpy(), c["tv"])
+        q = LM._frame_constants(me, tuple(scores.shape), spos, sscl)
+        qd = {n: (list(getattr(q, n)) if isinstance(getattr(q, n), ctypes.Array) else getattr(q, n)) for n, _ in q._fields_}
+        want = O.localize_decide(c["scores"], c["scores"], qd)
+        got = LM._host_out(scores.device)[1].astype(np.float64)
+        np.testing.assert_array_equal(got, want)
         v = LM.two_peaks(scores, None, [np.array([3.3, 4.7], np.float32)] * scores.shape[0]).numpy().astype(np.float64)
         ref = O.two_peaks(c["scores"], c["scores"], [np.array([3.3, 4.7], np.float32)] * scores.shape[0])
         np.testing.assert_array_equal(v, ref)                               # bit-exact: values are copied, indices integral
-        tv5 = LM.localize_advanced_tomp(me, scores, torch.from_numpy(c["sample_pos"]), torch.from_numpy(c["sample_scales"]))
-        assert len(tv5) == 5 and tv5[3] == flag
+        tv5 = LM.localize_advanced_tomp(me, scores, spos, sscl)
+        assert len(tv5) == 5 and tv5[3] == flag and tv5[4].tolist() == want[2:4].tolist()
+
+
+def test_localize_windowed_and_device_result_buffer():
+    """`perform_hn_without_windowing` (dimp.py:247-250): the first peak is searched in the windowed map, the second in
+    the raw one; and the kernel's result written to DEVICE memory equals the pinned-host result."""
+    import ctypes
+    from pytracking_amd import _lib, localization as LM
+    from localize_cases import cases
+    rng = np.random.default_rng(3)
+    for k, (me, c) in enumerate(cases(load_golden("localize"))):
+        if k % 6:
+            continue
+        S, H, W = c["scores"].shape
+        win = (0.2 + 0.8 * np.outer(np.hanning(H + 2)[1:-1], np.hanning(W + 2)[1:-1])).astype(np.float32)
+        me.output_window = T(win)
+        me.params.perform_hn_without_windowing = True
+        raw = c["scores"].copy()
+        scores = T(raw.copy())
+        spos, sscl = torch.from_numpy(c["sample_pos"]), torch.from_numpy(c["sample_scales"])
+        tv, scale_ind, s_hn, flag = LM.localize_advanced(me, scores, spos, sscl)
+        np.testing.assert_array_equal(s_hn.cpu().numpy(), raw)              # the un-windowed clone is what is returned
+        windowed = raw * win
+        np.testing.assert_array_equal(scores.cpu().numpy(), windowed)       # `scores *= window` in place, as the reference
+        q = LM._frame_constants(me, (S, H, W), spos, sscl)
+        qd = {n: (list(getattr(q, n)) if isinstance(getattr(q, n), ctypes.Array) else getattr(q, n)) for n, _ in q._fields_}
+        want = O.localize_decide(windowed, raw, qd)
+        np.testing.assert_array_equal(LM._host_out(scores.device)[1].astype(np.float64), want)
+        assert flag == O.LOC_FLAGS[int(want[0])]
+        dev = torch.zeros(16, device=DEV)
+        rc = _lib.lib().pt_localize_decide_f32(scores.data_ptr(), s_hn.data_ptr(), ctypes.byref(q), dev.data_ptr(), S, H, W,
+                                               torch.cuda.current_stream().cuda_stream)
+        assert rc == 0
+        np.testing.assert_array_equal(dev.cpu().numpy().astype(np.float64), want)
 
 
 def test_max2d_vs_oracle_with_ties():
@@ -693,6 +770,9 @@ def _iou_box_check(boxes, iou, g, tag, relative, atom=False):
     b64, i64 = out[0].numpy(), out[1].numpy()
     ref_err_b = float(np.abs(g[f"{tag}_boxes"] - b64).max())
     ref_err_i = float(np.abs(g[f"{tag}_iou"] - i64).max())
+    # the relaxation cannot inflate itself: if the float64 restatement drifts from the reference golden (an oracle bug),
+    # this fails instead of loosening the GPU bound (measured: 1.2e-3 px / 3e-5 IoU at worst)
+    assert ref_err_b < 5e-3 and ref_err_i < 2e-4, (ref_err_b, ref_err_i)
     close(boxes, b64, atol=max(1e-4, 2 * ref_err_b))
     close(iou, i64, atol=max(1e-4, 2 * ref_err_i))
     close(boxes, g[f"{tag}_boxes"], atol=1e-4 + 2 * ref_err_b)

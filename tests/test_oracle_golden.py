@@ -191,22 +191,25 @@ def test_clf_head(tag):
     np.testing.assert_allclose(y, g[f"{tag}_y"], atol=2e-6, rtol=2e-5)
 
 
-def test_localize_decision_ladder_and_two_peaks(monkeypatch):
-    """Host logic of pytracking_amd.localization (the reference's decision ladder) on top of the ORACLE's two-peak search,
-    against DiMP.localize_advanced run by the unmodified reference (tests/golden/localize.npz): flag, scale, translation."""
+def test_localize_frame_constants_and_decision():
+    """Host logic of pytracking_amd.localization (the per-frame constants handed to the localisation kernel) + the oracle's
+    restatement of the outcome (np_oracle.localize_decide), against DiMP.localize_advanced run by the unmodified
+    reference (tests/golden/localize.npz): flag, scale, translation vector."""
+    import ctypes
     import torch
     from pytracking_amd import localization as LM
     from localize_cases import cases
-    monkeypatch.setattr(LM, "two_peaks", lambda s, hn, neigh: torch.from_numpy(
-        O.two_peaks(s.numpy(), (s if hn is None else hn).numpy(), [n.numpy() for n in neigh])).float())
     seen = set()
     for me, c in cases(load_golden("localize")):
-        tv, scale_ind, _, flag = LM.localize_advanced(me, torch.from_numpy(c["scores"].copy()), torch.from_numpy(c["sample_pos"]),
-                                                      torch.from_numpy(c["sample_scales"]))
-        assert flag == str(c["flag"]) and int(scale_ind) == int(c["scale_ind"])
-        np.testing.assert_allclose(tv.numpy(), c["tv"], rtol=1e-6, atol=1e-6)
-        seen.add(flag)
-    assert seen == {"normal", "not_found", "uncertain", "hard_negative"}
+        S, H, W = c["scores"].shape
+        q = LM._frame_constants(me, (S, H, W), torch.from_numpy(c["sample_pos"]), torch.from_numpy(c["sample_scales"]))
+        qd = {n: (list(getattr(q, n)) if isinstance(getattr(q, n), ctypes.Array) else getattr(q, n)) for n, _ in q._fields_}
+        out = O.localize_decide(c["scores"], c["scores"], qd)
+        flag = O.LOC_FLAGS[int(out[0])]
+        assert flag == str(c["flag"]) and int(out[1]) == int(c["scale_ind"])
+        np.testing.assert_array_equal(out[4:6].astype(np.float32), c["tv"])       # same float32 operations, same order
+        seen.add((flag, int(out[12])))
+    assert {f for f, _ in seen} == {"normal", "not_found", "uncertain", "hard_negative"} and ("hard_negative", 2) in seen
 
 
 @pytest.mark.parametrize("tag,relative", [("default", False), ("default_decay", False), ("relative", True)])
