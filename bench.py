@@ -17,7 +17,11 @@ Prints ONE JSON line on rank 0.  Besides the contract fields:
                   to it `period_us`: K back-to-back launches of that kernel between ONE HIP event pair on the launch
                   stream (= duration + one dependent-launch boundary).  When rocprofv3 cannot run, `frac` is computed
                   from the event period (pessimistic by the boundary) and `timing` says so.
-  cpu_baseline    the reference's CPU execution path (torch-CPU port, oracle/frame_port.py) on this host, pinned threads.
+  other_workloads the other BASELINE configs on this GPU (tools/workloads.py): PrDiMP-50 frame, ToMP model prediction, LWL
+                  few-shot learner (3 and 4 iterations), ATOM CG update -- ms, algorithmic bytes / flops, roofline fraction.
+  end_to_end      the DiMP-50 frame with a stock-PyTorch ResNet-50 (conv1..layer3) in front: backbone ms, frames/s.
+  cpu_baseline    the reference's CPU execution path (torch-CPU port, oracle/frame_port.py) on this host, pinned threads
+                  (+ `one_thread`: the same on a single thread).
   gpu_stock_baseline  the same stock-PyTorch op sequence (MIOpen grouped convs) on this GPU: what a user of the reference
                   gets on ROCm today without these kernels (SURVEY.md section 8d "Stock-GPU baseline").
 """
@@ -36,13 +40,16 @@ import tempfile
 import time
 
 import numpy as np
-import torch
+
+os.environ.setdefault("MIOPEN_FIND_MODE", "FAST")   # stock-PyTorch baseline / backbone legs: no exhaustive MIOpen search
+import torch  # noqa: E402
 
 ROOT = os.path.dirname(os.path.abspath(__file__))
 if ROOT not in sys.path:
     sys.path.insert(0, ROOT)
 
 from pytracking_amd import _lib, bench_frame, sequences, synth  # noqa: E402
+from tools import workloads  # noqa: E402
 
 HBM_PEAK_GBS = 8000.0      # MI355X_MICROARCH.md: HBM3E 8.0 TB/s spec
 NUM_ITER = 5
@@ -61,12 +68,12 @@ def run_frames(st, pool, first, count):
         st.step(pool[f % POOL], slot=f % n, num_iter=NUM_ITER)
 
 
-def stock_baseline(cfg, n, device, budget_s, min_frames=10, max_frames=2000):
+def stock_baseline(cfg, n, device, budget_s, min_frames=10, max_frames=2000, threads=None):
     """The reference's op sequence in stock PyTorch (oracle/frame_port.TorchCpuTracker) on `device`, same workload,
     bounded sample.  Baseline leg only: nothing measured as the product touches oracle/."""
     from oracle.frame_port import TorchCpuTracker
     host = os.cpu_count() or 1
-    threads = min(CPU_THREADS, host)
+    threads = min(threads or CPU_THREADS, host)
     pool = make_pool(cfg, 99, device)
     tr = TorchCpuTracker(cfg, n, seed=1234, threads=threads, device=device)
     sync = torch.cuda.synchronize if str(device).startswith("cuda") else (lambda: None)
@@ -243,6 +250,7 @@ def main():
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-gpu-baseline", action="store_true")
     ap.add_argument("--no-roofline", action="store_true")
+    ap.add_argument("--no-other", action="store_true", help="skip the other BASELINE workloads and the end-to-end leg")
     ap.add_argument("--profile-child", action="store_true", help=argparse.SUPPRESS)
     ap.add_argument("--workload", default="dimp50", choices=("dimp50", "prdimp50"),
                     help="dimp50 = BASELINE configs[1] (the metric's configuration); prdimp50 = configs[2]'s per-GPU workload")
@@ -377,8 +385,17 @@ def main():
         if world == 1 and cfg_name == "dimp50" and not args.no_roofline:
             out["head_inclusive"] = head_inclusive(cfg, n, dev, stream)
         if world == 1 and cfg_name == "dimp50":
+            if not args.no_other:
+                out["other_workloads"] = workloads.all_other(dev)
+                try:
+                    out["end_to_end"] = workloads.end_to_end(dev)
+                except Exception as exc:                         # noqa: BLE001
+                    out["end_to_end"] = {"error": f"{type(exc).__name__}: {exc}"[:300]}
             if not args.no_cpu_baseline:
                 out["cpu_baseline"] = stock_baseline(cfg, n, "cpu", budget_s=12.0)
+                one = stock_baseline(cfg, n, "cpu", budget_s=5.0, min_frames=3, threads=1)
+                out["cpu_baseline"]["one_thread"] = {"value": one["value"], "unit": "frames/s", "cores": 1, "sample": one["sample"]}
+                torch.set_num_threads(min(CPU_THREADS, os.cpu_count() or 1))
             if not args.no_gpu_baseline:
                 out["gpu_stock_baseline"] = stock_baseline(cfg, n, dev, budget_s=4.0, min_frames=50)
         print(json.dumps(out), flush=True)

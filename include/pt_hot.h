@@ -278,6 +278,22 @@ typedef struct {
 int pt_localize_decide_f32(const float* scores, const float* scores_hn, const pt_localize_params* prm, float* out16,
                            int S, int H, int W, void* stream);
 
+/* The tracker's host state `localize_advanced` reads (all HOST values): `params.*` thresholds as the Python floats they
+ * are (absent optional ones: -infinity), the float32 contents of `kernel_size`, `img_support_sz`, `target_sz`, `pos`
+ * ([row, col]) and per scale `sample_scales[s]`, `sample_pos[s] = (row, col)`.
+ *   pt_localize_constants_f32: pt_localize_params from that state, in the reference's float32 operation order (host
+ *     only: no launch, no device access).
+ *   pt_localize_advanced_f32 = constants + pt_localize_decide_f32: one call per frame. */
+typedef struct {
+    double target_not_found_threshold, uncertain_threshold, hard_sample_threshold, distractor_threshold,
+        hard_negative_threshold, target_neighborhood_scale, dispalcement_scale;
+    float kernel_size[2], img_support_sz[2], target_sz[2], pos[2];
+    float sample_scales[8], sample_pos[16];
+} pt_localize_state;
+int pt_localize_constants_f32(const pt_localize_state* st, int S, int H, int W, pt_localize_params* prm);
+int pt_localize_advanced_f32(const float* scores, const float* scores_hn, const pt_localize_state* st, float* out16,
+                             int S, int H, int W, void* stream);
+
 /* ------------------------------------------------------------------------------------------------
  * IoU-guided box refinement -- DiMP.optimize_boxes_default / optimize_boxes_relative
  * (pytracking/tracker/dimp/dimp.py:725-788) on AtomIoUNet.predict_iou (ltr/models/bbreg/atom_iou_net.py:96-136):

@@ -46,20 +46,21 @@ def oracle_step(cfg, mem_feat, mem_bb, sample_weight, filt, test_feat, slot, num
 class TorchCpuTracker:
     """Reference CPU path port (see module docstring).  fp32, torch.no_grad, `threads` CPU threads."""
 
-    def __init__(self, cfg, n, seed, threads=None, device="cpu"):
+    def __init__(self, cfg, n, seed, threads=None, device="cpu", dtype=None):
         import torch
         self.torch = torch
         if threads:
             torch.set_num_threads(int(threads))
         self.cfg, self.n = dict(cfg), n
         self.dev = dev = torch.device(device)     # "cuda": the same stock-PyTorch ops on the GPU (MIOpen convs)
+        self.dtype = dtype = dtype or torch.float32   # float64: the closed-loop checker of the benchmark trajectory
         w0, feat, bb, sw = synth.dimp_problem(seed, n, cfg)
-        T = lambda a: torch.from_numpy(a).to(dev)
+        T = lambda a: torch.from_numpy(a).to(dev, dtype)
         self.mem_feat, self.mem_bb, self.sw, self.filter = T(feat), T(bb), T(sw), T(w0)[None]
         c = cfg
         self.label_w = T(synth.gauss_lut(c["num_dist_bins"], c["bin_displacement"], c["init_gauss_sigma"])).view(1, -1, 1, 1)
         self.mask_w = T(synth.mask_lut(c["num_dist_bins"], c["bin_displacement"], c["mask_init_factor"])).view(1, -1, 1, 1)
-        self.spat_w = torch.ones(1, c["num_dist_bins"], 1, 1, device=dev)
+        self.spat_w = torch.ones(1, c["num_dist_bins"], 1, 1, device=dev, dtype=dtype)
 
     # --- filter layer, as the reference issues it on CPU -------------------------------------------
     def corr(self, feat, w):                      # filter.py:54-57 (one sequence -> groups=1)
@@ -75,10 +76,10 @@ class TorchCpuTracker:
     def dist_maps(self, bb, K, O):                # optimizer.py:112-119 + distance.py:17-39
         torch, c = self.torch, self.cfg
         ctr = ((bb[:, :2] + bb[:, 2:] / 2) / c["feat_stride"]).flip((1,)) - (K % 2) / 2.0
-        k0 = torch.arange(O, dtype=torch.float32, device=self.dev).view(1, 1, -1, 1)
-        k1 = torch.arange(O, dtype=torch.float32, device=self.dev).view(1, 1, 1, -1)
+        k0 = torch.arange(O, dtype=self.dtype, device=self.dev).view(1, 1, -1, 1)
+        k1 = torch.arange(O, dtype=self.dtype, device=self.dev).view(1, 1, 1, -1)
         d = torch.sqrt((k0 - ctr[:, 0].view(-1, 1, 1, 1)) ** 2 + (k1 - ctr[:, 1].view(-1, 1, 1, 1)) ** 2)
-        diff = d / c["bin_displacement"] - torch.arange(c["num_dist_bins"], dtype=torch.float32, device=self.dev).view(1, -1, 1, 1)
+        diff = d / c["bin_displacement"] - torch.arange(c["num_dist_bins"], dtype=self.dtype, device=self.dev).view(1, -1, 1, 1)
         bins = torch.cat((torch.relu(1.0 - diff[:, :-1].abs()), (1.0 + diff[:, -1:]).clamp(0, 1)), dim=1)
         F = torch.nn.functional
         return F.conv2d(bins, self.label_w), torch.sigmoid(F.conv2d(bins, self.mask_w)), F.conv2d(bins, self.spat_w)

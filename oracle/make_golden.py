@@ -496,6 +496,37 @@ def gen_lwl_full():
     save("lwl_gn_cfg5_n32", **out)
 
 
+def gen_long_runs():
+    """Iteration counts the trackers really use beyond the per-frame setting:
+    LWL's first-frame optimisation `net_opt_iter = 20` (pytracking/parameter/lwl/lwl_ytvos.py:30) at the BASELINE
+    configs[4] geometry with n = 1 (the first frame of every sequence) and n = 32, and DiMP at 20 iterations
+    (the C ABI allows 64) on the configs[1] geometry, n = 15.  What a fused solver that carries scores by recurrence
+    could get wrong is drift: the final filter, the losses of all 21 iterates and the scores under the final filter
+    are stored.  Inputs are regenerated from the seed by the tests."""
+    from pytracking import TensorList
+    from ltr.models.meta.steepestdescent import GNSteepestDescent
+    from ltr.models.lwl.loss_residual_modules import LWTLResidual
+    for n, seed in ((1, 5101), (32, 5132)):
+        cfg = dict(synth.LWL, n=n)
+        w0, feat, label, sw = synth.lwl_problem(seed, cfg)
+        res = LWTLResidual(init_filter_reg=cfg["filter_reg"])
+        opt = GNSteepestDescent(residual_module=res, num_iter=20, compute_losses=True, steplength_reg=0.0,
+                                residual_batch_dim=1)
+        w, its, losses = opt(TensorList([T(w0)[None]]), feat=T(feat)[:, None], label=T(label)[:, None],
+                             sample_weight=T(sw)[:, None])
+        with torch.no_grad():
+            s = rfilter.apply_filter(T(feat[:1])[:, None], w[0].detach())
+        save(f"lwl_gn_cfg5_n{n}_it20", seed=seed, n=n, filter_reg=cfg["filter_reg"], num_iter=20,
+             losses=torch.stack([l.detach().reshape(()) for l in losses]).numpy(), final=w[0].detach()[0].numpy(),
+             iterate10=its[10][0][0].detach().numpy().astype(np.float16),      # coarse mid-run check, half the bytes
+             scores_first=s[:, 0].numpy())
+    cfg = synth.DIMP50
+    w0, feat, bb, sw = synth.dimp_problem(1235, 15, cfg)
+    its, losses, scores = _run_opt(_dimp_module(cfg), w0, feat, bb, sw, 20)
+    save("dimp_sd_cfg2_n15_it20", seed=1235, n=15, num_iter=20, losses=losses, scores=scores,
+         iterates=its[[5, 10, 20]], which=np.array([5, 10, 20]))
+
+
 def _iou_net(cfg, params):
     from ltr.models.bbreg.atom_iou_net import AtomIoUNet
     C, I = cfg["C"], cfg["I"]
@@ -677,7 +708,7 @@ def gen_trackers():
 if __name__ == "__main__":
     torch.set_num_threads(8)
     which = sys.argv[1:] or ["filter", "dimp", "l2", "prdimp", "atom", "prroi", "lwl", "atomgn", "tomp", "head", "localize", "iou",
-                             "branches", "ioufull", "atomgnfull", "lwlfull", "trackers", "patches"]
+                             "branches", "ioufull", "atomgnfull", "lwlfull", "trackers", "patches", "long"]
     if "tomp" in which:
         gen_tomp()
     if "head" in which:
@@ -714,3 +745,5 @@ if __name__ == "__main__":
         gen_trackers()
     if "patches" in which:
         gen_patches()
+    if "long" in which:
+        gen_long_runs()

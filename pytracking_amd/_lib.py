@@ -34,6 +34,15 @@ class LocalizeParams(ctypes.Structure):
                 + [(n, ctypes.c_float * 8) for n in ("scale", "neigh_r", "neigh_c", "prev_r", "prev_c")])
 
 
+class LocalizeState(ctypes.Structure):
+    """`pt_localize_state` of include/pt_hot.h."""
+    _fields_ = ([(n, ctypes.c_double) for n in ("target_not_found_threshold", "uncertain_threshold", "hard_sample_threshold",
+                                                "distractor_threshold", "hard_negative_threshold",
+                                                "target_neighborhood_scale", "dispalcement_scale")]
+                + [(n, ctypes.c_float * 2) for n in ("kernel_size", "img_support_sz", "target_sz", "pos")]
+                + [("sample_scales", ctypes.c_float * 8), ("sample_pos", ctypes.c_float * 16)])
+
+
 PT_LOC_FLAGS = ("normal", "hard_negative", "uncertain", "not_found")      # PT_LOC_* of include/pt_hot.h
 
 
@@ -55,6 +64,7 @@ EXPORTS = [
     "pt_tomp_param_floats", "pt_tomp_prepared_floats", "pt_tomp_prepare_f32", "pt_tomp_posenc_f32", "pt_tomp_predict_ws_bytes", "pt_tomp_predict_f32", "pt_tomp_linear_f32",
     "pt_tomp_bbreg_param_floats", "pt_tomp_bbreg_ws_bytes", "pt_tomp_bbreg_f32",
     "pt_clf_head_ws_bytes", "pt_clf_head_f32", "pt_max2d_f32", "pt_localize_f32", "pt_localize_decide_f32",
+    "pt_localize_constants_f32", "pt_localize_advanced_f32",
     "pt_iou_param_floats", "pt_iou_prepared_floats", "pt_iou_prepare_f32", "pt_iou_refine_ws_bytes", "pt_iou_refine_f32",
     "pt_track_frame_replay_pass_f32", "pt_sample_patch_f32", "pt_track_frame_head_ws_bytes", "pt_track_frame_head_f32",
 ]
@@ -188,6 +198,10 @@ def lib():
     L.pt_localize_f32.argtypes = [vp, vp, fp, fp, vp, i, i, i, vp]
     L.pt_localize_decide_f32.restype = i
     L.pt_localize_decide_f32.argtypes = [vp, vp, ctypes.POINTER(LocalizeParams), vp, i, i, i, vp]
+    L.pt_localize_constants_f32.restype = i
+    L.pt_localize_constants_f32.argtypes = [ctypes.POINTER(LocalizeState), i, i, i, ctypes.POINTER(LocalizeParams)]
+    L.pt_localize_advanced_f32.restype = i
+    L.pt_localize_advanced_f32.argtypes = [vp, vp, ctypes.POINTER(LocalizeState), vp, i, i, i, vp]
     ip = ctypes.POINTER(IouDims)
     L.pt_iou_param_floats.restype = sz
     L.pt_iou_param_floats.argtypes = [ip]

@@ -19,17 +19,22 @@ __device__ __forceinline__ bool better(const Peak& a, const Peak& b) {
     return a.v > b.v || (a.v == b.v && (a.c < b.c || (a.c == b.c && a.r < b.r)));
 }
 
-// block-wide arg-max with max2d's tie order; every thread gets the result
+// block-wide arg-max with max2d's tie order; every thread gets the result.  `better` is a strict total order over
+// distinct cells, so the butterfly leaves the same winner in every lane; the <= 4 wave winners meet in LDS.
 __device__ Peak block_peak(Peak p, Peak* sh) {
-    const int tid = threadIdx.x;
-    __syncthreads();
-    sh[tid] = p;
-    __syncthreads();
-    for (int s = blockDim.x >> 1; s > 0; s >>= 1) {
-        if (tid < s && better(sh[tid + s], sh[tid])) sh[tid] = sh[tid + s];
-        __syncthreads();
+#pragma unroll
+    for (int off = 32; off > 0; off >>= 1) {
+        const Peak o{__shfl_xor(p.v, off, 64), __shfl_xor(p.r, off, 64), __shfl_xor(p.c, off, 64)};
+        if (better(o, p)) p = o;
     }
-    return sh[0];
+    const int wave = threadIdx.x >> 6, nw = (blockDim.x + 63) >> 6;
+    __syncthreads();
+    if ((threadIdx.x & 63) == 0) sh[wave] = p;
+    __syncthreads();
+    Peak b = sh[0];
+    for (int w = 1; w < nw; ++w)
+        if (better(sh[w], b)) b = sh[w];
+    return b;
 }
 
 __device__ Peak scan_map(const float* m, int H, int W, int top, int bottom, int left, int right) {
@@ -51,7 +56,7 @@ struct LocArgs {
 };
 
 __global__ __launch_bounds__(256) void k_localize(LocArgs a) {
-    __shared__ Peak sh[256];
+    __shared__ Peak sh[4];
     Peak p1{-INFINITY, 0, 0};
     int s1 = 0;
     for (int s = 0; s < a.S; ++s) {
@@ -70,7 +75,7 @@ __global__ __launch_bounds__(256) void k_localize(LocArgs a) {
 }
 
 __global__ __launch_bounds__(256) void k_max2d(const float* a, float* max_val, long long* argmax, int H, int W) {
-    __shared__ Peak sh[256];
+    __shared__ Peak sh[4];
     const Peak p = block_peak(scan_map(a + (long)blockIdx.x * H * W, H, W, 0, 0, 0, 0), sh);
     if (threadIdx.x == 0) {
         max_val[blockIdx.x] = p.v;
@@ -99,7 +104,7 @@ struct DecideArgs {
 };
 
 __global__ __launch_bounds__(256) void k_localize_decide(DecideArgs a) {
-    __shared__ Peak sh[256];
+    __shared__ Peak sh[4];
     const pt_localize_params& q = a.p;
     Peak p1{-INFINITY, 0, 0};
     int s1 = 0;
@@ -152,6 +157,49 @@ __global__ __launch_bounds__(256) void k_localize_decide(DecideArgs a) {
 }
 
 }  // namespace
+
+// Per-frame constants of the localisation from the tracker's host state (dimp.py:241-244,268,285,291).  Every product /
+// quotient is a float32 operation in the reference (float32 CPU tensors; Python scalars are rounded to float32 by
+// torch's binary ops), so plain `float` arithmetic with contraction off reproduces the values bit for bit.
+#pragma clang fp contract(off)
+extern "C" int pt_localize_constants_f32(const pt_localize_state* st, int S, int H, int W, pt_localize_params* q) {
+    if (!st || !q) return PT_ERR_NULL;
+    if (S <= 0 || H <= 0 || W <= 0) return PT_ERR_SHAPE;
+    if (S > 8) return PT_ERR_UNSUPPORTED;
+    q->target_not_found_threshold = st->target_not_found_threshold;
+    q->uncertain_threshold = st->uncertain_threshold;
+    q->hard_sample_threshold = st->hard_sample_threshold;
+    q->distractor_threshold = (float)st->distractor_threshold;
+    q->hard_negative_threshold = (float)st->hard_negative_threshold;
+    q->target_not_found_f32 = (float)st->target_not_found_threshold;
+    q->disp_threshold = (float)(st->dispalcement_scale * sqrt((double)(H * W)) / 2);
+    const float out_r = (float)H - fmodf(st->kernel_size[0] + 1.0f, 2.0f);          // output_sz = score_sz - (K + 1) % 2
+    const float out_c = (float)W - fmodf(st->kernel_size[1] + 1.0f, 2.0f);
+    q->center_r = ((float)H - 1.0f) / 2.0f;
+    q->center_c = ((float)W - 1.0f) / 2.0f;
+    q->ratio_r = st->img_support_sz[0] / out_r;
+    q->ratio_c = st->img_support_sz[1] / out_c;
+    const float tns = (float)st->target_neighborhood_scale;
+    const float back_r = out_r / st->img_support_sz[0], back_c = out_c / st->img_support_sz[1];
+    for (int s = 0; s < 8; ++s) {
+        const bool in = s < S;
+        const float sc = in ? st->sample_scales[s] : 1.0f;
+        q->scale[s] = sc;
+        q->neigh_r[s] = in ? (tns * (st->target_sz[0] / sc)) * back_r : 0.f;
+        q->neigh_c[s] = in ? (tns * (st->target_sz[1] / sc)) * back_c : 0.f;
+        q->prev_r[s] = in ? (st->pos[0] - st->sample_pos[2 * s]) / (q->ratio_r * sc) : 0.f;
+        q->prev_c[s] = in ? (st->pos[1] - st->sample_pos[2 * s + 1]) / (q->ratio_c * sc) : 0.f;
+    }
+    return PT_OK;
+}
+
+extern "C" int pt_localize_advanced_f32(const float* scores, const float* scores_hn, const pt_localize_state* st,
+                                        float* out16, int S, int H, int W, void* stream) {
+    pt_localize_params q;
+    const int rc = pt_localize_constants_f32(st, S, H, W, &q);
+    if (rc) return rc;
+    return pt_localize_decide_f32(scores, scores_hn, &q, out16, S, H, W, stream);
+}
 
 extern "C" int pt_localize_decide_f32(const float* scores, const float* scores_hn, const pt_localize_params* prm,
                                       float* out16, int S, int H, int W, void* stream) {

@@ -13,7 +13,6 @@ and waits for the stream once.  The reference issues two max2d's, a clone, a mas
 import ctypes
 import math
 
-import numpy as np
 import torch
 
 from . import _lib
@@ -49,8 +48,8 @@ def two_peaks(scores, scores_hn, neigh):
     return out.cpu()                                         # the one synchronisation of the localisation step
 
 
-_F = np.float32
 _HOST_OUT = {}
+_NEG_INF = -float('inf')
 
 
 def _host_out(device):
@@ -63,45 +62,30 @@ def _host_out(device):
     return buf
 
 
-def _f32_pair(t):
-    """A two-element CPU tensor (or sequence) as two numpy float32 scalars."""
-    a, b = t.tolist() if isinstance(t, torch.Tensor) else t
-    return _F(a), _F(b)
-
-
-def _frame_constants(self, shape, sample_pos, sample_scales):
-    """`pt_localize_params` for this frame.  Every product / quotient below is a float32 operation in the reference
-    (float32 CPU tensors; Python scalars are rounded to float32 by torch's binary ops): numpy float32 scalars round
-    identically.  Optional thresholds the parameter file does not define are -inf (the test can never fire)."""
-    S, H, W = shape
+def tracker_state(self, sample_pos, sample_scales, st=None):
+    """`pt_localize_state` (include/pt_hot.h): the host values `localize_advanced` reads from the tracker, unprocessed --
+    the float32 arithmetic on them (dimp.py:241-244,268,285,291) happens inside the library in the reference's operation
+    order.  Optional thresholds the parameter file does not define are -inf (their test can never fire)."""
     prm = self.params
-    q = _lib.LocalizeParams()
-    q.target_not_found_threshold = float(prm.target_not_found_threshold)
-    q.uncertain_threshold = float(prm.get('uncertain_threshold', -float('inf')))
-    q.hard_sample_threshold = float(prm.get('hard_sample_threshold', -float('inf')))
-    q.distractor_threshold = float(prm.distractor_threshold)
-    q.hard_negative_threshold = float(prm.hard_negative_threshold)
-    q.target_not_found_f32 = float(prm.target_not_found_threshold)
-    q.disp_threshold = prm.dispalcement_scale * math.sqrt(H * W) / 2
-    kr, kc = _f32_pair(self.kernel_size)
-    out_r, out_c = _F(H) - (kr + _F(1)) % _F(2), _F(W) - (kc + _F(1)) % _F(2)      # output_sz
-    q.center_r, q.center_c = (_F(H) - _F(1)) / _F(2), (_F(W) - _F(1)) / _F(2)
-    sup_r, sup_c = _f32_pair(self.img_support_sz)
-    ratio_r, ratio_c = sup_r / out_r, sup_c / out_c
-    q.ratio_r, q.ratio_c = ratio_r, ratio_c
-    tns = _F(prm.target_neighborhood_scale)
-    tgt_r, tgt_c = _f32_pair(self.target_sz)
-    pos_r, pos_c = _f32_pair(self.pos)
-    scales = sample_scales.tolist() if isinstance(sample_scales, torch.Tensor) else list(sample_scales)
-    centres = sample_pos.tolist()
-    for s in range(S):
-        sc = _F(scales[s])
-        q.scale[s] = sc
-        q.neigh_r[s] = tns * (tgt_r / sc) * (out_r / sup_r)
-        q.neigh_c[s] = tns * (tgt_c / sc) * (out_c / sup_c)
-        q.prev_r[s] = (pos_r - _F(centres[s][0])) / (ratio_r * sc)
-        q.prev_c[s] = (pos_c - _F(centres[s][1])) / (ratio_c * sc)
-    return q
+    st = _lib.LocalizeState() if st is None else st
+    st.target_not_found_threshold = prm.target_not_found_threshold
+    st.uncertain_threshold = prm.get('uncertain_threshold', _NEG_INF)
+    st.hard_sample_threshold = prm.get('hard_sample_threshold', _NEG_INF)
+    st.distractor_threshold = prm.distractor_threshold
+    st.hard_negative_threshold = prm.hard_negative_threshold
+    st.target_neighborhood_scale = prm.target_neighborhood_scale
+    st.dispalcement_scale = prm.dispalcement_scale
+    st.kernel_size[:] = self.kernel_size.tolist() if isinstance(self.kernel_size, torch.Tensor) else self.kernel_size
+    st.img_support_sz[:] = self.img_support_sz.tolist()
+    st.target_sz[:] = self.target_sz.tolist()
+    st.pos[:] = self.pos.tolist()
+    scales = sample_scales.reshape(-1).tolist() if isinstance(sample_scales, torch.Tensor) else list(sample_scales)
+    S = len(scales)
+    if S > 8:
+        raise NotImplementedError("more than 8 scales per call")
+    st.sample_scales[:S] = scales
+    st.sample_pos[:2 * S] = sample_pos.reshape(-1).tolist()
+    return st, S
 
 
 @device_guarded
@@ -112,27 +96,21 @@ def _localize(self, scores, sample_pos, sample_scales):
         scores_hn = scores.clone()                           # the second peak is searched in the un-windowed map
         scores *= self.output_window
     H, W = scores.shape[-2:]
-    sc3 = scores.reshape(-1, H, W)
-    S = sc3.shape[0]
-    if S > 8:
-        raise NotImplementedError("more than 8 scales per call")
-    if not sc3.is_contiguous():
-        sc3 = sc3.contiguous()
+    sc3 = scores if scores.is_contiguous() else scores.contiguous()
     hn3 = None
     if scores_hn is not scores:
-        hn3 = scores_hn.reshape(-1, H, W)
-        hn3 = hn3 if hn3.is_contiguous() else hn3.contiguous()
-    q = _frame_constants(self, (S, H, W), sample_pos, sample_scales)
+        hn3 = scores_hn if scores_hn.is_contiguous() else scores_hn.contiguous()
+    st, S = tracker_state(self, sample_pos, sample_scales)
+    if S * H * W != sc3.numel():
+        raise ValueError("localize_advanced: one score map per sample scale expected")
     _, host, host_ptr = _host_out(scores.device)
     stream = torch.cuda.current_stream()
-    rc = _lib.lib().pt_localize_decide_f32(_ptr(sc3), None if hn3 is None else _ptr(hn3), ctypes.byref(q), host_ptr, S, H, W,
-                                           ctypes.c_void_p(stream.cuda_stream))
-    _lib.check(rc, "pt_localize_decide_f32")
+    rc = _lib.lib().pt_localize_advanced_f32(sc3.data_ptr(), None if hn3 is None else hn3.data_ptr(), ctypes.byref(st),
+                                             host_ptr, S, H, W, stream.cuda_stream)
+    _lib.check(rc, "pt_localize_advanced_f32")
     stream.synchronize()                                     # the one synchronisation of the localisation step
-    r = host.tolist()
-    translation_vec = torch.tensor(r[4:6], dtype=torch.float32)
-    max_disp = torch.tensor(r[2:4], dtype=torch.float32)
-    return translation_vec, torch.tensor(int(r[1])), scores_hn, _lib.PT_LOC_FLAGS[int(r[0])], max_disp
+    r = torch.from_numpy(host.copy())                        # private copy of the 16 results
+    return r[4:6], torch.tensor(int(host[1])), scores_hn, _lib.PT_LOC_FLAGS[int(host[0])], r[2:4]
 
 
 def localize_advanced(self, scores, sample_pos, sample_scales):

@@ -534,6 +534,57 @@ def test_track_frame_matches_oracle_composition(C, n):
     close(st.filter, ref["filter"], atol=2e-5)
 
 
+def test_bench_trajectory_closed_loop_60_frames():
+    """The benchmark's own trajectory (bench.py: n = 50, C = 512, 5 iterations, graph-replayed) checked closed-loop: 60
+    consecutive `pt_track_frame_f32` frames -- each classifies with the filter the previous frame produced, re-centres
+    a box on its own arg-max and overwrites a memory slot -- against the float64 CPU restatement of the reference's op
+    sequence stepping through the same inputs on its own state (oracle/frame_port.TorchCpuTracker, pinned against the
+    reference goldens in tests/test_oracle_golden.py).  Classification scores, filter, peak and boxes within 1e-4 at
+    EVERY frame; then the same 60 frames as three replays of one 20-frame hipGraph (the launch mode of
+    `bench.py --steps 20 --warmup 5`) must reproduce the eager states bit for bit."""
+    import os
+    from pytracking_amd import bench_frame
+    from oracle.frame_port import TorchCpuTracker
+    cfg, n, G, start = synth.DIMP50, 50, 20, 5
+    st = bench_frame.TrackState(cfg, n, seed=1234, device=DEV)
+    ref = TorchCpuTracker(cfg, n, seed=1234, threads=min(32, os.cpu_count() or 1), dtype=torch.float64)
+    pool_np = synth.clf_features(np.random.default_rng(4321), 50, cfg["C"], cfg["H"], cfg["W"], cfg["K"])
+    pool, pool64 = T(pool_np), torch.from_numpy(pool_np).double()
+    f0, m0, b0 = st.filter.clone(), st.mem_feat.clone(), st.mem_bb.clone()
+    snaps, worst = {}, dict(scores=0.0, filter=0.0, bb=0.0)
+    for f in range(60):
+        k = start + f % G                                               # memory slot = pool entry, as bench.run_frames
+        st.step(pool[k], slot=k, num_iter=5)
+        s_ref = ref.step(pool64[k], k, 5)
+        e_s = float((st.scores.double().cpu() - s_ref).abs().max())
+        e_w = float((st.filter.double().cpu() - ref.filter[0]).abs().max())
+        e_b = float((st.mem_bb.double().cpu() - ref.mem_bb).abs().max())
+        flat = int(torch.argmax(s_ref))
+        assert tuple(st.peak.cpu().numpy().astype(int)) == divmod(flat, s_ref.shape[1]), f
+        assert e_s <= 1e-4 and e_w <= 1e-4 and e_b <= 1e-4, (f, e_s, e_w, e_b)
+        worst = dict(scores=max(worst["scores"], e_s), filter=max(worst["filter"], e_w), bb=max(worst["bb"], e_b))
+        if (f + 1) % G == 0:
+            snaps[f + 1] = (st.filter.clone(), st.scores.clone(), st.mem_bb.clone(), st.mem_feat[start:start + G].clone())
+    assert float((st.filter - f0).abs().max()) > 1e-3                  # the trajectory moved
+    # the graph-replayed launch mode of the benchmark, from the same start state
+    st.filter.copy_(f0); st.mem_feat.copy_(m0); st.mem_bb.copy_(b0)
+    stream = torch.cuda.Stream()
+    stream.wait_stream(torch.cuda.current_stream())
+    with torch.cuda.stream(stream):
+        g = torch.cuda.CUDAGraph()
+        with torch.cuda.graph(g, stream=stream):
+            for f in range(G):
+                st.step(pool[start + f], slot=start + f, num_iter=5)
+        for rep in (1, 2, 3):
+            g.replay()
+            stream.synchronize()
+            w, s, b, m = snaps[rep * G]
+            assert torch.equal(st.filter, w) and torch.equal(st.scores, s) and torch.equal(st.mem_bb, b), rep
+            assert torch.equal(st.mem_feat[start:start + G], m)
+    torch.cuda.current_stream().wait_stream(stream)
+    print("closed-loop worst errors over 60 frames:", worst)
+
+
 # ------------------------------------------------------------------------------------------------------
 # ToMP transformer model predictor (SURVEY.md section 8a row a16)
 # ------------------------------------------------------------------------------------------------------
@@ -660,7 +711,7 @@ def test_localize_advanced_golden():
     vector bit-exact; the 16 numbers the kernel leaves equal the oracle's restatement."""
     import ctypes
     from pytracking_amd import localization as LM
-    from localize_cases import cases
+    from localize_cases import cases, constants
     for me, c in cases(load_golden("localize")):
         scores = T(c["scores"].copy())
         spos, sscl = torch.from_numpy(c["sample_pos"]), torch.from_numpy(c["sample_scales"])
@@ -668,8 +719,7 @@ def test_localize_advanced_golden():
         assert flag == str(c["flag"]) and int(scale_ind) == int(c["scale_ind"]) and s_out is scores
         assert not tv.is_cuda and tv.dtype == torch.float32
         np.testing.assert_array_equal(tv.numpy(), c["tv"])
-        q = LM._frame_constants(me, tuple(scores.shape), spos, sscl)
-        qd = {n: (list(getattr(q, n)) if isinstance(getattr(q, n), ctypes.Array) else getattr(q, n)) for n, _ in q._fields_}
+        _, qd = constants(me, tuple(scores.shape), spos, sscl)
         want = O.localize_decide(c["scores"], c["scores"], qd)
         got = LM._host_out(scores.device)[1].astype(np.float64)
         np.testing.assert_array_equal(got, want)
@@ -685,7 +735,7 @@ def test_localize_windowed_and_device_result_buffer():
     the raw one; and the kernel's result written to DEVICE memory equals the pinned-host result."""
     import ctypes
     from pytracking_amd import _lib, localization as LM
-    from localize_cases import cases
+    from localize_cases import cases, constants
     rng = np.random.default_rng(3)
     for k, (me, c) in enumerate(cases(load_golden("localize"))):
         if k % 6:
@@ -701,8 +751,7 @@ def test_localize_windowed_and_device_result_buffer():
         np.testing.assert_array_equal(s_hn.cpu().numpy(), raw)              # the un-windowed clone is what is returned
         windowed = raw * win
         np.testing.assert_array_equal(scores.cpu().numpy(), windowed)       # `scores *= window` in place, as the reference
-        q = LM._frame_constants(me, (S, H, W), spos, sscl)
-        qd = {n: (list(getattr(q, n)) if isinstance(getattr(q, n), ctypes.Array) else getattr(q, n)) for n, _ in q._fields_}
+        q, qd = constants(me, (S, H, W), spos, sscl)
         want = O.localize_decide(windowed, raw, qd)
         np.testing.assert_array_equal(LM._host_out(scores.device)[1].astype(np.float64), want)
         assert flag == O.LOC_FLAGS[int(want[0])]
@@ -919,6 +968,35 @@ def test_lwl_gn_config5_full_size_golden(num_iter):
     if num_iter == 4:
         s = FL.apply_filter(T(feat[:2])[:, None], its[-1][None])[:, 0]
         close(s, g["scores_first2"], atol=1e-4)
+
+
+@pytest.mark.parametrize("n", [1, 32])
+def test_lwl_gn_config5_twenty_iterations_golden(n):
+    """LWL's first-frame setting `net_opt_iter = 20` (lwl_ytvos.py:30) at the configs[4] geometry, n = 1 (the first frame
+    of every sequence) and n = 32: the fused solver carries the scores by recurrence -- final filter, iterate 10, all 21
+    losses and the scores under the final filter against the reference's autograd run bound the drift."""
+    from pytracking_amd import filter as FL
+    g = load_golden(f"lwl_gn_cfg5_n{n}_it20")
+    w0, feat, label, sw = synth.lwl_problem(int(g["seed"]), dict(synth.LWL, n=n))
+    its, losses = _lwl_run(w0, feat, label, sw, 20, float(g["filter_reg"]), 0.0)
+    close(its[-1], g["final"], atol=1e-4)
+    close(its[10], g["iterate10"].astype(np.float64), atol=2e-3, rtol=2e-3)      # stored as float16
+    close(losses, g["losses"], atol=1e-7, rtol=1e-4)
+    s = FL.apply_filter(T(feat[:1])[:, None], its[-1][None])[:, 0]
+    close(s, g["scores_first"], atol=1e-4)
+    assert np.all(np.diff(losses.cpu().numpy()) < 0)
+
+
+def test_dimp_sd_twenty_iterations_golden():
+    """DiMP at 20 iterations (4x the tracker's setting; the ABI allows 64) at the configs[1] geometry, n = 15: iterates
+    5 / 10 / 20, the 21 losses and the final scores against the reference -- no drift of s_t = s_{t-1} - a (F g)."""
+    from pytracking_amd import filter as F
+    g = load_golden("dimp_sd_cfg2_n15_it20")
+    w0, feat, bb, sw = synth.dimp_problem(int(g["seed"]), int(g["n"]))
+    its, losses = _run(_dimp_module(), w0, feat, bb, sw, 20)
+    close(its[g["which"]], g["iterates"], atol=1e-4)
+    close(losses, g["losses"], atol=1e-4, rtol=1e-4)
+    close(F.apply_filter(T(feat), its[-1][None])[:, 0], g["scores"], atol=1e-4)
 
 
 class _IoUNetFromParams(torch.nn.Module):

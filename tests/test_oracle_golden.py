@@ -70,6 +70,18 @@ def test_dimp_sd_cfg2_n15_full_size():
     close(losses, g["losses"], atol=1e-5, rtol=1e-4)
 
 
+def test_dimp_sd_cfg2_n15_twenty_iterations():
+    """DiMP at 20 iterations (4x the tracker's setting; the ABI allows 64): no drift of the restatement against the
+    reference over a long run -- iterates 5 / 10 / 20, all 21 losses, final scores."""
+    g = load_golden("dimp_sd_cfg2_n15_it20")
+    w0, feat, bb, sw = synth.dimp_problem(int(g["seed"]), int(g["n"]))
+    f64 = lambda a: a.astype(np.float64)
+    its, losses = O.dimp_sd(f64(w0), f64(feat), f64(bb), f64(sw), num_iter=20, **_dimp_kwargs(synth.DIMP50))
+    close(its[g["which"]], g["iterates"], atol=5e-6)
+    close(losses, g["losses"], atol=1e-5, rtol=1e-4)
+    close(O.apply_filter(f64(feat), its[-1]), g["scores"], atol=2e-5)
+
+
 def test_dimp_l2_small():
     g = load_golden("dimp_l2_small")
     f64 = lambda k: g[k].astype(np.float64)
@@ -198,12 +210,11 @@ def test_localize_frame_constants_and_decision():
     import ctypes
     import torch
     from pytracking_amd import localization as LM
-    from localize_cases import cases
+    from localize_cases import cases, constants
     seen = set()
     for me, c in cases(load_golden("localize")):
         S, H, W = c["scores"].shape
-        q = LM._frame_constants(me, (S, H, W), torch.from_numpy(c["sample_pos"]), torch.from_numpy(c["sample_scales"]))
-        qd = {n: (list(getattr(q, n)) if isinstance(getattr(q, n), ctypes.Array) else getattr(q, n)) for n, _ in q._fields_}
+        _, qd = constants(me, (S, H, W), torch.from_numpy(c["sample_pos"]), torch.from_numpy(c["sample_scales"]))
         out = O.localize_decide(c["scores"], c["scores"], qd)
         flag = O.LOC_FLAGS[int(out[0])]
         assert flag == str(c["flag"]) and int(out[1]) == int(c["scale_ind"])
@@ -340,6 +351,20 @@ def test_lwl_gn_config5_full_size_first_iteration():
     close(its[1], g["iterate1"], atol=2e-5)
     close(losses, g["losses4"][:2], atol=1e-7, rtol=1e-4)
     np.testing.assert_array_equal(g["losses3"], g["losses4"][:4])          # 3 iterations are the prefix of 4
+
+
+def test_lwl_gn_config5_first_frame_twenty_iterations():
+    """LWL's first-frame optimisation: `net_opt_iter = 20` (lwl_ytvos.py:30) on ONE sample at the configs[4] geometry
+    (512 x 30 x 52, 16 filters), float64 restatement against the reference's autograd run; the n = 32 run of the same
+    length is checked on the GPU only (its float64 numpy passes take minutes here)."""
+    g = load_golden("lwl_gn_cfg5_n1_it20")
+    w0, feat, label, sw = synth.lwl_problem(int(g["seed"]), dict(synth.LWL, n=int(g["n"])))
+    f64 = lambda a: a.astype(np.float64)
+    its, losses = O.lwl_gn_sd(f64(w0), f64(feat), f64(label), f64(sw), num_iter=20, filter_reg=float(g["filter_reg"]))
+    close(its[-1], g["final"], atol=2e-5)
+    close(its[10], g["iterate10"].astype(np.float64), atol=2e-3, rtol=2e-3)         # stored as float16
+    close(losses, g["losses"], atol=1e-7, rtol=1e-4)
+    close(O.apply_filter(f64(feat[:1]), its[-1]), g["scores_first"], atol=2e-5)
 
 
 @pytest.mark.parametrize("tag,relative", [("default", False), ("relative", True)])
