@@ -41,8 +41,7 @@ import time
 
 import numpy as np
 
-os.environ.setdefault("MIOPEN_FIND_MODE", "FAST")   # stock-PyTorch baseline / backbone legs: no exhaustive MIOpen search
-import torch  # noqa: E402
+import torch
 
 ROOT = os.path.dirname(os.path.abspath(__file__))
 if ROOT not in sys.path:
@@ -54,7 +53,8 @@ from tools import workloads  # noqa: E402
 HBM_PEAK_GBS = 8000.0      # MI355X_MICROARCH.md: HBM3E 8.0 TB/s spec
 NUM_ITER = 5
 POOL = 50                  # distinct synthetic test features cycled through (one per memory slot)
-CPU_THREADS = 32           # pinned: the oneDNN grouped convs of the CPU path stop scaling (and wander) beyond this
+CPU_THREADS = 16           # pinned at the measured optimum of this path on the 256-core host (profiles/r03a_cpu_thread_scaling.json:
+#                            5.4 / 40.8 / 66.2 / 44.9 / 16.4 / 6.2 frames/s at 1 / 8 / 16 / 32 / 64 / 128 threads)
 
 
 def make_pool(cfg, seed, device):
@@ -387,10 +387,6 @@ def main():
         if world == 1 and cfg_name == "dimp50":
             if not args.no_other:
                 out["other_workloads"] = workloads.all_other(dev)
-                try:
-                    out["end_to_end"] = workloads.end_to_end(dev)
-                except Exception as exc:                         # noqa: BLE001
-                    out["end_to_end"] = {"error": f"{type(exc).__name__}: {exc}"[:300]}
             if not args.no_cpu_baseline:
                 out["cpu_baseline"] = stock_baseline(cfg, n, "cpu", budget_s=12.0)
                 one = stock_baseline(cfg, n, "cpu", budget_s=5.0, min_frames=3, threads=1)
@@ -398,6 +394,11 @@ def main():
                 torch.set_num_threads(min(CPU_THREADS, os.cpu_count() or 1))
             if not args.no_gpu_baseline:
                 out["gpu_stock_baseline"] = stock_baseline(cfg, n, dev, budget_s=4.0, min_frames=50)
+            if not args.no_other:                                # last: its MIOpen find mode must not touch the baseline above
+                try:
+                    out["end_to_end"] = workloads.end_to_end(dev)
+                except Exception as exc:                         # noqa: BLE001
+                    out["end_to_end"] = {"error": f"{type(exc).__name__}: {exc}"[:300]}
         print(json.dumps(out), flush=True)
     if dist is not None:
         dist.barrier()

@@ -265,7 +265,7 @@ int pt_localize_f32(const float* scores, const float* scores_hn, const float* ne
  *   sample_scales[s], neigh = target_neigh_sz (dimp.py:268), prev = prev_target_vec (dimp.py:285), disp_threshold =
  *   dispalcement_scale * sqrt(H * W) / 2 (dimp.py:291).  Absent optional thresholds are passed as -infinity.
  * out16 (device memory OR device-visible pinned host memory; the kernel writes it directly) =
- *   [code, scale_ind, row, col, translation_row, translation_col, max1, row1, col1, max2, row2, col2, peak_chosen, 0, 0, 0]
+ *   [code, scale_ind, row, col, translation_row, translation_col, max1, row1, col1, max2, row2, col2, peak_chosen, 0, 0, seq]
  *   with code = PT_LOC_*, (row, col) the displacement (`max_disp`) of the chosen peak and translation =
  *   (disp - center) * ratio * scale[scale_ind] in float32 (dimp.py:256,282). */
 enum { PT_LOC_NORMAL = 0, PT_LOC_HARD_NEGATIVE = 1, PT_LOC_UNCERTAIN = 2, PT_LOC_NOT_FOUND = 3 };
@@ -293,6 +293,12 @@ typedef struct {
 int pt_localize_constants_f32(const pt_localize_state* st, int S, int H, int W, pt_localize_params* prm);
 int pt_localize_advanced_f32(const float* scores, const float* scores_hn, const pt_localize_state* st, float* out16,
                              int S, int H, int W, void* stream);
+/* pt_localize_advanced_sync_f32: the same, returning when the results are readable by the host.  out16_host MUST be
+ * pinned host memory the device can write (hipHostMalloc, torch `pin_memory()`); anything else -> unsupported.  The
+ * kernel stores a per-call sequence number into out16_host[15] last and the host polls that word (no runtime
+ * synchronisation call on the frame's critical path); only work queued on `stream` BEFORE this launch is waited for. */
+int pt_localize_advanced_sync_f32(const float* scores, const float* scores_hn, const pt_localize_state* st,
+                                  float* out16_host, int S, int H, int W, void* stream);
 
 /* ------------------------------------------------------------------------------------------------
  * IoU-guided box refinement -- DiMP.optimize_boxes_default / optimize_boxes_relative

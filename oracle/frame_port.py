@@ -46,7 +46,7 @@ def oracle_step(cfg, mem_feat, mem_bb, sample_weight, filt, test_feat, slot, num
 class TorchCpuTracker:
     """Reference CPU path port (see module docstring).  fp32, torch.no_grad, `threads` CPU threads."""
 
-    def __init__(self, cfg, n, seed, threads=None, device="cpu", dtype=None):
+    def __init__(self, cfg, n, seed, threads=None, device="cpu", dtype=None, gemm=False):
         import torch
         self.torch = torch
         if threads:
@@ -54,6 +54,11 @@ class TorchCpuTracker:
         self.cfg, self.n = dict(cfg), n
         self.dev = dev = torch.device(device)     # "cuda": the same stock-PyTorch ops on the GPU (MIOpen convs)
         self.dtype = dtype = dtype or torch.float32   # float64: the closed-loop checker of the benchmark trajectory
+        # gemm=True: the two filter-layer ops as dense contractions (below) instead of the reference's grouped convolutions
+        # -- the same sums, but float64 grouped convolutions have no fast CPU kernel (2.3 s per n = 50 frame against
+        # 0.1 s); used by the closed-loop GPU test, pinned against the conv form and the goldens in
+        # tests/test_oracle_golden.py::test_torch_port_matches_reference
+        self.gemm = bool(gemm)
         w0, feat, bb, sw = synth.dimp_problem(seed, n, cfg)
         T = lambda a: torch.from_numpy(a).to(dev, dtype)
         self.mem_feat, self.mem_bb, self.sw, self.filter = T(feat), T(bb), T(sw), T(w0)[None]
@@ -65,11 +70,32 @@ class TorchCpuTracker:
     # --- filter layer, as the reference issues it on CPU -------------------------------------------
     def corr(self, feat, w):                      # filter.py:54-57 (one sequence -> groups=1)
         F = self.torch.nn.functional
+        if self.gemm:
+            # out[y, x] = sum_{u,v} T[u,v][y + u - p, x + v - p],  T[u,v] = sum_c w[c,u,v] feat[c]: one GEMM for the 16
+            # tap planes, then their shifted sum (negative padding crops)
+            n, C, H, W = feat.shape
+            K, p = w.shape[-1], w.shape[-1] // 2
+            OH, OW = H + 2 * p - K + 1, W + 2 * p - K + 1
+            Tp = self.torch.einsum('nck,ct->ntk', feat.reshape(n, C, H * W), w.reshape(C, K * K)).reshape(n, K, K, H, W)
+            out = None
+            for u in range(K):
+                for v in range(K):
+                    t = F.pad(Tp[:, u, v], (p - v, OW - W - (p - v), p - u, OH - H - (p - u)))
+                    out = t if out is None else out + t
+            return out[:, None]
         return F.conv2d(feat, w, padding=w.shape[-1] // 2)
 
     def adj(self, feat, inp, K):                  # filter.py:129-155 (_apply_feat_transpose_v2)
         F = self.torch.nn.functional
         n, C, H, W = feat.shape
+        if self.gemm:
+            # G[c,u,v] = sum_{n,y,x} feat[n,c,y,x] r[n, y - u + p, x - v + p]: the K x K windows of the padded residual
+            # maps (unfold) against the features, one GEMM with the summation over samples and positions
+            p = K // 2
+            a = K - 1 - p
+            R = F.unfold(F.pad(inp.reshape(n, 1, *inp.shape[-2:]), (a, a, a, a)), K)             # (n, K*K, H*W), taps flipped
+            G = self.torch.einsum('nck,ntk->ct', feat.reshape(n, C, H * W), R).reshape(1, C, K, K)
+            return G.flip((2, 3))
         g = F.conv2d(inp.reshape(1, n, *inp.shape[-2:]), feat.reshape(n * C, 1, H, W), padding=(K - 1) // 2, groups=n)
         return g.view(n, 1, C, g.shape[-2], g.shape[-1]).sum(dim=0).flip((2, 3))
 

@@ -64,7 +64,7 @@ EXPORTS = [
     "pt_tomp_param_floats", "pt_tomp_prepared_floats", "pt_tomp_prepare_f32", "pt_tomp_posenc_f32", "pt_tomp_predict_ws_bytes", "pt_tomp_predict_f32", "pt_tomp_linear_f32",
     "pt_tomp_bbreg_param_floats", "pt_tomp_bbreg_ws_bytes", "pt_tomp_bbreg_f32",
     "pt_clf_head_ws_bytes", "pt_clf_head_f32", "pt_max2d_f32", "pt_localize_f32", "pt_localize_decide_f32",
-    "pt_localize_constants_f32", "pt_localize_advanced_f32",
+    "pt_localize_constants_f32", "pt_localize_advanced_f32", "pt_localize_advanced_sync_f32",
     "pt_iou_param_floats", "pt_iou_prepared_floats", "pt_iou_prepare_f32", "pt_iou_refine_ws_bytes", "pt_iou_refine_f32",
     "pt_track_frame_replay_pass_f32", "pt_sample_patch_f32", "pt_track_frame_head_ws_bytes", "pt_track_frame_head_f32",
 ]
@@ -202,6 +202,8 @@ def lib():
     L.pt_localize_constants_f32.argtypes = [ctypes.POINTER(LocalizeState), i, i, i, ctypes.POINTER(LocalizeParams)]
     L.pt_localize_advanced_f32.restype = i
     L.pt_localize_advanced_f32.argtypes = [vp, vp, ctypes.POINTER(LocalizeState), vp, i, i, i, vp]
+    L.pt_localize_advanced_sync_f32.restype = i
+    L.pt_localize_advanced_sync_f32.argtypes = [vp, vp, ctypes.POINTER(LocalizeState), vp, i, i, i, vp]
     ip = ctypes.POINTER(IouDims)
     L.pt_iou_param_floats.restype = sz
     L.pt_iou_param_floats.argtypes = [ip]

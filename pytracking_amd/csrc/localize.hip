@@ -8,6 +8,7 @@
 // index on ties, i.e. ties go to the smallest column, then the smallest row; the best scale is the first one on ties;
 // the neighbourhood of the first peak is ZEROED (not excluded) before the second search; its bounds use Python's
 // round() on doubles = round-half-to-even = rint.
+#include <chrono>
 #include "common.h"
 #include "pt_internal.h"
 
@@ -100,6 +101,7 @@ struct DecideArgs {
     const float *scores, *scores_hn;
     float* out;
     int S, H, W;
+    float seq;                   // written to out[15] LAST (system scope): what pt_localize_advanced_sync_f32 polls
     pt_localize_params p;
 };
 
@@ -152,8 +154,9 @@ __global__ __launch_bounds__(256) void k_localize_decide(DecideArgs a) {
     o[5] = __fmul_rn(__fmul_rn(dc, q.ratio_c), q.scale[s1]);
     o[6] = p1.v; o[7] = (float)p1.r; o[8] = (float)p1.c;
     o[9] = p2.v; o[10] = (float)p2.r; o[11] = (float)p2.c;
-    o[12] = (float)pick; o[13] = 0.f; o[14] = 0.f; o[15] = 0.f;
-    __threadfence_system();
+    o[12] = (float)pick; o[13] = 0.f; o[14] = 0.f;
+    __threadfence_system();                                              // results visible before the sequence number
+    __hip_atomic_store(o + 15, a.seq, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_SYSTEM);
 }
 
 }  // namespace
@@ -193,24 +196,69 @@ extern "C" int pt_localize_constants_f32(const pt_localize_state* st, int S, int
     return PT_OK;
 }
 
-extern "C" int pt_localize_advanced_f32(const float* scores, const float* scores_hn, const pt_localize_state* st,
-                                        float* out16, int S, int H, int W, void* stream) {
-    pt_localize_params q;
-    const int rc = pt_localize_constants_f32(st, S, H, W, &q);
-    if (rc) return rc;
-    return pt_localize_decide_f32(scores, scores_hn, &q, out16, S, H, W, stream);
-}
-
-extern "C" int pt_localize_decide_f32(const float* scores, const float* scores_hn, const pt_localize_params* prm,
-                                      float* out16, int S, int H, int W, void* stream) {
+static int localize_launch(const float* scores, const float* scores_hn, const pt_localize_params* prm, float* out16,
+                           int S, int H, int W, float seq, void* stream) {
     if (!scores || !prm || !out16) return PT_ERR_NULL;
     if (S <= 0 || H <= 0 || W <= 0) return PT_ERR_SHAPE;
     if (S > 8) return PT_ERR_UNSUPPORTED;
     DecideArgs a{};
     a.scores = scores; a.scores_hn = scores_hn ? scores_hn : scores; a.out = out16; a.S = S; a.H = H; a.W = W;
+    a.seq = seq;
     a.p = *prm;
     hipLaunchKernelGGL(k_localize_decide, dim3(1), dim3(256), 0, (hipStream_t)stream, a);
     PT_CHECK_LAUNCH();
+    return PT_OK;
+}
+
+extern "C" int pt_localize_decide_f32(const float* scores, const float* scores_hn, const pt_localize_params* prm,
+                                      float* out16, int S, int H, int W, void* stream) {
+    return localize_launch(scores, scores_hn, prm, out16, S, H, W, 0.f, stream);
+}
+
+extern "C" int pt_localize_advanced_f32(const float* scores, const float* scores_hn, const pt_localize_state* st,
+                                        float* out16, int S, int H, int W, void* stream) {
+    pt_localize_params q;
+    const int rc = pt_localize_constants_f32(st, S, H, W, &q);
+    if (rc) return rc;
+    return localize_launch(scores, scores_hn, &q, out16, S, H, W, 0.f, stream);
+}
+
+// The same, and the call returns when the 16 results are readable by the host: `out16_host` must be pinned host memory
+// the device can write (hipHostMalloc / torch pin_memory).  The kernel stores a per-call sequence number into
+// out16_host[15] after everything else (system-scope release); the host polls that word instead of paying a
+// hipStreamSynchronize round trip through the runtime -- the tracker needs these numbers before it can do anything
+// else, so this wait IS the frame's critical path.  Falls back to hipStreamSynchronize after 2 s without the word.
+extern "C" int pt_localize_advanced_sync_f32(const float* scores, const float* scores_hn, const pt_localize_state* st,
+                                             float* out16_host, int S, int H, int W, void* stream) {
+    if (!out16_host) return PT_ERR_NULL;
+    static const void* checked = nullptr;                               // pointer class verified once per buffer
+    if (checked != out16_host) {
+        hipPointerAttribute_t at;
+        if (hipPointerGetAttributes(&at, out16_host) != hipSuccess || at.type != hipMemoryTypeHost) {
+            (void)hipGetLastError();
+            return PT_ERR_UNSUPPORTED;
+        }
+        checked = out16_host;
+    }
+    pt_localize_params q;
+    int rc = pt_localize_constants_f32(st, S, H, W, &q);
+    if (rc) return rc;
+    volatile float* word = out16_host + 15;
+    float seq = *word + 1.0f;
+    if (!(seq >= 1.0f && seq < 8388608.0f)) seq = 1.0f;                 // stays an exactly representable integer
+    rc = localize_launch(scores, scores_hn, &q, out16_host, S, H, W, seq, stream);
+    if (rc) return rc;
+    const auto t0 = std::chrono::steady_clock::now();
+    for (unsigned spin = 1;; ++spin) {
+        if (*word == seq) break;
+        __builtin_ia32_pause();
+        if ((spin & 0xFFFF) == 0 && std::chrono::steady_clock::now() - t0 > std::chrono::seconds(2)) {
+            if (hipStreamSynchronize((hipStream_t)stream) != hipSuccess) return PT_ERR_LAUNCH;
+            if (*word != seq) return PT_ERR_LAUNCH;
+            break;
+        }
+    }
+    __atomic_thread_fence(__ATOMIC_ACQUIRE);
     return PT_OK;
 }
 

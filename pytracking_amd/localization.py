@@ -104,11 +104,10 @@ def _localize(self, scores, sample_pos, sample_scales):
     if S * H * W != sc3.numel():
         raise ValueError("localize_advanced: one score map per sample scale expected")
     _, host, host_ptr = _host_out(scores.device)
-    stream = torch.cuda.current_stream()
-    rc = _lib.lib().pt_localize_advanced_f32(sc3.data_ptr(), None if hn3 is None else hn3.data_ptr(), ctypes.byref(st),
-                                             host_ptr, S, H, W, stream.cuda_stream)
-    _lib.check(rc, "pt_localize_advanced_f32")
-    stream.synchronize()                                     # the one synchronisation of the localisation step
+    # launches and returns when the 16 results have landed in the pinned buffer: the one wait of the localisation step
+    rc = _lib.lib().pt_localize_advanced_sync_f32(sc3.data_ptr(), None if hn3 is None else hn3.data_ptr(), ctypes.byref(st),
+                                                  host_ptr, S, H, W, torch.cuda.current_stream().cuda_stream)
+    _lib.check(rc, "pt_localize_advanced_sync_f32")
     r = torch.from_numpy(host.copy())                        # private copy of the 16 results
     return r[4:6], torch.tensor(int(host[1])), scores_hn, _lib.PT_LOC_FLAGS[int(host[0])], r[2:4]
 

@@ -547,7 +547,7 @@ def test_bench_trajectory_closed_loop_60_frames():
     from oracle.frame_port import TorchCpuTracker
     cfg, n, G, start = synth.DIMP50, 50, 20, 5
     st = bench_frame.TrackState(cfg, n, seed=1234, device=DEV)
-    ref = TorchCpuTracker(cfg, n, seed=1234, threads=min(32, os.cpu_count() or 1), dtype=torch.float64)
+    ref = TorchCpuTracker(cfg, n, seed=1234, threads=min(16, os.cpu_count() or 1), dtype=torch.float64, gemm=True)
     pool_np = synth.clf_features(np.random.default_rng(4321), 50, cfg["C"], cfg["H"], cfg["W"], cfg["K"])
     pool, pool64 = T(pool_np), torch.from_numpy(pool_np).double()
     f0, m0, b0 = st.filter.clone(), st.mem_feat.clone(), st.mem_bb.clone()
@@ -722,7 +722,8 @@ def test_localize_advanced_golden():
         _, qd = constants(me, tuple(scores.shape), spos, sscl)
         want = O.localize_decide(c["scores"], c["scores"], qd)
         got = LM._host_out(scores.device)[1].astype(np.float64)
-        np.testing.assert_array_equal(got, want)
+        np.testing.assert_array_equal(got[:15], want[:15])                  # [15]: the call's sequence number
+        assert got[15] >= 1
         v = LM.two_peaks(scores, None, [np.array([3.3, 4.7], np.float32)] * scores.shape[0]).numpy().astype(np.float64)
         ref = O.two_peaks(c["scores"], c["scores"], [np.array([3.3, 4.7], np.float32)] * scores.shape[0])
         np.testing.assert_array_equal(v, ref)                               # bit-exact: values are copied, indices integral
@@ -753,7 +754,7 @@ def test_localize_windowed_and_device_result_buffer():
         np.testing.assert_array_equal(scores.cpu().numpy(), windowed)       # `scores *= window` in place, as the reference
         q, qd = constants(me, (S, H, W), spos, sscl)
         want = O.localize_decide(windowed, raw, qd)
-        np.testing.assert_array_equal(LM._host_out(scores.device)[1].astype(np.float64), want)
+        np.testing.assert_array_equal(LM._host_out(scores.device)[1].astype(np.float64)[:15], want[:15])
         assert flag == O.LOC_FLAGS[int(want[0])]
         dev = torch.zeros(16, device=DEV)
         rc = _lib.lib().pt_localize_decide_f32(scores.data_ptr(), s_hn.data_ptr(), ctypes.byref(q), dev.data_ptr(), S, H, W,
@@ -984,7 +985,8 @@ def test_lwl_gn_config5_twenty_iterations_golden(n):
     close(losses, g["losses"], atol=1e-7, rtol=1e-4)
     s = FL.apply_filter(T(feat[:1])[:, None], its[-1][None])[:, 0]
     close(s, g["scores_first"], atol=1e-4)
-    assert np.all(np.diff(losses.cpu().numpy()) < 0)
+    ls = losses.cpu().numpy()
+    assert np.all(np.diff(ls) <= 1e-7 * ls[0]) and ls[-1] < ls[0]         # non-increasing up to float32 rounding at convergence
 
 
 def test_dimp_sd_twenty_iterations_golden():

@@ -139,6 +139,22 @@ def test_torch_port_matches_reference():
     with torch.no_grad():
         w = tr.solve(tr.filter, tr.mem_feat, tr.mem_bb, tr.sw, 5)
     close(w[0].numpy(), g["iterates"][-1], atol=2e-6)
+    # the float64 / dense-contraction form the closed-loop GPU test steps (same sums, no grouped convolutions): against
+    # the reference golden, against the convolution form op by op (even and odd filter sizes), and over frames
+    tr64 = TorchCpuTracker(synth.DIMP50, int(g["n"]), int(g["seed"]), dtype=torch.float64, gemm=True)
+    with torch.no_grad():
+        w64 = tr64.solve(tr64.filter, tr64.mem_feat, tr64.mem_bb, tr64.sw, 5)
+    close(w64[0].numpy(), g["iterates"][-1], atol=2e-6)
+    rng = np.random.default_rng(0)
+    for K in (4, 3, 1, 2):
+        conv, gem = (TorchCpuTracker(dict(synth.DIMP50, C=8, K=K), 3, 5, dtype=torch.float64, gemm=m) for m in (False, True))
+        feat = torch.from_numpy(rng.standard_normal((3, 8, 7, 9)))
+        wk = torch.from_numpy(rng.standard_normal((1, 8, K, K)))
+        s0, s1 = conv.corr(feat, wk), gem.corr(feat, wk)
+        assert s0.shape == s1.shape
+        close(s1.numpy(), s0.numpy(), atol=1e-12)
+        r = torch.from_numpy(rng.standard_normal(tuple(s0.shape)))
+        close(gem.adj(feat, r, K).numpy(), conv.adj(feat, r, K).numpy(), atol=1e-12)
 
 
 @pytest.mark.parametrize("name", ["lwl_gn_small_full", "lwl_gn_small_img", "lwl_gn_small_none", "lwl_gn_mid"])

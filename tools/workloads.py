@@ -5,6 +5,7 @@ returns a dict with the measured time, the ALGORITHMIC work of the unit (SURVEY.
 Inputs are synthetic (pytracking_amd/synth.py generators), resident in HBM before the timed region.
 """
 import math
+import os
 import time
 
 import numpy as np
@@ -209,6 +210,7 @@ def end_to_end(dev, frames=60, num_iter=5):
     classify + arg-max + 5 SD iterations over n = 50).  Reports the backbone's own time next to the whole frame."""
     cfg = synth.DIMP50
     n = cfg["memory"]
+    os.environ.setdefault("MIOPEN_FIND_MODE", "FAST")        # ~25 convolution shapes: no exhaustive MIOpen search per shape
     torch.manual_seed(7)
     net = resnet50_to_layer3().to(dev).eval()
     st = bench_frame.TrackState(cfg, n, seed=777, device=dev)
@@ -228,14 +230,40 @@ def end_to_end(dev, frames=60, num_iter=5):
         st.step_from_backbone(backbone(k[0]), k[0] % n, num_iter)
         k[0] += 1
 
+    out = {"workload": "U(0,255) 288x288 patch -> stock PyTorch ResNet-50 conv1..layer3 (fp32, random init) -> head + classify + "
+                       "arg-max + insert + 5 SD iterations (pt_track_frame_head_f32), n=50"}
     with torch.no_grad():
         assert backbone(0).shape == (1024, cfg["H"], cfg["W"])
         t_bb = _timed(lambda: backbone(0), frames, warm=5)
         t_all = _timed(frame, frames, warm=5)
-    return {"workload": "U(0,255) 288x288 patch -> stock PyTorch ResNet-50 conv1..layer3 (fp32, eager, random init) -> head + "
-                        "classify + arg-max + insert + 5 SD iterations (pt_track_frame_head_f32), n=50",
-            "backbone_ms": round(t_bb * 1e3, 4), "frame_ms": round(t_all * 1e3, 4), "frames_per_s": round(1 / t_all, 1),
-            "hot_path_share": round(max(0.0, 1.0 - t_bb / t_all), 4)}
+        out["eager"] = {"backbone_ms": round(t_bb * 1e3, 4), "frame_ms": round(t_all * 1e3, 4), "frames_per_s": round(1 / t_all, 1),
+                        "note": "host-launch bound: ~150 eager stock-PyTorch kernel launches per backbone pass; the hot path's "
+                                "device time hides in the launch gaps"}
+        # the same work as hipGraphs (stock torch.cuda.graph capture of the backbone; one graph per patch / slot pair):
+        # device time of the backbone alone and of the whole frame
+        try:
+            s = torch.cuda.Stream(device=dev)
+            s.wait_stream(torch.cuda.current_stream())
+            with torch.cuda.stream(s):
+                gb = torch.cuda.CUDAGraph()
+                with torch.cuda.graph(gb, stream=s):
+                    keep = backbone(0)
+                G = 8
+                gf = torch.cuda.CUDAGraph()
+                with torch.cuda.graph(gf, stream=s):
+                    for f in range(G):
+                        st.step_from_backbone(backbone(f), f % n, num_iter)
+                t_gb = _timed(gb.replay, frames, warm=3)
+                t_gf = _timed(gf.replay, max(2, frames // G), warm=2) / G
+            torch.cuda.current_stream().wait_stream(s)
+            del keep
+            out["graph"] = {"backbone_ms": round(t_gb * 1e3, 4), "frame_ms": round(t_gf * 1e3, 4), "frames_per_s": round(1 / t_gf, 1),
+                            "hot_path_share": round(max(0.0, 1.0 - t_gb / t_gf), 4)}
+        except Exception as exc:                                 # noqa: BLE001
+            out["graph"] = {"error": f"{type(exc).__name__}: {exc}"[:200]}
+    best = out["graph"] if "frames_per_s" in out.get("graph", {}) else out["eager"]
+    out["frames_per_s"], out["backbone_ms"], out["frame_ms"] = best["frames_per_s"], best["backbone_ms"], best["frame_ms"]
+    return out
 
 
 def all_other(dev):
