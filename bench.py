@@ -175,7 +175,10 @@ def roofline(cfg, cfg_name, n, period, stats, why):
     event pairs around 200 back-to-back pass launches) and `stats` (rocprofv3 kernel averages of the child process)."""
     feat_bytes = 4 * n * cfg["C"] * cfg["H"] * cfg["W"]           # one pass streams the n-sample memory once
     kern = {}
-    for short in ("k_corr2", "k_adj2"):
+    # the correlation pass of the solve is the position-band kernel k_corr3 (k_corr2 with PT_SD_NO_BAND=1 / shapes it does not cover)
+    corr_name = "k_corr3" if (stats and any("k_corr3" in nm for nm in stats)) or not stats else "k_corr2"
+    period = {corr_name: period["corr"], "k_adj2": period["adj"]}
+    for short in (corr_name, "k_adj2"):
         rec = {"period_us": round(period[short], 3)}
         if stats:
             rows = [(nm, c, a) for nm, (c, a) in stats.items() if short in nm]
@@ -336,7 +339,7 @@ def main():
 
         period = None
         if want_roof:
-            period = {"k_corr2": event_period_us(st, stream, 0), "k_adj2": event_period_us(st, stream, 1)}
+            period = {"corr": event_period_us(st, stream, 0), "adj": event_period_us(st, stream, 1)}
         if use_graph and warm_graph is not None:
             warm_graph.replay()
         else:

@@ -580,8 +580,8 @@ __global__ __launch_bounds__(PT_ADJ_WAVES * 64) void k_adj2(Adj2Args a) {
     const bool wupd = V != V_PLAIN && a.t > 0 && ks == 0;
     const long wge = (long)cb * 16 * KK + min((int)threadIdx.x, 16 * KK - 1);
     if (V != V_PLAIN && a.t > 0) {                                  // optimizer.py:155-160 / :425-430
-        float q_in = 0.f, w_prev = 0.f, g_prev = 0.f;
-        for (int k = lane; k < a.sd.n; k += 64) q_in += a.sd.qs[k];
+        float w_prev = 0.f, g_prev = 0.f;
+        const float q_in = sd_q_lane(a.sd, lane);
         const float an_in = lane < a.sd.KS ? a.sd.anum[lane] : 0.f;
         if (wupd) {                                                 // uniform per workgroup
             w_prev = sd_w(a.sd, a.t - 1)[wge];

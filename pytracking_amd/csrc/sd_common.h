@@ -21,7 +21,9 @@ struct SdArgs {
     float *R;                    // (NG,256)
     float *gpart, *g;            // (KSPL,CKK), (CKK)
     float *anum;                 // (KS) per-channel-slice |g|^2 (written by the corr(g) pass)
-    float *qs;                   // (n)
+    float *qs;                   // (n) per-sample curvature terms, or with QB > 0 the band partials (n, QB, 2) of k_corr3
+    int QB;                      // 0: qs[i] = q_i.  > 0: DiMP kinds q_i = sum_b qs[i][b][0]; PrDiMP q_i = swp_i * max(A - B^2, 0),
+                                 //    A = sum_b qs[i][b][0] = sum_o P (F g)^2,  B = sum_b qs[i][b][1] = sum_o P (F g)
     float *lossp;                // (T+1, n)
     float *w_iters;              // (T+1, CKK)  caller's buffer; iterate 0 lives at w0
     const float *w0;             // initial filter
@@ -183,12 +185,31 @@ __device__ __forceinline__ void act_pair(int score_act, float bpar, float x, flo
 }
 
 
+// this lane's share of sum_i q_i (samples lane, lane + 64, ...), fixed order
+__device__ __forceinline__ float sd_q_lane(const SdArgs& a, int lane) {
+    float acc = 0.f;
+    if (a.QB == 0) {
+        for (int k = lane; k < a.n; k += 64) acc += a.qs[k];
+        return acc;
+    }
+    for (int k = lane; k < a.n; k += 64) {
+        const float* q = a.qs + (long)k * a.QB * 2;
+        float A = 0.f, B = 0.f;
+        for (int b = 0; b < a.QB; ++b) { A += q[2 * b]; B += q[2 * b + 1]; }
+        if (a.kind == PT_SD_PRDIMP) {
+            const float swp = a.has_sw ? a.sw[k] : 1.0f / (float)a.n;
+            acc += swp * fmaxf(A - B * B, 0.f);                                     // optimizer.py:419-422
+        } else {
+            acc += A;
+        }
+    }
+    return acc;
+}
+
 // optimizer.py:155-160 / :425-430: alpha = |g|^2 / max(sum_i q_i + (reg+eps)|g|^2, 1e-8), times the step length;
 // from one wave (every lane gets it): wave-parallel fixed-order sums, identical in every workgroup.
 __device__ __forceinline__ float sd_alpha_step_wave(const SdArgs& a, int lane) {
-    float den = 0.f;
-    for (int k = lane; k < a.n; k += 64) den += a.qs[k];
-    den = wave_sum(den);
+    float den = wave_sum(sd_q_lane(a, lane));
     const float a_num = wave_sum(lane < a.KS ? a.anum[lane] : 0.f);
     den = fmaxf(den + (a.reg + a.alpha_eps) * a_num, 1e-8f);
     return a.step * (a_num / den);

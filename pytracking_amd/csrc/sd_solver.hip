@@ -18,6 +18,7 @@
 //     pw SGQ        sg = F g ; per-sample curvature term q_i                                  [n WGs]
 //     pw UPDATE     alpha ; w_{t+1} ; s_{t+1} ; next residual map + R ; loss                  [n WGs]
 #include <algorithm>
+#include <cstdlib>
 #include "common.h"
 #include "pt_internal.h"
 #include "rbuild.h"
@@ -221,10 +222,20 @@ static FastCarve fast_carve(const PtFast& f, int max_iter) {
     c.gpart = take(pt_fast_gpart_floats(f));
     c.g = take((size_t)f.C * f.KK);
     c.anum = take(64);
-    c.qs = take(f.n);
+    c.qs = take((size_t)f.n * 16);                      // per-sample terms, or the band partials (n, <= 8 bands, 2)
     c.lossp = take((size_t)(max_iter + 1) * f.n);
     c.total = off;
     return c;
+}
+
+// Position-band correlation (band_corr.hip) instead of k_corr2 + k_fast_sgq inside the solve: measured in round 3 and NOT
+// the default -- it removes the five pointwise launches of a solve, but every workgroup then has to take in all C channels
+// of the reduced gradient (8 partials: 288 KB) next to 1.5x its share of the features, and with 200 workgroups on 200 CUs
+// the pass is bound by what ONE CU can ingest: 15.2 us against 10.1 + 4.9 us for k_corr2 + k_fast_sgq
+// (profiles/r03c_band_corr_experiment.txt).  PT_SD_BAND=1 in the environment selects it (parity-tested).
+static bool sd_use_band(const PtBand& b) {
+    const char* e = std::getenv("PT_SD_BAND");
+    return b.ok && e && e[0] == '1';
 }
 
 // packed operands of the update stage that k_adj2 runs as its prologue (PReg in fast_passes.hip)
@@ -328,7 +339,7 @@ static int sd_fast_setup(const PtFast& f, const pt_sd_params* prm, const float* 
     if (ws_bytes < cv.total * sizeof(float) || ((uintptr_t)ws % 256) != 0) return PT_ERR_WORKSPACE;
     float* base = (float*)ws;
     sd_fill_params(a, prm, bb, sample_weight, f.n, f.C, f.H, f.W, f.KH, f.OH, f.OW);
-    a.KS = 8; a.KSPL = f.KSPL;
+    a.KS = 8; a.KSPL = f.KSPL; a.QB = 0;
     a.label = base + cv.label; a.mask = base + cv.mask; a.sws = base + cv.sws; a.sg = base + cv.sg;
     a.lms = base + cv.lms; a.pk = base + cv.pk;
     a.spart = base + cv.spart; a.gpart = base + cv.gpart; a.g = base + cv.g; a.anum = base + cv.anum;
@@ -348,9 +359,12 @@ static int sd_solve_fast(const PtFast& f, const pt_sd_params* prm, const float* 
     if (rc) return rc;
     const int n = f.n;
     const int slot = cls ? cls->slot : -1;
+    const PtBand bp = pt_band_plan(f);
+    const bool band = sd_use_band(bp);
+    if (band) { a.KS = 1; a.QB = bp.B; }                         // complete score maps, one |g|^2 word, band curvature partials
     if (cls) {
         // the inserted sample's scores under w_in ARE the classification scores of the test frame
-        a.cls_spart = a.spart + (long)slot * a.OO; a.cls_KS = 8; a.cls_stride = (long)n * a.OO; a.cls_slot = slot;
+        a.cls_spart = a.spart + (long)slot * a.OO; a.cls_KS = a.KS; a.cls_stride = (long)n * a.OO; a.cls_slot = slot;
         a.cls_scores = cls->scores; a.cls_peak = cls->peak; a.cls_bb = cls->mem_bb;
     }
     const int want_loss = losses != nullptr;
@@ -362,7 +376,8 @@ static int sd_solve_fast(const PtFast& f, const pt_sd_params* prm, const float* 
     if (num_iter == 0 && !want_loss && !cls) return PT_OK;
 
     float* copy_dst = src ? const_cast<float*>(feat) + (long)slot * stride_n : nullptr;
-    rc = pt_launch_corr2(f, feat, stride_n, w_in, a.spart, st, nullptr, src ? slot : -1, src, copy_dst);
+    if (band) rc = pt_launch_corr3(f, bp, feat, stride_n, w_in, a.spart, st, nullptr, nullptr, src ? slot : -1, src, copy_dst);
+    else rc = pt_launch_corr2(f, feat, stride_n, w_in, a.spart, st, nullptr, src ? slot : -1, src, copy_dst);
     if (rc) return rc;
     hipLaunchKernelGGL(k_fast_init, dim3(n), dim3(384), 0, st, a);
     PT_CHECK_LAUNCH();
@@ -378,6 +393,11 @@ static int sd_solve_fast(const PtFast& f, const pt_sd_params* prm, const float* 
         rc = pt_launch_adj2_sd(f, feat, stride_n, a, t, want_loss, st);        // alpha_{t-1}, w_t, s_t, residual maps
         if (rc) return rc;
         PtCorrFuse fz = {a.gpart, f.KSPL, t == 0 ? w_in : w_iters + (long)t * a.CKK, a.reg, a.g, a.anum, nullptr};
+        if (band) {                                                            // g_t, |g_t|^2, F g_t, q partials, packed operands
+            rc = pt_launch_corr3(f, bp, feat, stride_n, nullptr, nullptr, st, &fz, &a);
+            if (rc) return rc;
+            continue;
+        }
         rc = pt_launch_corr2(f, feat, stride_n, nullptr, a.spart, st, &fz);    // g_t, |g_t|^2, F g_t
         if (rc) return rc;
         hipLaunchKernelGGL(k_fast_sgq, dim3(n), dim3(384), pw_lds, st, a);
@@ -425,7 +445,7 @@ int pt_sd_solve_impl(const pt_sd_params* prm, const float* w_in, const float* fe
 
     SdArgs a;
     a.n = n; a.C = C; a.H = H; a.W = W; a.K = K; a.OH = OH; a.OW = OW; a.OO = OH * OW; a.CKK = C * K * K;
-    a.KS = p.KS; a.KSPL = p.KSPL;
+    a.KS = p.KS; a.KSPL = p.KSPL; a.QB = 0;
     a.kind = prm->kind; a.score_act = prm->score_act; a.mask_act = prm->mask_act; a.has_sw = sample_weight != nullptr;
     a.has_softmax_reg = prm->has_softmax_reg; a.normalize_label = prm->normalize_label; a.num_bins = prm->num_bins;
     a.step = prm->step_length; a.reg = prm->reg; a.alpha_eps = prm->alpha_eps; a.feat_stride = prm->feat_stride;
@@ -513,12 +533,16 @@ int pt_sd_replay_impl(const pt_sd_params* prm, const float* w_in, const float* f
     const int t = num_iter - 1;
     a.s_in = sbuf[(t - 1) & 1];
     a.s = sbuf[t & 1];
+    const PtBand bp = pt_band_plan(f);
+    const bool band = sd_use_band(bp);
+    if (band) { a.KS = 1; a.QB = bp.B; }
     for (int r = 0; r < reps; ++r) {
         if (which == 1) {
             rc = pt_launch_adj2_sd(f, feat, feat_stride_n, a, t, 0, st);
         } else {
             PtCorrFuse fz = {a.gpart, f.KSPL, w_iters + (long)t * a.CKK, a.reg, a.g, a.anum, nullptr};
-            rc = pt_launch_corr2(f, feat, feat_stride_n, nullptr, a.spart, st, &fz);
+            if (band) rc = pt_launch_corr3(f, bp, feat, feat_stride_n, nullptr, nullptr, st, &fz, &a);
+            else rc = pt_launch_corr2(f, feat, feat_stride_n, nullptr, a.spart, st, &fz);
         }
         if (rc) return rc;
     }
