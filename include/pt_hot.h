@@ -384,6 +384,33 @@ int pt_sample_patch_f32(const float* im, int C, int H, int W, const pt_patch_geo
                         void* stream);
 
 /* ------------------------------------------------------------------------------------------------
+ * First-frame augmentation set (second half).
+ * Replaces: pytracking/features/preprocessing.py:13-30 `sample_patch_transformed` -- the loop `T(im_patch)` over the
+ * transforms of pytracking/features/augmentation.py (Identity :39, FlipHorizontal :44, FlipVertical :52, Translation :60,
+ * Scale :73, Rotate :111, Blur :128) followed by `Transform.crop_to_output` (:20-37) -- as built by
+ * pytracking/tracker/dimp/dimp.py:329-395 `generate_init_samples` (same in atom.py / tomp.py / kys.py).
+ *   patch  (C, EH, EW) base patch on the device (the output of pt_sample_patch_f32 at the augmentation size)
+ *   desc   T records on the HOST, one per transform (they travel in the kernel arguments):
+ *          kind      PT_AUG_*                         (Translation is PT_AUG_IDENTITY with its shift in the pads)
+ *          pad_top / pad_left = floor((OH - th) / 2) + shift[0], floor((OW - tw) / 2) + shift[1]   (augmentation.py:30-33)
+ *          th, tw    size of the transformed image before the crop (EH, EW except for PT_AUG_SCALE: :84-87)
+ *          fs0, fs1, tap_off0, tap_off1   PT_AUG_BLUR: half filter sizes ceil(2 sigma) and the offsets of the 2 fs + 1
+ *                    normalised taps of each axis in `taps` (host, n_taps floats)                                     (:135-140)
+ *          m[6]      PT_AUG_ROTATE: the 2x3 matrix that maps OUTPUT to INPUT pixels (the inverse of the matrix the
+ *                    reference hands to cv.warpAffine, :121-126); parity of this kind is UNPINNED (no cv2 in the image)
+ *   out    (T, C, OH, OW)
+ * ---------------------------------------------------------------------------------------------- */
+enum { PT_AUG_IDENTITY = 0, PT_AUG_FLIP_H = 1, PT_AUG_FLIP_V = 2, PT_AUG_BLUR = 3, PT_AUG_SCALE = 4, PT_AUG_ROTATE = 5 };
+typedef struct pt_aug_desc {
+    int kind, pad_top, pad_left, th, tw, fs0, fs1, tap_off0, tap_off1, reserved;
+    double m[6];
+} pt_aug_desc;
+#define PT_AUG_MAX_TRANSFORMS 24   /* per launch; longer lists are split by the library */
+#define PT_AUG_MAX_TAPS 256
+int pt_augment_patches_f32(const float* patch, int C, int EH, int EW, const pt_aug_desc* desc, int T, const float* taps,
+                           int n_taps, float* out, int OH, int OW, void* stream);
+
+/* ------------------------------------------------------------------------------------------------
  * Measurement entry (bench.py roofline leg; not part of the reference's API).  Re-issues ONE feature pass of the
  * solve that pt_track_frame_f32 last ran on `ws` -- the launch of its last iteration, same kernel instantiation and
  * operands -- `reps` times back to back on `stream`, so that the caller can bracket the run with ONE HIP event pair

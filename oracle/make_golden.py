@@ -695,6 +695,67 @@ def gen_patches():
     save("sample_patch", **out)
 
 
+def gen_augment():
+    """`sample_patch_transformed` of the unmodified reference (preprocessing.py:13-30) with transform lists built from the
+    reference's own classes (augmentation.py): Identity, Translation, FlipHorizontal, FlipVertical, Blur, Scale -- with and without
+    an output size, shifts that crop and shifts that pad.  `Rotate` needs cv2 (not installed): no golden, declared unpinned.
+    Case `s`: small, full outputs.  Case `d`: the DiMP-50 first-frame list (parameter/dimp/dimp50.py:38-44 without 'rotate';
+    288 output, expansion factor 2, random shifts drawn as dimp.py:363-366 does) -- outputs stored on a stride-5 pixel grid."""
+    from pytracking.features.preprocessing import sample_patch_transformed
+    from pytracking.features import augmentation as A
+    rng = np.random.default_rng(171)
+
+    def describe(Tr):
+        d = {"cls": type(Tr).__name__, "output_sz": -1 if Tr.output_sz is None else np.array(Tr.output_sz, np.int64),
+             "shift": np.array(Tr.shift, np.int64)}
+        if isinstance(Tr, A.Blur):
+            d["f0"], d["f1"] = Tr.filter[0].reshape(-1).numpy(), Tr.filter[1].reshape(-1).numpy()
+        if isinstance(Tr, A.Scale):
+            d["scale_factor"] = float(Tr.scale_factor)
+        return d
+
+    out = {}
+
+    def run(tag, im, pos, scale, image_sz, transforms, stride):
+        res = sample_patch_transformed(im, torch.Tensor(pos), scale, torch.Tensor(image_sz), transforms)
+        out.update({f"{tag}_im": im.numpy().astype(np.uint8), f"{tag}_pos": np.array(pos, np.float32), f"{tag}_scale": np.float32(scale),
+                    f"{tag}_image_sz": np.array(image_sz, np.float32), f"{tag}_n": len(transforms), f"{tag}_stride": stride,
+                    f"{tag}_out": res.numpy()[:, :, ::stride, ::stride], f"{tag}_shape": np.array(res.shape, np.int64),
+                    f"{tag}_sums": res.double().sum(dim=(1, 2, 3)).numpy()})
+        for k, Tr in enumerate(transforms):
+            for key, v in describe(Tr).items():
+                out[f"{tag}_t{k}_{key}"] = v
+
+    im = T(rng.integers(0, 256, size=(1, 3, 70, 90)).astype(np.float32))
+    osz = [32, 32]
+    trs = [A.Identity(osz, [0, 0]), A.Identity(osz, [3, -2]), A.Translation([5, -7], osz, [1, 1]), A.Translation([-20, 24], osz, [0, 0]),
+           A.FlipHorizontal(osz, [2, 3]), A.FlipVertical(osz, [-4, 0]), A.Blur((3, 1), osz, [0, 5]), A.Blur((1, 3), osz, None),
+           A.Blur(2, osz, [-6, -6]), A.Blur((0.2, 1.5), osz, [1, 0]), A.Scale(0.8, osz, [2, -3]), A.Scale(1.3, osz, None),
+           A.Scale(2.5, osz, [4, 4])]
+    run("s", im, (35.3, 44.8), 1.1, (64.0, 64.0), trs, 1)
+    trs = [A.Identity(None, None), A.Translation([9, -4]), A.FlipHorizontal(None, [3, 3]), A.Blur((1, 2), None, [-5, 2])]
+    run("n", im, (30.0, 50.0), 0.9, (48.0, 40.0), trs, 1)
+
+    # DiMP-50 first frame (dimp.py:329-395): image_sample_size 288, augmentation_expansion_factor 2, random_shift_factor 1/3
+    im = T(rng.integers(0, 256, size=(1, 3, 240, 320)).astype(np.float32))
+    img_sample_sz = torch.Tensor([288.0, 288.0])
+    aug_expansion_sz = (img_sample_sz * 2).long()
+    aug_expansion_sz += (aug_expansion_sz - img_sample_sz.long()) % 2
+    aug_expansion_sz = aug_expansion_sz.float()
+    aug_output_sz = img_sample_sz.long().tolist()
+    torch.manual_seed(5)
+    global_shift = torch.zeros(2)
+    rand_shift = lambda: ((torch.rand(2) - 0.5) * img_sample_sz * (1 / 3) + global_shift).long().tolist()
+    get_absolute = lambda shift: (torch.Tensor(shift) * img_sample_sz / 2).long().tolist()
+    trs = [A.Identity(aug_output_sz, global_shift.long().tolist())]
+    trs += [A.Translation(get_absolute(sh), aug_output_sz, global_shift.long().tolist())
+            for sh in [(0.6, 0.6), (-0.6, 0.6), (0.6, -0.6), (-0.6, -0.6)]]
+    trs.append(A.FlipHorizontal(aug_output_sz, rand_shift()))
+    trs += [A.Blur(sig, aug_output_sz, rand_shift()) for sig in [(3, 1), (1, 3), (2, 2)]]
+    run("d", im, (118.0, 163.0), 0.7, aug_expansion_sz.tolist(), trs, 5)
+    save("augment", **out)
+
+
 def gen_trackers():
     """Trajectory-level vectors: the unmodified reference DiMP tracker (initialize + 10 x track) on a stubbed backbone,
     every boundary call recorded (oracle/tracker_harness.py)."""
@@ -708,7 +769,7 @@ def gen_trackers():
 if __name__ == "__main__":
     torch.set_num_threads(8)
     which = sys.argv[1:] or ["filter", "dimp", "l2", "prdimp", "atom", "prroi", "lwl", "atomgn", "tomp", "head", "localize", "iou",
-                             "branches", "ioufull", "atomgnfull", "lwlfull", "trackers", "patches", "long"]
+                             "branches", "ioufull", "atomgnfull", "lwlfull", "trackers", "patches", "long", "augment"]
     if "tomp" in which:
         gen_tomp()
     if "head" in which:
@@ -747,3 +808,5 @@ if __name__ == "__main__":
         gen_patches()
     if "long" in which:
         gen_long_runs()
+    if "augment" in which:
+        gen_augment()

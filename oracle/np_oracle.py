@@ -699,10 +699,22 @@ def localize_decide(scores, scores_hn, q):
 # --------------------------------------------------------------------------------------------
 # image-patch sampling (pytracking/features/preprocessing.py:54-148), pixel part
 # --------------------------------------------------------------------------------------------
+def _fma32(a, b, c):
+    """float32 fused multiply-add: the product of two float32 values is exact in float64; one rounding of the sum.
+    (The float64 sum is itself rounded before the final rounding -- a double rounding that needs a tie at the 29th extra bit;
+    it has not occurred on any golden.)"""
+    return (np.asarray(a, np.float64) * np.asarray(b, np.float64) + np.asarray(c, np.float64)).astype(np.float32)
+
+
 def sample_patch_pixels(im, df, os0, os1, tl0, tl1, crop_h, crop_w, out_hw):
     """Strided view `im[..., os0::df, os1::df]`, crop [tl, tl + crop) with replicate padding, bilinear resize with
-    `F.interpolate(mode='bilinear', align_corners=False)` semantics (ATen: scale = in / out in float32,
-    src = scale * (dst + 0.5) - 0.5 clamped at 0, blend of the two column blends).  im (C,H,W) float32 -> (C,oh,ow)."""
+    `F.interpolate(mode='bilinear', align_corners=False)` semantics as ATen's CPU kernel executes them in this image
+    (UpSampleKernel.cpp, generic separable path): scale = in / out in float32, src = fma(scale, dst + 0.5, -0.5) clamped at 0
+    -- the build contracts that expression into ONE fused multiply-add (found by matching its output: with the unfused form
+    the weights of a 403 -> 576 resize are an ulp of src ~ 3e-5 off and pixels move by up to 3.6e-3, with the fused form the
+    restatement is within 5e-5 = 3 ulp of a 0..255 pixel) -- lambda1 = src - floor(src), row blends then the column blend.
+    How the compiler contracted the BLENDS differs between the kernel's loop specialisations (shape dependent; 17 of the 24
+    golden patches are bit-identical with either form), so they are left unfused here.  im (C,H,W) float32 -> (C,oh,ow)."""
     f32 = np.float32
     im2 = im[:, os0::df, os1::df]
     H2, W2 = im2.shape[1:]
@@ -710,12 +722,17 @@ def sample_patch_pixels(im, df, os0, os1, tl0, tl1, crop_h, crop_w, out_hw):
     cols = np.clip(tl1 + np.arange(crop_w), 0, W2 - 1)
     patch = im2[:, rows][:, :, cols].astype(f32)
     oh, ow = out_hw
+    if (oh, ow) == (crop_h, crop_w):
+        return patch                                                     # preprocessing.py:139-140: no resampling
 
     def axis(n_in, n_out):
+        if n_in == n_out:                                                # ATen: scale factor 1 copies (lambda0 = 1, lambda1 = 0)
+            i0 = np.arange(n_out)
+            return i0, i0, np.ones(n_out, f32), np.zeros(n_out, f32)
         scale = f32(n_in) / f32(n_out)
-        src = scale * (np.arange(n_out, dtype=f32) + f32(0.5)) - f32(0.5)
+        src = _fma32(scale, np.arange(n_out, dtype=f32) + f32(0.5), f32(-0.5))
         src = np.maximum(src, f32(0))
-        i0 = src.astype(np.int64)
+        i0 = np.minimum(src.astype(np.int64), n_in - 1)
         i1 = i0 + (i0 < n_in - 1)
         l1 = np.clip(src - i0.astype(f32), f32(0), f32(1)).astype(f32)
         return i0, i1, (f32(1) - l1).astype(f32), l1
@@ -724,3 +741,96 @@ def sample_patch_pixels(im, df, os0, os1, tl0, tl1, crop_h, crop_w, out_hw):
     top = patch[:, y0][:, :, x0] * lx0 + patch[:, y0][:, :, x1] * lx1
     bot = patch[:, y1][:, :, x0] * lx0 + patch[:, y1][:, :, x1] * lx1
     return (top * ly0[None, :, None] + bot * ly1[None, :, None]).astype(f32)
+
+
+# --------------------------------------------------------------------------------------------
+# first-frame augmentation set (pytracking/features/augmentation.py:11-147, preprocessing.py:13-30)
+# --------------------------------------------------------------------------------------------
+def aug_crop_to_output(img, output_sz, shift):
+    """`Transform.crop_to_output` (augmentation.py:20-37): F.pad(mode='replicate') with pads floor/ceil((out - in) / 2) +- shift;
+    negative pads crop.  img (C, H, W)."""
+    H, W = img.shape[1:]
+    pad_h = 0.0 if output_sz is None else (output_sz[0] - H) / 2
+    pad_w = 0.0 if output_sz is None else (output_sz[1] - W) / 2
+    top, bottom = math.floor(pad_h) + shift[0], math.ceil(pad_h) - shift[0]
+    left, right = math.floor(pad_w) + shift[1], math.ceil(pad_w) - shift[1]
+    rows = np.clip(np.arange(H + top + bottom) - top, 0, H - 1)
+    cols = np.clip(np.arange(W + left + right) - left, 0, W - 1)
+    return img[:, rows][:, :, cols]
+
+
+def aug_blur(img, f0, f1):
+    """`Blur.__call__` (:142-147): correlation with f0 along the rows (zero padding), the float32 result correlated with f1
+    along the columns.  Accumulation in float32, taps in ascending order."""
+    f32 = np.float32
+    C, H, W = img.shape
+    fs0, fs1 = (len(f0) - 1) // 2, (len(f1) - 1) // 2
+    p = np.zeros((C, H + 2 * fs0, W), f32)
+    p[:, fs0:fs0 + H] = img
+    im1 = np.zeros((C, H, W), f32)
+    for i in range(2 * fs0 + 1):
+        im1 = (im1 + f32(f0[i]) * p[:, i:i + H]).astype(f32)
+    p = np.zeros((C, H, W + 2 * fs1), f32)
+    p[:, :, fs1:fs1 + W] = im1
+    out = np.zeros((C, H, W), f32)
+    for j in range(2 * fs1 + 1):
+        out = (out + f32(f1[j]) * p[:, :, j:j + W]).astype(f32)
+    return out
+
+
+def aug_scale_size(h_orig, scale_factor):
+    h_new = round(h_orig / scale_factor)                                   # :84-87
+    return h_new + (h_new - h_orig) % 2
+
+
+def aug_rotate(img, angle_deg):
+    """`Rotate.__call__` (:118-126) = cv2.warpAffine(image, [R | c - R c], (W, H), INTER_LINEAR, BORDER_REPLICATE), restated
+    from OpenCV's published algorithm (imgwarp.cpp: the matrix is inverted in double, source coordinates are formed in
+    fixed point with 10 fractional bits, rounded to 1/32 pixel, bilinear weights k/32 in float).  PARITY UNPINNED: cv2 is
+    not installed in the build container, no golden exists for this transform."""
+    f32 = np.float32
+    C, H, W = img.shape
+    a = math.pi * angle_deg / 180
+    ca, sa = math.cos(a), math.sin(a)
+    c0, c1 = (H - 1) / 2, (W - 1) / 2
+    M = [ca, sa, c0 - (ca * c0 + sa * c1), -sa, ca, c1 - (-sa * c0 + ca * c1)]
+    D = M[0] * M[4] - M[1] * M[3]
+    D = 1.0 / D if D != 0 else 0.0
+    m0, m1, m3, m4 = M[4] * D, M[1] * (-D), M[3] * (-D), M[0] * D
+    m2, m5 = -m0 * M[2] - m1 * M[5], -m3 * M[2] - m4 * M[5]
+    xs, ys = np.arange(W, dtype=np.float64), np.arange(H, dtype=np.float64)
+    X = (np.rint(m0 * xs * 1024.0).astype(np.int64)[None, :] + (np.rint((m1 * ys + m2) * 1024.0).astype(np.int64) + 16)[:, None]) >> 5
+    Y = (np.rint(m3 * xs * 1024.0).astype(np.int64)[None, :] + (np.rint((m4 * ys + m5) * 1024.0).astype(np.int64) + 16)[:, None]) >> 5
+    ix, iy = X >> 5, Y >> 5
+    ax, ay = (X & 31).astype(f32) / f32(32), (Y & 31).astype(f32) / f32(32)
+    cy = lambda v: np.clip(v, 0, H - 1)
+    cx = lambda v: np.clip(v, 0, W - 1)
+    p00, p01 = img[:, cy(iy), cx(ix)], img[:, cy(iy), cx(ix + 1)]
+    p10, p11 = img[:, cy(iy + 1), cx(ix)], img[:, cy(iy + 1), cx(ix + 1)]
+    one = f32(1)
+    return (p00 * ((one - ax) * (one - ay)) + p01 * (ax * (one - ay)) + p10 * ((one - ax) * ay) + p11 * (ax * ay)).astype(f32)
+
+
+def augment_patch(patch, specs):
+    """`torch.cat([T(im_patch) for T in transforms])` (preprocessing.py:28).  patch (C, EH, EW) float32; specs: list of dicts
+    {kind: identity | fliplr | flipud | blur | scale | rotate, output_sz, shift, f0 / f1, scale_factor, angle}."""
+    outs = []
+    for sp in specs:
+        k = sp["kind"]
+        if k == "identity":
+            img = patch
+        elif k == "fliplr":
+            img = patch[:, :, ::-1]
+        elif k == "flipud":
+            img = patch[:, ::-1]
+        elif k == "blur":
+            img = aug_blur(patch, sp["f0"], sp["f1"])
+        elif k == "scale":
+            hn, wn = aug_scale_size(patch.shape[1], sp["scale_factor"]), aug_scale_size(patch.shape[2], sp["scale_factor"])
+            img = sample_patch_pixels(patch, 1, 0, 0, 0, 0, patch.shape[1], patch.shape[2], (hn, wn))
+        elif k == "rotate":
+            img = aug_rotate(patch, sp["angle"])
+        else:
+            raise ValueError(k)
+        outs.append(aug_crop_to_output(img, sp.get("output_sz"), sp.get("shift", (0, 0))))
+    return np.stack(outs).astype(np.float32)

@@ -26,6 +26,16 @@ class PatchGeom(ctypes.Structure):
     _fields_ = [(n, ctypes.c_int) for n in ("df", "os0", "os1", "tl0", "tl1", "crop_h", "crop_w")]
 
 
+class AugDesc(ctypes.Structure):
+    """`pt_aug_desc` of include/pt_hot.h."""
+    _fields_ = ([(n, ctypes.c_int) for n in ("kind", "pad_top", "pad_left", "th", "tw", "fs0", "fs1", "tap_off0", "tap_off1",
+                                             "reserved")] + [("m", ctypes.c_double * 6)])
+
+
+PT_AUG_IDENTITY, PT_AUG_FLIP_H, PT_AUG_FLIP_V, PT_AUG_BLUR, PT_AUG_SCALE, PT_AUG_ROTATE = range(6)
+PT_AUG_MAX_TAPS = 256
+
+
 class LocalizeParams(ctypes.Structure):
     """`pt_localize_params` of include/pt_hot.h."""
     _fields_ = ([(n, ctypes.c_double) for n in ("target_not_found_threshold", "uncertain_threshold", "hard_sample_threshold")]
@@ -66,7 +76,7 @@ EXPORTS = [
     "pt_clf_head_ws_bytes", "pt_clf_head_f32", "pt_max2d_f32", "pt_localize_f32", "pt_localize_decide_f32",
     "pt_localize_constants_f32", "pt_localize_advanced_f32", "pt_localize_advanced_sync_f32",
     "pt_iou_param_floats", "pt_iou_prepared_floats", "pt_iou_prepare_f32", "pt_iou_refine_ws_bytes", "pt_iou_refine_f32",
-    "pt_track_frame_replay_pass_f32", "pt_sample_patch_f32", "pt_track_frame_head_ws_bytes", "pt_track_frame_head_f32",
+    "pt_track_frame_replay_pass_f32", "pt_sample_patch_f32", "pt_augment_patches_f32", "pt_track_frame_head_ws_bytes", "pt_track_frame_head_f32",
 ]
 
 
@@ -93,18 +103,47 @@ def needs_build() -> bool:
 
 
 def build_library(force=False, verbose=False) -> str:
-    """hipcc --offload-arch=gfx950 -> pytracking_amd/libpt_hot.so (in-tree, travels with the repo snapshot)."""
+    """hipcc --offload-arch=gfx950 -> pytracking_amd/libpt_hot.so (in-tree, travels with the repo snapshot).
+    One object per source under pytracking_amd/build/ (compiled in parallel, only the stale ones unless `force`), then
+    one link step."""
     if not force and not needs_build():
         return LIB_PATH
+    from concurrent.futures import ThreadPoolExecutor
     hipcc = os.environ.get("HIPCC", "/opt/rocm/bin/hipcc")
-    cmd = [hipcc, "--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-shared", "-Wno-pass-failed"] + \
-          os.environ.get("PT_HOT_CFLAGS", "").split() + ["-o", LIB_PATH] + [os.path.join(_HERE, "csrc", s) for s in SOURCES]
+    flags = ["--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-Wno-pass-failed"] + os.environ.get("PT_HOT_CFLAGS", "").split()
+    bdir = os.path.join(_HERE, "build")
+    os.makedirs(bdir, exist_ok=True)
+    stamp = os.path.join(bdir, "flags.txt")
+    if not os.path.exists(stamp) or open(stamp).read() != " ".join(flags):
+        force = True
+    hdr_t = max(os.path.getmtime(os.path.join(_HERE, "csrc", h)) for h in HEADERS if os.path.exists(os.path.join(_HERE, "csrc", h)))
+
+    def compile_one(src):
+        spath = os.path.join(_HERE, "csrc", src)
+        obj = os.path.join(bdir, os.path.splitext(src)[0] + ".o")
+        if not force and os.path.exists(obj) and os.path.getmtime(obj) > max(os.path.getmtime(spath), hdr_t):
+            return obj, None
+        cmd = [hipcc] + flags + ["-c", spath, "-o", obj]
+        res = subprocess.run(cmd, capture_output=True, text=True)
+        if verbose or res.returncode != 0:
+            print(" ".join(cmd))
+            print(res.stdout, res.stderr)
+        return obj, (res.stderr if res.returncode != 0 else None)
+
+    with ThreadPoolExecutor(max_workers=min(len(SOURCES), os.cpu_count() or 4)) as ex:
+        results = list(ex.map(compile_one, SOURCES))
+    errs = [e for _, e in results if e]
+    if errs:
+        raise RuntimeError("hipcc failed building libpt_hot.so:\n" + "\n".join(errs))
+    cmd = [hipcc, "--offload-arch=gfx950", "-shared", "-fPIC", "-o", LIB_PATH] + [o for o, _ in results]
     res = subprocess.run(cmd, capture_output=True, text=True)
     if verbose or res.returncode != 0:
         print(" ".join(cmd))
         print(res.stdout, res.stderr)
     if res.returncode != 0:
-        raise RuntimeError("hipcc failed building libpt_hot.so:\n" + res.stderr)
+        raise RuntimeError("hipcc failed linking libpt_hot.so:\n" + res.stderr)
+    with open(stamp, "w") as fh:
+        fh.write(" ".join(flags))
     return LIB_PATH
 
 
@@ -223,6 +262,8 @@ def lib():
     L.pt_track_frame_head_f32.argtypes = [ctypes.POINTER(SdParams), vp, vp, vp, vp, vp, vp, f, f] + [i] * 8 + [vp, vp, vp, sz, vp]
     L.pt_sample_patch_f32.restype = i
     L.pt_sample_patch_f32.argtypes = [vp, i, i, i, ctypes.POINTER(PatchGeom), i, vp, i, i, vp]
+    L.pt_augment_patches_f32.restype = i
+    L.pt_augment_patches_f32.argtypes = [vp, i, i, i, ctypes.POINTER(AugDesc), i, ctypes.POINTER(ctypes.c_float), i, vp, i, i, vp]
     _lib = L
     return L
 

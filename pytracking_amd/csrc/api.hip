@@ -51,7 +51,7 @@ extern "C" int pt_apply_filter_f32(const float* feat, long feat_stride_n, const 
     if (pt_fast_usable(f, feat, feat_stride_n, filt)) {
         rc = pt_launch_corr2(f, feat, feat_stride_n, filt, spart, st);
         if (rc) return rc;
-        return pt_launch_sum_slices(spart, scores, 8, (size_t)n * f.OO, st);
+        return pt_launch_sum_slices(spart, scores, f.KSC, (size_t)n * f.OO, st);
     }
     PtPlan p = pt_make_plan(n, C, H, W, KH, KW, OH, OW);
     rc = pt_launch_corr(p, feat, feat_stride_n, filt, spart, st);

@@ -29,16 +29,33 @@ __device__ __forceinline__ f32x4 mfma16(float a, float b, f32x4 c) {
     return __builtin_amdgcn_mfma_f32_16x16x4f32(a, b, c, 0, 0, 0);
 }
 
+// Wave-wide reductions, every lane gets the result.  Inside a row of 16 lanes the butterfly runs on DPP operands (xor 1 and
+// xor 2 as quad permutes, then row_half_mirror and row_mirror: each step adds the partner group's total, so all lanes of the
+// row hold the same bits); the four rows are combined in fixed order through v_readlane.  ~10 instructions of a few cycles
+// instead of six dependent ds_bpermute round trips (the alpha of the k_adj2 prologue sat behind twelve of them).
+// (a lane whose DPP source is switched off receives `old`: 0 for sums, its own value for maxima; the callers run with full waves)
+template <int CTRL>
+__device__ __forceinline__ float pt_dpp(float v, float old = 0.f) {
+    return __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(__builtin_bit_cast(int, old), __builtin_bit_cast(int, v), CTRL, 0xF, 0xF, false));
+}
+__device__ __forceinline__ float pt_lane(float v, int l) {
+    return __builtin_bit_cast(float, __builtin_amdgcn_readlane(__builtin_bit_cast(int, v), l));
+}
+
 __device__ __forceinline__ float wave_sum(float v) {
-#pragma unroll
-    for (int off = 32; off > 0; off >>= 1) v += __shfl_xor(v, off, 64);
-    return v;
+    v += pt_dpp<0xB1>(v);                  // quad_perm [1,0,3,2]
+    v += pt_dpp<0x4E>(v);                  // quad_perm [2,3,0,1]
+    v += pt_dpp<0x141>(v);                 // row_half_mirror
+    v += pt_dpp<0x140>(v);                 // row_mirror
+    return ((pt_lane(v, 0) + pt_lane(v, 16)) + pt_lane(v, 32)) + pt_lane(v, 48);
 }
 
 __device__ __forceinline__ float wave_max(float v) {
-#pragma unroll
-    for (int off = 32; off > 0; off >>= 1) v = fmaxf(v, __shfl_xor(v, off, 64));
-    return v;
+    v = fmaxf(v, pt_dpp<0xB1>(v, v));
+    v = fmaxf(v, pt_dpp<0x4E>(v, v));
+    v = fmaxf(v, pt_dpp<0x141>(v, v));
+    v = fmaxf(v, pt_dpp<0x140>(v, v));
+    return fmaxf(fmaxf(pt_lane(v, 0), pt_lane(v, 16)), fmaxf(pt_lane(v, 32), pt_lane(v, 48)));
 }
 
 // Deterministic block-wide sum; `scratch` needs blockDim.x/64 floats of LDS.  Every thread gets the result.

@@ -24,6 +24,51 @@
 #define PT_ADJ_WAVES 8                     // waves per k_adj2 workgroup (16 measured no better at 18x18, worse at 22x22)
 #endif
 #define PT_ADJ_UMAX (128 / PT_ADJ_WAVES)   // 16-position groups per wave (all of a wave's loads are in flight at once)
+// experiment knobs (profiles/r03f_*): feature loads requested ahead of the MFMAs / register cap of k_corr2
+#ifndef PT_C2_CD
+#define PT_C2_CD 2       // round 3 sweep (profiles/r03l_*): 2 / 3 / 4 / 6 / 8 ahead -> 8.72 / 8.97 / 8.99 / 9.49 / 9.76 us
+#endif
+#ifndef PT_C2_MINW
+#define PT_C2_MINW 6
+#endif
+#ifndef PT_ADJ_PD
+#define PT_ADJ_PD 3      // round 3 sweep: 3 / 4 / 6 / 8 / 12 / 16 ahead -> 8.08 / 8.36 / 8.50 / 8.67 / 8.84 / 9.0 us
+#endif
+#ifndef PT_C2_BAR
+#define PT_C2_BAR 0      // 1: workgroup barrier between the filter-operand loads and the first feature loads
+#endif
+#ifndef PT_C2_R16
+#define PT_C2_R16 0      // 1: 16 channel ranges -- the two k-step halves of an XCD's range as separate 5-wave workgroups
+#endif
+#ifndef PT_ADJ_EARLY
+#define PT_ADJ_EARLY 1   // 1: first feature loads in front of the LDS work; 0: behind barrier 1
+#endif
+
+// Phase time stamps (experiments only, -DPT_STAMPS; tools/exp_stamps.py): every wave records the 100 MHz device wall clock at
+// up to 8 points into a buffer registered with pt_debug_set_stamps(); layout [workgroup][wave (16 slots)][8].
+#ifdef PT_STAMPS
+static unsigned long long* g_pt_stamps = nullptr;
+extern "C" void pt_debug_set_stamps(void* p) { g_pt_stamps = (unsigned long long*)p; }
+#define PT_STAMP_ARG unsigned long long* stamps;
+#define PT_STAMP_SET(a) (a).stamps = g_pt_stamps
+#define PT_STAMP(a, k)                                                                                       \
+    do {                                                                                                     \
+        if ((a).stamps && (threadIdx.x & 63) == 0)                                                           \
+            (a).stamps[((long)blockIdx.x * 16 + (threadIdx.x >> 6)) * 8 + (k)] = (unsigned long long)wall_clock64(); \
+    } while (0)
+#else
+#define PT_STAMP_ARG
+#define PT_STAMP_SET(a)
+#define PT_STAMP(a, k)
+#endif
+// second stamp set (-DPT_STAMPS=2): the k_adj2 prologue in detail; the coarse k_adj2 stamps are then off
+#if defined(PT_STAMPS) && PT_STAMPS == 2
+#define PT_STAMP_A(a, k)
+#define PT_STAMP_B(a, k) PT_STAMP(a, k)
+#else
+#define PT_STAMP_A(a, k) PT_STAMP(a, k)
+#define PT_STAMP_B(a, k)
+#endif
 
 // ---------------------------------------------------------------------------------------------------
 // geometry
@@ -47,6 +92,8 @@ PtFast pt_fast_plan(int n, int C, int H, int W, int KH, int KW, int OH, int OW) 
     // larger maps (22x22: 8 tiles) use one wave per tile with all of the XCD's k-steps
     p.nh = 2 * p.tiles <= 10 ? 2 : 1;
     p.CX = C / 8;
+    p.KSC = 8;
+    if (PT_C2_R16 && p.nh == 2 && n > 16) { p.nh = 1; p.CX = C / 16; p.KSC = 16; }
     p.NK = p.CX / 4 / p.nh;
     if (p.NK > 16) return p;
     p.HWp = 64 * (p.TF + (p.rem > 0 ? 1 : 0)) + 4;
@@ -87,11 +134,12 @@ __device__ __forceinline__ int fdiv(int v, float inv_d) { return (int)(((float)v
 // ---------------------------------------------------------------------------------------------------
 struct Corr2Args {
     const float* feat; long stride_n; const float* filt; float* spart;
-    int n, C, H, W, KH, KW, OH, OW, CX, TF, rem, tiles, HWp, nh;
+    int n, C, H, W, KH, KW, OH, OW, CX, TF, rem, tiles, HWp, nh, KSC;
     // fused gradient reduction (optimizer.py:146-148): filter operand = sum_k gpart[k] + reg*w
     const float* gpart; int KSPL; const float* w; float reg; float* g_out; float* anum_part;
     // source override: sample `slot` is read from `src` (C,H,W) and stored to copy_dst (the memory slot)
     int slot; const float* src; float* copy_dst;
+    PT_STAMP_ARG
 };
 
 // generic (slow) form of one filter-operand element; only used for slices larger than 4 elements per thread
@@ -118,15 +166,23 @@ __device__ __forceinline__ float corr2_filter_elem(const Corr2Args& a, int KK, i
 // FUSE = 0: filter operand read from `filt`.  FUSE = 8 / 16 / 32: operand = sum of <= FUSE gradient partials + reg*w
 // (optimizer.py:146-148), every load of the reduction issued before the first wait.
 // Two 10-wave workgroups per CU put up to 6 waves on one SIMD (3+3): <= 80 VGPRs for the common channel counts.
-template <int NK, bool LEFT, int FUSE>
-__global__ __launch_bounds__(1024, (NK <= 8 ? 6 : 4)) void k_corr2(Corr2Args a) {
+// K16: the filter has 16 taps (4x4, the trackers' size) -- a compile-time fact, so that the prologue is ONE basic block: with
+// the tap count as a run-time branch the compiler started the partial sum inside the branch and put `s_waitcnt vmcnt(8)`
+// -- a whole memory round trip -- in front of the first feature load (round 3, profiles/r03g_pass_phase_stamps.txt).
+// NH: k-step halves per tile (2 for 18x18 maps, 1 for 22x22) -- compile time as well: as a run-time value every tap of the
+// shift-and-add became `ds_read; branch; ds_read; s_waitcnt lgkmcnt(0)`, 16 serialised LDS round trips (0.9 us of the pass).
+template <int NK, bool LEFT, int FUSE, bool K16, int NH>
+__global__ __launch_bounds__(1024, (NK <= 8 ? PT_C2_MINW : 4)) void k_corr2(Corr2Args a) {
     extern __shared__ __attribute__((aligned(16))) float lds[];     // afilt[CX][16] | T[2][KK][HWp]
     __shared__ float scratch[16];
+    PT_STAMP(a, 0);
     constexpr int EPT = 2;
     constexpr int FP = FUSE > 0 ? FUSE : 1;
-    const int b = blockIdx.x, x = b & 7, i = b >> 3;
+    // KSC = 16: ranges 2x and 2x + 1 both run on XCD x (the adjoint pass owns channels [x C/8, (x+1) C/8) there)
+    const int b = blockIdx.x, xc = b & 7, q = b >> 3;
+    const int x = a.KSC == 16 ? 2 * xc + (q & 1) : xc, i = a.KSC == 16 ? q >> 1 : q;
     const int HW = a.H * a.W, KK = a.KH * a.KW;
-    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const int lane = threadIdx.x & 63, wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);   // wave-uniform: scalar branches
     const int kq = lane >> 4, j = lane & 15;
     const int h = wave >= a.tiles ? 1 : 0, t = wave - h * a.tiles;
     const int cx0 = a.CX * x;
@@ -139,7 +195,7 @@ __global__ __launch_bounds__(1024, (NK <= 8 ? 6 : 4)) void k_corr2(Corr2Args a) 
 
     // ---- filter operand: straight-line, clamped addresses, all loads in flight together.  With 16 taps the slice
     //      is one contiguous run of CX*16 floats: 16-byte loads, one per thread; otherwise up to EPT scalars.
-    const bool k16 = KK == 16;
+    constexpr bool k16 = K16;
     const int n4 = nsl >> 1;                                        // 8-byte pieces (keeps the register count low
     const int e4 = min((int)threadIdx.x, n4 - 1);                   //  enough for two workgroups per CU)
     f32x2 part4[FP], wv4 = {0, 0};
@@ -181,7 +237,7 @@ __global__ __launch_bounds__(1024, (NK <= 8 ? 6 : 4)) void k_corr2(Corr2Args a) 
     // ---- feature slice of this wave: NK float4 (+ NK scalars for the trailing quads).  A wave stalls at a load it
     //      cannot issue (the CU accepts ~45 B/clk), so only the first CD k-steps are requested before the filter is
     //      staged; the rest are issued CD k-steps ahead of the MFMAs that consume them.
-    constexpr int CD = NK < 4 ? NK : 4;    // 6 or 8 ahead: register spills under the 80-VGPR cap, 10.3 vs 10.15 us
+    constexpr int CD = NK < PT_C2_CD ? NK : PT_C2_CD;    // 6 or 8 ahead: register spills under the 80-VGPR cap, 10.3 vs 10.15 us
     const int cbase = cx0 + 4 * (h * NK) + kq;
     const int pos = 64 * t + 4 * j;
     const bool pv = pos < HW;
@@ -196,8 +252,16 @@ __global__ __launch_bounds__(1024, (NK <= 8 ? 6 : 4)) void k_corr2(Corr2Args a) 
         bq[k] = pt_bload4(fr, fo + (unsigned)(4 * k) * HW * 4u);
         if (LEFT && t == 0) bl[k] = pt_bload1(fr, lo + (unsigned)(4 * k) * HW * 4u);
     };
+    if (PT_C2_BAR) __syncthreads();
+    // the leftover-quad scalars first: the filter reduction below then waits for vmcnt(CD) on every wave -- the 16-byte loads stay
+    // in flight behind it -- instead of a count that fits the waves without the leftover tile
+    if (LEFT && t == 0) {
 #pragma unroll
-    for (int k = 0; k < CD; ++k) ldq(k);
+        for (int k = 0; k < CD; ++k) bl[k] = pt_bload1(fr, lo + (unsigned)(4 * k) * HW * 4u);
+    }
+#pragma unroll
+    for (int k = 0; k < CD; ++k) bq[k] = pt_bload4(fr, fo + (unsigned)(4 * k) * HW * 4u);
+    PT_STAMP(a, 1);
 
     // ---- reduce + publish the filter slice
     float gsq = 0.f;
@@ -245,7 +309,9 @@ __global__ __launch_bounds__(1024, (NK <= 8 ? 6 : 4)) void k_corr2(Corr2Args a) 
         const float tot = block_sum(gsq, scratch);
         if (threadIdx.x == 0) a.anum_part[x] = tot;
     }
+    PT_STAMP(a, 2);
     __syncthreads();
+    PT_STAMP(a, 3);
 
     f32x4 acc0 = {0, 0, 0, 0}, acc1 = {0, 0, 0, 0}, acc2 = {0, 0, 0, 0}, acc3 = {0, 0, 0, 0}, accL = {0, 0, 0, 0};
 #pragma unroll
@@ -258,6 +324,7 @@ __global__ __launch_bounds__(1024, (NK <= 8 ? 6 : 4)) void k_corr2(Corr2Args a) 
         acc3 = mfma16(av, bq[k][3], acc3);
         if (LEFT && t == 0) accL = mfma16(av, bl[k], accL);
     }
+    PT_STAMP(a, 4);
     // ---- memory insert rides on the pass (pytracking/tracker/dimp/dimp.py:429-441)
     if (over && a.copy_dst) {
         float* __restrict__ dp = a.copy_dst + pos + (long)cbase * HW;
@@ -281,7 +348,9 @@ __global__ __launch_bounds__(1024, (NK <= 8 ? 6 : 4)) void k_corr2(Corr2Args a) 
             if (LEFT && t == 0) Tl[row * a.HWp + lpos] = accL[r];  // j >= 4*rem: padding as well (lpos < HWp)
         }
     }
+    PT_STAMP(a, 5);
     __syncthreads();
+    PT_STAMP(a, 6);
 
     // ---- shift-and-add of the tap planes (both halves), fixed order
     const int ph = a.KH / 2, pw = a.KW / 2, OO = a.OH * a.OW;
@@ -301,7 +370,7 @@ __global__ __launch_bounds__(1024, (NK <= 8 ? 6 : 4)) void k_corr2(Corr2Args a) 
                     const int xx = xx0 + v - 2;
                     const bool ok = (unsigned)yy < (unsigned)a.H && (unsigned)xx < (unsigned)a.W;
                     const int idx = (u * 4 + v) * a.HWp + (ok ? yy * a.W + xx : 0);
-                    const float tsum = a.nh == 2 ? T0[idx] + T1[idx] : T0[idx];
+                    const float tsum = NH == 2 ? T0[idx] + T1[idx] : T0[idx];
                     tv[u * 4 + v] = ok ? tsum : 0.f;
                 }
             }
@@ -310,6 +379,7 @@ __global__ __launch_bounds__(1024, (NK <= 8 ? 6 : 4)) void k_corr2(Corr2Args a) 
             for (int q = 0; q < 16; ++q) s += tv[q];
             out[o] = s;
         }
+        PT_STAMP(a, 7);
         return;
     }
     for (int o = threadIdx.x; o < OO; o += blockDim.x) {
@@ -322,7 +392,7 @@ __global__ __launch_bounds__(1024, (NK <= 8 ? 6 : 4)) void k_corr2(Corr2Args a) 
                 const int xx = xx0 + v - pw;
                 if ((unsigned)xx < (unsigned)a.W) {
                     const int idx = (u * a.KW + v) * a.HWp + yy * a.W + xx;
-                    s += a.nh == 2 ? T0[idx] + T1[idx] : T0[idx];
+                    s += NH == 2 ? T0[idx] + T1[idx] : T0[idx];
                 }
             }
         }
@@ -335,20 +405,31 @@ int pt_launch_corr2(const PtFast& p, const float* feat, long stride_n, const flo
     Corr2Args a;
     a.feat = feat; a.stride_n = stride_n; a.filt = filt; a.spart = spart;
     a.n = p.n; a.C = p.C; a.H = p.H; a.W = p.W; a.KH = p.KH; a.KW = p.KW; a.OH = p.OH; a.OW = p.OW;
-    a.CX = p.CX; a.TF = p.TF; a.rem = p.rem; a.tiles = p.tiles; a.HWp = p.HWp; a.nh = p.nh;
+    a.CX = p.CX; a.TF = p.TF; a.rem = p.rem; a.tiles = p.tiles; a.HWp = p.HWp; a.nh = p.nh; a.KSC = p.KSC;
     a.gpart = nullptr; a.KSPL = 0; a.w = nullptr; a.reg = 0.f; a.g_out = nullptr; a.anum_part = nullptr;
     if (fuse) { a.gpart = fuse->gpart; a.KSPL = fuse->KSPL; a.w = fuse->w; a.reg = fuse->reg; a.g_out = fuse->g_out; a.anum_part = fuse->anum_part; }
     a.slot = slot; a.src = src; a.copy_dst = copy_dst;
+    PT_STAMP_SET(a);
     if (((uintptr_t)feat % 16) || (stride_n % 4) || ((uintptr_t)src % 16) || ((uintptr_t)copy_dst % 16)) return PT_ERR_UNSUPPORTED;
     if ((long)p.n * stride_n * 4 >= (1L << 31)) return PT_ERR_UNSUPPORTED;
     if (p.KK == 16 && (((uintptr_t)filt % 16) || ((uintptr_t)a.gpart % 16) || ((uintptr_t)a.w % 16) || ((uintptr_t)a.g_out % 16)))
         return PT_ERR_UNSUPPORTED;
-    dim3 grid(8 * p.n), block(p.corr_threads);
-#define PT_C2F(NKV, LF)                                                                                          \
+    dim3 grid(p.KSC * p.n), block(p.corr_threads);
+#define PT_C2G(NKV, LF, KF, NHV)                                                                                    \
     do {                                                                                                         \
-        if (!a.gpart) hipLaunchKernelGGL((k_corr2<NKV, LF, 0>), grid, block, p.corr_lds, st, a);                 \
-        else if (a.KSPL <= 8) hipLaunchKernelGGL((k_corr2<NKV, LF, 8>), grid, block, p.corr_lds, st, a);         \
-        else hipLaunchKernelGGL((k_corr2<NKV, LF, 16>), grid, block, p.corr_lds, st, a);                         \
+        if (!a.gpart) hipLaunchKernelGGL((k_corr2<NKV, LF, 0, KF, NHV>), grid, block, p.corr_lds, st, a);             \
+        else if (a.KSPL <= 8) hipLaunchKernelGGL((k_corr2<NKV, LF, 8, KF, NHV>), grid, block, p.corr_lds, st, a);     \
+        else hipLaunchKernelGGL((k_corr2<NKV, LF, 16, KF, NHV>), grid, block, p.corr_lds, st, a);                     \
+    } while (0)
+#define PT_C2H(NKV, LF, KF)              \
+    do {                                 \
+        if (p.nh == 2) PT_C2G(NKV, LF, KF, 2); \
+        else PT_C2G(NKV, LF, KF, 1);     \
+    } while (0)
+#define PT_C2F(NKV, LF)                  \
+    do {                                 \
+        if (p.KK == 16) PT_C2H(NKV, LF, true); \
+        else PT_C2H(NKV, LF, false);     \
     } while (0)
 #define PT_C2(NKV)                  \
     do {                            \
@@ -359,6 +440,8 @@ int pt_launch_corr2(const PtFast& p, const float* feat, long stride_n, const flo
     else if (p.NK == 4) PT_C2(4);
     else if (p.NK == 8) PT_C2(8);
     else PT_C2(16);
+#undef PT_C2G
+#undef PT_C2H
 #undef PT_C2F
 #undef PT_C2
     PT_CHECK_LAUNCH();
@@ -374,6 +457,7 @@ struct Adj2Args {
     const float* inp;        // V_PLAIN: residual maps (n, OH, OW)
     SdArgs sd;               // solver variants: solver state
     int t, want_loss;        //                  iterate index of the maps this launch builds
+    PT_STAMP_ARG
 };
 
 // residual-map providers of k_adj2
@@ -517,6 +601,8 @@ template <int V, int E, int UM>
 __global__ __launch_bounds__(PT_ADJ_WAVES * 64) void k_adj2(Adj2Args a) {
     extern __shared__ __attribute__((aligned(16))) float maps[];    // [ns_max][PH][PW] zero-padded residual maps, zn zeros, quad table
     __shared__ float red[PT_ADJ_WAVES][256];
+    PT_STAMP_A(a, 0);
+    PT_STAMP_B(a, 0);
     const int b = blockIdx.x, x = b & 7, rr = b >> 3;
     const int cb = a.bpx * x + rr % a.bpx, ks = rr / a.bpx;
     const int HW = a.H * a.W, KK = a.KH * a.KW, PHPW = a.PH * a.PW;
@@ -533,16 +619,64 @@ __global__ __launch_bounds__(PT_ADJ_WAVES * 64) void k_adj2(Adj2Args a) {
     // pixel (yy,xx) sits at (yy + oy, xx + ox)
     const int oy = a.KH - 1 - a.KH / 2, ox = a.KW - 1 - a.KW / 2;
 
-    for (int e = threadIdx.x; e < ns * PHPW; e += blockDim.x) maps[e] = 0.f;
-    for (int e = threadIdx.x; e < a.zn; e += blockDim.x) maps[ZB + e] = 0.f;
-
-    constexpr int PD = UM < 8 ? UM : (UM == 8 ? 8 : 6);
+    constexpr int PD = UM < 8 ? UM : (UM == 8 ? 8 : (PT_ADJ_PD < UM ? PT_ADJ_PD : UM));
     const int c = cb * 16 + j;
     const __amdgpu_buffer_rsrc_t fr = pt_rsrc(a.feat, (unsigned)(((long)(a.n - 1) * a.stride_n + (long)a.C * HW) * 4));
     const int uj = j / a.KW, vj = j - uj * a.KW;
     // lanes j >= K*K feed accumulator columns that are never stored: any in-range tap offset does
     const unsigned tapoff4 = j < KK ? 4u * (unsigned)((a.KH - 1 - uj) * a.PW + (a.KW - 1 - vj)) : 0u;
     const unsigned chw4 = 4u * (unsigned)c * (unsigned)HW;
+    const int Pm = 16 * gbeg < total ? 16 * gbeg : 0;
+    // where quad (k-quarter tk, wave tw, group tu) of this workgroup lives: sample, position inside the sample (a masked
+    // quad re-reads a line already fetched)
+    auto quad_at = [&](int tk, int tw, int tu, int& i, int& p0) {
+        const int g = gbeg + tw * a.U + tu;
+        const int P0 = 16 * g + 4 * tk;
+        const bool okk = tu < a.U && g < gend && P0 < total;
+        const int Pc = okk ? P0 : Pm + 4 * tk;
+        i = fdiv(Pc, inv_hw);
+        p0 = Pc - i * HW;
+        return okk;
+    };
+
+    // ---- Order of the prologue (round 3, profiles/r03g_pass_phase_stamps.txt: the first feature load used to leave 2.7 us
+    //      after the kernel started -- behind the table build, the update-stage loads and a `s_waitcnt vmcnt(0)` for alpha):
+    //      (1) the small, L2-resident inputs of the update stage are requested first: the memory counter retires in order, so
+    //          waiting for them later leaves the feature loads behind them in flight;
+    //      (2) the first PD feature loads go out with offsets computed directly (one division per group);
+    //      (3) only then the LDS work (zeroed maps, quad table) and the barrier; alpha and the update stage follow.
+    PReg<E> pr;
+    const bool have = wave < ns;
+    const int hg0 = ((i_lo + wave) * HW) >> 4;                      // the slice holding a sample's first group owns it
+    const bool home0 = have && cb == 0 && hg0 >= gbeg && hg0 < gend;
+    sdp_load<V, E>(a, i_lo + min(wave, ns - 1), lane, home0, pr);
+    const bool wupd = V != V_PLAIN && a.t > 0 && ks == 0;
+    const long wge = (long)cb * 16 * KK + min((int)threadIdx.x, 16 * KK - 1);
+    float w_prev = 0.f, g_prev = 0.f, an_in = 0.f;
+    SdQLane q_in = {0.f, 0.f};
+    if (V != V_PLAIN && a.t > 0) {                                  // optimizer.py:155-160 / :425-430
+        q_in = sd_q_lane(a.sd, lane);
+        an_in = lane < a.sd.KS ? a.sd.anum[lane] : 0.f;
+        if (wupd) {                                                 // uniform per workgroup
+            w_prev = sd_w(a.sd, a.t - 1)[wge];
+            g_prev = a.sd.g[wge];
+        }
+    }
+    PT_STAMP_B(a, 1);
+    f32x4 av[UM];
+    if (PT_ADJ_EARLY) {
+#pragma unroll
+        for (int u = 0; u < PD; ++u) {
+            int qi, qp;
+            quad_at(kq, wave, u, qi, qp);
+            av[u] = pt_bload4(fr, ((unsigned)qi * (unsigned)a.stride_n + (unsigned)qp) * 4u + chw4);
+        }
+    }
+
+    PT_STAMP_B(a, 2);
+    for (int e = threadIdx.x; e < ns * PHPW; e += blockDim.x) maps[e] = 0.f;
+    for (int e = threadIdx.x; e < a.zn; e += blockDim.x) maps[ZB + e] = 0.f;
+    PT_STAMP_B(a, 3);
     // Where a quad of positions lives does not depend on the channel or the tap: the workgroup computes it once per quad
     // (sample, feature offset, the 4 residual-map cells incl. the row wrap inside the quad) into an LDS table instead of
     // every lane redoing two divisions and the wrap selects per group -- the pass is bound by VALU issue, not by memory
@@ -552,14 +686,10 @@ __global__ __launch_bounds__(PT_ADJ_WAVES * 64) void k_adj2(Adj2Args a) {
     //                       re-reads a line already fetched and points at the zero block behind the maps.
     int* __restrict__ tabA = (int*)(maps + ZB + a.zn);
     int* __restrict__ tabI = tabA + 4 * PT_ADJ_WAVES * UM;
-    const int Pm = 16 * gbeg < total ? 16 * gbeg : 0;
     for (int e = threadIdx.x; e < 4 * PT_ADJ_WAVES * UM; e += blockDim.x) {
         const int tu = e % UM, tw = (e / UM) % PT_ADJ_WAVES, tk = e / (UM * PT_ADJ_WAVES);
-        const int g = gbeg + tw * a.U + tu;
-        const int P0 = 16 * g + 4 * tk;
-        const bool okk = tu < a.U && g < gend && P0 < total;
-        const int Pc = okk ? P0 : Pm + 4 * tk;
-        const int i = fdiv(Pc, inv_hw), p0 = Pc - i * HW;
+        int i, p0;
+        const bool okk = quad_at(tk, tw, tu, i, p0);
         tabA[e] = (int)(((unsigned)i * (unsigned)a.stride_n + (unsigned)p0) * 4u);
         const int y0 = fdiv(p0, inv_w), x0 = p0 - y0 * a.W;
         // a quad may wrap to the next feature row: one row further in the padded map is PW - W cells more
@@ -567,34 +697,12 @@ __global__ __launch_bounds__(PT_ADJ_WAVES * 64) void k_adj2(Adj2Args a) {
 #pragma unroll
         for (int k = 0; k < 4; ++k) tabI[4 * e + k] = 4 * (okk ? base + k + (x0 + k >= a.W ? wr : 0) : ZB);
     }
-
-    // ---- update stage: its inputs are small and L2/MALL resident, and the MFMA chain cannot start before the residual
-    //      maps exist.  The quad table above does not depend on it, so the first PD feature loads are issued in front of
-    //      it (after the barrier that publishes the table) and fly while the stage waits for its own inputs.
-    PReg<E> pr;
-    const bool have = wave < ns;
-    const int hg0 = ((i_lo + wave) * HW) >> 4;                      // the slice holding a sample's first group owns it
-    const bool home0 = have && cb == 0 && hg0 >= gbeg && hg0 < gend;
-    sdp_load<V, E>(a, i_lo + min(wave, ns - 1), lane, home0, pr);
-    float astep = 0.f;
-    const bool wupd = V != V_PLAIN && a.t > 0 && ks == 0;
-    const long wge = (long)cb * 16 * KK + min((int)threadIdx.x, 16 * KK - 1);
-    if (V != V_PLAIN && a.t > 0) {                                  // optimizer.py:155-160 / :425-430
-        float w_prev = 0.f, g_prev = 0.f;
-        const float q_in = sd_q_lane(a.sd, lane);
-        const float an_in = lane < a.sd.KS ? a.sd.anum[lane] : 0.f;
-        if (wupd) {                                                 // uniform per workgroup
-            w_prev = sd_w(a.sd, a.t - 1)[wge];
-            g_prev = a.sd.g[wge];
-        }
-        const float a_num = wave_sum(an_in);
-        const float den = fmaxf(wave_sum(q_in) + (a.sd.reg + a.sd.alpha_eps) * a_num, 1e-8f);
-        astep = a.sd.step * (a_num / den);
-        if (wupd && (int)threadIdx.x < 16 * KK)                     // w_t = w_{t-1} - step*alpha*g   (:160)
-            a.sd.w_iters[(long)a.t * a.sd.CKK + wge] = w_prev - astep * g_prev;
-    }
+    PT_STAMP_A(a, 1);
+    PT_STAMP_B(a, 4);
     __syncthreads();                                                // maps zeroed, quad table written
-    // the first feature loads go out now: they fly while the update stage below waits for its own (small) inputs
+    PT_STAMP_A(a, 2);
+    PT_STAMP_B(a, 5);
+
     const int tq = (kq * PT_ADJ_WAVES + wave) * UM;
     int foff[UM];
 #pragma unroll
@@ -603,7 +711,6 @@ __global__ __launch_bounds__(PT_ADJ_WAVES * 64) void k_adj2(Adj2Args a) {
 #pragma unroll
         for (int k = 0; k < 4; ++k) foff[u + k] = v[k];
     }
-    f32x4 av[UM];
     float bv[UM][4];
     i32x4 cell[UM];
     auto issue = [&](int u) { av[u] = pt_bload4(fr, (unsigned)foff[u] + chw4); };
@@ -612,8 +719,18 @@ __global__ __launch_bounds__(PT_ADJ_WAVES * 64) void k_adj2(Adj2Args a) {
 #pragma unroll
         for (int k = 0; k < 4; ++k) bv[u][k] = *(const float*)((const char*)maps + ((unsigned)cell[u][k] + tapoff4));
     };
+    if (!PT_ADJ_EARLY) {
 #pragma unroll
-    for (int u = 0; u < PD; ++u) issue(u);
+        for (int u = 0; u < PD; ++u) issue(u);
+    }
+    float astep = 0.f;
+    if (V != V_PLAIN && a.t > 0) {
+        const float a_num = wave_sum(an_in);
+        const float den = fmaxf(wave_sum(q_in.head + q_in.tail) + (a.sd.reg + a.sd.alpha_eps) * a_num, 1e-8f);
+        astep = a.sd.step * (a_num / den);
+        if (wupd && (int)threadIdx.x < 16 * KK)                     // w_t = w_{t-1} - step*alpha*g   (:160)
+            a.sd.w_iters[(long)a.t * a.sd.CKK + wge] = w_prev - astep * g_prev;
+    }
     if (have) sdp_compute<V, E>(a, i_lo + wave, lane, pr, astep, maps + wave * PHPW, oy, ox, home0);
     for (int sl = wave + PT_ADJ_WAVES; sl < ns; sl += PT_ADJ_WAVES) {   // more samples than waves (tiny maps)
         const int i = i_lo + sl;
@@ -622,7 +739,10 @@ __global__ __launch_bounds__(PT_ADJ_WAVES * 64) void k_adj2(Adj2Args a) {
         sdp_load<V, E>(a, i, lane, home, pr);
         sdp_compute<V, E>(a, i, lane, pr, astep, maps + sl * PHPW, oy, ox, home);
     }
+    PT_STAMP_A(a, 3);
+    PT_STAMP_B(a, 6);
     __syncthreads();
+    PT_STAMP_A(a, 4);
 
     // ---- G[c][tap] += feat[c][P] * r[P shifted by tap] over the U contiguous 16-position groups of this wave.
     //      A wave stalls at a load it cannot issue (the CU's memory pipeline accepts ~20-45 B/clk), so the loads are
@@ -642,9 +762,11 @@ __global__ __launch_bounds__(PT_ADJ_WAVES * 64) void k_adj2(Adj2Args a) {
         accA = mfma16(av[u][2], bv[u][2], accA);
         accB = mfma16(av[u][3], bv[u][3], accB);
     }
+    PT_STAMP_A(a, 5);
 #pragma unroll
     for (int r = 0; r < 4; ++r) red[wave][(4 * kq + r) * 16 + j] = accA[r] + accB[r];
     __syncthreads();
+    PT_STAMP_A(a, 6);
     if (threadIdx.x < 256) {
         const int e = threadIdx.x, row = e >> 4, tap = e & 15;
         float s = 0.f;
@@ -652,6 +774,8 @@ __global__ __launch_bounds__(PT_ADJ_WAVES * 64) void k_adj2(Adj2Args a) {
         for (int w = 0; w < PT_ADJ_WAVES; ++w) s += red[w][e];
         if (tap < KK) a.gpart[(long)ks * a.C * KK + (long)(cb * 16 + row) * KK + tap] = s;
     }
+    PT_STAMP_A(a, 7);
+    PT_STAMP_B(a, 7);
 }
 
 static void adj2_fill(const PtFast& p, Adj2Args& a, const float* feat, long stride_n, float* gpart) {
@@ -659,6 +783,7 @@ static void adj2_fill(const PtFast& p, Adj2Args& a, const float* feat, long stri
     a.n = p.n; a.C = p.C; a.H = p.H; a.W = p.W; a.KH = p.KH; a.KW = p.KW; a.OH = p.OH; a.OW = p.OW;
     a.NG = p.NG; a.gper = p.gper; a.U = p.U; a.bpx = p.bpx; a.PH = p.PH; a.PW = p.PW; a.ns_max = p.ns_max; a.zn = p.zn;
     a.inp = nullptr; a.t = 0; a.want_loss = 0;
+    PT_STAMP_SET(a);
 }
 
 template <int V>

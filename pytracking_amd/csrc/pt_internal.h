@@ -52,7 +52,8 @@ int pt_launch_build_R(const PtPlan& p, const float* inp, float* R, hipStream_t s
 struct PtFast {
     int ok;
     int n, C, H, W, KH, KW, OH, OW, HW, KK, OO, Q;
-    int CX, NK, TF, rem, tiles, left, HWp, corr_threads, nh;   // corr2: grid 8*n, waves = 2 halves x tiles
+    int CX, NK, TF, rem, tiles, left, HWp, corr_threads, nh;   // corr2: grid KSC*n, waves = nh halves x tiles
+    int KSC;                                                    // channel ranges = partial score maps per sample: 8 (one per XCD) or 16
     size_t corr_lds;
     int CB, bpx, NG, KSPL, gper, U, PH, PW, ns_max, E, zn; // adj2: grid CB*KSPL, 8 waves x U contiguous groups; zero block
     size_t adj_lds;
@@ -66,7 +67,7 @@ static inline bool pt_fast_usable(const PtFast& f, const void* feat, long stride
     return f.ok && ((uintptr_t)feat % 16) == 0 && (stride_n % 4) == 0 && (long)f.n * stride_n * 4 < (1L << 31) &&
            ((uintptr_t)src % 16) == 0 && (f.KK != 16 || ((uintptr_t)filt % 16) == 0);
 }
-static inline size_t pt_fast_spart_floats(const PtFast& p) { return (size_t)8 * p.n * p.OO; }
+static inline size_t pt_fast_spart_floats(const PtFast& p) { return (size_t)16 * p.n * p.OO; }   // room for KSC = 16
 static inline size_t pt_fast_gpart_floats(const PtFast& p) { return (size_t)p.KSPL * p.C * p.KK; }
 // spart[x][i][OH*OW], x = XCD channel range (8 slices).  `slot`/`src`/`copy_dst`: sample `slot` is read from `src`
 // and stored to `copy_dst` while it streams (src == nullptr: no override).

@@ -185,12 +185,16 @@ __device__ __forceinline__ void act_pair(int score_act, float bpar, float x, flo
 }
 
 
-// this lane's share of sum_i q_i (samples lane, lane + 64, ...), fixed order
-__device__ __forceinline__ float sd_q_lane(const SdArgs& a, int lane) {
-    float acc = 0.f;
+// this lane's share of sum_i q_i (samples lane, lane + 64, ...), fixed order: head (sample `lane`, ONE predicated load that
+// nothing waits for here -- the k_adj2 prologue keeps it in flight behind its feature loads) + tail (samples lane + 64, ...;
+// only memories of more than 64 samples enter the loop).  Callers add head + tail.
+struct SdQLane { float head, tail; };
+__device__ __forceinline__ SdQLane sd_q_lane(const SdArgs& a, int lane) {
+    SdQLane r = {0.f, 0.f};
     if (a.QB == 0) {
-        for (int k = lane; k < a.n; k += 64) acc += a.qs[k];
-        return acc;
+        r.head = lane < a.n ? a.qs[lane] : 0.f;
+        for (int k = lane + 64; k < a.n; k += 64) r.tail += a.qs[k];
+        return r;
     }
     for (int k = lane; k < a.n; k += 64) {
         const float* q = a.qs + (long)k * a.QB * 2;
@@ -198,18 +202,19 @@ __device__ __forceinline__ float sd_q_lane(const SdArgs& a, int lane) {
         for (int b = 0; b < a.QB; ++b) { A += q[2 * b]; B += q[2 * b + 1]; }
         if (a.kind == PT_SD_PRDIMP) {
             const float swp = a.has_sw ? a.sw[k] : 1.0f / (float)a.n;
-            acc += swp * fmaxf(A - B * B, 0.f);                                     // optimizer.py:419-422
+            r.tail += swp * fmaxf(A - B * B, 0.f);                                  // optimizer.py:419-422
         } else {
-            acc += A;
+            r.tail += A;
         }
     }
-    return acc;
+    return r;
 }
 
 // optimizer.py:155-160 / :425-430: alpha = |g|^2 / max(sum_i q_i + (reg+eps)|g|^2, 1e-8), times the step length;
 // from one wave (every lane gets it): wave-parallel fixed-order sums, identical in every workgroup.
 __device__ __forceinline__ float sd_alpha_step_wave(const SdArgs& a, int lane) {
-    float den = wave_sum(sd_q_lane(a, lane));
+    const SdQLane ql = sd_q_lane(a, lane);
+    float den = wave_sum(ql.head + ql.tail);
     const float a_num = wave_sum(lane < a.KS ? a.anum[lane] : 0.f);
     den = fmaxf(den + (a.reg + a.alpha_eps) * a_num, 1e-8f);
     return a.step * (a_num / den);

@@ -304,6 +304,198 @@ __global__ __launch_bounds__(512) void k_fast_sgq(SdArgs a) {
     }
 }
 
+// ----------------------------------------------------------------------------------------------------
+// Pointwise stages of the fast path, one memory round trip each (round 3).  The first versions above (kept for the band
+// path and as the reference of the parity tests' history) read their operands where the reference's statements use them: the
+// compiler must keep a load behind every earlier store that may alias it, so k_fast_sgq was three dependent round trips
+// (slices -> s, mask -> label, sws) and k_fast_init five.  Here every operand of an element is requested before the first
+// wait, values stay in registers between the steps, and all stores come last; one element per thread (blockDim >= OO).
+// ----------------------------------------------------------------------------------------------------
+#define PT_PW_MAXKS 16
+// sum of the KS (<= 16) channel-range partials of element (i, o): all loads in flight together, fixed summation order
+__device__ __forceinline__ void pw_load_slices(const SdArgs& a, int i, int oc, float (&v)[PT_PW_MAXKS]) {
+    const float* p = a.spart + (long)i * a.OO + oc;
+    const long st = (long)a.n * a.OO;
+#pragma unroll
+    for (int k = 0; k < PT_PW_MAXKS; ++k) v[k] = p[(long)min(k, a.KS - 1) * st];
+}
+__device__ __forceinline__ float pw_sum_slices(const SdArgs& a, const float (&v)[PT_PW_MAXKS]) {
+    float s = 0.f;
+#pragma unroll
+    for (int k = 0; k < PT_PW_MAXKS; ++k) s += k < a.KS ? v[k] : 0.f;
+    return s;
+}
+
+// F g = sum of the slices; per-sample curvature term (optimizer.py:151-156 / :416-422); packed operands for k_adj2
+__global__ __launch_bounds__(1024) void k_fast_sgq2(SdArgs a) {
+    extern __shared__ __attribute__((aligned(16))) float lds[];
+    __shared__ float scratch[16];
+    const int i = blockIdx.x, o = threadIdx.x;
+    const bool ok = o < a.OO;
+    const int oc = min(o, a.OO - 1);
+    const long q = (long)i * a.OO + oc;
+    float v[PT_PW_MAXKS];
+    pw_load_slices(a, i, oc, v);
+    const float sv = a.s[q];
+    if (a.kind != PT_SD_PRDIMP) {
+        const f32x4 lm = ((const f32x4*)a.lms)[q];                                  // {label, mask, sws, -}
+        const float sgv = pw_sum_slices(a, v);
+        const int sact = a.kind == PT_SD_DIMP_L2 ? 2 : a.score_act;
+        float act, der;
+        act_pair(sact, a.act_param, sv, lm[1], act, der);
+        const float qq = lm[2] * (der * sgv);                                       // :151-152
+        const float tot = block_sum(ok ? qq * qq : 0.f, scratch);
+        if (ok) {
+            a.sg[q] = sgv;
+            f32x4 pk;
+            if (a.kind == PT_SD_DIMP && a.score_act == PT_ACT_BENTPAR) pk = (f32x4){sv, sgv, lm[0], lm[1]};
+            else { const float w2 = lm[2] * lm[2]; pk = (f32x4){w2 * sv, w2 * sgv, w2 * lm[0], lm[1]}; }
+            ((f32x4*)a.pk)[q] = pk;
+        }
+        if (o == 0) a.qs[i] = tot;
+    } else {
+        const float P = a.mask[q], L = a.label[q];
+        const float swp = a.has_sw ? a.sw[i] : 1.0f / (float)a.n;
+        const float sgv = pw_sum_slices(a, v);
+        const float tot = block_sum(ok ? P * sgv : 0.f, scratch);                   // :419
+        const float ghg = block_sum(ok ? sgv * (P * sgv - P * tot) : 0.f, scratch); // :420
+        if (ok) {
+            a.sg[q] = sgv;
+            ((f32x4*)a.pk)[q] = (f32x4){sv, sgv, L, 0.f};
+        }
+        if (o == 0) a.qs[i] = swp * fmaxf(ghg, 0.f);                                // :421-422
+    }
+}
+
+// s_0 = sum of the slices; classification epilogue of the inserted slot (its score row IS s_0 of that sample);
+// label / mask / weight maps (optimizer.py:111-125, 201-208, 331-353); packed operands for k_adj2
+__global__ __launch_bounds__(1024) void k_fast_init2(SdArgs a) {
+    extern __shared__ __attribute__((aligned(16))) float lut[];    // DiMP: label | mask | spatial look-up tables
+    __shared__ float scratch[16];
+    __shared__ float bv[16];
+    __shared__ int bi[16];
+    __shared__ float bbs[4];
+    const int i = blockIdx.x, o = threadIdx.x;
+    const bool ok = o < a.OO;
+    const int oc = min(o, a.OO - 1);
+    const long q = (long)i * a.OO + oc;
+    // ---- everything this element needs, requested at once
+    float v[PT_PW_MAXKS];
+    pw_load_slices(a, i, oc, v);
+    const float* bp = a.bb + 4 * i;
+    float b0 = bp[0], b1 = bp[1], b2 = bp[2], b3 = bp[3];
+    const float swv = a.has_sw ? a.sw[i] : 1.0f / (float)a.n;
+    if (a.kind == PT_SD_DIMP) {
+        for (int e = o; e < 3 * a.num_bins; e += blockDim.x) {
+            const int t = e / a.num_bins, k = e - t * a.num_bins;
+            lut[e] = (t == 0 ? a.label_lut : (t == 1 ? a.mask_lut : a.spatial_lut))[k];
+        }
+    }
+    const float s0 = pw_sum_slices(a, v);
+    // ---- classification of the test frame (pytracking/libs/dcf.py:156-164: first maximum) re-centres this sample's box
+    const bool cls = a.cls_spart != nullptr && i == a.cls_slot;     // uniform per workgroup
+    if (cls) {
+        float best = ok ? s0 : -INFINITY;
+        int besti = ok ? o : 0x7fffffff;
+#pragma unroll
+        for (int off = 32; off > 0; off >>= 1) {
+            const float ov = __shfl_xor(best, off, 64);
+            const int oi = __shfl_xor(besti, off, 64);
+            if (ov > best || (ov == best && oi < besti)) { best = ov; besti = oi; }
+        }
+        const int lane = o & 63, wave = o >> 6, nw = (blockDim.x + 63) >> 6;
+        if (lane == 0) { bv[wave] = best; bi[wave] = besti; }
+        __syncthreads();
+        if (o == 0) {
+            for (int w = 1; w < nw; ++w)
+                if (bv[w] > best || (bv[w] == best && bi[w] < besti)) { best = bv[w]; besti = bi[w]; }
+            const int row = besti / a.OW, col = besti - row * a.OW;
+            const float off = (float)(a.K % 2) * 0.5f;
+            bbs[0] = ((float)col + off) * a.feat_stride - b2 * 0.5f;
+            bbs[1] = ((float)row + off) * a.feat_stride - b3 * 0.5f;
+            a.cls_peak[0] = (float)row;
+            a.cls_peak[1] = (float)col;
+            a.cls_bb[4 * a.cls_slot] = bbs[0];
+            a.cls_bb[4 * a.cls_slot + 1] = bbs[1];
+        }
+        __syncthreads();
+        b0 = bbs[0];
+        b1 = bbs[1];
+        if (ok) a.cls_scores[o] = s0;
+    } else {
+        __syncthreads();                                            // look-up tables staged
+    }
+    // ---- maps
+    const float off = (float)(a.K % 2) * 0.5f;
+    const float ctr_r = (b1 + b3 * 0.5f) / a.feat_stride - off;     // optimizer.py:112-113 (flip -> row first)
+    const float ctr_c = (b0 + b2 * 0.5f) / a.feat_stride - off;
+    const int y = oc / a.OW, x = oc - y * a.OW;
+    const float d0 = (float)y - ctr_r, d1 = (float)x - ctr_c;
+    float lb, m = 0.f, sw = 0.f;
+    if (a.kind == PT_SD_DIMP) {
+        const float t = sqrtf(d0 * d0 + d1 * d1) / a.bin_disp;
+        lb = pl_lut(lut, a.num_bins, t);
+        m = pl_lut(lut + a.num_bins, a.num_bins, t);
+        if (a.mask_act == PT_MASK_SIGMOID) m = 1.0f / (1.0f + expf(-m));
+        sw = sqrtf(swv) * pl_lut(lut + 2 * a.num_bins, a.num_bins, t);             // :122-125
+    } else if (a.kind == PT_SD_DIMP_L2) {
+        const float coef = -1.0f / (2.0f * a.gauss_sigma * a.gauss_sigma);
+        const float gss = expf(coef * d0 * d0) * expf(coef * d1 * d1);              // :201-208
+        m = gss > a.hinge_thr ? 1.0f : 0.0f;                                        // :245
+        lb = gss * m;
+        sw = sqrtf(swv);                                                            // :249-252
+    } else {                                                                        // PrDiMP label density, :331-353
+        float gss;
+        if (a.gauss_sigma == 0.f) {
+            // one-hot at the grid point closest to the centre (first minimum per axis, as the reference's argmin)
+            int r0 = 0, c0 = 0;
+            float m0 = INFINITY, m1 = INFINITY;
+            for (int yy = 0; yy < a.OH; ++yy) { float d = ((float)yy - ctr_r); d *= d; if (d < m0) { m0 = d; r0 = yy; } }
+            for (int xx = 0; xx < a.OW; ++xx) { float d = ((float)xx - ctr_c); d *= d; if (d < m1) { m1 = d; c0 = xx; } }
+            gss = (y == r0 && x == c0) ? 1.0f : 0.0f;
+        } else {
+            const float s2 = a.gauss_sigma * a.gauss_sigma, coef = -1.0f / (2.0f * s2);
+            gss = (expf(coef * d0 * d0) / (2.0f * 3.14159265358979323846f * s2)) * expf(coef * d1 * d1);
+        }
+        gss = gss > a.label_thr ? gss : 0.f;
+        const float tot = block_sum(ok ? gss : 0.f, scratch);
+        const float inv = a.normalize_label ? 1.0f / (tot + 1e-8f) : 1.0f;
+        const float uni = a.uni_weight / (float)a.OO;
+        lb = (1.0f - a.label_shrink) * ((1.0f - a.uni_weight) * (gss * inv) + uni);
+    }
+    // ---- stores
+    if (!ok) return;
+    a.s[q] = s0;
+    a.label[q] = lb;
+    f32x4 pk;
+    if (a.kind == PT_SD_PRDIMP) {
+        pk = (f32x4){s0, 0.f, lb, 0.f};
+    } else {
+        a.mask[q] = m;
+        a.sws[q] = sw;
+        ((f32x4*)a.lms)[q] = (f32x4){lb, m, sw, 0.f};
+        if (a.kind == PT_SD_DIMP && a.score_act == PT_ACT_BENTPAR) pk = (f32x4){s0, 0.f, lb, m};
+        else { const float w2 = sw * sw; pk = (f32x4){w2 * s0, w2 * 0.f, w2 * lb, m}; }
+    }
+    ((f32x4*)a.pk)[q] = pk;
+}
+
+// the last filter update of a solve, w_T = w_{T-1} - step*alpha*g (optimizer.py:160): its operands are requested together with the
+// inputs of alpha; n workgroups, each a slice of the filter
+__global__ __launch_bounds__(512) void k_fast_final(SdArgs a, int t) {
+    const int i = blockIdx.x, lane = threadIdx.x & 63;
+    const int chunk = (a.CKK + a.n - 1) / a.n;
+    const float* wp = sd_w(a, t - 1);
+    float* wn = a.w_final ? a.w_final : a.w_iters + (long)t * a.CKK;
+    const int e = i * chunk + threadIdx.x;
+    const bool ok = (int)threadIdx.x < chunk && e < a.CKK;
+    const int ec = ok ? e : 0;
+    const float wv = wp[ec], gv = a.g[ec];
+    const float astep = sd_alpha_step_wave(a, lane);
+    if (ok) wn[e] = wv - astep * gv;
+    for (int e2 = e + blockDim.x; e2 < min(a.CKK, (i + 1) * chunk); e2 += blockDim.x) wn[e2] = wp[e2] - astep * a.g[e2];
+}
+
 #define PT_SD_MAX_ITER 64
 
 extern "C" size_t pt_sd_ws_bytes(int n, int C, int H, int W, int K) {
@@ -339,7 +531,7 @@ static int sd_fast_setup(const PtFast& f, const pt_sd_params* prm, const float* 
     if (ws_bytes < cv.total * sizeof(float) || ((uintptr_t)ws % 256) != 0) return PT_ERR_WORKSPACE;
     float* base = (float*)ws;
     sd_fill_params(a, prm, bb, sample_weight, f.n, f.C, f.H, f.W, f.KH, f.OH, f.OW);
-    a.KS = 8; a.KSPL = f.KSPL; a.QB = 0;
+    a.KS = f.KSC; a.KSPL = f.KSPL; a.QB = 0;
     a.label = base + cv.label; a.mask = base + cv.mask; a.sws = base + cv.sws; a.sg = base + cv.sg;
     a.lms = base + cv.lms; a.pk = base + cv.pk;
     a.spart = base + cv.spart; a.gpart = base + cv.gpart; a.g = base + cv.g; a.anum = base + cv.anum;
@@ -379,7 +571,11 @@ static int sd_solve_fast(const PtFast& f, const pt_sd_params* prm, const float* 
     if (band) rc = pt_launch_corr3(f, bp, feat, stride_n, w_in, a.spart, st, nullptr, nullptr, src ? slot : -1, src, copy_dst);
     else rc = pt_launch_corr2(f, feat, stride_n, w_in, a.spart, st, nullptr, src ? slot : -1, src, copy_dst);
     if (rc) return rc;
-    hipLaunchKernelGGL(k_fast_init, dim3(n), dim3(384), 0, st, a);
+    const int pw_threads = ((a.OO + 63) / 64) * 64;                 // one element per thread (OO <= 1024 on this path)
+    const size_t lut_lds = a.kind == PT_SD_DIMP ? (size_t)3 * a.num_bins * sizeof(float) : 0;
+    const bool pw2 = !band && a.KS <= PT_PW_MAXKS && lut_lds <= 48 * 1024;
+    if (pw2) hipLaunchKernelGGL(k_fast_init2, dim3(n), dim3(pw_threads), lut_lds, st, a);
+    else hipLaunchKernelGGL(k_fast_init, dim3(n), dim3(384), 0, st, a);
     PT_CHECK_LAUNCH();
     if (num_iter == 0) {
         if (!want_loss) return PT_OK;
@@ -400,11 +596,13 @@ static int sd_solve_fast(const PtFast& f, const pt_sd_params* prm, const float* 
         }
         rc = pt_launch_corr2(f, feat, stride_n, nullptr, a.spart, st, &fz);    // g_t, |g_t|^2, F g_t
         if (rc) return rc;
-        hipLaunchKernelGGL(k_fast_sgq, dim3(n), dim3(384), pw_lds, st, a);
+        if (pw2) hipLaunchKernelGGL(k_fast_sgq2, dim3(n), dim3(pw_threads), 0, st, a);
+        else hipLaunchKernelGGL(k_fast_sgq, dim3(n), dim3(384), pw_lds, st, a);
         PT_CHECK_LAUNCH();
     }
     if (num_iter > 0) {
-        hipLaunchKernelGGL(k_sd_pw, dim3(n), dim3(512), pw_lds, st, a, (int)PW_UPDATE, num_iter, 1, want_loss);
+        if (!want_loss && !band) hipLaunchKernelGGL(k_fast_final, dim3(n), dim3(512), 0, st, a, num_iter);
+        else hipLaunchKernelGGL(k_sd_pw, dim3(n), dim3(512), pw_lds, st, a, (int)PW_UPDATE, num_iter, 1, want_loss);
         PT_CHECK_LAUNCH();
     }
     if (want_loss) {

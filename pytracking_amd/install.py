@@ -385,14 +385,15 @@ def _install_preprocessing(orig, strict):
     """`sample_patch` / `sample_patch_multiscale` (pytracking/features/preprocessing.py:33-148): for an image tensor that
     lives on the device, crop + replicate padding + bilinear resize become one gather launch.  The reference trackers
     build the image with `numpy_to_torch` on the CPU, so this route is taken when the caller uploads the frame first;
-    CPU images, masks and the first-frame augmentation set keep the reference's functions."""
+    CPU images and masks keep the reference's functions; the first-frame augmentation set (`sample_patch_transformed`) runs on
+    the device for the transforms pytracking_amd/preprocessing.py covers and falls back to the reference for the rest."""
     from . import preprocessing as _pp
     try:
         pmod = importlib.import_module("pytracking.features.preprocessing")
     except Exception:
         return
-    ref_sp, ref_ms = pmod.sample_patch, pmod.sample_patch_multiscale
-    orig["preprocessing"] = {"functions": (ref_sp, ref_ms), "importers": []}
+    ref_sp, ref_ms, ref_tr = pmod.sample_patch, pmod.sample_patch_multiscale, pmod.sample_patch_transformed
+    orig["preprocessing"] = {"functions": (ref_sp, ref_ms, ref_tr), "importers": []}
 
     def sample_patch(im, pos, sample_sz, output_sz=None, mode='replicate', max_scale_change=None, is_mask=False):
         if im.is_cuda and im.dtype == torch.float32 and not is_mask and im.dim() == 4 and im.shape[0] == 1:
@@ -409,9 +410,22 @@ def _install_preprocessing(orig, strict):
             raise NotImplementedError("sample_patch_multiscale: call outside the gfx950 hot path")
         return ref_ms(im, pos, scales, image_sz, mode=mode, max_scale_change=max_scale_change)
 
-    for fn, ref in ((sample_patch, ref_sp), (sample_patch_multiscale, ref_ms)):
+    def sample_patch_transformed(im, pos, scale, image_sz, transforms, is_mask=False):
+        # first-frame augmentation set (generate_init_samples, dimp.py:329-395): one gather launch over the base patch
+        if im.is_cuda and im.dtype == torch.float32 and not is_mask and im.dim() == 4 and im.shape[0] == 1:
+            try:
+                return _pp.sample_patch_transformed(im, pos, scale, image_sz, transforms)
+            except NotImplementedError:                       # a transform the device path does not cover (RandomAffine, ...)
+                if strict:
+                    raise
+        elif strict and im.is_cuda:
+            raise NotImplementedError("sample_patch_transformed: call outside the gfx950 hot path")
+        return ref_tr(im, pos, scale, image_sz, transforms, is_mask=is_mask)
+
+    for fn, ref in ((sample_patch, ref_sp), (sample_patch_multiscale, ref_ms), (sample_patch_transformed, ref_tr)):
         fn.__doc__, fn.__wrapped__ = ref.__doc__, ref
     pmod.sample_patch, pmod.sample_patch_multiscale = sample_patch, sample_patch_multiscale
+    pmod.sample_patch_transformed = sample_patch_transformed
     # the trackers import the names (`from pytracking.features.preprocessing import sample_patch_multiscale, ...`)
     # ... and ATOM reaches them through its feature extractors (`pytracking/features/extractor.py:3,112`)
     for modname in ("pytracking.tracker.dimp.dimp", "pytracking.tracker.atom.atom", "pytracking.tracker.tomp.tomp",
@@ -423,7 +437,8 @@ def _install_preprocessing(orig, strict):
                 tmod = importlib.import_module(modname)
             except Exception:
                 continue
-        for name, fn, ref in (("sample_patch", sample_patch, ref_sp), ("sample_patch_multiscale", sample_patch_multiscale, ref_ms)):
+        for name, fn, ref in (("sample_patch", sample_patch, ref_sp), ("sample_patch_multiscale", sample_patch_multiscale, ref_ms),
+                              ("sample_patch_transformed", sample_patch_transformed, ref_tr)):
             if getattr(tmod, name, None) is ref:
                 setattr(tmod, name, fn)
                 orig["preprocessing"]["importers"].append((tmod, name, ref))
@@ -611,7 +626,7 @@ def uninstall():
             mod.PrRoIPool2D = cls
     if "preprocessing" in orig:
         pm = importlib.import_module("pytracking.features.preprocessing")
-        pm.sample_patch, pm.sample_patch_multiscale = orig["preprocessing"]["functions"]
+        pm.sample_patch, pm.sample_patch_multiscale, pm.sample_patch_transformed = orig["preprocessing"]["functions"]
         for tmod, name, ref in orig["preprocessing"]["importers"]:
             setattr(tmod, name, ref)
     if "lwl" in orig:

@@ -5,8 +5,13 @@ The reference crops on the CPU (strided view, F.pad, F.interpolate) and uploads 
 once and crop + replicate padding + bilinear resize are ONE gather launch for all scales (pt_sample_patch_f32).  The
 integer geometry -- pre-downsampling stride, crop corners, the 'inside' / 'inside_major' shifts -- decides which pixels
 are read and is therefore computed here on the host with the reference's own rules, in plain Python integers.
-Masks (nearest resampling, zero padding) and the first-frame augmentation set are not on the per-frame path and are not
-covered (NotImplementedError; `pytracking_amd.install` hands such calls to the reference).
+`sample_patch_transformed` (:13-30) -- the first-frame augmentation set built by `generate_init_samples`
+(pytracking/tracker/dimp/dimp.py:329-395) -- runs as a second gather launch over the base patch for the whole transform list
+(pt_augment_patches_f32): the reference's own `augmentation.Transform` objects are read for their parameters (shift, output
+size, blur taps, scale factor, angle), never called.  `Rotate` follows OpenCV's published warpAffine arithmetic and is
+PARITY-UNPINNED (cv2 is not installed where the goldens are generated); everything else is pinned by `augment.npz`.
+Masks (nearest resampling, zero padding) are not on the per-frame path and are not covered (NotImplementedError;
+`pytracking_amd.install` hands such calls to the reference).
 """
 import ctypes
 import math
@@ -117,3 +122,109 @@ def sample_patch(im, pos, sample_sz, output_sz=None, mode='replicate', max_scale
     rc = _lib.lib().pt_sample_patch_f32(_ptr(im), C, H, W, (_lib.PatchGeom * 1)(g), 1, _ptr(out), oh, ow, _stream())
     _lib.check(rc, "pt_sample_patch_f32")
     return out, torch.tensor([c], dtype=torch.float32)
+
+
+# ---------------------------------------------------------------------------------------------------------------------
+# first-frame augmentation set
+# ---------------------------------------------------------------------------------------------------------------------
+def _invert_affine(M):
+    """cv::invertAffineTransform on a 2x3 matrix given as 6 Python floats (double arithmetic, OpenCV's operation order)."""
+    D = M[0] * M[4] - M[1] * M[3]
+    D = 1.0 / D if D != 0 else 0.0
+    A11, A22 = M[4] * D, M[0] * D
+    m0, m1, m3, m4 = A11, M[1] * (-D), M[3] * (-D), A22
+    return [m0, m1, -m0 * M[2] - m1 * M[5], m3, m4, -m3 * M[2] - m4 * M[5]]
+
+
+def transform_descriptors(transforms, patch_hw):
+    """(AugDesc array, taps list, (OH, OW)) for a list of the reference's transform objects (augmentation.py) applied to a
+    patch of size `patch_hw`.  Classes are recognised by name so that the reference module is not imported here."""
+    EH, EW = int(patch_hw[0]), int(patch_hw[1])
+    descs = (_lib.AugDesc * len(transforms))()
+    taps, out_hw = [], None
+    for k, T in enumerate(transforms):
+        name = type(T).__name__
+        d = descs[k]
+        th, tw = EH, EW
+        if name in ("Identity", "Translation"):
+            d.kind = _lib.PT_AUG_IDENTITY
+        elif name == "FlipHorizontal":
+            d.kind = _lib.PT_AUG_FLIP_H
+        elif name == "FlipVertical":
+            d.kind = _lib.PT_AUG_FLIP_V
+        elif name == "Blur":                                             # augmentation.py:128-147
+            d.kind = _lib.PT_AUG_BLUR
+            d.fs0, d.fs1 = int(T.filter_size[0]), int(T.filter_size[1])
+            f0 = [float(v) for v in T.filter[0].reshape(-1)]
+            f1 = [float(v) for v in T.filter[1].reshape(-1)]
+            if len(f0) != 2 * d.fs0 + 1 or len(f1) != 2 * d.fs1 + 1:
+                raise ValueError("Blur: filter length does not match filter_size")
+            d.tap_off0 = len(taps)
+            taps += f0
+            d.tap_off1 = len(taps)
+            taps += f1
+        elif name == "Scale":                                            # :80-92
+            if EH != EW:
+                raise NotImplementedError
+            d.kind = _lib.PT_AUG_SCALE
+            th = round(EH / T.scale_factor)
+            th += (th - EH) % 2
+            tw = round(EW / T.scale_factor)
+            tw += (tw - EW) % 2
+        elif name == "Rotate":                                           # :118-126 (UNPINNED: OpenCV arithmetic restated)
+            d.kind = _lib.PT_AUG_ROTATE
+            ca, sa = math.cos(T.angle), math.sin(T.angle)
+            c0, c1 = (EH - 1) / 2, (EW - 1) / 2                          # the reference's centre vector (rows first, as written)
+            M = [ca, sa, c0 - (ca * c0 + sa * c1), -sa, ca, c1 - (-sa * c0 + ca * c1)]
+            inv = _invert_affine(M)
+            for q in range(6):
+                d.m[q] = inv[q]
+        else:
+            raise NotImplementedError("augmentation transform '%s' is not covered on the device" % name)
+        d.th, d.tw = th, tw
+        osz = getattr(T, "output_sz", None)
+        sh = getattr(T, "shift", (0, 0))
+        if osz is None:
+            pad_h = pad_w = 0.0
+        else:
+            pad_h, pad_w = (osz[0] - th) / 2, (osz[1] - tw) / 2
+        d.pad_top = math.floor(pad_h) + int(sh[0])                       # :30-33
+        d.pad_left = math.floor(pad_w) + int(sh[1])
+        hw = (th + math.floor(pad_h) + math.ceil(pad_h), tw + math.floor(pad_w) + math.ceil(pad_w))
+        if out_hw is None:
+            out_hw = hw
+        elif hw != out_hw:
+            raise ValueError("transforms produce different output sizes (torch.cat would fail in the reference)")
+    if len(taps) > _lib.PT_AUG_MAX_TAPS:
+        raise NotImplementedError("more than %d blur taps in one transform list" % _lib.PT_AUG_MAX_TAPS)
+    return descs, taps, out_hw
+
+
+@device_guarded
+def augment_patch(im_patch, transforms):
+    """`torch.cat([T(im_patch) for T in transforms])` (preprocessing.py:28) for a device patch (1, C, EH, EW)."""
+    _require_device(im_patch)
+    if im_patch.dim() != 4 or im_patch.shape[0] != 1:
+        raise NotImplementedError("augment_patch takes one patch (1, C, H, W)")
+    if len(transforms) == 0:
+        raise ValueError("empty transform list")
+    C, EH, EW = (int(v) for v in im_patch.shape[1:])
+    descs, taps, (oh, ow) = transform_descriptors(transforms, (EH, EW))
+    if oh < 1 or ow < 1:
+        raise ValueError("transforms crop the patch to nothing")
+    im_patch = im_patch.contiguous()
+    out = torch.empty((len(transforms), C, oh, ow), dtype=torch.float32, device=im_patch.device)
+    tap_arr = (ctypes.c_float * max(len(taps), 1))(*taps)
+    rc = _lib.lib().pt_augment_patches_f32(_ptr(im_patch), C, EH, EW, descs, len(transforms), tap_arr, len(taps), _ptr(out), oh, ow,
+                                           _stream())
+    _lib.check(rc, "pt_augment_patches_f32")
+    return out
+
+
+@device_guarded
+def sample_patch_transformed(im, pos, scale, image_sz, transforms, is_mask=False):
+    """preprocessing.py:13-30 for a device image: base patch at `image_sz`, then every transform of the list."""
+    if is_mask:
+        raise NotImplementedError("mask patches (nearest resampling) are not on the per-frame path")
+    im_patch, _ = sample_patch(im, pos, scale * image_sz, image_sz)
+    return augment_patch(im_patch, transforms)

@@ -240,14 +240,26 @@ def test_preprocessing_install_dispatch():
     import pytracking.features.preprocessing as pp
     import pytracking.tracker.dimp.dimp as dimp_mod
     from pytracking_amd import install as amd
-    ref_sp, ref_ms = pp.sample_patch, pp.sample_patch_multiscale
+    from pytracking.features import augmentation as A
+    ref_sp, ref_ms, ref_tr = pp.sample_patch, pp.sample_patch_multiscale, pp.sample_patch_transformed
     im = torch.rand(1, 3, 40, 50) * 255
     want, wc = ref_ms(im, torch.Tensor([20.0, 25.0]), torch.Tensor([1.0, 1.5]), torch.Tensor([16.0, 16.0]))
+    trs = [A.Identity([16, 16], [0, 0]), A.Translation([3, -2], [16, 16]), A.FlipHorizontal([16, 16], [1, 1]), A.Blur((2, 1), [16, 16])]
+    want_t = ref_tr(im, torch.Tensor([20.0, 25.0]), 1.2, torch.Tensor([32.0, 32.0]), trs)
     amd.install()
     try:
         assert pp.sample_patch.__wrapped__ is ref_sp and dimp_mod.sample_patch_multiscale is pp.sample_patch_multiscale
+        assert dimp_mod.sample_patch_transformed is pp.sample_patch_transformed and pp.sample_patch_transformed.__wrapped__ is ref_tr
         got, gc = dimp_mod.sample_patch_multiscale(im, torch.Tensor([20.0, 25.0]), torch.Tensor([1.0, 1.5]), torch.Tensor([16.0, 16.0]))
         assert torch.equal(got, want) and torch.equal(gc, wc)
+        assert torch.equal(dimp_mod.sample_patch_transformed(im, torch.Tensor([20.0, 25.0]), 1.2, torch.Tensor([32.0, 32.0]), trs), want_t)
+        # the host descriptors read from the REAL reference objects (names, filter layout, shifts as the classes store them)
+        from pytracking_amd import preprocessing as PP
+        descs, taps, hw = PP.transform_descriptors(trs + [A.Scale(0.8, [16, 16], [2, 0]), A.Rotate(10, [16, 16])], (32, 32))
+        assert hw == (16, 16) and [d.kind for d in descs] == [0, 0, 1, 3, 4, 5]
+        assert (descs[1].pad_top, descs[1].pad_left) == (-8 + 3, -8 - 2) and (descs[4].th, descs[4].pad_top) == (40, -12 + 2)
+        assert len(taps) == (2 * 4 + 1) + (2 * 2 + 1) and abs(sum(taps[:9]) - 1) < 1e-6
     finally:
         amd.uninstall()
-    assert pp.sample_patch is ref_sp and dimp_mod.sample_patch_multiscale is ref_ms
+    assert pp.sample_patch is ref_sp and dimp_mod.sample_patch_multiscale is ref_ms and pp.sample_patch_transformed is ref_tr
+    assert dimp_mod.sample_patch_transformed is ref_tr
