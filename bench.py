@@ -175,8 +175,7 @@ def roofline(cfg, cfg_name, n, period, stats, why):
     event pairs around 200 back-to-back pass launches) and `stats` (rocprofv3 kernel averages of the child process)."""
     feat_bytes = 4 * n * cfg["C"] * cfg["H"] * cfg["W"]           # one pass streams the n-sample memory once
     kern = {}
-    # the correlation pass of the solve is the position-band kernel k_corr3 (k_corr2 with PT_SD_NO_BAND=1 / shapes it does not cover)
-    corr_name = "k_corr3" if (stats and any("k_corr3" in nm for nm in stats)) or not stats else "k_corr2"
+    corr_name = "k_corr2"
     period = {corr_name: period["corr"], "k_adj2": period["adj"]}
     for short in (corr_name, "k_adj2"):
         rec = {"period_us": round(period[short], 3)}

@@ -59,9 +59,10 @@ __device__ __forceinline__ float wave_max(float v) {
 }
 
 // Deterministic block-wide sum; `scratch` needs blockDim.x/64 floats of LDS.  Every thread gets the result.
-__device__ __forceinline__ float block_sum(float v, float* scratch) {
+// (`nthreads`: pass the block size when the kernel knows it -- blockDim.x is an implicit kernel argument, a scalar load of its own)
+__device__ __forceinline__ float block_sum(float v, float* scratch, int nthreads = 0) {
     v = wave_sum(v);
-    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6, nw = (blockDim.x + 63) >> 6;
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6, nw = ((nthreads > 0 ? nthreads : (int)blockDim.x) + 63) >> 6;
     __syncthreads();
     if (lane == 0) scratch[wave] = v;
     __syncthreads();
@@ -79,6 +80,54 @@ __device__ __forceinline__ float block_max(float v, float* scratch) {
     float t = scratch[0];
     for (int w = 1; w < nw; ++w) t = fmaxf(t, scratch[w]);
     return t;
+}
+
+// The argument block of a kernel whose leading scalar parameters are preloaded (-amdgpu-kernarg-preload-count): fetched BEHIND
+// the point where the prologue has requested its operands, in ONE batch, with ONE wait.
+//   * The compiler materialises accesses to a by-value struct parameter as scalar loads at the kernel entry and waits for all of
+//     them (`s_waitcnt lgkmcnt(0)`: scalar loads return out of order) at the first instruction that uses one OR overwrites a scalar
+//     register one of them is landing in -- in practice a few instructions into the prologue, ~1.2 us in front of the first
+//     vector load.  pt_late_args() therefore reads the block through a pointer into the kernel-argument segment that the compiler
+//     cannot see through (`asm volatile`), copied word by word through the constant address space (scalar loads; unused words
+//     disappear).  `byte_offset` = offset of the struct parameter in the segment (the scalars in front of it, 8-aligned).
+//   * Whole 16-dword blocks are fetched and defined in SGPRs by an `asm volatile` right there: otherwise the compiler re-fetches
+//     fields at their uses, one ~1.2 us stall each, where it finds that cheaper than holding them in registers.
+typedef int pt_i32x16 __attribute__((ext_vector_type(16)));
+template <typename T>
+struct PtLate { pt_i32x16 blk[(sizeof(T) / 4 + 15) / 16]; };
+// request the block (s_load_dwordx16 each; the last one may read into the implicit arguments behind it, inside the segment)
+template <typename T>
+__device__ __forceinline__ PtLate<T> pt_late_issue(unsigned byte_offset) {
+    static_assert(sizeof(T) % 4 == 0 && sizeof(T) <= 3 * 64, "argument blocks: whole dwords, at most 3 x 16 (SGPR budget)");
+    const char __attribute__((address_space(4)))* p = (const char __attribute__((address_space(4)))*)__builtin_amdgcn_kernarg_segment_ptr();
+    p += byte_offset;
+    asm volatile("" : "+s"(p)::"memory");
+    const pt_i32x16 __attribute__((address_space(4)))* q = (const pt_i32x16 __attribute__((address_space(4)))*)p;
+    PtLate<T> r;
+#pragma unroll
+    for (unsigned b = 0; b < sizeof(r.blk) / sizeof(r.blk[0]); ++b) r.blk[b] = q[b];
+    return r;
+}
+// the one place where the fetch is waited for.  Every dword of a block is live up to here (the asm takes whole blocks), so no
+// scalar register under a landing load is reused in between -- that is what makes a wait appear early
+template <typename T>
+__device__ __forceinline__ T pt_late_get(PtLate<T>& r) {
+    constexpr int NW = sizeof(T) / 4;
+    struct Words { int w[NW]; };
+    Words tmp;
+#pragma unroll
+    for (unsigned b = 0; b < sizeof(r.blk) / sizeof(r.blk[0]); ++b) {
+        asm volatile("" : "+s"(r.blk[b]));
+#pragma unroll
+        for (int k = 0; k < 16; ++k)
+            if ((int)b * 16 + k < NW) tmp.w[b * 16 + k] = r.blk[b][k];
+    }
+    return __builtin_bit_cast(T, tmp);
+}
+template <typename T>
+__device__ __forceinline__ T pt_late_args(unsigned byte_offset) {
+    PtLate<T> r = pt_late_issue<T>(byte_offset);
+    return pt_late_get<T>(r);
 }
 
 static inline int pt_ceil_div(int a, int b) { return (a + b - 1) / b; }

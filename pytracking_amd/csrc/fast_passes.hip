@@ -122,6 +122,9 @@ PtFast pt_fast_plan(int n, int C, int H, int W, int KH, int KW, int OH, int OW) 
     p.adj_lds = ((size_t)p.ns_max * p.PH * p.PW + p.zn + (size_t)5 * 4 * PT_ADJ_WAVES * PT_ADJ_UMAX) * sizeof(float);
     if (p.adj_lds > 96 * 1024 || p.OO > 1024) return p;
     p.E = p.OO <= 384 ? 6 : (p.OO <= 576 ? 9 : 16);
+    // what the packed kernel parameters of the two passes can hold (k_corr2: h_dims / h_geo, k_adj2: h_g1 .. h_g4)
+    if (H > 255 || W > 255 || n > 65535 || p.gper > 65535 || p.PH > 63 || p.PW > 63 || p.zn > 255 || p.ns_max > 63 || KH > 7 || KW > 7)
+        return p;
     p.ok = 1;
     return p;
 }
@@ -172,25 +175,38 @@ __device__ __forceinline__ float corr2_filter_elem(const Corr2Args& a, int KK, i
 // NH: k-step halves per tile (2 for 18x18 maps, 1 for 22x22) -- compile time as well: as a run-time value every tap of the
 // shift-and-add became `ds_read; branch; ds_read; s_waitcnt lgkmcnt(0)`, 16 serialised LDS round trips (0.9 us of the pass).
 template <int NK, bool LEFT, int FUSE, bool K16, int NH>
-__global__ __launch_bounds__(1024, (NK <= 8 ? PT_C2_MINW : 4)) void k_corr2(Corr2Args a) {
+__global__ __launch_bounds__(1024, (NK <= 8 ? PT_C2_MINW : 4)) void k_corr2(const float* h_feat, long h_stride, const float* h_filt, const float* h_w, const float* h_src, int h_slot,
+                                                                              unsigned h_dims, unsigned h_geo, Corr2Args a_arg) {
+    // The h_* parameters repeat what the prologue needs to REQUEST its operands (13 dwords).  Scalar kernel parameters are
+    // preloaded into SGPRs at wave launch (-amdgpu-kernarg-preload-count), the argument block `a` arrives by scalar loads about
+    // 1.2 us later (measured in round 3: a kernel whose arguments are all preloaded is that much shorter, eager and in graph
+    // replay alike) -- by then the filter partials and the first feature tiles are on their way.
+    //   h_filt = gradient partials (FUSE > 0) or the filter (FUSE == 0);  h_dims = C << 16 | H*W;
+    //   h_geo  = tiles | TF << 5 | rem << 10 | KSPL << 14 | (16 channel ranges) << 20
     extern __shared__ __attribute__((aligned(16))) float lds[];     // afilt[CX][16] | T[2][KK][HWp]
     __shared__ float scratch[16];
-    PT_STAMP(a, 0);
+    PT_STAMP(a_arg, 0);
     constexpr int EPT = 2;
     constexpr int FP = FUSE > 0 ? FUSE : 1;
-    // KSC = 16: ranges 2x and 2x + 1 both run on XCD x (the adjoint pass owns channels [x C/8, (x+1) C/8) there)
+    const int hC = (int)(h_dims >> 16), HW = (int)(h_dims & 0xffffu);
+    const int h_tiles = (int)(h_geo & 31u), h_TF = (int)((h_geo >> 5) & 31u), h_rem = (int)((h_geo >> 10) & 15u);
+    const int h_KSPL = (int)((h_geo >> 14) & 63u);
+    const bool ksc16 = ((h_geo >> 20) & 1u) != 0;
+    const int nthreads = NH * h_tiles * 64;
+    const int hCX = ksc16 ? hC >> 4 : hC >> 3, hHWp = 64 * (h_TF + (h_rem > 0 ? 1 : 0)) + 4;
+    // 16 ranges: 2x and 2x + 1 both run on XCD x (the adjoint pass owns channels [x C/8, (x+1) C/8) there)
     const int b = blockIdx.x, xc = b & 7, q = b >> 3;
-    const int x = a.KSC == 16 ? 2 * xc + (q & 1) : xc, i = a.KSC == 16 ? q >> 1 : q;
-    const int HW = a.H * a.W, KK = a.KH * a.KW;
+    const int x = ksc16 ? 2 * xc + (q & 1) : xc, i = ksc16 ? q >> 1 : q;
+    const int KK = K16 ? 16 : a_arg.KH * a_arg.KW;
     const int lane = threadIdx.x & 63, wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);   // wave-uniform: scalar branches
     const int kq = lane >> 4, j = lane & 15;
-    const int h = wave >= a.tiles ? 1 : 0, t = wave - h * a.tiles;
-    const int cx0 = a.CX * x;
-    const int nsl = a.CX * 16;
+    const int h = wave >= h_tiles ? 1 : 0, t = wave - h * h_tiles;
+    const int cx0 = hCX * x;
+    const int nsl = hCX * 16;
     float* __restrict__ afilt = lds;
-    float* __restrict__ Tl = lds + nsl + (long)h * KK * a.HWp;
-    const bool over = a.src != nullptr && i == a.slot;
-    const float* __restrict__ fi = over ? a.src : a.feat + (long)i * a.stride_n;
+    float* __restrict__ Tl = lds + nsl + (long)h * KK * hHWp;
+    const bool over = h_src != nullptr && i == h_slot;
+    const float* __restrict__ fi = over ? h_src : h_feat + (long)i * h_stride;
     const bool publish = FUSE > 0 && i == 0;
 
     // ---- filter operand: straight-line, clamped addresses, all loads in flight together.  With 16 taps the slice
@@ -206,30 +222,30 @@ __global__ __launch_bounds__(1024, (NK <= 8 ? PT_C2_MINW : 4)) void k_corr2(Corr
         const long g4 = ((long)cx0 * 16 >> 1) + e4;
         if (FUSE > 0) {
             // partial k in the scalar offset of the buffer load: no 64-bit address arithmetic per load on the VALU
-            const unsigned ckk_b = (unsigned)a.C * 16u * 4u;
-            const __amdgpu_buffer_rsrc_t rg = pt_rsrc(a.gpart, (unsigned)a.KSPL * ckk_b);
+            const unsigned ckk_b = (unsigned)hC * 16u * 4u;
+            const __amdgpu_buffer_rsrc_t rg = pt_rsrc(h_filt, (unsigned)h_KSPL * ckk_b);
 #pragma unroll
             for (int k = 0; k < FP; ++k)
-                part4[k] = __builtin_bit_cast(f32x2, __builtin_amdgcn_raw_buffer_load_b64(rg, (unsigned)g4 * 8u, (unsigned)min(k, a.KSPL - 1) * ckk_b, 0));
-            wv4 = ((const f32x2*)a.w)[g4];
+                part4[k] = __builtin_bit_cast(f32x2, __builtin_amdgcn_raw_buffer_load_b64(rg, (unsigned)g4 * 8u, (unsigned)min(k, h_KSPL - 1) * ckk_b, 0));
+            wv4 = ((const f32x2*)h_w)[g4];
         } else {
-            part4[0] = ((const f32x2*)a.filt)[g4];
+            part4[0] = ((const f32x2*)h_filt)[g4];
         }
     } else {
 #pragma unroll
         for (int q = 0; q < EPT; ++q) {
-            const int e = threadIdx.x + q * blockDim.x;
+            const int e = threadIdx.x + q * nthreads;
             const int ec = min(e, nsl - 1);
             const int cl = ec >> 4, tp = ec & 15;
             okv[q] = e < nsl && tp < KK;
             gev[q] = (long)(cx0 + cl) * KK + (tp < KK ? tp : 0);
             if (FUSE > 0) {
-                const long CKK = (long)a.C * KK;
+                const long CKK = (long)hC * KK;
 #pragma unroll
-                for (int k = 0; k < FP; ++k) part[q][k] = a.gpart[(long)min(k, a.KSPL - 1) * CKK + gev[q]];
-                wv[q] = a.w[gev[q]];
+                for (int k = 0; k < FP; ++k) part[q][k] = h_filt[(long)min(k, h_KSPL - 1) * CKK + gev[q]];
+                wv[q] = h_w[gev[q]];
             } else {
-                part[q][0] = a.filt[gev[q]];
+                part[q][0] = h_filt[gev[q]];
             }
         }
     }
@@ -241,10 +257,10 @@ __global__ __launch_bounds__(1024, (NK <= 8 ? PT_C2_MINW : 4)) void k_corr2(Corr
     const int cbase = cx0 + 4 * (h * NK) + kq;
     const int pos = 64 * t + 4 * j;
     const bool pv = pos < HW;
-    const __amdgpu_buffer_rsrc_t fr = pt_rsrc(fi, (unsigned)a.C * HW * 4u);
+    const __amdgpu_buffer_rsrc_t fr = pt_rsrc(fi, (unsigned)hC * HW * 4u);
     const unsigned fo = ((unsigned)cbase * HW + (pv ? pos : 0)) * 4u;
-    const int lpos = 64 * a.TF + j;
-    const bool lv = LEFT && t == 0 && j < 4 * a.rem;
+    const int lpos = 64 * h_TF + j;
+    const bool lv = LEFT && t == 0 && j < 4 * h_rem;
     const unsigned lo = lv ? ((unsigned)cbase * HW + lpos) * 4u : 0xFFFFFFF0u - 64u * (unsigned)HW * 4u;   // no position: reads 0
     f32x4 bq[NK];
     float bl[NK];
@@ -261,6 +277,8 @@ __global__ __launch_bounds__(1024, (NK <= 8 ? PT_C2_MINW : 4)) void k_corr2(Corr
     }
 #pragma unroll
     for (int k = 0; k < CD; ++k) bq[k] = pt_bload4(fr, fo + (unsigned)(4 * k) * HW * 4u);
+    __builtin_amdgcn_sched_barrier(0);                              // nothing that needs the argument block above this line
+    const Corr2Args a = pt_late_args<Corr2Args>(56);                // 5 pointers / longs + 3 dwords = 52 bytes, 8-aligned
     PT_STAMP(a, 1);
 
     // ---- reduce + publish the filter slice
@@ -271,7 +289,7 @@ __global__ __launch_bounds__(1024, (NK <= 8 ? PT_C2_MINW : 4)) void k_corr2(Corr
             v4 = (f32x2){0, 0};
 #pragma unroll
             for (int k = 0; k < FP; ++k)
-                if (k < a.KSPL) v4 += part4[k];                                     // fixed order
+                if (k < h_KSPL) v4 += part4[k];                                     // fixed order
             v4 += a.reg * wv4;
             if ((int)threadIdx.x < n4) {
                 gsq = v4[0] * v4[0] + v4[1] * v4[1];
@@ -281,17 +299,17 @@ __global__ __launch_bounds__(1024, (NK <= 8 ? PT_C2_MINW : 4)) void k_corr2(Corr
             v4 = part4[0];
         }
         if ((int)threadIdx.x < n4) ((f32x2*)afilt)[e4] = v4;
-        for (int q4 = threadIdx.x + blockDim.x; q4 < n4; q4 += blockDim.x)          // slices larger than the block
+        for (int q4 = threadIdx.x + nthreads; q4 < n4; q4 += nthreads)          // slices larger than the block
             for (int m = 0; m < 2; ++m) afilt[2 * q4 + m] = corr2_filter_elem(a, KK, cx0, 2 * q4 + m, publish, gsq);
     } else {
 #pragma unroll
         for (int q = 0; q < EPT; ++q) {
-            const int e = threadIdx.x + q * blockDim.x;
+            const int e = threadIdx.x + q * nthreads;
             float v;
             if (FUSE > 0) {
                 v = 0.f;
 #pragma unroll
-                for (int k = 0; k < FP; ++k) v += k < a.KSPL ? part[q][k] : 0.f;   // fixed order
+                for (int k = 0; k < FP; ++k) v += k < h_KSPL ? part[q][k] : 0.f;   // fixed order
                 v += a.reg * wv[q];
                 if (okv[q]) {
                     gsq += v * v;
@@ -302,11 +320,11 @@ __global__ __launch_bounds__(1024, (NK <= 8 ? PT_C2_MINW : 4)) void k_corr2(Corr
             }
             if (e < nsl) afilt[e] = okv[q] ? v : 0.f;
         }
-        for (int e = threadIdx.x + EPT * blockDim.x; e < nsl; e += blockDim.x)
+        for (int e = threadIdx.x + EPT * nthreads; e < nsl; e += nthreads)
             afilt[e] = corr2_filter_elem(a, KK, cx0, e, publish, gsq);
     }
     if (publish) {                                                  // uniform per workgroup
-        const float tot = block_sum(gsq, scratch);
+        const float tot = block_sum(gsq, scratch, nthreads);
         if (threadIdx.x == 0) a.anum_part[x] = tot;
     }
     PT_STAMP(a, 2);
@@ -344,8 +362,8 @@ __global__ __launch_bounds__(1024, (NK <= 8 ? PT_C2_MINW : 4)) void k_corr2(Corr
         const int row = 4 * kq + r;
         if (row < KK) {
             f32x4 v = {acc0[r], acc1[r], acc2[r], acc3[r]};
-            *(f32x4*)(Tl + row * a.HWp + pos) = v;                 // columns >= HW land in the padding
-            if (LEFT && t == 0) Tl[row * a.HWp + lpos] = accL[r];  // j >= 4*rem: padding as well (lpos < HWp)
+            *(f32x4*)(Tl + row * hHWp + pos) = v;                 // columns >= HW land in the padding
+            if (LEFT && t == 0) Tl[row * hHWp + lpos] = accL[r];  // j >= 4*rem: padding as well (lpos < HWp)
         }
     }
     PT_STAMP(a, 5);
@@ -356,10 +374,10 @@ __global__ __launch_bounds__(1024, (NK <= 8 ? PT_C2_MINW : 4)) void k_corr2(Corr
     const int ph = a.KH / 2, pw = a.KW / 2, OO = a.OH * a.OW;
     const float inv_ow = 1.0f / (float)a.OW;
     const float* __restrict__ T0 = lds + nsl;
-    const float* __restrict__ T1 = T0 + (long)KK * a.HWp;          // second k-step half (a.nh == 2)
+    const float* __restrict__ T1 = T0 + (long)KK * hHWp;          // second k-step half (a.nh == 2)
     float* __restrict__ out = a.spart + ((long)x * a.n + i) * OO;
     if (a.KH == 4 && a.KW == 4) {                                   // the trackers' filter size: fully unrolled
-        for (int o = threadIdx.x; o < OO; o += blockDim.x) {
+        for (int o = threadIdx.x; o < OO; o += nthreads) {
             const int y = fdiv(o, inv_ow), xx0 = o - y * a.OW;
             float tv[16];
 #pragma unroll
@@ -369,7 +387,7 @@ __global__ __launch_bounds__(1024, (NK <= 8 ? PT_C2_MINW : 4)) void k_corr2(Corr
                 for (int v = 0; v < 4; ++v) {
                     const int xx = xx0 + v - 2;
                     const bool ok = (unsigned)yy < (unsigned)a.H && (unsigned)xx < (unsigned)a.W;
-                    const int idx = (u * 4 + v) * a.HWp + (ok ? yy * a.W + xx : 0);
+                    const int idx = (u * 4 + v) * hHWp + (ok ? yy * a.W + xx : 0);
                     const float tsum = NH == 2 ? T0[idx] + T1[idx] : T0[idx];
                     tv[u * 4 + v] = ok ? tsum : 0.f;
                 }
@@ -382,7 +400,7 @@ __global__ __launch_bounds__(1024, (NK <= 8 ? PT_C2_MINW : 4)) void k_corr2(Corr
         PT_STAMP(a, 7);
         return;
     }
-    for (int o = threadIdx.x; o < OO; o += blockDim.x) {
+    for (int o = threadIdx.x; o < OO; o += nthreads) {
         const int y = fdiv(o, inv_ow), xx0 = o - y * a.OW;
         float s = 0.f;
         for (int u = 0; u < a.KH; ++u) {
@@ -391,7 +409,7 @@ __global__ __launch_bounds__(1024, (NK <= 8 ? PT_C2_MINW : 4)) void k_corr2(Corr
             for (int v = 0; v < a.KW; ++v) {
                 const int xx = xx0 + v - pw;
                 if ((unsigned)xx < (unsigned)a.W) {
-                    const int idx = (u * a.KW + v) * a.HWp + yy * a.W + xx;
+                    const int idx = (u * a.KW + v) * hHWp + yy * a.W + xx;
                     s += NH == 2 ? T0[idx] + T1[idx] : T0[idx];
                 }
             }
@@ -415,11 +433,16 @@ int pt_launch_corr2(const PtFast& p, const float* feat, long stride_n, const flo
     if (p.KK == 16 && (((uintptr_t)filt % 16) || ((uintptr_t)a.gpart % 16) || ((uintptr_t)a.w % 16) || ((uintptr_t)a.g_out % 16)))
         return PT_ERR_UNSUPPORTED;
     dim3 grid(p.KSC * p.n), block(p.corr_threads);
+    if (p.C >= (1 << 16) || p.HW >= (1 << 16) || p.tiles > 31 || p.TF > 31 || p.rem > 15 || a.KSPL > 63) return PT_ERR_UNSUPPORTED;
+    const unsigned h_dims = ((unsigned)p.C << 16) | (unsigned)p.HW;
+    const unsigned h_geo = (unsigned)p.tiles | ((unsigned)p.TF << 5) | ((unsigned)p.rem << 10) | ((unsigned)a.KSPL << 14) |
+                           ((p.KSC == 16 ? 1u : 0u) << 20);
+#define PT_C2_HOT(FPTR) a.feat, a.stride_n, (const float*)(FPTR), a.w, a.src, a.slot, h_dims, h_geo
 #define PT_C2G(NKV, LF, KF, NHV)                                                                                    \
     do {                                                                                                         \
-        if (!a.gpart) hipLaunchKernelGGL((k_corr2<NKV, LF, 0, KF, NHV>), grid, block, p.corr_lds, st, a);             \
-        else if (a.KSPL <= 8) hipLaunchKernelGGL((k_corr2<NKV, LF, 8, KF, NHV>), grid, block, p.corr_lds, st, a);     \
-        else hipLaunchKernelGGL((k_corr2<NKV, LF, 16, KF, NHV>), grid, block, p.corr_lds, st, a);                     \
+        if (!a.gpart) hipLaunchKernelGGL((k_corr2<NKV, LF, 0, KF, NHV>), grid, block, p.corr_lds, st, PT_C2_HOT(a.filt), a);             \
+        else if (a.KSPL <= 8) hipLaunchKernelGGL((k_corr2<NKV, LF, 8, KF, NHV>), grid, block, p.corr_lds, st, PT_C2_HOT(a.gpart), a);     \
+        else hipLaunchKernelGGL((k_corr2<NKV, LF, 16, KF, NHV>), grid, block, p.corr_lds, st, PT_C2_HOT(a.gpart), a);                     \
     } while (0)
 #define PT_C2H(NKV, LF, KF)              \
     do {                                 \
@@ -440,6 +463,7 @@ int pt_launch_corr2(const PtFast& p, const float* feat, long stride_n, const flo
     else if (p.NK == 4) PT_C2(4);
     else if (p.NK == 8) PT_C2(8);
     else PT_C2(16);
+#undef PT_C2_HOT
 #undef PT_C2G
 #undef PT_C2H
 #undef PT_C2F
@@ -460,6 +484,25 @@ struct Adj2Args {
     PT_STAMP_ARG
 };
 
+// What k_adj2 needs BEHIND its prologue, compact (46 dwords = three scalar 16-dword loads): fetched late, see pt_late_issue.
+// Same member names as Adj2Args / SdArgs so that the update-stage helpers below read either.
+struct Adj2SdLate {
+    int n, CKK, has_sw, has_softmax_reg;
+    float step, reg, alpha_eps, act_param, softmax_reg;
+    int pad0;
+    const float *sw, *s_in, *w0;
+    float *mask, *sws, *s, *sg, *lms, *g, *lossp, *w_iters;
+};
+struct Adj2Late {
+    float* gpart;
+    int C, KH, KW, OH, OW, PH, PW, ns_max, zn, t, want_loss, pad1;
+    Adj2SdLate sd;
+    PT_STAMP_ARG
+};
+#ifndef PT_STAMPS
+static_assert(sizeof(Adj2Late) == 46 * 4, "Adj2Late layout");
+#endif
+
 // residual-map providers of k_adj2
 enum { V_PLAIN = 0, V_DIMP_RELU = 1, V_DIMP_BENT = 2, V_L2 = 3, V_PRDIMP = 4 };
 
@@ -472,21 +515,27 @@ enum { V_PLAIN = 0, V_DIMP_RELU = 1, V_DIMP_BENT = 2, V_L2 = 3, V_PRDIMP = 4 };
 template <int E>
 struct PReg { f32x4 pk[E]; float s[E], sg[E], sw[E]; };
 
+// hot part: the packed operands through pointers that arrived as preloaded kernel parameters (no argument block needed)
 template <int V, int E>
-__device__ __forceinline__ void sdp_load(const Adj2Args& a, int i, int lane, bool home, PReg<E>& r) {
+__device__ __forceinline__ void sdp_load_hot(const float* __restrict__ pkp, int OO, int i, int lane, PReg<E>& r) {
+    const long base = (long)i * OO;
+#pragma unroll
+    for (int e = 0; e < E; ++e) {
+        const long q = base + min(lane + 64 * e, OO - 1);
+        if (V == V_PLAIN) r.s[e] = pkp[q];
+        else r.pk[e] = ((const f32x4*)pkp)[q];
+    }
+}
+// the rest: bentpar weights, and the raw maps of the wave that owns the sample
+template <int V, int E, typename A>
+__device__ __forceinline__ void sdp_load_rest(const A& a, int i, int lane, bool home, PReg<E>& r) {
     const int OO = a.OH * a.OW;
     const long base = (long)i * OO;
     // t == 0: there is no F g yet; astep is 0 and any finite operand does
     const float* __restrict__ sgp = a.t > 0 ? a.sd.sg : a.sd.s_in;
+    if (V == V_DIMP_BENT) {
 #pragma unroll
-    for (int e = 0; e < E; ++e) {
-        const long q = base + min(lane + 64 * e, OO - 1);
-        if (V == V_PLAIN) {
-            r.s[e] = a.inp[q];
-        } else {
-            r.pk[e] = ((const f32x4*)a.sd.pk)[q];
-            if (V == V_DIMP_BENT) r.sw[e] = a.sd.sws[q];
-        }
+        for (int e = 0; e < E; ++e) r.sw[e] = a.sd.sws[base + min(lane + 64 * e, OO - 1)];
     }
     if (V != V_PLAIN && home) {                                     // uniform per wave
 #pragma unroll
@@ -497,14 +546,19 @@ __device__ __forceinline__ void sdp_load(const Adj2Args& a, int i, int lane, boo
         }
     }
 }
+template <int V, int E, typename A>
+__device__ __forceinline__ void sdp_load(const A& a, const float* __restrict__ pkp, int i, int lane, bool home, PReg<E>& r) {
+    sdp_load_hot<V, E>(pkp, a.OH * a.OW, i, lane, r);
+    sdp_load_rest<V, E>(a, i, lane, home, r);
+}
 
 // Update stage of the steepest-descent iteration for sample i, executed by one wave
 // (optimizer.py:137-146,160 / :403-408,430): s_t = s_{t-1} - step*alpha*(F g); residual map -> zero-padded LDS map;
 // the owning workgroup (`home`) also stores s_t (and the PrDiMP softmax) and the sample's loss term.
-template <int V, int E>
-__device__ __forceinline__ void sdp_compute(const Adj2Args& a, int i, int lane, const PReg<E>& r, float astep,
+template <int V, int E, typename A>
+__device__ __forceinline__ void sdp_compute(const A& a, int i, int lane, const PReg<E>& r, float astep,
                                             float* __restrict__ map, int oy, int ox, bool home) {
-    const SdArgs& sd = a.sd;
+    const auto& sd = a.sd;
     const int OO = a.OH * a.OW;
     const long base = (long)i * OO;
     const float inv_ow = 1.0f / (float)a.OW;
@@ -598,41 +652,46 @@ __device__ __forceinline__ void sdp_compute(const Adj2Args& a, int i, int lane, 
 
 // UM: 16-position groups per wave (compile-time trip count of the pipelined loop; 12 for the 22x22 PrDiMP geometry)
 template <int V, int E, int UM>
-__global__ __launch_bounds__(PT_ADJ_WAVES * 64) void k_adj2(Adj2Args a) {
+__global__ __launch_bounds__(PT_ADJ_WAVES * 64) void k_adj2(const float* h_feat, long h_stride, const float* h_pk, const float* h_qs, const float* h_anum, unsigned h_g1,
+                                                                unsigned h_g2, unsigned h_g3, unsigned h_g4, Adj2Late a_arg) {
+    // h_*: everything up to the first barrier, as scalar kernel parameters preloaded into SGPRs at wave launch (14 dwords; the
+    // argument block arrives by scalar loads ~1.2 us later -- see k_corr2 -- and is fetched behind the prologue, pt_late_issue):
+    //   h_pk = packed update-stage operands (V_PLAIN: the input maps);
+    //   h_g1 = H | W << 8 | U << 16 | bpx << 21 | t << 25;  h_g2 = n | gper << 16;  h_g3 = OO | (C / 16) << 16 | KS << 24
+    //   h_g4 = PH | PW << 6 | zn << 12 | ns_max << 20 | KH << 26 | KW << 29
     extern __shared__ __attribute__((aligned(16))) float maps[];    // [ns_max][PH][PW] zero-padded residual maps, zn zeros, quad table
     __shared__ float red[PT_ADJ_WAVES][256];
-    PT_STAMP_A(a, 0);
-    PT_STAMP_B(a, 0);
+    PT_STAMP_A(a_arg, 0);
+    PT_STAMP_B(a_arg, 0);
+    const int hH = (int)(h_g1 & 255u), hW = (int)((h_g1 >> 8) & 255u), hU = (int)((h_g1 >> 16) & 31u), hbpx = (int)((h_g1 >> 21) & 15u);
+    const int ht = (int)(h_g1 >> 25);
+    const int hn = (int)(h_g2 & 0xffffu), hgper = (int)(h_g2 >> 16);
+    const int hOO = (int)(h_g3 & 0xffffu), hC = 16 * (int)((h_g3 >> 16) & 255u), hKS = (int)((h_g3 >> 24) & 127u);
+    const int hPH = (int)(h_g4 & 63u), hPW = (int)((h_g4 >> 6) & 63u), hzn = (int)((h_g4 >> 12) & 255u), hns_max = (int)((h_g4 >> 20) & 63u);
+    const int hKH = (int)((h_g4 >> 26) & 7u), hKW = (int)((h_g4 >> 29) & 7u);
     const int b = blockIdx.x, x = b & 7, rr = b >> 3;
-    const int cb = a.bpx * x + rr % a.bpx, ks = rr / a.bpx;
-    const int HW = a.H * a.W, KK = a.KH * a.KW, PHPW = a.PH * a.PW;
+    const int cb = hbpx * x + rr % hbpx, ks = rr / hbpx;
+    const int HW = hH * hW;
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
     const int kq = lane >> 4, j = lane & 15;
-    const int gbeg = ks * a.gper, gend = min(a.NG, gbeg + a.gper);
-    const int total = a.n * HW;
-    const float inv_hw = 1.0f / (float)HW, inv_w = 1.0f / (float)a.W;
+    const int total = hn * HW;
+    const int hNG = (total + 15) >> 4;
+    const int gbeg = ks * hgper, gend = min(hNG, gbeg + hgper);
+    const float inv_hw = 1.0f / (float)HW, inv_w = 1.0f / (float)hW;
     const int i_lo = fdiv(gbeg * 16, inv_hw);
-    const int i_hi = min(a.n - 1, fdiv(gend * 16 - 1, inv_hw));
+    const int i_hi = min(hn - 1, fdiv(gend * 16 - 1, inv_hw));
     const int ns = i_hi - i_lo + 1;
-    const int ZB = a.ns_max * PHPW;                                 // a.zn zeros: what masked quads gather (any tap)
-    // residual coordinate of (position (y,x), tap (u,v)) is (y-u+KH/2, x-v+KW/2); in the padded map the residual
-    // pixel (yy,xx) sits at (yy + oy, xx + ox)
-    const int oy = a.KH - 1 - a.KH / 2, ox = a.KW - 1 - a.KW / 2;
-
     constexpr int PD = UM < 8 ? UM : (UM == 8 ? 8 : (PT_ADJ_PD < UM ? PT_ADJ_PD : UM));
     const int c = cb * 16 + j;
-    const __amdgpu_buffer_rsrc_t fr = pt_rsrc(a.feat, (unsigned)(((long)(a.n - 1) * a.stride_n + (long)a.C * HW) * 4));
-    const int uj = j / a.KW, vj = j - uj * a.KW;
-    // lanes j >= K*K feed accumulator columns that are never stored: any in-range tap offset does
-    const unsigned tapoff4 = j < KK ? 4u * (unsigned)((a.KH - 1 - uj) * a.PW + (a.KW - 1 - vj)) : 0u;
+    const __amdgpu_buffer_rsrc_t fr = pt_rsrc(h_feat, (unsigned)(((long)(hn - 1) * h_stride + (long)hC * HW) * 4));
     const unsigned chw4 = 4u * (unsigned)c * (unsigned)HW;
     const int Pm = 16 * gbeg < total ? 16 * gbeg : 0;
     // where quad (k-quarter tk, wave tw, group tu) of this workgroup lives: sample, position inside the sample (a masked
     // quad re-reads a line already fetched)
     auto quad_at = [&](int tk, int tw, int tu, int& i, int& p0) {
-        const int g = gbeg + tw * a.U + tu;
+        const int g = gbeg + tw * hU + tu;
         const int P0 = 16 * g + 4 * tk;
-        const bool okk = tu < a.U && g < gend && P0 < total;
+        const bool okk = tu < hU && g < gend && P0 < total;
         const int Pc = okk ? P0 : Pm + 4 * tk;
         i = fdiv(Pc, inv_hw);
         p0 = Pc - i * HW;
@@ -640,43 +699,50 @@ __global__ __launch_bounds__(PT_ADJ_WAVES * 64) void k_adj2(Adj2Args a) {
     };
 
     // ---- Order of the prologue (round 3, profiles/r03g_pass_phase_stamps.txt: the first feature load used to leave 2.7 us
-    //      after the kernel started -- behind the table build, the update-stage loads and a `s_waitcnt vmcnt(0)` for alpha):
+    //      after the kernel started -- behind the argument fetch, the table build, the update-stage loads and a
+    //      `s_waitcnt vmcnt(0)` for alpha):
     //      (1) the small, L2-resident inputs of the update stage are requested first: the memory counter retires in order, so
     //          waiting for them later leaves the feature loads behind them in flight;
     //      (2) the first PD feature loads go out with offsets computed directly (one division per group);
-    //      (3) only then the LDS work (zeroed maps, quad table) and the barrier; alpha and the update stage follow.
+    //      (3) the argument block is requested;
+    //      (4) only then the LDS work (zeroed maps, quad table) and the barrier -- all of it on preloaded parameters;
+    //      (5) the argument block is waited for; alpha and the update stage follow.
     PReg<E> pr;
     const bool have = wave < ns;
     const int hg0 = ((i_lo + wave) * HW) >> 4;                      // the slice holding a sample's first group owns it
     const bool home0 = have && cb == 0 && hg0 >= gbeg && hg0 < gend;
-    sdp_load<V, E>(a, i_lo + min(wave, ns - 1), lane, home0, pr);
-    const bool wupd = V != V_PLAIN && a.t > 0 && ks == 0;
-    const long wge = (long)cb * 16 * KK + min((int)threadIdx.x, 16 * KK - 1);
-    float w_prev = 0.f, g_prev = 0.f, an_in = 0.f;
+    sdp_load_hot<V, E>(h_pk, hOO, i_lo + min(wave, ns - 1), lane, pr);
+    float an_in = 0.f;
     SdQLane q_in = {0.f, 0.f};
-    if (V != V_PLAIN && a.t > 0) {                                  // optimizer.py:155-160 / :425-430
-        q_in = sd_q_lane(a.sd, lane);
-        an_in = lane < a.sd.KS ? a.sd.anum[lane] : 0.f;
-        if (wupd) {                                                 // uniform per workgroup
-            w_prev = sd_w(a.sd, a.t - 1)[wge];
-            g_prev = a.sd.g[wge];
-        }
+    if (V != V_PLAIN && ht > 0) {                                   // optimizer.py:155-160 / :425-430 (operands of alpha)
+        q_in.head = lane < hn ? h_qs[lane] : 0.f;
+        an_in = lane < hKS ? h_anum[lane] : 0.f;
     }
-    PT_STAMP_B(a, 1);
+    PT_STAMP_B(a_arg, 1);
     f32x4 av[UM];
     if (PT_ADJ_EARLY) {
 #pragma unroll
         for (int u = 0; u < PD; ++u) {
             int qi, qp;
             quad_at(kq, wave, u, qi, qp);
-            av[u] = pt_bload4(fr, ((unsigned)qi * (unsigned)a.stride_n + (unsigned)qp) * 4u + chw4);
+            av[u] = pt_bload4(fr, ((unsigned)qi * (unsigned)h_stride + (unsigned)qp) * 4u + chw4);
         }
     }
+    __builtin_amdgcn_sched_barrier(0);                              // nothing that needs the argument block above this line
+    PtLate<Adj2Late> late = pt_late_issue<Adj2Late>(56);            // 5 pointers / longs + 4 dwords = 56 bytes
+    const int KK = hKH * hKW, PHPW = hPH * hPW;
+    const int ZB = hns_max * PHPW;                                  // hzn zeros: what masked quads gather (any tap)
+    // residual coordinate of (position (y,x), tap (u,v)) is (y-u+KH/2, x-v+KW/2); in the padded map the residual
+    // pixel (yy,xx) sits at (yy + oy, xx + ox)
+    const int oy = hKH - 1 - hKH / 2, ox = hKW - 1 - hKW / 2;
+    const int uj = j / hKW, vj = j - uj * hKW;
+    // lanes j >= K*K feed accumulator columns that are never stored: any in-range tap offset does
+    const unsigned tapoff4 = j < KK ? 4u * (unsigned)((hKH - 1 - uj) * hPW + (hKW - 1 - vj)) : 0u;
 
-    PT_STAMP_B(a, 2);
-    for (int e = threadIdx.x; e < ns * PHPW; e += blockDim.x) maps[e] = 0.f;
-    for (int e = threadIdx.x; e < a.zn; e += blockDim.x) maps[ZB + e] = 0.f;
-    PT_STAMP_B(a, 3);
+    PT_STAMP_B(a_arg, 2);
+    for (int e = threadIdx.x; e < ns * PHPW; e += (PT_ADJ_WAVES * 64)) maps[e] = 0.f;
+    for (int e = threadIdx.x; e < hzn; e += (PT_ADJ_WAVES * 64)) maps[ZB + e] = 0.f;
+    PT_STAMP_B(a_arg, 3);
     // Where a quad of positions lives does not depend on the channel or the tap: the workgroup computes it once per quad
     // (sample, feature offset, the 4 residual-map cells incl. the row wrap inside the quad) into an LDS table instead of
     // every lane redoing two divisions and the wrap selects per group -- the pass is bound by VALU issue, not by memory
@@ -684,18 +750,30 @@ __global__ __launch_bounds__(PT_ADJ_WAVES * 64) void k_adj2(Adj2Args a) {
     //   tabA[kq][wave][u]   byte offset of the quad in the feature tensor (channel 0)
     //   tabI[kq][wave][u]   byte offsets of its 4 cells in `maps` for tap (KH-1, KW-1); + tapoff4 per lane.  A masked quad
     //                       re-reads a line already fetched and points at the zero block behind the maps.
-    int* __restrict__ tabA = (int*)(maps + ZB + a.zn);
+    int* __restrict__ tabA = (int*)(maps + ZB + hzn);
     int* __restrict__ tabI = tabA + 4 * PT_ADJ_WAVES * UM;
-    for (int e = threadIdx.x; e < 4 * PT_ADJ_WAVES * UM; e += blockDim.x) {
+    for (int e = threadIdx.x; e < 4 * PT_ADJ_WAVES * UM; e += (PT_ADJ_WAVES * 64)) {
         const int tu = e % UM, tw = (e / UM) % PT_ADJ_WAVES, tk = e / (UM * PT_ADJ_WAVES);
         int i, p0;
         const bool okk = quad_at(tk, tw, tu, i, p0);
-        tabA[e] = (int)(((unsigned)i * (unsigned)a.stride_n + (unsigned)p0) * 4u);
-        const int y0 = fdiv(p0, inv_w), x0 = p0 - y0 * a.W;
+        tabA[e] = (int)(((unsigned)i * (unsigned)h_stride + (unsigned)p0) * 4u);
+        const int y0 = fdiv(p0, inv_w), x0 = p0 - y0 * hW;
         // a quad may wrap to the next feature row: one row further in the padded map is PW - W cells more
-        const int base = (i - i_lo) * PHPW + y0 * a.PW + x0, wr = a.PW - a.W;
+        const int base = (i - i_lo) * PHPW + y0 * hPW + x0, wr = hPW - hW;
 #pragma unroll
-        for (int k = 0; k < 4; ++k) tabI[4 * e + k] = 4 * (okk ? base + k + (x0 + k >= a.W ? wr : 0) : ZB);
+        for (int k = 0; k < 4; ++k) tabI[4 * e + k] = 4 * (okk ? base + k + (x0 + k >= hW ? wr : 0) : ZB);
+    }
+    const Adj2Late a = pt_late_get<Adj2Late>(late);
+    sdp_load_rest<V, E>(a, i_lo + min(wave, ns - 1), lane, home0, pr);
+    const bool wupd = V != V_PLAIN && a.t > 0 && ks == 0;
+    const long wge = (long)cb * 16 * KK + min((int)threadIdx.x, 16 * KK - 1);
+    float w_prev = 0.f, g_prev = 0.f;
+    if (V != V_PLAIN && a.t > 0) {
+        for (int k = lane + 64; k < hn; k += 64) q_in.tail += h_qs[k];          // memories of more than 64 samples
+        if (wupd) {                                                 // uniform per workgroup; consumed at the end of the kernel
+            w_prev = sd_w(a.sd, a.t - 1)[wge];
+            g_prev = a.sd.g[wge];
+        }
     }
     PT_STAMP_A(a, 1);
     PT_STAMP_B(a, 4);
@@ -728,15 +806,13 @@ __global__ __launch_bounds__(PT_ADJ_WAVES * 64) void k_adj2(Adj2Args a) {
         const float a_num = wave_sum(an_in);
         const float den = fmaxf(wave_sum(q_in.head + q_in.tail) + (a.sd.reg + a.sd.alpha_eps) * a_num, 1e-8f);
         astep = a.sd.step * (a_num / den);
-        if (wupd && (int)threadIdx.x < 16 * KK)                     // w_t = w_{t-1} - step*alpha*g   (:160)
-            a.sd.w_iters[(long)a.t * a.sd.CKK + wge] = w_prev - astep * g_prev;
     }
     if (have) sdp_compute<V, E>(a, i_lo + wave, lane, pr, astep, maps + wave * PHPW, oy, ox, home0);
     for (int sl = wave + PT_ADJ_WAVES; sl < ns; sl += PT_ADJ_WAVES) {   // more samples than waves (tiny maps)
         const int i = i_lo + sl;
         const int hg = (i * HW) >> 4;
         const bool home = cb == 0 && hg >= gbeg && hg < gend;
-        sdp_load<V, E>(a, i, lane, home, pr);
+        sdp_load<V, E>(a, h_pk, i, lane, home, pr);
         sdp_compute<V, E>(a, i, lane, pr, astep, maps + sl * PHPW, oy, ox, home);
     }
     PT_STAMP_A(a, 3);
@@ -774,6 +850,9 @@ __global__ __launch_bounds__(PT_ADJ_WAVES * 64) void k_adj2(Adj2Args a) {
         for (int w = 0; w < PT_ADJ_WAVES; ++w) s += red[w][e];
         if (tap < KK) a.gpart[(long)ks * a.C * KK + (long)(cb * 16 + row) * KK + tap] = s;
     }
+    // w_t = w_{t-1} - step*alpha*g (:160): nothing in this launch reads it, so its two loads (requested behind the feature
+    // loads, the counter retires in order) are only waited for here
+    if (wupd && (int)threadIdx.x < 16 * KK) a.sd.w_iters[(long)a.t * a.sd.CKK + wge] = w_prev - astep * g_prev;
     PT_STAMP_A(a, 7);
     PT_STAMP_B(a, 7);
 }
@@ -787,12 +866,37 @@ static void adj2_fill(const PtFast& p, Adj2Args& a, const float* feat, long stri
 }
 
 template <int V>
-static void adj2_dispatch(const PtFast& p, const Adj2Args& a, hipStream_t st) {
+static int adj2_dispatch(const PtFast& p, const Adj2Args& a, hipStream_t st) {
     dim3 grid(p.CB * p.KSPL), block(PT_ADJ_WAVES * 64);
-    if (p.E == 6) hipLaunchKernelGGL((k_adj2<V, 6, 16>), grid, block, p.adj_lds, st, a);
-    else if (p.E == 9 && p.U <= 12) hipLaunchKernelGGL((k_adj2<V, 9, 12>), grid, block, p.adj_lds, st, a);
-    else if (p.E == 9) hipLaunchKernelGGL((k_adj2<V, 9, 16>), grid, block, p.adj_lds, st, a);
-    else hipLaunchKernelGGL((k_adj2<V, 16, 16>), grid, block, p.adj_lds, st, a);
+    if (p.H > 255 || p.W > 255 || p.U > 31 || p.bpx > 15 || a.t > 127 || p.n > 65535 || p.gper > 65535 || p.OO > 65535 || p.CB > 255 ||
+        a.sd.KS > 127 || p.PH > 63 || p.PW > 63 || p.zn > 255 || p.ns_max > 63 || p.KH > 7 || p.KW > 7)
+        return PT_ERR_UNSUPPORTED;
+    const unsigned g1 = (unsigned)p.H | ((unsigned)p.W << 8) | ((unsigned)p.U << 16) | ((unsigned)p.bpx << 21) | ((unsigned)a.t << 25);
+    const unsigned g2 = (unsigned)p.n | ((unsigned)p.gper << 16);
+    const unsigned g3 = (unsigned)p.OO | ((unsigned)p.CB << 16) | ((unsigned)(V == V_PLAIN ? 0 : a.sd.KS) << 24);
+    const unsigned g4 = (unsigned)p.PH | ((unsigned)p.PW << 6) | ((unsigned)p.zn << 12) | ((unsigned)p.ns_max << 20) | ((unsigned)p.KH << 26) |
+                        ((unsigned)p.KW << 29);
+    const float* pkp = V == V_PLAIN ? a.inp : a.sd.pk;
+    const float* qsp = V == V_PLAIN ? nullptr : a.sd.qs;
+    const float* anp = V == V_PLAIN ? nullptr : a.sd.anum;
+    Adj2Late l = {};
+    l.gpart = a.gpart; l.C = a.C; l.KH = a.KH; l.KW = a.KW; l.OH = a.OH; l.OW = a.OW; l.PH = a.PH; l.PW = a.PW;
+    l.ns_max = a.ns_max; l.zn = a.zn; l.t = a.t; l.want_loss = a.want_loss;
+    const SdArgs& sd = a.sd;
+    l.sd.n = sd.n; l.sd.CKK = sd.CKK; l.sd.has_sw = sd.has_sw; l.sd.has_softmax_reg = sd.has_softmax_reg;
+    l.sd.step = sd.step; l.sd.reg = sd.reg; l.sd.alpha_eps = sd.alpha_eps; l.sd.act_param = sd.act_param; l.sd.softmax_reg = sd.softmax_reg;
+    l.sd.sw = sd.sw; l.sd.s_in = sd.s_in; l.sd.w0 = sd.w0; l.sd.mask = sd.mask; l.sd.sws = sd.sws; l.sd.s = sd.s; l.sd.sg = sd.sg;
+    l.sd.lms = sd.lms; l.sd.g = sd.g; l.sd.lossp = sd.lossp; l.sd.w_iters = sd.w_iters;
+#ifdef PT_STAMPS
+    l.stamps = a.stamps;
+#endif
+#define PT_A2_HOT a.feat, a.stride_n, pkp, qsp, anp, g1, g2, g3, g4, l
+    if (p.E == 6) hipLaunchKernelGGL((k_adj2<V, 6, 16>), grid, block, p.adj_lds, st, PT_A2_HOT);
+    else if (p.E == 9 && p.U <= 12) hipLaunchKernelGGL((k_adj2<V, 9, 12>), grid, block, p.adj_lds, st, PT_A2_HOT);
+    else if (p.E == 9) hipLaunchKernelGGL((k_adj2<V, 9, 16>), grid, block, p.adj_lds, st, PT_A2_HOT);
+    else hipLaunchKernelGGL((k_adj2<V, 16, 16>), grid, block, p.adj_lds, st, PT_A2_HOT);
+#undef PT_A2_HOT
+    return PT_OK;
 }
 
 int pt_launch_adj2_plain(const PtFast& p, const float* feat, long stride_n, const float* inp, float* gpart,
@@ -802,7 +906,8 @@ int pt_launch_adj2_plain(const PtFast& p, const float* feat, long stride_n, cons
     adj2_fill(p, a, feat, stride_n, gpart);
     a.inp = inp;
     a.sd = SdArgs();
-    adj2_dispatch<V_PLAIN>(p, a, st);
+    const int rc = adj2_dispatch<V_PLAIN>(p, a, st);
+    if (rc) return rc;
     PT_CHECK_LAUNCH();
     return PT_OK;
 }
@@ -815,10 +920,12 @@ int pt_launch_adj2_sd(const PtFast& p, const float* feat, long stride_n, const S
     a.sd = sd;
     a.t = t;
     a.want_loss = want_loss;
-    if (sd.kind == PT_SD_PRDIMP) adj2_dispatch<V_PRDIMP>(p, a, st);
-    else if (sd.kind == PT_SD_DIMP_L2) adj2_dispatch<V_L2>(p, a, st);
-    else if (sd.score_act == PT_ACT_BENTPAR) adj2_dispatch<V_DIMP_BENT>(p, a, st);
-    else adj2_dispatch<V_DIMP_RELU>(p, a, st);
+    int rc;
+    if (sd.kind == PT_SD_PRDIMP) rc = adj2_dispatch<V_PRDIMP>(p, a, st);
+    else if (sd.kind == PT_SD_DIMP_L2) rc = adj2_dispatch<V_L2>(p, a, st);
+    else if (sd.score_act == PT_ACT_BENTPAR) rc = adj2_dispatch<V_DIMP_BENT>(p, a, st);
+    else rc = adj2_dispatch<V_DIMP_RELU>(p, a, st);
+    if (rc) return rc;
     PT_CHECK_LAUNCH();
     return PT_OK;
 }

@@ -77,18 +77,6 @@ int pt_launch_corr2(const PtFast& p, const float* feat, long stride_n, const flo
 int pt_launch_adj2_plain(const PtFast& p, const float* feat, long stride_n, const float* inp, float* gpart,
                          hipStream_t st);
 struct SdArgs;
-// ---- position-band correlation (band_corr.hip): workgroup = (sample, band of output rows), all channels ----------
-struct PtBand {
-    int ok, B, SPX, TL, NKW, threads, TP;      // bands per sample, samples per XCD, 64-position tiles, k-steps per wave
-    int in0[8], in1[8], out0[8], out1[8];      // input / output row range of each band
-    size_t lds;
-};
-PtBand pt_band_plan(const PtFast& f);
-// fuse == nullptr: scores of `filt` -> s_out (n, OH*OW), complete.  fuse != nullptr: filter operand = reduced gradient,
-// F g -> sd->sg, curvature partials -> sd->qs[n][B][2], packed update operands -> sd->pk (what k_fast_sgq produced)
-int pt_launch_corr3(const PtFast& f, const PtBand& p, const float* feat, long stride_n, const float* filt, float* s_out,
-                    hipStream_t st, const PtCorrFuse* fuse = nullptr, const SdArgs* sd = nullptr, int slot = -1,
-                    const float* src = nullptr, float* copy_dst = nullptr);
 int pt_launch_adj2_sd(const PtFast& p, const float* feat, long stride_n, const SdArgs& sd, int t, int want_loss,
                       hipStream_t st);
 

@@ -21,9 +21,7 @@ struct SdArgs {
     float *R;                    // (NG,256)
     float *gpart, *g;            // (KSPL,CKK), (CKK)
     float *anum;                 // (KS) per-channel-slice |g|^2 (written by the corr(g) pass)
-    float *qs;                   // (n) per-sample curvature terms, or with QB > 0 the band partials (n, QB, 2) of k_corr3
-    int QB;                      // 0: qs[i] = q_i.  > 0: DiMP kinds q_i = sum_b qs[i][b][0]; PrDiMP q_i = swp_i * max(A - B^2, 0),
-                                 //    A = sum_b qs[i][b][0] = sum_o P (F g)^2,  B = sum_b qs[i][b][1] = sum_o P (F g)
+    float *qs;                   // (n) per-sample curvature terms q_i
     float *lossp;                // (T+1, n)
     float *w_iters;              // (T+1, CKK)  caller's buffer; iterate 0 lives at w0
     const float *w0;             // initial filter
@@ -36,7 +34,8 @@ struct SdArgs {
     float *cls_scores, *cls_peak, *cls_bb;
 };
 
-__device__ __forceinline__ const float* sd_w(const SdArgs& a, int t) {
+template <typename A>
+__device__ __forceinline__ const float* sd_w(const A& a, int t) {
     return t == 0 ? a.w0 : a.w_iters + (long)t * a.CKK;
 }
 
@@ -189,31 +188,17 @@ __device__ __forceinline__ void act_pair(int score_act, float bpar, float x, flo
 // nothing waits for here -- the k_adj2 prologue keeps it in flight behind its feature loads) + tail (samples lane + 64, ...;
 // only memories of more than 64 samples enter the loop).  Callers add head + tail.
 struct SdQLane { float head, tail; };
-__device__ __forceinline__ SdQLane sd_q_lane(const SdArgs& a, int lane) {
+__device__ __forceinline__ SdQLane sd_q_lane(const float* __restrict__ qs, int n, int lane) {
     SdQLane r = {0.f, 0.f};
-    if (a.QB == 0) {
-        r.head = lane < a.n ? a.qs[lane] : 0.f;
-        for (int k = lane + 64; k < a.n; k += 64) r.tail += a.qs[k];
-        return r;
-    }
-    for (int k = lane; k < a.n; k += 64) {
-        const float* q = a.qs + (long)k * a.QB * 2;
-        float A = 0.f, B = 0.f;
-        for (int b = 0; b < a.QB; ++b) { A += q[2 * b]; B += q[2 * b + 1]; }
-        if (a.kind == PT_SD_PRDIMP) {
-            const float swp = a.has_sw ? a.sw[k] : 1.0f / (float)a.n;
-            r.tail += swp * fmaxf(A - B * B, 0.f);                                  // optimizer.py:419-422
-        } else {
-            r.tail += A;
-        }
-    }
+    r.head = lane < n ? qs[lane] : 0.f;
+    for (int k = lane + 64; k < n; k += 64) r.tail += qs[k];
     return r;
 }
 
 // optimizer.py:155-160 / :425-430: alpha = |g|^2 / max(sum_i q_i + (reg+eps)|g|^2, 1e-8), times the step length;
 // from one wave (every lane gets it): wave-parallel fixed-order sums, identical in every workgroup.
 __device__ __forceinline__ float sd_alpha_step_wave(const SdArgs& a, int lane) {
-    const SdQLane ql = sd_q_lane(a, lane);
+    const SdQLane ql = sd_q_lane(a.qs, a.n, lane);
     float den = wave_sum(ql.head + ql.tail);
     const float a_num = wave_sum(lane < a.KS ? a.anum[lane] : 0.f);
     den = fmaxf(den + (a.reg + a.alpha_eps) * a_num, 1e-8f);

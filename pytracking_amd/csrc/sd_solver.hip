@@ -207,6 +207,8 @@ static SdCarve sd_carve(const PtPlan& p, int max_iter) {
 // ----------------------------------------------------------------------------------------------------
 // fast path (fast_passes.hip): per iteration  adj2 [update prologue fused] -> corr2 [gradient reduction fused] -> SGQ
 // ----------------------------------------------------------------------------------------------------
+static const float* sd_w_host(const SdArgs& a, int t) { return t == 0 ? a.w0 : a.w_iters + (long)t * a.CKK; }
+
 struct FastCarve {
     size_t label, mask, sws, lms, pk, s0, s1, sg, spart, gpart, g, anum, qs, lossp, total;
 };
@@ -222,20 +224,10 @@ static FastCarve fast_carve(const PtFast& f, int max_iter) {
     c.gpart = take(pt_fast_gpart_floats(f));
     c.g = take((size_t)f.C * f.KK);
     c.anum = take(64);
-    c.qs = take((size_t)f.n * 16);                      // per-sample terms, or the band partials (n, <= 8 bands, 2)
+    c.qs = take((size_t)f.n);
     c.lossp = take((size_t)(max_iter + 1) * f.n);
     c.total = off;
     return c;
-}
-
-// Position-band correlation (band_corr.hip) instead of k_corr2 + k_fast_sgq inside the solve: measured in round 3 and NOT
-// the default -- it removes the five pointwise launches of a solve, but every workgroup then has to take in all C channels
-// of the reduced gradient (8 partials: 288 KB) next to 1.5x its share of the features, and with 200 workgroups on 200 CUs
-// the pass is bound by what ONE CU can ingest: 15.2 us against 10.1 + 4.9 us for k_corr2 + k_fast_sgq
-// (profiles/r03c_band_corr_experiment.txt).  PT_SD_BAND=1 in the environment selects it (parity-tested).
-static bool sd_use_band(const PtBand& b) {
-    const char* e = std::getenv("PT_SD_BAND");
-    return b.ok && e && e[0] == '1';
 }
 
 // packed operands of the update stage that k_adj2 runs as its prologue (PReg in fast_passes.hip)
@@ -305,8 +297,8 @@ __global__ __launch_bounds__(512) void k_fast_sgq(SdArgs a) {
 }
 
 // ----------------------------------------------------------------------------------------------------
-// Pointwise stages of the fast path, one memory round trip each (round 3).  The first versions above (kept for the band
-// path and as the reference of the parity tests' history) read their operands where the reference's statements use them: the
+// Pointwise stages of the fast path, one memory round trip each (round 3).  The first versions above (kept for
+// look-up tables too large for LDS and as the reference of the parity tests' history) read their operands where the reference's statements use them: the
 // compiler must keep a load behind every earlier store that may alias it, so k_fast_sgq was three dependent round trips
 // (slices -> s, mask -> label, sws) and k_fast_init five.  Here every operand of an element is requested before the first
 // wait, values stay in registers between the steps, and all stores come last; one element per thread (blockDim >= OO).
@@ -326,74 +318,116 @@ __device__ __forceinline__ float pw_sum_slices(const SdArgs& a, const float (&v)
     return s;
 }
 
-// F g = sum of the slices; per-sample curvature term (optimizer.py:151-156 / :416-422); packed operands for k_adj2
-__global__ __launch_bounds__(1024) void k_fast_sgq2(SdArgs a) {
-    extern __shared__ __attribute__((aligned(16))) float lds[];
+// F g = sum of the slices; per-sample curvature term (optimizer.py:151-156 / :416-422); packed operands for k_adj2.
+// The pointers of the LOADS and the sizes are scalar kernel parameters (preloaded into SGPRs at wave launch, see
+// fast_passes.hip: pt_late_issue); what the stores need comes in the late block.
+//   DiMP kinds: p3 = lms {label, mask, sws, -};   PrDiMP: p3 = softmax P (mask), p4 = label density
+//   pa = n | OO << 16;   pb = KS | kind << 8 | score_act << 12 | has_sw << 16
+struct SgqLate { float *sg, *pk, *qs; const float* sw; };
+__global__ __launch_bounds__(1024) void k_fast_sgq2(const float* __restrict__ spart, const float* __restrict__ sp, const float* __restrict__ p3,
+                                                    const float* __restrict__ p4, unsigned pa, unsigned pb, float act_param, SgqLate l_arg) {
     __shared__ float scratch[16];
+    const int n = (int)(pa & 0xffffu), OO = (int)(pa >> 16);
+    const int KS = (int)(pb & 255u), kind = (int)((pb >> 8) & 15u), score_act = (int)((pb >> 12) & 15u);
+    const bool has_sw = ((pb >> 16) & 1u) != 0;
     const int i = blockIdx.x, o = threadIdx.x;
-    const bool ok = o < a.OO;
-    const int oc = min(o, a.OO - 1);
-    const long q = (long)i * a.OO + oc;
+    const bool ok = o < OO;
+    const int oc = min(o, OO - 1);
+    const long q = (long)i * OO + oc;
+    const int nthreads = ((OO + 63) >> 6) << 6;
     float v[PT_PW_MAXKS];
-    pw_load_slices(a, i, oc, v);
-    const float sv = a.s[q];
-    if (a.kind != PT_SD_PRDIMP) {
-        const f32x4 lm = ((const f32x4*)a.lms)[q];                                  // {label, mask, sws, -}
-        const float sgv = pw_sum_slices(a, v);
-        const int sact = a.kind == PT_SD_DIMP_L2 ? 2 : a.score_act;
+    {
+        const float* p = spart + q;
+        const long st = (long)n * OO;
+#pragma unroll
+        for (int k = 0; k < PT_PW_MAXKS; ++k) v[k] = p[(long)min(k, KS - 1) * st];
+    }
+    const float sv = sp[q];
+    f32x4 lm = {0, 0, 0, 0};
+    float P = 0.f, L = 0.f;
+    if (kind != PT_SD_PRDIMP) lm = ((const f32x4*)p3)[q];
+    else { P = p3[q]; L = p4[q]; }
+    __builtin_amdgcn_sched_barrier(0);
+    const SgqLate l = pt_late_args<SgqLate>(48);                    // 4 pointers + 3 dwords = 44 bytes, 8-aligned
+    float sgv = 0.f;
+#pragma unroll
+    for (int k = 0; k < PT_PW_MAXKS; ++k) sgv += k < KS ? v[k] : 0.f;           // fixed order
+    if (kind != PT_SD_PRDIMP) {
+        const int sact = kind == PT_SD_DIMP_L2 ? 2 : score_act;
         float act, der;
-        act_pair(sact, a.act_param, sv, lm[1], act, der);
+        act_pair(sact, act_param, sv, lm[1], act, der);
         const float qq = lm[2] * (der * sgv);                                       // :151-152
-        const float tot = block_sum(ok ? qq * qq : 0.f, scratch);
+        const float tot = block_sum(ok ? qq * qq : 0.f, scratch, nthreads);
         if (ok) {
-            a.sg[q] = sgv;
+            l.sg[q] = sgv;
             f32x4 pk;
-            if (a.kind == PT_SD_DIMP && a.score_act == PT_ACT_BENTPAR) pk = (f32x4){sv, sgv, lm[0], lm[1]};
+            if (kind == PT_SD_DIMP && score_act == PT_ACT_BENTPAR) pk = (f32x4){sv, sgv, lm[0], lm[1]};
             else { const float w2 = lm[2] * lm[2]; pk = (f32x4){w2 * sv, w2 * sgv, w2 * lm[0], lm[1]}; }
-            ((f32x4*)a.pk)[q] = pk;
+            ((f32x4*)l.pk)[q] = pk;
         }
-        if (o == 0) a.qs[i] = tot;
+        if (o == 0) l.qs[i] = tot;
     } else {
-        const float P = a.mask[q], L = a.label[q];
-        const float swp = a.has_sw ? a.sw[i] : 1.0f / (float)a.n;
-        const float sgv = pw_sum_slices(a, v);
-        const float tot = block_sum(ok ? P * sgv : 0.f, scratch);                   // :419
-        const float ghg = block_sum(ok ? sgv * (P * sgv - P * tot) : 0.f, scratch); // :420
+        const float swp = has_sw ? l.sw[i] : 1.0f / (float)n;
+        const float tot = block_sum(ok ? P * sgv : 0.f, scratch, nthreads);                   // :419
+        const float ghg = block_sum(ok ? sgv * (P * sgv - P * tot) : 0.f, scratch, nthreads); // :420
         if (ok) {
-            a.sg[q] = sgv;
-            ((f32x4*)a.pk)[q] = (f32x4){sv, sgv, L, 0.f};
+            l.sg[q] = sgv;
+            ((f32x4*)l.pk)[q] = (f32x4){sv, sgv, L, 0.f};
         }
-        if (o == 0) a.qs[i] = swp * fmaxf(ghg, 0.f);                                // :421-422
+        if (o == 0) l.qs[i] = swp * fmaxf(ghg, 0.f);                                // :421-422
     }
 }
 
 // s_0 = sum of the slices; classification epilogue of the inserted slot (its score row IS s_0 of that sample);
-// label / mask / weight maps (optimizer.py:111-125, 201-208, 331-353); packed operands for k_adj2
-__global__ __launch_bounds__(1024) void k_fast_init2(SdArgs a) {
+// label / mask / weight maps (optimizer.py:111-125, 201-208, 331-353); packed operands for k_adj2.
+// Scalar kernel parameters (preloaded) = what the first loads need; the rest in the late block.
+//   pa = n | OO << 16;  pb = KS | kind << 8 | cls_slot << 12 (0xfffff: none);  pc = OW | K << 12 | num_bins << 16
+struct InitLate {
+    const float *label_lut, *mask_lut, *spatial_lut;
+    float *s, *label, *mask, *sws, *lms, *pk, *cls_scores, *cls_peak, *cls_bb;
+    int OH, score_act, mask_act, normalize_label;
+    float bin_disp, gauss_sigma, hinge_thr, uni_weight, label_shrink, label_thr;
+};
+static_assert(sizeof(InitLate) <= 3 * 64, "InitLate: three 16-dword blocks");
+__global__ __launch_bounds__(1024) void k_fast_init2(const float* __restrict__ spart, const float* __restrict__ bb, const float* __restrict__ swp_,
+                                                     unsigned pa, unsigned pb, unsigned pc, float feat_stride, InitLate l_arg) {
     extern __shared__ __attribute__((aligned(16))) float lut[];    // DiMP: label | mask | spatial look-up tables
     __shared__ float scratch[16];
     __shared__ float bv[16];
     __shared__ int bi[16];
     __shared__ float bbs[4];
+    const int n = (int)(pa & 0xffffu), OO = (int)(pa >> 16);
+    const int KS = (int)(pb & 255u), kind = (int)((pb >> 8) & 15u), cls_slot = (int)(pb >> 12);
+    const int OW = (int)(pc & 0xfffu), K = (int)((pc >> 12) & 15u), num_bins = (int)(pc >> 16);
     const int i = blockIdx.x, o = threadIdx.x;
-    const bool ok = o < a.OO;
-    const int oc = min(o, a.OO - 1);
-    const long q = (long)i * a.OO + oc;
+    const bool ok = o < OO;
+    const int oc = min(o, OO - 1);
+    const long q = (long)i * OO + oc;
+    const int nthreads = ((OO + 63) >> 6) << 6;
     // ---- everything this element needs, requested at once
     float v[PT_PW_MAXKS];
-    pw_load_slices(a, i, oc, v);
-    const float* bp = a.bb + 4 * i;
+    {
+        const float* p = spart + q;
+        const long st = (long)n * OO;
+#pragma unroll
+        for (int k = 0; k < PT_PW_MAXKS; ++k) v[k] = p[(long)min(k, KS - 1) * st];
+    }
+    const float* bp = bb + 4 * i;
     float b0 = bp[0], b1 = bp[1], b2 = bp[2], b3 = bp[3];
-    const float swv = a.has_sw ? a.sw[i] : 1.0f / (float)a.n;
-    if (a.kind == PT_SD_DIMP) {
-        for (int e = o; e < 3 * a.num_bins; e += blockDim.x) {
-            const int t = e / a.num_bins, k = e - t * a.num_bins;
-            lut[e] = (t == 0 ? a.label_lut : (t == 1 ? a.mask_lut : a.spatial_lut))[k];
+    const float swv = swp_ ? swp_[i] : 1.0f / (float)n;
+    __builtin_amdgcn_sched_barrier(0);
+    const InitLate l = pt_late_args<InitLate>(40);                  // 3 pointers + 4 dwords = 40 bytes
+    if (kind == PT_SD_DIMP) {
+        for (int e = o; e < 3 * num_bins; e += nthreads) {
+            const int t = e / num_bins, k = e - t * num_bins;
+            lut[e] = (t == 0 ? l.label_lut : (t == 1 ? l.mask_lut : l.spatial_lut))[k];
         }
     }
-    const float s0 = pw_sum_slices(a, v);
+    float s0 = 0.f;
+#pragma unroll
+    for (int k = 0; k < PT_PW_MAXKS; ++k) s0 += k < KS ? v[k] : 0.f;            // fixed order
     // ---- classification of the test frame (pytracking/libs/dcf.py:156-164: first maximum) re-centres this sample's box
-    const bool cls = a.cls_spart != nullptr && i == a.cls_slot;     // uniform per workgroup
+    const bool cls = i == cls_slot;                                 // uniform per workgroup
     if (cls) {
         float best = ok ? s0 : -INFINITY;
         int besti = ok ? o : 0x7fffffff;
@@ -403,97 +437,107 @@ __global__ __launch_bounds__(1024) void k_fast_init2(SdArgs a) {
             const int oi = __shfl_xor(besti, off, 64);
             if (ov > best || (ov == best && oi < besti)) { best = ov; besti = oi; }
         }
-        const int lane = o & 63, wave = o >> 6, nw = (blockDim.x + 63) >> 6;
+        const int lane = o & 63, wave = o >> 6, nw = nthreads >> 6;
         if (lane == 0) { bv[wave] = best; bi[wave] = besti; }
         __syncthreads();
         if (o == 0) {
             for (int w = 1; w < nw; ++w)
                 if (bv[w] > best || (bv[w] == best && bi[w] < besti)) { best = bv[w]; besti = bi[w]; }
-            const int row = besti / a.OW, col = besti - row * a.OW;
-            const float off = (float)(a.K % 2) * 0.5f;
-            bbs[0] = ((float)col + off) * a.feat_stride - b2 * 0.5f;
-            bbs[1] = ((float)row + off) * a.feat_stride - b3 * 0.5f;
-            a.cls_peak[0] = (float)row;
-            a.cls_peak[1] = (float)col;
-            a.cls_bb[4 * a.cls_slot] = bbs[0];
-            a.cls_bb[4 * a.cls_slot + 1] = bbs[1];
+            const int row = besti / OW, col = besti - row * OW;
+            const float off = (float)(K % 2) * 0.5f;
+            bbs[0] = ((float)col + off) * feat_stride - b2 * 0.5f;
+            bbs[1] = ((float)row + off) * feat_stride - b3 * 0.5f;
+            l.cls_peak[0] = (float)row;
+            l.cls_peak[1] = (float)col;
+            l.cls_bb[4 * cls_slot] = bbs[0];
+            l.cls_bb[4 * cls_slot + 1] = bbs[1];
         }
         __syncthreads();
         b0 = bbs[0];
         b1 = bbs[1];
-        if (ok) a.cls_scores[o] = s0;
+        if (ok) l.cls_scores[o] = s0;
     } else {
         __syncthreads();                                            // look-up tables staged
     }
     // ---- maps
-    const float off = (float)(a.K % 2) * 0.5f;
-    const float ctr_r = (b1 + b3 * 0.5f) / a.feat_stride - off;     // optimizer.py:112-113 (flip -> row first)
-    const float ctr_c = (b0 + b2 * 0.5f) / a.feat_stride - off;
-    const int y = oc / a.OW, x = oc - y * a.OW;
+    const float off = (float)(K % 2) * 0.5f;
+    const float ctr_r = (b1 + b3 * 0.5f) / feat_stride - off;       // optimizer.py:112-113 (flip -> row first)
+    const float ctr_c = (b0 + b2 * 0.5f) / feat_stride - off;
+    const int y = oc / OW, x = oc - y * OW;
     const float d0 = (float)y - ctr_r, d1 = (float)x - ctr_c;
     float lb, m = 0.f, sw = 0.f;
-    if (a.kind == PT_SD_DIMP) {
-        const float t = sqrtf(d0 * d0 + d1 * d1) / a.bin_disp;
-        lb = pl_lut(lut, a.num_bins, t);
-        m = pl_lut(lut + a.num_bins, a.num_bins, t);
-        if (a.mask_act == PT_MASK_SIGMOID) m = 1.0f / (1.0f + expf(-m));
-        sw = sqrtf(swv) * pl_lut(lut + 2 * a.num_bins, a.num_bins, t);             // :122-125
-    } else if (a.kind == PT_SD_DIMP_L2) {
-        const float coef = -1.0f / (2.0f * a.gauss_sigma * a.gauss_sigma);
+    if (kind == PT_SD_DIMP) {
+        const float t = sqrtf(d0 * d0 + d1 * d1) / l.bin_disp;
+        lb = pl_lut(lut, num_bins, t);
+        m = pl_lut(lut + num_bins, num_bins, t);
+        if (l.mask_act == PT_MASK_SIGMOID) m = 1.0f / (1.0f + expf(-m));
+        sw = sqrtf(swv) * pl_lut(lut + 2 * num_bins, num_bins, t);                  // :122-125
+    } else if (kind == PT_SD_DIMP_L2) {
+        const float coef = -1.0f / (2.0f * l.gauss_sigma * l.gauss_sigma);
         const float gss = expf(coef * d0 * d0) * expf(coef * d1 * d1);              // :201-208
-        m = gss > a.hinge_thr ? 1.0f : 0.0f;                                        // :245
+        m = gss > l.hinge_thr ? 1.0f : 0.0f;                                        // :245
         lb = gss * m;
         sw = sqrtf(swv);                                                            // :249-252
     } else {                                                                        // PrDiMP label density, :331-353
         float gss;
-        if (a.gauss_sigma == 0.f) {
+        if (l.gauss_sigma == 0.f) {
             // one-hot at the grid point closest to the centre (first minimum per axis, as the reference's argmin)
             int r0 = 0, c0 = 0;
             float m0 = INFINITY, m1 = INFINITY;
-            for (int yy = 0; yy < a.OH; ++yy) { float d = ((float)yy - ctr_r); d *= d; if (d < m0) { m0 = d; r0 = yy; } }
-            for (int xx = 0; xx < a.OW; ++xx) { float d = ((float)xx - ctr_c); d *= d; if (d < m1) { m1 = d; c0 = xx; } }
+            for (int yy = 0; yy < l.OH; ++yy) { float d = ((float)yy - ctr_r); d *= d; if (d < m0) { m0 = d; r0 = yy; } }
+            for (int xx = 0; xx < OW; ++xx) { float d = ((float)xx - ctr_c); d *= d; if (d < m1) { m1 = d; c0 = xx; } }
             gss = (y == r0 && x == c0) ? 1.0f : 0.0f;
         } else {
-            const float s2 = a.gauss_sigma * a.gauss_sigma, coef = -1.0f / (2.0f * s2);
+            const float s2 = l.gauss_sigma * l.gauss_sigma, coef = -1.0f / (2.0f * s2);
             gss = (expf(coef * d0 * d0) / (2.0f * 3.14159265358979323846f * s2)) * expf(coef * d1 * d1);
         }
-        gss = gss > a.label_thr ? gss : 0.f;
-        const float tot = block_sum(ok ? gss : 0.f, scratch);
-        const float inv = a.normalize_label ? 1.0f / (tot + 1e-8f) : 1.0f;
-        const float uni = a.uni_weight / (float)a.OO;
-        lb = (1.0f - a.label_shrink) * ((1.0f - a.uni_weight) * (gss * inv) + uni);
+        gss = gss > l.label_thr ? gss : 0.f;
+        const float tot = block_sum(ok ? gss : 0.f, scratch, nthreads);
+        const float inv = l.normalize_label ? 1.0f / (tot + 1e-8f) : 1.0f;
+        const float uni = l.uni_weight / (float)OO;
+        lb = (1.0f - l.label_shrink) * ((1.0f - l.uni_weight) * (gss * inv) + uni);
     }
     // ---- stores
     if (!ok) return;
-    a.s[q] = s0;
-    a.label[q] = lb;
+    l.s[q] = s0;
+    l.label[q] = lb;
     f32x4 pk;
-    if (a.kind == PT_SD_PRDIMP) {
+    if (kind == PT_SD_PRDIMP) {
         pk = (f32x4){s0, 0.f, lb, 0.f};
     } else {
-        a.mask[q] = m;
-        a.sws[q] = sw;
-        ((f32x4*)a.lms)[q] = (f32x4){lb, m, sw, 0.f};
-        if (a.kind == PT_SD_DIMP && a.score_act == PT_ACT_BENTPAR) pk = (f32x4){s0, 0.f, lb, m};
+        l.mask[q] = m;
+        l.sws[q] = sw;
+        ((f32x4*)l.lms)[q] = (f32x4){lb, m, sw, 0.f};
+        if (kind == PT_SD_DIMP && l.score_act == PT_ACT_BENTPAR) pk = (f32x4){s0, 0.f, lb, m};
         else { const float w2 = sw * sw; pk = (f32x4){w2 * s0, w2 * 0.f, w2 * lb, m}; }
     }
-    ((f32x4*)a.pk)[q] = pk;
+    ((f32x4*)l.pk)[q] = pk;
 }
 
 // the last filter update of a solve, w_T = w_{T-1} - step*alpha*g (optimizer.py:160): its operands are requested together with the
-// inputs of alpha; n workgroups, each a slice of the filter
-__global__ __launch_bounds__(512) void k_fast_final(SdArgs a, int t) {
+// inputs of alpha; n workgroups, each a slice of the filter.  Every argument is a scalar kernel parameter: with
+// -amdgpu-kernarg-preload-count the hardware delivers them in SGPRs at wave launch, no scalar-load round trip in front of the
+// first vector load (experiment of round 3: does the ~4 us floor of a dependent tiny kernel move?).
+__global__ __launch_bounds__(512) void k_fast_final(const float* __restrict__ wp, const float* __restrict__ g, float* __restrict__ wn,
+                                                    const float* __restrict__ qs, const float* __restrict__ anum, int n, int CKK, int KS,
+                                                    float step, float reg_eps) {
     const int i = blockIdx.x, lane = threadIdx.x & 63;
-    const int chunk = (a.CKK + a.n - 1) / a.n;
-    const float* wp = sd_w(a, t - 1);
-    float* wn = a.w_final ? a.w_final : a.w_iters + (long)t * a.CKK;
+    const int chunk = (CKK + n - 1) / n;
     const int e = i * chunk + threadIdx.x;
-    const bool ok = (int)threadIdx.x < chunk && e < a.CKK;
+    const bool ok = (int)threadIdx.x < chunk && e < CKK;
     const int ec = ok ? e : 0;
-    const float wv = wp[ec], gv = a.g[ec];
-    const float astep = sd_alpha_step_wave(a, lane);
+    const float wv = wp[ec], gv = g[ec];
+    // alpha as sd_alpha_step_wave computes it: same operands, same order
+    const float qh = lane < n ? qs[lane] : 0.f;
+    float qt = 0.f;
+    for (int k = lane + 64; k < n; k += 64) qt += qs[k];
+    const float an = lane < KS ? anum[lane] : 0.f;
+    float den = wave_sum(qh + qt);
+    const float a_num = wave_sum(an);
+    den = fmaxf(den + reg_eps * a_num, 1e-8f);
+    const float astep = step * (a_num / den);
     if (ok) wn[e] = wv - astep * gv;
-    for (int e2 = e + blockDim.x; e2 < min(a.CKK, (i + 1) * chunk); e2 += blockDim.x) wn[e2] = wp[e2] - astep * a.g[e2];
+    for (int e2 = e + blockDim.x; e2 < min(CKK, (i + 1) * chunk); e2 += blockDim.x) wn[e2] = wp[e2] - astep * g[e2];
 }
 
 #define PT_SD_MAX_ITER 64
@@ -531,7 +575,7 @@ static int sd_fast_setup(const PtFast& f, const pt_sd_params* prm, const float* 
     if (ws_bytes < cv.total * sizeof(float) || ((uintptr_t)ws % 256) != 0) return PT_ERR_WORKSPACE;
     float* base = (float*)ws;
     sd_fill_params(a, prm, bb, sample_weight, f.n, f.C, f.H, f.W, f.KH, f.OH, f.OW);
-    a.KS = f.KSC; a.KSPL = f.KSPL; a.QB = 0;
+    a.KS = f.KSC; a.KSPL = f.KSPL;
     a.label = base + cv.label; a.mask = base + cv.mask; a.sws = base + cv.sws; a.sg = base + cv.sg;
     a.lms = base + cv.lms; a.pk = base + cv.pk;
     a.spart = base + cv.spart; a.gpart = base + cv.gpart; a.g = base + cv.g; a.anum = base + cv.anum;
@@ -551,9 +595,6 @@ static int sd_solve_fast(const PtFast& f, const pt_sd_params* prm, const float* 
     if (rc) return rc;
     const int n = f.n;
     const int slot = cls ? cls->slot : -1;
-    const PtBand bp = pt_band_plan(f);
-    const bool band = sd_use_band(bp);
-    if (band) { a.KS = 1; a.QB = bp.B; }                         // complete score maps, one |g|^2 word, band curvature partials
     if (cls) {
         // the inserted sample's scores under w_in ARE the classification scores of the test frame
         a.cls_spart = a.spart + (long)slot * a.OO; a.cls_KS = a.KS; a.cls_stride = (long)n * a.OO; a.cls_slot = slot;
@@ -568,13 +609,25 @@ static int sd_solve_fast(const PtFast& f, const pt_sd_params* prm, const float* 
     if (num_iter == 0 && !want_loss && !cls) return PT_OK;
 
     float* copy_dst = src ? const_cast<float*>(feat) + (long)slot * stride_n : nullptr;
-    if (band) rc = pt_launch_corr3(f, bp, feat, stride_n, w_in, a.spart, st, nullptr, nullptr, src ? slot : -1, src, copy_dst);
-    else rc = pt_launch_corr2(f, feat, stride_n, w_in, a.spart, st, nullptr, src ? slot : -1, src, copy_dst);
+    rc = pt_launch_corr2(f, feat, stride_n, w_in, a.spart, st, nullptr, src ? slot : -1, src, copy_dst);
     if (rc) return rc;
     const int pw_threads = ((a.OO + 63) / 64) * 64;                 // one element per thread (OO <= 1024 on this path)
     const size_t lut_lds = a.kind == PT_SD_DIMP ? (size_t)3 * a.num_bins * sizeof(float) : 0;
-    const bool pw2 = !band && a.KS <= PT_PW_MAXKS && lut_lds <= 48 * 1024;
-    if (pw2) hipLaunchKernelGGL(k_fast_init2, dim3(n), dim3(pw_threads), lut_lds, st, a);
+    const bool pw2 = a.KS <= PT_PW_MAXKS && lut_lds <= 48 * 1024;
+    if (pw2) {
+        if (n > 65535 || a.OO > 65535 || a.OW > 4095 || a.K > 15 || a.num_bins > 65535 || n >= 0xfffff) return PT_ERR_UNSUPPORTED;
+        InitLate il;
+        il.label_lut = a.label_lut; il.mask_lut = a.mask_lut; il.spatial_lut = a.spatial_lut;
+        il.s = a.s; il.label = a.label; il.mask = a.mask; il.sws = a.sws; il.lms = a.lms; il.pk = a.pk;
+        il.cls_scores = a.cls_scores; il.cls_peak = a.cls_peak; il.cls_bb = a.cls_bb;
+        il.OH = a.OH; il.score_act = a.score_act; il.mask_act = a.mask_act; il.normalize_label = a.normalize_label;
+        il.bin_disp = a.bin_disp; il.gauss_sigma = a.gauss_sigma; il.hinge_thr = a.hinge_thr; il.uni_weight = a.uni_weight;
+        il.label_shrink = a.label_shrink; il.label_thr = a.label_thr;
+        const unsigned cslot = (a.cls_spart && a.cls_slot >= 0) ? (unsigned)a.cls_slot : 0xfffffu;
+        hipLaunchKernelGGL(k_fast_init2, dim3(n), dim3(pw_threads), lut_lds, st, (const float*)a.spart, a.bb, a.has_sw ? a.sw : (const float*)nullptr,
+                           (unsigned)n | ((unsigned)a.OO << 16), (unsigned)a.KS | ((unsigned)a.kind << 8) | (cslot << 12),
+                           (unsigned)a.OW | ((unsigned)a.K << 12) | ((unsigned)(a.kind == PT_SD_DIMP ? a.num_bins : 0) << 16), a.feat_stride, il);
+    }
     else hipLaunchKernelGGL(k_fast_init, dim3(n), dim3(384), 0, st, a);
     PT_CHECK_LAUNCH();
     if (num_iter == 0) {
@@ -589,19 +642,26 @@ static int sd_solve_fast(const PtFast& f, const pt_sd_params* prm, const float* 
         rc = pt_launch_adj2_sd(f, feat, stride_n, a, t, want_loss, st);        // alpha_{t-1}, w_t, s_t, residual maps
         if (rc) return rc;
         PtCorrFuse fz = {a.gpart, f.KSPL, t == 0 ? w_in : w_iters + (long)t * a.CKK, a.reg, a.g, a.anum, nullptr};
-        if (band) {                                                            // g_t, |g_t|^2, F g_t, q partials, packed operands
-            rc = pt_launch_corr3(f, bp, feat, stride_n, nullptr, nullptr, st, &fz, &a);
-            if (rc) return rc;
-            continue;
-        }
         rc = pt_launch_corr2(f, feat, stride_n, nullptr, a.spart, st, &fz);    // g_t, |g_t|^2, F g_t
         if (rc) return rc;
-        if (pw2) hipLaunchKernelGGL(k_fast_sgq2, dim3(n), dim3(pw_threads), 0, st, a);
+        if (pw2) {
+            const bool pr = a.kind == PT_SD_PRDIMP;
+            const SgqLate sl = {a.sg, a.pk, a.qs, a.sw};
+            hipLaunchKernelGGL(k_fast_sgq2, dim3(n), dim3(pw_threads), 0, st, (const float*)a.spart, (const float*)a.s,
+                               (const float*)(pr ? a.mask : a.lms), (const float*)(pr ? a.label : nullptr),
+                               (unsigned)n | ((unsigned)a.OO << 16),
+                               (unsigned)a.KS | ((unsigned)a.kind << 8) | ((unsigned)a.score_act << 12) | ((unsigned)(a.has_sw ? 1 : 0) << 16),
+                               a.act_param, sl);
+        }
         else hipLaunchKernelGGL(k_fast_sgq, dim3(n), dim3(384), pw_lds, st, a);
         PT_CHECK_LAUNCH();
     }
     if (num_iter > 0) {
-        if (!want_loss && !band) hipLaunchKernelGGL(k_fast_final, dim3(n), dim3(512), 0, st, a, num_iter);
+        static const bool final_old = std::getenv("PT_SD_FINAL_OLD") != nullptr;     // experiment: the struct-argument kernel
+        if (!want_loss && !final_old)
+            hipLaunchKernelGGL(k_fast_final, dim3(n), dim3(512), 0, st, sd_w_host(a, num_iter - 1), (const float*)a.g,
+                               a.w_final ? a.w_final : a.w_iters + (long)num_iter * a.CKK, (const float*)a.qs, (const float*)a.anum, n, a.CKK,
+                               a.KS, a.step, a.reg + a.alpha_eps);
         else hipLaunchKernelGGL(k_sd_pw, dim3(n), dim3(512), pw_lds, st, a, (int)PW_UPDATE, num_iter, 1, want_loss);
         PT_CHECK_LAUNCH();
     }
@@ -643,7 +703,7 @@ int pt_sd_solve_impl(const pt_sd_params* prm, const float* w_in, const float* fe
 
     SdArgs a;
     a.n = n; a.C = C; a.H = H; a.W = W; a.K = K; a.OH = OH; a.OW = OW; a.OO = OH * OW; a.CKK = C * K * K;
-    a.KS = p.KS; a.KSPL = p.KSPL; a.QB = 0;
+    a.KS = p.KS; a.KSPL = p.KSPL;
     a.kind = prm->kind; a.score_act = prm->score_act; a.mask_act = prm->mask_act; a.has_sw = sample_weight != nullptr;
     a.has_softmax_reg = prm->has_softmax_reg; a.normalize_label = prm->normalize_label; a.num_bins = prm->num_bins;
     a.step = prm->step_length; a.reg = prm->reg; a.alpha_eps = prm->alpha_eps; a.feat_stride = prm->feat_stride;
@@ -731,16 +791,12 @@ int pt_sd_replay_impl(const pt_sd_params* prm, const float* w_in, const float* f
     const int t = num_iter - 1;
     a.s_in = sbuf[(t - 1) & 1];
     a.s = sbuf[t & 1];
-    const PtBand bp = pt_band_plan(f);
-    const bool band = sd_use_band(bp);
-    if (band) { a.KS = 1; a.QB = bp.B; }
     for (int r = 0; r < reps; ++r) {
         if (which == 1) {
             rc = pt_launch_adj2_sd(f, feat, feat_stride_n, a, t, 0, st);
         } else {
             PtCorrFuse fz = {a.gpart, f.KSPL, w_iters + (long)t * a.CKK, a.reg, a.g, a.anum, nullptr};
-            if (band) rc = pt_launch_corr3(f, bp, feat, feat_stride_n, nullptr, nullptr, st, &fz, &a);
-            else rc = pt_launch_corr2(f, feat, feat_stride_n, nullptr, a.spart, st, &fz);
+            rc = pt_launch_corr2(f, feat, feat_stride_n, nullptr, a.spart, st, &fz);
         }
         if (rc) return rc;
     }

@@ -155,27 +155,6 @@ def test_dimp_sd_golden_baseline_size(name):
     assert np.all(np.diff(losses.cpu().numpy()) < 0)                      # monotone decrease
 
 
-@pytest.mark.parametrize("name,kind", [("dimp_sd_cfg2_n50", "dimp"), ("prdimp_sd_cfg3_n50", "prdimp"), ("dimp_sd_cfg2_n15", "dimp")])
-def test_band_correlation_variant_golden(name, kind, monkeypatch):
-    """The position-band correlation pass (csrc/band_corr.hip, PT_SD_BAND=1: all channels of a sample band in one
-    workgroup, curvature partials folded into the adjoint's prologue; measured slower than the default and kept as an
-    opt-in) reproduces the same reference goldens."""
-    monkeypatch.setenv("PT_SD_BAND", "1")
-    g = load_golden(name)
-    if kind == "dimp":
-        w0, feat, bb, sw = synth.dimp_problem(int(g["seed"]), int(g["n"]))
-        its, losses = _run(_dimp_module(), w0, feat, bb, sw, 5)
-    else:
-        w0, feat, bb, sw = synth.dimp_problem(int(g["seed"]), int(g["n"]), synth.PRDIMP50)
-        its, losses = _run(_prdimp_module(), w0 * 0, feat, bb, sw, 5)
-    close(its, g["iterates"], atol=1e-4)
-    close(losses, g["losses"], atol=1e-4, rtol=1e-4)
-    monkeypatch.delenv("PT_SD_BAND")
-    if kind == "dimp":
-        its2, _ = _run(_dimp_module(), w0, feat, bb, sw, 5)
-        close(its2, its.cpu().numpy(), atol=2e-6)                       # both decompositions agree far inside the bound
-
-
 def test_dimp_l2_golden():
     from pytracking_amd import optimizer
     g = load_golden("dimp_l2_small")

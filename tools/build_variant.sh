@@ -10,7 +10,7 @@ SRC=${PT_VARIANT_SRC:-fast_passes}
 OBJS=""
 for o in build/*.o; do b=$(basename $o .o); [[ " $SRC " == *" $b "* ]] || OBJS="$OBJS $o"; done
 for s in $SRC; do
-  /opt/rocm/bin/hipcc --offload-arch=gfx950 -O3 -std=c++17 -fPIC -Wno-pass-failed $@ -c csrc/$s.hip -o variants/${s}_$NAME.o
+  /opt/rocm/bin/hipcc --offload-arch=gfx950 -O3 -std=c++17 -fPIC -Wno-pass-failed -mllvm -amdgpu-kernarg-preload-count=14 $@ -c csrc/$s.hip -o variants/${s}_$NAME.o
   OBJS="$OBJS variants/${s}_$NAME.o"
 done
 /opt/rocm/bin/hipcc --offload-arch=gfx950 -shared -fPIC -o variants/libpt_hot_$NAME.so $OBJS
