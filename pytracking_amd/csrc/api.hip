@@ -140,7 +140,7 @@ extern "C" int pt_track_frame_f32(const pt_sd_params* prm, float* filter, float*
     const long CHW = (long)C * H * W;
     float* base = (float*)ws;
     PtFast f = pt_fast_plan(n, C, H, W, K, K, OH, OW);
-    if (pt_fast_usable(f, mem_feat, CHW, filter, test_feat)) {
+    if (pt_fast_usable(f, mem_feat, CHW, filter, test_feat) && f.KSPL <= 16) {      // (the SD solver sums <= 16 gradient partials)
         // Fast path: the first correlation of the solve reads sample `slot` from test_feat (and stores it into the
         // memory slot, dimp.py:429-441); its score row under the current filter IS the classification of the test
         // frame (dimp.py:190-194 -> linear_filter.py:75-80).  Localisation runs in the init stage.
@@ -210,7 +210,7 @@ extern "C" int pt_track_frame_head_f32(const pt_sd_params* prm, float* filter, f
     hipStream_t st = (hipStream_t)stream;
     const int OH = H + (K + 1) % 2, OW = W + (K + 1) % 2;
     PtFast f = pt_fast_plan(n, C, H, W, K, K, OH, OW);
-    if (pt_fast_usable(f, mem_feat, CHW, filter))
+    if (pt_fast_usable(f, mem_feat, CHW, filter) && f.KSPL <= 16)
         return pt_sd_solve_impl(prm, filter, mem_feat, CHW, mem_bb, sample_weight, n, C, H, W, K, num_iter, fb + cv.w_iters,
                                 nullptr, fb + cv.sd, (cv.total - cv.sd) * sizeof(float), st, /*copy_w0=*/false,
                                 /*w_final=*/filter, &cls, /*src=*/nullptr);

@@ -79,7 +79,7 @@ PtFast pt_fast_plan(int n, int C, int H, int W, int KH, int KW, int OH, int OW) 
     p.n = n; p.C = C; p.H = H; p.W = W; p.KH = KH; p.KW = KW; p.OH = OH; p.OW = OW;
     p.HW = H * W; p.KK = KH * KW; p.OO = OH * OW;
     if ((p.HW % 4) != 0 || W < 4 || p.KK > 16) return p;
-    if (C != 128 && C != 256 && C != 512 && C != 1024) return p;
+    if (C != 64 && C != 128 && C != 256 && C != 512 && C != 1024) return p;
     if ((long)n * p.HW >= (1L << 20)) return p;
     if ((long)n * C * p.HW * 4 >= (1L << 31)) return p;             // 32-bit byte offsets of the raw buffer loads
     p.Q = p.HW / 4;
@@ -93,7 +93,8 @@ PtFast pt_fast_plan(int n, int C, int H, int W, int KH, int KW, int OH, int OW) 
     p.nh = 2 * p.tiles <= 10 ? 2 : 1;
     p.CX = C / 8;
     p.KSC = 8;
-    if (PT_C2_R16 && p.nh == 2 && n > 16) { p.nh = 1; p.CX = C / 16; p.KSC = 16; }
+    if (C == 64) { p.CX = C; p.KSC = 1; }                           // ATOM's compressed samples: a workgroup takes ALL channels of a sample
+    if (PT_C2_R16 && p.nh == 2 && n > 16 && C > 64) { p.nh = 1; p.CX = C / 16; p.KSC = 16; }
     p.NK = p.CX / 4 / p.nh;
     if (p.NK > 16) return p;
     p.HWp = 64 * (p.TF + (p.rem > 0 ? 1 : 0)) + 4;
@@ -101,10 +102,12 @@ PtFast pt_fast_plan(int n, int C, int H, int W, int KH, int KW, int OH, int OW) 
     p.corr_lds = ((size_t)p.CX * 16 + (size_t)p.nh * p.KK * p.HWp) * sizeof(float);
     if (p.corr_lds > 150 * 1024) return p;
     p.CB = C / 16;
-    p.bpx = p.CB / 8;
+    p.bpx = p.CB / 8;                                               // 0: fewer channel blocks than XCDs (workgroup b: block b % CB, slice b / CB)
     p.NG = (int)(((long)n * p.HW + 15) / 16);
     p.KSPL = 0;
-    for (int ks = 8; ks <= 16; ks *= 2) {
+    // position slices: 8 or 16 (the fused gradient reduction of k_corr2 sums at most 16 partials); with few channel blocks up to
+    // 64, so that CB * KSPL workgroups still fill the chip (ATOM: 4 x 64) -- such plans serve the passes, not the SD solver
+    for (int ks = 8; ks <= (p.CB < 8 ? 64 : 16); ks *= 2) {
         const int gper = pt_ceil_div(p.NG, ks), U = pt_ceil_div(gper, PT_ADJ_WAVES);
         if (U <= PT_ADJ_UMAX) { p.gper = gper; p.U = U; p.KSPL = pt_ceil_div(p.NG, gper); break; }
     }
@@ -182,7 +185,7 @@ __global__ __launch_bounds__(1024, (NK <= 8 ? PT_C2_MINW : 4)) void k_corr2(cons
     // 1.2 us later (measured in round 3: a kernel whose arguments are all preloaded is that much shorter, eager and in graph
     // replay alike) -- by then the filter partials and the first feature tiles are on their way.
     //   h_filt = gradient partials (FUSE > 0) or the filter (FUSE == 0);  h_dims = C << 16 | H*W;
-    //   h_geo  = tiles | TF << 5 | rem << 10 | KSPL << 14 | (16 channel ranges) << 20
+    //   h_geo  = tiles | TF << 5 | rem << 10 | KSPL << 14 | (16 channel ranges) << 20 | (1 channel range: C = 64) << 21
     extern __shared__ __attribute__((aligned(16))) float lds[];     // afilt[CX][16] | T[2][KK][HWp]
     __shared__ float scratch[16];
     PT_STAMP(a_arg, 0);
@@ -191,12 +194,12 @@ __global__ __launch_bounds__(1024, (NK <= 8 ? PT_C2_MINW : 4)) void k_corr2(cons
     const int hC = (int)(h_dims >> 16), HW = (int)(h_dims & 0xffffu);
     const int h_tiles = (int)(h_geo & 31u), h_TF = (int)((h_geo >> 5) & 31u), h_rem = (int)((h_geo >> 10) & 15u);
     const int h_KSPL = (int)((h_geo >> 14) & 63u);
-    const bool ksc16 = ((h_geo >> 20) & 1u) != 0;
+    const bool ksc16 = ((h_geo >> 20) & 1u) != 0, ksc1 = ((h_geo >> 21) & 1u) != 0;
     const int nthreads = NH * h_tiles * 64;
-    const int hCX = ksc16 ? hC >> 4 : hC >> 3, hHWp = 64 * (h_TF + (h_rem > 0 ? 1 : 0)) + 4;
+    const int hCX = ksc1 ? hC : (ksc16 ? hC >> 4 : hC >> 3), hHWp = 64 * (h_TF + (h_rem > 0 ? 1 : 0)) + 4;
     // 16 ranges: 2x and 2x + 1 both run on XCD x (the adjoint pass owns channels [x C/8, (x+1) C/8) there)
     const int b = blockIdx.x, xc = b & 7, q = b >> 3;
-    const int x = ksc16 ? 2 * xc + (q & 1) : xc, i = ksc16 ? q >> 1 : q;
+    const int x = ksc1 ? 0 : (ksc16 ? 2 * xc + (q & 1) : xc), i = ksc1 ? b : (ksc16 ? q >> 1 : q);
     const int KK = K16 ? 16 : a_arg.KH * a_arg.KW;
     const int lane = threadIdx.x & 63, wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);   // wave-uniform: scalar branches
     const int kq = lane >> 4, j = lane & 15;
@@ -433,10 +436,10 @@ int pt_launch_corr2(const PtFast& p, const float* feat, long stride_n, const flo
     if (p.KK == 16 && (((uintptr_t)filt % 16) || ((uintptr_t)a.gpart % 16) || ((uintptr_t)a.w % 16) || ((uintptr_t)a.g_out % 16)))
         return PT_ERR_UNSUPPORTED;
     dim3 grid(p.KSC * p.n), block(p.corr_threads);
-    if (p.C >= (1 << 16) || p.HW >= (1 << 16) || p.tiles > 31 || p.TF > 31 || p.rem > 15 || a.KSPL > 63) return PT_ERR_UNSUPPORTED;
+    if (p.C >= (1 << 16) || p.HW >= (1 << 16) || p.tiles > 31 || p.TF > 31 || p.rem > 15 || a.KSPL > 16) return PT_ERR_UNSUPPORTED;
     const unsigned h_dims = ((unsigned)p.C << 16) | (unsigned)p.HW;
     const unsigned h_geo = (unsigned)p.tiles | ((unsigned)p.TF << 5) | ((unsigned)p.rem << 10) | ((unsigned)a.KSPL << 14) |
-                           ((p.KSC == 16 ? 1u : 0u) << 20);
+                           ((p.KSC == 16 ? 1u : 0u) << 20) | ((p.KSC == 1 ? 1u : 0u) << 21);
 #define PT_C2_HOT(FPTR) a.feat, a.stride_n, (const float*)(FPTR), a.w, a.src, a.slot, h_dims, h_geo
 #define PT_C2G(NKV, LF, KF, NHV)                                                                                    \
     do {                                                                                                         \
@@ -670,7 +673,9 @@ __global__ __launch_bounds__(PT_ADJ_WAVES * 64) void k_adj2(const float* h_feat,
     const int hPH = (int)(h_g4 & 63u), hPW = (int)((h_g4 >> 6) & 63u), hzn = (int)((h_g4 >> 12) & 255u), hns_max = (int)((h_g4 >> 20) & 63u);
     const int hKH = (int)((h_g4 >> 26) & 7u), hKW = (int)((h_g4 >> 29) & 7u);
     const int b = blockIdx.x, x = b & 7, rr = b >> 3;
-    const int cb = hbpx * x + rr % hbpx, ks = rr / hbpx;
+    const int hCB = (int)((h_g3 >> 16) & 255u);
+    // channel block and position slice of this workgroup; XCD x (= b % 8) always meets the same channel blocks
+    const int cb = hbpx > 0 ? hbpx * x + rr % hbpx : b % hCB, ks = hbpx > 0 ? rr / hbpx : b / hCB;
     const int HW = hH * hW;
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
     const int kq = lane >> 4, j = lane & 15;

@@ -690,7 +690,7 @@ int pt_sd_solve_impl(const pt_sd_params* prm, const float* w_in, const float* fe
     const int OH = H + (K + 1) % 2, OW = W + (K + 1) % 2;               // optimizer.py:105
     {
         PtFast f = pt_fast_plan(n, C, H, W, K, K, OH, OW);
-        if (pt_fast_usable(f, feat, feat_stride_n, w_in, src) && ((uintptr_t)w_iters % 16) == 0)
+        if (pt_fast_usable(f, feat, feat_stride_n, w_in, src) && ((uintptr_t)w_iters % 16) == 0 && f.KSPL <= 16)
             return sd_solve_fast(f, prm, w_in, feat, feat_stride_n, bb, sample_weight, num_iter, w_iters, losses, ws,
                                  ws_bytes, st, copy_w0, w_final, cls, src);
     }
@@ -782,7 +782,7 @@ int pt_sd_replay_impl(const pt_sd_params* prm, const float* w_in, const float* f
     if (num_iter < 2 || reps < 1 || which < 0 || which > 1) return PT_ERR_SHAPE;
     const int OH = H + (K + 1) % 2, OW = W + (K + 1) % 2;
     PtFast f = pt_fast_plan(n, C, H, W, K, K, OH, OW);
-    if (!pt_fast_usable(f, feat, feat_stride_n, w_in)) return PT_ERR_UNSUPPORTED;
+    if (!pt_fast_usable(f, feat, feat_stride_n, w_in) || f.KSPL > 16) return PT_ERR_UNSUPPORTED;
     SdArgs a;
     float* sbuf[2];
     int rc = sd_fast_setup(f, prm, w_in, bb, sample_weight, w_iters, nullptr, ws, ws_bytes, a, sbuf);
