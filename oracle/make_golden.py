@@ -670,6 +670,33 @@ def gen_branches():
              fletcher_reeves=int(fr), forget=forget)
 
 
+def gen_atom_cg_c64():
+    """ATOM's compressed-channel shape (C = 64, 4x4 filter) at a small map: the shape class the fused CG path of
+    csrc/atom_cg.hip serves.  Polak-Ribiere and Fletcher-Reeves, with and without direction forgetting, the CG state carried
+    over three run() calls (optimization.py:72-163, 227-289).  Inputs are regenerated from the seed by the tests."""
+    from pytracking import TensorList
+    from pytracking.libs import optimization
+    from pytracking.tracker.atom.optim import ConvProblem
+    from ltr.models.layers import activation
+    acfg = synth.ATOM18
+    small = dict(C=64, H=12, W=12)
+    out = dict(seed=321, n=12, H=12, W=12, iters=np.array([3, 2, 3]))
+    for tag, fr, forget in (("pr", False, 0.75), ("fr", True, 0.5), ("pr0", False, 0.0), ("fr0", True, 0.0)):
+        x0, samples, y, sw1 = synth.atom_problem(321, 12, acfg, small=small)
+        prob = ConvProblem(TensorList([T(samples)]), TensorList([T(y)[:, None]]), TensorList([acfg["filter_reg"]]),
+                           TensorList([T(sw1)]), activation.MLU(acfg["act_min_val"]))
+        x = TensorList([T(x0.copy())[None].clone()])
+        opt = optimization.ConjugateGradient(prob, x, fletcher_reeves=fr, direction_forget_factor=forget)
+        outs = []
+        for iters in (3, 2, 3):
+            opt.run(iters)
+            outs.append(x[0].detach()[0].numpy().copy())
+        out[f"{tag}_x_out"] = np.stack(outs)
+        out[f"{tag}_fr"] = int(fr)
+        out[f"{tag}_forget"] = forget
+    save("atom_cg_c64", **out)
+
+
 def gen_patches():
     """`sample_patch` / `sample_patch_multiscale` of the unmodified reference (preprocessing.py:33-148) on synthetic images:
     every border mode, pre-downsampling factors 1..3, crops hanging over each border, up- and down-sampling."""
@@ -769,7 +796,7 @@ def gen_trackers():
 if __name__ == "__main__":
     torch.set_num_threads(8)
     which = sys.argv[1:] or ["filter", "dimp", "l2", "prdimp", "atom", "prroi", "lwl", "atomgn", "tomp", "head", "localize", "iou",
-                             "branches", "ioufull", "atomgnfull", "lwlfull", "trackers", "patches", "long", "augment"]
+                             "branches", "ioufull", "atomgnfull", "lwlfull", "trackers", "patches", "long", "augment", "atomc64"]
     if "tomp" in which:
         gen_tomp()
     if "head" in which:
@@ -810,3 +837,5 @@ if __name__ == "__main__":
         gen_long_runs()
     if "augment" in which:
         gen_augment()
+    if "atomc64" in which:
+        gen_atom_cg_c64()

@@ -943,6 +943,22 @@ def test_atom_cg_direction_forgetting_golden(tag):
         close(x[0][0], g["x_out"][call], atol=2e-5, rtol=1e-4)
 
 
+@pytest.mark.parametrize("tag", ["pr", "fr", "pr0", "fr0"])
+def test_atom_cg_compressed_channels_golden(tag):
+    """C = 64, 4x4 filter -- the shape class of ATOM's online update, served by the fused path of csrc/atom_cg.hip (CG
+    recurrences in the prologue of the correlation launch, pointwise stage in its epilogue): Polak-Ribiere / Fletcher-Reeves,
+    with / without direction forgetting, state carried over three run() calls, against the reference's autograd CG."""
+    from pytracking_amd.optimization import ConjugateGradient, ConvProblem, MLU
+    g = load_golden("atom_cg_c64")
+    x0, samples, y, sw = synth.atom_problem(int(g["seed"]), int(g["n"]), small=dict(C=64, H=int(g["H"]), W=int(g["W"])))
+    x = [T(x0.copy())[None].clone()]
+    prob = ConvProblem([T(samples)], [T(y)[:, None]], [synth.ATOM18["filter_reg"]], [T(sw)], MLU(synth.ATOM18["act_min_val"]))
+    opt = ConjugateGradient(prob, x, fletcher_reeves=bool(int(g[f"{tag}_fr"])), direction_forget_factor=float(g[f"{tag}_forget"]))
+    for call, iters in enumerate(g["iters"]):
+        opt.run(int(iters))
+        close(x[0][0], g[f"{tag}_x_out"][call], atol=2e-5, rtol=1e-4)
+
+
 @pytest.mark.parametrize("tag,fr", [("pr", False), ("fr", True)])
 def test_atom_joint_gn_first_frame_schedule_golden(tag, fr):
     """ATOM first frame at the deployed schedule: 6 Gauss-Newton x 10 CG iterations on 30 x 256 x 18 x 18 samples, 64

@@ -450,3 +450,18 @@ def test_augmentation_set(tag):
         th = d.th
         pad_h = 0.0 if sp["output_sz"] is None else (sp["output_sz"][0] - th) / 2
         assert d.pad_top == int(np.floor(pad_h)) + sp["shift"][0]
+
+
+@pytest.mark.parametrize("tag", ["pr", "fr", "pr0", "fr0"])
+def test_atom_cg_compressed_channels(tag):
+    """The oracle's CG (optimization.py:72-163, 227-289) at ATOM's compressed-channel shape class (C = 64, 4x4), PR / FR, with and
+    without direction forgetting, three run() calls with the state carried over."""
+    g = load_golden("atom_cg_c64")
+    x0, samples, y, sw = synth.atom_problem(int(g["seed"]), int(g["n"]), small=dict(C=64, H=int(g["H"]), W=int(g["W"])))
+    f64 = lambda a: a.astype(np.float64)
+    x, state = f64(x0), None
+    for call, iters in enumerate(g["iters"]):
+        x, state = O.atom_cg(x, f64(samples), f64(y), f64(sw), filter_reg=synth.ATOM18["filter_reg"],
+                             act_min_val=synth.ATOM18["act_min_val"], num_iter=int(iters), fletcher_reeves=bool(int(g[f"{tag}_fr"])),
+                             direction_forget_factor=float(g[f"{tag}_forget"]), state=state)
+        close(x, g[f"{tag}_x_out"][call], atol=2e-5, rtol=1e-4)
