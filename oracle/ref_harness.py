@@ -113,4 +113,17 @@ def install():
             raise AttributeError(name)
         return _orig(self, name)
     _tl.TensorList.__getattr__ = _safe_getattr
+
+    # torch.rfft / torch.irfft (removed in torch 1.8) as pytracking/libs/fourier.py:24,31 call them (ATOM's localisation):
+    # onesided real FFT over the last `signal_ndim` dimensions, complex numbers as a trailing dimension of 2
+    import torch
+    if not hasattr(torch, "rfft") or isinstance(getattr(torch, "rfft", None), types.ModuleType):
+        def _rfft(a, signal_ndim, normalized=False, onesided=True):
+            assert onesided and not normalized
+            return torch.view_as_real(torch.fft.rfftn(a, dim=tuple(range(-signal_ndim, 0))))
+
+        def _irfft(a, signal_ndim, normalized=False, onesided=True, signal_sizes=None):
+            assert onesided and not normalized
+            return torch.fft.irfftn(torch.view_as_complex(a.contiguous()), s=signal_sizes, dim=tuple(range(-signal_ndim, 0)))
+        torch.rfft, torch.irfft = _rfft, _irfft
     _installed = True

@@ -512,3 +512,297 @@ class TompRefOps:
         tv, scale_ind, _, flag, loc = ToMP.localize_advanced(me, scores.squeeze(1).clone(), torch.from_numpy(ev["sample_pos"]),
                                                              torch.from_numpy(ev["sample_scales"]))
         return tv, scale_ind, flag, loc
+
+
+# ------------------------------------------------------------------------------------------------------
+# ATOM (pytracking/tracker/atom/atom.py): first-frame joint Gauss-Newton (filter + projection matrix), per-frame
+# classification with the compressed features, IoU-guided refinement with backtracking, CG update of the filter
+# ------------------------------------------------------------------------------------------------------
+ATOM18_TEST = dict(C_backbone=256, C_layer2=128, C=64, H=18, W=18, H2=36, W2=36, C_iou=256, K=4, base_seed=41, noise=0.3)
+ATOM_RUN = dict(seed=4500, n_frames=8, dims=ATOM18_TEST, thresholds=dict(target_not_found_threshold=-1e9, train_skipping=2))
+
+
+def atom_feature_maps(seed, k, n, dims):
+    """Raw backbone maps of extract call k (n patches), as the stub feature returns them BEFORE the extractor's own
+    normalisation (featurebase.py:104-108, normalize_power = 2)."""
+    return synth.tracker_backbone(seed + k, n, dims)
+
+
+def atom_normalize(feat):
+    """`MultiFeatureBase.get_feature` normalisation with normalize_power = 2 (featurebase.py:104-108) -- stock torch."""
+    return feat / (torch.sum(feat.abs().view(feat.shape[0], 1, 1, -1) ** 2, dim=3, keepdim=True) /
+                   (feat.shape[1] * feat.shape[2] * feat.shape[3]) + 1e-10) ** (1 / 2)
+
+
+def build_atom_iounet(seed, dims=ATOM18_TEST):
+    ref_harness.install()
+    from ltr.models.bbreg.atom_iou_net import AtomIoUNet
+    torch.manual_seed(seed)
+    net = AtomIoUNet(input_dim=(dims["C_layer2"], dims["C_backbone"]), pred_input_dim=(dims["C_iou"], dims["C_iou"]),
+                     pred_inter_dim=(dims["C_iou"], dims["C_iou"]))
+    net.eval()
+    sd = net.state_dict()
+    with torch.no_grad():
+        for k, v in synth.iou_net_params(seed + 901, dict(C=dims["C_iou"], I=dims["C_iou"])).items():
+            sd[k].copy_(torch.from_numpy(v))
+    return net
+
+
+def atom_params(features, thresholds=None):
+    """pytracking/parameter/atom/default.py, CPU, without the cv2-only / random augmentations ('rotate' needs OpenCV, 'dropout'
+    draws from torch's global RNG inside the feature path)."""
+    from pytracking.utils import TrackerParams
+    p = TrackerParams()
+    p.debug = 0
+    p.visualization = False
+    p.use_gpu = False
+    p.device = "cpu"
+    p.max_image_sample_size = (18 * 16) ** 2
+    p.min_image_sample_size = (18 * 16) ** 2
+    p.search_area_scale = 5
+    p.feature_size_odd = False
+    p.CG_iter = 5
+    p.init_CG_iter = 60
+    p.init_GN_iter = 6
+    p.post_init_CG_iter = 0
+    p.fletcher_reeves = False
+    p.standard_alpha = True
+    p.CG_forgetting_rate = None
+    p.sample_memory_size = 250
+    p.train_skipping = 10
+    p.feature_window = False
+    p.window_output = False
+    p.scale_factors = torch.ones(1)
+    p.score_upsample_factor = 1
+    p.augmentation = {'fliplr': True, 'blur': [(2, 0.2), (0.2, 2), (3, 1), (1, 3), (2, 2)],
+                      'relativeshift': [(0.6, 0.6), (-0.6, 0.6), (0.6, -0.6), (-0.6, -0.6)]}
+    p.augmentation_expansion_factor = 2
+    p.random_shift_factor = 1 / 3
+    p.update_projection_matrix = True
+    p.proj_init_method = 'randn'
+    p.filter_init_method = 'randn'
+    p.projection_activation = 'none'
+    p.response_activation = ('mlu', 0.05)
+    p.advanced_localization = True
+    p.target_not_found_threshold = 0.25
+    p.distractor_threshold = 0.8
+    p.hard_negative_threshold = 0.5
+    p.target_neighborhood_scale = 2.2
+    p.dispalcement_scale = 0.8
+    p.hard_negative_learning_rate = 0.02
+    p.hard_negative_CG_iter = 5
+    p.update_scale_when_uncertain = True
+    p.use_iou_net = True
+    p.iounet_augmentation = False
+    p.iounet_k = 3
+    p.num_init_random_boxes = 9
+    p.box_jitter_pos = 0.1
+    p.box_jitter_sz = 0.5
+    p.maximal_aspect_ratio = 6
+    p.box_refinement_iter = 5
+    p.box_refinement_step_length = 1
+    p.box_refinement_step_decay = 1
+    p.features = features
+    for k, v in (thresholds or {}).items():
+        setattr(p, k, v)
+    return p
+
+
+def run_atom(seed=4500, n_frames=8, dims=ATOM18_TEST, thresholds=None):
+    """initialize() + n_frames x track() of the reference ATOM with a stub deep feature (seeded layer2 / layer3 maps in place of the
+    ResNet-18, seeded IoU features in place of the IoU net's stock convolutions).  Events: atom_gn (first-frame joint optimisation),
+    atom_classify, atom_localize, atom_refine, atom_memory, atom_cg."""
+    ref_harness.install()
+    from pytracking import TensorList
+    from pytracking.utils import TrackerParams, FeatureParams
+    from pytracking.features.featurebase import MultiFeatureBase
+    from pytracking.features.extractor import MultiResolutionExtractor
+    import pytracking.tracker.atom.atom as atom_mod
+    from pytracking.libs import optimization as ropt
+    rec = Recorder()
+    iounet = build_atom_iounet(seed, dims)
+    calls = {"k": 0, "log": []}
+
+    class StubAtomFeature(MultiFeatureBase):
+        """pytracking/features/deep.py:ATOMResNet18 with the networks replaced by seeded maps."""
+
+        def initialize(self):
+            self.pool_stride = [1]
+            self.iou_predictor = iounet
+
+        def dim(self):
+            return TensorList([dims["C_backbone"]])
+
+        def stride(self):
+            return TensorList([16])
+
+        def extract(self, im):
+            n = im.shape[0]
+            k = calls["k"]
+            calls["k"] += 1
+            calls["log"].append((k, n))
+            m = atom_feature_maps(seed, k, n, dims)
+            l2, l3 = torch.from_numpy(m["layer2"]), torch.from_numpy(m["layer3"])
+            self.iounet_backbone_features = TensorList([l2.clone(), l3.clone()])
+            f3, f4 = synth.tracker_iou_feat(seed + 5000 + k, n, dims)
+            self.iounet_features = TensorList([torch.from_numpy(f3), torch.from_numpy(f4)])
+            return TensorList([l3])
+
+    deep_params = TrackerParams()
+    deep_params.learning_rate = 0.01
+    deep_params.init_samples_minimum_weight = 0.25
+    deep_params.output_sigma_factor = 1 / 4
+    deep_params.kernel_size = (4, 4)
+    deep_params.compressed_dim = dims["C"]
+    deep_params.filter_reg = 1e-1
+    deep_params.projection_reg = 1e-4
+    deep_params.use_augmentation = True
+    feat = StubAtomFeature(fparams=FeatureParams(feature_params=[deep_params]), normalize_power=2)
+    params = atom_params(MultiResolutionExtractor([feat]), thresholds)
+
+    # recording optimisers (the tracker module's own names are rebound on the imported module, nothing in the tree is edited)
+    class RecGN(ropt.GaussNewtonCG):
+        def run(self, num_cg_iter, num_gn_iter=None):
+            f0, P0 = self.x[0].clone(), self.x[1].clone()
+            out = super().run(num_cg_iter, num_gn_iter)
+            rec.add("atom_gn", num_cg_iter=num_cg_iter, num_gn_iter=-1 if num_gn_iter is None else num_gn_iter, filter0=f0, proj0=P0,
+                    filter=self.x[0], proj=self.x[1], init_call=calls["log"][-1][0], n_aug=calls["log"][-1][1],
+                    y=self.problem.y[0], sw=self.problem.sample_weights[0], filter_reg=self.problem.filter_reg[0],
+                    projection_reg=self.problem.projection_reg[0])
+            return out
+
+    class RecCG(ropt.ConjugateGradient):
+        def run(self, num_cg_iter):
+            out = super().run(num_cg_iter)
+            if num_cg_iter > 0:
+                rec.add("atom_cg", num_iter=num_cg_iter, filter=self.x[0], sw=self.problem.sample_weights[0].clone())
+            return out
+    orig_gn, orig_cg = atom_mod.GaussNewtonCG, atom_mod.ConjugateGradient
+    atom_mod.GaussNewtonCG, atom_mod.ConjugateGradient = RecGN, RecCG
+    try:
+        tracker = atom_mod.ATOM(params)
+        tracker.visdom = None
+        orig_apply = tracker.apply_filter
+
+        def apply_filter(sample_x):
+            s = orig_apply(sample_x)
+            rec.add("atom_classify", test_call=calls["k"] - 1, scores=s[0])
+            return s
+        tracker.apply_filter = apply_filter
+        orig_loc = tracker.localize_target
+
+        def localize_target(scores_raw):
+            tv, scale_ind, s, flag = orig_loc(scores_raw)
+            rec.add("atom_localize", tv=tv, scale_ind=int(scale_ind), flag=str(flag))
+            return tv, scale_ind, s, flag
+        tracker.localize_target = localize_target
+        orig_ob = tracker.optimize_boxes
+
+        def optimize_boxes(iou_features, init_boxes):
+            b, iou = orig_ob(iou_features, init_boxes)
+            rec.add("atom_refine", init_boxes=init_boxes, boxes=b, iou=iou, iou_call=calls["k"] - 1,
+                    mod3=tracker.target_feat[0], mod4=tracker.target_feat[1])
+            return b, iou
+        tracker.optimize_boxes = optimize_boxes
+        orig_mem = tracker.update_memory
+
+        def update_memory(sample_x, sample_y, learning_rate=None):
+            orig_mem(sample_x, sample_y, learning_rate)
+            rec.add("atom_memory", slot=int(tracker.previous_replace_ind[0]), stored=int(tracker.num_stored_samples[0]), y=sample_y[0],
+                    test_call=calls["k"] - 1)
+        tracker.update_memory = update_memory
+
+        rng = np.random.default_rng(seed + 77)
+        torch.manual_seed(seed)
+        rec.add("config", seed=seed, n_frames=n_frames, memory_size=params.sample_memory_size,
+                **{f"dim_{k}": v for k, v in dims.items()}, filter_reg=1e-1, act_min_val=0.05, CG_iter=params.CG_iter,
+                box_refinement_iter=params.box_refinement_iter, box_refinement_step_length=params.box_refinement_step_length,
+                box_refinement_step_decay=params.box_refinement_step_decay)
+        tracker.initialize(synthetic_frame(rng), {"init_bbox": [200.0, 140.0, 70.0, 90.0]})
+        rec.add("atom_init_done", n_init=int(tracker.num_init_samples[0]), sw=tracker.sample_weights[0].clone(),
+                y_init=tracker.y[0][:int(tracker.num_init_samples[0])].clone())
+        outs = []
+        for _ in range(n_frames):
+            rec.add("frame", frame=tracker.frame_num + 1)
+            out = tracker.track(synthetic_frame(rng))
+            outs.append(np.array(out["target_bbox"], dtype=np.float64))
+            rec.add("state", target_bbox=outs[-1], flag=str(tracker.debug_info.get("flag", "")))
+    finally:
+        atom_mod.GaussNewtonCG, atom_mod.ConjugateGradient = orig_gn, orig_cg
+    return np.stack(outs), rec, (tracker, iounet)
+
+
+class AtomRefOps:
+    """tests/tracker_replay.py `replay_atom` served by the reference's own classes on CPU (validates the log and the player)."""
+
+    def __init__(self, iounet, params):
+        self.iounet, self.params = iounet, params
+
+    def to_numpy(self, t):
+        return t.detach().cpu().numpy() if isinstance(t, torch.Tensor) else np.asarray(t)
+
+    def normalize(self, raw):
+        return atom_normalize(torch.from_numpy(raw))
+
+    def gn(self, f0, P0, raw, y, sw, num_cg, num_gn, filter_reg, projection_reg):
+        import torch.nn.functional as F
+        from pytracking import TensorList
+        from pytracking.libs import optimization as ropt
+        from pytracking.tracker.atom.optim import FactorizedConvProblem
+        T = torch.from_numpy
+        filt, proj = TensorList([T(f0).clone()]), TensorList([T(P0).clone()])
+        prob = FactorizedConvProblem(TensorList([raw]), TensorList([T(y)]), TensorList([filter_reg]), TensorList([projection_reg]),
+                                     self.params, TensorList([T(sw)]), lambda x: x, lambda x: F.elu(F.leaky_relu(x, 1 / 0.05), 0.05))
+        opt = ropt.GaussNewtonCG(prob, filt.concat(proj))
+        if num_gn < 0:
+            opt.run(num_cg)
+        else:
+            opt.run(num_cg, num_gn)
+        return opt.x[0], opt.x[1]
+
+    def project(self, raw, proj):
+        return torch.nn.functional.conv2d(raw, proj)
+
+    def new_memory(self, size, init_x, y_init, sw):
+        mem = init_x.new_zeros(size, *init_x.shape[1:])
+        mem[:init_x.shape[0]] = init_x
+        y = init_x.new_zeros(size, 1, *init_x.shape[2:])
+        y[:init_x.shape[0]] = torch.from_numpy(y_init)
+        return mem, y, torch.from_numpy(sw).clone()
+
+    def cg_new(self, memory, y, sw, filt, filter_reg, act_min):
+        import torch.nn.functional as F
+        from pytracking import TensorList
+        from pytracking.libs import optimization as ropt
+        from pytracking.tracker.atom.optim import ConvProblem
+        x = TensorList([filt.clone()])
+        prob = ConvProblem(TensorList([memory]), TensorList([y]), TensorList([filter_reg]), TensorList([sw]),
+                           lambda s: F.elu(F.leaky_relu(s, 1 / act_min), act_min))
+        return (ropt.ConjugateGradient(prob, x, fletcher_reeves=False, direction_forget_factor=0), x)
+
+    def current_filter(self, cg):
+        return cg[1][0]
+
+    def cg_run(self, cg, num_iter):
+        cg[0].run(num_iter)
+        return cg[1][0]
+
+    def classify(self, filt, x):
+        from pytracking import TensorList
+        from pytracking.libs import operation
+        return operation.conv2d(TensorList([x]), TensorList([filt]), mode='same')[0]
+
+    def store(self, memory, mem_y, slot, x, y):
+        memory[slot:slot + 1] = x
+        mem_y[slot:slot + 1] = torch.from_numpy(y)
+
+    def set_weights(self, mem_sw, sw):
+        mem_sw.copy_(torch.from_numpy(sw))
+
+    def refine(self, feats, mods, init_boxes, cfg):
+        import types
+        from pytracking import TensorList
+        from pytracking.tracker.atom.atom import ATOM
+        me = types.SimpleNamespace(params=self.params, iou_predictor=self.iounet,
+                                   target_feat=TensorList([torch.from_numpy(m) for m in mods]))
+        return ATOM.optimize_boxes(me, TensorList([torch.from_numpy(f) for f in feats]), torch.from_numpy(init_boxes))

@@ -40,6 +40,9 @@
 #ifndef PT_C2_R16
 #define PT_C2_R16 0      // 1: 16 channel ranges -- the two k-step halves of an XCD's range as separate 5-wave workgroups
 #endif
+#ifndef PT_ADJ_BAR
+#define PT_ADJ_BAR 0     // 1: workgroup barrier between the small update-stage loads and the first feature loads
+#endif
 #ifndef PT_ADJ_EARLY
 #define PT_ADJ_EARLY 1   // 1: first feature loads in front of the LDS work; 0: behind barrier 1
 #endif
@@ -724,6 +727,7 @@ __global__ __launch_bounds__(PT_ADJ_WAVES * 64) void k_adj2(const float* h_feat,
         an_in = lane < hKS ? h_anum[lane] : 0.f;
     }
     PT_STAMP_B(a_arg, 1);
+    if (PT_ADJ_BAR) __syncthreads();
     f32x4 av[UM];
     if (PT_ADJ_EARLY) {
 #pragma unroll

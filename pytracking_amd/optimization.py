@@ -126,7 +126,8 @@ class GaussNewtonCG:
         L = _lib.lib()
         with on_device(filt):
             y = y.reshape(n, H, W).contiguous()
-            sw = sw.reshape(n).contiguous()
+            # the tracker's first frame passes ONE weight, 1 / n, broadcast over the samples (atom.py:578 init_sample_weights)
+            sw = (sw.reshape(-1).expand(n) if sw.numel() == 1 else sw.reshape(n)).contiguous()
             nb = L.pt_atom_gn_ws_bytes(n, M, Kc, H, W, K)
             if nb == 0:
                 raise RuntimeError("GaussNewtonCG: configuration not covered by the gfx950 kernels")

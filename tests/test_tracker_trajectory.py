@@ -118,3 +118,44 @@ def test_gfx950_modules_replay_the_tomp_tracker_log():
     evs = _tomp_events()
     dev = TR.replay_tomp(evs, TR.TompMirrorOps(evs, "cuda"), atol=1e-4)
     print("ToMP: max deviation per boundary call over the 6-frame trajectory:", {k: f"{v:.2e}" for k, v in dev.items()})
+
+
+# ------------------------------------------------------------------------------------------------------
+# ATOM: initialize() + 8 x track() of the unmodified reference tracker (tests/golden/tracker_atom18.npz).  `ATOM.track()` goes
+# through pytracking/libs/fourier.py:24,31 (`torch.rfft` / `torch.irfft`, removed in torch 1.8): oracle/ref_harness.py supplies
+# them on top of torch.fft for the recording run (harness only).
+# ------------------------------------------------------------------------------------------------------
+def _atom_events():
+    return TR.events_from_npz(load_golden("tracker_atom18"))
+
+
+def test_atom_log_covers_every_boundary_call():
+    evs = _atom_events()
+    kinds = [e["kind"] for e in evs]
+    for k in ("atom_gn", "atom_init_done", "atom_classify", "atom_localize", "atom_refine", "atom_memory", "atom_cg", "state"):
+        assert k in kinds, k
+    gn = next(e for e in evs if e["kind"] == "atom_gn")
+    assert int(gn["num_cg_iter"]) == 10 and int(gn["num_gn_iter"]) == 6 and int(gn["n_aug"]) == 11      # atom/default.py:27-28
+    assert sum(k == "atom_classify" for k in kinds) == int(evs[0]["n_frames"]) == 8
+    assert {str(e["flag"]) for e in evs if e["kind"] == "atom_localize"} >= {"hard_negative", "uncertain"}
+    assert sum(k == "atom_cg" for k in kinds) >= 5 and sum(k == "atom_memory" for k in kinds) >= 4
+
+
+def test_reference_atom_modules_replay_the_log():
+    _need_reference()
+    from oracle import tracker_harness as TH
+    iounet = TH.build_atom_iounet(TH.ATOM_RUN["seed"], TH.ATOM_RUN["dims"])
+    params = TH.atom_params(None, TH.ATOM_RUN["thresholds"])
+    dev = TR.replay_atom(_atom_events(), TH.AtomRefOps(iounet, params), atol=5e-6)
+    assert set(dev) == {"gn_filter", "gn_projection", "classify", "refine_iou", "refine_boxes", "cg_filter"}
+
+
+@pytest.mark.gpu
+def test_gfx950_modules_replay_the_atom_tracker_log():
+    """Closed loop over the 8-frame ATOM trajectory on the GPU: joint Gauss-Newton at the deployed 6 x 10 schedule on the 11
+    first-frame samples, every classification score map, every backtracking box refinement and every CG update of the filter over the
+    250-slot memory (the fused C = 64 path of csrc/atom_cg.hip) within 1e-4 of the unmodified tracker's CPU run."""
+    evs = _atom_events()
+    dev = TR.replay_atom(evs, TR.AtomMirrorOps(evs, "cuda"), atol=1e-4)
+    assert set(dev) == {"gn_filter", "gn_projection", "classify", "refine_iou", "refine_boxes", "cg_filter"}
+    print("ATOM: max deviation per boundary call over the 8-frame trajectory:", {k: f"{v:.2e}" for k, v in dev.items()})

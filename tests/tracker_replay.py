@@ -308,3 +308,154 @@ class TompMirrorOps:
                                                                 torch.from_numpy(ev["sample_pos"]),
                                                                 torch.from_numpy(ev["sample_scales"]))
         return tv, scale_ind, flag, loc
+
+
+# ------------------------------------------------------------------------------------------------------
+# ATOM (atom.py): first-frame joint Gauss-Newton on (filter, projection matrix), per-frame classification of the compressed test
+# sample (`operation.conv2d(mode='same')`), IoU-guided refinement with per-proposal backtracking, CG update of the filter over the
+# 250-slot memory of compressed samples.  Closed loop on projection matrix, filter and memory; the glue (positions, flags, labels,
+# sample weights, proposals) from the log; backbone / IoU features regenerated from the seeds.
+#   ops: gn(f0, P0, raw, y, sw, num_cg, num_gn, filter_reg, projection_reg) -> (f, P);  project(raw, P) -> compressed;
+#        classify(f, x) -> (1,1,H,W);  cg_new(memory, y, sw, f, filter_reg, act_min) -> handle;  cg_run(handle, num_iter) -> f;
+#        refine((c3, c4), (mod3, mod4), init_boxes, cfg) -> (boxes, iou);  normalize(raw) -> torch;  to_numpy(t)
+# ------------------------------------------------------------------------------------------------------
+def replay_atom(events, ops, atol=1e-4):
+    cfg = events[0]
+    dims = {k[4:]: (int(v) if float(v).is_integer() else float(v)) for k, v in cfg.items() if k.startswith("dim_")}
+    seed = int(cfg["seed"])
+    dev = {}
+
+    def check(kind, got, want, tol):
+        got, want = np.asarray(ops.to_numpy(got), dtype=np.float64), np.asarray(want, dtype=np.float64)
+        assert got.shape == want.shape, (kind, got.shape, want.shape)
+        err = float(np.abs(got - want).max())
+        dev[kind] = max(dev.get(kind, 0.0), err)
+        assert err <= tol, (kind, err)
+
+    raw = lambda k, n: ops.normalize(synth.tracker_backbone(seed + int(k), int(n), dims)["layer3"])
+    filt = proj = memory = mem_y = mem_sw = cg = test_x = None
+    for ev in events[1:]:
+        kind = ev["kind"]
+        if kind == "atom_gn":
+            init_raw = raw(ev["init_call"], ev["n_aug"])
+            filt, proj = ops.gn(ev["filter0"], ev["proj0"], init_raw, ev["y"], ev["sw"], int(ev["num_cg_iter"]), int(ev["num_gn_iter"]),
+                                float(ev["filter_reg"]), float(ev["projection_reg"]))
+            check("gn_filter", filt, ev["filter"], atol)
+            check("gn_projection", proj, ev["proj"], atol)
+            init_x = ops.project(init_raw, proj)                            # atom.py:186-189: re-project with the new matrix
+        elif kind == "atom_init_done":
+            memory, mem_y, mem_sw = ops.new_memory(int(cfg["memory_size"]), init_x, ev["y_init"], ev["sw"])
+            cg = ops.cg_new(memory, mem_y, mem_sw, filt, float(cfg["filter_reg"]), float(cfg["act_min_val"]))
+        elif kind == "atom_classify":
+            test_x = ops.project(raw(ev["test_call"], 1), proj)
+            scores = ops.classify(ops.current_filter(cg), test_x)
+            check("classify", scores, ev["scores"], atol)
+        elif kind == "atom_refine":
+            c3, c4 = synth.tracker_iou_feat(seed + 5000 + int(ev["iou_call"]), 1, dims)
+            boxes, iou = ops.refine((c3, c4), (ev["mod3"], ev["mod4"]), ev["init_boxes"], cfg)
+            check("refine_iou", iou, ev["iou"], atol)
+            check("refine_boxes", boxes, ev["boxes"], 2e-4)
+        elif kind == "atom_memory":
+            ops.store(memory, mem_y, int(ev["slot"]), test_x, ev["y"])
+        elif kind == "atom_cg":
+            ops.set_weights(mem_sw, ev["sw"])
+            f = ops.cg_run(cg, int(ev["num_iter"]))
+            check("cg_filter", f, ev["filter"], atol)
+    return dev
+
+
+class AtomMirrorOps:
+    """`replay_atom` served by the gfx950 modules: pytracking_amd.optimization (GaussNewtonCG / ConjugateGradient on the explicit
+    Gauss-Newton operators), filter.corr_raw (operation.conv2d 'same'), iou_refine.optimize_boxes_atom."""
+
+    def __init__(self, events, device="cuda"):
+        import types
+        import torch
+        self.torch, self.types, self.dev = torch, types, torch.device(device)
+        self.T = lambda a: torch.from_numpy(np.ascontiguousarray(a)).to(self.dev)
+        cfg = events[0]
+        self.dims = {k[4:]: (int(v) if float(v).is_integer() else float(v)) for k, v in cfg.items() if k.startswith("dim_")}
+        self.iou_params = synth.iou_net_params(int(cfg["seed"]) + 901, dict(C=self.dims["C_iou"], I=self.dims["C_iou"]))
+        self.iou_net = None
+
+    def to_numpy(self, t):
+        return t.detach().cpu().numpy() if isinstance(t, self.torch.Tensor) else np.asarray(t)
+
+    def normalize(self, raw):                                               # featurebase.py:104-108 (stock torch)
+        x = self.T(raw)
+        return x / (self.torch.sum(x.abs().view(x.shape[0], 1, 1, -1) ** 2, dim=3, keepdim=True) /
+                    (x.shape[1] * x.shape[2] * x.shape[3]) + 1e-10) ** (1 / 2)
+
+    def gn(self, f0, P0, raw, y, sw, num_cg, num_gn, filter_reg, projection_reg):
+        import torch.nn.functional as F
+        from pytracking_amd.optimization import FactorizedConvProblem, GaussNewtonCG
+        prob = FactorizedConvProblem([raw], [self.T(y)], [filter_reg], [projection_reg], None, [self.T(sw)],
+                                     lambda x: x, lambda x: F.elu(F.leaky_relu(x, 1 / 0.05), 0.05))
+        filt, proj = self.T(f0).clone(), self.T(P0).clone()
+        opt = GaussNewtonCG(prob, [filt, proj])
+        if num_gn < 0:
+            opt.run(num_cg)
+        else:
+            opt.run(num_cg, num_gn)
+        return filt, proj
+
+    def project(self, raw, proj):
+        return self.torch.nn.functional.conv2d(raw, proj)                   # stock 1x1 convolution (operation.conv2d)
+
+    def new_memory(self, size, init_x, y_init, sw):
+        mem = init_x.new_zeros(size, *init_x.shape[1:])
+        mem[:init_x.shape[0]] = init_x
+        y = init_x.new_zeros(size, 1, *init_x.shape[2:])
+        y[:init_x.shape[0]] = self.T(y_init)
+        return mem, y, self.T(sw).clone()
+
+    def cg_new(self, memory, y, sw, filt, filter_reg, act_min):
+        from pytracking_amd.optimization import ConjugateGradient, ConvProblem, MLU
+        x = [filt.clone()]
+        opt = ConjugateGradient(ConvProblem([memory], [y], [filter_reg], [sw], MLU(act_min)), x, fletcher_reeves=False,
+                                direction_forget_factor=0)
+        return (opt, x)
+
+    def current_filter(self, cg):
+        return cg[1][0]
+
+    def cg_run(self, cg, num_iter):
+        cg[0].run(num_iter)
+        return cg[1][0]
+
+    def classify(self, filt, x):
+        from pytracking_amd import filter as FL
+        return FL.corr_raw(x, filt[0], out_hw=tuple(x.shape[-2:])).unsqueeze(1)
+
+    def store(self, memory, mem_y, slot, x, y):
+        memory[slot:slot + 1] = x
+        mem_y[slot:slot + 1] = self.T(y)
+
+    def set_weights(self, mem_sw, sw):
+        mem_sw.copy_(self.T(sw))
+
+    def refine(self, feats, mods, init_boxes, cfg):
+        from pytracking_amd import iou_refine as IR
+        torch = self.torch
+        if self.iou_net is None:
+            C = self.dims["C_iou"]
+            types = self.types
+
+            class Net(torch.nn.Module):
+                def __init__(net):
+                    super().__init__()
+                    for name, k in (("fc3_rt", 5), ("fc4_rt", 3)):
+                        blk = torch.nn.Module()
+                        blk.linear, blk.bn, blk.relu = torch.nn.Linear(C * k * k, C), torch.nn.BatchNorm2d(C), torch.nn.ReLU()
+                        setattr(net, name, blk)
+                    net.iou_predictor = torch.nn.Linear(2 * C, 1)
+                    net.prroi_pool3t = types.SimpleNamespace(pooled_height=5, pooled_width=5, spatial_scale=1 / 8)
+                    net.prroi_pool4t = types.SimpleNamespace(pooled_height=3, pooled_width=3, spatial_scale=1 / 16)
+            net = Net()
+            net.load_state_dict({k: torch.from_numpy(v.copy()) for k, v in self.iou_params.items()}, strict=False)
+            self.iou_net = net.to(self.dev).eval()
+        params = MirrorOps._Params(box_refinement_iter=int(cfg["box_refinement_iter"]),
+                                   box_refinement_step_length=float(cfg["box_refinement_step_length"]),
+                                   box_refinement_step_decay=float(cfg["box_refinement_step_decay"]))
+        me = self.types.SimpleNamespace(params=params, iou_predictor=self.iou_net, target_feat=[self.T(m) for m in mods])
+        return IR.optimize_boxes_atom(me, [self.T(f) for f in feats], torch.from_numpy(np.ascontiguousarray(init_boxes)))
