@@ -327,6 +327,17 @@ int pt_iou_refine_f32(const pt_iou_dims* dims, const float* params, const float*
                       int P, int num_iter, const float* step_length4, float step_decay, int relative, int backtrack,
                       void* ws, size_t ws_bytes, void* stream);
 
+/* The same for the per-frame call of the trackers (proposals formed on the host, refined boxes needed on the host:
+ * dimp.py:691-722, atom.py:724-756): init_boxes_host = P <= 16 boxes (xywh) in HOST memory, passed inside a kernel argument
+ * block; out_host = PT_IOU_HOST_FLOATS floats of pinned host memory: boxes [0, 4P), IoU [64, 64+P), sequence word [95].
+ * Returns when the results are readable (polls the sequence word; no hipStreamSynchronize).  PT_ERR_UNSUPPORTED for
+ * P > 16 or out_host not device-writable host memory: use pt_iou_refine_f32. */
+#define PT_IOU_HOST_FLOATS 96
+int pt_iou_refine_sync_f32(const pt_iou_dims* dims, const float* params, const float* prepared, const float* c3, const float* c4,
+                           const float* mod3, const float* mod4, const float* init_boxes_host, float* out_host, int P,
+                           int num_iter, const float* step_length4, float step_decay, int relative, int backtrack, void* ws,
+                           size_t ws_bytes, void* stream);
+
 /* ------------------------------------------------------------------------------------------------
  * Precise RoI Pooling -- replaces ltr/external/PreciseRoIPooling (empty git submodule;
  * import sites ltr/models/target_classifier/initializer.py:4,18,45 and

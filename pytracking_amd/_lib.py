@@ -75,7 +75,7 @@ EXPORTS = [
     "pt_tomp_bbreg_param_floats", "pt_tomp_bbreg_ws_bytes", "pt_tomp_bbreg_f32",
     "pt_clf_head_ws_bytes", "pt_clf_head_f32", "pt_max2d_f32", "pt_localize_f32", "pt_localize_decide_f32",
     "pt_localize_constants_f32", "pt_localize_advanced_f32", "pt_localize_advanced_sync_f32",
-    "pt_iou_param_floats", "pt_iou_prepared_floats", "pt_iou_prepare_f32", "pt_iou_refine_ws_bytes", "pt_iou_refine_f32",
+    "pt_iou_param_floats", "pt_iou_prepared_floats", "pt_iou_prepare_f32", "pt_iou_refine_ws_bytes", "pt_iou_refine_f32", "pt_iou_refine_sync_f32",
     "pt_track_frame_replay_pass_f32", "pt_sample_patch_f32", "pt_augment_patches_f32", "pt_track_frame_head_ws_bytes", "pt_track_frame_head_f32",
 ]
 
@@ -256,6 +256,8 @@ def lib():
     L.pt_iou_refine_ws_bytes.argtypes = [ip, i]
     L.pt_iou_refine_f32.restype = i
     L.pt_iou_refine_f32.argtypes = [ip, vp, vp, vp, vp, vp, vp, vp, vp, vp, i, i, fp, f, i, i, vp, sz, vp]
+    L.pt_iou_refine_sync_f32.restype = i
+    L.pt_iou_refine_sync_f32.argtypes = [ip, vp, vp, vp, vp, vp, vp, vp, vp, i, i, fp, f, i, i, vp, sz, vp]
     L.pt_track_frame_replay_pass_f32.restype = i
     L.pt_track_frame_replay_pass_f32.argtypes = [ctypes.POINTER(SdParams), vp, vp, vp, vp] + [i] * 6 + [vp, sz, i, i, vp]
     L.pt_track_frame_head_ws_bytes.restype = sz

@@ -130,4 +130,11 @@ __device__ __forceinline__ T pt_late_args(unsigned byte_offset) {
     return pt_late_get<T>(r);
 }
 
+// A pointer that came out of pt_late_args() is an integer pair to the compiler: accesses through it are FLAT (address-space
+// check per access, counted on both the vector-memory and the LDS counter).  pt_global() states that it points to global memory.
+template <typename T>
+using pt_gptr = T __attribute__((address_space(1)))*;
+template <typename T>
+__device__ __forceinline__ pt_gptr<T> pt_global(T* p) { return (pt_gptr<T>)p; }
+
 static inline int pt_ceil_div(int a, int b) { return (a + b - 1) / b; }

@@ -18,6 +18,18 @@ from .filter import _ptr, _require_device, _stream, device_guarded, workspace
 from .transformer import _Pack
 
 _CACHE = weakref.WeakKeyDictionary()          # AtomIoUNet instance -> (pack, prepared buffer, key)
+_HOST_OUT = {}                                # device index -> pinned result buffer of pt_iou_refine_sync_f32
+HOST_FLOATS = 96                              # PT_IOU_HOST_FLOATS (include/pt_hot.h)
+SYNC_MAX_P = 16
+
+
+def _host_out(device):
+    buf = _HOST_OUT.get(device.index)
+    if buf is None:
+        t = torch.zeros(HOST_FLOATS, dtype=torch.float32).pin_memory()
+        buf = (t, ctypes.c_void_p(t.data_ptr()))
+        _HOST_OUT[device.index] = buf
+    return buf
 
 
 def _packs(net, dims):
@@ -40,15 +52,23 @@ def _packs(net, dims):
 
 
 @device_guarded
-def refine_boxes(net, modulation, iou_features, init_boxes, num_iter, step_length, step_decay, relative, backtrack=False):
+def refine_boxes(net, modulation, iou_features, init_boxes, num_iter, step_length, step_decay, relative, backtrack=False,
+                 to_host=False):
     """-> (boxes (P,4), iou (P)) device tensors.  net: AtomIoUNet; modulation: (mod3, mod4) of one target;
-    iou_features: (c3_t (1,C3,H3,W3), c4_t (1,C4,H4,W4)); init_boxes (P,4) xywh."""
+    iou_features: (c3_t (1,C3,H3,W3), c4_t (1,C4,H4,W4)); init_boxes (P,4) xywh.
+    to_host: the trackers' per-frame call -- CPU tensors are returned; with CPU `init_boxes` and P <= 16 the proposals travel in a
+    kernel argument block and the results land in pinned host memory (`pt_iou_refine_sync_f32`: no copies, no stream sync)."""
     if net.training or net.fc3_rt.bn is None or net.fc3_rt.relu is None:
         raise NotImplementedError("IoU refinement: eval-mode LinearBlocks with BatchNorm + ReLU (the reference's network)")
     c3, c4 = [f.contiguous() for f in iou_features]
     mod3, mod4 = [m.reshape(-1).contiguous() for m in modulation]
-    boxes = init_boxes.reshape(-1, 4).to(c3.device, torch.float32).contiguous()
-    _require_device(c3, c4, mod3, mod4, boxes)
+    sync = to_host and init_boxes.device.type == 'cpu' and init_boxes.numel() <= 4 * SYNC_MAX_P
+    if sync:
+        boxes = init_boxes.reshape(-1, 4).to(torch.float32).contiguous()
+        _require_device(c3, c4, mod3, mod4)
+    else:
+        boxes = init_boxes.reshape(-1, 4).to(c3.device, torch.float32).contiguous()
+        _require_device(c3, c4, mod3, mod4, boxes)
     if c3.shape[0] != 1 or c4.shape[0] != 1:
         raise NotImplementedError("IoU refinement runs on one test image (the trackers' call)")
     for pool, size, scale in ((net.prroi_pool3t, 5, 1 / 8), (net.prroi_pool4t, 3, 1 / 16)):
@@ -70,20 +90,29 @@ def refine_boxes(net, modulation, iou_features, init_boxes, num_iter, step_lengt
     else:
         steps = [float(step_length)] * 4
     ws = workspace(nb, c3.device)
+    if sync:
+        host, host_ptr = _host_out(c3.device)
+        rc = L.pt_iou_refine_sync_f32(ctypes.byref(dims), _ptr(pack), _ptr(prepared), _ptr(c3), _ptr(c4), _ptr(mod3), _ptr(mod4),
+                                      ctypes.c_void_p(boxes.data_ptr()), host_ptr, P, int(num_iter), (ctypes.c_float * 4)(*steps),
+                                      float(step_decay), int(bool(relative)), int(bool(backtrack)), _ptr(ws), ws.numel(), _stream())
+        _lib.check(rc, "pt_iou_refine_sync_f32")
+        return host[:4 * P].clone().view(P, 4), host[64:64 + P].clone()
     out_boxes = torch.empty_like(boxes)
     out_iou = torch.empty(P, dtype=torch.float32, device=c3.device)
     rc = L.pt_iou_refine_f32(ctypes.byref(dims), _ptr(pack), _ptr(prepared), _ptr(c3), _ptr(c4), _ptr(mod3), _ptr(mod4),
                              _ptr(boxes), _ptr(out_boxes), _ptr(out_iou), P, int(num_iter), (ctypes.c_float * 4)(*steps),
                              float(step_decay), int(bool(relative)), int(bool(backtrack)), _ptr(ws), ws.numel(), _stream())
     _lib.check(rc, "pt_iou_refine_f32")
+    if to_host:
+        return out_boxes.cpu(), out_iou.cpu()
     return out_boxes, out_iou
 
 
 def _optimize(self, iou_features, init_boxes, relative):
     p = self.params
     boxes, iou = refine_boxes(self.net.bb_regressor, self.iou_modulation, iou_features, init_boxes, p.box_refinement_iter,
-                              p.box_refinement_step_length, p.box_refinement_step_decay, relative)
-    return boxes.view(-1, 4).cpu(), iou.view(-1).cpu()
+                              p.box_refinement_step_length, p.box_refinement_step_decay, relative, to_host=True)
+    return boxes.view(-1, 4), iou.view(-1)
 
 
 def optimize_boxes_atom(self, iou_features, init_boxes):
@@ -94,8 +123,9 @@ def optimize_boxes_atom(self, iou_features, init_boxes):
     if space not in ('default', 'relative'):
         raise ValueError('Unknown box_refinement_space {}'.format(space))
     boxes, iou = refine_boxes(self.iou_predictor, self.target_feat, iou_features, init_boxes, p.box_refinement_iter,
-                              p.box_refinement_step_length, p.box_refinement_step_decay, space == 'relative', backtrack=True)
-    return boxes.view(-1, 4).cpu(), iou.view(-1).cpu()
+                              p.box_refinement_step_length, p.box_refinement_step_decay, space == 'relative', backtrack=True,
+                              to_host=True)
+    return boxes.view(-1, 4), iou.view(-1)
 
 
 def optimize_boxes_default(self, iou_features, init_boxes):
