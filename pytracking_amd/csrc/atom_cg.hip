@@ -147,9 +147,9 @@ __global__ __launch_bounds__(1024) void k_atom_vec(CgArgs a, int phase, int ii) 
 // ----------------------------------------------------------------------------------------------------
 #define ACG_ST 16
 struct AcgLate {
-    const float *y, *sw;
-    float *d, *rmap, *nxt, *x;
-    const float *q, *pqp;
+    pt_gcf y, sw;
+    pt_gf d, rmap, nxt, x;
+    pt_gcf q, pqp;
     int n, H, W, OH, OW, fr, nred, pad;
     float act_min, forget;
 };
@@ -288,7 +288,7 @@ __global__ __launch_bounds__(640, 2) void k_acg_fwd(const float* h_feat, long h_
         f0 = has_p ? rn0 + beta * p0 : rn0;
         f1 = has_p ? rn1 + beta * p1 : rn1;
         if (i == 0) {                                               // one workgroup stores the state of this step
-            float* nx = l.nxt;
+            const pt_gf nx = l.nxt;
             if (stop != 0.f) {
                 if (v0) l.x[e0] += dn0;
                 if (v1) l.x[e1] += dn1;
@@ -435,13 +435,14 @@ static int acg_solve_fast(const PtFast& f, float* x, const float* samples, long 
     float* q = base + cv.q;
     float* pqp = base + cv.pqp;
     AcgLate l;
-    l.y = y; l.sw = sw; l.d = base + cv.d; l.rmap = base + cv.rmap; l.x = x; l.q = q; l.pqp = pqp;
+    l.y = (pt_gcf)y; l.sw = (pt_gcf)sw; l.d = (pt_gf)(base + cv.d); l.rmap = (pt_gf)(base + cv.rmap); l.x = (pt_gf)x; l.q = (pt_gcf)q;
+    l.pqp = (pt_gcf)pqp;
     l.n = n; l.H = f.H; l.W = f.W; l.OH = f.OH; l.OW = f.OW; l.fr = fr; l.nred = nred; l.pad = 0;
     l.act_min = act_min; l.forget = forget;
     const unsigned dims = ((unsigned)f.C << 16) | (unsigned)f.HW;
     const unsigned geo0 = (unsigned)f.tiles | ((unsigned)f.TF << 5) | ((unsigned)f.rem << 10);
     auto fwd = [&](int phase, const float* cur, const float* in, float* nxt) {
-        l.nxt = nxt;
+        l.nxt = (pt_gf)nxt;
         const unsigned geo = geo0 | ((unsigned)phase << 14);
         if (f.left) hipLaunchKernelGGL((k_acg_fwd<true>), dim3(n), dim3(f.corr_threads), f.corr_lds, st, samples, stride_n, cur, in, dims, geo, lambda, l);
         else hipLaunchKernelGGL((k_acg_fwd<false>), dim3(n), dim3(f.corr_threads), f.corr_lds, st, samples, stride_n, cur, in, dims, geo, lambda, l);
@@ -449,14 +450,14 @@ static int acg_solve_fast(const PtFast& f, float* x, const float* samples, long 
     // linearisation point: s0 = conv(x), d, J^T f0
     fwd(0, cg_state, x, nullptr);
     PT_CHECK_LAUNCH();
-    int rc = pt_launch_adj2_plain(f, samples, stride_n, l.rmap, gpart, st);
+    int rc = pt_launch_adj2_plain(f, samples, stride_n, (const float*)l.rmap, gpart, st);
     if (rc) return rc;
     // right-hand side b = -J^T f0 (:262-265), first direction, J p
     hipLaunchKernelGGL(k_acg_red, dim3(nred), dim3(256), 0, st, (const float*)gpart, (const float*)x, q, pqp, (const float*)(cg_state + 2 * CKK), f.KSPL, CKK, 1, lambda);
     PT_CHECK_LAUNCH();
     fwd(1, cg_state, q, S[0]);
     PT_CHECK_LAUNCH();
-    rc = pt_launch_adj2_plain(f, samples, stride_n, l.rmap, gpart, st);
+    rc = pt_launch_adj2_plain(f, samples, stride_n, (const float*)l.rmap, gpart, st);
     if (rc) return rc;
     int cur = 0;
     for (int ii = 0; ii < num_iter; ++ii) {
@@ -466,7 +467,7 @@ static int acg_solve_fast(const PtFast& f, float* x, const float* samples, long 
         fwd(2, S[cur], q, S[cur ^ 1]);
         PT_CHECK_LAUNCH();
         cur ^= 1;
-        rc = pt_launch_adj2_plain(f, samples, stride_n, l.rmap, gpart, st);
+        rc = pt_launch_adj2_plain(f, samples, stride_n, (const float*)l.rmap, gpart, st);
         if (rc) return rc;
     }
     hipLaunchKernelGGL(k_acg_final, dim3(1), dim3(1024), 0, st, (const float*)S[cur], (const float*)q, (const float*)pqp, x, cg_state, CKK, nred, fr);

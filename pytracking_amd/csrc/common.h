@@ -134,6 +134,10 @@ __device__ __forceinline__ T pt_late_args(unsigned byte_offset) {
 // check per access, counted on both the vector-memory and the LDS counter).  pt_global() states that it points to global memory.
 template <typename T>
 using pt_gptr = T __attribute__((address_space(1)))*;
+// pointer members of late-fetched argument blocks are declared with these types: every access through them is a global_load /
+// global_store (as generic pointers they were flat_* -- 134-166 of them in k_adj2)
+typedef const float __attribute__((address_space(1)))* pt_gcf;
+typedef float __attribute__((address_space(1)))* pt_gf;
 template <typename T>
 __device__ __forceinline__ pt_gptr<T> pt_global(T* p) { return (pt_gptr<T>)p; }
 

@@ -141,13 +141,13 @@ __device__ __forceinline__ int fdiv(int v, float inv_d) { return (int)(((float)v
 // ---------------------------------------------------------------------------------------------------
 // k_corr2
 // ---------------------------------------------------------------------------------------------------
-struct Corr2Args {
-    const float* feat; long stride_n; const float* filt; float* spart;
+struct Corr2Args {                  // pointer members global-qualified: fetched late (pt_late_args), see pt_gcf in common.h
+    pt_gcf feat; long stride_n; pt_gcf filt; pt_gf spart;
     int n, C, H, W, KH, KW, OH, OW, CX, TF, rem, tiles, HWp, nh, KSC;
     // fused gradient reduction (optimizer.py:146-148): filter operand = sum_k gpart[k] + reg*w
-    const float* gpart; int KSPL; const float* w; float reg; float* g_out; float* anum_part;
+    pt_gcf gpart; int KSPL; pt_gcf w; float reg; pt_gf g_out; pt_gf anum_part;
     // source override: sample `slot` is read from `src` (C,H,W) and stored to copy_dst (the memory slot)
-    int slot; const float* src; float* copy_dst;
+    int slot; pt_gcf src; pt_gf copy_dst;
     PT_STAMP_ARG
 };
 
@@ -351,13 +351,13 @@ __global__ __launch_bounds__(1024, (NK <= 8 ? PT_C2_MINW : 4)) void k_corr2(cons
     PT_STAMP(a, 4);
     // ---- memory insert rides on the pass (pytracking/tracker/dimp/dimp.py:429-441)
     if (over && a.copy_dst) {
-        float* __restrict__ dp = a.copy_dst + pos + (long)cbase * HW;
+        const pt_gf dp = a.copy_dst + pos + (long)cbase * HW;
         if (pv) {
 #pragma unroll
             for (int k = 0; k < NK; ++k) *(f32x4*)(dp + (long)(4 * k) * HW) = bq[k];
         }
         if (lv) {
-            float* __restrict__ dl = a.copy_dst + lpos + (long)cbase * HW;
+            const pt_gf dl = a.copy_dst + lpos + (long)cbase * HW;
 #pragma unroll
             for (int k = 0; k < NK; ++k) dl[(long)(4 * k) * HW] = bl[k];
         }
@@ -381,7 +381,7 @@ __global__ __launch_bounds__(1024, (NK <= 8 ? PT_C2_MINW : 4)) void k_corr2(cons
     const float inv_ow = 1.0f / (float)a.OW;
     const float* __restrict__ T0 = lds + nsl;
     const float* __restrict__ T1 = T0 + (long)KK * hHWp;          // second k-step half (a.nh == 2)
-    float* __restrict__ out = a.spart + ((long)x * a.n + i) * OO;
+    const pt_gf out = a.spart + ((long)x * a.n + i) * OO;
     if (a.KH == 4 && a.KW == 4) {                                   // the trackers' filter size: fully unrolled
         for (int o = threadIdx.x; o < OO; o += nthreads) {
             const int y = fdiv(o, inv_ow), xx0 = o - y * a.OW;
@@ -427,12 +427,15 @@ __global__ __launch_bounds__(1024, (NK <= 8 ? PT_C2_MINW : 4)) void k_corr2(cons
 int pt_launch_corr2(const PtFast& p, const float* feat, long stride_n, const float* filt, float* spart, hipStream_t st,
                     const PtCorrFuse* fuse, int slot, const float* src, float* copy_dst) {
     Corr2Args a;
-    a.feat = feat; a.stride_n = stride_n; a.filt = filt; a.spart = spart;
+    a.feat = (pt_gcf)feat; a.stride_n = stride_n; a.filt = (pt_gcf)filt; a.spart = (pt_gf)spart;
     a.n = p.n; a.C = p.C; a.H = p.H; a.W = p.W; a.KH = p.KH; a.KW = p.KW; a.OH = p.OH; a.OW = p.OW;
     a.CX = p.CX; a.TF = p.TF; a.rem = p.rem; a.tiles = p.tiles; a.HWp = p.HWp; a.nh = p.nh; a.KSC = p.KSC;
     a.gpart = nullptr; a.KSPL = 0; a.w = nullptr; a.reg = 0.f; a.g_out = nullptr; a.anum_part = nullptr;
-    if (fuse) { a.gpart = fuse->gpart; a.KSPL = fuse->KSPL; a.w = fuse->w; a.reg = fuse->reg; a.g_out = fuse->g_out; a.anum_part = fuse->anum_part; }
-    a.slot = slot; a.src = src; a.copy_dst = copy_dst;
+    if (fuse) {
+        a.gpart = (pt_gcf)fuse->gpart; a.KSPL = fuse->KSPL; a.w = (pt_gcf)fuse->w; a.reg = fuse->reg; a.g_out = (pt_gf)fuse->g_out;
+        a.anum_part = (pt_gf)fuse->anum_part;
+    }
+    a.slot = slot; a.src = (pt_gcf)src; a.copy_dst = (pt_gf)copy_dst;
     PT_STAMP_SET(a);
     if (((uintptr_t)feat % 16) || (stride_n % 4) || ((uintptr_t)src % 16) || ((uintptr_t)copy_dst % 16)) return PT_ERR_UNSUPPORTED;
     if ((long)p.n * stride_n * 4 >= (1L << 31)) return PT_ERR_UNSUPPORTED;
@@ -443,7 +446,7 @@ int pt_launch_corr2(const PtFast& p, const float* feat, long stride_n, const flo
     const unsigned h_dims = ((unsigned)p.C << 16) | (unsigned)p.HW;
     const unsigned h_geo = (unsigned)p.tiles | ((unsigned)p.TF << 5) | ((unsigned)p.rem << 10) | ((unsigned)a.KSPL << 14) |
                            ((p.KSC == 16 ? 1u : 0u) << 20) | ((p.KSC == 1 ? 1u : 0u) << 21);
-#define PT_C2_HOT(FPTR) a.feat, a.stride_n, (const float*)(FPTR), a.w, a.src, a.slot, h_dims, h_geo
+#define PT_C2_HOT(FPTR) (const float*)a.feat, a.stride_n, (const float*)(FPTR), (const float*)a.w, (const float*)a.src, a.slot, h_dims, h_geo
 #define PT_C2G(NKV, LF, KF, NHV)                                                                                    \
     do {                                                                                                         \
         if (!a.gpart) hipLaunchKernelGGL((k_corr2<NKV, LF, 0, KF, NHV>), grid, block, p.corr_lds, st, PT_C2_HOT(a.filt), a);             \
@@ -496,11 +499,11 @@ struct Adj2SdLate {
     int n, CKK, has_sw, has_softmax_reg;
     float step, reg, alpha_eps, act_param, softmax_reg;
     int pad0;
-    const float *sw, *s_in, *w0;
-    float *mask, *sws, *s, *sg, *lms, *g, *lossp, *w_iters;
+    pt_gcf sw, s_in, w0;
+    pt_gf mask, sws, s, sg, lms, g, lossp, w_iters;
 };
 struct Adj2Late {
-    float* gpart;
+    pt_gf gpart;
     int C, KH, KW, OH, OW, PH, PW, ns_max, zn, t, want_loss, pad1;
     Adj2SdLate sd;
     PT_STAMP_ARG
@@ -538,7 +541,7 @@ __device__ __forceinline__ void sdp_load_rest(const A& a, int i, int lane, bool 
     const int OO = a.OH * a.OW;
     const long base = (long)i * OO;
     // t == 0: there is no F g yet; astep is 0 and any finite operand does
-    const float* __restrict__ sgp = a.t > 0 ? a.sd.sg : a.sd.s_in;
+    const pt_gcf sgp = a.t > 0 ? (pt_gcf)a.sd.sg : a.sd.s_in;
     if (V == V_DIMP_BENT) {
 #pragma unroll
         for (int e = 0; e < E; ++e) r.sw[e] = a.sd.sws[base + min(lane + 64 * e, OO - 1)];
@@ -889,13 +892,14 @@ static int adj2_dispatch(const PtFast& p, const Adj2Args& a, hipStream_t st) {
     const float* qsp = V == V_PLAIN ? nullptr : a.sd.qs;
     const float* anp = V == V_PLAIN ? nullptr : a.sd.anum;
     Adj2Late l = {};
-    l.gpart = a.gpart; l.C = a.C; l.KH = a.KH; l.KW = a.KW; l.OH = a.OH; l.OW = a.OW; l.PH = a.PH; l.PW = a.PW;
+    l.gpart = (pt_gf)a.gpart; l.C = a.C; l.KH = a.KH; l.KW = a.KW; l.OH = a.OH; l.OW = a.OW; l.PH = a.PH; l.PW = a.PW;
     l.ns_max = a.ns_max; l.zn = a.zn; l.t = a.t; l.want_loss = a.want_loss;
     const SdArgs& sd = a.sd;
     l.sd.n = sd.n; l.sd.CKK = sd.CKK; l.sd.has_sw = sd.has_sw; l.sd.has_softmax_reg = sd.has_softmax_reg;
     l.sd.step = sd.step; l.sd.reg = sd.reg; l.sd.alpha_eps = sd.alpha_eps; l.sd.act_param = sd.act_param; l.sd.softmax_reg = sd.softmax_reg;
-    l.sd.sw = sd.sw; l.sd.s_in = sd.s_in; l.sd.w0 = sd.w0; l.sd.mask = sd.mask; l.sd.sws = sd.sws; l.sd.s = sd.s; l.sd.sg = sd.sg;
-    l.sd.lms = sd.lms; l.sd.g = sd.g; l.sd.lossp = sd.lossp; l.sd.w_iters = sd.w_iters;
+    l.sd.sw = (pt_gcf)sd.sw; l.sd.s_in = (pt_gcf)sd.s_in; l.sd.w0 = (pt_gcf)sd.w0; l.sd.mask = (pt_gf)sd.mask; l.sd.sws = (pt_gf)sd.sws;
+    l.sd.s = (pt_gf)sd.s; l.sd.sg = (pt_gf)sd.sg; l.sd.lms = (pt_gf)sd.lms; l.sd.g = (pt_gf)sd.g; l.sd.lossp = (pt_gf)sd.lossp;
+    l.sd.w_iters = (pt_gf)sd.w_iters;
 #ifdef PT_STAMPS
     l.stamps = a.stamps;
 #endif

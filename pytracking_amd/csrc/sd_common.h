@@ -34,9 +34,10 @@ struct SdArgs {
     float *cls_scores, *cls_peak, *cls_bb;
 };
 
+// (returns the member's own pointer type: plain in the argument structs passed by value, global-qualified in the late-fetched ones)
 template <typename A>
-__device__ __forceinline__ const float* sd_w(const A& a, int t) {
-    return t == 0 ? a.w0 : a.w_iters + (long)t * a.CKK;
+__device__ __forceinline__ auto sd_w(const A& a, int t) -> decltype(a.w0) {
+    return t == 0 ? a.w0 : (decltype(a.w0))(a.w_iters + (long)t * a.CKK);
 }
 
 // ----------------------------------------------------------------------------------------------------

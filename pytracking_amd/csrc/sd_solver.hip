@@ -323,7 +323,7 @@ __device__ __forceinline__ float pw_sum_slices(const SdArgs& a, const float (&v)
 // fast_passes.hip: pt_late_issue); what the stores need comes in the late block.
 //   DiMP kinds: p3 = lms {label, mask, sws, -};   PrDiMP: p3 = softmax P (mask), p4 = label density
 //   pa = n | OO << 16;   pb = KS | kind << 8 | score_act << 12 | has_sw << 16
-struct SgqLate { float *sg, *pk, *qs; const float* sw; };
+struct SgqLate { pt_gf sg, pk, qs; pt_gcf sw; };              // global-qualified members: see pt_gcf (common.h)
 __global__ __launch_bounds__(1024) void k_fast_sgq2(const float* __restrict__ spart, const float* __restrict__ sp, const float* __restrict__ p3,
                                                     const float* __restrict__ p4, unsigned pa, unsigned pb, float act_param, SgqLate l_arg) {
     __shared__ float scratch[16];
@@ -383,8 +383,8 @@ __global__ __launch_bounds__(1024) void k_fast_sgq2(const float* __restrict__ sp
 // Scalar kernel parameters (preloaded) = what the first loads need; the rest in the late block.
 //   pa = n | OO << 16;  pb = KS | kind << 8 | cls_slot << 12 (0xfffff: none);  pc = OW | K << 12 | num_bins << 16
 struct InitLate {
-    const float *label_lut, *mask_lut, *spatial_lut;
-    float *s, *label, *mask, *sws, *lms, *pk, *cls_scores, *cls_peak, *cls_bb;
+    pt_gcf label_lut, mask_lut, spatial_lut;
+    pt_gf s, label, mask, sws, lms, pk, cls_scores, cls_peak, cls_bb;
     int OH, score_act, mask_act, normalize_label;
     float bin_disp, gauss_sigma, hinge_thr, uni_weight, label_shrink, label_thr;
 };
@@ -617,9 +617,9 @@ static int sd_solve_fast(const PtFast& f, const pt_sd_params* prm, const float* 
     if (pw2) {
         if (n > 65535 || a.OO > 65535 || a.OW > 4095 || a.K > 15 || a.num_bins > 65535 || n >= 0xfffff) return PT_ERR_UNSUPPORTED;
         InitLate il;
-        il.label_lut = a.label_lut; il.mask_lut = a.mask_lut; il.spatial_lut = a.spatial_lut;
-        il.s = a.s; il.label = a.label; il.mask = a.mask; il.sws = a.sws; il.lms = a.lms; il.pk = a.pk;
-        il.cls_scores = a.cls_scores; il.cls_peak = a.cls_peak; il.cls_bb = a.cls_bb;
+        il.label_lut = (pt_gcf)a.label_lut; il.mask_lut = (pt_gcf)a.mask_lut; il.spatial_lut = (pt_gcf)a.spatial_lut;
+        il.s = (pt_gf)a.s; il.label = (pt_gf)a.label; il.mask = (pt_gf)a.mask; il.sws = (pt_gf)a.sws; il.lms = (pt_gf)a.lms;
+        il.pk = (pt_gf)a.pk; il.cls_scores = (pt_gf)a.cls_scores; il.cls_peak = (pt_gf)a.cls_peak; il.cls_bb = (pt_gf)a.cls_bb;
         il.OH = a.OH; il.score_act = a.score_act; il.mask_act = a.mask_act; il.normalize_label = a.normalize_label;
         il.bin_disp = a.bin_disp; il.gauss_sigma = a.gauss_sigma; il.hinge_thr = a.hinge_thr; il.uni_weight = a.uni_weight;
         il.label_shrink = a.label_shrink; il.label_thr = a.label_thr;
@@ -646,7 +646,7 @@ static int sd_solve_fast(const PtFast& f, const pt_sd_params* prm, const float* 
         if (rc) return rc;
         if (pw2) {
             const bool pr = a.kind == PT_SD_PRDIMP;
-            const SgqLate sl = {a.sg, a.pk, a.qs, a.sw};
+            const SgqLate sl = {(pt_gf)a.sg, (pt_gf)a.pk, (pt_gf)a.qs, (pt_gcf)a.sw};
             hipLaunchKernelGGL(k_fast_sgq2, dim3(n), dim3(pw_threads), 0, st, (const float*)a.spart, (const float*)a.s,
                                (const float*)(pr ? a.mask : a.lms), (const float*)(pr ? a.label : nullptr),
                                (unsigned)n | ((unsigned)a.OO << 16),
