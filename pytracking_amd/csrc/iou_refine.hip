@@ -402,38 +402,48 @@ struct BinGeo {
 static_assert(sizeof(BinGeo) == 45 * 4, "BinGeo layout");
 constexpr int GEO_MAX = FUSED_MAX_P * P3 * P3;
 
+// two threads per (proposal, bin): one the column weights, one the row weights (500 of the 512 threads busy at 10 proposals x 25 bins)
+// (first5: the RoI of this thread's first entry if the caller requested it earlier -- k_iou_bwd does, in front of its argument fetch)
 template <bool BWD, typename RP>
-__device__ __forceinline__ void iou_geometry(BinGeo* geo, RP rois, int P, int PH, float scale, int H, int W) {
+__device__ __forceinline__ void iou_geometry(BinGeo* geo, RP rois, int P, int PH, float scale, int H, int W, const float* first5 = nullptr) {
     const int PP = PH * PH;
-    for (int e = threadIdx.x; e < P * PP; e += FT) {
+    for (int e2 = threadIdx.x; e2 < 2 * P * PP; e2 += FT) {
+        const int e = e2 >> 1, rows = e2 & 1;
         const int slot = e / PP, bin = e - slot * PP, pp = bin / PH, q = bin - pp * PH;
-        const float rr[5] = {rois[5 * slot], rois[5 * slot + 1], rois[5 * slot + 2], rois[5 * slot + 3], rois[5 * slot + 4]};
+        float rr[5];
+        if (first5 && e2 == (int)threadIdx.x) {
+#pragma unroll
+            for (int u = 0; u < 5; ++u) rr[u] = first5[u];
+        } else {
+#pragma unroll
+            for (int u = 0; u < 5; ++u) rr[u] = rois[5 * slot + u];
+        }
         const Bin k = make_bin(rr, pp, q, PH, PH, scale, H, W);
         const int nj = k.j1 - k.j0 + 1, ni = k.i1 - k.i0 + 1;
         BinGeo& g = geo[e];
+        // the same expressions for either axis: [lo, hi] = the bin's extent, first = its first pixel, cnt = pixels it touches
+        const float lo = rows ? k.ys : k.xs, hi = rows ? k.ye : k.xe;
+        const int first = rows ? k.j0 : k.i0, cnt = rows ? nj : ni;
+        float* wv = rows ? g.wy : g.wx;
+        float* hs = rows ? g.hys : g.hxs;
+        float* he = rows ? g.hye : g.hxe;
 #pragma unroll
         for (int ii = 0; ii < GW; ++ii) {
-            const float i = (float)(k.i0 + ii);
-            const bool in = ii < ni;
-            g.wx[ii] = in ? hat_cdf(k.xe - i) - hat_cdf(k.xs - i) : 0.f;
+            const float i = (float)(first + ii);
+            const bool in = ii < cnt;
+            wv[ii] = in ? hat_cdf(hi - i) - hat_cdf(lo - i) : 0.f;
             if (BWD) {
-                g.hxs[ii] = in ? hat(k.xs - i) : 0.f;
-                g.hxe[ii] = in ? hat(k.xe - i) : 0.f;
+                hs[ii] = in ? hat(lo - i) : 0.f;
+                he[ii] = in ? hat(hi - i) : 0.f;
             }
         }
-#pragma unroll
-        for (int jj = 0; jj < GW; ++jj) {
-            const float j = (float)(k.j0 + jj);
-            const bool in = jj < nj;
-            g.wy[jj] = in ? hat_cdf(k.ye - j) - hat_cdf(k.ys - j) : 0.f;
-            if (BWD) {
-                g.hys[jj] = in ? hat(k.ys - j) : 0.f;
-                g.hye[jj] = in ? hat(k.ye - j) : 0.f;
-            }
+        if (rows) {
+            g.j0 = k.j0; g.j1 = k.j1;
+            g.flag = (k.area > 0.f && k.b == 0 && nj > 0 && ni > 0) ? ((nj <= GW && ni <= GW) ? 1 : 2) : 0;
+        } else {
+            g.area = k.area; g.bw = k.bw; g.bh = k.bh;
+            g.i0 = k.i0; g.i1 = k.i1;
         }
-        g.area = k.area; g.bw = k.bw; g.bh = k.bh;
-        g.i0 = k.i0; g.i1 = k.i1; g.j0 = k.j0; g.j1 = k.j1;
-        g.flag = (k.area > 0.f && k.b == 0 && nj > 0 && ni > 0) ? ((nj <= GW && ni <= GW) ? 1 : 2) : 0;
     }
 }
 
@@ -630,6 +640,13 @@ __global__ __launch_bounds__(FT) void k_iou_bwd(int nz0, int P, const float* __r
     const int t = threadIdx.x, lane = t & 63, w = __builtin_amdgcn_readfirstlane(t >> 6), c16 = lane & 15, kg = lane >> 4;
     const int l = (int)blockIdx.x >= nz0, zz = (int)blockIdx.x - (l ? nz0 : 0);
     IOU_STAMP(0);
+    // the RoI of this thread's geometry entry: `rois` and P are preloaded parameters, the request goes out before the argument block
+    float roi5[5];
+    {
+        const int slot = min((t >> 1) / (l ? P4 * P4 : P3 * P3), P - 1);
+#pragma unroll
+        for (int u = 0; u < 5; ++u) roi5[u] = rois[5 * slot + u];
+    }
     const Lv L = pt_late_args<Lv>(LV_OFF + (l ? (unsigned)sizeof(Lv) : 0u));
     const int K = L.K, I = L.I, PH = l ? P4 : P3, PP = l ? P4 * P4 : P3 * P3, H = L.H, W = L.W;
     const float scale = l ? S4 : S3;
@@ -654,7 +671,7 @@ __global__ __launch_bounds__(FT) void k_iou_bwd(int nz0, int P, const float* __r
     const int gk = k0 + min(lane, kn - 1), c = l ? gk / (P4 * P4) : gk / (P3 * P3), bin = gk - c * PP, pp = bin / PH, q = bin - pp * PH;
     const pt_gptr<const float> f = pt_global(L.feat) + (long)c * H * W;
     const float mo = pt_global(L.mod)[c];
-    iou_geometry<true>(geo, rois, P, PH, scale, H, W);
+    iou_geometry<true>(geo, rois, P, PH, scale, H, W, roi5);
     if (staged) stage_planes_store(planes, pr, c_last - c_first + 1, H * W);
     __syncthreads();
     IOU_STAMP(1);

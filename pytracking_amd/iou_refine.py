@@ -18,6 +18,7 @@ from .filter import _ptr, _require_device, _stream, device_guarded, workspace
 from .transformer import _Pack
 
 _CACHE = weakref.WeakKeyDictionary()          # AtomIoUNet instance -> (pack, prepared buffer, key)
+_SHAPES = weakref.WeakKeyDictionary()         # AtomIoUNet instance -> {(c3 shape, c4 shape, P): (dims, workspace bytes, parameter count)}
 _HOST_OUT = {}                                # device index -> pinned result buffer of pt_iou_refine_sync_f32
 HOST_FLOATS = 96                              # PT_IOU_HOST_FLOATS (include/pt_hot.h)
 SYNC_MAX_P = 16
@@ -71,19 +72,26 @@ def refine_boxes(net, modulation, iou_features, init_boxes, num_iter, step_lengt
         _require_device(c3, c4, mod3, mod4, boxes)
     if c3.shape[0] != 1 or c4.shape[0] != 1:
         raise NotImplementedError("IoU refinement runs on one test image (the trackers' call)")
-    for pool, size, scale in ((net.prroi_pool3t, 5, 1 / 8), (net.prroi_pool4t, 3, 1 / 16)):
-        if (getattr(pool, "pooled_height", size), getattr(pool, "pooled_width", size)) != (size, size) or \
-                abs(getattr(pool, "spatial_scale", scale) - scale) > 1e-12:
-            raise NotImplementedError("IoU refinement: pools other than 5x5 @ 1/8 and 3x3 @ 1/16")
-    dims = _lib.IouDims(c3.shape[1], c4.shape[1], net.fc3_rt.linear.out_features, net.fc4_rt.linear.out_features,
-                        c3.shape[2], c3.shape[3], c4.shape[2], c4.shape[3])
     L = _lib.lib()
     P = boxes.shape[0]
-    nb = L.pt_iou_refine_ws_bytes(ctypes.byref(dims), P)
-    if nb == 0:
-        raise NotImplementedError("IoU refinement: configuration not covered by the gfx950 kernels")
+    # everything that depends on the network object and the shapes only is checked once (this runs every frame)
+    key = (c3.shape, c4.shape, P)
+    shape_cache = _SHAPES.setdefault(net, {})
+    hit = shape_cache.get(key)
+    if hit is None:
+        for pool, size, scale in ((net.prroi_pool3t, 5, 1 / 8), (net.prroi_pool4t, 3, 1 / 16)):
+            if (getattr(pool, "pooled_height", size), getattr(pool, "pooled_width", size)) != (size, size) or \
+                    abs(getattr(pool, "spatial_scale", scale) - scale) > 1e-12:
+                raise NotImplementedError("IoU refinement: pools other than 5x5 @ 1/8 and 3x3 @ 1/16")
+        dims = _lib.IouDims(c3.shape[1], c4.shape[1], net.fc3_rt.linear.out_features, net.fc4_rt.linear.out_features,
+                            c3.shape[2], c3.shape[3], c4.shape[2], c4.shape[3])
+        nb = L.pt_iou_refine_ws_bytes(ctypes.byref(dims), P)
+        if nb == 0:
+            raise NotImplementedError("IoU refinement: configuration not covered by the gfx950 kernels")
+        hit = shape_cache[key] = (dims, nb, L.pt_iou_param_floats(ctypes.byref(dims)))
+    dims, nb, n_param = hit
     pack, prepared = _packs(net, dims)
-    if pack.numel() != L.pt_iou_param_floats(ctypes.byref(dims)):
+    if pack.numel() != n_param:
         raise ValueError("AtomIoUNet parameters do not match the feature dimensions")
     if isinstance(step_length, (tuple, list)):
         steps = [step_length[0], step_length[0], step_length[1], step_length[1]]
