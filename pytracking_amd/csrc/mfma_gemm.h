@@ -442,6 +442,12 @@ GemmArgs gemm_args(const float* A, long lda, long a_rows, const float* Wt, int M
 // 32x32x64 everywhere except wide outputs (N >= 1024, many rows), where 64x64 tiles with 32-wide K steps halve the operand
 // traffic per flop and two workgroups still fit a CU: FFN first GEMM 36.3 -> 28.0 us.  Larger tiles (128x64, 128x128) run
 // their K steps at 67-74 % of the MFMA rate but leave too few workgroups at these sizes.
+// experiment knob: smallest N that takes the 64 x 64 tile kernel (PT_GEMM_T64N, default 1024)
+static int pt_gemm_tile64_min_n() {
+    static const int v = [] { const char* e = getenv("PT_GEMM_T64N"); return e ? atoi(e) : 1024; }();
+    return v;
+}
+
 int launch_gemm(const GemmArgs& g, hipStream_t st, bool conv = false) {
     // K % 4: a loader thread fetches 4 consecutive k (16 bytes); quads past K are not requested at all (zeros)
     if (g.K % 4 != 0 || (conv && g.K % 32 != 0) || g.M <= 0 || g.N <= 0 || (g.batch && g.ksteps)) return PT_ERR_UNSUPPORTED;
@@ -459,7 +465,7 @@ int launch_gemm(const GemmArgs& g, hipStream_t st, bool conv = false) {
     if (conv) {
         if (g.Cin % 64 != 0) return PT_ERR_UNSUPPORTED;
         hipLaunchKernelGGL((k_gemm<32, 32, 1>), dim3((g.N + 31) / 32, (g.M + 31) / 32, nz), dim3(256), 0, st, g);
-    } else if (g.N >= 1024 && g.M >= 1024 && nz == 1 && g.K % 32 == 0) {
+    } else if (g.N >= pt_gemm_tile64_min_n() && g.M >= 1024 && nz == 1 && g.K % 32 == 0) {
         GemmArgs gs = g;
         const int gy = (g.M + 63) / 64;
         gs.swizzle = gy >= 16;

@@ -213,6 +213,44 @@ __global__ __launch_bounds__(512) void k_attn(AttnArgs a) {
 // ------------------------------------------------------------------------------------------------------------------
 // row LayerNorm, one wavefront per row (D % 64 == 0, D <= 512); in-place safe
 // ------------------------------------------------------------------------------------------------------------------
+// PER = D / 64 known at compile time: the row is ONE vector load per lane and gamma / beta are requested with it (with a run-time
+// count the loop stayed rolled -- a memory round trip per element -- and gamma / beta were read behind both reductions)
+template <int PER>
+__global__ __launch_bounds__(256) void k_ln_rows_t(const float* in, float* out, const float* __restrict__ gam,
+                                                   const float* __restrict__ bet, int rows) {
+    constexpr int D = 64 * PER;
+    const int row = blockIdx.x * 4 + (threadIdx.x >> 6), lane = threadIdx.x & 63;
+    if (row >= rows) return;
+    float v[PER], g[PER], b[PER];
+    const float* src = in + (long)row * D + lane * PER;
+    if (PER == 4) {
+        const f32x4 t = *(const f32x4*)src, tg = *(const f32x4*)(gam + lane * 4), tb = *(const f32x4*)(bet + lane * 4);
+#pragma unroll
+        for (int i = 0; i < 4; ++i) { v[i] = t[i]; g[i] = tg[i]; b[i] = tb[i]; }
+    } else {
+#pragma unroll
+        for (int i = 0; i < PER; ++i) { v[i] = src[i]; g[i] = gam[lane * PER + i]; b[i] = bet[lane * PER + i]; }
+    }
+    float s = 0.f;
+#pragma unroll
+    for (int i = 0; i < PER; ++i) s += v[i];
+    const float mean = wave_sum(s) / D;
+    float q = 0.f;
+#pragma unroll
+    for (int i = 0; i < PER; ++i) q += (v[i] - mean) * (v[i] - mean);
+    const float rstd = rsqrtf(wave_sum(q) / D + 1e-5f);
+    float* dst = out + (long)row * D + lane * PER;
+    if (PER == 4) {
+        f32x4 o;
+#pragma unroll
+        for (int i = 0; i < 4; ++i) o[i] = (v[i] - mean) * rstd * g[i] + b[i];
+        *(f32x4*)dst = o;
+    } else {
+#pragma unroll
+        for (int i = 0; i < PER; ++i) dst[i] = (v[i] - mean) * rstd * g[i] + b[i];
+    }
+}
+
 __global__ __launch_bounds__(256) void k_ln_rows(const float* in, float* out, const float* gam, const float* bet,
                                                  int rows, int D) {
     const int row = blockIdx.x * 4 + (threadIdx.x >> 6), lane = threadIdx.x & 63;
@@ -234,6 +272,15 @@ __global__ __launch_bounds__(256) void k_ln_rows(const float* in, float* out, co
     }
 }
 
+static void launch_ln_rows(const float* in, float* out, const float* gam, const float* bet, int rows, int D, hipStream_t st) {
+    const dim3 grid((rows + 3) / 4), block(256);
+    const bool al = ((uintptr_t)in % 16 == 0) && ((uintptr_t)out % 16 == 0) && ((uintptr_t)gam % 16 == 0) && ((uintptr_t)bet % 16 == 0);
+    if (D == 256 && al) hipLaunchKernelGGL(k_ln_rows_t<4>, grid, block, 0, st, in, out, gam, bet, rows);
+    else if (D == 128) hipLaunchKernelGGL(k_ln_rows_t<2>, grid, block, 0, st, in, out, gam, bet, rows);
+    else if (D == 64) hipLaunchKernelGGL(k_ln_rows_t<1>, grid, block, 0, st, in, out, gam, bet, rows);
+    else hipLaunchKernelGGL(k_ln_rows, grid, block, 0, st, in, out, gam, bet, rows, D);
+}
+
 // ------------------------------------------------------------------------------------------------------------------
 // token build (filter_predictor.py:113-128)
 // ------------------------------------------------------------------------------------------------------------------
@@ -241,6 +288,7 @@ struct TokArgs {
     const float *train, *test, *label, *fg, *testtok;
     float* X;
     int nf, ns, dup, D, HW, L;
+    float* zero; int nzero;         // a buffer this launch clears on the side (the decoder's initial state: no memset node per frame)
 };
 
 // NCHW feature maps -> token-major rows, + fg_token * label (memory frames) or + test_token (test frame)
@@ -248,6 +296,8 @@ __global__ __launch_bounds__(256) void k_tomp_tokens(TokArgs a) {
     __shared__ float tile[32][33];
     const int tx = threadIdx.x & 31, ty = threadIdx.x >> 5;
     const int p0 = blockIdx.x * 32, c0 = blockIdx.y * 32;
+    if (blockIdx.x == 0 && blockIdx.y == 0 && blockIdx.z == 0)
+        for (int i = threadIdx.x; i < a.nzero; i += 256) a.zero[i] = 0.f;
     const int B = a.dup ? 2 : a.ns;
     const int fr = blockIdx.z / B, b = blockIdx.z - fr * B, s = a.dup ? 0 : b;
     const bool train = fr < a.nf;
@@ -526,10 +576,141 @@ __global__ __launch_bounds__(256) void k_gemv(GemvArgs a) {
     }
 }
 
+// The decoder's GEMVs (<= 2 batch rows, K = 256 * NCH): the `cached` path of k_gemv as its own kernel.  What the prologue needs to
+// REQUEST every operand arrives as preloaded scalar parameters (six pointers, two packed words = 14 dwords); bias / residual-LayerNorm
+// parameters / output pointer are fetched behind the loads (pt_late_args).  The LayerNorm gamma / beta of the input and the additive
+// vector are requested with the weights instead of behind the statistics.  Same arithmetic in the same order as k_gemv.
+struct GemvLate { pt_gcf bias, rg, rb; pt_gf out; };
+template <int NCH>
+__global__ __launch_bounds__(256) void k_gemv_dec(const float* __restrict__ Wt, const float* __restrict__ x, const float* __restrict__ xg,
+                                                  const float* __restrict__ xb, const float* __restrict__ xadd,
+                                                  const float* __restrict__ res, unsigned nk, unsigned flags, GemvLate l_arg) {
+    constexpr int V = 4, WCH = 8;
+    const int N = (int)(nk & 0xffffu), K = (int)(nk >> 16);
+    const int B = (int)(flags & 15u), nrc = (int)((flags >> 8) & 15u);
+    const bool relu = (flags >> 4) & 1u, has_rg = (flags >> 5) & 1u;
+    const int lane = threadIdx.x & 63, n = blockIdx.x * 4 + (threadIdx.x >> 6);
+    if (n >= N) return;
+    const float* w = Wt + (long)n * K;
+    float wreg[NCH][V], xc[2][NCH][V], gv[NCH][V], bv[NCH][V], av[NCH][V], rc[2][WCH][V];
+#pragma unroll
+    for (int ch = 0; ch < NCH; ++ch) {
+        const int k = ch * 64 * V + lane * V;
+        ldv<V>(w + k, wreg[ch]);
+#pragma unroll
+        for (int b = 0; b < 2; ++b)
+            if (b < B) ldv<V>(x + (long)b * K + k, xc[b][ch]);
+#pragma unroll
+        for (int e = 0; e < V; ++e) gv[ch][e] = 1.f, bv[ch][e] = 0.f, av[ch][e] = 0.f;
+        if (xg) {
+            ldv<V>(xg + k, gv[ch]);
+            ldv<V>(xb + k, bv[ch]);
+        }
+        if (xadd) ldv<V>(xadd + k, av[ch]);
+    }
+    float rn[2] = {0.f, 0.f};
+    if (res) {
+#pragma unroll
+        for (int b = 0; b < 2; ++b) {
+            if (b >= B) continue;
+            rn[b] = res[(long)b * N + n];
+            if (has_rg) {
+#pragma unroll
+                for (int ch = 0; ch < WCH; ++ch)
+                    if (ch < nrc) ldv<V>(res + (long)b * N + ch * 64 * V + lane * V, rc[b][ch]);
+            }
+        }
+    }
+    const GemvLate l = pt_late_args<GemvLate>(56);                  // 6 pointers + 2 dwords = 56 bytes
+    const float bias = l.bias ? l.bias[n] : 0.f;
+    const float rgn = has_rg ? l.rg[n] : 1.f, rbn = has_rg ? l.rb[n] : 0.f;
+    float mean[2] = {0.f, 0.f}, rstd[2] = {1.f, 1.f}, rterm[2] = {0.f, 0.f};
+    if (res) {
+#pragma unroll
+        for (int b = 0; b < 2; ++b) {
+            if (b >= B) continue;
+            float m = 0.f, rs = 1.f;
+            if (has_rg) {                                           // the two-pass formula of wave_row_stats, from registers
+                float s = 0.f;
+#pragma unroll
+                for (int ch = 0; ch < WCH; ++ch)
+                    if (ch < nrc) {
+#pragma unroll
+                        for (int e = 0; e < V; ++e) s += rc[b][ch][e];
+                    }
+                m = wave_sum(s) / N;
+                float q = 0.f;
+#pragma unroll
+                for (int ch = 0; ch < WCH; ++ch)
+                    if (ch < nrc) {
+#pragma unroll
+                        for (int e = 0; e < V; ++e) q += (rc[b][ch][e] - m) * (rc[b][ch][e] - m);
+                    }
+                rs = rsqrtf(wave_sum(q) / N + 1e-5f);
+            }
+            rterm[b] = (rn[b] - m) * rs * rgn + rbn;
+        }
+    }
+    if (xg) {
+#pragma unroll
+        for (int b = 0; b < 2; ++b) {
+            if (b >= B) continue;
+            float s = 0.f;
+#pragma unroll
+            for (int ch = 0; ch < NCH; ++ch)
+#pragma unroll
+                for (int e = 0; e < V; ++e) s += xc[b][ch][e];
+            mean[b] = wave_sum(s) / K;
+            float q = 0.f;
+#pragma unroll
+            for (int ch = 0; ch < NCH; ++ch)
+#pragma unroll
+                for (int e = 0; e < V; ++e) q += (xc[b][ch][e] - mean[b]) * (xc[b][ch][e] - mean[b]);
+            rstd[b] = rsqrtf(wave_sum(q) / K + 1e-5f);
+        }
+    }
+    float acc[2] = {0.f, 0.f};
+#pragma unroll
+    for (int ch = 0; ch < NCH; ++ch)
+#pragma unroll
+        for (int b = 0; b < 2; ++b) {
+            if (b >= B) continue;
+#pragma unroll
+            for (int e = 0; e < V; ++e) {
+                float xv = (xc[b][ch][e] - mean[b]) * rstd[b] * gv[ch][e] + bv[ch][e];
+                xv += av[ch][e];
+                acc[b] += wreg[ch][e] * xv;
+            }
+        }
+#pragma unroll
+    for (int b = 0; b < 2; ++b) {
+        if (b >= B) continue;
+        float v = wave_sum(acc[b]) + bias;
+        if (relu) v = fmaxf(v, 0.f);
+        v += rterm[b];
+        if (lane == 0) l.out[(long)b * N + n] = v;
+    }
+}
+
 int launch_gemv(const GemvArgs& a, hipStream_t st) {
     if (a.B > 8 || a.K % 64 != 0 || (a.rg && a.N % 64 != 0)) return PT_ERR_UNSUPPORTED;
     const bool v4 = a.K % 256 == 0 && (!a.rg || a.N % 256 == 0);
-    if (v4)
+    const int nch = a.K / 256;
+    auto al16 = [](const void* p) { return ((uintptr_t)p % 16) == 0; };
+    const bool dec = v4 && a.B <= 2 && (nch == 1 || nch == 2 || nch == 4 || nch == 8) && a.N < 65536 && (!a.rg || (a.res && a.N <= 2048)) &&
+                     al16(a.Wt) && al16(a.x) && al16(a.xg) && al16(a.xb) && al16(a.xadd) && al16(a.res);
+    if (dec) {
+        const unsigned nk = (unsigned)a.N | ((unsigned)a.K << 16);
+        const unsigned flags = (unsigned)a.B | ((a.relu ? 1u : 0u) << 4) | ((a.rg ? 1u : 0u) << 5) | ((unsigned)(a.rg ? a.N / 256 : 0) << 8);
+        const GemvLate l{(pt_gcf)a.bias, (pt_gcf)a.rg, (pt_gcf)a.rb, (pt_gf)a.out};
+        const dim3 grid((a.N + 3) / 4), block(256);
+#define PT_GEMV_DEC(NC) hipLaunchKernelGGL((k_gemv_dec<NC>), grid, block, 0, st, a.Wt, a.x, a.xg, a.xb, a.xadd, a.res, nk, flags, l)
+        if (nch == 1) PT_GEMV_DEC(1);
+        else if (nch == 2) PT_GEMV_DEC(2);
+        else if (nch == 4) PT_GEMV_DEC(4);
+        else PT_GEMV_DEC(8);
+#undef PT_GEMV_DEC
+    } else if (v4)
         hipLaunchKernelGGL((k_gemv<4>), dim3((a.N + 3) / 4), dim3(256), 0, st, a);
     else
         hipLaunchKernelGGL((k_gemv<1>), dim3((a.N + 3) / 4), dim3(256), 0, st, a);
@@ -974,7 +1155,7 @@ extern "C" int pt_tomp_predict_f32(const pt_tomp_dims* d, const float* params, c
     // ---- tokens (filter_predictor.py:113-128)
     {
         TokArgs t{train_feat, test_feat, train_label, P + po.fg, P + po.testtok, X, n_train, n_seq, parallel ? 1 : 0, D,
-                  HW, L};
+                  HW, L, base + cv.zero, B * D};
         hipLaunchKernelGGL(k_tomp_tokens, dim3((HW + 31) / 32, (D + 31) / 32, (n_train + 1) * B), dim3(256), 0, st, t);
         PT_CHECK_LAUNCH();
         BoxArgs bx{train_ltrb, P + po.bw1, P + po.bb1, P + po.bn1, P + po.bn2, base + cv.E1, base + cv.bnsc,
@@ -1011,7 +1192,7 @@ extern "C" int pt_tomp_predict_f32(const pt_tomp_dims* d, const float* params, c
         g = gemm_args(AO, D, rows, P + e.sa.w_out, rows, D, D, P + e.sa.b_out, Y, D);
         g.R = X;
         if ((rc = launch_gemm(g, st))) return rc;
-        hipLaunchKernelGGL(k_ln_rows, dim3((rows + 3) / 4), dim3(256), 0, st, Y, X, P + e.n1g, P + e.n1b, rows, D);
+        launch_ln_rows(Y, X, P + e.n1g, P + e.n1b, rows, D, st);
         PT_CHECK_LAUNCH();
         g = gemm_args(X, D, rows, P + e.w1, rows, ff, D, P + e.b1, Hd, ff);
         g.relu = 1;
@@ -1019,11 +1200,11 @@ extern "C" int pt_tomp_predict_f32(const pt_tomp_dims* d, const float* params, c
         g = gemm_args(Hd, ff, rows, P + e.w2, rows, D, ff, P + e.b2, Y, D);
         g.R = X;
         if ((rc = launch_gemm(g, st))) return rc;
-        hipLaunchKernelGGL(k_ln_rows, dim3((rows + 3) / 4), dim3(256), 0, st, Y, X, P + e.n2g, P + e.n2b, rows, D);
+        launch_ln_rows(Y, X, P + e.n2g, P + e.n2b, rows, D, st);
         PT_CHECK_LAUNCH();
     }
     // ---- decoder (transformer.py:224-238), one query per batch row; T = LayerNorm(pre) is applied by the consumers
-    if (hipMemsetAsync(base + cv.zero, 0, (size_t)B * D * sizeof(float), st) != hipSuccess) return PT_ERR_LAUNCH;
+    // (base + cv.zero was cleared by k_tomp_tokens)
     DecAttnArgs da{};
     da.mem = X; da.pos = pos; da.qk = base + cv.qk; da.scores = base + cv.scores; da.ctx = base + cv.ctx;
     da.B = B; da.L = L; da.D = D; da.nhead = NH; da.HW = HW;
@@ -1069,11 +1250,11 @@ extern "C" int pt_tomp_predict_f32(const pt_tomp_dims* d, const float* params, c
     }
     // norm3 of the last layer, then the decoder's final norm (transformer.py:141-142)
     if (d->n_dec > 0) {
-        hipLaunchKernelGGL(k_ln_rows, dim3((B + 3) / 4), dim3(256), 0, st, tpre, base + cv.a, tg, tb, B, D);
+        launch_ln_rows(tpre, base + cv.a, tg, tb, B, D, st);
         PT_CHECK_LAUNCH();
         tpre = base + cv.a;
     }
-    hipLaunchKernelGGL(k_ln_rows, dim3((B + 3) / 4), dim3(256), 0, st, tpre, filters, P + po.dng, P + po.dnb, B, D);
+    launch_ln_rows(tpre, filters, P + po.dng, P + po.dnb, B, D, st);
     PT_CHECK_LAUNCH();
     hipLaunchKernelGGL(k_tokens_to_nchw, dim3((HW + 31) / 32, (D + 31) / 32, B), dim3(256), 0, st, X, enc_feat, B, L, D,
                        HW, Ltr);
