@@ -758,8 +758,11 @@ static MfPlan mf_plan(int n, int F, int C, int H, int W, int K, int br_force = 0
     p.spg = (n + NSG - 1) / NSG;
     p.NSG = (n + p.spg - 1) / p.spg;
     p.bps = 1;
-    if (p.spg == 1 && (long)n * CBn < 256 && p.ga.NB > 1) {         // few samples: a sample's bands over several workgroups
-        int bps = std::min(p.ga.NB, (int)((256 + (long)n * CBn - 1) / ((long)n * CBn)));
+    // few samples: a sample's bands over several workgroups -- up to two 256-thread workgroups per CU (with one, every SIMD holds a
+    // single wave and nothing overlaps its MFMAs)
+    static const int adj_target = [] { const char* e = getenv("PT_MF_ADJ_WGS"); return e ? atoi(e) : 512; }();
+    if (p.spg == 1 && (long)n * CBn < adj_target && p.ga.NB > 1) {
+        int bps = std::min(p.ga.NB, (int)((adj_target + (long)n * CBn - 1) / ((long)n * CBn)));
         while (bps > 1 && n * bps > 32) --bps;
         const int bpg = (p.ga.NB + bps - 1) / bps;
         bps = (p.ga.NB + bpg - 1) / bpg;                            // no empty share
@@ -832,10 +835,26 @@ int pt_mf_corr_splits(int n, int F, int C, int H, int W, int K) {
     MfPlan p = mf_plan(n, F, C, H, W, K);
     if (!p.ok || K != 3) return 1;
     const int nch = (C + MF_CK - 1) / MF_CK;
-    int ks = 1;
-    while (ks < 8 && 2 * ks <= nch / 2 && (long)n * p.g.NB * ks < 192) ks *= 2;
-    while (ks > 1 && (ks - 1) * ((nch + ks - 1) / ks) >= nch) ks /= 2;     // every split owns at least one chunk
-    return ks;
+    // The pass takes (rounds of workgroups over the 256 CUs) x (channel chunks per split) chunk-times plus a per-workgroup prologue /
+    // epilogue worth about two chunks; n = 8 with the old power-of-two rule ran 320 workgroups = 2 rounds of 8 chunks where 240
+    // workgroups of 11 chunks are one round.  Any split count up to nch / 2 may be chosen (PT_MF_KS_POW2=1: the old rule).
+    static const bool pow2 = [] { const char* e = getenv("PT_MF_KS_POW2"); return e && e[0] == '1'; }();
+    if (pow2) {
+        int ks = 1;
+        while (ks < 8 && 2 * ks <= nch / 2 && (long)n * p.g.NB * ks < 192) ks *= 2;
+        while (ks > 1 && (ks - 1) * ((nch + ks - 1) / ks) >= nch) ks /= 2;     // every split owns at least one chunk
+        return ks;
+    }
+    int best = 1;
+    long best_cost = -1;
+    for (int ks = 1; ks <= 16 && ks <= nch / 2; ++ks) {
+        const int cps = (nch + ks - 1) / ks;
+        if ((ks - 1) * cps >= nch) continue;                                   // every split owns at least one chunk
+        const long wgs = (long)n * p.g.NB * ks, rounds = (wgs + 255) / 256;
+        const long cost = rounds * (cps + 2) * 16 + ks;                        // + ks: the partial maps are written and summed
+        if (best_cost < 0 || cost < best_cost) { best_cost = cost; best = ks; }
+    }
+    return best;
 }
 size_t pt_mf_corr_part_floats(int n, int F, int C, int H, int W, int K) {
     const int ks = pt_mf_corr_splits(n, F, C, H, W, K);

@@ -448,6 +448,12 @@ static int pt_gemm_tile64_min_n() {
     return v;
 }
 
+// experiment knob: tile of long-K narrow-N products (PT_GEMM_LONGK: 0 = 32 x 32, 1 = 32 x 64, 2 = 64 x 32)
+static int pt_gemm_longk_tile() {
+    static const int v = [] { const char* e = getenv("PT_GEMM_LONGK"); return e ? atoi(e) : 0; }();
+    return v;
+}
+
 int launch_gemm(const GemmArgs& g, hipStream_t st, bool conv = false) {
     // K % 4: a loader thread fetches 4 consecutive k (16 bytes); quads past K are not requested at all (zeros)
     if (g.K % 4 != 0 || (conv && g.K % 32 != 0) || g.M <= 0 || g.N <= 0 || (g.batch && g.ksteps)) return PT_ERR_UNSUPPORTED;
@@ -471,6 +477,19 @@ int launch_gemm(const GemmArgs& g, hipStream_t st, bool conv = false) {
         gs.swizzle = gy >= 16;
         hipLaunchKernelGGL((k_gemm<64, 64, 0, 32>), dim3((g.N + 63) / 64, gs.swizzle ? (gy + 7) / 8 * 8 : gy, 1), dim3(256), 0,
                            st, gs);
+    } else if (pt_gemm_longk_tile() && !g.batch && nz == 1 && g.K >= 1024 && g.K % 32 == 0 && g.M >= 1024 && g.N >= 64) {
+        // long-K, narrow-N products (the FFN's second GEMM: 1944 x 256 x 2048): 32 x 32 tiles re-read both operands through L2
+        // 488 times; a 2:1 tile halves one operand's traffic at the same workgroup count per CU
+        GemmArgs gs = g;
+        if (pt_gemm_longk_tile() == 1) {
+            const int gy = (g.M + 31) / 32;
+            gs.swizzle = gy >= 16;
+            hipLaunchKernelGGL((k_gemm<32, 64, 0>), dim3((g.N + 63) / 64, gs.swizzle ? (gy + 7) / 8 * 8 : gy, 1), dim3(256), 0, st, gs);
+        } else {
+            const int gy = (g.M + 63) / 64;
+            gs.swizzle = gy >= 16;
+            hipLaunchKernelGGL((k_gemm<64, 32, 0>), dim3((g.N + 31) / 32, gs.swizzle ? (gy + 7) / 8 * 8 : gy, 1), dim3(256), 0, st, gs);
+        }
     } else {
         GemmArgs gs = g;
         const int gy = (g.M + 31) / 32;
