@@ -144,6 +144,11 @@ def test_iou_refine_argument_checks(L):
     assert L.pt_iou_refine_f32(ctypes.byref(bad), *a, 10, 5, f4, 1.0, 0, 0, one, 1 << 30, n) == -3
     assert L.pt_iou_refine_f32(ctypes.byref(d), *a, 10, 5, f4, 1.0, 0, 0, one, 0, n) == -4
     assert L.pt_iou_prepare_f32(ctypes.byref(d), one, n, n) == -1
+    # the per-frame variant: host proposals / pinned host results, <= 16 proposals (checked before any device call)
+    a8 = [one] * 8
+    assert L.pt_iou_refine_sync_f32(ctypes.byref(d), *a8[:7], n, 10, 5, f4, 1.0, 0, 0, one, 1 << 30, n) == -1
+    assert L.pt_iou_refine_sync_f32(ctypes.byref(d), *a8[:6], n, one, 10, 5, f4, 1.0, 0, 0, one, 1 << 30, n) == -1
+    assert L.pt_iou_refine_sync_f32(ctypes.byref(d), *a8, 17, 5, f4, 1.0, 0, 0, one, 1 << 30, n) == -3
 
 
 def test_tomp_mirror_contract():

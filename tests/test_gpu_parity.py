@@ -853,6 +853,37 @@ def test_iou_refinement_golden(tag, relative):
         assert torch.equal(b3, boxes)
 
 
+@pytest.mark.parametrize("relative,backtrack", [(False, False), (True, False), (False, True)])
+def test_iou_refinement_paths_agree(relative, backtrack):
+    """One refinement, three routes through the library: the per-frame call (proposals from host memory in a kernel argument block,
+    results polled from pinned host memory: pt_iou_refine_sync_f32), device in / device out on the fused iteration
+    (pt_iou_refine_f32, <= 16 proposals), and the unfused six-launch iteration that serves larger proposal sets -- the first two
+    bit-identical, the third (other summation order; here on 20 proposals = the 10 golden ones twice) within the north_star bound
+    of the float64 restatement."""
+    from pytracking_amd import iou_refine as IR
+    from oracle import iou_oracle as IO
+    g = load_golden("iou_refine")
+    net = _IoUNetStandIn(g).to(DEV).eval()
+    mod, feat = (T(g["mod3"]), T(g["mod4"])), (T(g["c3"]), T(g["c4"]))
+    b0 = torch.from_numpy(g["boxes"].copy())
+    step, decay = (2.5e-3, 1.0) if relative else (1.0, 0.5 if backtrack else 1.0)
+    host = IR.refine_boxes(net, mod, feat, b0, 5, step, decay, relative, backtrack=backtrack, to_host=True)
+    dev = IR.refine_boxes(net, mod, feat, b0.to(DEV), 5, step, decay, relative, backtrack=backtrack)
+    assert not host[0].is_cuda and dev[0].is_cuda
+    assert torch.equal(host[0], dev[0].cpu()) and torch.equal(host[1], dev[1].cpu())
+    b20 = torch.cat((b0, b0))
+    big = IR.refine_boxes(net, mod, feat, b20.to(DEV), 5, step, decay, relative, backtrack=backtrack)
+    t64 = lambda a: torch.from_numpy(np.asarray(a, dtype=np.float64))
+    p = {k[2:]: t64(v) for k, v in g.items() if k.startswith("w_")}
+    fn = IO.refine_atom if backtrack else IO.refine
+    want = fn(p, (t64(g["mod3"]), t64(g["mod4"])), (t64(g["c3"]), t64(g["c4"])), t64(g["boxes"]), 5, float(step), float(decay), relative)
+    for half in (slice(0, 10), slice(10, 20)):
+        close(big[0][half], want[0].numpy(), atol=2e-3 if backtrack else 5e-4)
+        close(big[1][half], want[1].numpy(), atol=1e-4)
+    close(host[0], want[0].numpy(), atol=2e-3 if backtrack else 5e-4)
+    close(host[1], want[1].numpy(), atol=1e-4)
+
+
 @pytest.mark.parametrize("tag,space", [("atom_default", "default"), ("atom_relative", "relative"), ("atom_nodecay", "default")])
 def test_iou_refinement_atom_golden(tag, space):
     """ATOM.optimize_boxes (atom.py:758-836) with per-proposal backtracking vs the reference run on CPU.  Backtracking is
