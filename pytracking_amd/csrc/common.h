@@ -134,10 +134,19 @@ __device__ __forceinline__ T pt_late_args(unsigned byte_offset) {
 // check per access, counted on both the vector-memory and the LDS counter).  pt_global() states that it points to global memory.
 template <typename T>
 using pt_gptr = T __attribute__((address_space(1)))*;
-// pointer members of late-fetched argument blocks are declared with these types: every access through them is a global_load /
-// global_store (as generic pointers they were flat_* -- 134-166 of them in k_adj2)
+// Pointer members of the late-fetched argument blocks of the solver / ATOM kernels have these types.  Declared global
+// (-DPT_LATE_GLOBAL) every access through them is a global_load / global_store instead of flat_* (134-166 flat accesses in k_adj2,
+// 3428 in fast_passes.hip) -- and the frame is 1 % SLOWER (A/B on one box, twice: 109.6 / 109.5 vs 108.5 / 108.6 us, k_corr2 8.43 vs
+// 8.34, k_adj2 7.77 vs 7.66 us; profiles/r03ae_late_pointer_address_space.txt): they are result stores and late loads, and the
+// compiler's schedule around them differs.  The generic form stays the default; the IoU kernels use pt_global() where it was measured
+// with their loads.
+#ifdef PT_LATE_GLOBAL
 typedef const float __attribute__((address_space(1)))* pt_gcf;
 typedef float __attribute__((address_space(1)))* pt_gf;
+#else
+typedef const float* pt_gcf;
+typedef float* pt_gf;
+#endif
 template <typename T>
 __device__ __forceinline__ pt_gptr<T> pt_global(T* p) { return (pt_gptr<T>)p; }
 

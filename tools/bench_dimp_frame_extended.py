@@ -40,13 +40,8 @@ def iou_net(dev):
     return net.to(dev).eval()
 
 
-def main():
-    ap = argparse.ArgumentParser()
-    ap.add_argument("--frames", type=int, default=300)
-    a = ap.parse_args()
-    if _lib.needs_build():
-        _lib.build_library()
-    dev = torch.device("cuda", 0)
+def measure(dev, frames=300):
+    a = types.SimpleNamespace(frames=frames)
     torch.manual_seed(1234)
     cfg = synth.DIMP50
     st = bench_frame.TrackState(cfg, cfg["memory"], seed=1234, device=dev)
@@ -87,8 +82,18 @@ def main():
         torch.cuda.synchronize()
         dt = (time.perf_counter() - t0) / a.frames
         out[tag] = {"us_per_frame": round(dt * 1e6, 1), "frames_per_s": round(1 / dt, 1)}
-    out["workload"] = "DiMP-50 frame without the backbone: clf head + classify/insert/5 SD iterations + localisation + IoU refinement"
-    print(json.dumps(out))
+    out["workload"] = ("DiMP-50 frame without the backbone, eager launches, host wall time: clf head + classify/insert/5 SD iterations + "
+                       "localisation (results on the host) + IoU refinement (results on the host)")
+    return out
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--frames", type=int, default=300)
+    a = ap.parse_args()
+    if _lib.needs_build():
+        _lib.build_library()
+    print(json.dumps(measure(torch.device("cuda", 0), a.frames)))
 
 
 if __name__ == "__main__":

@@ -50,10 +50,7 @@ def stock_default(net, mod, feat, boxes, iters, step):
     return b.view(-1, 4).cpu(), out.detach().view(-1).cpu()
 
 
-def main():
-    if _lib.needs_build():
-        _lib.build_library()
-    dev = torch.device("cuda", 0)
+def measure(dev, with_stock=True, reps=50):
     torch.manual_seed(0)
     net = Net().to(dev).eval()
     feat = (torch.randn(1, 256, 36, 36, device=dev), torch.randn(1, 256, 18, 18, device=dev))
@@ -66,22 +63,29 @@ def main():
         me = types.SimpleNamespace(params=params, net=types.SimpleNamespace(bb_regressor=net), iou_modulation=mod)
         fn = IR.optimize_boxes_relative if rel else IR.optimize_boxes_default
         runs = {"fused_us": lambda: fn(me, feat, boxes)}
-        if not rel:
+        if not rel and with_stock:
             runs["stock_autograd_us"] = lambda: stock_default(net, mod, feat, boxes.to(dev), iters, step)
         for name, f in runs.items():
             for _ in range(5):
                 r = f()
             torch.cuda.synchronize()
             t0 = time.perf_counter()
-            for _ in range(50):
+            for _ in range(reps):
                 r = f()
             torch.cuda.synchronize()
-            out[f"{tag}_{name}"] = round((time.perf_counter() - t0) / 50 * 1e6, 1)
-        if not rel:
+            out[f"{tag}_{name}"] = round((time.perf_counter() - t0) / reps * 1e6, 1)
+        if not rel and with_stock:
             a, b = fn(me, feat, boxes), stock_default(net, mod, feat, boxes.to(dev), iters, step)
             out[f"{tag}_max_box_diff"] = float((a[0] - b[0]).abs().max())
-    out["workload"] = "10 proposals, 256-channel IoU features 36x36 / 18x18, host wall time per call incl. the final copy"
-    print(json.dumps(out))
+    out["workload"] = ("10 proposals (host memory), 256-channel IoU features 36x36 / 18x18; host wall time per call until the refined boxes "
+                       "are readable on the host")
+    return out
+
+
+def main():
+    if _lib.needs_build():
+        _lib.build_library()
+    print(json.dumps(measure(torch.device("cuda", 0))))
 
 
 if __name__ == "__main__":

@@ -266,12 +266,25 @@ def end_to_end(dev, frames=60, num_iter=5):
     return out
 
 
+def iou_refine(dev):
+    """IoU-guided box refinement as the trackers call it per frame: tools/bench_iou.py without the stock leg."""
+    from tools import bench_iou
+    return bench_iou.measure(dev, with_stock=False, reps=100)
+
+
+def frame_after_backbone(dev):
+    """Everything of a DiMP-50 frame behind the backbone (tools/bench_dimp_frame_extended.py)."""
+    from tools import bench_dimp_frame_extended
+    return bench_dimp_frame_extended.measure(dev, frames=200)
+
+
 def all_other(dev):
-    """The BASELINE configs beyond the headline one, in a few hundred ms of device time."""
+    """The BASELINE configs beyond the headline one and the rows either side of the solver, in a few hundred ms of device time."""
     out = {}
     for key, fn in (("prdimp50_frame", lambda: sd_frame(dev, "prdimp")), ("tomp_predict", lambda: tomp(dev)),
                     ("lwl_n32_it3", lambda: lwl(dev, 32, 3)), ("lwl_n32_it4", lambda: lwl(dev, 32, 4)),
-                    ("atom_cg_n250", lambda: atom_cg(dev))):
+                    ("lwl_n8_it3", lambda: lwl(dev, 8, 3)), ("atom_cg_n250", lambda: atom_cg(dev)),
+                    ("iou_refine", lambda: iou_refine(dev)), ("dimp50_frame_after_backbone", lambda: frame_after_backbone(dev))):
         try:
             out[key] = fn()
         except Exception as exc:                                 # noqa: BLE001 -- a failing side workload must not hide the headline
