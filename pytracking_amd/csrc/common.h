@@ -132,8 +132,13 @@ __device__ __forceinline__ T pt_late_args(unsigned byte_offset) {
 
 // A pointer that came out of pt_late_args() is an integer pair to the compiler: accesses through it are FLAT (address-space
 // check per access, counted on both the vector-memory and the LDS counter).  pt_global() states that it points to global memory.
+#ifdef PT_GLOBAL_OFF                                // A/B switch: pt_global() becomes a no-op (flat accesses)
+template <typename T>
+using pt_gptr = T*;
+#else
 template <typename T>
 using pt_gptr = T __attribute__((address_space(1)))*;
+#endif
 // Pointer members of the late-fetched argument blocks of the solver / ATOM kernels have these types.  Declared global
 // (-DPT_LATE_GLOBAL) every access through them is a global_load / global_store instead of flat_* (134-166 flat accesses in k_adj2,
 // 3428 in fast_passes.hip) -- and the frame is 1 % SLOWER (A/B on one box, twice: 109.6 / 109.5 vs 108.5 / 108.6 us, k_corr2 8.43 vs
