@@ -6,9 +6,10 @@
 //   rect_to_rel / rel_to_rect                                 ltr/data/bounding_box_utils.py:4-33
 // The reference runs every refinement step as an autograd forward + backward (~60 launches, a host-visible graph per
 // step, 5-10 steps per frame).  Here the gradient of the predicted IoU w.r.t. the box is written out: forward pools ->
-// split-K GEMM on the matrix cores -> BatchNorm/ReLU/IoU head that also emits dIoU/d(pre-activation) -> GEMM with the
-// transposed weights -> PrRoIPool coordinate gradient -> box update, ten launches per step, no host synchronisation
-// until the boxes are read.
+// LinearBlock products on the matrix cores -> BatchNorm/ReLU/IoU head that also emits dIoU/d(pre-activation) -> products with
+// the transposed weights -> PrRoIPool coordinate gradient -> box update, no host synchronisation until the boxes are read.
+// Two forms: the general six-launch iteration (any proposal count <= 256) and, for the trackers' <= 16 proposals, a fused
+// three-launch iteration in which one workgroup owns a chunk of the pooled axis in both directions (second half of this file).
 #include "common.h"
 #include "pt_internal.h"
 #include "mfma_gemm.h"
@@ -260,9 +261,10 @@ __global__ __launch_bounds__(64) void k_iou_update(UpdArgs a) {
 //               dIoU/d(pre-activation);
 //   k_iou_bwd   forms its chunk of d IoU / d pooled (16 x I by I x 64, rows of the transposed weight) and immediately contracts
 //               it with the PrRoIPool coordinate gradient of the same elements -> four partial sums per proposal and chunk;
-//   k_iou_update2 adds the chunk partials and moves the boxes.
+//   the box update (chunk partials -> gradient -> step -> RoIs) runs in front of the NEXT k_iou_fwd, k_iou_final after the last one.
 // The weights (9 MB at ResNet-50 sizes) are read once per direction and stay in L2 between iterations; nothing of size
 // P x K is written to memory any more.
+
 // one pyramid level's operands; the kernels fetch the block of THEIR level in one batch (pt_late_args, common.h) -- indexing
 // a by-value argument struct with the run-time level made every field its own scalar load + wait at its point of use
 struct Lv {
@@ -286,11 +288,6 @@ extern "C" void pt_debug_set_iou_stamps(void* p) { g_iou_stamps = (unsigned long
 constexpr int FT = 512;                             // threads of k_iou_fwd / k_iou_bwd: 8 waves; wave w serves proposals w and w + 8
 typedef float f32x2 __attribute__((ext_vector_type(2)));
 
-// Geometry of one (proposal, bin): everything of the PrRoIPool integral that does not depend on the channel.  A chunk of 64 pooled
-// elements is ~2.5 channels x all bins, so computed per element (as the stand-alone op does) the ~300 instructions of hat-function
-// weights were repeated for every channel and the kernels were bound by them (a wave issues ~0.5 instructions / ns: measured,
-// experiments/icache_probe.hip).  The first P * bins threads of a workgroup fill this table once; an element then costs its 16 pixel
-// loads and ~50 instructions.  The weights are the expressions of prroi_fwd_window_sum / prroi_coor_window_sums, evaluated by another lane.
 // ---- the box update, folded into the front of the NEXT forward kernel (and a one-workgroup kernel after the last iteration) ----
 // A separate update launch cost ~5 us per iteration for 40 sums.  Every workgroup of k_iou_fwd now adds the gradient partials of the
 // previous iteration itself (22 KB from L2), moves the boxes, and keeps the RoIs in LDS; workgroup 0 also publishes them (state
@@ -392,6 +389,11 @@ __device__ __forceinline__ void iou_step(const UpdLate& U, int P, float (*red)[6
     __syncthreads();
 }
 
+// Geometry of one (proposal, bin): everything of the PrRoIPool integral that does not depend on the channel.  A chunk of 64 pooled
+// elements is ~2.5 channels x all bins, so computed per element (as the stand-alone op does) the ~300 instructions of hat-function
+// weights were repeated for every channel and the kernels were bound by them (a wave issues ~0.5 instructions / ns: measured,
+// experiments/icache_probe.hip).  The threads of a workgroup fill this table once; an element then costs its 36 window reads (LDS)
+// and ~100 instructions.  The weights are the expressions of prroi_fwd_window_sum / prroi_coor_window_sums, evaluated by another lane.
 constexpr int GW = 6;                               // window of the table path: bins that touch <= 6 x 6 pixels (the stand-alone op's two window sizes)
 struct BinGeo {
     float wx[GW], wy[GW], hxs[GW], hxe[GW], hys[GW], hye[GW];
