@@ -19,17 +19,20 @@ from .transformer import _Pack
 
 _CACHE = weakref.WeakKeyDictionary()          # AtomIoUNet instance -> (pack, prepared buffer, key)
 _SHAPES = weakref.WeakKeyDictionary()         # AtomIoUNet instance -> {(c3 shape, c4 shape, P): (dims, workspace bytes, parameter count)}
-_HOST_OUT = {}                                # device index -> pinned result buffer of pt_iou_refine_sync_f32
+_HOST_OUT = {}                                # (device index, stream) -> pinned result buffer of pt_iou_refine_sync_f32
 HOST_FLOATS = 96                              # PT_IOU_HOST_FLOATS (include/pt_hot.h)
 SYNC_MAX_P = 16
 
 
 def _host_out(device):
-    buf = _HOST_OUT.get(device.index)
+    """One pinned buffer per (device, stream), like `filter.workspace`: the sequence word is a per-buffer protocol, two trackers on two
+    streams of one device must not share it."""
+    key = (device.index, torch.cuda.current_stream(device).cuda_stream)
+    buf = _HOST_OUT.get(key)
     if buf is None:
         t = torch.zeros(HOST_FLOATS, dtype=torch.float32).pin_memory()
         buf = (t, ctypes.c_void_p(t.data_ptr()))
-        _HOST_OUT[device.index] = buf
+        _HOST_OUT[key] = buf
     return buf
 
 

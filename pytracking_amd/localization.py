@@ -54,11 +54,12 @@ _NEG_INF = -float('inf')
 
 def _host_out(device):
     """16 floats of pinned host memory per device that the localisation kernel writes directly (no copy launch)."""
-    buf = _HOST_OUT.get(device.index)
+    key = (device.index, torch.cuda.current_stream(device).cuda_stream)       # per (device, stream), like filter.workspace
+    buf = _HOST_OUT.get(key)
     if buf is None:
         t = torch.zeros(16, dtype=torch.float32).pin_memory()
         buf = (t, t.numpy(), ctypes.c_void_p(t.data_ptr()))
-        _HOST_OUT[device.index] = buf
+        _HOST_OUT[key] = buf
     return buf
 
 
