@@ -10,7 +10,9 @@ import subprocess
 _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.environ.get("PT_HOT_LIB", os.path.join(_HERE, "libpt_hot.so"))   # override: experiments only
 SOURCES = ["filter_kernels.hip", "fast_passes.hip", "sd_solver.hip", "mf_kernels.hip", "lwl_solver.hip", "atom_cg.hip", "atom_gn.hip", "tomp.hip", "localize.hip", "iou_refine.hip", "prroi.hip", "patch.hip", "api.hip"]
-HEADERS = ["common.h", "pt_internal.h", "rbuild.h", "sd_common.h", "mfma_gemm.h", os.path.join("..", "..", "include", "pt_hot.h")]
+HEADERS = ["common.h", "pt_internal.h", "rbuild.h", "sd_common.h", "mfma_gemm.h", "prroi_dev.h", os.path.join("..", "..", "include", "pt_hot.h")]
+# kernarg preload: leading scalar kernel parameters arrive in SGPRs at wave launch (kernels that take them that way only)
+HIPCC_FLAGS = ["--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-Wno-pass-failed", "-mllvm", "-amdgpu-kernarg-preload-count=14"]
 
 PT_SD_DIMP, PT_SD_DIMP_L2, PT_SD_PRDIMP = 0, 1, 2
 PT_ACT_RELU, PT_ACT_BENTPAR = 0, 1
@@ -110,9 +112,7 @@ def build_library(force=False, verbose=False) -> str:
         return LIB_PATH
     from concurrent.futures import ThreadPoolExecutor
     hipcc = os.environ.get("HIPCC", "/opt/rocm/bin/hipcc")
-    # kernarg preload: leading scalar kernel parameters arrive in SGPRs at wave launch (kernels that take them that way only)
-    flags = ["--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-Wno-pass-failed", "-mllvm", "-amdgpu-kernarg-preload-count=14"] + \
-        os.environ.get("PT_HOT_CFLAGS", "").split()
+    flags = HIPCC_FLAGS + os.environ.get("PT_HOT_CFLAGS", "").split()
     bdir = os.path.join(_HERE, "build")
     os.makedirs(bdir, exist_ok=True)
     stamp = os.path.join(bdir, "flags.txt")
