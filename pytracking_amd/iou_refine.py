@@ -36,16 +36,36 @@ def _host_out(device):
     return buf
 
 
+def _iou_tensors(net):
+    """The 14 parameter / buffer tensors of the IoU head in the order of the packed layout (`iou_layout`, csrc/iou_refine.hip).
+    Runs every frame: read through the modules' registries (what `nn.Module.__getattr__` resolves to, without ~40 Python-level
+    `__getattr__` calls); anything that is not laid out like the reference's AtomIoUNet takes the attribute path."""
+    try:
+        mods = net._modules
+        out = []
+        for name in ("fc3_rt", "fc4_rt"):
+            blk = mods[name]._modules
+            lin, bn = blk["linear"], blk["bn"]
+            out += [lin._parameters["weight"], lin._parameters["bias"], bn._parameters["weight"], bn._parameters["bias"],
+                    bn._buffers["running_mean"], bn._buffers["running_var"]]
+        head = mods["iou_predictor"]._parameters
+        out += [head["weight"], head["bias"]]
+        if all(isinstance(t, torch.Tensor) for t in out):
+            return out
+    except (AttributeError, KeyError, TypeError):
+        pass
+    out = []
+    for blk in (net.fc3_rt, net.fc4_rt):
+        out += [blk.linear.weight, blk.linear.bias, blk.bn.weight, blk.bn.bias, blk.bn.running_mean, blk.bn.running_var]
+    return out + [net.iou_predictor.weight, net.iou_predictor.bias]
+
+
 def _packs(net, dims):
     st = _CACHE.get(net)
     if st is None:
         st = {"pack": _Pack(), "prepared": None, "key": None}
         _CACHE[net] = st
-    tensors = []
-    for blk in (net.fc3_rt, net.fc4_rt):
-        tensors += [blk.linear.weight, blk.linear.bias, blk.bn.weight, blk.bn.bias, blk.bn.running_mean, blk.bn.running_var]
-    tensors += [net.iou_predictor.weight, net.iou_predictor.bias]
-    pack = st["pack"].get(tensors)
+    pack = st["pack"].get(_iou_tensors(net))
     if st["key"] != st["pack"].key:
         L = _lib.lib()
         st["prepared"] = torch.empty(L.pt_iou_prepared_floats(ctypes.byref(dims)), dtype=torch.float32, device=pack.device)

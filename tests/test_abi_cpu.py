@@ -234,3 +234,26 @@ def test_product_never_imports_oracle():
         if fn.endswith(".py"):
             src = open(os.path.join(pkg, fn)).read()
             assert "import oracle" not in src and "from oracle" not in src, fn
+
+
+def test_iou_head_tensor_gathering_matches_attribute_access():
+    """`iou_refine._iou_tensors` reads the IoU head's parameters through the module registries (per-frame path); it must hand out the
+    very tensor objects attribute access does, in the packed order, and fall back for objects that are not nn.Modules."""
+    import types
+    import torch
+    from pytracking_amd import iou_refine as IR
+
+    def block(k):
+        m = torch.nn.Module()
+        m.linear, m.bn, m.relu = torch.nn.Linear(8 * k * k, 32), torch.nn.BatchNorm2d(32), torch.nn.ReLU()
+        return m
+    net = torch.nn.Module()
+    net.fc3_rt, net.fc4_rt, net.iou_predictor = block(5), block(3), torch.nn.Linear(64, 1)
+    want = []
+    for blk in (net.fc3_rt, net.fc4_rt):
+        want += [blk.linear.weight, blk.linear.bias, blk.bn.weight, blk.bn.bias, blk.bn.running_mean, blk.bn.running_var]
+    want += [net.iou_predictor.weight, net.iou_predictor.bias]
+    got = IR._iou_tensors(net)
+    assert len(got) == 14 and all(a is b for a, b in zip(got, want))
+    loose = types.SimpleNamespace(fc3_rt=net.fc3_rt, fc4_rt=net.fc4_rt, iou_predictor=net.iou_predictor)   # no registries: attribute path
+    assert all(a is b for a, b in zip(IR._iou_tensors(loose), want))
