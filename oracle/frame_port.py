@@ -25,8 +25,19 @@ def _dimp_kwargs(cfg):
                 alpha_eps=cfg["alpha_eps"])
 
 
-def oracle_step(cfg, mem_feat, mem_bb, sample_weight, filt, test_feat, slot, num_iter):
-    """classify -> first arg-max -> re-centre box `slot` -> memory insert -> DiMP SD solve (float64)."""
+def _prdimp_kwargs(cfg):
+    return dict(step_length=cfg["init_step_length"], filter_reg=cfg["init_filter_reg"],
+                min_filter_reg=cfg["min_filter_reg"], feat_stride=cfg["feat_stride"], gauss_sigma=cfg["gauss_sigma"],
+                alpha_eps=cfg["alpha_eps"], uni_weight=cfg["init_uni_weight"] or 0.0,
+                normalize_label=cfg["normalize_label"], label_shrink=cfg["label_shrink"],
+                softmax_reg_val=cfg["softmax_reg"], label_threshold=cfg["label_threshold"])
+
+
+def oracle_step(cfg, mem_feat, mem_bb, sample_weight, filt, test_feat, slot, num_iter, kind="dimp"):
+    """classify -> first arg-max -> re-centre box `slot` -> memory insert -> SD solve (float64).
+    kind "dimp": DiMPSteepestDescentGN (optimizer.py:85-170); "prdimp": PrDiMPSteepestDescentNewton
+    (optimizer.py:355-439).  The frame composition follows pytracking/tracker/dimp/dimp.py:190-194 (classify),
+    :605-648 (memory insert + filter update)."""
     f64 = lambda a: np.asarray(a, dtype=np.float64)
     K = cfg["K"]
     scores = O.apply_filter(f64(test_feat)[None], f64(filt))[0]
@@ -38,15 +49,19 @@ def oracle_step(cfg, mem_feat, mem_bb, sample_weight, filt, test_feat, slot, num
     bb[slot, 1] = (row + off) * cfg["feat_stride"] - bb[slot, 3] / 2.0
     mem = f64(mem_feat).copy()
     mem[slot] = f64(test_feat)
-    its, _ = O.dimp_sd(f64(filt), mem, bb, f64(sample_weight), num_iter=num_iter, compute_losses=False,
-                       **_dimp_kwargs(cfg))
+    if kind == "prdimp":
+        its, _ = O.prdimp_sd(f64(filt), mem, bb, f64(sample_weight), num_iter=num_iter, compute_losses=False,
+                             **_prdimp_kwargs(cfg))
+    else:
+        its, _ = O.dimp_sd(f64(filt), mem, bb, f64(sample_weight), num_iter=num_iter, compute_losses=False,
+                           **_dimp_kwargs(cfg))
     return dict(scores=scores, peak=(row, col), bb=bb, filter=its[-1], mem=mem)
 
 
 class TorchCpuTracker:
     """Reference CPU path port (see module docstring).  fp32, torch.no_grad, `threads` CPU threads."""
 
-    def __init__(self, cfg, n, seed, threads=None, device="cpu", dtype=None, gemm=False):
+    def __init__(self, cfg, n, seed, threads=None, device="cpu", dtype=None, gemm=False, kind="dimp"):
         import torch
         self.torch = torch
         if threads:
@@ -61,8 +76,13 @@ class TorchCpuTracker:
         self.gemm = bool(gemm)
         w0, feat, bb, sw = synth.dimp_problem(seed, n, cfg)
         T = lambda a: torch.from_numpy(a).to(dev, dtype)
+        self.kind = kind
+        if kind == "prdimp":                       # zero start filter, as bench_frame.TrackState(kind="prdimp") and the
+            w0 = w0 * 0                            # golden prdimp_sd_cfg3_n50 (oracle/make_golden.py)
         self.mem_feat, self.mem_bb, self.sw, self.filter = T(feat), T(bb), T(sw), T(w0)[None]
         c = cfg
+        if kind == "prdimp":
+            return
         self.label_w = T(synth.gauss_lut(c["num_dist_bins"], c["bin_displacement"], c["init_gauss_sigma"])).view(1, -1, 1, 1)
         self.mask_w = T(synth.mask_lut(c["num_dist_bins"], c["bin_displacement"], c["mask_init_factor"])).view(1, -1, 1, 1)
         self.spat_w = torch.ones(1, c["num_dist_bins"], 1, 1, device=dev, dtype=dtype)
@@ -130,6 +150,55 @@ class TorchCpuTracker:
             w = w - (step * a_num / a_den) * g
         return w
 
+    def label_density(self, bb, K, O):            # optimizer.py:331-353 (get_label_density)
+        torch, c = self.torch, self.cfg
+        ctr = ((bb[:, :2] + bb[:, 2:] / 2) / c["feat_stride"]).flip((1,)) - (K % 2) / 2.0
+        k0 = torch.arange(O, dtype=self.dtype, device=self.dev).view(1, -1, 1)
+        k1 = torch.arange(O, dtype=self.dtype, device=self.dev).view(1, 1, -1)
+        d0 = (k0 - ctr[:, 0].view(-1, 1, 1)) ** 2
+        d1 = (k1 - ctr[:, 1].view(-1, 1, 1)) ** 2
+        sig = c["gauss_sigma"]
+        if sig == 0:                               # :337-344
+            i0, i1 = d0.view(-1, O).argmin(dim=-1), d1.view(-1, O).argmin(dim=-1)
+            gauss = torch.zeros(bb.shape[0], O, O, dtype=self.dtype, device=self.dev)
+            gauss[torch.arange(bb.shape[0]), i0, i1] = 1.0
+        else:
+            g0 = torch.exp(-1.0 / (2 * sig ** 2) * d0)
+            g1 = torch.exp(-1.0 / (2 * sig ** 2) * d1)
+            gauss = (g0 / (2 * math.pi * sig ** 2)) * g1                                       # :348
+        gauss = gauss * (gauss > c["label_threshold"]).to(self.dtype)                        # :349
+        if c["normalize_label"]:
+            gauss = gauss / (gauss.sum(dim=(-2, -1), keepdim=True) + 1e-8)
+        uni = c["init_uni_weight"] or 0.0
+        return (1.0 - c["label_shrink"]) * ((1.0 - uni) * gauss + uni / (O * O))
+
+    def solve_prdimp(self, w, feat, bb, sw, num_iter):   # optimizer.py:355-439, compute_losses=False
+        torch, c = self.torch, self.cfg
+        K = w.shape[-1]
+        O = feat.shape[-1] + (K + 1) % 2
+        n = feat.shape[0]
+        step = c["init_step_length"]
+        reg = max(c["init_filter_reg"] ** 2, c["min_filter_reg"] ** 2)
+        label = self.label_density(bb, K, O).view(n, 1, O, O)
+        swv = sw.view(-1, 1, 1, 1)                 # :387-390: NOT square-rooted
+        for _ in range(num_iter):
+            s = self.corr(feat, w)                                                             # :406
+            flat = s.reshape(n, -1)                # activation.softmax_reg (activation.py:7-16): an extra constant logit
+            if c["softmax_reg"] is not None:
+                flat = torch.cat((flat, flat.new_full((n, 1), float(c["softmax_reg"]))), dim=1)
+            P = torch.softmax(flat, dim=1)[:, :O * O].reshape(s.shape)
+            res = swv * (P - label)                                                            # :408
+            g = self.adj(feat, res, K) + reg * w                                               # :414-415
+            sg = self.corr(feat, g)                                                            # :418
+            psg = P * sg
+            h = psg - P * psg.sum(dim=(-2, -1), keepdim=True)                                  # :420
+            ghg = (sg * h).reshape(n, -1).sum(dim=1).clamp(min=0)                              # :421
+            ghg = (sw.view(-1) * ghg).sum()                                                    # :422
+            a_num = (g * g).sum()
+            a_den = (ghg + (reg + c["alpha_eps"]) * a_num).clamp(1e-8)
+            w = w - (step * a_num / a_den) * g                                                 # :430
+        return w
+
     def step(self, test_feat, slot, num_iter):
         torch, c = self.torch, self.cfg
         with torch.no_grad():
@@ -140,5 +209,6 @@ class TorchCpuTracker:
             self.mem_bb[slot, 0] = (col + off) * c["feat_stride"] - self.mem_bb[slot, 2] / 2.0
             self.mem_bb[slot, 1] = (row + off) * c["feat_stride"] - self.mem_bb[slot, 3] / 2.0
             self.mem_feat[slot] = test_feat
-            self.filter = self.solve(self.filter, self.mem_feat, self.mem_bb, self.sw, num_iter)
+            solve = self.solve_prdimp if self.kind == "prdimp" else self.solve
+            self.filter = solve(self.filter, self.mem_feat, self.mem_bb, self.sw, num_iter)
         return scores

@@ -15,6 +15,7 @@ HEADERS = ["common.h", "pt_internal.h", "rbuild.h", "sd_common.h", "mfma_gemm.h"
 HIPCC_FLAGS = ["--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-Wno-pass-failed", "-mllvm", "-amdgpu-kernarg-preload-count=14"]
 
 PT_SD_DIMP, PT_SD_DIMP_L2, PT_SD_PRDIMP = 0, 1, 2
+PT_ERR_NULL, PT_ERR_SHAPE, PT_ERR_UNSUPPORTED, PT_ERR_WORKSPACE, PT_ERR_LAUNCH = -1, -2, -3, -4, -5   # include/pt_hot.h
 PT_ACT_RELU, PT_ACT_BENTPAR = 0, 1
 PT_MASK_SIGMOID, PT_MASK_LINEAR = 0, 1
 
@@ -96,8 +97,15 @@ class SdParams(ctypes.Structure):
     ]
 
 
+def _build_flags():
+    return HIPCC_FLAGS + os.environ.get("PT_HOT_CFLAGS", "").split()
+
+
 def needs_build() -> bool:
     if not os.path.exists(LIB_PATH):
+        return True
+    stamp = os.path.join(_HERE, "build", "flags.txt")       # a changed PT_HOT_CFLAGS is a rebuild, not a silently stale library
+    if os.path.exists(stamp) and open(stamp).read() != " ".join(_build_flags()):
         return True
     t = os.path.getmtime(LIB_PATH)
     deps = [os.path.join(_HERE, "csrc", s) for s in SOURCES + HEADERS]
@@ -112,7 +120,7 @@ def build_library(force=False, verbose=False) -> str:
         return LIB_PATH
     from concurrent.futures import ThreadPoolExecutor
     hipcc = os.environ.get("HIPCC", "/opt/rocm/bin/hipcc")
-    flags = HIPCC_FLAGS + os.environ.get("PT_HOT_CFLAGS", "").split()
+    flags = _build_flags()
     bdir = os.path.join(_HERE, "build")
     os.makedirs(bdir, exist_ok=True)
     stamp = os.path.join(bdir, "flags.txt")

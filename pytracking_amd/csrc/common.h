@@ -92,35 +92,74 @@ __device__ __forceinline__ float block_max(float v, float* scratch) {
 //     disappear).  `byte_offset` = offset of the struct parameter in the segment (the scalars in front of it, 8-aligned).
 //   * Whole 16-dword blocks are fetched and defined in SGPRs by an `asm volatile` right there: otherwise the compiler re-fetches
 //     fields at their uses, one ~1.2 us stall each, where it finds that cheaper than holding them in registers.
+//   * The fetch never leaves the struct: whole 16-dword blocks for sizeof(T) / 64, then ONE narrower load per set bit of the
+//     remaining dword count (x8 / x4 / x2 / x1).  (Round 3 rounded the last block up to 64 bytes and read up to 56 bytes past
+//     the end of the kernel-argument segment -- a fault if the segment ends at the end of the runtime's argument pool.)
 typedef int pt_i32x16 __attribute__((ext_vector_type(16)));
+typedef int pt_i32x8 __attribute__((ext_vector_type(8)));
+typedef int pt_i32x4 __attribute__((ext_vector_type(4)));
+typedef int pt_i32x2 __attribute__((ext_vector_type(2)));
 template <typename T>
-struct PtLate { pt_i32x16 blk[(sizeof(T) / 4 + 15) / 16]; };
-// request the block (s_load_dwordx16 each; the last one may read into the implicit arguments behind it, inside the segment)
+struct PtLate {
+    static constexpr int NW = sizeof(T) / 4, NB = NW / 16, R = NW % 16;
+    pt_i32x16 blk[NB > 0 ? NB : 1];
+    pt_i32x8 t8;
+    pt_i32x4 t4;
+    pt_i32x2 t2;
+    int t1;
+};
+// request the block (s_load_dwordx16 each + the narrow tail); exactly sizeof(T) bytes are read
 template <typename T>
 __device__ __forceinline__ PtLate<T> pt_late_issue(unsigned byte_offset) {
     static_assert(sizeof(T) % 4 == 0 && sizeof(T) <= 3 * 64, "argument blocks: whole dwords, at most 3 x 16 (SGPR budget)");
+    typedef PtLate<T> L;
     const char __attribute__((address_space(4)))* p = (const char __attribute__((address_space(4)))*)__builtin_amdgcn_kernarg_segment_ptr();
     p += byte_offset;
     asm volatile("" : "+s"(p)::"memory");
-    const pt_i32x16 __attribute__((address_space(4)))* q = (const pt_i32x16 __attribute__((address_space(4)))*)p;
-    PtLate<T> r;
+    L r;
 #pragma unroll
-    for (unsigned b = 0; b < sizeof(r.blk) / sizeof(r.blk[0]); ++b) r.blk[b] = q[b];
+    for (int b = 0; b < L::NB; ++b) r.blk[b] = ((const pt_i32x16 __attribute__((address_space(4)))*)p)[b];
+    const char __attribute__((address_space(4)))* q = p + 64 * L::NB;
+    if constexpr ((L::R & 8) != 0) { r.t8 = *(const pt_i32x8 __attribute__((address_space(4)))*)q; q += 32; }
+    if constexpr ((L::R & 4) != 0) { r.t4 = *(const pt_i32x4 __attribute__((address_space(4)))*)q; q += 16; }
+    if constexpr ((L::R & 2) != 0) { r.t2 = *(const pt_i32x2 __attribute__((address_space(4)))*)q; q += 8; }
+    if constexpr ((L::R & 1) != 0) { r.t1 = *(const int __attribute__((address_space(4)))*)q; }
     return r;
 }
 // the one place where the fetch is waited for.  Every dword of a block is live up to here (the asm takes whole blocks), so no
 // scalar register under a landing load is reused in between -- that is what makes a wait appear early
 template <typename T>
 __device__ __forceinline__ T pt_late_get(PtLate<T>& r) {
-    constexpr int NW = sizeof(T) / 4;
-    struct Words { int w[NW]; };
+    typedef PtLate<T> L;
+    struct Words { int w[L::NW]; };
     Words tmp;
 #pragma unroll
-    for (unsigned b = 0; b < sizeof(r.blk) / sizeof(r.blk[0]); ++b) {
+    for (int b = 0; b < L::NB; ++b) {
         asm volatile("" : "+s"(r.blk[b]));
 #pragma unroll
-        for (int k = 0; k < 16; ++k)
-            if ((int)b * 16 + k < NW) tmp.w[b * 16 + k] = r.blk[b][k];
+        for (int k = 0; k < 16; ++k) tmp.w[b * 16 + k] = r.blk[b][k];
+    }
+    int at = 16 * L::NB;
+    if constexpr ((L::R & 8) != 0) {
+        asm volatile("" : "+s"(r.t8));
+#pragma unroll
+        for (int k = 0; k < 8; ++k) tmp.w[at + k] = r.t8[k];
+        at += 8;
+    }
+    if constexpr ((L::R & 4) != 0) {
+        asm volatile("" : "+s"(r.t4));
+#pragma unroll
+        for (int k = 0; k < 4; ++k) tmp.w[at + k] = r.t4[k];
+        at += 4;
+    }
+    if constexpr ((L::R & 2) != 0) {
+        asm volatile("" : "+s"(r.t2));
+        tmp.w[at] = r.t2[0]; tmp.w[at + 1] = r.t2[1];
+        at += 2;
+    }
+    if constexpr ((L::R & 1) != 0) {
+        asm volatile("" : "+s"(r.t1));
+        tmp.w[at] = r.t1;
     }
     return __builtin_bit_cast(T, tmp);
 }

@@ -913,15 +913,7 @@ extern "C" int pt_iou_refine_sync_f32(const pt_iou_dims* d, const float* params,
                                       int relative, int backtrack, void* ws, size_t ws_bytes, void* stream) {
     if (!out_host || !init_boxes_host) return PT_ERR_NULL;
     if (P > FUSED_MAX_P) return PT_ERR_UNSUPPORTED;
-    static const void* checked = nullptr;                               // pointer class verified once per buffer
-    if (checked != out_host) {
-        hipPointerAttribute_t at;
-        if (hipPointerGetAttributes(&at, out_host) != hipSuccess || at.type != hipMemoryTypeHost) {
-            (void)hipGetLastError();
-            return PT_ERR_UNSUPPORTED;
-        }
-        checked = out_host;
-    }
+    if (!pt_pinned_host_checked(out_host) || pt_stream_is_capturing(stream)) return PT_ERR_UNSUPPORTED;
     volatile float* word = out_host + 95;
     float seq = *word + 1.0f;
     if (!(seq >= 1.0f && seq < 8388608.0f)) seq = 1.0f;                 // stays an exactly representable integer

@@ -231,15 +231,7 @@ extern "C" int pt_localize_advanced_f32(const float* scores, const float* scores
 extern "C" int pt_localize_advanced_sync_f32(const float* scores, const float* scores_hn, const pt_localize_state* st,
                                              float* out16_host, int S, int H, int W, void* stream) {
     if (!out16_host) return PT_ERR_NULL;
-    static const void* checked = nullptr;                               // pointer class verified once per buffer
-    if (checked != out16_host) {
-        hipPointerAttribute_t at;
-        if (hipPointerGetAttributes(&at, out16_host) != hipSuccess || at.type != hipMemoryTypeHost) {
-            (void)hipGetLastError();
-            return PT_ERR_UNSUPPORTED;
-        }
-        checked = out16_host;
-    }
+    if (!pt_pinned_host_checked(out16_host) || pt_stream_is_capturing(stream)) return PT_ERR_UNSUPPORTED;
     pt_localize_params q;
     int rc = pt_localize_constants_f32(st, S, H, W, &q);
     if (rc) return rc;

@@ -137,3 +137,28 @@ int pt_launch_prroi_bwd_coor2(const float* const grad_out[2], const float* const
                               const int C[2], const int H[2], const int W[2], const int PH[2], const float scale[2],
                               const float* rois, int R, int slices, hipStream_t st);
 
+
+// Result buffers of the *_sync_* entry points (pinned host memory the device writes and the host polls).  The pointer class
+// is verified once per buffer; the verified set is small, lock-free and shared by all threads (one tracker per stream / thread
+// alternates between its own buffers, so a single cached pointer would re-verify on every call and race between threads).
+#include <atomic>
+static inline bool pt_pinned_host_checked(const void* p) {
+    static std::atomic<const void*> seen[8];
+    static std::atomic<unsigned> next{0};
+    for (auto& s : seen)
+        if (s.load(std::memory_order_acquire) == p) return true;
+    hipPointerAttribute_t at;
+    if (hipPointerGetAttributes(&at, p) != hipSuccess || at.type != hipMemoryTypeHost) {
+        (void)hipGetLastError();
+        return false;
+    }
+    seen[next.fetch_add(1, std::memory_order_relaxed) & 7].store(p, std::memory_order_release);
+    return true;
+}
+// A host-polled result cannot be waited for while the stream is being captured into a graph (nothing executes): refuse at once
+// instead of spinning into the 2 s fallback.
+static inline bool pt_stream_is_capturing(void* stream) {
+    hipStreamCaptureStatus cs = hipStreamCaptureStatusNone;
+    if (hipStreamIsCapturing((hipStream_t)stream, &cs) != hipSuccess) { (void)hipGetLastError(); return false; }
+    return cs != hipStreamCaptureStatusNone;
+}

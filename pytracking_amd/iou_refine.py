@@ -126,8 +126,11 @@ def refine_boxes(net, modulation, iou_features, init_boxes, num_iter, step_lengt
         rc = L.pt_iou_refine_sync_f32(ctypes.byref(dims), _ptr(pack), _ptr(prepared), _ptr(c3), _ptr(c4), _ptr(mod3), _ptr(mod4),
                                       ctypes.c_void_p(boxes.data_ptr()), host_ptr, P, int(num_iter), (ctypes.c_float * 4)(*steps),
                                       float(step_decay), int(bool(relative)), int(bool(backtrack)), _ptr(ws), ws.numel(), _stream())
-        _lib.check(rc, "pt_iou_refine_sync_f32")
-        return host[:4 * P].clone().view(P, 4), host[64:64 + P].clone()
+        if rc != _lib.PT_ERR_UNSUPPORTED:
+            _lib.check(rc, "pt_iou_refine_sync_f32")
+            return host[:4 * P].clone().view(P, 4), host[64:64 + P].clone()
+        # the fused iteration is switched off (PT_IOU_UNFUSED=1) or the stream is being captured: the regular device route
+        boxes = boxes.to(c3.device)
     out_boxes = torch.empty_like(boxes)
     out_iou = torch.empty(P, dtype=torch.float32, device=c3.device)
     rc = L.pt_iou_refine_f32(ctypes.byref(dims), _ptr(pack), _ptr(prepared), _ptr(c3), _ptr(c4), _ptr(mod3), _ptr(mod4),

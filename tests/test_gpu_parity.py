@@ -585,6 +585,84 @@ def test_bench_trajectory_closed_loop_60_frames():
     print("closed-loop worst errors over 60 frames:", worst)
 
 
+@pytest.mark.parametrize("C,n", [(32, 5), (128, 6), (512, 7)])
+def test_track_frame_prdimp_matches_oracle_composition(C, n):
+    """`pt_track_frame_f32(PT_SD_PRDIMP)` -- classification read off the solve's first correlation, first arg-max, box
+    re-centring, memory insert, softmax-Newton solve (optimizer.py:355-439; dimp.py:190-194,605-648) -- against the
+    float64 composition of the oracle pieces, from a NON-zero filter (so the classification map is not trivially 0)
+    and from the zero start filter of the benchmark state."""
+    from pytracking_amd import bench_frame
+    from oracle import frame_port
+    cfg = dict(synth.PRDIMP50, C=C)
+    for zero_start in (False, True):
+        st = bench_frame.TrackState(cfg, n, seed=177, device=DEV, kind="prdimp")
+        if not zero_start:
+            w_np = synth.dimp_problem(177, n, cfg)[0]
+            st.filter.copy_(T(w_np))
+        rng = np.random.default_rng(178)
+        x = synth.clf_features(rng, 1, cfg["C"], cfg["H"], cfg["W"], cfg["K"])
+        mem0, bb0, w0 = st.mem_feat.cpu().numpy().copy(), st.mem_bb.cpu().numpy().copy(), st.filter.cpu().numpy().copy()
+        st.step(T(x)[0], slot=3, num_iter=3)
+        torch.cuda.synchronize()
+        ref = frame_port.oracle_step(cfg, mem0, bb0, st.sample_weight.cpu().numpy(), w0, x[0], slot=3, num_iter=3, kind="prdimp")
+        close(st.scores, ref["scores"], atol=2e-5)
+        assert tuple(st.peak.cpu().numpy().astype(int)) == tuple(ref["peak"])
+        close(st.mem_bb, ref["bb"], atol=1e-4)
+        close(st.mem_feat, ref["mem"], atol=0)
+        close(st.filter, ref["filter"], atol=2e-5)
+
+
+def test_bench_trajectory_prdimp_closed_loop_40_frames():
+    """BENCH's `prdimp50_frame` workload / BASELINE configs[2]'s per-GPU workload on its exact call path: 40 consecutive
+    `pt_track_frame_f32(PT_SD_PRDIMP)` frames at n = 50, C = 512, 22x22 features (23x23 score maps), 5 iterations, zero
+    start filter -- each frame classifies with the filter the previous frame left, re-centres a box on its own arg-max and
+    overwrites a memory slot -- against the float64 restatement of the reference's op sequence
+    (oracle/frame_port.TorchCpuTracker(kind="prdimp"), pinned to the reference golden `prdimp_sd_cfg3_n50` in
+    tests/test_oracle_golden.py::test_torch_port_prdimp_matches_reference).  Scores, filter and boxes within 1e-4 at EVERY
+    frame, peaks equal; then the same frames as two replays of one 20-frame hipGraph bit-equal to the eager states."""
+    import os
+    from pytracking_amd import bench_frame
+    from oracle.frame_port import TorchCpuTracker
+    cfg, n, G, start, frames = synth.PRDIMP50, 50, 20, 5, 40
+    st = bench_frame.TrackState(cfg, n, seed=2234, device=DEV, kind="prdimp")
+    ref = TorchCpuTracker(cfg, n, seed=2234, threads=min(16, os.cpu_count() or 1), dtype=torch.float64, gemm=True, kind="prdimp")
+    pool_np = synth.clf_features(np.random.default_rng(4322), 50, cfg["C"], cfg["H"], cfg["W"], cfg["K"])
+    pool, pool64 = T(pool_np), torch.from_numpy(pool_np).double()
+    f0, m0, b0 = st.filter.clone(), st.mem_feat.clone(), st.mem_bb.clone()
+    snaps, worst = {}, dict(scores=0.0, filter=0.0, bb=0.0)
+    for f in range(frames):
+        k = start + f % G
+        st.step(pool[k], slot=k, num_iter=5)
+        s_ref = ref.step(pool64[k], k, 5)
+        e_s = float((st.scores.double().cpu() - s_ref).abs().max())
+        e_w = float((st.filter.double().cpu() - ref.filter[0]).abs().max())
+        e_b = float((st.mem_bb.double().cpu() - ref.mem_bb).abs().max())
+        flat = int(torch.argmax(s_ref))
+        assert tuple(st.peak.cpu().numpy().astype(int)) == divmod(flat, s_ref.shape[1]), f
+        assert e_s <= 1e-4 and e_w <= 1e-4 and e_b <= 1e-4, (f, e_s, e_w, e_b)
+        worst = dict(scores=max(worst["scores"], e_s), filter=max(worst["filter"], e_w), bb=max(worst["bb"], e_b))
+        if (f + 1) % G == 0:
+            snaps[f + 1] = (st.filter.clone(), st.scores.clone(), st.mem_bb.clone(), st.mem_feat[start:start + G].clone())
+    assert float(st.filter.abs().max()) > 1e-2                        # the filter left its zero start
+    assert float(st.scores.abs().max()) > 1e-2                        # and the classification map is a real one
+    st.filter.copy_(f0); st.mem_feat.copy_(m0); st.mem_bb.copy_(b0)
+    stream = torch.cuda.Stream()
+    stream.wait_stream(torch.cuda.current_stream())
+    with torch.cuda.stream(stream):
+        g = torch.cuda.CUDAGraph()
+        with torch.cuda.graph(g, stream=stream):
+            for f in range(G):
+                st.step(pool[start + f], slot=start + f, num_iter=5)
+        for rep in range(1, frames // G + 1):
+            g.replay()
+            stream.synchronize()
+            w, s, b, m = snaps[rep * G]
+            assert torch.equal(st.filter, w) and torch.equal(st.scores, s) and torch.equal(st.mem_bb, b), rep
+            assert torch.equal(st.mem_feat[start:start + G], m)
+    torch.cuda.current_stream().wait_stream(stream)
+    print("PrDiMP closed-loop worst errors over %d frames:" % frames, worst)
+
+
 # ------------------------------------------------------------------------------------------------------
 # ToMP transformer model predictor (SURVEY.md section 8a row a16)
 # ------------------------------------------------------------------------------------------------------
@@ -853,35 +931,31 @@ def test_iou_refinement_golden(tag, relative):
         assert torch.equal(b3, boxes)
 
 
-@pytest.mark.parametrize("relative,backtrack", [(False, False), (True, False), (False, True)])
-def test_iou_refinement_paths_agree(relative, backtrack):
+@pytest.mark.parametrize("tag,relative,backtrack", [("default", False, False), ("relative", True, False), ("atom_default", False, True)])
+def test_iou_refinement_paths_agree(tag, relative, backtrack):
     """One refinement, three routes through the library: the per-frame call (proposals from host memory in a kernel argument block,
     results polled from pinned host memory: pt_iou_refine_sync_f32), device in / device out on the fused iteration
     (pt_iou_refine_f32, <= 16 proposals), and the unfused six-launch iteration that serves larger proposal sets -- the first two
-    bit-identical, the third (other summation order; here on 20 proposals = the 10 golden ones twice) within the north_star bound
-    of the float64 restatement."""
+    bit-identical, the third (other summation order; here on 20 proposals = the 10 golden ones twice: proposals are independent
+    of each other in an eval-mode network) under the SAME rule as every other refinement test (`_iou_box_check`: the north_star
+    bound against the float64 restatement and the reference golden)."""
     from pytracking_amd import iou_refine as IR
-    from oracle import iou_oracle as IO
     g = load_golden("iou_refine")
     net = _IoUNetStandIn(g).to(DEV).eval()
     mod, feat = (T(g["mod3"]), T(g["mod4"])), (T(g["c3"]), T(g["c4"]))
     b0 = torch.from_numpy(g["boxes"].copy())
-    step, decay = (2.5e-3, 1.0) if relative else (1.0, 0.5 if backtrack else 1.0)
-    host = IR.refine_boxes(net, mod, feat, b0, 5, step, decay, relative, backtrack=backtrack, to_host=True)
-    dev = IR.refine_boxes(net, mod, feat, b0.to(DEV), 5, step, decay, relative, backtrack=backtrack)
+    iters, step, decay = g[f"{tag}_cfg"]
+    iters, step, decay = int(iters), float(step), float(decay)
+    host = IR.refine_boxes(net, mod, feat, b0, iters, step, decay, relative, backtrack=backtrack, to_host=True)
+    dev = IR.refine_boxes(net, mod, feat, b0.to(DEV), iters, step, decay, relative, backtrack=backtrack)
     assert not host[0].is_cuda and dev[0].is_cuda
     assert torch.equal(host[0], dev[0].cpu()) and torch.equal(host[1], dev[1].cpu())
-    b20 = torch.cat((b0, b0))
-    big = IR.refine_boxes(net, mod, feat, b20.to(DEV), 5, step, decay, relative, backtrack=backtrack)
-    t64 = lambda a: torch.from_numpy(np.asarray(a, dtype=np.float64))
-    p = {k[2:]: t64(v) for k, v in g.items() if k.startswith("w_")}
-    fn = IO.refine_atom if backtrack else IO.refine
-    want = fn(p, (t64(g["mod3"]), t64(g["mod4"])), (t64(g["c3"]), t64(g["c4"])), t64(g["boxes"]), 5, float(step), float(decay), relative)
+    _iou_box_check(host[0], host[1], g, tag, relative, atom=backtrack)
+    big = IR.refine_boxes(net, mod, feat, torch.cat((b0, b0)).to(DEV), iters, step, decay, relative, backtrack=backtrack)
+    assert big[0].shape == (20, 4)
     for half in (slice(0, 10), slice(10, 20)):
-        close(big[0][half], want[0].numpy(), atol=2e-3 if backtrack else 5e-4)
-        close(big[1][half], want[1].numpy(), atol=1e-4)
-    close(host[0], want[0].numpy(), atol=2e-3 if backtrack else 5e-4)
-    close(host[1], want[1].numpy(), atol=1e-4)
+        _iou_box_check(big[0][half], big[1][half], g, tag, relative, atom=backtrack)
+    assert torch.equal(big[0][:10], big[0][10:]) and torch.equal(big[1][:10], big[1][10:])
 
 
 @pytest.mark.parametrize("tag,space", [("atom_default", "default"), ("atom_relative", "relative"), ("atom_nodecay", "default")])
@@ -1099,10 +1173,32 @@ def test_iou_refinement_deployed_size_golden(tag):
     assert float(np.abs(g[f"{tag}_boxes"] - boxes).max()) > 2.0
 
 
+@pytest.mark.parametrize("tag", ["default", "relative", "atom"])
+def test_iou_refinement_deployed_size_unfused_route(tag):
+    """The unfused iteration (more than 16 proposals: `k_iou_setup` / `k_prroi_*2` / `k_gemm_pair` / `k_iou_head` /
+    `k_iou_update`) at the DEPLOYED sizes (256-channel IoU features, 256-wide LinearBlocks): 20 proposals = the golden's 10
+    twice (an eval-mode network treats proposals independently, atom_iou_net.py:96-136), each half against the reference run
+    at the north_star bound 1e-4 (IoU and pixels) -- the same bar as the fused route in the test above."""
+    from pytracking_amd import iou_refine as IR
+    g = load_golden("iou_refine_full")
+    cfg = synth.IOU50
+    net = _IoUNetFromParams(synth.iou_net_params(int(g["param_seed"])), cfg["C"], cfg["I"]).to(DEV).eval()
+    c3, c4, m3, m4, boxes = synth.iou_inputs(int(g["input_seed"]))
+    iters, step, decay = g[f"{tag}_cfg"]
+    b20 = torch.from_numpy(np.concatenate((boxes, boxes))).to(DEV)
+    b, iou = IR.refine_boxes(net, (T(m3), T(m4)), (T(c3), T(c4)), b20, int(iters), float(step), float(decay),
+                             tag == "relative", backtrack=(tag == "atom"))
+    assert b.shape == (20, 4) and iou.shape == (20,)
+    for half in (slice(0, 10), slice(10, 20)):
+        close(iou[half], g[f"{tag}_iou"], atol=1e-4)
+        close(b[half], g[f"{tag}_boxes"], atol=1e-4)
+
+
 def test_track_frame_is_deterministic_under_repeated_launches():
-    """The pointwise solver stages ride on the correlation launches (last-arriver hand-off between workgroups, agent-scope
-    release / acquire): 300 frames from identical state must give bit-identical filters, scores and boxes every time --
-    a stale read of another workgroup's partial score map would show up as a differing bit pattern."""
+    """Determinism under cache churn: every reduction of the frame (score-map slices, gradient partials, per-sample
+    curvature terms) is summed in a fixed order by a fixed owner, and kernels hand data to each other only across launch
+    boundaries (the in-launch hand-offs tried in round 2 were reverted) -- so 300 frames from identical
+    state must give bit-identical filters, scores and boxes every time, whatever ran in between."""
     from pytracking_amd import bench_frame
     cfg = synth.DIMP50
     st = bench_frame.TrackState(cfg, 50, seed=321, device=DEV)

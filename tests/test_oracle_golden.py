@@ -157,6 +157,37 @@ def test_torch_port_matches_reference():
         close(gem.adj(feat, r, K).numpy(), conv.adj(feat, r, K).numpy(), atol=1e-12)
 
 
+def test_torch_port_prdimp_matches_reference():
+    """The PrDiMP variant of the frame port (softmax-Newton solve, optimizer.py:355-439; zero start filter, 22x22 maps)
+    reproduces the reference's iterates: BASELINE configs[2] size (`prdimp_sd_cfg3_n50`) in float32 / convolutions and
+    in float64 / dense contractions (the form the closed-loop GPU test steps), and the option branches (softmax
+    regularisation, uniform weight, label shrink / threshold, one-hot label) on the small goldens."""
+    import torch
+    from oracle.frame_port import TorchCpuTracker
+    g = load_golden("prdimp_sd_cfg3_n50")
+    for kw in (dict(), dict(dtype=torch.float64, gemm=True)):
+        tr = TorchCpuTracker(synth.PRDIMP50, int(g["n"]), int(g["seed"]), kind="prdimp", **kw)
+        assert float(tr.filter.abs().max()) == 0.0
+        with torch.no_grad():
+            w = tr.solve_prdimp(tr.filter, tr.mem_feat, tr.mem_bb, tr.sw, int(g["num_iter"]))
+        close(w[0].numpy(), g["iterates"][-1], atol=2e-6)
+
+    def run_small(name, cfg, with_sw):
+        gs = load_golden(name)
+        tr = TorchCpuTracker(dict(cfg, C=16, H=10, W=10), gs["feat"].shape[0], 0, kind="prdimp", dtype=torch.float64, gemm=True)
+        T = lambda a: torch.from_numpy(np.asarray(a, np.float64))
+        sw = T(gs["sw"]) if with_sw else torch.full((gs["feat"].shape[0],), 1.0 / gs["feat"].shape[0], dtype=torch.float64)
+        with torch.no_grad():
+            w = tr.solve_prdimp(T(gs["w0"])[None], T(gs["feat"]), T(gs["bb"]), sw, int(gs["num_iter"]))
+        close(w[0].numpy(), gs["iterates"][-1], atol=2e-6)
+        return gs
+    run_small("prdimp_sd_small", synth.PRDIMP50, True)
+    go = load_golden("prdimp_sd_opts")
+    run_small("prdimp_sd_opts", dict(synth.PRDIMP50, softmax_reg=float(go["softmax_reg"]), init_uni_weight=float(go["uni_weight"]),
+                                     label_shrink=float(go["label_shrink"]), label_threshold=float(go["label_threshold"])), False)
+    run_small("prdimp_sd_sigma0", dict(synth.PRDIMP50, gauss_sigma=0.0), True)
+
+
 @pytest.mark.parametrize("name", ["lwl_gn_small_full", "lwl_gn_small_img", "lwl_gn_small_none", "lwl_gn_mid"])
 def test_lwl_gn_sd(name):
     """LWL few-shot learner (GNSteepestDescent on LWTLResidual, steepestdescent.py:32-105) vs the reference run."""
