@@ -13,10 +13,18 @@ collective); RCCL is used only for the barrier and the end-of-batch (frames, sec
 Prints ONE JSON line on rank 0.  Besides the contract fields:
   roofline        dominant feature-pass kernel: algorithmic bytes per launch / its average launch duration.  The
                   duration is rocprofv3's (`--kernel-trace --stats` of this very command in a child process, parsed
-                  here -- the same tool that writes profiles/*kernel_stats.csv, so the two agree by construction); next
-                  to it `period_us`: K back-to-back launches of that kernel between ONE HIP event pair on the launch
-                  stream (= duration + one dependent-launch boundary).  When rocprofv3 cannot run, `frac` is computed
-                  from the event period (pessimistic by the boundary) and `timing` says so.
+                  here -- the same tool that writes profiles/*kernel_stats.csv, so the two agree by construction), taken
+                  in the launch mode the headline is timed in: the child REPLAYS a 20-frame hipGraph (`avg_launch_us`,
+                  `sum_kernels_us_per_frame.graph` -- comparable with `ms_per_step`); a second child launches the same
+                  frames eagerly (`avg_launch_us_eager`, `sum_kernels_us_per_frame.eager`).  Next to them `period_us`:
+                  K back-to-back launches of that kernel between ONE HIP event pair on the launch stream (= duration +
+                  one dependent-launch boundary).  When rocprofv3 cannot run, `frac` is computed from the event period
+                  (pessimistic by the boundary) and `timing` says so.
+  repeats         the timed region (exactly --steps frames) run 6 more times AFTER the reported one: us/frame of each,
+                  so that the reported value can be placed inside the box's own spread.
+  multi_sequence  throughput headroom, NOT the metric: 2 and 4 independent sequences on ONE GPU, each on its own stream
+                  with its own state, workspace and graph (what pytracking/evaluation/multi_object_wrapper.py:7-35 would
+                  use); the metric's configuration stays one sequence per GPU.
   other_workloads the other BASELINE configs on this GPU (tools/workloads.py): PrDiMP-50 frame, ToMP model prediction, LWL
                   few-shot learner (3 and 4 iterations), ATOM CG update -- ms, algorithmic bytes / flops, roofline fraction.
   end_to_end      the DiMP-50 frame with a stock-PyTorch ResNet-50 (conv1..layer3) in front: backbone ms, frames/s.
@@ -119,12 +127,16 @@ def event_period_us(st, stream, which, reps=200):
     return e0.elapsed_time(e1) * 1e3 / reps
 
 
-PROF_FRAMES, PROF_WARMUP = 120, 10
+PROF_FRAMES, PROF_WARMUP = 200, 10
 
 
-def rocprof_kernel_stats(workload, frames=PROF_FRAMES):
-    """Run this file's --profile-child leg under `rocprofv3 --kernel-trace --stats` and return {kernel name: (calls,
-    average ns)} from its kernel-stats CSV, or (None, reason)."""
+PROF_GRAPH = 20            # frames per graph in the graph-replay child (the driver's --steps 20 launch mode)
+
+
+def rocprof_kernel_stats(workload, frames=PROF_FRAMES, mode="graph"):
+    """Run this file's --profile-child leg (mode "graph": replays of one 20-frame hipGraph; "eager": frame by frame) under
+    `rocprofv3 --kernel-trace --stats` and return {kernel name: (calls, average ns)} from its kernel-stats CSV, or
+    (None, reason)."""
     exe = shutil.which("rocprofv3") or "/opt/rocm/bin/rocprofv3"
     if not os.path.exists(exe):
         return None, "rocprofv3 not found"
@@ -135,8 +147,9 @@ def rocprof_kernel_stats(workload, frames=PROF_FRAMES):
     for k in ("RANK", "LOCAL_RANK", "WORLD_SIZE", "MASTER_ADDR", "MASTER_PORT"):
         env.pop(k, None)
     cmd = [exe, "--kernel-trace", "--stats", "--output-format", "csv", "-d", tmp, "-o", "bench", "--",
-           sys.executable, os.path.abspath(__file__), "--profile-child", "--steps", str(frames), "--warmup", str(PROF_WARMUP),
-           "--workload", workload]
+           sys.executable, os.path.abspath(__file__), "--profile-child", "--steps", str(frames),
+           "--warmup", str(2 if mode == "graph" else PROF_WARMUP),
+           "--workload", workload, "--profile-mode", mode]
     try:
         res = subprocess.run(cmd, cwd="/tmp", env=env, capture_output=True, text=True, timeout=300)
     except Exception as exc:                                  # noqa: BLE001
@@ -160,7 +173,7 @@ def rocprof_kernel_stats(workload, frames=PROF_FRAMES):
         stats, res = {}, type("R", (), {"returncode": -1, "stderr": str(exc), "stdout": ""})()
     keep = os.environ.get("PT_BENCH_KEEP_STATS")
     if keep and stats:
-        with open(keep, "w") as fh:
+        with open(keep.replace(".csv", "") + "_" + mode + ".csv", "w") as fh:
             fh.write("Name,Calls,AverageNs\n")
             for nm, (c, a) in sorted(stats.items(), key=lambda kv: -kv[1][0] * kv[1][1]):
                 fh.write(f'"{nm}",{c},{a:.1f}\n')
@@ -170,23 +183,38 @@ def rocprof_kernel_stats(workload, frames=PROF_FRAMES):
     return stats, None
 
 
-def roofline(cfg, cfg_name, n, period, stats, why):
-    """Assemble the roofline object from the two kernel-level legs measured in front of the frame timing: `period` (HIP
-    event pairs around 200 back-to-back pass launches) and `stats` (rocprofv3 kernel averages of the child process)."""
+def _frames_in_trace(stats):
+    """Frames a kernel-stats table covers: the per-frame pointwise kernel `k_fast_final` runs exactly once per frame."""
+    calls = [c for nm, (c, _) in stats.items() if "k_fast_final" in nm]
+    return sum(calls) if calls else None
+
+
+def roofline(cfg, cfg_name, n, period, stats, why, stats_eager=None):
+    """Assemble the roofline object from the kernel-level legs measured in front of the frame timing: `period` (HIP event
+    pairs around 200 back-to-back pass launches), `stats` (rocprofv3 kernel averages of the GRAPH-REPLAY child: the mode
+    the headline is timed in) and `stats_eager` (the same frames launched one by one)."""
     feat_bytes = 4 * n * cfg["C"] * cfg["H"] * cfg["W"]           # one pass streams the n-sample memory once
     kern = {}
     corr_name = "k_corr2"
     period = {corr_name: period["corr"], "k_adj2": period["adj"]}
+
+    def avg(table, short):
+        rows = [(nm, c, a) for nm, (c, a) in (table or {}).items() if short in nm]
+        if not rows:
+            return None
+        calls = sum(c for _, c, _ in rows)
+        top = max(rows, key=lambda r: r[1])                                          # the in-iteration instantiation
+        return round(sum(c * a for _, c, a in rows) / calls / 1e3, 3), calls, round(top[2] / 1e3, 3), top[0][:60]
+
     for short in (corr_name, "k_adj2"):
         rec = {"period_us": round(period[short], 3)}
-        if stats:
-            rows = [(nm, c, a) for nm, (c, a) in stats.items() if short in nm]
-            if rows:
-                calls = sum(c for _, c, _ in rows)
-                rec["avg_launch_us"] = round(sum(c * a for _, c, a in rows) / calls / 1e3, 3)    # all instantiations
-                rec["launches"] = calls
-                fused = [(c, a) for nm, c, a in rows if c == max(r[1] for r in rows)]             # the in-iteration one
-                rec["avg_launch_us_in_iteration"] = round(fused[0][1] / 1e3, 3)
+        g, e = avg(stats, short), avg(stats_eager, short)
+        if g:
+            rec["avg_launch_us"], rec["launches"], rec["avg_launch_us_in_iteration"], rec["instantiation"] = g
+        if e:
+            rec["avg_launch_us_eager"] = e[0]
+            if not g:
+                rec["avg_launch_us"], rec["launches"], rec["avg_launch_us_in_iteration"], rec["instantiation"] = e
         dur = rec.get("avg_launch_us", rec["period_us"])
         rec["achieved_GBs"] = round(feat_bytes / dur / 1e3, 1)
         kern[short] = rec
@@ -197,13 +225,59 @@ def roofline(cfg, cfg_name, n, period, stats, why):
         rec = json.load(open(pmc)).get(cfg_name, {}).get(dom)
         if rec:
             traffic, traffic_src = rec["hbm_bytes_per_launch"], rec["source"]
-    timing = ("rocprofv3 --kernel-trace --stats of this command (child process), parsed in-process" if stats and
-              "avg_launch_us" in kern[dom] else f"HIP event pair around 200 back-to-back launches (includes one launch boundary each); {why}")
+    if stats and "avg_launch_us" in kern[dom]:
+        timing = ("rocprofv3 --kernel-trace --stats of this command (child process replaying a %d-frame hipGraph, the launch mode "
+                  "of the headline), parsed in-process" % PROF_GRAPH)
+    elif stats_eager and "avg_launch_us" in kern[dom]:
+        timing = "rocprofv3 --kernel-trace --stats of this command (child process, EAGER launches: the graph child failed: %s)" % why
+    else:
+        timing = f"HIP event pair around 200 back-to-back launches (includes one launch boundary each); {why}"
+
+    def per_frame(table):
+        fr = _frames_in_trace(table) if table else None
+        return None if not fr else round(sum(c * a for c, a in table.values()) / 1e3 / fr, 2)
     return {"bound": "hbm", "kernel": dom, "achieved": kern[dom]["achieved_GBs"], "peak": HBM_PEAK_GBS, "unit": "GB/s",
             "frac": round(kern[dom]["achieved_GBs"] / HBM_PEAK_GBS, 4), "traffic": traffic, "traffic_source": traffic_src,
             "avg_launch_us": kern[dom].get("avg_launch_us", kern[dom]["period_us"]), "timing": timing,
             "algorithmic_bytes_per_launch": feat_bytes, "kernels": kern,
-            "all_kernels_us_per_frame": None if not stats else round(sum(c * a for c, a in stats.values()) / 1e3 / (PROF_FRAMES + PROF_WARMUP), 2)}
+            "sum_kernels_us_per_frame": {"graph": per_frame(stats), "eager": per_frame(stats_eager),
+                                         "note": "sum over ALL kernels of the trace / frames in it; each rocprofv3 duration carries the "
+                                                 "kernel's own start-up and drain, the frame time (ms_per_step) additionally the "
+                                                 "dependent-launch boundaries between its 18 kernels"}}
+
+
+def multi_sequence(cfg, cfg_name, n, dev, counts=(2, 4), G=20, replays=10):
+    """Throughput headroom (extra key, not the metric): S independent sequences on one GPU, each with its own TrackState
+    (filter, memory, workspace), stream and 20-frame hipGraph; all S graphs are replayed `replays` times, interleaved."""
+    out = {}
+    for S in counts:
+        streams = [torch.cuda.Stream(device=dev) for _ in range(S)]
+        states, graphs = [], []
+        for k, sm in enumerate(streams):
+            with torch.cuda.stream(sm):
+                st = bench_frame.TrackState(cfg, n, seed=4000 + k, device=dev, kind="dimp" if cfg_name == "dimp50" else "prdimp")
+                pool = make_pool(cfg, 5000 + k, dev)
+                run_frames(st, pool, 0, 2)
+                sm.synchronize()
+                g = torch.cuda.CUDAGraph()
+                with torch.cuda.graph(g, stream=sm):
+                    run_frames(st, pool, 2, G)
+                g.replay()
+                sm.synchronize()
+                states.append((st, pool)); graphs.append(g)
+        torch.cuda.synchronize()
+        t0 = time.perf_counter()
+        for _ in range(replays):
+            for sm, g in zip(streams, graphs):
+                with torch.cuda.stream(sm):
+                    g.replay()
+        torch.cuda.synchronize()
+        dt = time.perf_counter() - t0
+        out[str(S)] = {"frames_per_s": round(S * G * replays / dt, 1), "us_per_frame_per_sequence": round(1e6 * dt / (G * replays), 2)}
+        del states, graphs, streams
+    out["what"] = ("S independent sequences on ONE GPU, one stream + state + workspace + %d-frame hipGraph each, %d interleaved "
+                   "replays; aggregate frames/s over the S sequences.  Headroom only: the metric is one sequence per GPU" % (G, replays))
+    return out
 
 
 def head_inclusive(cfg, n, dev, stream, frames=200):
@@ -254,6 +328,7 @@ def main():
     ap.add_argument("--no-roofline", action="store_true")
     ap.add_argument("--no-other", action="store_true", help="skip the other BASELINE workloads and the end-to-end leg")
     ap.add_argument("--profile-child", action="store_true", help=argparse.SUPPRESS)
+    ap.add_argument("--profile-mode", default="graph", choices=("graph", "eager"), help=argparse.SUPPRESS)
     ap.add_argument("--workload", default="dimp50", choices=("dimp50", "prdimp50"),
                     help="dimp50 = BASELINE configs[1] (the metric's configuration); prdimp50 = configs[2]'s per-GPU workload")
     args = ap.parse_args()
@@ -291,16 +366,26 @@ def main():
     K, Wm = args.steps, args.warmup
     stream = torch.cuda.Stream(device=dev)
 
-    if args.profile_child:                                     # the leg rocprofv3 traces: eager frames, nothing else
+    if args.profile_child:                                     # the legs rocprofv3 traces, nothing else in the process
         with torch.cuda.stream(stream):
-            run_frames(st, pool, 0, Wm + K)
+            if args.profile_mode == "eager":
+                run_frames(st, pool, 0, Wm + K)
+            else:                                              # the headline's launch mode: replays of one 20-frame graph
+                run_frames(st, pool, 0, Wm)
+                stream.synchronize()
+                g = torch.cuda.CUDAGraph()
+                with torch.cuda.graph(g, stream=stream):
+                    run_frames(st, pool, Wm, PROF_GRAPH)
+                for _ in range(max(1, K // PROF_GRAPH)):
+                    g.replay()
             stream.synchronize()
         return
 
     # ---- kernel-level legs first (rocprofv3 child process, then the event-pair periods of the two passes in this process):
     #      the frame timing that follows starts on a device that has just been busy, whatever --warmup says
     want_roof = not args.no_roofline and rank == 0 and world == 1
-    stats, why = rocprof_kernel_stats(cfg_name) if want_roof else (None, "not requested")
+    stats, why = rocprof_kernel_stats(cfg_name, mode="graph") if want_roof else (None, "not requested")
+    stats_eager = rocprof_kernel_stats(cfg_name, frames=60, mode="eager")[0] if want_roof else None
 
     # ---- frame launcher: hipGraphs of G consecutive frames starting at frame --warmup, G = the timed steps themselves when
     #      they fit one memory cycle, else their common divisor with the memory size (whole graph replays; a graph is valid
@@ -355,10 +440,24 @@ def main():
             dist.barrier()
         elapsed = time.perf_counter() - t0
 
-        roof = roofline(cfg, cfg_name, n, period, stats, why) if want_roof else None
+        # the same K-step region again (state keeps advancing; same graphs): where the reported value sits in this box's spread
+        repeats = []
+        if rank == 0 and world == 1 and not args.no_roofline:
+            for _ in range(6):
+                if use_graph and warm_graph is not None:
+                    warm_graph.replay()
+                else:
+                    advance(0, Wm)
+                stream.synchronize()
+                t1 = time.perf_counter()
+                advance(Wm, K)
+                stream.synchronize()
+                repeats.append(round(1e6 * (time.perf_counter() - t1) / K, 2))
+
+        roof = roofline(cfg, cfg_name, n, period, stats, why, stats_eager) if want_roof else None
 
     # the only collective: the end-of-batch (frames, seconds) gather; whole-job rate = all frames / slowest rank
-    total_frames, tmax, _ = sequences.gather_throughput(K, elapsed, device=dev)
+    total_frames, tmax, per_rank = sequences.gather_throughput(K, elapsed, device=dev)
     value = total_frames / tmax
 
     if rank == 0:
@@ -383,7 +482,21 @@ def main():
                         "n=50x512x22x22, K=4"),
                        "sequences_per_gpu": 1, "launch": launch, "parallelism": f"{world} independent sequences"},
             "roofline": roof,
+            # self-verifying multi-GPU record: what every rank timed, and how many ranks the collective really had
+            "per_rank": [{"rank": r, "frames": f, "seconds": round(sec, 6), "frames_per_s": round(f / sec, 1)}
+                         for r, (f, sec) in enumerate(per_rank)],
+            "collective": {"backend": (dist.get_backend() if dist is not None else None),
+                           "ranks": (dist.get_world_size() if dist is not None else 1),
+                           "what": "barrier + one 16-byte all_gather of (frames, seconds); RCCL when backend == nccl"},
         }
+        if repeats:
+            out["repeats"] = {"us_per_frame": repeats, "reported_us_per_frame": round(1e6 * tmax / K, 2),
+                              "what": "the timed region (exactly --steps frames) run 6 more times after the reported one"}
+        if world == 1 and not args.no_roofline:
+            try:
+                out["multi_sequence"] = multi_sequence(cfg, cfg_name, n, dev)
+            except Exception as exc:                             # noqa: BLE001
+                out["multi_sequence"] = {"error": f"{type(exc).__name__}: {exc}"[:300]}
         if world == 1 and cfg_name == "dimp50" and not args.no_roofline:
             out["head_inclusive"] = head_inclusive(cfg, n, dev, stream)
         if world == 1 and cfg_name == "dimp50":
