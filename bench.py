@@ -398,10 +398,14 @@ def main():
         run_frames(st, pool, 0, 2)                             # first-touch / code-object load outside everything
         stream.synchronize()
 
+        uploaded = []
+
         def capture(first, count):
             g = torch.cuda.CUDAGraph()
             with torch.cuda.graph(g, stream=stream):
                 run_frames(st, pool, first, count)
+            # the executable's one-time transfer to the device happens here, not inside the first (timed) replay; no kernel runs
+            uploaded.append(_lib.graph_upload(g, stream))
             return g
 
         if use_graph:
@@ -467,7 +471,8 @@ def main():
             roof["solve_level"] = {"algorithmic_bytes_per_frame": solve_bytes, "achieved_GBs": round(gbs, 1),
                                    "frac": round(gbs / HBM_PEAK_GBS, 4),
                                    "note": "2 feature reads per iteration x 5 iterations (SURVEY 8d) / measured frame time"}
-        launch = (f"hipGraph replay, {G} frames per graph ({K // G} replay(s) in the timed region, {len(graphs)} start slot(s))" if use_graph
+        launch = (f"hipGraph replay, {G} frames per graph ({K // G} replay(s) in the timed region, {len(graphs)} start slot(s); "
+                  f"executables uploaded before the timed region: {all(uploaded) and bool(uploaded)})" if use_graph
                   else "eager (18 launches per frame)")
         out = {
             "metric": "frames/sec DiMP-50 online track (288x288, 5 SD iters)" if cfg_name == "dimp50" else "frames/sec PrDiMP-50 online track (352x352, 5 SD iters)", "value": round(value, 2),
