@@ -433,15 +433,6 @@ int pt_track_frame_replay_pass_f32(const pt_sd_params* prm, const float* filter,
                                    const float* mem_bb, const float* sample_weight, int n, int C, int H, int W, int K,
                                    int num_iter, void* ws, size_t ws_bytes, int which, int reps, void* stream);
 
-/* ------------------------------------------------------------------------------------------------
- * Graph-launched frames.  Every entry point above is capturable (no host synchronisation, no allocation), so a tracker --
- * or bench.py -- records frames into a hipGraph and replays it.  The FIRST launch of an instantiated graph pays a
- * one-time transfer of the executable (its kernel-argument segments) to the device, measured at ~60 us for a 20-frame graph
- * of 360 kernel nodes; pt_graph_upload does that transfer ahead of time (hipGraphUpload) so that the first replay runs like
- * the following ones.  `graph_exec` is a hipGraphExec_t (torch: CUDAGraph.raw_cuda_graph_exec()).  Executes no kernel.
- * ---------------------------------------------------------------------------------------------- */
-int pt_graph_upload(void* graph_exec, void* stream);
-
 #ifdef __cplusplus
 }
 #endif

@@ -80,7 +80,6 @@ EXPORTS = [
     "pt_localize_constants_f32", "pt_localize_advanced_f32", "pt_localize_advanced_sync_f32",
     "pt_iou_param_floats", "pt_iou_prepared_floats", "pt_iou_prepare_f32", "pt_iou_refine_ws_bytes", "pt_iou_refine_f32", "pt_iou_refine_sync_f32",
     "pt_track_frame_replay_pass_f32", "pt_sample_patch_f32", "pt_augment_patches_f32", "pt_track_frame_head_ws_bytes", "pt_track_frame_head_f32",
-    "pt_graph_upload",
 ]
 
 
@@ -267,8 +266,6 @@ def lib():
     L.pt_iou_refine_f32.argtypes = [ip, vp, vp, vp, vp, vp, vp, vp, vp, vp, i, i, fp, f, i, i, vp, sz, vp]
     L.pt_iou_refine_sync_f32.restype = i
     L.pt_iou_refine_sync_f32.argtypes = [ip, vp, vp, vp, vp, vp, vp, vp, vp, i, i, fp, f, i, i, vp, sz, vp]
-    L.pt_graph_upload.restype = i
-    L.pt_graph_upload.argtypes = [vp, vp]
     L.pt_track_frame_replay_pass_f32.restype = i
     L.pt_track_frame_replay_pass_f32.argtypes = [ctypes.POINTER(SdParams), vp, vp, vp, vp] + [i] * 6 + [vp, sz, i, i, vp]
     L.pt_track_frame_head_ws_bytes.restype = sz
@@ -287,12 +284,3 @@ def check(status: int, what: str):
     if status != 0:
         raise RuntimeError(f"{what} failed: {lib().pt_strerror(status).decode()} ({status})")
 
-
-def graph_upload(graph, stream) -> bool:
-    """Transfer an instantiated torch.cuda.CUDAGraph to the device ahead of its first replay (`pt_graph_upload`); False when
-    this torch build does not expose the executable's handle or the runtime refuses (the first replay then pays it)."""
-    try:
-        handle = graph.raw_cuda_graph_exec()
-    except Exception:                                           # noqa: BLE001
-        return False
-    return lib().pt_graph_upload(ctypes.c_void_p(int(handle)), ctypes.c_void_p(stream.cuda_stream)) == 0

@@ -237,13 +237,3 @@ extern "C" int pt_track_frame_replay_pass_f32(const pt_sd_params* prm, const flo
                              base + cv.w_iters, base + cv.sd, (cv.total - cv.sd) * sizeof(float), which, reps,
                              (hipStream_t)stream);
 }
-
-// hipGraphUpload: the executable's one-time transfer to the device, outside the first replay (see pt_hot.h)
-extern "C" int pt_graph_upload(void* graph_exec, void* stream) {
-    if (!graph_exec) return PT_ERR_NULL;
-    if (hipGraphUpload((hipGraphExec_t)graph_exec, (hipStream_t)stream) != hipSuccess) {
-        (void)hipGetLastError();
-        return PT_ERR_LAUNCH;
-    }
-    return PT_OK;
-}

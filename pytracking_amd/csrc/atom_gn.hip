@@ -73,27 +73,6 @@ __global__ __launch_bounds__(512) void k_gn_pw(GnArgs a, int mode) {
     pt_build_R_sample(lds, a.R, i, a.n, a.H, a.W, a.K, a.K, a.H, a.W);
 }
 
-// dL/dc[i,k,yy,xx] = sum_{u,v} v[i, yy-u+p, xx-v+p] * x[k,u,v]      (input gradient of conv2d(mode='same'))
-__global__ void k_gn_backproject(GnArgs a) {
-    const long e = (long)blockIdx.x * blockDim.x + threadIdx.x;
-    const long total = (long)a.n * a.Kc * a.HW;
-    if (e >= total) return;
-    const int pos = (int)(e % a.HW), k = (int)((e / a.HW) % a.Kc), i = (int)(e / ((long)a.HW * a.Kc));
-    const int yy = pos / a.W, xx = pos - yy * a.W, p = a.K / 2;
-    const float* __restrict__ vm = a.v + (long)i * a.HW;
-    const float* __restrict__ fk = a.f + (long)k * a.KK;
-    float s = 0.f;
-    for (int u = 0; u < a.K; ++u) {
-        const int y = yy - u + p;
-        if ((unsigned)y >= (unsigned)a.H) continue;
-        for (int w = 0; w < a.K; ++w) {
-            const int x = xx - w + p;
-            if ((unsigned)x < (unsigned)a.W) s += vm[y * a.W + x] * fk[u * a.K + w];
-        }
-    }
-    a.gc[e] = s;
-}
-
 __device__ float gn_dot2(const float* u, const float* v, int n, float* scratch) {
     float acc = 0.f;
     for (int e = threadIdx.x; e < n; e += blockDim.x) acc += u[e] * v[e];
@@ -315,11 +294,11 @@ static int gn_project(const GnArgs& a, const float* samples, long stride_n, cons
 
 // J^T of the data part for the map in a.v / a.R: filter-adjoint partials -> gpf, projection-adjoint partials -> gpP
 static int gn_jt(const GnArgs& a, const PtPlan& pl, const float* samples, long stride_n, hipStream_t st) {
-    int rc = pt_launch_adj(pl, a.c, (long)a.Kc * a.HW, a.R, a.gpf, st);
+    // the filter adjoint and dL/dc = conv_same^T(v, x) (filter_kernels.hip: input_grad_jobs) read the same map and do not depend on
+    // each other: ONE launch (round 4; they were two dependent ones of 8.1 + 9.3 us)
+    const PtInputGrad ig = {a.v, a.f, a.gc, a.n, a.Kc, a.H, a.W, a.K};
+    int rc = pt_launch_adj(pl, a.c, (long)a.Kc * a.HW, a.R, a.gpf, st, &ig);
     if (rc) return rc;
-    const long total = (long)a.n * a.Kc * a.HW;
-    hipLaunchKernelGGL(k_gn_backproject, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, st, a);
-    PT_CHECK_LAUNCH();
     if (a.Kc % 16 == 0 && a.NSG == a.n && a.HW % 4 == 0 && stride_n % 4 == 0 && ((uintptr_t)samples % 16) == 0) {
         // one partial per sample: a batch of n small NT GEMMs  gpP[., i][f][m] = sum_pos gc[i][f][pos] * S[i][m][pos]
         // (K = H*W contiguous in both operands) instead of the banded LDS kernel, whose fixed cost per workgroup
@@ -387,9 +366,14 @@ extern "C" int pt_atom_gn_f32(float* filter, float* proj, const float* samples, 
         for (int ii = 0; ii < ncg; ++ii) {
             rc = gn_project(a, samples, samples_stride_n, a.p + a.NF, a.dc, wT, st);           // conv1x1(S, pP)
             if (rc) return rc;
-            rc = pt_launch_corr(pl, a.c, cs, a.p, a.sp1, st);                                  // conv_same(c, px)
-            if (rc) return rc;
-            rc = pt_launch_corr(pl, a.dc, cs, filter, a.sp2, st);                              // conv_same(dc, x)
+            // conv_same(c, px) -> sp1 and conv_same(dc, x) -> sp2 in one paired launch (same shape, two operand sets)
+            const PtCorrFuse pair = {nullptr, 0, nullptr, 0.f, nullptr, nullptr, nullptr, a.dc, filter, a.sp2};
+            rc = pt_launch_corr(pl, a.c, cs, a.p, a.sp1, st, &pair);
+            if (rc == PT_ERR_UNSUPPORTED) {
+                rc = pt_launch_corr(pl, a.c, cs, a.p, a.sp1, st);                              // conv_same(c, px)
+                if (rc) return rc;
+                rc = pt_launch_corr(pl, a.dc, cs, filter, a.sp2, st);                          // conv_same(dc, x)
+            }
             if (rc) return rc;
             hipLaunchKernelGGL(k_gn_pw, dim3(n), dim3(512), pw_lds, st, a, 1);
             PT_CHECK_LAUNCH();

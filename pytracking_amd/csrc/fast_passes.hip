@@ -23,7 +23,15 @@
 #ifndef PT_ADJ_WAVES
 #define PT_ADJ_WAVES 8                     // waves per k_adj2 workgroup (16 measured no better at 18x18, worse at 22x22)
 #endif
-#define PT_ADJ_UMAX (128 / PT_ADJ_WAVES)   // 16-position groups per wave (all of a wave's loads are in flight at once)
+#ifndef PT_ADJ_UMAX
+#define PT_ADJ_UMAX (128 / PT_ADJ_WAVES)   // 16-position groups per wave of the common instantiations
+#endif
+// 22x22 / 23x23 maps (PrDiMP-50: E == 9): up to 24 groups per wave, so that n = 50 is EIGHT position slices = 256 workgroups, one
+// per CU, instead of sixteen = 512 (round 4: k_adj2 15.1 -> see DESIGN section 7; the correlation's prologue then sums 8 gradient
+// partials instead of 16).  The loads are pipelined PD groups ahead, so the register cost of a longer run is the unrolled loop only.
+#ifndef PT_ADJ_UMAX_WIDE
+#define PT_ADJ_UMAX_WIDE (192 / PT_ADJ_WAVES)
+#endif
 // experiment knobs (profiles/r03f_*): feature loads requested ahead of the MFMAs / register cap of k_corr2
 #ifndef PT_C2_CD
 #define PT_C2_CD 2       // round 3 sweep (profiles/r03l_*): 2 / 3 / 4 / 6 / 8 ahead -> 8.72 / 8.97 / 8.99 / 9.49 / 9.76 us
@@ -110,9 +118,11 @@ PtFast pt_fast_plan(int n, int C, int H, int W, int KH, int KW, int OH, int OW) 
     p.KSPL = 0;
     // position slices: 8 or 16 (the fused gradient reduction of k_corr2 sums at most 16 partials); with few channel blocks up to
     // 64, so that CB * KSPL workgroups still fill the chip (ATOM: 4 x 64) -- such plans serve the passes, not the SD solver
+    p.E = p.OO <= 384 ? 6 : (p.OO <= 576 ? 9 : 16);
+    const int umax = p.E == 9 ? PT_ADJ_UMAX_WIDE : PT_ADJ_UMAX;
     for (int ks = 8; ks <= (p.CB < 8 ? 64 : 16); ks *= 2) {
         const int gper = pt_ceil_div(p.NG, ks), U = pt_ceil_div(gper, PT_ADJ_WAVES);
-        if (U <= PT_ADJ_UMAX) { p.gper = gper; p.U = U; p.KSPL = pt_ceil_div(p.NG, gper); break; }
+        if (U <= umax) { p.gper = gper; p.U = U; p.KSPL = pt_ceil_div(p.NG, gper); break; }
     }
     if (p.KSPL == 0) return p;
     p.PH = H + KH - 1;
@@ -125,9 +135,8 @@ PtFast pt_fast_plan(int n, int C, int H, int W, int KH, int KW, int OH, int OW) 
     // follows is 16-byte aligned
     p.zn = (KH - 1) * p.PW + KW + 4;
     while (((p.ns_max * p.PH * p.PW + p.zn) % 4) != 0) ++p.zn;
-    p.adj_lds = ((size_t)p.ns_max * p.PH * p.PW + p.zn + (size_t)5 * 4 * PT_ADJ_WAVES * PT_ADJ_UMAX) * sizeof(float);
+    p.adj_lds = ((size_t)p.ns_max * p.PH * p.PW + p.zn + (size_t)5 * 4 * PT_ADJ_WAVES * umax) * sizeof(float);
     if (p.adj_lds > 96 * 1024 || p.OO > 1024) return p;
-    p.E = p.OO <= 384 ? 6 : (p.OO <= 576 ? 9 : 16);
     // what the packed kernel parameters of the two passes can hold (k_corr2: h_dims / h_geo, k_adj2: h_g1 .. h_g4)
     if (H > 255 || W > 255 || n > 65535 || p.gper > 65535 || p.PH > 63 || p.PW > 63 || p.zn > 255 || p.ns_max > 63 || KH > 7 || KW > 7)
         return p;
@@ -904,9 +913,11 @@ static int adj2_dispatch(const PtFast& p, const Adj2Args& a, hipStream_t st) {
     l.stamps = a.stamps;
 #endif
 #define PT_A2_HOT a.feat, a.stride_n, pkp, qsp, anp, g1, g2, g3, g4, l
-    if (p.E == 6) hipLaunchKernelGGL((k_adj2<V, 6, 16>), grid, block, p.adj_lds, st, PT_A2_HOT);
+    if (p.E == 6 && p.U <= 12 && PT_ADJ_WAVES != 8) hipLaunchKernelGGL((k_adj2<V, 6, 12>), grid, block, p.adj_lds, st, PT_A2_HOT);   // experiment builds only
+    else if (p.E == 6) hipLaunchKernelGGL((k_adj2<V, 6, 16>), grid, block, p.adj_lds, st, PT_A2_HOT);
     else if (p.E == 9 && p.U <= 12) hipLaunchKernelGGL((k_adj2<V, 9, 12>), grid, block, p.adj_lds, st, PT_A2_HOT);
-    else if (p.E == 9) hipLaunchKernelGGL((k_adj2<V, 9, 16>), grid, block, p.adj_lds, st, PT_A2_HOT);
+    else if (p.E == 9 && p.U <= 16) hipLaunchKernelGGL((k_adj2<V, 9, 16>), grid, block, p.adj_lds, st, PT_A2_HOT);
+    else if (p.E == 9) hipLaunchKernelGGL((k_adj2<V, 9, PT_ADJ_UMAX_WIDE>), grid, block, p.adj_lds, st, PT_A2_HOT);
     else hipLaunchKernelGGL((k_adj2<V, 16, 16>), grid, block, p.adj_lds, st, PT_A2_HOT);
 #undef PT_A2_HOT
     return PT_OK;

@@ -92,6 +92,7 @@ __global__ void k_corr(const float* __restrict__ feat, long stride_n, const floa
     extern __shared__ __attribute__((aligned(16))) float lds[];     // afilt[cper][16] | T[KK][HWp]
     __shared__ float scratch[16];
     constexpr int NKA = NK > 0 ? NK : 1;
+    if (blockIdx.z) { feat = fz.feat2; filt = fz.filt2; spart = fz.spart2; }   // second problem of a paired launch (uniform)
     const int i = blockIdx.x, cs = blockIdx.y;
     const int HW = H * W, KK = KH * KW;
     const int ntiles = (HW + 63) >> 6;
@@ -231,12 +232,49 @@ __global__ void k_corr(const float* __restrict__ feat, long stride_n, const floa
 // channel cb*16+(l&15) at positions g*16 + 4*(l>>4)..+3 and one float4 of R.  Loads are issued U groups
 // (2*U KiB per wave) ahead of the MFMAs that consume them.
 // ---------------------------------------------------------------------------------------------------
+// conv_same input gradient, jobs = (sample, group of 4 filter-bank rows): every thread one position, 4 outputs from the same 16
+// reads of the map; summation over (u, v) in the order of the stand-alone kernel it replaces (bit-identical)
+__device__ __forceinline__ void input_grad_jobs(const PtInputGrad& g, int job, int njobs) {
+    constexpr int KG = 4;
+    const int HW = g.H * g.W, KK = g.K * g.K, p = g.K / 2;
+    const int groups = (g.Kc + KG - 1) / KG;
+    for (int jb = job; jb < g.n * groups; jb += njobs) {
+        const int i = jb / groups, k0 = (jb - i * groups) * KG;
+        const float* __restrict__ vm = g.v + (long)i * HW;
+        const float* __restrict__ fk = g.filt + (long)k0 * KK;
+        for (int pos = threadIdx.x; pos < HW; pos += blockDim.x) {
+            const int yy = pos / g.W, xx = pos - yy * g.W;
+            float s[KG] = {0.f, 0.f, 0.f, 0.f};
+            for (int u = 0; u < g.K; ++u) {
+                const int y = yy - u + p;
+                if ((unsigned)y >= (unsigned)g.H) continue;
+                for (int w = 0; w < g.K; ++w) {
+                    const int x = xx - w + p;
+                    if ((unsigned)x < (unsigned)g.W) {
+                        const float vv = vm[y * g.W + x];
+#pragma unroll
+                        for (int c = 0; c < KG; ++c) s[c] += vv * fk[(k0 + c < g.Kc ? c : 0) * KK + u * g.K + w];
+                    }
+                }
+            }
+#pragma unroll
+            for (int c = 0; c < KG; ++c)
+                if (k0 + c < g.Kc) g.out[((long)i * g.Kc + k0 + c) * HW + pos] = s[c];
+        }
+    }
+}
+
 template <bool VEC>
 __global__ __launch_bounds__(512) void k_adj(const float* __restrict__ feat, long stride_n,
                                              const float* __restrict__ R, float* __restrict__ gpart, int n, int C,
-                                             int HW, int KK, int NG, int gper) {
+                                             int HW, int KK, int NG, int gper, PtInputGrad ig) {
     constexpr int U = 16;
     __shared__ float red[8][256];
+    if (blockIdx.z) {                                               // uniform: this workgroup serves the input gradient
+        const int per = gridDim.x * gridDim.y;
+        input_grad_jobs(ig, (blockIdx.z - 1) * per + blockIdx.y * gridDim.x + blockIdx.x, (gridDim.z - 1) * per);
+        return;
+    }
     const int cb = blockIdx.x, ks = blockIdx.y;
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
     const int kq = lane >> 4, j = lane & 15;
@@ -381,8 +419,13 @@ static void corr_dispatch(const PtPlan& p, dim3 grid, dim3 block, hipStream_t st
 int pt_launch_corr(const PtPlan& p, const float* feat, long stride_n, const float* filt, float* spart, hipStream_t st,
                    const PtCorrFuse* fuse) {
     dim3 grid(p.n, p.KS), block(p.corr_threads);
-    PtCorrFuse fz = {nullptr, 0, nullptr, 0.f, nullptr, nullptr, nullptr};
+    PtCorrFuse fz = {nullptr, 0, nullptr, 0.f, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr};
     if (fuse) fz = *fuse;
+    if (fz.feat2) {                                                 // paired launch: same shape, second operand set
+        if (!fz.filt2 || !fz.spart2 || fz.gpart || fz.copy_dst) return PT_ERR_UNSUPPORTED;
+        if (((uintptr_t)fz.feat2 % 16) != ((uintptr_t)feat % 16)) return PT_ERR_UNSUPPORTED;
+        grid.z = 2;
+    }
     if (fz.copy_dst && p.n != 1) return PT_ERR_SHAPE;
     if (p.vec4 && (stride_n % 4) == 0 && ((uintptr_t)feat % 16) == 0 && ((uintptr_t)fz.copy_dst % 16) == 0)
         corr_dispatch<true>(p, grid, block, st, feat, stride_n, filt, spart, fz);
@@ -392,12 +435,20 @@ int pt_launch_corr(const PtPlan& p, const float* feat, long stride_n, const floa
     return PT_OK;
 }
 
-int pt_launch_adj(const PtPlan& p, const float* feat, long stride_n, const float* R, float* gpart, hipStream_t st) {
+int pt_launch_adj(const PtPlan& p, const float* feat, long stride_n, const float* R, float* gpart, hipStream_t st,
+                  const PtInputGrad* ig) {
     dim3 grid(pt_ceil_div(p.C, 16), p.KSPL), block(512);
+    PtInputGrad g = {nullptr, nullptr, nullptr, 0, 0, 0, 0, 0};
+    if (ig) {
+        // enough extra layers that the (sample, 4-row group) jobs spread over the chip (~2 workgroups per CU)
+        g = *ig;
+        const int jobs = g.n * ((g.Kc + 3) / 4), per = (int)(grid.x * grid.y);
+        grid.z = 1 + std::max(1, std::min(pt_ceil_div(std::min(jobs, 512), per), 64));
+    }
     if (p.vec4 && (stride_n % 4) == 0 && ((uintptr_t)feat % 16) == 0)
-        hipLaunchKernelGGL(k_adj<true>, grid, block, 0, st, feat, stride_n, R, gpart, p.n, p.C, p.HW, p.KK, p.NG, p.gper);
+        hipLaunchKernelGGL(k_adj<true>, grid, block, 0, st, feat, stride_n, R, gpart, p.n, p.C, p.HW, p.KK, p.NG, p.gper, g);
     else
-        hipLaunchKernelGGL(k_adj<false>, grid, block, 0, st, feat, stride_n, R, gpart, p.n, p.C, p.HW, p.KK, p.NG, p.gper);
+        hipLaunchKernelGGL(k_adj<false>, grid, block, 0, st, feat, stride_n, R, gpart, p.n, p.C, p.HW, p.KK, p.NG, p.gper, g);
     PT_CHECK_LAUNCH();
     return PT_OK;
 }

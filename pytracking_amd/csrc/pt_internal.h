@@ -38,11 +38,22 @@ struct PtCorrFuse {
     float* g_out;         // (C*KK) reduced gradient, written by the workgroups of sample 0
     float* anum_part;     // (KS)   per-channel-slice sum of g^2, written by the workgroups of sample 0
     float* copy_dst;      // (C,H,W) destination of a copy of sample 0's features (requires n == 1)
+    // second problem of the same shape in the same launch (grid.z = 2; generic k_corr only): ATOM's joint Gauss-Newton needs
+    // conv_same(c, p_x) and conv_same(dc, x) side by side (optim.py:30-44) -- one launch instead of two dependent ones
+    const float* feat2;
+    const float* filt2;
+    float* spart2;
 };
+
+// Input gradient of conv2d(mode='same') for a single filter bank: out[i,k,yy,xx] = sum_{u,v} v[i, yy-u+p, xx-v+p] * filt[k,u,v]
+// (the back-projection of ATOM's joint Gauss-Newton, pytracking/tracker/atom/optim.py:46-62 through autograd in the reference).
+// It reads the same map as the filter adjoint and is independent of it, so it rides on k_adj's launch as grid.z layers >= 1.
+struct PtInputGrad { const float* v; const float* filt; float* out; int n, Kc, H, W, K; };
 
 int pt_launch_corr(const PtPlan& p, const float* feat, long stride_n, const float* filt, float* spart, hipStream_t st,
                    const PtCorrFuse* fuse = nullptr);
-int pt_launch_adj(const PtPlan& p, const float* feat, long stride_n, const float* R, float* gpart, hipStream_t st);
+int pt_launch_adj(const PtPlan& p, const float* feat, long stride_n, const float* R, float* gpart, hipStream_t st,
+                  const PtInputGrad* ig = nullptr);
 // scores[i][o] = sum_ks spart[ks][i][o]
 int pt_launch_sum_slices(const float* part, float* out, int slices, size_t count, hipStream_t st);
 // R (im2col of the residual map, MFMA-B layout) from inp (n, OH, OW)

@@ -17,14 +17,15 @@ from pytracking_amd import bench_frame, synth  # noqa: E402
 
 def main():
     ns = [int(a) for a in sys.argv[1:]] or [24, 32, 40, 48, 50, 56, 64]
-    cfg = synth.DIMP50
+    kind = os.environ.get("PT_EXP_KIND", "dimp")                 # "prdimp": BASELINE configs[2]'s per-GPU workload
+    cfg = synth.PRDIMP50 if kind == "prdimp" else synth.DIMP50
     dev = torch.device("cuda:0")
     stream = torch.cuda.Stream()
     pool = bench.make_pool(cfg, 99, dev)
     out = []
     with torch.cuda.stream(stream):
         for n in ns:
-            st = bench_frame.TrackState(cfg, n, seed=1234, device=dev)
+            st = bench_frame.TrackState(cfg, n, seed=1234, device=dev, kind=kind)
             bench.run_frames(st, pool, 0, 10)
             stream.synchronize()
             corr = min(bench.event_period_us(st, stream, 0) for _ in range(3))
@@ -42,7 +43,7 @@ def main():
             e1.record(stream)
             e1.synchronize()
             frame = e0.elapsed_time(e1) * 1e3 / 200
-            rec = {"n": n, "corr_period_us": round(corr, 2), "adj_period_us": round(adj, 2), "frame_us": round(frame, 2),
+            rec = {"kind": kind, "n": n, "corr_period_us": round(corr, 2), "adj_period_us": round(adj, 2), "frame_us": round(frame, 2),
                    "MB_per_pass": round(4e-6 * n * cfg["C"] * cfg["H"] * cfg["W"], 2)}
             print(json.dumps(rec), flush=True)
             out.append(rec)
