@@ -215,21 +215,32 @@ __global__ __launch_bounds__(512) void k_attn(AttnArgs a) {
 // ------------------------------------------------------------------------------------------------------------------
 // PER = D / 64 known at compile time: the row is ONE vector load per lane and gamma / beta are requested with it (with a run-time
 // count the loop stayed rolled -- a memory round trip per element -- and gamma / beta were read behind both reductions)
+// in2 / in3 (optional, same layout): further addends of the row -- the second half of a split-K product and the residual the
+// GEMM epilogue would have added (v = (in + in2) + in3, fixed order)
 template <int PER>
 __global__ __launch_bounds__(256) void k_ln_rows_t(const float* in, float* out, const float* __restrict__ gam,
-                                                   const float* __restrict__ bet, int rows) {
+                                                   const float* __restrict__ bet, int rows, const float* in2 = nullptr,
+                                                   const float* in3 = nullptr) {
     constexpr int D = 64 * PER;
     const int row = blockIdx.x * 4 + (threadIdx.x >> 6), lane = threadIdx.x & 63;
     if (row >= rows) return;
     float v[PER], g[PER], b[PER];
-    const float* src = in + (long)row * D + lane * PER;
+    const long ro = (long)row * D + lane * PER;
+    const float* src = in + ro;
     if (PER == 4) {
         const f32x4 t = *(const f32x4*)src, tg = *(const f32x4*)(gam + lane * 4), tb = *(const f32x4*)(bet + lane * 4);
+        f32x4 t2 = {0, 0, 0, 0}, t3 = {0, 0, 0, 0};
+        if (in2) t2 = *(const f32x4*)(in2 + ro);                     // uniform branches: all loads requested together
+        if (in3) t3 = *(const f32x4*)(in3 + ro);
 #pragma unroll
-        for (int i = 0; i < 4; ++i) { v[i] = t[i]; g[i] = tg[i]; b[i] = tb[i]; }
+        for (int i = 0; i < 4; ++i) { v[i] = in2 ? (t[i] + t2[i]) + t3[i] : t[i]; g[i] = tg[i]; b[i] = tb[i]; }
     } else {
 #pragma unroll
-        for (int i = 0; i < PER; ++i) { v[i] = src[i]; g[i] = gam[lane * PER + i]; b[i] = bet[lane * PER + i]; }
+        for (int i = 0; i < PER; ++i) {
+            v[i] = src[i];
+            if (in2) v[i] = (v[i] + in2[ro + i]) + (in3 ? in3[ro + i] : 0.f);
+            g[i] = gam[lane * PER + i]; b[i] = bet[lane * PER + i];
+        }
     }
     float s = 0.f;
 #pragma unroll
@@ -272,10 +283,24 @@ __global__ __launch_bounds__(256) void k_ln_rows(const float* in, float* out, co
     }
 }
 
-static void launch_ln_rows(const float* in, float* out, const float* gam, const float* bet, int rows, int D, hipStream_t st) {
+// experiment knob (round 4): PT_TOMP_FFN2_SPLIT=2 runs the FFN's second product (K = dim_ff) as two K-halves whose partial sums,
+// bias included, meet in the LayerNorm that follows (which then also adds the residual)
+static int pt_tomp_ffn2_split() {
+    static const int v = [] { const char* e = getenv("PT_TOMP_FFN2_SPLIT"); return e ? atoi(e) : 0; }();
+    return v;
+}
+
+// in2 / in3 are only served by the 256-wide vector path: callers check ln_rows_wide_ok() first
+static bool ln_rows_wide_ok(const float* in, const float* out, const float* gam, const float* bet, int D) {
+    return D == 256 && ((uintptr_t)in % 16 == 0) && ((uintptr_t)out % 16 == 0) && ((uintptr_t)gam % 16 == 0) && ((uintptr_t)bet % 16 == 0);
+}
+
+static void launch_ln_rows(const float* in, float* out, const float* gam, const float* bet, int rows, int D, hipStream_t st,
+                           const float* in2 = nullptr, const float* in3 = nullptr) {
     const dim3 grid((rows + 3) / 4), block(256);
-    const bool al = ((uintptr_t)in % 16 == 0) && ((uintptr_t)out % 16 == 0) && ((uintptr_t)gam % 16 == 0) && ((uintptr_t)bet % 16 == 0);
-    if (D == 256 && al) hipLaunchKernelGGL(k_ln_rows_t<4>, grid, block, 0, st, in, out, gam, bet, rows);
+    const bool al = ((uintptr_t)in % 16 == 0) && ((uintptr_t)out % 16 == 0) && ((uintptr_t)gam % 16 == 0) && ((uintptr_t)bet % 16 == 0) &&
+                    ((uintptr_t)in2 % 16 == 0) && ((uintptr_t)in3 % 16 == 0);
+    if (D == 256 && al) hipLaunchKernelGGL(k_ln_rows_t<4>, grid, block, 0, st, in, out, gam, bet, rows, in2, in3);
     else if (D == 128) hipLaunchKernelGGL(k_ln_rows_t<2>, grid, block, 0, st, in, out, gam, bet, rows);
     else if (D == 64) hipLaunchKernelGGL(k_ln_rows_t<1>, grid, block, 0, st, in, out, gam, bet, rows);
     else hipLaunchKernelGGL(k_ln_rows, grid, block, 0, st, in, out, gam, bet, rows, D);
@@ -1197,6 +1222,14 @@ extern "C" int pt_tomp_predict_f32(const pt_tomp_dims* d, const float* params, c
         g = gemm_args(X, D, rows, P + e.w1, rows, ff, D, P + e.b1, Hd, ff);
         g.relu = 1;
         if ((rc = launch_gemm(g, st))) return rc;
+        if (pt_tomp_ffn2_split() == 2 && (ff / 64) % 2 == 0 && cv.Y > cv.AO && ln_rows_wide_ok(AO, X, P + e.n2g, P + e.n2b, D)) {
+            g = gemm_args(Hd, ff, rows, P + e.w2, rows, D, ff, P + e.b2, AO, D);
+            g.ksteps = ff / 64 / 2; g.c_zstride = (long)(cv.Y - cv.AO);          // halves -> AO, Y (bias rides on the first)
+            if ((rc = launch_gemm(g, st))) return rc;
+            launch_ln_rows(AO, X, P + e.n2g, P + e.n2b, rows, D, st, Y, X);
+            PT_CHECK_LAUNCH();
+            continue;
+        }
         g = gemm_args(Hd, ff, rows, P + e.w2, rows, D, ff, P + e.b2, Y, D);
         g.R = X;
         if ((rc = launch_gemm(g, st))) return rc;
