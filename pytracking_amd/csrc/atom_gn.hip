@@ -50,20 +50,32 @@ __global__ __launch_bounds__(512) void k_gn_pw(GnArgs a, int mode) {
     const int i = blockIdx.x;
     const long base = (long)i * a.HW;
     const float sq = sqrtf(a.sw[i]);
-    for (int o = threadIdx.x; o < a.HW; o += blockDim.x) {
+    // channel-slice partials in fixed-size batches with clamped indices: a run-time trip count makes the compiler's unrolled body
+    // start at 8 iterations and hands fewer (KS = 4 at ATOM's sizes) to a remainder loop of one dependent load per round trip
+    // (round 4: 8 round trips per element here, 7.4 us per launch)
+    const long sstride = (long)a.n * a.HW;
+    auto slice_sum = [&](const float* __restrict__ sp, int o) {
         float t = 0.f;
-#pragma unroll 8
-        for (int k = 0; k < a.KS; ++k) t += a.sp1[((long)k * a.n + i) * a.HW + o];
+        for (int k0 = 0; k0 < a.KS; k0 += 8) {
+            float v[8];
+#pragma unroll
+            for (int k = 0; k < 8; ++k) v[k] = sp[(long)min(k0 + k, a.KS - 1) * sstride + (long)i * a.HW + o];
+#pragma unroll
+            for (int k = 0; k < 8; ++k) t += k0 + k < a.KS ? v[k] : 0.f;               // same order as the plain loop
+        }
+        return t;
+    };
+    for (int o = threadIdx.x; o < a.HW; o += blockDim.x) {
         float val;
         if (mode == 0) {
+            const float yv = a.y[base + o];
+            const float t = slice_sum(a.sp1, o);
             const float dv = sq * gn_mlu_d(t, a.act_min);
             a.d[base + o] = dv;
-            val = dv * (sq * (gn_mlu(t, a.act_min) - a.y[base + o]));
+            val = dv * (sq * (gn_mlu(t, a.act_min) - yv));
         } else {
-            float t2 = 0.f;
-#pragma unroll 8
-            for (int k = 0; k < a.KS; ++k) t2 += a.sp2[((long)k * a.n + i) * a.HW + o];
             const float dv = a.d[base + o];
+            const float t = slice_sum(a.sp1, o), t2 = slice_sum(a.sp2, o);
             val = dv * (dv * (t + t2));
         }
         a.v[base + o] = val;
@@ -81,18 +93,32 @@ __device__ float gn_dot2(const float* u, const float* v, int n, float* scratch) 
 
 // element e of J^T(.) assembled from the pass partials (+ the regularisation part `reg * vec[e]`)
 __device__ __forceinline__ float gn_gather(const GnArgs& a, int e, const float* vec) {
+    // partial slabs in fixed-size batches of 8 with clamped indices (all loads of a batch in flight, fixed summation order); with a
+    // run-time trip count the unrolled loop's remainder -- 6 of the 30 per-sample slabs -- was one dependent load per round trip
     float s = 0.f;
+    const float rv = vec[e];
     if (e < a.NF) {
-#pragma unroll 8
-        for (int k = 0; k < a.KSPL; ++k) s += a.gpf[(long)k * a.NF + e];       // unrolled: 8 partial loads in flight
-        return s + a.lf * vec[e];
+        for (int k0 = 0; k0 < a.KSPL; k0 += 8) {
+            float v[8];
+#pragma unroll
+            for (int k = 0; k < 8; ++k) v[k] = a.gpf[(long)min(k0 + k, a.KSPL - 1) * a.NF + e];
+#pragma unroll
+            for (int k = 0; k < 8; ++k) s += k0 + k < a.KSPL ? v[k] : 0.f;
+        }
+        return s + a.lf * rv;
     }
     const int ep = e - a.NF, row = ep / a.M, m = ep - row * a.M, grp = row >> 4, rl = row & 15;
     const int Fg = min(16, a.Kc - 16 * grp);
-    const float* gp = a.gpP + (long)grp * a.NSG * 16 * a.M;
-#pragma unroll 8
-    for (int k = 0; k < a.NSG; ++k) s += gp[((long)k * Fg + rl) * a.M + m];
-    return s + a.lP * vec[e];
+    const float* gp = a.gpP + (long)grp * a.NSG * 16 * a.M + (long)rl * a.M + m;
+    const long kst = (long)Fg * a.M;
+    for (int k0 = 0; k0 < a.NSG; k0 += 8) {
+        float v[8];
+#pragma unroll
+        for (int k = 0; k < 8; ++k) v[k] = gp[(long)min(k0 + k, a.NSG - 1) * kst];
+#pragma unroll
+        for (int k = 0; k < 8; ++k) s += k0 + k < a.NSG ? v[k] : 0.f;
+    }
+    return s + a.lP * rv;
 }
 
 // search direction from the residual r with the diagonal preconditioner (optimization.py:97-125, optim.py:67-68)

@@ -37,7 +37,7 @@ __device__ __forceinline__ float lwl_sw(const LwlArgs& a, long e) {
 // every thread: the sum of the LWL_NBLK partials, fixed order (thread k holds partial k; wave sums, then the waves in order).
 // As a serial loop in every thread this was 2 x 256 dependent loads in front of the update kernel.
 __device__ __forceinline__ float lwl_sum_parts(const float* p, float* scratch) {
-    static_assert(LWL_NBLK == 256, "one partial per thread of the 256-thread block");
+    static_assert(LWL_NBLK == 256 && PT_MF_SQ_PARTS == LWL_NBLK, "one partial per thread of the 256-thread block");
     return block_sum(p[threadIdx.x], scratch);
 }
 
@@ -94,9 +94,15 @@ __global__ __launch_bounds__(256) void k_lwl_g(LwlArgs a, int t) {
     float acc = 0.f;
     for (long e = (long)blockIdx.x * 256 + threadIdx.x; e < a.CKK; e += (long)LWL_NBLK * 256) {
         float v = 0.f;
-#pragma unroll 8
-        for (int k = 0; k < a.NSG; ++k) v += a.gpart[(long)k * a.CKK + e];       // unrolled: the loads of 8 partials in flight
-        v += a.lam * a.lam * w[e];
+        const float wv = w[e];
+        for (int k0 = 0; k0 < a.NSG; k0 += 8) {                     // fixed-size batches, clamped: 8 partial loads in flight whatever NSG is
+            float pv[8];
+#pragma unroll
+            for (int k = 0; k < 8; ++k) pv[k] = a.gpart[(long)min(k0 + k, a.NSG - 1) * a.CKK + e];
+#pragma unroll
+            for (int k = 0; k < 8; ++k) v += k0 + k < a.NSG ? pv[k] : 0.f;
+        }
+        v += a.lam * a.lam * wv;
         a.g[e] = v;
         {                                                           // the same value in the order k_mf_corr reads it
             const int tap = (int)(e % a.KK), c = (int)((e / a.KK) % a.C), f = (int)(e / ((long)a.KK * a.C));
@@ -256,10 +262,16 @@ extern "C" int pt_lwl_gn_solve_f32(const float* w_in, const float* feat, long fe
         if (rc) return rc;
         hipLaunchKernelGGL(k_lwl_g, dim3(LWL_NBLK), dim3(256), 0, st, a, t);
         PT_CHECK_LAUNCH();
-        rc = pt_launch_mf_corr(feat, feat_stride_n, a.gT, a.sg, n, F, C, H, W, K, st, 0, 1, cpart);  // F g
+        // F g; with few samples the correlation is split over the channels and the kernel that sums the splits leaves the
+        // partials of |sw * F g|^2 as well (one launch less per iteration where launches are what an iteration costs)
+        int hh_done = 0;
+        const PtMfSq sq = {a.sw, a.sw_mode, a.sw_scalar, (long)a.F * a.HW, a.hhp, &hh_done};
+        rc = pt_launch_mf_corr(feat, feat_stride_n, a.gT, a.sg, n, F, C, H, W, K, st, 0, 1, cpart, &sq);
         if (rc) return rc;
-        hipLaunchKernelGGL(k_lwl_hh, dim3(LWL_NBLK), dim3(256), 0, st, a);
-        PT_CHECK_LAUNCH();
+        if (!hh_done) {
+            hipLaunchKernelGGL(k_lwl_hh, dim3(LWL_NBLK), dim3(256), 0, st, a);
+            PT_CHECK_LAUNCH();
+        }
         hipLaunchKernelGGL(k_lwl_upd, dim3(LWL_NBLK), dim3(256), 0, st, a, t + 1, want_loss, (int)(t + 1 == num_iter));
         PT_CHECK_LAUNCH();
     }

@@ -860,17 +860,45 @@ size_t pt_mf_corr_part_floats(int n, int F, int C, int H, int W, int K) {
     const int ks = pt_mf_corr_splits(n, F, C, H, W, K);
     return ks > 1 ? (size_t)ks * n * F * H * W : 0;
 }
+// sum of the <= 16 channel-split partial maps of an element quad: every load requested before the first add (with the run-time
+// count as the loop bound each split was its own memory round trip), fixed order
+__device__ __forceinline__ f32x4 mf_parts_quad(const float* __restrict__ part, int parts, long count, long e) {
+    f32x4 v[16];
+#pragma unroll
+    for (int k = 0; k < 16; ++k) v[k] = *(const f32x4*)(part + (long)min(k, parts - 1) * count + e);
+    f32x4 s = v[0];
+#pragma unroll
+    for (int k = 1; k < 16; ++k)
+        if (k < parts) s += v[k];
+    return s;
+}
 __global__ void k_mf_sum_parts(const float* __restrict__ part, float* __restrict__ out, int parts, long count) {
     const long e = ((long)blockIdx.x * blockDim.x + threadIdx.x) * 4;
     if (e >= count) return;
-    f32x4 s = *(const f32x4*)(part + e);
-    for (int k = 1; k < parts; ++k) s += *(const f32x4*)(part + (long)k * count + e);
-    *(f32x4*)(out + e) = s;
+    *(f32x4*)(out + e) = mf_parts_quad(part, parts, count, e);
+}
+// the same with the squared-norm rider (PtMfSq): PT_MF_SQ_PARTS workgroups stride over the quads, each leaves one partial sum
+__global__ __launch_bounds__(256) void k_mf_sum_parts_sq(const float* __restrict__ part, float* __restrict__ out, int parts, long count,
+                                                         PtMfSq q) {
+    __shared__ float scratch[16];
+    float acc = 0.f;
+    for (long e = ((long)blockIdx.x * 256 + threadIdx.x) * 4; e < count; e += (long)PT_MF_SQ_PARTS * 256 * 4) {
+        const f32x4 s = mf_parts_quad(part, parts, count, e);
+        *(f32x4*)(out + e) = s;
+#pragma unroll
+        for (int u = 0; u < 4; ++u) {
+            const float w = q.sw_mode == 0 ? q.sw_scalar : (q.sw_mode == 1 ? q.sw[(e + u) / q.per_image] : q.sw[e + u]);
+            const float h = w * s[u];
+            acc += h * h;
+        }
+    }
+    const float tot = block_sum(acc, scratch);
+    if (threadIdx.x == 0) q.out[blockIdx.x] = tot;
 }
 
 // wT: weights pre-transposed by pt_launch_mf_wtrans (pt_mf_wt_floats(C, K) floats, 16-byte aligned)
 int pt_launch_mf_corr(const float* feat, long stride_n, const float* wT, float* scores, int n, int F, int C, int H,
-                      int W, int K, hipStream_t st, long out_stride_n, int groups, float* part) {
+                      int W, int K, hipStream_t st, long out_stride_n, int groups, float* part, const PtMfSq* sq) {
     MfPlan p = mf_plan(n, F, C, H, W, K);
     if (out_stride_n == 0) out_stride_n = (long)F * H * W;
     if (!p.ok || groups < 1) return PT_ERR_UNSUPPORTED;
@@ -893,7 +921,13 @@ int pt_launch_mf_corr(const float* feat, long stride_n, const float* wT, float* 
     PT_CHECK_LAUNCH();
     if (ksp > 1) {
         const long count = (long)n * out_stride_n;
-        hipLaunchKernelGGL(k_mf_sum_parts, dim3((unsigned)((count / 4 + 255) / 256)), dim3(256), 0, st, part, scores, ksp, count);
+        if (ksp > 16) return PT_ERR_UNSUPPORTED;                     // mf_parts_quad sums at most 16 splits (pt_mf_corr_splits: <= 16)
+        if (sq && sq->out && sq->done) {
+            hipLaunchKernelGGL(k_mf_sum_parts_sq, dim3(PT_MF_SQ_PARTS), dim3(256), 0, st, part, scores, ksp, count, *sq);
+            *sq->done = 1;
+        } else {
+            hipLaunchKernelGGL(k_mf_sum_parts, dim3((unsigned)((count / 4 + 255) / 256)), dim3(256), 0, st, part, scores, ksp, count);
+        }
         PT_CHECK_LAUNCH();
     }
     return PT_OK;

@@ -112,8 +112,14 @@ int pt_launch_mf_corr1_direct(const float* feat, long stride_n, const float* fil
                               int H, int W, hipStream_t st, long out_stride_n);     // 1x1, weights (Ftot, C) untransposed
 int pt_mf_corr_splits(int n, int F, int C, int H, int W, int K);               // channel splits used with a partial workspace
 size_t pt_mf_corr_part_floats(int n, int F, int C, int H, int W, int K);         // its size (0: no split for this shape)
+// `sq`: optional rider of the channel-split reduction (LWL few-shot learner: |sw * F g|^2 of steepestdescent.py:76-80): when the
+// launch goes through the partial-map workspace, the kernel that sums the splits also leaves PT_MF_SQ_PARTS partial sums of
+// (weight * score)^2 in sq->out and *sq->done = 1; otherwise sq is left alone (the caller runs its own reduction).
+#define PT_MF_SQ_PARTS 256
+struct PtMfSq { const float* sw; int sw_mode; float sw_scalar; long per_image; float* out; int* done; };
 int pt_launch_mf_corr(const float* feat, long stride_n, const float* wT, float* scores, int n, int F, int C, int H,
-                      int W, int K, hipStream_t st, long out_stride_n = 0, int groups = 1, float* part = nullptr);
+                      int W, int K, hipStream_t st, long out_stride_n = 0, int groups = 1, float* part = nullptr,
+                      const PtMfSq* sq = nullptr);
 int pt_launch_mf_adj(const float* feat, long stride_n, const float* inp, float* gpart, int n, int F, int C, int H, int W,
                      int K, hipStream_t st, long inp_stride_n = 0, int groups = 1);
 

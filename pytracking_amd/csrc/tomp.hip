@@ -100,14 +100,29 @@ __global__ __launch_bounds__(512) void k_attn(AttnArgs a) {
     for (int d = 0; d < DT; ++d) ot[d] = f32x4{0.f, 0.f, 0.f, 0.f};
     float m_run = -INFINITY, l_run = 0.f;
 
+    // Padding keys (round 4).  A 128-key iteration that lies entirely inside the padding range [mlo, mhi) contributes exp(-inf) = 0
+    // to every query and leaves (max, sum, O) bit for bit as they were: it is not fetched at all (ToMP's second batch row masks 324
+    // of its 972 keys: two of its eight iterations).  A 64-key half chunk inside the range is skipped by its four wavefronts; one
+    // that touches neither the range nor the end of the sequence runs without the per-key tests.
     const int nit = (a.L + 127) / 128;
-    fetch(0);
-    for (int it = 0; it < nit; ++it) {
+    auto live = [&](int it) { return !(it * 128 >= mlo && it * 128 + 128 <= mhi); };
+    int pk[4];
+#pragma unroll
+    for (int r = 0; r < 4; ++r) pk[r] = prow(4 * kq + r);
+    int it = 0;
+    while (it < nit && !live(it)) ++it;
+    if (it < nit) fetch(it * 128);
+    while (it < nit) {
+        int nx = it + 1;
+        while (nx < nit && !live(nx)) ++nx;
         __syncthreads();                                          // previous iteration's LDS reads are done
         stash();
         __syncthreads();
-        if (it + 1 < nit) fetch((it + 1) * 128);
+        if (nx < nit) fetch(nx * 128);
         const int c0 = it * 128 + half * 64;
+        it = nx;
+        if (c0 >= a.L || (c0 >= mlo && c0 + 64 <= mhi)) continue;  // wave-uniform: nothing but padding in this half chunk
+        const bool tests = c0 + 64 > a.L || (c0 < mhi && c0 + 64 > mlo);
         const float* Kh = Ks + half * 64 * KS;
         const float* Vh = Vs + half * 64 * VS;
         // ---- S^T tiles: rows = keys, cols = queries.  The K fragments of tile kt+1 (and the V operands of the first PV
@@ -143,12 +158,15 @@ __global__ __launch_bounds__(512) void k_attn(AttnArgs a) {
 #pragma unroll
                 for (int e = 0; e < 4; ++e) sc = mfma16(kf[kt & 1][v][e], qf[4 * v + e], sc);
             }
+            if (tests) {                                          // wave-uniform
 #pragma unroll
-            for (int r = 0; r < 4; ++r) {
-                const int key = c0 + kt * 16 + prow(4 * kq + r);
-                if (key >= a.L || (key >= mlo && key < mhi)) sc[r] = -INFINITY;
-                mc = fmaxf(mc, sc[r]);
+                for (int r = 0; r < 4; ++r) {
+                    const int key = c0 + kt * 16 + pk[r];
+                    if (key >= a.L || (key >= mlo && key < mhi)) sc[r] = -INFINITY;
+                }
             }
+#pragma unroll
+            for (int r = 0; r < 4; ++r) mc = fmaxf(mc, sc[r]);
             st[kt] = sc;
             __builtin_amdgcn_sched_barrier(0);
         }
@@ -283,10 +301,11 @@ __global__ __launch_bounds__(256) void k_ln_rows(const float* in, float* out, co
     }
 }
 
-// experiment knob (round 4): PT_TOMP_FFN2_SPLIT=2 runs the FFN's second product (K = dim_ff) as two K-halves whose partial sums,
-// bias included, meet in the LayerNorm that follows (which then also adds the residual)
+// The FFN's second product (K = dim_ff) runs as two K-halves whose partial sums, bias included, meet in the LayerNorm that follows
+// (which then also adds the residual): 976 instead of 488 workgroups of half the K loop, ToMP frame 1.006 -> 0.996 ms (round 4,
+// profiles/r04e_*).  PT_TOMP_FFN2_SPLIT=0 restores the single product (A/B knob).
 static int pt_tomp_ffn2_split() {
-    static const int v = [] { const char* e = getenv("PT_TOMP_FFN2_SPLIT"); return e ? atoi(e) : 0; }();
+    static const int v = [] { const char* e = getenv("PT_TOMP_FFN2_SPLIT"); return e ? atoi(e) : 2; }();
     return v;
 }
 
