@@ -16,9 +16,12 @@
 //             wave w owns U contiguous 16-position groups.  G[c][tap] = sum_P feat[c][P] * r[P shifted by tap]; the B
 //             operand is gathered from zero-padded residual maps the workgroup builds in LDS -- there is no im2col
 //             buffer in HBM.  In the solver the maps come from the fused update prologue (alpha, s_{t}, residual).
+#include <type_traits>
 #include "common.h"
 #include "pt_internal.h"
 #include "sd_common.h"
+
+typedef float f32x2a4 __attribute__((ext_vector_type(2), aligned(4)));   // 8-byte LDS access at 4-byte alignment (ds_read_b64)
 
 #ifndef PT_ADJ_WAVES
 #define PT_ADJ_WAVES 8                     // waves per k_adj2 workgroup (16 measured no better at 18x18, worse at 22x22)
@@ -45,11 +48,19 @@
 #ifndef PT_C2_BAR
 #define PT_C2_BAR 0      // 1: workgroup barrier between the filter-operand loads and the first feature loads
 #endif
+#ifndef PT_C2_PAIR
+#define PT_C2_PAIR 1     // 1: sample-pair workgroups in k_corr2 where the plan allows them (pt_fast_plan); 0: round 3's one sample per workgroup
+#endif
 #ifndef PT_C2_R16
 #define PT_C2_R16 0      // 1: 16 channel ranges -- the two k-step halves of an XCD's range as separate 5-wave workgroups
 #endif
 #ifndef PT_ADJ_BAR
 #define PT_ADJ_BAR 0     // 1: workgroup barrier between the small update-stage loads and the first feature loads
+#endif
+#ifndef PT_ADJ_G2
+#define PT_ADJ_G2 0      // 1: residual cells of a quad gathered as two 8-byte LDS reads at 4-byte alignment (even map widths).  Measured in
+//                          round 4 and NOT kept: k_adj2 7.6 -> 12.0 us (PrDiMP 12.7 -> 17.7) -- a misaligned ds_read_b64 costs far more
+//                          than the two scalar reads and two address adds it replaces (profiles/r04j_adjoint_pair_gather_ab.txt)
 #endif
 #ifndef PT_ADJ_EARLY
 #define PT_ADJ_EARLY 1   // 1: first feature loads in front of the LDS work; 0: behind barrier 1
@@ -106,11 +117,20 @@ PtFast pt_fast_plan(int n, int C, int H, int W, int KH, int KW, int OH, int OW) 
     p.KSC = 8;
     if (C == 64) { p.CX = C; p.KSC = 1; }                           // ATOM's compressed samples: a workgroup takes ALL channels of a sample
     if (PT_C2_R16 && p.nh == 2 && n > 16 && C > 64) { p.nh = 1; p.CX = C / 16; p.KSC = 16; }
+    // Sample pairs (round 4).  With more samples than one workgroup per CU (8 n > 256) the pass lasted as long as a CU holding two
+    // 10-wave workgroups -- two prologues, two filter reductions, their MFMA phases colliding -- while other CUs held one.  A pair
+    // workgroup takes TWO samples with the same 10 waves: wave = (sample of the pair, tile), each with ALL k-steps of the XCD's
+    // channel range (no k-step halves: no second tap-plane set to add), the filter operand reduced and staged once for both.
+    // 8 n / 2 workgroups, at most one per CU up to n = 64.  Even n only (the pair index is formed before the argument block arrives).
+    p.spw = 1;
+    // Maps of 6-8 tiles (22x22) already run one wave per tile with all k-steps; their pairs (16 waves) were measured SLOWER
+    // (PrDiMP-50: 11.25 vs 10.83 us, profiles/r04i_*) and keep one sample per workgroup.
+    if (PT_C2_PAIR && p.nh == 2 && p.KSC == 8 && p.CX / 4 <= 16 && (n % 2) == 0 && 8 * n > 256) { p.nh = 1; p.spw = 2; }
     p.NK = p.CX / 4 / p.nh;
     if (p.NK > 16) return p;
     p.HWp = 64 * (p.TF + (p.rem > 0 ? 1 : 0)) + 4;
-    p.corr_threads = p.nh * p.tiles * 64;
-    p.corr_lds = ((size_t)p.CX * 16 + (size_t)p.nh * p.KK * p.HWp) * sizeof(float);
+    p.corr_threads = p.spw * p.nh * p.tiles * 64;
+    p.corr_lds = ((size_t)p.CX * 16 + (size_t)p.spw * p.nh * p.KK * p.HWp) * sizeof(float);
     if (p.corr_lds > 150 * 1024) return p;
     p.CB = C / 16;
     p.bpx = p.CB / 8;                                               // 0: fewer channel blocks than XCDs (workgroup b: block b % CB, slice b / CB)
@@ -197,7 +217,8 @@ __global__ __launch_bounds__(1024, (NK <= 8 ? PT_C2_MINW : 4)) void k_corr2(cons
     // 1.2 us later (measured in round 3: a kernel whose arguments are all preloaded is that much shorter, eager and in graph
     // replay alike) -- by then the filter partials and the first feature tiles are on their way.
     //   h_filt = gradient partials (FUSE > 0) or the filter (FUSE == 0);  h_dims = C << 16 | H*W;
-    //   h_geo  = tiles | TF << 5 | rem << 10 | KSPL << 14 | (16 channel ranges) << 20 | (1 channel range: C = 64) << 21
+    //   h_geo  = tiles | TF << 5 | rem << 10 | KSPL << 14 | (16 channel ranges) << 20 | (1 channel range: C = 64) << 21 |
+    //            (sample pairs: workgroup b >> 3 takes samples 2 (b >> 3) and 2 (b >> 3) + 1) << 22
     extern __shared__ __attribute__((aligned(16))) float lds[];     // afilt[CX][16] | T[2][KK][HWp]
     __shared__ float scratch[16];
     PT_STAMP(a_arg, 0);
@@ -206,23 +227,26 @@ __global__ __launch_bounds__(1024, (NK <= 8 ? PT_C2_MINW : 4)) void k_corr2(cons
     const int hC = (int)(h_dims >> 16), HW = (int)(h_dims & 0xffffu);
     const int h_tiles = (int)(h_geo & 31u), h_TF = (int)((h_geo >> 5) & 31u), h_rem = (int)((h_geo >> 10) & 15u);
     const int h_KSPL = (int)((h_geo >> 14) & 63u);
-    const bool ksc16 = ((h_geo >> 20) & 1u) != 0, ksc1 = ((h_geo >> 21) & 1u) != 0;
-    const int nthreads = NH * h_tiles * 64;
+    const bool ksc16 = ((h_geo >> 20) & 1u) != 0, ksc1 = ((h_geo >> 21) & 1u) != 0, pair = ((h_geo >> 22) & 1u) != 0;
+    const int wps = NH * h_tiles;                                   // waves per sample
+    const int nthreads = (pair ? 2 : 1) * wps * 64;
     const int hCX = ksc1 ? hC : (ksc16 ? hC >> 4 : hC >> 3), hHWp = 64 * (h_TF + (h_rem > 0 ? 1 : 0)) + 4;
     // 16 ranges: 2x and 2x + 1 both run on XCD x (the adjoint pass owns channels [x C/8, (x+1) C/8) there)
     const int b = blockIdx.x, xc = b & 7, q = b >> 3;
-    const int x = ksc1 ? 0 : (ksc16 ? 2 * xc + (q & 1) : xc), i = ksc1 ? b : (ksc16 ? q >> 1 : q);
+    const int x = ksc1 ? 0 : (ksc16 ? 2 * xc + (q & 1) : xc), i0 = ksc1 ? b : (ksc16 ? q >> 1 : q);
     const int KK = K16 ? 16 : a_arg.KH * a_arg.KW;
     const int lane = threadIdx.x & 63, wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);   // wave-uniform: scalar branches
     const int kq = lane >> 4, j = lane & 15;
-    const int h = wave >= h_tiles ? 1 : 0, t = wave - h * h_tiles;
+    const int ws = (pair && wave >= wps) ? 1 : 0, wl = wave - ws * wps;   // which sample of the pair, wave inside the sample
+    const int i = pair ? 2 * i0 + ws : i0;
+    const int h = wl >= h_tiles ? 1 : 0, t = wl - h * h_tiles;
     const int cx0 = hCX * x;
     const int nsl = hCX * 16;
     float* __restrict__ afilt = lds;
-    float* __restrict__ Tl = lds + nsl + (long)h * KK * hHWp;
+    float* __restrict__ Tl = lds + nsl + (long)(ws * NH + h) * KK * hHWp;
     const bool over = h_src != nullptr && i == h_slot;
     const float* __restrict__ fi = over ? h_src : h_feat + (long)i * h_stride;
-    const bool publish = FUSE > 0 && i == 0;
+    const bool publish = FUSE > 0 && i0 == 0;                       // uniform per workgroup
 
     // ---- filter operand: straight-line, clamped addresses, all loads in flight together.  With 16 taps the slice
     //      is one contiguous run of CX*16 floats: 16-byte loads, one per thread; otherwise up to EPT scalars.
@@ -388,11 +412,13 @@ __global__ __launch_bounds__(1024, (NK <= 8 ? PT_C2_MINW : 4)) void k_corr2(cons
     // ---- shift-and-add of the tap planes (both halves), fixed order
     const int ph = a.KH / 2, pw = a.KW / 2, OO = a.OH * a.OW;
     const float inv_ow = 1.0f / (float)a.OW;
-    const float* __restrict__ T0 = lds + nsl;
-    const float* __restrict__ T1 = T0 + (long)KK * hHWp;          // second k-step half (a.nh == 2)
-    const pt_gf out = a.spart + ((long)x * a.n + i) * OO;
+    const int nsm = pair ? 2 : 1;                                   // samples whose tap planes this workgroup holds
     if (a.KH == 4 && a.KW == 4) {                                   // the trackers' filter size: fully unrolled
-        for (int o = threadIdx.x; o < OO; o += nthreads) {
+        for (int o2 = threadIdx.x; o2 < nsm * OO; o2 += nthreads) {
+            const int s2 = o2 >= OO ? 1 : 0, o = o2 - s2 * OO;
+            const float* __restrict__ T0 = lds + nsl + (long)s2 * NH * KK * hHWp;
+            const float* __restrict__ T1 = T0 + (long)KK * hHWp;  // second k-step half (NH == 2)
+            const pt_gf out = a.spart + ((long)x * a.n + (pair ? 2 * i0 + s2 : i0)) * OO;
             const int y = fdiv(o, inv_ow), xx0 = o - y * a.OW;
             float tv[16];
 #pragma unroll
@@ -415,7 +441,11 @@ __global__ __launch_bounds__(1024, (NK <= 8 ? PT_C2_MINW : 4)) void k_corr2(cons
         PT_STAMP(a, 7);
         return;
     }
-    for (int o = threadIdx.x; o < OO; o += nthreads) {
+    for (int o2 = threadIdx.x; o2 < nsm * OO; o2 += nthreads) {
+        const int s2 = o2 >= OO ? 1 : 0, o = o2 - s2 * OO;
+        const float* __restrict__ T0 = lds + nsl + (long)s2 * NH * KK * hHWp;
+        const float* __restrict__ T1 = T0 + (long)KK * hHWp;
+        const pt_gf out = a.spart + ((long)x * a.n + (pair ? 2 * i0 + s2 : i0)) * OO;
         const int y = fdiv(o, inv_ow), xx0 = o - y * a.OW;
         float s = 0.f;
         for (int u = 0; u < a.KH; ++u) {
@@ -450,11 +480,11 @@ int pt_launch_corr2(const PtFast& p, const float* feat, long stride_n, const flo
     if ((long)p.n * stride_n * 4 >= (1L << 31)) return PT_ERR_UNSUPPORTED;
     if (p.KK == 16 && (((uintptr_t)filt % 16) || ((uintptr_t)a.gpart % 16) || ((uintptr_t)a.w % 16) || ((uintptr_t)a.g_out % 16)))
         return PT_ERR_UNSUPPORTED;
-    dim3 grid(p.KSC * p.n), block(p.corr_threads);
+    dim3 grid(p.KSC * (p.n / p.spw)), block(p.corr_threads);
     if (p.C >= (1 << 16) || p.HW >= (1 << 16) || p.tiles > 31 || p.TF > 31 || p.rem > 15 || a.KSPL > 16) return PT_ERR_UNSUPPORTED;
     const unsigned h_dims = ((unsigned)p.C << 16) | (unsigned)p.HW;
     const unsigned h_geo = (unsigned)p.tiles | ((unsigned)p.TF << 5) | ((unsigned)p.rem << 10) | ((unsigned)a.KSPL << 14) |
-                           ((p.KSC == 16 ? 1u : 0u) << 20) | ((p.KSC == 1 ? 1u : 0u) << 21);
+                           ((p.KSC == 16 ? 1u : 0u) << 20) | ((p.KSC == 1 ? 1u : 0u) << 21) | ((p.spw == 2 ? 1u : 0u) << 22);
 #define PT_C2_HOT(FPTR) (const float*)a.feat, a.stride_n, (const float*)(FPTR), (const float*)a.w, (const float*)a.src, a.slot, h_dims, h_geo
 #define PT_C2G(NKV, LF, KF, NHV)                                                                                    \
     do {                                                                                                         \
@@ -814,10 +844,6 @@ __global__ __launch_bounds__(PT_ADJ_WAVES * 64) void k_adj2(const float* h_feat,
     i32x4 cell[UM];
     auto issue = [&](int u) { av[u] = pt_bload4(fr, (unsigned)foff[u] + chw4); };
     auto cells = [&](int u) { cell[u] = *(const i32x4*)__builtin_assume_aligned(tabI + 4 * (tq + u), 16); };
-    auto gather = [&](int u) {
-#pragma unroll
-        for (int k = 0; k < 4; ++k) bv[u][k] = *(const float*)((const char*)maps + ((unsigned)cell[u][k] + tapoff4));
-    };
     if (!PT_ADJ_EARLY) {
 #pragma unroll
         for (int u = 0; u < PD; ++u) issue(u);
@@ -844,21 +870,40 @@ __global__ __launch_bounds__(PT_ADJ_WAVES * 64) void k_adj2(const float* h_feat,
     // ---- G[c][tap] += feat[c][P] * r[P shifted by tap] over the U contiguous 16-position groups of this wave.
     //      A wave stalls at a load it cannot issue (the CU's memory pipeline accepts ~20-45 B/clk), so the loads are
     //      software-pipelined PD groups ahead of the MFMAs that consume them instead of being issued all up front.
+    //      The loop is bound by instruction issue (3.3 of the pass's 7.6 us: 11 vector / LDS instructions around 4 MFMAs per group,
+    //      profiles/r04a_pmc_counters.txt).  Experiment PT_ADJ_G2 (round 4, lost): with an even map width a row wrap can only fall
+    //      between a quad's second and third position, so cells (0,1) and (2,3) are neighbours in the padded map and the four scalar
+    //      gathers can be two 8-byte LDS reads -- at 4-byte alignment, which the LDS serves far slower than four aligned dwords.
     f32x4 accA = {0, 0, 0, 0}, accB = {0, 0, 0, 0};
-    cells(0);
-    if (UM > 1) cells(1);
-    gather(0);
+    auto mfma_loop = [&](auto pair_tag) {
+        constexpr bool G2 = decltype(pair_tag)::value;
+        auto gather = [&](int u) {
+            if constexpr (G2) {
+                const f32x2a4 lo = *(const f32x2a4*)((const char*)maps + ((unsigned)cell[u][0] + tapoff4));
+                const f32x2a4 hi = *(const f32x2a4*)((const char*)maps + ((unsigned)cell[u][2] + tapoff4));
+                bv[u][0] = lo[0]; bv[u][1] = lo[1]; bv[u][2] = hi[0]; bv[u][3] = hi[1];
+            } else {
 #pragma unroll
-    for (int u = 0; u < UM; ++u) {
-        if (u + PD < UM) issue(u + PD);
-        if (u + 2 < UM) cells(u + 2);
-        if (u + 1 < UM) gather(u + 1);
-        // masked quads multiply a finite, re-read feature value by a gathered zero
-        accA = mfma16(av[u][0], bv[u][0], accA);
-        accB = mfma16(av[u][1], bv[u][1], accB);
-        accA = mfma16(av[u][2], bv[u][2], accA);
-        accB = mfma16(av[u][3], bv[u][3], accB);
-    }
+                for (int k = 0; k < 4; ++k) bv[u][k] = *(const float*)((const char*)maps + ((unsigned)cell[u][k] + tapoff4));
+            }
+        };
+        cells(0);
+        if (UM > 1) cells(1);
+        gather(0);
+#pragma unroll
+        for (int u = 0; u < UM; ++u) {
+            if (u + PD < UM) issue(u + PD);
+            if (u + 2 < UM) cells(u + 2);
+            if (u + 1 < UM) gather(u + 1);
+            // masked quads multiply a finite, re-read feature value by a gathered zero
+            accA = mfma16(av[u][0], bv[u][0], accA);
+            accB = mfma16(av[u][1], bv[u][1], accB);
+            accA = mfma16(av[u][2], bv[u][2], accA);
+            accB = mfma16(av[u][3], bv[u][3], accB);
+        }
+    };
+    if (PT_ADJ_G2 && (hW & 1) == 0) mfma_loop(std::true_type{});    // uniform
+    else mfma_loop(std::false_type{});
     PT_STAMP_A(a, 5);
 #pragma unroll
     for (int r = 0; r < 4; ++r) red[wave][(4 * kq + r) * 16 + j] = accA[r] + accB[r];

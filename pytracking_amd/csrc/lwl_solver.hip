@@ -248,9 +248,9 @@ extern "C" int pt_lwl_gn_solve_f32(const float* w_in, const float* feat, long fe
         hipMemcpyAsync(w_iters, w_in, (size_t)a.CKK * sizeof(float), hipMemcpyDeviceToDevice, st) != hipSuccess)
         return PT_ERR_LAUNCH;
     if (num_iter == 0 && !want_loss) return PT_OK;
-    // the padding of the transposed gradient table is written once (k_lwl_g only touches live entries)
-    if (hipMemsetAsync(a.gT, 0, pt_mf_wt_floats(C, K) * sizeof(float), st) != hipSuccess) return PT_ERR_LAUNCH;
-    rc = pt_launch_mf_wtrans(w_in, base + cv.wT, F, C, K, st);
+    // the padding of the transposed gradient table is written once (k_lwl_g only touches live entries): by the launch that
+    // transposes the start filter (round 4; it was a memset node of its own in front of every solve)
+    rc = pt_launch_mf_wtrans(w_in, base + cv.wT, F, C, K, st, 1, a.gT);
     if (rc) return rc;
     float* cpart = pt_mf_corr_part_floats(n, F, C, H, W, K) ? base + cv.cpart : nullptr;
     rc = pt_launch_mf_corr(feat, feat_stride_n, base + cv.wT, a.s, n, F, C, H, W, K, st, 0, 1, cpart);   // s_0 = F w_0

@@ -451,13 +451,16 @@ __global__ __launch_bounds__(256) void k_mf_corr1(const float* __restrict__ feat
 
 // Weights in the order the correlation consumes them: wT[c/4][lane = (c%4)*16 + filter][MF_TP taps], zero padded to 16
 // filters, to 12 taps and to a multiple of MF_CK channels (one contiguous 16-byte-loadable block per channel chunk).
+// clear2 (optional): a second table of the same size that this launch zeroes on the side (the few-shot learner's transposed
+// gradient table, whose padding is written once per solve -- no memset node in front of the solve)
 __global__ void k_mf_wtrans(const float* __restrict__ filt, float* __restrict__ wT, int F, int C, int KK, int Cpad,
-                            long filt_zstride, long wt_zstride) {
+                            long filt_zstride, long wt_zstride, float* __restrict__ clear2) {
     filt += (long)blockIdx.y * filt_zstride;
     wT += (long)blockIdx.y * wt_zstride;
     const int TP = MF_TP(KK);
     const int e = blockIdx.x * blockDim.x + threadIdx.x;
     if (e >= (Cpad >> 2) * 64 * TP) return;
+    if (clear2 && blockIdx.y == 0) clear2[e] = 0.f;
     const int tap = e % TP, ln = (e / TP) & 63, c4 = e / (TP * 64);
     const int f = ln & 15, c = 4 * c4 + (ln >> 4);
     wT[e] = (tap < KK && f < F && c < C) ? filt[((long)f * C + c) * KK + tap] : 0.f;
@@ -775,10 +778,10 @@ static MfPlan mf_plan(int n, int F, int C, int H, int W, int K, int br_force = 0
 
 size_t pt_mf_wt_floats(int C, int K) { return (size_t)(((C + MF_CK - 1) / MF_CK) * MF_CK / 4) * 64 * MF_TP(K * K); }
 
-int pt_launch_mf_wtrans(const float* filt, float* wT, int F, int C, int K, hipStream_t st, int groups) {
+int pt_launch_mf_wtrans(const float* filt, float* wT, int F, int C, int K, hipStream_t st, int groups, float* clear2) {
     const int Cpad = ((C + MF_CK - 1) / MF_CK) * MF_CK, total = (Cpad >> 2) * 64 * MF_TP(K * K);
     hipLaunchKernelGGL(k_mf_wtrans, dim3((total + 255) / 256, groups), dim3(256), 0, st, filt, wT, F, C, K * K, Cpad,
-                       (long)F * C * K * K, (long)pt_mf_wt_floats(C, K));
+                       (long)F * C * K * K, (long)pt_mf_wt_floats(C, K), clear2);
     PT_CHECK_LAUNCH();
     return PT_OK;
 }

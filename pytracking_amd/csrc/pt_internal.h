@@ -63,7 +63,8 @@ int pt_launch_build_R(const PtPlan& p, const float* inp, float* R, hipStream_t s
 struct PtFast {
     int ok;
     int n, C, H, W, KH, KW, OH, OW, HW, KK, OO, Q;
-    int CX, NK, TF, rem, tiles, left, HWp, corr_threads, nh;   // corr2: grid KSC*n, waves = nh halves x tiles
+    int CX, NK, TF, rem, tiles, left, HWp, corr_threads, nh;   // corr2: grid KSC*n/spw, waves = spw samples x nh halves x tiles
+    int spw;                                                    // samples per k_corr2 workgroup (2: sample pairs, see pt_fast_plan)
     int KSC;                                                    // channel ranges = partial score maps per sample: 8 (one per XCD) or 16
     size_t corr_lds;
     int CB, bpx, NG, KSPL, gper, U, PH, PW, ns_max, E, zn; // adj2: grid CB*KSPL, 8 waves x U contiguous groups; zero block
@@ -99,7 +100,8 @@ size_t pt_mf_wt_floats(int C, int K);                                    // pre-
 __host__ __device__ inline long pt_mf_wt_index(int c, int f, int tap, int KK) {
     return ((long)(c >> 2) * 64 + (c & 3) * 16 + f) * (KK == 1 ? 1 : 12) + tap;
 }
-int pt_launch_mf_wtrans(const float* filt, float* wT, int F, int C, int K, hipStream_t st, int groups = 1);
+int pt_launch_mf_wtrans(const float* filt, float* wT, int F, int C, int K, hipStream_t st, int groups = 1,
+                        float* clear2 = nullptr);   // clear2: a second table of pt_mf_wt_floats zeroed by the same launch
 // out_stride_n / inp_stride_n: floats between consecutive samples of scores / inp (0 = dense F*H*W); lets a group of
 // <= 16 filters be a slice of a wider (n, Ftotal, H, W) tensor; groups > 1: `groups` consecutive banks of F filters in ONE
 // launch (grid.z) -- weight tables pt_mf_wt_floats apart, maps F*H*W apart inside a sample, adjoint partials
