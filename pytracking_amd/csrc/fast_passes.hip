@@ -203,14 +203,15 @@ __device__ __forceinline__ float corr2_filter_elem(const Corr2Args& a, int KK, i
 
 // FUSE = 0: filter operand read from `filt`.  FUSE = 8 / 16 / 32: operand = sum of <= FUSE gradient partials + reg*w
 // (optimizer.py:146-148), every load of the reduction issued before the first wait.
-// Two 10-wave workgroups per CU put up to 6 waves on one SIMD (3+3): <= 80 VGPRs for the common channel counts.
+// Two 10-wave workgroups per CU put up to 6 waves on one SIMD (3+3): <= 80 VGPRs for the k-half instantiations (NH == 2) of the
+// common channel counts; the one-wave-per-tile ones (NH == 1: large maps, sample pairs) run at most 4 waves per SIMD.
 // K16: the filter has 16 taps (4x4, the trackers' size) -- a compile-time fact, so that the prologue is ONE basic block: with
 // the tap count as a run-time branch the compiler started the partial sum inside the branch and put `s_waitcnt vmcnt(8)`
 // -- a whole memory round trip -- in front of the first feature load (round 3, profiles/r03g_pass_phase_stamps.txt).
 // NH: k-step halves per tile (2 for 18x18 maps, 1 for 22x22) -- compile time as well: as a run-time value every tap of the
 // shift-and-add became `ds_read; branch; ds_read; s_waitcnt lgkmcnt(0)`, 16 serialised LDS round trips (0.9 us of the pass).
 template <int NK, bool LEFT, int FUSE, bool K16, int NH>
-__global__ __launch_bounds__(1024, (NK <= 8 ? PT_C2_MINW : 4)) void k_corr2(const float* h_feat, long h_stride, const float* h_filt, const float* h_w, const float* h_src, int h_slot,
+__global__ __launch_bounds__(1024, (NK <= 8 && NH == 2 ? PT_C2_MINW : 4)) void k_corr2(const float* h_feat, long h_stride, const float* h_filt, const float* h_w, const float* h_src, int h_slot,
                                                                               unsigned h_dims, unsigned h_geo, Corr2Args a_arg) {
     // The h_* parameters repeat what the prologue needs to REQUEST its operands (13 dwords).  Scalar kernel parameters are
     // preloaded into SGPRs at wave launch (-amdgpu-kernarg-preload-count), the argument block `a` arrives by scalar loads about
@@ -414,11 +415,11 @@ __global__ __launch_bounds__(1024, (NK <= 8 ? PT_C2_MINW : 4)) void k_corr2(cons
     const float inv_ow = 1.0f / (float)a.OW;
     const int nsm = pair ? 2 : 1;                                   // samples whose tap planes this workgroup holds
     if (a.KH == 4 && a.KW == 4) {                                   // the trackers' filter size: fully unrolled
-        for (int o2 = threadIdx.x; o2 < nsm * OO; o2 += nthreads) {
-            const int s2 = o2 >= OO ? 1 : 0, o = o2 - s2 * OO;
-            const float* __restrict__ T0 = lds + nsl + (long)s2 * NH * KK * hHWp;
-            const float* __restrict__ T1 = T0 + (long)KK * hHWp;  // second k-step half (NH == 2)
-            const pt_gf out = a.spart + ((long)x * a.n + (pair ? 2 * i0 + s2 : i0)) * OO;
+      for (int s2 = 0; s2 < nsm; ++s2) {                            // uniform: one round of the block per sample of the pair
+        const float* __restrict__ T0 = lds + nsl + (long)s2 * NH * KK * hHWp;
+        const float* __restrict__ T1 = T0 + (long)KK * hHWp;      // second k-step half (NH == 2)
+        const pt_gf out = a.spart + ((long)x * a.n + (pair ? 2 * i0 + s2 : i0)) * OO;
+        for (int o = threadIdx.x; o < OO; o += nthreads) {
             const int y = fdiv(o, inv_ow), xx0 = o - y * a.OW;
             float tv[16];
 #pragma unroll
@@ -438,14 +439,16 @@ __global__ __launch_bounds__(1024, (NK <= 8 ? PT_C2_MINW : 4)) void k_corr2(cons
             for (int q = 0; q < 16; ++q) s += tv[q];
             out[o] = s;
         }
+      }
         PT_STAMP(a, 7);
         return;
     }
-    for (int o2 = threadIdx.x; o2 < nsm * OO; o2 += nthreads) {
-        const int s2 = o2 >= OO ? 1 : 0, o = o2 - s2 * OO;
-        const float* __restrict__ T0 = lds + nsl + (long)s2 * NH * KK * hHWp;
-        const float* __restrict__ T1 = T0 + (long)KK * hHWp;
-        const pt_gf out = a.spart + ((long)x * a.n + (pair ? 2 * i0 + s2 : i0)) * OO;
+    // other filter sizes
+    for (int s2 = 0; s2 < nsm; ++s2) {
+      const float* __restrict__ T0 = lds + nsl + (long)s2 * NH * KK * hHWp;
+      const float* __restrict__ T1 = T0 + (long)KK * hHWp;
+      const pt_gf out = a.spart + ((long)x * a.n + (pair ? 2 * i0 + s2 : i0)) * OO;
+      for (int o = threadIdx.x; o < OO; o += nthreads) {
         const int y = fdiv(o, inv_ow), xx0 = o - y * a.OW;
         float s = 0.f;
         for (int u = 0; u < a.KH; ++u) {
@@ -460,6 +463,7 @@ __global__ __launch_bounds__(1024, (NK <= 8 ? PT_C2_MINW : 4)) void k_corr2(cons
             }
         }
         out[o] = s;
+      }
     }
 }
 
