@@ -421,23 +421,22 @@ def main():
                     run_frames(st, pool, f, 1)
                     f += 1
 
-        if use_graph and warm_graph is not None:
-            warm_graph.replay()
-        else:
-            advance(0, Wm)
-        stream.synchronize()
-        # Clock warm-up, every rank: the two feature passes of the last solve re-issued back to back for ~10 ms
-        # (pt_track_frame_replay_pass_f32: idempotent, the sequence state does not move).  After the idle seconds of the
+        # Clock warm-up, every rank, in FRONT of the W warm-up frames: the two feature passes of the last solve re-issued back to back
+        # for ~10 ms (pt_track_frame_replay_pass_f32: idempotent, the sequence state does not move).  After the idle seconds of the
         # profiling children the first 2 ms burst ran 2-3 % slower than the following ones and settled over ~3 replays of a
-        # 20-frame graph (profiles/r04b_*, r04c_*: 112.1 -> 110.5 -> 109.1 us/frame; hipGraphUpload changed nothing, an
-        # untimed first launch of the executable recovered only a third) -- a frequency ramp, not a first-launch cost of the
-        # executable.  The same launches are the roofline leg's event-pair periods (last round trip kept).
+        # 20-frame graph (profiles/r04c_short_region_warmup.txt: 112.1 -> 110.5 -> 109.1 us/frame; hipGraphUpload changed
+        # nothing, an untimed first launch of the executable recovered a third).  The same launches are the roofline leg's
+        # event-pair periods (last round trip kept).  The W warm-up frames then run directly in front of the timed region.
         period = None
         try:
             for _ in range(3):
                 period = {"corr": event_period_us(st, stream, 0), "adj": event_period_us(st, stream, 1)}
         except RuntimeError:
             period = None                                      # configuration outside the fast path: no replay helper
+        if use_graph and warm_graph is not None:
+            warm_graph.replay()
+        else:
+            advance(0, Wm)
         stream.synchronize()
         if dist is not None:
             dist.barrier()
@@ -478,7 +477,7 @@ def main():
                                    "frac": round(gbs / HBM_PEAK_GBS, 4),
                                    "note": "2 feature reads per iteration x 5 iterations (SURVEY 8d) / measured frame time"}
         launch = (f"hipGraph replay, {G} frames per graph ({K // G} replay(s) in the timed region, {len(graphs)} start slot(s); "
-                  f"clock warm-up: ~10 ms of idempotent pass replays in front of the timed region)" if use_graph
+                  f"clock warm-up: ~10 ms of idempotent pass replays in front of the warm-up frames)" if use_graph
                   else "eager (18 launches per frame)")
         out = {
             "metric": "frames/sec DiMP-50 online track (288x288, 5 SD iters)" if cfg_name == "dimp50" else "frames/sec PrDiMP-50 online track (352x352, 5 SD iters)", "value": round(value, 2),
