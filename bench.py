@@ -383,9 +383,12 @@ def main():
 
     # ---- kernel-level legs first (rocprofv3 child process, then the event-pair periods of the two passes in this process):
     #      the frame timing that follows starts on a device that has just been busy, whatever --warmup says
-    want_roof = not args.no_roofline and rank == 0 and world == 1
-    stats, why = rocprof_kernel_stats(cfg_name, mode="graph") if want_roof else (None, "not requested")
-    stats_eager = rocprof_kernel_stats(cfg_name, frames=60, mode="eager")[0] if want_roof else None
+    want_roof = not args.no_roofline and rank == 0
+    # the profiling children only in a single-rank run (the other ranks of a multi-GPU job would idle at the barrier for ~25 s);
+    # a multi-rank line carries the roofline of rank 0 from the event-pair periods
+    prof = want_roof and world == 1
+    stats, why = rocprof_kernel_stats(cfg_name, mode="graph") if prof else (None, "multi-rank run: no profiling child" if want_roof else "not requested")
+    stats_eager = rocprof_kernel_stats(cfg_name, frames=60, mode="eager")[0] if prof else None
 
     # ---- frame launcher: hipGraphs of G consecutive frames starting at frame --warmup, G = the timed steps themselves when
     #      they fit one memory cycle, else their common divisor with the memory size (whole graph replays; a graph is valid

@@ -585,6 +585,46 @@ def test_bench_trajectory_closed_loop_60_frames():
     print("closed-loop worst errors over 60 frames:", worst)
 
 
+@pytest.mark.parametrize("n,C", [(34, 128), (64, 256), (35, 128), (40, 512)])
+def test_apply_filter_sample_pair_workgroups(n, C):
+    """Round 4: with more than 32 samples (even count) the XCD-aligned correlation runs two samples per workgroup
+    (csrc/fast_passes.hip: pt_fast_plan, spw = 2); an odd count keeps one.  Scores of every sample against the float64
+    oracle, and the adjoint of the same maps (unchanged kernel, same plan object) for good measure."""
+    from pytracking_amd import filter as F
+    rng = np.random.default_rng(4000 + n + C)
+    feat = synth.clf_features(rng, n, C, 18, 18, 4)
+    filt = (rng.standard_normal((C, 4, 4), dtype=np.float32) * np.float32(0.5 / np.sqrt(C * 16)))
+    s = F.apply_filter(T(feat), T(filt[None]))
+    want = O.apply_filter(feat.astype(np.float64), filt.astype(np.float64))
+    assert s.shape == (n, 1) + want.shape[1:]
+    close(s[:, 0], want, atol=2e-5)
+    r = rng.standard_normal(want.shape).astype(np.float32)
+    adj = F.apply_feat_transpose(T(feat), T(r)[:, None], (4, 4), training=False)
+    close(adj[0], O.apply_feat_transpose(feat.astype(np.float64), r.astype(np.float64), 4), atol=1e-4)
+
+
+@pytest.mark.parametrize("slot", [6, 7, 33])
+def test_track_frame_pair_workgroup_slot_parity(slot):
+    """The memory insert rides on the first correlation: the inserted sample may be the first or the second member of a
+    sample pair (even / odd slot), or the last sample.  n = 34, C = 128 runs pairs; against the float64 oracle composition."""
+    from pytracking_amd import bench_frame
+    from oracle import frame_port
+    cfg = dict(synth.DIMP50, C=128)
+    n = 34
+    st = bench_frame.TrackState(cfg, n, seed=91, device=DEV)
+    rng = np.random.default_rng(92 + slot)
+    x = synth.clf_features(rng, 1, cfg["C"], cfg["H"], cfg["W"], cfg["K"])
+    mem0, bb0, w0 = st.mem_feat.cpu().numpy().copy(), st.mem_bb.cpu().numpy().copy(), st.filter.cpu().numpy().copy()
+    st.step(T(x)[0], slot=slot, num_iter=3)
+    torch.cuda.synchronize()
+    ref = frame_port.oracle_step(cfg, mem0, bb0, st.sample_weight.cpu().numpy(), w0, x[0], slot=slot, num_iter=3)
+    close(st.scores, ref["scores"], atol=2e-5)
+    assert tuple(st.peak.cpu().numpy().astype(int)) == tuple(ref["peak"])
+    close(st.mem_feat, ref["mem"], atol=0)
+    close(st.mem_bb, ref["bb"], atol=1e-4)
+    close(st.filter, ref["filter"], atol=2e-5)
+
+
 @pytest.mark.parametrize("C,n", [(32, 5), (128, 6), (512, 7)])
 def test_track_frame_prdimp_matches_oracle_composition(C, n):
     """`pt_track_frame_f32(PT_SD_PRDIMP)` -- classification read off the solve's first correlation, first arg-max, box
