@@ -344,6 +344,12 @@ def main():
         os.execv(sys.executable, cmd)
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    # stdout carries ONE JSON line and nothing else: everything any library writes to descriptor 1 from here on (RCCL prints a
+    # version banner there from its C runtime, flushed at exit -- i.e. BEHIND the line) goes to stderr; the line itself is written
+    # to the saved descriptor
+    sys.stdout.flush()
+    json_fd = os.dup(1)
+    os.dup2(2, 1)
     torch.cuda.set_device(local_rank)
     dev = torch.device("cuda", local_rank)
     dist = None
@@ -448,9 +454,9 @@ def main():
         advance(Wm, K)
         stream.synchronize()
         torch.cuda.synchronize()
+        elapsed = time.perf_counter() - t0                     # this rank's K frames; the job's time is the MAX over ranks (gather below)
         if dist is not None:
-            dist.barrier()
-        elapsed = time.perf_counter() - t0
+            dist.barrier()                                     # closing barrier of the bracket: not part of anybody's K frames
 
         # the same K-step region again (state keeps advancing; same graphs): where the reported value sits in this box's spread
         repeats = []
@@ -527,7 +533,8 @@ def main():
                     out["end_to_end"] = workloads.end_to_end(dev)
                 except Exception as exc:                         # noqa: BLE001
                     out["end_to_end"] = {"error": f"{type(exc).__name__}: {exc}"[:300]}
-        print(json.dumps(out), flush=True)
+        sys.stdout.flush()
+        os.write(json_fd, (json.dumps(out) + "\n").encode())      # the one line on the real stdout
     if dist is not None:
         dist.barrier()
         dist.destroy_process_group()
