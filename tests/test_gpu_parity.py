@@ -155,6 +155,29 @@ def test_dimp_sd_golden_baseline_size(name):
     assert np.all(np.diff(losses.cpu().numpy()) < 0)                      # monotone decrease
 
 
+def test_dimp_sd_wide_adjoint_plan_22x22():
+    """Round 4: 22x22 maps with n = 50 samples run the adjoint as EIGHT position slices of 24 groups per wave
+    (k_adj2<V, 9, 24>; the PrDiMP goldens cover V = PrDiMP).  The same plan for the DiMP residual (V = relu) and the plain
+    adjoint, against the float64 oracle: 128 channels keep the oracle in seconds."""
+    from pytracking_amd import filter as F
+    cfg = dict(synth.DIMP50, C=128, H=22, W=22)
+    w0, feat, bb, sw = synth.dimp_problem(8122, 50, cfg)
+    its, losses = _run(_dimp_module(cfg), w0, feat, bb, sw, 2)
+    f64 = lambda a: np.asarray(a, np.float64)
+    want, wl = O.dimp_sd(f64(w0), f64(feat), f64(bb), f64(sw), num_iter=2, step_length=cfg["init_step_length"],
+                         filter_reg=cfg["init_filter_reg"], min_filter_reg=cfg["min_filter_reg"], feat_stride=cfg["feat_stride"],
+                         label_w=synth.gauss_lut(cfg["num_dist_bins"], cfg["bin_displacement"], cfg["init_gauss_sigma"]),
+                         mask_w=synth.mask_lut(cfg["num_dist_bins"], cfg["bin_displacement"], cfg["mask_init_factor"]),
+                         spatial_w=np.ones(cfg["num_dist_bins"], np.float32), bin_displacement=cfg["bin_displacement"],
+                         alpha_eps=cfg["alpha_eps"])
+    close(its, want, atol=2e-5)
+    close(losses, np.array(wl), atol=2e-5, rtol=1e-4)
+    rng = np.random.default_rng(8123)
+    r = rng.standard_normal((50, 23, 23)).astype(np.float32)
+    adj = F.apply_feat_transpose(T(feat), T(r)[:, None], (4, 4), training=False)
+    close(adj[0], O.apply_feat_transpose(f64(feat), f64(r), 4), atol=1e-4)
+
+
 def test_dimp_l2_golden():
     from pytracking_amd import optimizer
     g = load_golden("dimp_l2_small")
