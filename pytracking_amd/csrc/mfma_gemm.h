@@ -17,6 +17,7 @@ constexpr unsigned OOB = 0xFFFFFFF0u;      // raw buffer loads past num_records 
 // ------------------------------------------------------------------------------------------------------------------
 // generic NT GEMM on MFMA
 // ------------------------------------------------------------------------------------------------------------------
+#define GEMM_GN_MAX_SLICES 256
 struct GemmArgs {
     const float* A; long lda; unsigned a_bytes;
     const float* Wt; unsigned w_bytes;          // (N, K) row-major
@@ -27,6 +28,10 @@ struct GemmArgs {
     int relu, expo, nchw;                       // nchw: C[((r / HW) * N + n) * HW + r % HW]
     const float* pos; unsigned pos_bytes; int pos_cols, L, HW;   // A[r][k] + pos[(r % L) % HW][k] for column tiles < pos_cols
     int H, Wd, Cin;                             // MODE 1: 3x3 zero-padded gather, K = 9 * Cin, weights (N, tap, Cin)
+    // MODE 1, optional: the gathered operand is relu(GroupNorm(1, Cin)(A)) of the PREVIOUS layer's raw sums, normalised on its way
+    // into LDS -- A holds the un-normalised activations, gn_stats the per-slice (sum, sum of squares) pairs of k_gn_reduce
+    // (gn_slices <= GEMM_GN_MAX_SLICES per image of gn_count values), gn_gam / gn_bet the affine parameters.  Zero padding stays zero.
+    const float* gn_stats; int gn_slices, gn_count; const float* gn_gam; const float* gn_bet;
     int swizzle;                                // XCD-aware workgroup -> tile map (grid.y rounded up to a multiple of 8)
     int ksteps; long c_zstride;                 // split-K: blockIdx.z owns K-steps [z*ksteps, (z+1)*ksteps) and writes its
                                                 // partial product to C + z*c_zstride (bias on z = 0 only); 0 = no split
@@ -144,13 +149,40 @@ __device__ __forceinline__ void gemm_tile(const GemmArgs& g, const int bxi, cons
     }
     const int m0 = by * BM, n0 = bx * BN;
     const int lrow = tid / (BK / 4), lc4 = (tid % (BK / 4)) * 4;   // loader: BK/4 threads cover one row segment of BK floats
+    // fused GroupNorm + ReLU on the gathered operand (MODE 1): mean / rstd of the <= 2 images this tile's rows belong to, from the
+    // slice statistics, summed in double in slice order by ONE thread per image -- the arithmetic of the stand-alone k_gn_apply
+    const bool gn = MODE == 1 && g.gn_stats != nullptr;
+    __shared__ float gn_st[MODE == 1 ? 2 * 2 * GEMM_GN_MAX_SLICES : 1];
+    __shared__ float gn_mr[4];
+    const int img_lo = MODE == 1 ? m0 / g.HW : 0;
+    float gmean[2] = {0.f, 0.f}, grstd[2] = {1.f, 1.f};
+    if (gn) {
+        const int nimg = g.M / g.HW;
+        for (int e = tid; e < 2 * 2 * g.gn_slices; e += 256) {
+            const int im = e / (2 * g.gn_slices), k = e - im * 2 * g.gn_slices;
+            gn_st[e] = g.gn_stats[(long)min(img_lo + im, nimg - 1) * 2 * g.gn_slices + k];
+        }
+        __syncthreads();
+        if (tid < 2) {
+            double sd = 0.0, qd = 0.0;
+            for (int k = 0; k < g.gn_slices; ++k) {
+                sd += (double)gn_st[(tid * g.gn_slices + k) * 2];
+                qd += (double)gn_st[(tid * g.gn_slices + k) * 2 + 1];
+            }
+            const double mean_d = sd / g.gn_count;
+            gn_mr[2 * tid] = (float)mean_d;
+            gn_mr[2 * tid + 1] = (float)(1.0 / sqrt(fmax(qd / g.gn_count - mean_d * mean_d, 0.0) + 1e-5));
+        }
+        __syncthreads();
+        gmean[0] = gn_mr[0]; grstd[0] = gn_mr[1]; gmean[1] = gn_mr[2]; grstd[1] = gn_mr[3];
+    }
     const long zb = g.batch ? (long)bzi : 0;
     const __amdgpu_buffer_rsrc_t rsA = pt_rsrc(g.A + zb * g.a_zstride, g.a_bytes), rsW = pt_rsrc(g.Wt + zb * g.w_zstride, g.w_bytes);
     const bool addpos = MODE == 0 && g.pos != nullptr && n0 < g.pos_cols;
     const __amdgpu_buffer_rsrc_t rsP = pt_rsrc(addpos ? g.pos : g.A, addpos ? g.pos_bytes : 16u);
 
     unsigned aoff[AL], poff[AL], woff[BL];
-    int py[AL], px[AL];
+    int py[AL], px[AL], rimg[AL];
 #pragma unroll
     for (int i = 0; i < AL; ++i) {
         const int row = m0 + lrow + RP * i;
@@ -158,8 +190,10 @@ __device__ __forceinline__ void gemm_tile(const GemmArgs& g, const int bxi, cons
         if (MODE == 0) {
             aoff[i] = ok ? (unsigned)(((long)row * g.lda + lc4) * 4) : OOB;
             poff[i] = (addpos && ok) ? (unsigned)(((long)((row % g.L) % g.HW) * g.K + lc4) * 4) : OOB;
+            rimg[i] = 0;
         } else {
             const int img = row / g.HW, p = row - img * g.HW;
+            rimg[i] = min(max(img - img_lo, 0), 1);
             py[i] = ok ? p / g.Wd : -4;                                  // -4: every tap falls outside the map
             px[i] = p - (p / g.Wd) * g.Wd;
             aoff[i] = (unsigned)(((long)img * g.HW * g.lda + lc4) * 4);
@@ -177,6 +211,8 @@ __device__ __forceinline__ void gemm_tile(const GemmArgs& g, const int bxi, cons
     // bookkeeping stays exact -- a fetch inside a branch makes it wait for ALL outstanding loads before the LDS store.
     constexpr int PD = 2;
     f32x4 ra[PD][AL], rp[PD][AL], rb[PD][BL];
+    f32x4 rgam[PD], rbet[PD];                                           // fused GroupNorm: gamma / beta of the slot's 4 channels
+    unsigned inm[PD] = {0u, 0u};                                        //                  which of its rows lie inside the map
     // Addressing without VALU work per load (the vector instructions of a K-step are issue time taken from the MFMAs:
     // experiments/mfma_issue.hip): the row part of an address is a loop-invariant VGPR (out-of-range for rows outside
     // the matrix), the K-step part goes into the scalar offset of the buffer instruction.  A step past the end re-fetches
@@ -205,11 +241,18 @@ __device__ __forceinline__ void gemm_tile(const GemmArgs& g, const int bxi, cons
         } else {
             const int k0 = kc * BK, tap = k0 / g.Cin, c0 = k0 - tap * g.Cin;
             const int dy = tap / 3 - 1, dx = tap - (tap / 3) * 3 - 1;
+            unsigned m = 0u;
 #pragma unroll
             for (int i = 0; i < AL; ++i) {
                 const int y = py[i] + dy, x = px[i] + dx;
                 const bool in = y >= 0 && y < g.H && x >= 0 && x < g.Wd;
+                m |= in ? (1u << i) : 0u;
                 ra[sl][i] = pt_bload4(rsA, in ? aoff[i] + (unsigned)(((long)(y * g.Wd + x) * g.lda + c0) * 4) : OOB);
+            }
+            inm[sl] = m;
+            if (gn) {                                                    // uniform
+                rgam[sl] = *reinterpret_cast<const f32x4*>(g.gn_gam + c0 + lc4);
+                rbet[sl] = *reinterpret_cast<const f32x4*>(g.gn_bet + c0 + lc4);
             }
         }
 #pragma unroll
@@ -221,6 +264,12 @@ __device__ __forceinline__ void gemm_tile(const GemmArgs& g, const int bxi, cons
         for (int i = 0; i < AL; ++i) {
             f32x4 v = ra[sl][i];
             if (addpos) v += rp[sl][i];
+            if (gn) {                                                    // uniform; the expression of k_gn_apply, padding stays 0
+                const float mu = gmean[rimg[i]], rs = grstd[rimg[i]];
+                const bool in = ((inm[sl] >> i) & 1u) != 0u;
+#pragma unroll
+                for (int e = 0; e < 4; ++e) v[e] = in ? fmaxf((v[e] - mu) * rs * rgam[sl][e] + rbet[sl][e], 0.f) : 0.f;
+            }
             *reinterpret_cast<f32x4*>(&As[buf][(lrow + RP * i) * LS + lc4]) = v;
         }
 #pragma unroll

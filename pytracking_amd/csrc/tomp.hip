@@ -1377,19 +1377,33 @@ extern "C" int pt_tomp_bbreg_f32(const float* params, const float* feat, const f
     // each 3x3 convolution = 9 per-tap partial GEMMs (one K-slice of Cin per tap) reduced by the GroupNorm statistics pass
     float *src = base + cv.T0, *dst = base + cv.T1;
     const long zs = (long)M * D;
+    // Round 4: GroupNorm + ReLU of layer i are applied by layer i + 1's loader (mfma_gemm.h: gn_*): the tower is conv -> reduce per
+    // layer, the activations between two layers exist only as raw sums + slice statistics (k_gn_apply stays for shapes the fused
+    // loader does not take: more than GEMM_GN_MAX_SLICES slices per image, maps smaller than a 32-row tile)
+    const bool fuse_gn = cv.slices <= GEMM_GN_MAX_SLICES && HW >= 32 && ((uintptr_t)(params + ro.gg[0]) % 16) == 0 &&
+                         ((uintptr_t)(params + ro.gb[0]) % 16) == 0 && (D % 4) == 0;
+    auto with_gn = [&](GemmArgs& g, int prev) {
+        if (!fuse_gn || prev < 0) return;
+        g.gn_stats = stats; g.gn_slices = cv.slices; g.gn_count = HW * D;
+        g.gn_gam = params + ro.gg[prev]; g.gn_bet = params + ro.gb[prev];
+    };
     for (int i = 0; i < 4; ++i) {
         GemmArgs g = gemm_args(src, D, M, params + ro.cw[i], M, D, 9 * D, params + ro.cb[i], part, D);
         g.H = H; g.Wd = W; g.Cin = D; g.HW = HW; g.ksteps = D / 64; g.c_zstride = zs;
+        with_gn(g, i - 1);
         if ((rc = launch_gemm(g, st, true))) return rc;
         hipLaunchKernelGGL(k_gn_reduce, dim3(cv.slices, n), dim3(256), 0, st, part, 9, zs, dst, stats, HW * D);
         PT_CHECK_LAUNCH();
-        hipLaunchKernelGGL(k_gn_apply, dim3(cv.slices, n), dim3(256), 0, st, dst, stats, params + ro.gg[i],
-                           params + ro.gb[i], D, HW * D);
-        PT_CHECK_LAUNCH();
+        if (!fuse_gn) {
+            hipLaunchKernelGGL(k_gn_apply, dim3(cv.slices, n), dim3(256), 0, st, dst, stats, params + ro.gg[i],
+                               params + ro.gb[i], D, HW * D);
+            PT_CHECK_LAUNCH();
+        }
         std::swap(src, dst);
     }
     GemmArgs g = gemm_args(src, D, M, params + ro.fw, M, 4, 9 * D, params + ro.fb, part, 4);
     g.H = H; g.Wd = W; g.Cin = D; g.HW = HW; g.ksteps = D / 64; g.c_zstride = (long)M * 4;
+    with_gn(g, 3);
     if ((rc = launch_gemm(g, st, true))) return rc;
     hipLaunchKernelGGL(k_reg_finish, dim3((M * 4 + 255) / 256), dim3(256), 0, st, part, 9, (long)M * 4, ltrb, M, HW);
     PT_CHECK_LAUNCH();
