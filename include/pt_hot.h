@@ -204,7 +204,9 @@ typedef struct pt_tomp_dims {
 size_t pt_tomp_param_floats(const pt_tomp_dims* dims);
 /* Weight-only products of the decoder, folded once per weight update into a second caller-owned buffer of
  * pt_tomp_prepared_floats() floats (one query token per batch row makes self-attention, the query/key product and
- * value + out_proj plain matrix-vector products: W_o W_v, W_k,h^T W_q,h / sqrt(d_h), W_o[:,h] W_v,h and their biases). */
+ * value + out_proj plain matrix-vector products: W_o W_v, W_k,h^T W_q,h / sqrt(d_h), W_o[:,h] W_v,h and their biases; the
+ * decoder starts from zeros, so the first layer's state after self-attention and its folded query are constants of the
+ * weights and are stored here as well). */
 size_t pt_tomp_prepared_floats(const pt_tomp_dims* dims);
 int pt_tomp_prepare_f32(const pt_tomp_dims* dims, const float* params, float* prepared, void* stream);
 int pt_tomp_posenc_f32(float* pos, int H, int W, int d_model, int max_res, void* stream);

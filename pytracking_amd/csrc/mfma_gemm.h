@@ -150,32 +150,12 @@ __device__ __forceinline__ void gemm_tile(const GemmArgs& g, const int bxi, cons
     const int m0 = by * BM, n0 = bx * BN;
     const int lrow = tid / (BK / 4), lc4 = (tid % (BK / 4)) * 4;   // loader: BK/4 threads cover one row segment of BK floats
     // fused GroupNorm + ReLU on the gathered operand (MODE 1): mean / rstd of the <= 2 images this tile's rows belong to, from the
-    // slice statistics, summed in double in slice order by ONE thread per image -- the arithmetic of the stand-alone k_gn_apply
+    // slice statistics (double precision, as the stand-alone k_gn_apply; tree order instead of its serial order)
     const bool gn = MODE == 1 && g.gn_stats != nullptr;
-    __shared__ float gn_st[MODE == 1 ? 2 * 2 * GEMM_GN_MAX_SLICES : 1];
+    __shared__ double gn_red[MODE == 1 ? 8 : 1];
     __shared__ float gn_mr[4];
     const int img_lo = MODE == 1 ? m0 / g.HW : 0;
     float gmean[2] = {0.f, 0.f}, grstd[2] = {1.f, 1.f};
-    if (gn) {
-        const int nimg = g.M / g.HW;
-        for (int e = tid; e < 2 * 2 * g.gn_slices; e += 256) {
-            const int im = e / (2 * g.gn_slices), k = e - im * 2 * g.gn_slices;
-            gn_st[e] = g.gn_stats[(long)min(img_lo + im, nimg - 1) * 2 * g.gn_slices + k];
-        }
-        __syncthreads();
-        if (tid < 2) {
-            double sd = 0.0, qd = 0.0;
-            for (int k = 0; k < g.gn_slices; ++k) {
-                sd += (double)gn_st[(tid * g.gn_slices + k) * 2];
-                qd += (double)gn_st[(tid * g.gn_slices + k) * 2 + 1];
-            }
-            const double mean_d = sd / g.gn_count;
-            gn_mr[2 * tid] = (float)mean_d;
-            gn_mr[2 * tid + 1] = (float)(1.0 / sqrt(fmax(qd / g.gn_count - mean_d * mean_d, 0.0) + 1e-5));
-        }
-        __syncthreads();
-        gmean[0] = gn_mr[0]; grstd[0] = gn_mr[1]; gmean[1] = gn_mr[2]; grstd[1] = gn_mr[3];
-    }
     const long zb = g.batch ? (long)bzi : 0;
     const __amdgpu_buffer_rsrc_t rsA = pt_rsrc(g.A + zb * g.a_zstride, g.a_bytes), rsW = pt_rsrc(g.Wt + zb * g.w_zstride, g.w_bytes);
     const bool addpos = MODE == 0 && g.pos != nullptr && n0 < g.pos_cols;
@@ -298,6 +278,30 @@ __device__ __forceinline__ void gemm_tile(const GemmArgs& g, const int bxi, cons
     const int nk = g.ksteps ? min(nkt, kb0 + g.ksteps * KSU) : nkt;
 #pragma unroll
     for (int sl = 0; sl < PD; ++sl) fetch(kb0 + sl, sl, kb0 + sl < nk);
+    // (the statistics are only needed by the first LDS store: their round trip runs under the first operand loads)
+    if (gn) {
+        // one slice per thread (gn_slices <= 256 = the block), double-precision wave + block reduction: a serial sum by one
+        // thread (the order of k_gn_apply) cost 3.5 us in front of every tile's first load (profiles/r04s_*)
+        const int nimg = g.M / g.HW;
+        const int img_hi = min((min(m0 + BM, g.M) - 1) / g.HW, nimg - 1);
+        for (int im = 0; im <= img_hi - img_lo && im < 2; ++im) {                       // uniform; one image unless the tile straddles two
+            const float* st = g.gn_stats + (long)(img_lo + im) * 2 * g.gn_slices;
+            double sd = tid < g.gn_slices ? (double)st[2 * tid] : 0.0, qd = tid < g.gn_slices ? (double)st[2 * tid + 1] : 0.0;
+#pragma unroll
+            for (int off = 32; off > 0; off >>= 1) { sd += __shfl_xor(sd, off, 64); qd += __shfl_xor(qd, off, 64); }
+            if (lane == 0) { gn_red[2 * wave] = sd; gn_red[2 * wave + 1] = qd; }
+            __syncthreads();
+            if (tid == 0) {
+                const double s4 = (gn_red[0] + gn_red[2]) + (gn_red[4] + gn_red[6]), q4 = (gn_red[1] + gn_red[3]) + (gn_red[5] + gn_red[7]);
+                const double mean_d = s4 / g.gn_count;
+                gn_mr[2 * im] = (float)mean_d;
+                gn_mr[2 * im + 1] = (float)(1.0 / sqrt(fmax(q4 / g.gn_count - mean_d * mean_d, 0.0) + 1e-5));
+            }
+            __syncthreads();
+        }
+        gmean[0] = gn_mr[0]; grstd[0] = gn_mr[1];
+        if (img_hi > img_lo) { gmean[1] = gn_mr[2]; grstd[1] = gn_mr[3]; }
+    }
     stash(0, 0);
     __syncthreads();
     for (int t0 = kb0; t0 < nk; t0 += PD) {

@@ -238,7 +238,7 @@ __global__ __launch_bounds__(512) void k_attn(AttnArgs a) {
 template <int PER>
 __global__ __launch_bounds__(256) void k_ln_rows_t(const float* in, float* out, const float* __restrict__ gam,
                                                    const float* __restrict__ bet, int rows, const float* in2 = nullptr,
-                                                   const float* in3 = nullptr) {
+                                                   const float* in3 = nullptr, const float* gam2 = nullptr, const float* bet2 = nullptr) {
     constexpr int D = 64 * PER;
     const int row = blockIdx.x * 4 + (threadIdx.x >> 6), lane = threadIdx.x & 63;
     if (row >= rows) return;
@@ -269,6 +269,19 @@ __global__ __launch_bounds__(256) void k_ln_rows_t(const float* in, float* out, 
     for (int i = 0; i < PER; ++i) q += (v[i] - mean) * (v[i] - mean);
     const float rstd = rsqrtf(wave_sum(q) / D + 1e-5f);
     float* dst = out + (long)row * D + lane * PER;
+    if (gam2) {                                                     // uniform: a second LayerNorm on the result (the decoder's norm3 + final norm)
+        float o[PER], s2 = 0.f;
+#pragma unroll
+        for (int i = 0; i < PER; ++i) { o[i] = (v[i] - mean) * rstd * g[i] + b[i]; s2 += o[i]; }
+        const float mean2 = wave_sum(s2) / D;
+        float q2 = 0.f;
+#pragma unroll
+        for (int i = 0; i < PER; ++i) q2 += (o[i] - mean2) * (o[i] - mean2);
+        const float rstd2 = rsqrtf(wave_sum(q2) / D + 1e-5f);
+#pragma unroll
+        for (int i = 0; i < PER; ++i) dst[i] = (o[i] - mean2) * rstd2 * gam2[lane * PER + i] + bet2[lane * PER + i];
+        return;
+    }
     if (PER == 4) {
         f32x4 o;
 #pragma unroll
@@ -315,11 +328,12 @@ static bool ln_rows_wide_ok(const float* in, const float* out, const float* gam,
 }
 
 static void launch_ln_rows(const float* in, float* out, const float* gam, const float* bet, int rows, int D, hipStream_t st,
-                           const float* in2 = nullptr, const float* in3 = nullptr) {
+                           const float* in2 = nullptr, const float* in3 = nullptr, const float* gam2 = nullptr,
+                           const float* bet2 = nullptr) {
     const dim3 grid((rows + 3) / 4), block(256);
     const bool al = ((uintptr_t)in % 16 == 0) && ((uintptr_t)out % 16 == 0) && ((uintptr_t)gam % 16 == 0) && ((uintptr_t)bet % 16 == 0) &&
                     ((uintptr_t)in2 % 16 == 0) && ((uintptr_t)in3 % 16 == 0);
-    if (D == 256 && al) hipLaunchKernelGGL(k_ln_rows_t<4>, grid, block, 0, st, in, out, gam, bet, rows, in2, in3);
+    if (D == 256 && al) hipLaunchKernelGGL(k_ln_rows_t<4>, grid, block, 0, st, in, out, gam, bet, rows, in2, in3, gam2, bet2);
     else if (D == 128) hipLaunchKernelGGL(k_ln_rows_t<2>, grid, block, 0, st, in, out, gam, bet, rows);
     else if (D == 64) hipLaunchKernelGGL(k_ln_rows_t<1>, grid, block, 0, st, in, out, gam, bet, rows);
     else hipLaunchKernelGGL(k_ln_rows, grid, block, 0, st, in, out, gam, bet, rows, D);
@@ -333,6 +347,10 @@ struct TokArgs {
     float* X;
     int nf, ns, dup, D, HW, L;
     float* zero; int nzero;         // a buffer this launch clears on the side (the decoder's initial state: no memset node per frame)
+    // two more side jobs (round 4): `rep` copies of cp_src[k] (cp_n[k] floats) into cp_dst[k] -- the first decoder layer's state
+    // after self-attention and its folded query do not depend on the frame (the decoder starts from zeros) and come from the
+    // prepared buffer instead of two GEMV launches
+    const float* cp_src[2]; float* cp_dst[2]; int cp_n[2]; int rep;
 };
 
 // NCHW feature maps -> token-major rows, + fg_token * label (memory frames) or + test_token (test frame)
@@ -342,6 +360,10 @@ __global__ __launch_bounds__(256) void k_tomp_tokens(TokArgs a) {
     const int p0 = blockIdx.x * 32, c0 = blockIdx.y * 32;
     if (blockIdx.x == 0 && blockIdx.y == 0 && blockIdx.z == 0)
         for (int i = threadIdx.x; i < a.nzero; i += 256) a.zero[i] = 0.f;
+    if (blockIdx.z == 0 && blockIdx.y >= 1 && blockIdx.y <= 2 && a.cp_src[blockIdx.y - 1]) {     // spread over the blocks of row y
+        const int k = blockIdx.y - 1, n = a.cp_n[k];
+        for (int i = blockIdx.x * 256 + threadIdx.x; i < n * a.rep; i += gridDim.x * 256) a.cp_dst[k][i] = a.cp_src[k][i % n];
+    }
     const int B = a.dup ? 2 : a.ns;
     const int fr = blockIdx.z / B, b = blockIdx.z - fr * B, s = a.dup ? 0 : b;
     const bool train = fr < a.nf;
@@ -1055,7 +1077,7 @@ PackOff pack_layout(int D, int ff, int n_enc, int n_dec) {
 }
 
 struct PrepOff { size_t wsa, bsa, mq, cq, wov, bov; };
-struct PrepLayout { PrepOff dec[16]; size_t total; };
+struct PrepLayout { PrepOff dec[16]; size_t qk0; size_t total; };   // qk0: the first decoder layer's folded query (below), (nhead, D)
 PrepLayout prep_layout(int D, int nhead, int n_dec) {
     PrepLayout o{};
     size_t c = 0;
@@ -1065,6 +1087,7 @@ PrepLayout prep_layout(int D, int nhead, int n_dec) {
         p.wsa = take((size_t)D * D); p.bsa = take(D); p.mq = take((size_t)nhead * D * D); p.cq = take((size_t)nhead * D);
         p.wov = take((size_t)D * nhead * D); p.bov = take(D);
     }
+    o.qk0 = take((size_t)nhead * D);
     o.total = c;
     return o;
 }
@@ -1170,6 +1193,18 @@ extern "C" int pt_tomp_prepare_f32(const pt_tomp_dims* d, const float* params, f
                            prepared + pp.wov, prepared + pp.bov, D, NH);
         PT_CHECK_LAUNCH();
     }
+    if (d->n_dec > 0) {
+        // The decoder starts from zeros (transformer.py:224-238), so layer 0's self-attention output is its folded bias,
+        // Pa = (Wo bv + bo), and its folded query Mq (LN1(Pa) + query_pos) + cq is a constant of the weights: one GEMV here
+        // instead of two per frame (the same kernel, one row -> bit-identical to what the per-frame launches produced)
+        const DecOff& dc = po.dec[0];
+        const PrepOff& pp = pl.dec[0];
+        GemvArgs v{};
+        v.Wt = prepared + pp.mq; v.bias = prepared + pp.cq; v.N = NH * D; v.K = D; v.x = prepared + pp.bsa; v.xg = params + dc.n1g;
+        v.xb = params + dc.n1b; v.xadd = params + po.fg; v.B = 1; v.out = prepared + pl.qk0;
+        const int rc2 = launch_gemv(v, st);
+        if (rc2) return rc2;
+    }
     return PT_OK;
 }
 
@@ -1196,10 +1231,18 @@ extern "C" int pt_tomp_predict_f32(const pt_tomp_dims* d, const float* params, c
     const float* P = params;
     float *X = base + cv.X, *QKV = base + cv.QKV, *AO = base + cv.AO, *Y = base + cv.Y, *Hd = base + cv.Hd;
 
+    bool dec0_const = false;                                       // decoder layer 0's first two GEMVs replaced by prepared constants
     // ---- tokens (filter_predictor.py:113-128)
     {
         TokArgs t{train_feat, test_feat, train_label, P + po.fg, P + po.testtok, X, n_train, n_seq, parallel ? 1 : 0, D,
-                  HW, L, base + cv.zero, B * D};
+                  HW, L, base + cv.zero, B * D, {nullptr, nullptr}, {nullptr, nullptr}, {0, 0}, B};
+        static const bool dec0_off = [] { const char* e = getenv("PT_TOMP_DEC0"); return e && e[0] == '0'; }();   // A/B knob
+        if (d->n_dec > 0 && (D + 31) / 32 >= 3 && !dec0_off) {    // layer 0 of the decoder: state after self-attention, folded query
+            const PrepLayout pl0 = prep_layout(D, NH, d->n_dec);
+            t.cp_src[0] = prepared + pl0.dec[0].bsa; t.cp_dst[0] = base + cv.P1; t.cp_n[0] = D;
+            t.cp_src[1] = prepared + pl0.qk0; t.cp_dst[1] = base + cv.qk; t.cp_n[1] = NH * D;
+        }
+        dec0_const = t.cp_src[0] != nullptr;
         hipLaunchKernelGGL(k_tomp_tokens, dim3((HW + 31) / 32, (D + 31) / 32, (n_train + 1) * B), dim3(256), 0, st, t);
         PT_CHECK_LAUNCH();
         BoxArgs bx{train_ltrb, P + po.bw1, P + po.bb1, P + po.bn1, P + po.bn2, base + cv.E1, base + cv.bnsc,
@@ -1273,12 +1316,12 @@ extern "C" int pt_tomp_predict_f32(const pt_tomp_dims* d, const float* params, c
         // self-attention over one token (softmax of a single key is 1), folded: Pa = t + (Wo Wv) t + (Wo bv + bo)
         v.Wt = prepared + pp.wsa; v.bias = prepared + pp.bsa; v.N = D; v.K = D; v.x = tpre; v.xg = tg; v.xb = tb;
         v.res = tpre; v.rg = tg; v.rb = tb; v.B = B; v.out = Pa;
-        if ((rc = launch_gemv(v, st))) return rc;
+        if (!(i == 0 && dec0_const) && (rc = launch_gemv(v, st))) return rc;        // layer 0: written by k_tomp_tokens
         // cross-attention query folded onto the keys: qk[b][h] = Wk_h^T (Wq_h (LN1(Pa) + query_pos) + bq_h) / sqrt(HD)
         v = GemvArgs{};
         v.Wt = prepared + pp.mq; v.bias = prepared + pp.cq; v.N = NH * D; v.K = D; v.x = Pa; v.xg = P + dc.n1g;
         v.xb = P + dc.n1b; v.xadd = qpos; v.B = B; v.out = base + cv.qk;     // one query_pos row for all batch rows
-        if ((rc = launch_gemv(v, st))) return rc;
+        if (!(i == 0 && dec0_const) && (rc = launch_gemv(v, st))) return rc;
         hipLaunchKernelGGL(k_dec_scores, dim3((L + 15) / 16, B), dim3(64), 0, st, da);
         PT_CHECK_LAUNCH();
         hipLaunchKernelGGL(k_dec_ctx, dim3(D / 16, B), dim3(1024),
@@ -1301,13 +1344,18 @@ extern "C" int pt_tomp_predict_f32(const pt_tomp_dims* d, const float* params, c
         tpre = Pc; tg = P + dc.n3g; tb = P + dc.n3b;
     }
     // norm3 of the last layer, then the decoder's final norm (transformer.py:141-142)
-    if (d->n_dec > 0) {
-        launch_ln_rows(tpre, base + cv.a, tg, tb, B, D, st);
+    if (d->n_dec > 0 && ln_rows_wide_ok(tpre, filters, tg, tb, D)) {
+        launch_ln_rows(tpre, filters, tg, tb, B, D, st, nullptr, nullptr, P + po.dng, P + po.dnb);   // both norms, one launch
         PT_CHECK_LAUNCH();
-        tpre = base + cv.a;
+    } else {
+        if (d->n_dec > 0) {
+            launch_ln_rows(tpre, base + cv.a, tg, tb, B, D, st);
+            PT_CHECK_LAUNCH();
+            tpre = base + cv.a;
+        }
+        launch_ln_rows(tpre, filters, P + po.dng, P + po.dnb, B, D, st);
+        PT_CHECK_LAUNCH();
     }
-    launch_ln_rows(tpre, filters, P + po.dng, P + po.dnb, B, D, st);
-    PT_CHECK_LAUNCH();
     hipLaunchKernelGGL(k_tokens_to_nchw, dim3((HW + 31) / 32, (D + 31) / 32, B), dim3(256), 0, st, X, enc_feat, B, L, D,
                        HW, Ltr);
     PT_CHECK_LAUNCH();
