@@ -854,7 +854,7 @@ __global__ __launch_bounds__(64) void k_dec_scores(DecAttnArgs a) {
     const unsigned oq = li < a.nhead ? (unsigned)((((long)b * a.nhead + li) * a.D + 4 * kq) * 4) : OOB;
     f32x4 acc = f32x4{0.f, 0.f, 0.f, 0.f};
     const int nks = a.D / 16;                                     // D % 64 == 0: whole batches of 4 k-steps
-    for (int k0 = 0; k0 < nks; k0 += 4) {                         // 12 loads in flight, then 16 MFMAs
+    for (int k0 = 0; k0 < nks; k0 += 4) {                         // 12 loads in flight, then 16 MFMAs (24 in flight: measured slower, round 4)
         f32x4 m[4], pp[4], qv[4];
 #pragma unroll
         for (int u = 0; u < 4; ++u) {
@@ -889,18 +889,42 @@ __global__ __launch_bounds__(1024) void k_dec_ctx(DecAttnArgs a) {
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, li = lane & 15, kq = lane >> 4;
     const int b = blockIdx.y, c0 = blockIdx.x * 16;
     if (wave < a.nhead) {
+        // the head's score row in ONE batch of loads (L <= 1408 by the LDS budget the launcher checks: 22 per lane), kept in
+        // registers for both softmax passes.  As two strided loops with a run-time bound (round 3) every element was its own
+        // memory round trip, twice: 32 dependent round trips = the kernel's 10 us (round 4: profiles/r04x_*)
+        constexpr int NSV = 22;
         const float* s = a.scores + ((long)b * a.nhead + wave) * a.L;
+        if (a.L > 64 * NSV) {                                       // uniform: longer rows (few heads) keep the two strided passes
+            float mx = -INFINITY;
+            for (int l = lane; l < a.L; l += 64) mx = fmaxf(mx, s[l]);
+            mx = wave_max(mx);
+            float sum = 0.f;
+            for (int l = lane; l < Lp; l += 64) {
+                const float e = l < a.L ? __expf(s[l] - mx) : 0.f;
+                p[(size_t)wave * Lp + l] = e;
+                sum += e;
+            }
+            sum = wave_sum(sum);
+            if (lane == 0) inv[wave] = 1.f / sum;
+        } else {
+        float sv[NSV];
+#pragma unroll
+        for (int u = 0; u < NSV; ++u) sv[u] = s[min(lane + 64 * u, a.L - 1)];
         float mx = -INFINITY;
-        for (int l = lane; l < a.L; l += 64) mx = fmaxf(mx, s[l]);
+#pragma unroll
+        for (int u = 0; u < NSV; ++u) mx = fmaxf(mx, lane + 64 * u < a.L ? sv[u] : -INFINITY);
         mx = wave_max(mx);
         float sum = 0.f;
-        for (int l = lane; l < Lp; l += 64) {
-            const float e = l < a.L ? __expf(s[l] - mx) : 0.f;
-            p[(size_t)wave * Lp + l] = e;
+#pragma unroll
+        for (int u = 0; u < NSV; ++u) {
+            const int l = lane + 64 * u;
+            const float e = l < a.L ? __expf(sv[u] - mx) : 0.f;
+            if (l < Lp) p[(size_t)wave * Lp + l] = e;
             sum += e;
         }
         sum = wave_sum(sum);
         if (lane == 0) inv[wave] = 1.f / sum;
+        }
     }
     __syncthreads();
     const __amdgpu_buffer_rsrc_t rm = pt_rsrc(a.mem, (unsigned)((long)a.B * a.L * a.D * 4));
@@ -909,7 +933,7 @@ __global__ __launch_bounds__(1024) void k_dec_ctx(DecAttnArgs a) {
     f32x4 acc = f32x4{0.f, 0.f, 0.f, 0.f};
     const int nks = Lp / 4;
     for (int ks = wave; ks < nks; ks += 64) {                     // this wavefront's k-steps ks, ks+16, ks+32, ks+48:
-        float mv[4], pv[4];                                       // four loads in flight, then four MFMAs
+        float mv[4], pv[4];                                       // four loads in flight, then four MFMAs (sixteen: measured slower)
 #pragma unroll
         for (int u = 0; u < 4; ++u) {
             const int k2 = ks + 16 * u, l = 4 * k2 + kq;
@@ -944,10 +968,27 @@ __global__ __launch_bounds__(256) void k_reg_attend(const float* feat, const flo
     const int tx = threadIdx.x & 31, ty = threadIdx.x >> 5, p0 = blockIdx.x * 32, img = blockIdx.y;
     const float* src = feat + (long)img * D * HW;
     float part = 0.f;
-    for (int c = ty; c < D; c += 8) {
-        const float v = (p0 + tx < HW) ? src[(long)c * HW + p0 + tx] : 0.f;
-        tile[c * 33 + tx] = v;
-        part += v * filt[c];
+    // 16 channels per thread and batch, clamped: all loads of a batch in flight (with the run-time bound as the only loop every
+    // channel was its own round trip: 32 of them at D = 256, 13 us for a 330 KB map; round 4)
+    const int px = min(p0 + tx, HW - 1);
+    const bool pin = p0 + tx < HW;
+    for (int cb = 0; cb < D; cb += 128) {
+        float v[16], fv[16];
+#pragma unroll
+        for (int u = 0; u < 16; ++u) {
+            const int c = min(cb + ty + 8 * u, D - 1);
+            v[u] = src[(long)c * HW + px];
+            fv[u] = filt[c];
+        }
+#pragma unroll
+        for (int u = 0; u < 16; ++u) {
+            const int c = cb + ty + 8 * u;
+            if (c < D) {
+                const float x = pin ? v[u] : 0.f;
+                tile[c * 33 + tx] = x;
+                part += x * fv[u];
+            }
+        }
     }
     __shared__ float red[8][33];
     red[ty][tx] = part;
