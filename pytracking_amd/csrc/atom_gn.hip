@@ -122,10 +122,52 @@ __device__ __forceinline__ float gn_gather(const GnArgs& a, int e, const float* 
 }
 
 // search direction from the residual r with the diagonal preconditioner (optimization.py:97-125, optim.py:67-68)
+#define GN_NE 20   // elements per thread of the register-resident CG step (NV <= 20480)
 __device__ void gn_direction(const GnArgs& a, float* scratch) {
     const float rho1 = a.scal[0];
     float acc = 0.f, acc2 = 0.f;
     const bool has_p = a.scal[2] != 0.f;
+    if (a.NV <= 1024 * GN_NE && blockDim.x == 1024) {
+        // on registers (one round of loads, the two sums, one round of stores; same summation order as the sweeps below, which
+        // paid one memory round trip per 1024 elements and array -- the first direction of every Gauss-Newton iteration, round 4)
+        const bool pr = has_p && !a.fletcher_reeves;
+        float re[GN_NE], pe[GN_NE], rp[GN_NE];
+#pragma unroll
+        for (int k = 0; k < GN_NE; ++k) {
+            const int ec = min((int)threadIdx.x + 1024 * k, a.NV - 1);
+            re[k] = a.r[ec];
+            pe[k] = has_p ? a.p[ec] : 0.f;
+            rp[k] = pr ? a.rprev[ec] : 0.f;
+        }
+#pragma unroll
+        for (int k = 0; k < GN_NE; ++k) {
+            const int e = threadIdx.x + 1024 * k;
+            if (e < a.NV) {
+                const float z = re[k] / (e < a.NF ? a.lf : a.lP);
+                acc += re[k] * z;
+                if (pr) acc2 += rp[k] * z;
+            }
+        }
+        const float rho = block_sum(acc, scratch);
+        const float rho2 = block_sum(acc2, scratch);
+        __syncthreads();
+        if (rho == 0.f) {                                               // :108-113
+            if (threadIdx.x == 0) { a.scal[0] = rho; a.scal[1] = 1.f; }
+            return;
+        }
+        float beta = 0.f;
+        if (has_p) beta = fmaxf(a.fletcher_reeves ? rho / rho1 : (rho - rho2) / rho1, 0.f);   // :118-124
+#pragma unroll
+        for (int k = 0; k < GN_NE; ++k) {
+            const int e = threadIdx.x + 1024 * k;
+            if (e < a.NV) {
+                const float z = re[k] / (e < a.NF ? a.lf : a.lP);
+                a.p[e] = has_p ? z + beta * pe[k] : z;
+            }
+        }
+        if (threadIdx.x == 0) { a.scal[0] = rho; a.scal[2] = 1.f; }
+        return;
+    }
     for (int e = threadIdx.x; e < a.NV; e += blockDim.x) {
         const float z = a.r[e] / (e < a.NF ? a.lf : a.lP);
         acc += a.r[e] * z;
@@ -174,7 +216,6 @@ __global__ __launch_bounds__(256) void k_gn_gather(GnArgs a, int phase) {
 // The recurrences of a CG step on the assembled vectors (one workgroup; fixed summation order):
 // phase 0: state reset (:82-83), first direction
 // phase 1: alpha, delta, residual (:127-146); then the next direction, or x += delta after the last one
-#define GN_NE 20   // elements per thread of the register-resident CG step (NV <= 20480)
 __global__ __launch_bounds__(1024) void k_gn_vec(GnArgs a, int phase, int ii, int num_iter) {
     __shared__ float scratch[16];
     if (phase == 0) {
@@ -247,6 +288,30 @@ __global__ __launch_bounds__(1024) void k_gn_vec(GnArgs a, int phase, int ii, in
     }
     const float pq = block_sum(acc, scratch);
     const float alpha = a.scal[0] / pq;                                 // :131
+    if (!more && a.NV <= 1024 * GN_NE) {
+        // last CG step of a Gauss-Newton iteration, on registers like the others: delta += alpha p, then x += delta (:143-146,
+        // :403-404).  As two strided sweeps with a run-time bound this was 17 dependent round trips per array (round 4)
+        float re[GN_NE], pe[GN_NE], de[GN_NE], xe[GN_NE];
+#pragma unroll
+        for (int k = 0; k < GN_NE; ++k) {
+            const int e = threadIdx.x + 1024 * k, ec = min(e, a.NV - 1);
+            re[k] = a.r[ec];
+            pe[k] = a.p[ec];
+            de[k] = a.delta[ec];
+            xe[k] = ec < a.NF ? a.f[ec] : a.P[ec - a.NF];
+        }
+#pragma unroll
+        for (int k = 0; k < GN_NE; ++k) {
+            const int e = threadIdx.x + 1024 * k;
+            if (e < a.NV) {
+                if (!a.fletcher_reeves) a.rprev[e] = re[k];
+                const float dn = de[k] + alpha * pe[k];
+                a.delta[e] = dn;
+                (e < a.NF ? a.f[e] : a.P[e - a.NF]) = xe[k] + dn;
+            }
+        }
+        return;
+    }
     for (int e = threadIdx.x; e < a.NV; e += blockDim.x) {
         const float re = a.r[e];
         if (!a.fletcher_reeves) a.rprev[e] = re;
