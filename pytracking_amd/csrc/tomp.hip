@@ -888,6 +888,15 @@ __global__ __launch_bounds__(1024) void k_dec_ctx(DecAttnArgs a) {
     float* part = inv + 16;
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, li = lane & 15, kq = lane >> 4;
     const int b = blockIdx.y, c0 = blockIdx.x * 16;
+    // the first round of memory rows is requested in front of the softmax (it does not depend on it)
+    const __amdgpu_buffer_rsrc_t rm = pt_rsrc(a.mem, (unsigned)((long)a.B * a.L * a.D * 4));
+    const int nks = Lp / 4;
+    float mv0[4];
+#pragma unroll
+    for (int u = 0; u < 4; ++u) {
+        const int k2 = wave + 16 * u, l = 4 * k2 + kq;
+        mv0[u] = pt_bload1(rm, (k2 < nks && l < a.L) ? (unsigned)((((long)b * a.L + l) * a.D + c0 + li) * 4) : OOB);
+    }
     if (wave < a.nhead) {
         // the head's score row in ONE batch of loads (L <= 1408 by the LDS budget the launcher checks: 22 per lane), kept in
         // registers for both softmax passes.  As two strided loops with a run-time bound (round 3) every element was its own
@@ -927,18 +936,17 @@ __global__ __launch_bounds__(1024) void k_dec_ctx(DecAttnArgs a) {
         }
     }
     __syncthreads();
-    const __amdgpu_buffer_rsrc_t rm = pt_rsrc(a.mem, (unsigned)((long)a.B * a.L * a.D * 4));
     const float hsel = li < a.nhead ? 1.f : 0.f;
     const float* ph = p + (size_t)min(li, a.nhead - 1) * Lp;
     f32x4 acc = f32x4{0.f, 0.f, 0.f, 0.f};
-    const int nks = Lp / 4;
     for (int ks = wave; ks < nks; ks += 64) {                     // this wavefront's k-steps ks, ks+16, ks+32, ks+48:
         float mv[4], pv[4];                                       // four loads in flight, then four MFMAs (sixteen: measured slower)
 #pragma unroll
         for (int u = 0; u < 4; ++u) {
             const int k2 = ks + 16 * u, l = 4 * k2 + kq;
             const bool live = k2 < nks;
-            mv[u] = pt_bload1(rm, (live && l < a.L) ? (unsigned)((((long)b * a.L + l) * a.D + c0 + li) * 4) : OOB);
+            if (ks == wave) mv[u] = mv0[u];                       // uniform: the round requested in front of the softmax
+            else mv[u] = pt_bload1(rm, (live && l < a.L) ? (unsigned)((((long)b * a.L + l) * a.D + c0 + li) * 4) : OOB);
             pv[u] = live ? ph[l] * hsel : 0.f;
         }
 #pragma unroll
