@@ -45,29 +45,53 @@ __device__ __forceinline__ float lwl_sum_parts(const float* p, float* scratch) {
 __global__ __launch_bounds__(256) void k_lwl_upd(LwlArgs a, int t, int want_loss, int last) {
     __shared__ float scratch[16];
     float alpha = 0.f;
-    if (t > 0) {
-        const float gg = lwl_sum_parts(a.ggp, scratch), hh = lwl_sum_parts(a.hhp, scratch) + a.lam * a.lam * gg;
-        alpha = gg / fmaxf(hh + a.slreg * gg, 1e-8f);                                   // steepestdescent.py:76-80
-        const float* wp = lwl_w(a, t - 1);
-        float* wn = a.w_iters + (long)t * a.CKK;
-        for (long e = (long)blockIdx.x * 256 + threadIdx.x; e < a.CKK; e += (long)LWL_NBLK * 256)
-            wn[e] = wp[e] - alpha * a.g[e];                                             // :83-88
-    }
-    if (last && !want_loss) return;
-    float lacc = 0.f;
     // LWL_U strided elements per round: all loads of a round are issued before the first store (one element per round left
-    // every round waiting for its own loads: 12 dependent round trips)
+    // every round waiting for its own loads: 12 dependent round trips).  Round 4: the FIRST round -- the only one with few
+    // samples -- and the filter elements are requested in front of the step-length reduction, which they do not depend on.
     constexpr int LWL_U = 4;
     const long stride = (long)LWL_NBLK * 256;
-    for (long e0 = (long)blockIdx.x * 256 + threadIdx.x; e0 < a.N; e0 += LWL_U * stride) {
-        float sv[LWL_U], gv[LWL_U], lb[LWL_U], sw[LWL_U];
+    const long ef = (long)blockIdx.x * 256 + threadIdx.x;
+    const bool skip = last && !want_loss;
+    float sv[LWL_U], gv[LWL_U], lb[LWL_U], sw[LWL_U];
+    if (!skip) {
 #pragma unroll
         for (int u = 0; u < LWL_U; ++u) {
-            const long e = min(e0 + u * stride, a.N - 1);
+            const long e = min(ef + u * stride, a.N - 1);
             sv[u] = a.s[e];
             gv[u] = t > 0 ? a.sg[e] : 0.f;
             lb[u] = a.label[e];
             sw[u] = lwl_sw(a, e);
+        }
+    }
+    if (t > 0) {
+        const float* wp = lwl_w(a, t - 1);
+        float* wn = a.w_iters + (long)t * a.CKK;
+        constexpr int WU = 2;                                                           // filter elements per thread and round
+        float wv[WU], gw[WU];
+#pragma unroll
+        for (int u = 0; u < WU; ++u) {
+            const long e = min(ef + u * stride, (long)a.CKK - 1);
+            wv[u] = wp[e]; gw[u] = a.g[e];
+        }
+        const float gg = lwl_sum_parts(a.ggp, scratch), hh = lwl_sum_parts(a.hhp, scratch) + a.lam * a.lam * gg;
+        alpha = gg / fmaxf(hh + a.slreg * gg, 1e-8f);                                   // steepestdescent.py:76-80
+#pragma unroll
+        for (int u = 0; u < WU; ++u)
+            if (ef + u * stride < a.CKK) wn[ef + u * stride] = wv[u] - alpha * gw[u];   // :83-88
+        for (long e = ef + WU * stride; e < a.CKK; e += stride) wn[e] = wp[e] - alpha * a.g[e];
+    }
+    if (skip) return;
+    float lacc = 0.f;
+    for (long e0 = ef; e0 < a.N; e0 += LWL_U * stride) {
+        if (e0 != ef) {                                                                 // uniform per thread position: later rounds
+#pragma unroll
+            for (int u = 0; u < LWL_U; ++u) {
+                const long e = min(e0 + u * stride, a.N - 1);
+                sv[u] = a.s[e];
+                gv[u] = t > 0 ? a.sg[e] : 0.f;
+                lb[u] = a.label[e];
+                sw[u] = lwl_sw(a, e);
+            }
         }
 #pragma unroll
         for (int u = 0; u < LWL_U; ++u) {
