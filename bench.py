@@ -431,14 +431,14 @@ def main():
                     f += 1
 
         # Clock warm-up, every rank, in FRONT of the W warm-up frames: the two feature passes of the last solve re-issued back to back
-        # for ~10 ms (pt_track_frame_replay_pass_f32: idempotent, the sequence state does not move).  After the idle seconds of the
+        # for ~40 ms (pt_track_frame_replay_pass_f32: idempotent, the sequence state does not move).  After the idle seconds of the
         # profiling children the first 2 ms burst ran 2-3 % slower than the following ones and settled over ~3 replays of a
         # 20-frame graph (profiles/r04c_short_region_warmup.txt: 112.1 -> 110.5 -> 109.1 us/frame; hipGraphUpload changed
         # nothing, an untimed first launch of the executable recovered a third).  The same launches are the roofline leg's
         # event-pair periods (last round trip kept).  The W warm-up frames then run directly in front of the timed region.
         period = None
         try:
-            for _ in range(3):
+            for _ in range(12):                                # ~40 ms: the ramp was still visible after 10 (repeats 109.4 -> 108.4 us)
                 period = {"corr": event_period_us(st, stream, 0), "adj": event_period_us(st, stream, 1)}
         except RuntimeError:
             period = None                                      # configuration outside the fast path: no replay helper
@@ -486,7 +486,7 @@ def main():
                                    "frac": round(gbs / HBM_PEAK_GBS, 4),
                                    "note": "2 feature reads per iteration x 5 iterations (SURVEY 8d) / measured frame time"}
         launch = (f"hipGraph replay, {G} frames per graph ({K // G} replay(s) in the timed region, {len(graphs)} start slot(s); "
-                  f"clock warm-up: ~10 ms of idempotent pass replays in front of the warm-up frames)" if use_graph
+                  f"clock warm-up: ~40 ms of idempotent pass replays in front of the warm-up frames)" if use_graph
                   else "eager (18 launches per frame)")
         out = {
             "metric": "frames/sec DiMP-50 online track (288x288, 5 SD iters)" if cfg_name == "dimp50" else "frames/sec PrDiMP-50 online track (352x352, 5 SD iters)", "value": round(value, 2),
