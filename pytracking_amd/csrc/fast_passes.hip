@@ -60,7 +60,8 @@ typedef float f32x2a4 __attribute__((ext_vector_type(2), aligned(4)));   // 8-by
 #ifndef PT_ADJ_G2
 #define PT_ADJ_G2 0      // 1: residual cells of a quad gathered as two 8-byte LDS reads at 4-byte alignment (even map widths).  Measured in
 //                          round 4 and NOT kept: k_adj2 7.6 -> 12.0 us (PrDiMP 12.7 -> 17.7) -- a misaligned ds_read_b64 costs far more
-//                          than the two scalar reads and two address adds it replaces (profiles/r04j_adjoint_pair_gather_ab.txt)
+//                          than the two scalar reads and two address adds it replaces; as two ds_read2_b32 (dword pairs, no alignment demand): 7.55 -> 7.94 us
+//                          (profiles/r04j_adjoint_pair_gather_ab.txt) -- fewer instructions in the loop do not make it faster
 #endif
 #ifndef PT_ADJ_EARLY
 #define PT_ADJ_EARLY 1   // 1: first feature loads in front of the LDS work; 0: behind barrier 1
@@ -883,6 +884,7 @@ __global__ __launch_bounds__(PT_ADJ_WAVES * 64) void k_adj2(const float* h_feat,
         constexpr bool G2 = decltype(pair_tag)::value;
         auto gather = [&](int u) {
             if constexpr (G2) {
+#else
                 const f32x2a4 lo = *(const f32x2a4*)((const char*)maps + ((unsigned)cell[u][0] + tapoff4));
                 const f32x2a4 hi = *(const f32x2a4*)((const char*)maps + ((unsigned)cell[u][2] + tapoff4));
                 bv[u][0] = lo[0]; bv[u][1] = lo[1]; bv[u][2] = hi[0]; bv[u][3] = hi[1];
