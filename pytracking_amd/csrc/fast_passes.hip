@@ -884,7 +884,6 @@ __global__ __launch_bounds__(PT_ADJ_WAVES * 64) void k_adj2(const float* h_feat,
         constexpr bool G2 = decltype(pair_tag)::value;
         auto gather = [&](int u) {
             if constexpr (G2) {
-#else
                 const f32x2a4 lo = *(const f32x2a4*)((const char*)maps + ((unsigned)cell[u][0] + tapoff4));
                 const f32x2a4 hi = *(const f32x2a4*)((const char*)maps + ((unsigned)cell[u][2] + tapoff4));
                 bv[u][0] = lo[0]; bv[u][1] = lo[1]; bv[u][2] = hi[0]; bv[u][3] = hi[1];
