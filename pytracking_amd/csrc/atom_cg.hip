@@ -165,12 +165,12 @@ __global__ __launch_bounds__(256) void k_acg_red(const float* __restrict__ gpart
     const int ec = min(e, CKK - 1);
     const float pv = px[ec];
     float acc = 0.f;
-    for (int k0 = g; k0 < KSPL; k0 += 32) {                              // partials g, g+4, ...: 8 loads in flight
-        float v[8];
+    for (int k0 = g; k0 < KSPL; k0 += 64) {                              // partials g, g+4, ...: 16 loads in flight (the tracker's 64
+        float v[16];                                                     // position slices: ONE round trip; round 3 took two of 8)
 #pragma unroll
-        for (int u = 0; u < 8; ++u) v[u] = gpart[(long)min(k0 + 4 * u, KSPL - 1) * CKK + ec];
+        for (int u = 0; u < 16; ++u) v[u] = gpart[(long)min(k0 + 4 * u, KSPL - 1) * CKK + ec];
 #pragma unroll
-        for (int u = 0; u < 8; ++u) acc += k0 + 4 * u < KSPL ? v[u] : 0.f;
+        for (int u = 0; u < 16; ++u) acc += k0 + 4 * u < KSPL ? v[u] : 0.f;
     }
     part[g][el] = acc;
     __syncthreads();
