@@ -865,15 +865,21 @@ size_t pt_mf_corr_part_floats(int n, int F, int C, int H, int W, int K) {
 }
 // sum of the <= 16 channel-split partial maps of an element quad: every load requested before the first add (with the run-time
 // count as the loop bound each split was its own memory round trip), fixed order
-__device__ __forceinline__ f32x4 mf_parts_quad(const float* __restrict__ part, int parts, long count, long e) {
-    f32x4 v[16];
+template <int NB>
+__device__ __forceinline__ f32x4 mf_parts_batch(const float* __restrict__ part, int parts, long count, long e) {
+    f32x4 v[NB];
 #pragma unroll
-    for (int k = 0; k < 16; ++k) v[k] = *(const f32x4*)(part + (long)min(k, parts - 1) * count + e);
+    for (int k = 0; k < NB; ++k) v[k] = *(const f32x4*)(part + (long)min(k, parts - 1) * count + e);
     f32x4 s = v[0];
 #pragma unroll
-    for (int k = 1; k < 16; ++k)
+    for (int k = 1; k < NB; ++k)
         if (k < parts) s += v[k];
     return s;
+}
+__device__ __forceinline__ f32x4 mf_parts_quad(const float* __restrict__ part, int parts, long count, long e) {
+    if (parts <= 4) return mf_parts_batch<4>(part, parts, count, e);       // uniform: no more clamped re-reads than the next batch size
+    if (parts <= 8) return mf_parts_batch<8>(part, parts, count, e);
+    return mf_parts_batch<16>(part, parts, count, e);
 }
 __global__ void k_mf_sum_parts(const float* __restrict__ part, float* __restrict__ out, int parts, long count) {
     const long e = ((long)blockIdx.x * blockDim.x + threadIdx.x) * 4;

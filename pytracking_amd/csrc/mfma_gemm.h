@@ -151,10 +151,14 @@ __device__ __forceinline__ void gemm_tile(const GemmArgs& g, const int bxi, cons
     const int lrow = tid / (BK / 4), lc4 = (tid % (BK / 4)) * 4;   // loader: BK/4 threads cover one row segment of BK floats
     // fused GroupNorm + ReLU on the gathered operand (MODE 1): mean / rstd of the <= 2 images this tile's rows belong to, from the
     // slice statistics (double precision, as the stand-alone k_gn_apply; tree order instead of its serial order)
-    const bool gn = MODE == 1 && g.gn_stats != nullptr;
-    __shared__ double gn_red[MODE == 1 ? 8 : 1];
+    // MODE 2 = MODE 1 (3x3 gather) + the fused GroupNorm loader: its own instantiation, so that the plain gather kernel (the
+    // classification-feature head over several frames, the tower's first layer) keeps the code it had (with the statistics path
+    // as a run-time branch of MODE 1 that kernel was 6 us slower on the ToMP head, same-box A/B, round 4)
+    constexpr bool GATHER = MODE >= 1;
+    constexpr bool gn = MODE == 2;
+    __shared__ double gn_red[MODE == 2 ? 8 : 1];
     __shared__ float gn_mr[4];
-    const int img_lo = MODE == 1 ? m0 / g.HW : 0;
+    const int img_lo = GATHER ? m0 / g.HW : 0;
     float gmean[2] = {0.f, 0.f}, grstd[2] = {1.f, 1.f};
     const long zb = g.batch ? (long)bzi : 0;
     const __amdgpu_buffer_rsrc_t rsA = pt_rsrc(g.A + zb * g.a_zstride, g.a_bytes), rsW = pt_rsrc(g.Wt + zb * g.w_zstride, g.w_bytes);
@@ -523,7 +527,12 @@ int launch_gemm(const GemmArgs& g, hipStream_t st, bool conv = false) {
     }
     if (conv) {
         if (g.Cin % 64 != 0) return PT_ERR_UNSUPPORTED;
-        hipLaunchKernelGGL((k_gemm<32, 32, 1>), dim3((g.N + 31) / 32, (g.M + 31) / 32, nz), dim3(256), 0, st, g);
+        if (g.gn_stats) {
+            if (g.gn_slices > GEMM_GN_MAX_SLICES || g.gn_slices < 1 || !g.gn_gam || !g.gn_bet || g.HW < 32) return PT_ERR_UNSUPPORTED;
+            hipLaunchKernelGGL((k_gemm<32, 32, 2>), dim3((g.N + 31) / 32, (g.M + 31) / 32, nz), dim3(256), 0, st, g);
+        } else {
+            hipLaunchKernelGGL((k_gemm<32, 32, 1>), dim3((g.N + 31) / 32, (g.M + 31) / 32, nz), dim3(256), 0, st, g);
+        }
     } else if (g.N >= pt_gemm_tile64_min_n() && g.M >= 1024 && nz == 1 && g.K % 32 == 0) {
         GemmArgs gs = g;
         const int gy = (g.M + 63) / 64;

@@ -1030,9 +1030,16 @@ __global__ __launch_bounds__(256) void k_gn_reduce(const float* __restrict__ par
     for (int u = 0; u < GN_SLICE / 1024; ++u) {
         const int i = i0 + (u * 256 + threadIdx.x) * 4;
         if (i < n_per_img) {
-            f32x4 v = *reinterpret_cast<const f32x4*>(part + base + i);
-#pragma unroll 8
-            for (int z = 1; z < nz; ++z) v += *reinterpret_cast<const f32x4*>(part + z * zstride + base + i);
+            // the split partials in ONE batch of loads, fixed order (a run-time bound leaves fewer than 8 iterations -- the
+            // feature head's 8 channel splits -- to a remainder loop of one dependent load per round trip; round 4)
+            f32x4 pv[9];                                            // 8 channel splits (feature head) or 9 taps (tower): one batch
+#pragma unroll
+            for (int z = 0; z < 9; ++z) pv[z] = *reinterpret_cast<const f32x4*>(part + (long)min(z, nz - 1) * zstride + base + i);
+            f32x4 v = pv[0];
+#pragma unroll
+            for (int z = 1; z < 9; ++z)
+                if (z < nz) v += pv[z];
+            for (int z = 9; z < nz; ++z) v += *reinterpret_cast<const f32x4*>(part + z * zstride + base + i);
             *reinterpret_cast<f32x4*>(x + base + i) = v;
             s += (v[0] + v[1]) + (v[2] + v[3]);
             q += (v[0] * v[0] + v[1] * v[1]) + (v[2] * v[2] + v[3] * v[3]);
