@@ -2,9 +2,10 @@
 
 Import shim that lets the *unmodified* reference (visionml/pytracking mounted read-only at
 /root/reference) execute on CPU inside the build container so that golden vectors can be
-generated from the reference's own code.  It exists only in
-the build container; /root/reference is absent on the GPU box, so nothing that runs there may
-import this module (tests/golden/*.npz are the portable artefact, see oracle/make_golden.py).
+generated from the reference's own code.  /root/reference is absent on
+the GPU box: there the same shim resolves to oracle/_ref/reference, the byte-for-byte bundle oracle/make_ref_bundle.py
+writes (git-ignored, sha256 manifest), used by tests/test_trackers_on_device.py and bench.py's baseline legs;
+tests/golden/*.npz stay the portable artefact of every other test (oracle/make_golden.py).
 
 What it does (none of it edits /root/reference):
   * stubs the third-party imports the reference pulls in but the path never executes
@@ -21,7 +22,21 @@ import sys
 import types
 from unittest import mock
 
-REFERENCE_ROOT = os.environ.get("PYTRACKING_REFERENCE", "/root/reference")
+_BUNDLE = os.path.join(os.path.dirname(os.path.abspath(__file__)), "_ref", "reference")
+
+
+def _resolve_root():
+    """$PYTRACKING_REFERENCE, else the mounted tree (build container), else the recipe-built byte-for-byte bundle
+    oracle/_ref/reference (oracle/make_ref_bundle.py: git-ignored, travels to the GPU box with the snapshot)."""
+    env = os.environ.get("PYTRACKING_REFERENCE")
+    if env:
+        return env
+    if os.path.isdir("/root/reference/ltr"):
+        return "/root/reference"
+    return _BUNDLE
+
+
+REFERENCE_ROOT = _resolve_root()
 
 _STUBS = [
     "cv2", "visdom", "visdom.server", "jpeg4py", "torchvision", "torchvision.models",

@@ -37,25 +37,58 @@ class StubBackbone:
     """Seeded stand-in for the stock-PyTorch parts in front of the hot path.  Call k of `backbone(n)` returns the maps
     drawn from `default_rng(seed + k)`; `iou_feat(n)` likewise with its own counter."""
 
-    def __init__(self, seed, dims):
+    def __init__(self, seed, dims, device="cpu"):
         self.seed, self.d = int(seed), dict(dims)
         self.k_backbone = 0
         self.k_iou = 0
+        self.device = torch.device(device)
 
     def backbone(self, n):
         out = synth.tracker_backbone(self.seed + self.k_backbone, n, self.d)
         self.k_backbone += 1
-        return OrderedDict((k, torch.from_numpy(v)) for k, v in out.items())
+        return OrderedDict((k, torch.from_numpy(v).to(self.device)) for k, v in out.items())
 
     def iou_feat(self, n):
         out = synth.tracker_iou_feat(self.seed + 5000 + self.k_iou, n, self.d)
         self.k_iou += 1
-        return [torch.from_numpy(v) for v in out]
+        return [torch.from_numpy(v).to(self.device) for v in out]
+
+
+def use_device(params, device):
+    """`params.use_gpu` / `params.device` as pytracking/parameter/*/ sets them for a GPU run (dimp50.py:10 `use_gpu = True`;
+    the trackers derive `params.device` from it, dimp.py:28-29)."""
+    device = torch.device(device)
+    params.use_gpu = device.type == "cuda"
+    params.device = str(device) if device.type == "cuda" else "cpu"
+    return params
+
+
+class host_rng_for_device_tensors:
+    """Device runs only.  ATOM draws its start filter and projection matrix with `Tensor.normal_()` on tensors that live on
+    the tracker's device (atom.py:147,544); on a GPU that consumes the device generator, so the run would start from other
+    random numbers than the recorded CPU run and leave the host generator (proposal jitter, atom.py:715) out of step.  Inside
+    this context `normal_` on a device tensor draws on the host generator and copies: same numbers, same stream position."""
+
+    def __enter__(self):
+        self._orig = orig = torch.Tensor.normal_
+
+        def normal_(t, mean=0, std=1, *, generator=None):
+            if t.is_cuda and generator is None:
+                t.copy_(orig(torch.empty(t.shape, dtype=t.dtype), mean, std))
+                return t
+            return orig(t, mean, std, generator=generator)
+        torch.Tensor.normal_ = normal_
+        return self
+
+    def __exit__(self, *exc):
+        torch.Tensor.normal_ = self._orig
+        return False
 
 
 class Recorder:
     def __init__(self):
         self.events = []
+        self.notes = []                 # (event kind, implementing module) pairs: not part of the serialised log
 
     def add(self, kind, **kw):
         ev = {"kind": kind}
@@ -177,14 +210,16 @@ def synthetic_frame(rng, hw=(360, 480)):
     return rng.integers(0, 256, size=(hw[0], hw[1], 3), dtype=np.uint8)
 
 
-def run_dimp(seed=4100, n_frames=6, dims=DIMP50_TEST, record=True, score_gain=None, thresholds=None):
-    """initialize() + n_frames x track() of the reference DiMP on a stubbed backbone.  Returns (outputs, recorder)."""
+def run_dimp(seed=4100, n_frames=6, dims=DIMP50_TEST, record=True, score_gain=None, thresholds=None, device="cpu"):
+    """initialize() + n_frames x track() of the reference DiMP on a stubbed backbone.  Returns (outputs, recorder).
+    `device="cuda"`: the same unmodified tracker as the reference runs it on a GPU (`params.use_gpu = True`, network and
+    features on the device)."""
     ref_harness.install()
     from pytracking.tracker.dimp.dimp import DiMP
-    net = build_dimp50(seed, dims)
-    stub = StubBackbone(seed, dims)
+    net = build_dimp50(seed, dims).to(device)
+    stub = StubBackbone(seed, dims, device)
     ns = NetStub(net, stub)
-    params = dimp50_params(ns)
+    params = use_device(dimp50_params(ns), device)
     if thresholds:
         for k, v in thresholds.items():
             setattr(params, k, v)
@@ -424,15 +459,15 @@ def tomp50_params(net_stub):
     return p
 
 
-def run_tomp(seed=4300, n_frames=6, dims=TOMP50_TEST, thresholds=None):
+def run_tomp(seed=4300, n_frames=6, dims=TOMP50_TEST, thresholds=None, device="cpu"):
     """initialize() + n_frames x track() of the reference ToMP on a stubbed backbone; one event per classify_target call
     (head features of the test frame and of the memory frames, filter prediction, classifier, box regressor)."""
     ref_harness.install()
     from pytracking.tracker.tomp.tomp import ToMP
-    net = build_tomp50(seed, dims)
-    stub = StubBackbone(seed, dims)
+    net = build_tomp50(seed, dims).to(device)
+    stub = StubBackbone(seed, dims, device)
     ns = NetStub(net, stub)
-    params = tomp50_params(ns)
+    params = use_device(tomp50_params(ns), device)
     for k, v in (thresholds or {}).items():
         setattr(params, k, v)
     tracker = ToMP(params)
@@ -608,7 +643,7 @@ def atom_params(features, thresholds=None):
     return p
 
 
-def run_atom(seed=4500, n_frames=8, dims=ATOM18_TEST, thresholds=None):
+def run_atom(seed=4500, n_frames=8, dims=ATOM18_TEST, thresholds=None, device="cpu"):
     """initialize() + n_frames x track() of the reference ATOM with a stub deep feature (seeded layer2 / layer3 maps in place of the
     ResNet-18, seeded IoU features in place of the IoU net's stock convolutions).  Events: atom_gn (first-frame joint optimisation),
     atom_classify, atom_localize, atom_refine, atom_memory, atom_cg."""
@@ -620,8 +655,9 @@ def run_atom(seed=4500, n_frames=8, dims=ATOM18_TEST, thresholds=None):
     import pytracking.tracker.atom.atom as atom_mod
     from pytracking.libs import optimization as ropt
     rec = Recorder()
-    iounet = build_atom_iounet(seed, dims)
+    iounet = build_atom_iounet(seed, dims).to(device)
     calls = {"k": 0, "log": []}
+    dv = lambda a: torch.from_numpy(a).to(device)
 
     class StubAtomFeature(MultiFeatureBase):
         """pytracking/features/deep.py:ATOMResNet18 with the networks replaced by seeded maps."""
@@ -642,10 +678,10 @@ def run_atom(seed=4500, n_frames=8, dims=ATOM18_TEST, thresholds=None):
             calls["k"] += 1
             calls["log"].append((k, n))
             m = atom_feature_maps(seed, k, n, dims)
-            l2, l3 = torch.from_numpy(m["layer2"]), torch.from_numpy(m["layer3"])
+            l2, l3 = dv(m["layer2"]), dv(m["layer3"])
             self.iounet_backbone_features = TensorList([l2.clone(), l3.clone()])
             f3, f4 = synth.tracker_iou_feat(seed + 5000 + k, n, dims)
-            self.iounet_features = TensorList([torch.from_numpy(f3), torch.from_numpy(f4)])
+            self.iounet_features = TensorList([dv(f3), dv(f4)])
             return TensorList([l3])
 
     deep_params = TrackerParams()
@@ -658,27 +694,44 @@ def run_atom(seed=4500, n_frames=8, dims=ATOM18_TEST, thresholds=None):
     deep_params.projection_reg = 1e-4
     deep_params.use_augmentation = True
     feat = StubAtomFeature(fparams=FeatureParams(feature_params=[deep_params]), normalize_power=2)
-    params = atom_params(MultiResolutionExtractor([feat]), thresholds)
+    params = use_device(atom_params(MultiResolutionExtractor([feat]), thresholds), device)
 
-    # recording optimisers (the tracker module's own names are rebound on the imported module, nothing in the tree is edited)
-    class RecGN(ropt.GaussNewtonCG):
-        def run(self, num_cg_iter, num_gn_iter=None):
-            f0, P0 = self.x[0].clone(), self.x[1].clone()
-            out = super().run(num_cg_iter, num_gn_iter)
+    # recording optimisers: the tracker module's own names (atom.py:8 `from pytracking.libs.optimization import ...`) are
+    # rebound on the imported module to factories that build WHATEVER class is bound in pytracking.libs.optimization at that
+    # moment (the reference's, or the one pytracking_amd.install() put there) and wrap `.run` on the instance; nothing in the
+    # tree is edited
+    def RecGN(problem, variable, *a, **kw):
+        opt = ropt.GaussNewtonCG(problem, variable, *a, **kw)
+        opt_run = opt.run
+
+        def run(num_cg_iter, num_gn_iter=None):
+            f0, P0 = opt.x[0].clone(), opt.x[1].clone()
+            out = opt_run(num_cg_iter, num_gn_iter)
             rec.add("atom_gn", num_cg_iter=num_cg_iter, num_gn_iter=-1 if num_gn_iter is None else num_gn_iter, filter0=f0, proj0=P0,
-                    filter=self.x[0], proj=self.x[1], init_call=calls["log"][-1][0], n_aug=calls["log"][-1][1],
-                    y=self.problem.y[0], sw=self.problem.sample_weights[0], filter_reg=self.problem.filter_reg[0],
-                    projection_reg=self.problem.projection_reg[0])
+                    filter=opt.x[0], proj=opt.x[1], init_call=calls["log"][-1][0], n_aug=calls["log"][-1][1],
+                    y=opt.problem.y[0], sw=opt.problem.sample_weights[0], filter_reg=opt.problem.filter_reg[0],
+                    projection_reg=opt.problem.projection_reg[0])
+            rec.notes.append(("atom_gn", type(opt).__module__))
             return out
+        opt.run = run
+        return opt
 
-    class RecCG(ropt.ConjugateGradient):
-        def run(self, num_cg_iter):
-            out = super().run(num_cg_iter)
+    def RecCG(problem, variable, *a, **kw):
+        opt = ropt.ConjugateGradient(problem, variable, *a, **kw)
+        opt_run = opt.run
+
+        def run(num_cg_iter):
+            out = opt_run(num_cg_iter)
             if num_cg_iter > 0:
-                rec.add("atom_cg", num_iter=num_cg_iter, filter=self.x[0], sw=self.problem.sample_weights[0].clone())
+                rec.add("atom_cg", num_iter=num_cg_iter, filter=opt.x[0], sw=opt.problem.sample_weights[0].clone())
+                rec.notes.append(("atom_cg", type(opt).__module__))
             return out
+        opt.run = run
+        return opt
     orig_gn, orig_cg = atom_mod.GaussNewtonCG, atom_mod.ConjugateGradient
     atom_mod.GaussNewtonCG, atom_mod.ConjugateGradient = RecGN, RecCG
+    import contextlib
+    rng_ctx = host_rng_for_device_tensors() if torch.device(device).type == "cuda" else contextlib.nullcontext()
     try:
         tracker = atom_mod.ATOM(params)
         tracker.visdom = None
@@ -694,6 +747,12 @@ def run_atom(seed=4500, n_frames=8, dims=ATOM18_TEST, thresholds=None):
         def localize_target(scores_raw):
             tv, scale_ind, s, flag = orig_loc(scores_raw)
             rec.add("atom_localize", tv=tv, scale_ind=int(scale_ind), flag=str(flag))
+            if isinstance(scale_ind, torch.Tensor) and scale_ind.is_cuda:
+                # torch >= 2 shim, device runs only (same class as the torch.rfft one in ref_harness.py): atom.py:252 indexes the
+                # HOST tensor `sample_scales` with this index, which torch 1.x accepted for a 0-dim device tensor and torch 2
+                # rejects ("indices should be either on cpu or on the same device"); the reference without install() stops at
+                # the same line on this image
+                scale_ind = scale_ind.cpu()
             return tv, scale_ind, s, flag
         tracker.localize_target = localize_target
         orig_ob = tracker.optimize_boxes
@@ -718,7 +777,8 @@ def run_atom(seed=4500, n_frames=8, dims=ATOM18_TEST, thresholds=None):
                 **{f"dim_{k}": v for k, v in dims.items()}, filter_reg=1e-1, act_min_val=0.05, CG_iter=params.CG_iter,
                 box_refinement_iter=params.box_refinement_iter, box_refinement_step_length=params.box_refinement_step_length,
                 box_refinement_step_decay=params.box_refinement_step_decay)
-        tracker.initialize(synthetic_frame(rng), {"init_bbox": [200.0, 140.0, 70.0, 90.0]})
+        with rng_ctx:
+            tracker.initialize(synthetic_frame(rng), {"init_bbox": [200.0, 140.0, 70.0, 90.0]})
         rec.add("atom_init_done", n_init=int(tracker.num_init_samples[0]), sw=tracker.sample_weights[0].clone(),
                 y_init=tracker.y[0][:int(tracker.num_init_samples[0])].clone())
         outs = []

@@ -36,6 +36,7 @@ is handed to the reference's ORIGINAL function object -- its own stock-PyTorch c
 unless `strict=True`, in which case it raises.  The rebound *classes* have no such escape: they run the fused
 solver or raise.
 """
+import collections
 import importlib
 import sys
 import types
@@ -49,6 +50,16 @@ from . import prroi_pool as _prroi
 from . import steepestdescent as _sd
 
 _state = {"installed": False, "originals": {}}
+
+# which branch every rebound symbol took, per call: "<symbol>.fast" (gfx950 path) / "<symbol>.reference" (handed to the
+# reference's own code).  tests/test_trackers_on_device.py asserts on it that a tracker running on the GPU really went
+# through the HIP library; reset with `stats.clear()`.
+stats = collections.Counter()
+
+
+def _hit(name, fast):
+    stats[name + (".fast" if fast else ".reference")] += 1
+    return fast
 
 
 def _covered(feat, filt, dilation_factors=None):
@@ -67,7 +78,7 @@ def _make_dispatchers(orig_mod, strict):
     o_apply, o_adj, o_grad = orig_mod.apply_filter, orig_mod.apply_feat_transpose, orig_mod.filter_gradient
 
     def apply_filter(feat, filter, dilation_factors=None):
-        if _covered(feat, filter, dilation_factors):
+        if _hit("apply_filter", _covered(feat, filter, dilation_factors)):
             return _filter.apply_filter(feat, filter)
         if strict:
             raise NotImplementedError("apply_filter: configuration outside the gfx950 hot path")
@@ -76,15 +87,16 @@ def _make_dispatchers(orig_mod, strict):
     def apply_feat_transpose(feat, input, filter_ksz, training=True, groups=1):
         ksz = (filter_ksz, filter_ksz) if isinstance(filter_ksz, int) else tuple(filter_ksz)
         mf = input.dim() == 5 and input.shape[2] <= 16 and ksz[0] == ksz[1] and ksz[0] in (1, 3) and feat.shape[-1] <= 256
-        if feat.is_cuda and feat.dtype == torch.float32 and groups == 1 and (mf or (input.dim() == 4 and ksz[0] * ksz[1] <= 16)) \
-                and not (torch.is_grad_enabled() and feat.requires_grad):
+        if _hit("apply_feat_transpose", feat.is_cuda and feat.dtype == torch.float32 and groups == 1
+                and (mf or (input.dim() == 4 and ksz[0] * ksz[1] <= 16))
+                and not (torch.is_grad_enabled() and feat.requires_grad)):
             return _filter.apply_feat_transpose(feat, input, ksz, training=training, groups=groups)
         if strict:
             raise NotImplementedError("apply_feat_transpose: configuration outside the gfx950 hot path")
         return o_adj(feat, input, filter_ksz, training=training, groups=groups)
 
     def filter_gradient(feat, filter, label=None, training=True):
-        if _covered(feat, filter):
+        if _hit("filter_gradient", _covered(feat, filter)):
             return _filter.filter_gradient(feat, filter, label=label, training=training)
         if strict:
             raise NotImplementedError("filter_gradient: configuration outside the gfx950 hot path")
@@ -123,7 +135,7 @@ def _optimizer_class(fused_cls, ref_cls, strict):
                      and weights.shape[-1] == weights.shape[-2] and weights.shape[-1] ** 2 <= 16
                      and (sample_weight is None or isinstance(sample_weight, torch.Tensor))
                      and not (torch.is_grad_enabled() and (weights.requires_grad or feat.requires_grad)))
-            if fused:
+            if _hit(ref_cls.__name__, fused):
                 return fused_cls.forward(self, weights, feat, bb, sample_weight=sample_weight, num_iter=num_iter,
                                          compute_losses=compute_losses)
             if strict:
@@ -157,7 +169,7 @@ def provide_prroi_module(orig=None):
         __doc__ = _prroi.PrRoIPool2D.__doc__
 
         def forward(self, features, rois):
-            if features.is_cuda or prev_cls is None:
+            if _hit("PrRoIPool2D", features.is_cuda or prev_cls is None):
                 return _prroi.PrRoIPool2D.forward(self, features, rois)
             return prev_cls(self.pooled_height, self.pooled_width, self.spatial_scale)(features, rois)
 
@@ -248,7 +260,7 @@ def _install_clf_head(orig, strict):
         def forward(self, x):
             fused = (x.is_cuda and x.dtype == torch.float32 and not self.training
                      and not (torch.is_grad_enabled() and (x.requires_grad or self[0].weight.requires_grad)))
-            if fused:
+            if _hit("residual_bottleneck", fused):
                 return _fm.ClfHead.forward(self, x)
             if strict:
                 raise NotImplementedError("clf feature head: call outside the gfx950 hot path")
@@ -279,7 +291,7 @@ def _install_localization(orig, strict):
     orig["localization"] = {"max2d": ref_max2d}
 
     def max2d(a):
-        if a.is_cuda and a.dtype == torch.float32:
+        if _hit("max2d", a.is_cuda and a.dtype == torch.float32):
             return _loc.max2d(a)
         if strict:
             raise NotImplementedError("max2d: tensor outside the gfx950 hot path")
@@ -296,8 +308,8 @@ def _install_localization(orig, strict):
         ref_method = cls.localize_advanced
         orig["localization"][(modname, clsname)] = ref_method
 
-        def method(self, scores, sample_pos, sample_scales, _fast=fn, _ref=ref_method):
-            if scores.is_cuda and scores.dtype == torch.float32 and scores.dim() == 3 and scores.shape[0] <= 8:
+        def method(self, scores, sample_pos, sample_scales, _fast=fn, _ref=ref_method, _name=clsname + ".localize_advanced"):
+            if _hit(_name, scores.is_cuda and scores.dtype == torch.float32 and scores.dim() == 3 and scores.shape[0] <= 8):
                 return _fast(self, scores, sample_pos, sample_scales)
             if strict:
                 raise NotImplementedError("localize_advanced: scores outside the gfx950 hot path")
@@ -328,17 +340,21 @@ def _install_iou_refine(orig, strict):
     for cls, name, fast, get_net in targets:
         ref_method = getattr(cls, name)
 
-        def method(self, iou_features, init_boxes, _fast=fast, _ref=ref_method, _net=get_net):
+        def method(self, iou_features, init_boxes, _fast=fast, _ref=ref_method, _net=get_net,
+                   _name=cls.__name__ + "." + name):
             feats = list(iou_features)
             ok = (len(feats) == 2 and all(f.is_cuda and f.dtype == torch.float32 and f.shape[0] == 1 for f in feats)
                   and not _net(self).training)
             if ok:
                 try:
-                    return _fast(self, feats, init_boxes)
+                    out = _fast(self, feats, init_boxes)
+                    _hit(_name, True)
+                    return out
                 except NotImplementedError:
                     if strict:
                         raise
-            elif strict:
+            _hit(_name, False)
+            if strict and not ok:
                 raise NotImplementedError(f"{_ref.__name__}: call outside the gfx950 hot path")
             return _ref(self, iou_features, init_boxes)
 
@@ -368,6 +384,8 @@ def _install_operation(orig, strict):
                  and input.dim() == 4 and weight.dim() == 4 and weight.shape[0] == 1 and weight.shape[1] == input.shape[1]
                  and weight.shape[2] * weight.shape[3] <= 16 and weight.is_cuda
                  and not (torch.is_grad_enabled() and (input.requires_grad or weight.requires_grad)))
+        if mode == 'same' and isinstance(input, torch.Tensor) and input.is_cuda:       # the classification call; the 1x1 projection
+            _hit("operation.conv2d[same]", fused)                                       # (mode None) is stock PyTorch by design
         if fused:
             return _filter.corr_raw(input, weight[0], out_hw=tuple(input.shape[-2:])).unsqueeze(1)
         if strict and isinstance(input, torch.Tensor) and input.is_cuda and mode == 'same':
@@ -396,7 +414,7 @@ def _install_preprocessing(orig, strict):
     orig["preprocessing"] = {"functions": (ref_sp, ref_ms, ref_tr), "importers": []}
 
     def sample_patch(im, pos, sample_sz, output_sz=None, mode='replicate', max_scale_change=None, is_mask=False):
-        if im.is_cuda and im.dtype == torch.float32 and not is_mask and im.dim() == 4 and im.shape[0] == 1:
+        if _hit("sample_patch", im.is_cuda and im.dtype == torch.float32 and not is_mask and im.dim() == 4 and im.shape[0] == 1):
             return _pp.sample_patch(im, pos, sample_sz, output_sz, mode=mode, max_scale_change=max_scale_change)
         if strict and im.is_cuda:
             raise NotImplementedError("sample_patch: call outside the gfx950 hot path")
@@ -404,7 +422,7 @@ def _install_preprocessing(orig, strict):
 
     def sample_patch_multiscale(im, pos, scales, image_sz, mode='replicate', max_scale_change=None):
         n = 1 if isinstance(scales, (int, float)) else len(scales)
-        if im.is_cuda and im.dtype == torch.float32 and im.dim() == 4 and im.shape[0] == 1 and n <= 8:
+        if _hit("sample_patch_multiscale", im.is_cuda and im.dtype == torch.float32 and im.dim() == 4 and im.shape[0] == 1 and n <= 8):
             return _pp.sample_patch_multiscale(im, pos, scales, image_sz, mode=mode, max_scale_change=max_scale_change)
         if strict and im.is_cuda:
             raise NotImplementedError("sample_patch_multiscale: call outside the gfx950 hot path")
@@ -414,12 +432,15 @@ def _install_preprocessing(orig, strict):
         # first-frame augmentation set (generate_init_samples, dimp.py:329-395): one gather launch over the base patch
         if im.is_cuda and im.dtype == torch.float32 and not is_mask and im.dim() == 4 and im.shape[0] == 1:
             try:
-                return _pp.sample_patch_transformed(im, pos, scale, image_sz, transforms)
+                out = _pp.sample_patch_transformed(im, pos, scale, image_sz, transforms)
+                _hit("sample_patch_transformed", True)
+                return out
             except NotImplementedError:                       # a transform the device path does not cover (RandomAffine, ...)
                 if strict:
                     raise
         elif strict and im.is_cuda:
             raise NotImplementedError("sample_patch_transformed: call outside the gfx950 hot path")
+        _hit("sample_patch_transformed", False)
         return ref_tr(im, pos, scale, image_sz, transforms, is_mask=is_mask)
 
     for fn, ref in ((sample_patch, ref_sp), (sample_patch_multiscale, ref_ms), (sample_patch_transformed, ref_tr)):
@@ -507,7 +528,7 @@ def install(strict=False, atom_cg=True, tomp=True, clf_head=True, localization=T
                 feat = kwargs.get("feat")
                 fused = (isinstance(feat, torch.Tensor) and feat.is_cuda and w.is_cuda and not args
                          and not (torch.is_grad_enabled() and (w.requires_grad or feat.requires_grad)))
-                if fused:
+                if _hit("GNSteepestDescent", fused):
                     return _sd.GNSteepestDescent.forward(self, meta_parameter, num_iter, **kwargs)
                 if strict:
                     raise NotImplementedError("GNSteepestDescent: call outside the gfx950 hot path")
@@ -544,7 +565,7 @@ def install(strict=False, atom_cg=True, tomp=True, clf_head=True, localization=T
                             and variable[0].is_cuda and variable[0].shape[-1] == variable[0].shape[-2]
                             and variable[0].shape[-1] ** 2 <= 16 and not kw.get("debug", False)
                             and kw.get("standard_alpha", True) and kw.get("cg_eps", 0.0) == 0.0)
-                    if fast:
+                    if _hit("ConjugateGradient", fast):
                         return _optimization.ConjugateGradient(problem, variable, *args, **kw)
                     if strict:
                         raise NotImplementedError("ConjugateGradient: problem outside the gfx950 hot path")
@@ -566,7 +587,7 @@ def install(strict=False, atom_cg=True, tomp=True, clf_head=True, localization=T
                             and not any(kw.get(k, False) for k in ("debug", "analyze", "plotting"))
                             and kw.get("standard_alpha", True) and kw.get("cg_eps", 0.0) == 0.0
                             and kw.get("direction_forget_factor", 0) == 0)
-                    if fast:
+                    if _hit("GaussNewtonCG", fast):
                         return _optimization.GaussNewtonCG(problem, variable, *args, **kw)
                     if strict:
                         raise NotImplementedError("GaussNewtonCG: problem outside the gfx950 hot path")
