@@ -28,12 +28,15 @@ Prints ONE JSON line on rank 0.  Besides the contract fields:
   other_workloads the other BASELINE configs on this GPU (tools/workloads.py): PrDiMP-50 frame, ToMP model prediction, LWL
                   few-shot learner (3 and 4 iterations), ATOM CG update -- ms, algorithmic bytes / flops, roofline fraction.
   end_to_end      the DiMP-50 frame with a stock-PyTorch ResNet-50 (conv1..layer3) in front: backbone ms, frames/s.
-  cpu_baseline    the reference's CPU execution path (torch-CPU port, oracle/frame_port.py) on this host, pinned threads
-                  (+ `one_thread`: the same on a single thread).
-  gpu_stock_baseline  the same stock-PyTorch op sequence (MIOpen grouped convs) on this GPU: what a user of the reference
-                  gets on ROCm today without these kernels (SURVEY.md section 8d "Stock-GPU baseline").
+  cpu_baseline    the reference's CPU execution path on this host, pinned threads: kind "reference" = the reference's OWN modules
+                  (apply_filter + DiMPSteepestDescentGN.forward, imported unmodified from the bundle oracle/_ref that
+                  oracle/make_ref_bundle.py writes; oracle/frame_ref.py), with the torch port of the same op sequence
+                  (oracle/frame_port.py) beside it under "port" and `one_thread`; kind "port" alone when the bundle is absent.
+  gpu_stock_baseline  the same reference modules `.to('cuda')` in stock PyTorch-ROCm (MIOpen grouped convs) on this GPU: what a
+                  user of the reference gets on ROCm today without these kernels (SURVEY.md section 8d "Stock-GPU baseline").
 """
 import argparse
+import contextlib
 import csv
 import ctypes
 import glob
@@ -76,14 +79,34 @@ def run_frames(st, pool, first, count):
         st.step(pool[f % POOL], slot=f % n, num_iter=NUM_ITER)
 
 
-def stock_baseline(cfg, n, device, budget_s, min_frames=10, max_frames=2000, threads=None):
-    """The reference's op sequence in stock PyTorch (oracle/frame_port.TorchCpuTracker) on `device`, same workload,
-    bounded sample.  Baseline leg only: nothing measured as the product touches oracle/."""
-    from oracle.frame_port import TorchCpuTracker
+def reference_available():
+    """The reference's own modules importable here?  (/root/reference in the build container; on the GPU box the byte-for-byte
+    bundle oracle/_ref/reference that oracle/make_ref_bundle.py writes -- git-ignored, travels with the snapshot.)"""
+    try:
+        from oracle import frame_ref
+        return frame_ref.available()
+    except Exception:                                         # noqa: BLE001
+        return False
+
+
+def stock_baseline(cfg, n, device, budget_s, min_frames=10, max_frames=2000, threads=None, impl="port"):
+    """The same workload in stock PyTorch on `device`, bounded sample.  impl "reference": the reference's OWN modules
+    (`ltr.models.layers.filter.apply_filter` + `DiMPSteepestDescentGN.forward`, optimizer.py:85-170, imported unmodified:
+    oracle/frame_ref.ReferenceTracker); impl "port": the torch restatement of that op sequence (oracle/frame_port.TorchCpuTracker).
+    Baseline leg only: nothing measured as the product touches oracle/."""
     host = os.cpu_count() or 1
     threads = min(threads or CPU_THREADS, host)
     pool = make_pool(cfg, 99, device)
-    tr = TorchCpuTracker(cfg, n, seed=1234, threads=threads, device=device)
+    if impl == "reference":
+        from oracle.frame_ref import ReferenceTracker
+        tr = ReferenceTracker(cfg, n, seed=1234, threads=threads, device=device)
+        what = ("the reference's own Python (ltr/models/layers/filter.py apply_filter + ltr/models/target_classifier/optimizer.py "
+                "DiMPSteepestDescentGN.forward, unmodified bundle oracle/_ref)")
+    else:
+        from oracle.frame_port import TorchCpuTracker
+        tr = TorchCpuTracker(cfg, n, seed=1234, threads=threads, device=device)
+        what = ("torch port of the reference's op sequence (grouped F.conv2d apply_filter / feature-as-weights adjoint, 3 passes per "
+                "iteration, DistanceMap)")
     sync = torch.cuda.synchronize if str(device).startswith("cuda") else (lambda: None)
     for f in range(3):
         tr.step(pool[f % POOL], f % n, NUM_ITER)
@@ -98,13 +121,42 @@ def stock_baseline(cfg, n, device, budget_s, min_frames=10, max_frames=2000, thr
     sync()
     dt = time.perf_counter() - t0
     if str(device).startswith("cuda"):
-        return {"value": round(frames / dt, 2), "unit": "frames/s", "kind": "port",
-                "sample": f"{frames} frames of the same workload in {dt:.1f}s: the reference's op sequence (grouped "
-                          f"F.conv2d apply_filter / feature-as-weights adjoint, 3 passes per iteration, DistanceMap) in "
-                          f"stock PyTorch-ROCm on this GPU, fp32, eager"}
-    return {"value": round(frames / dt, 3), "unit": "frames/s", "cores": threads, "host_cores": host, "kind": "port",
-            "sample": f"{frames} frames of the same workload in {dt:.1f}s (torch-CPU port of the reference path, fp32, "
+        return {"value": round(frames / dt, 2), "unit": "frames/s", "kind": impl,
+                "sample": f"{frames} frames of the same workload in {dt:.1f}s: {what} in stock PyTorch-ROCm on this GPU, fp32, eager"}
+    return {"value": round(frames / dt, 3), "unit": "frames/s", "cores": threads, "host_cores": host, "kind": impl,
+            "sample": f"{frames} frames of the same workload in {dt:.1f}s ({what}, fp32, "
                       f"{threads} threads pinned on a {host}-core host)"}
+
+
+def baselines(cfg, n, dev, want_cpu, want_gpu):
+    """cpu_baseline / gpu_stock_baseline objects.  With the reference importable the headline of each is kind "reference" (its own
+    modules) and the port sits beside it under "port"; without it kind "port" (and `reference_unavailable` says why)."""
+    out = {}
+    ref = reference_available()
+    if want_cpu:
+        if ref:
+            cpu = stock_baseline(cfg, n, "cpu", budget_s=12.0, impl="reference")
+            port = stock_baseline(cfg, n, "cpu", budget_s=6.0, impl="port")
+            cpu["port"] = {k: port[k] for k in ("value", "unit", "cores", "sample")}
+            one = stock_baseline(cfg, n, "cpu", budget_s=5.0, min_frames=3, threads=1, impl="reference")
+        else:
+            cpu = stock_baseline(cfg, n, "cpu", budget_s=12.0, impl="port")
+            cpu["reference_unavailable"] = "oracle/_ref/reference not built (python -B oracle/make_ref_bundle.py where /root/reference is mounted)"
+            one = stock_baseline(cfg, n, "cpu", budget_s=5.0, min_frames=3, threads=1, impl="port")
+        cpu["one_thread"] = {"value": one["value"], "unit": "frames/s", "cores": 1, "kind": one["kind"], "sample": one["sample"]}
+        cpu["threads_note"] = ("%d threads = the measured optimum of this path on the 256-core host class "
+                               "(profiles/r03a_cpu_thread_scaling.json)" % CPU_THREADS)
+        torch.set_num_threads(min(CPU_THREADS, os.cpu_count() or 1))
+        out["cpu_baseline"] = cpu
+    if want_gpu:
+        if ref:
+            gpu = stock_baseline(cfg, n, dev, budget_s=4.0, min_frames=50, impl="reference")
+            port = stock_baseline(cfg, n, dev, budget_s=3.0, min_frames=50, impl="port")
+            gpu["port"] = {k: port[k] for k in ("value", "unit", "sample")}
+        else:
+            gpu = stock_baseline(cfg, n, dev, budget_s=4.0, min_frames=50, impl="port")
+        out["gpu_stock_baseline"] = gpu
+    return out
 
 
 # ---------------------------------------------------------------------------------------------------------------------
@@ -311,6 +363,30 @@ def head_inclusive(cfg, n, dev, stream, frames=200):
                     "hipGraph replay, 25 frames per graph" % cfg["C"]}
 
 
+class _DryStream:
+    """Control-flow dry run (PT_BENCH_DRYRUN=1): stands in for a HIP stream on a box without a GPU."""
+    cuda_stream = 0
+
+    def synchronize(self):
+        pass
+
+
+class _DryState:
+    """Control-flow dry run: stands in for bench_frame.TrackState.  `step` does a token amount of host work so that the timed
+    region has a duration; nothing about it is a measurement."""
+
+    def __init__(self, cfg, n, seed):
+        self.cfg, self.n = dict(cfg), n
+        self.acc = torch.zeros(64, dtype=torch.float64) + seed
+
+    def step(self, feat, slot, num_iter):
+        self.acc = (self.acc * 1.0000001 + slot + num_iter).sin_()
+
+    def bytes_per_solve(self, num_iter):
+        c = self.cfg
+        return 2 * num_iter * 4 * self.n * c["C"] * c["H"] * c["W"]
+
+
 def free_port():
     with socket.socket() as s:
         s.bind(("127.0.0.1", 0))
@@ -327,12 +403,19 @@ def main():
     ap.add_argument("--no-gpu-baseline", action="store_true")
     ap.add_argument("--no-roofline", action="store_true")
     ap.add_argument("--no-other", action="store_true", help="skip the other BASELINE workloads and the end-to-end leg")
+    ap.add_argument("--no-clock-warmup", action="store_true",
+                    help="skip the ~40 ms of idempotent pass replays in front of the warm-up frames (rounds 1-3 protocol)")
     ap.add_argument("--profile-child", action="store_true", help=argparse.SUPPRESS)
     ap.add_argument("--profile-mode", default="graph", choices=("graph", "eager"), help=argparse.SUPPRESS)
     ap.add_argument("--workload", default="dimp50", choices=("dimp50", "prdimp50"),
                     help="dimp50 = BASELINE configs[1] (the metric's configuration); prdimp50 = configs[2]'s per-GPU workload")
     args = ap.parse_args()
 
+    # PT_BENCH_DRYRUN=1: walk this file's control flow (launcher re-exec, rank wiring, build-on-rank-0 + barrier, warm-up, barrier-
+    # bracketed timed region, closing barrier, gather, ONE JSON line on rank 0) on a box WITHOUT a GPU: gloo instead of RCCL, a stub
+    # sequence state, no graphs, no kernel-level legs.  tests/test_bench_multirank_cpu.py runs it with 2 and 8 ranks; the line it
+    # prints says "data": "dry-run" and is not a measurement.
+    dry = os.environ.get("PT_BENCH_DRYRUN") == "1"
     world = int(os.environ.get("WORLD_SIZE", "1"))
     if args.gpus > 1 and world != args.gpus:
         if "WORLD_SIZE" in os.environ:
@@ -350,13 +433,21 @@ def main():
     sys.stdout.flush()
     json_fd = os.dup(1)
     os.dup2(2, 1)
-    torch.cuda.set_device(local_rank)
-    dev = torch.device("cuda", local_rank)
+    if dry:
+        dev = torch.device("cpu")
+        args.no_roofline = args.no_other = args.no_cpu_baseline = args.no_gpu_baseline = args.no_graph = True
+    else:
+        torch.cuda.set_device(local_rank)
+        dev = torch.device("cuda", local_rank)
+    sync_all = (lambda: None) if dry else torch.cuda.synchronize
     dist = None
     if world > 1 or "RANK" in os.environ:                      # under a launcher even one rank takes the RCCL path
         import torch.distributed as dist
         os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
-        dist.init_process_group(backend="nccl", device_id=dev)
+        if dry:
+            dist.init_process_group(backend="gloo")
+        else:
+            dist.init_process_group(backend="nccl", device_id=dev)
 
     if _lib.needs_build():
         if rank == 0:
@@ -366,11 +457,15 @@ def main():
     cfg_name = args.workload
     cfg = synth.DIMP50 if cfg_name == "dimp50" else synth.PRDIMP50
     n = cfg["memory"]
-    st = bench_frame.TrackState(cfg, n, seed=1234 + rank, device=dev,      # one independent sequence per GPU
-                                kind="dimp" if cfg_name == "dimp50" else "prdimp")
-    pool = make_pool(cfg, 4321 + rank, dev)
+    if dry:
+        st, pool = _DryState(cfg, n, seed=1234 + rank), torch.zeros(POOL, 1)
+        stream, on_stream = _DryStream(), (lambda s_: contextlib.nullcontext())
+    else:
+        st = bench_frame.TrackState(cfg, n, seed=1234 + rank, device=dev,      # one independent sequence per GPU
+                                    kind="dimp" if cfg_name == "dimp50" else "prdimp")
+        pool = make_pool(cfg, 4321 + rank, dev)
+        stream, on_stream = torch.cuda.Stream(device=dev), torch.cuda.stream
     K, Wm = args.steps, args.warmup
-    stream = torch.cuda.Stream(device=dev)
 
     if args.profile_child:                                     # the legs rocprofv3 traces, nothing else in the process
         with torch.cuda.stream(stream):
@@ -403,7 +498,7 @@ def main():
     G = K if K <= n else math.gcd(K, n)
     use_graph = (not args.no_graph) and G >= 5
     graphs = {}
-    with torch.cuda.stream(stream):
+    with on_stream(stream):
         run_frames(st, pool, 0, 2)                             # first-touch / code-object load outside everything
         stream.synchronize()
 
@@ -438,7 +533,7 @@ def main():
         # event-pair periods (last round trip kept).  The W warm-up frames then run directly in front of the timed region.
         period = None
         try:
-            for _ in range(12):                                # ~40 ms: the ramp was still visible after 10 (repeats 109.4 -> 108.4 us)
+            for _ in range(0 if (dry or args.no_clock_warmup) else 12):                                # ~40 ms: the ramp was still visible after 10 (repeats 109.4 -> 108.4 us)
                 period = {"corr": event_period_us(st, stream, 0), "adj": event_period_us(st, stream, 1)}
         except RuntimeError:
             period = None                                      # configuration outside the fast path: no replay helper
@@ -449,14 +544,15 @@ def main():
         stream.synchronize()
         if dist is not None:
             dist.barrier()
-        torch.cuda.synchronize()
+        sync_all()
         t0 = time.perf_counter()
         advance(Wm, K)
         stream.synchronize()
-        torch.cuda.synchronize()
+        sync_all()
         elapsed = time.perf_counter() - t0                     # this rank's K frames; the job's time is the MAX over ranks (gather below)
         if dist is not None:
             dist.barrier()                                     # closing barrier of the bracket: not part of anybody's K frames
+        elapsed_closed = time.perf_counter() - t0              # rounds 1-3 bracket: this rank's clock incl. the closing barrier
 
         # the same K-step region again (state keeps advancing; same graphs): where the reported value sits in this box's spread
         repeats = []
@@ -485,14 +581,15 @@ def main():
             roof["solve_level"] = {"algorithmic_bytes_per_frame": solve_bytes, "achieved_GBs": round(gbs, 1),
                                    "frac": round(gbs / HBM_PEAK_GBS, 4),
                                    "note": "2 feature reads per iteration x 5 iterations (SURVEY 8d) / measured frame time"}
-        launch = (f"hipGraph replay, {G} frames per graph ({K // G} replay(s) in the timed region, {len(graphs)} start slot(s); "
-                  f"clock warm-up: ~40 ms of idempotent pass replays in front of the warm-up frames)" if use_graph
+        launch = (f"hipGraph replay, {G} frames per graph ({K // G} replay(s) in the timed region, {len(graphs)} start slot(s)"
+                  + ("" if args.no_clock_warmup else "; clock warm-up: ~40 ms of idempotent pass replays in front of the warm-up frames")
+                  + ")" if use_graph
                   else "eager (18 launches per frame)")
         out = {
             "metric": "frames/sec DiMP-50 online track (288x288, 5 SD iters)" if cfg_name == "dimp50" else "frames/sec PrDiMP-50 online track (352x352, 5 SD iters)", "value": round(value, 2),
             "unit": "frames/s", "n_gpus": world, "steps": K, "warmup": Wm,
             "ms_per_step": round(1e3 * tmax / K, 5), "higher_is_better": True, "scaling": "weak",
-            "vs_baseline": None, "dtype": "f32", "data": "synthetic",
+            "vs_baseline": None, "dtype": "f32", "data": "dry-run (no GPU: control flow only, NOT a measurement)" if dry else "synthetic",
             "config": {"workload": ("BASELINE configs[1]: DiMP-50 single sequence per GPU; per frame classify(1x512x18x18) "
                                     "+ arg-max + memory insert + DiMPSteepestDescentGN(5 it) over n=50x512x18x18, K=4")
                        if cfg_name == "dimp50" else
@@ -504,6 +601,11 @@ def main():
             # self-verifying multi-GPU record: what every rank timed, and how many ranks the collective really had
             "per_rank": [{"rank": r, "frames": f, "seconds": round(sec, 6), "frames_per_s": round(f / sec, 1)}
                          for r, (f, sec) in enumerate(per_rank)],
+            # the two brackets side by side: `value` uses the MAX over ranks of each rank's own K frames (closing barrier
+            # outside); rounds 1-3 timed rank 0 up to and including the closing barrier
+            "bracket": {"max_rank_seconds": round(tmax, 6), "rank0_seconds_incl_closing_barrier": round(elapsed_closed, 6),
+                        "value_incl_closing_barrier": round(total_frames / elapsed_closed, 2),
+                        "clock_warmup": not (dry or args.no_clock_warmup)},
             "collective": {"backend": (dist.get_backend() if dist is not None else None),
                            "ranks": (dist.get_world_size() if dist is not None else 1),
                            "what": "barrier + one 16-byte all_gather of (frames, seconds); RCCL when backend == nccl"},
@@ -521,13 +623,7 @@ def main():
         if world == 1 and cfg_name == "dimp50":
             if not args.no_other:
                 out["other_workloads"] = workloads.all_other(dev)
-            if not args.no_cpu_baseline:
-                out["cpu_baseline"] = stock_baseline(cfg, n, "cpu", budget_s=12.0)
-                one = stock_baseline(cfg, n, "cpu", budget_s=5.0, min_frames=3, threads=1)
-                out["cpu_baseline"]["one_thread"] = {"value": one["value"], "unit": "frames/s", "cores": 1, "sample": one["sample"]}
-                torch.set_num_threads(min(CPU_THREADS, os.cpu_count() or 1))
-            if not args.no_gpu_baseline:
-                out["gpu_stock_baseline"] = stock_baseline(cfg, n, dev, budget_s=4.0, min_frames=50)
+            out.update(baselines(cfg, n, dev, not args.no_cpu_baseline, not args.no_gpu_baseline))
             if not args.no_other:                                # last: its MIOpen find mode must not touch the baseline above
                 try:
                     out["end_to_end"] = workloads.end_to_end(dev)
