@@ -383,6 +383,71 @@ int pt_track_frame_head_f32(const pt_sd_params* prm, float* filter, float* mem_f
                             int num_iter, float* scores_out, float* peak_out, void* ws, size_t ws_bytes, void* stream);
 
 /* ------------------------------------------------------------------------------------------------
+ * The WHOLE DiMP frame behind the backbone as one call (SURVEY.md section 8f items 1-3 joined to the frame above):
+ *   head -> classify + memory insert + re-optimisation (pt_track_frame_head_f32) -> localize_advanced on the score map
+ *   -> the tracker's glue between localisation and refinement ON THE DEVICE -> IoU-guided refinement of the proposals,
+ * with ONE host wait at the end.  Replaces the call sequence of `DiMP.track` (pytracking/tracker/dimp/dimp.py:95-131):
+ *   get_classification_features (:312-314), classify_target (:190-194), localize_target -> localize_advanced (:196-303),
+ *   `new_pos = sample_pos[scale_ind] + translation_vec` (:118), update_state (:486-495), refine_target_box (:650-678:
+ *   get_iounet_box :498-504, the jittered proposals :663-675), optimize_boxes_default / _relative (:725-788),
+ * whose two host round trips (the localisation result, the refined boxes) and the Python between them are the frame's
+ * critical path once the kernels are fast.  The proposals depend on the localisation result, so that dependency moves to
+ * the device (`k_frame_glue`): the same float32 operations in the reference's order; the frame's random numbers
+ * (`torch.rand(num_init_random_boxes, 4)`, :671) are drawn by the HOST generator as the reference does and passed in.
+ * When the localisation says `not_found` the reference skips the refinement (:121): here it still runs and the caller
+ * ignores boxes / IoU (the flag is in the result block).  S = 1 scale (the trackers' configuration).
+ *
+ * out_host: PT_FRAME_HOST_FLOATS floats of pinned host memory (device-writable):
+ *   [0,16)   the 16 localisation results of pt_localize_advanced_f32
+ *   [16,18)  self.pos after update_state (row, col);  [18,22) init_box (x, y, w, h) of get_iounet_box
+ *   [32,32+4P) refined boxes, [96,96+P) predicted IoU, [127] sequence word the call polls.   P = 1 + num_random <= 16.
+ * ---------------------------------------------------------------------------------------------- */
+#define PT_FRAME_HOST_FLOATS 128
+typedef struct pt_frame_glue {
+    float image_sz[2];                 /* self.image_sz (rows, cols) */
+    float img_sample_sz[2];            /* self.img_sample_sz */
+    double target_inside_ratio;        /* params.target_inside_ratio (default 0.2) */
+    double box_jitter_pos, box_jitter_sz;   /* params.box_jitter_pos / box_jitter_sz */
+    int use_classifier;                /* params.use_classifier (default 1): update_state(new_pos) before the refinement */
+    int num_random;                    /* params.num_init_random_boxes, 0 .. 15 */
+    float rand_u[60];                  /* torch.rand(num_random, 4) of this frame, row-major */
+} pt_frame_glue;
+typedef struct pt_frame_full {
+    /* head + solver: exactly the arguments of pt_track_frame_head_f32 */
+    const pt_sd_params* sd;
+    float *filter, *mem_feat, *mem_bb;
+    const float *sample_weight, *backbone_feat, *head_weight_tap_major;
+    float norm_scale, norm_eps;
+    int slot, n, Cin, C, H, W, K, num_iter;
+    float *scores_out, *peak_out;
+    /* localisation + glue */
+    const pt_localize_state* loc;
+    const pt_frame_glue* glue;
+    /* refinement: exactly the arguments of pt_iou_refine_f32 (boxes come from the glue) */
+    const pt_iou_dims* iou_dims;
+    const float *iou_params, *iou_prepared, *c3, *c4, *mod3, *mod4;
+    int iou_iter, relative;
+    float step_length4[4];
+    float step_decay;
+    /* optional second HIP stream.  The localisation + glue + refinement chain needs only the classification scores, which exist
+     * after the frame's first correlation; with aux_stream != NULL that chain forks there (event) and runs on aux_stream CONCURRENTLY
+     * with the steepest-descent iterations on `stream`, and `stream` joins it before the call's launches end (so everything queued on
+     * `stream` afterwards is ordered behind both chains).  Valid because in this synthetic frame the new
+     * sample's label box comes from the classification peak; `DiMP.track` labels the update with the REFINED state (dimp.py:139-145),
+     * which makes its update depend on the refinement: leave aux_stream NULL for that order.  On return the result block is
+     * host-visible; the filter / memory are complete in `stream` order, not necessarily yet. */
+    void* aux_stream;
+} pt_frame_full;
+size_t pt_track_frame_full_ws_bytes(const pt_frame_full* f);
+int pt_track_frame_full_f32(const pt_frame_full* f, float* out_host, void* ws, size_t ws_bytes, void* stream);
+/* the launches without the wait (graph capture, or a caller that waits on the stream itself) */
+int pt_track_frame_full_launch_f32(const pt_frame_full* f, float* out, void* ws, size_t ws_bytes, void* stream);
+
+/* Result buffers of the *_sync_* / full-frame entry points are verified once (pinned, device-writable) and remembered;
+ * call this before freeing such a buffer so that a later allocation at the same address is verified again. */
+void pt_host_buffer_forget(const void* p);
+
+/* ------------------------------------------------------------------------------------------------
  * Image-patch sampling in front of the backbone.
  * Replaces: pytracking/features/preprocessing.py:54-148 `sample_patch` (strided pre-downsampling, crop with replicate
  * padding, F.interpolate(mode='bilinear')) and :33-51 `sample_patch_multiscale` (S scales in one launch).

@@ -9,7 +9,7 @@ import subprocess
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.environ.get("PT_HOT_LIB", os.path.join(_HERE, "libpt_hot.so"))   # override: experiments only
-SOURCES = ["filter_kernels.hip", "fast_passes.hip", "sd_solver.hip", "mf_kernels.hip", "lwl_solver.hip", "atom_cg.hip", "atom_gn.hip", "tomp.hip", "localize.hip", "iou_refine.hip", "prroi.hip", "patch.hip", "api.hip"]
+SOURCES = ["filter_kernels.hip", "fast_passes.hip", "sd_solver.hip", "mf_kernels.hip", "lwl_solver.hip", "atom_cg.hip", "atom_gn.hip", "tomp.hip", "localize.hip", "iou_refine.hip", "prroi.hip", "patch.hip", "frame_full.hip", "api.hip"]
 HEADERS = ["common.h", "pt_internal.h", "rbuild.h", "sd_common.h", "mfma_gemm.h", "prroi_dev.h", os.path.join("..", "..", "include", "pt_hot.h")]
 # kernarg preload: leading scalar kernel parameters arrive in SGPRs at wave launch (kernels that take them that way only)
 HIPCC_FLAGS = ["--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-Wno-pass-failed", "-mllvm", "-amdgpu-kernarg-preload-count=14"]
@@ -59,6 +59,16 @@ class LocalizeState(ctypes.Structure):
 PT_LOC_FLAGS = ("normal", "hard_negative", "uncertain", "not_found")      # PT_LOC_* of include/pt_hot.h
 
 
+class FrameGlue(ctypes.Structure):
+    """`pt_frame_glue` of include/pt_hot.h."""
+    _fields_ = [("image_sz", ctypes.c_float * 2), ("img_sample_sz", ctypes.c_float * 2), ("target_inside_ratio", ctypes.c_double),
+                ("box_jitter_pos", ctypes.c_double), ("box_jitter_sz", ctypes.c_double), ("use_classifier", ctypes.c_int),
+                ("num_random", ctypes.c_int), ("rand_u", ctypes.c_float * 60)]
+
+
+PT_FRAME_HOST_FLOATS = 128
+
+
 class TompDims(ctypes.Structure):
     """`pt_tomp_dims` of include/pt_hot.h."""
     _fields_ = [(n, ctypes.c_int) for n in ("d_model", "nhead", "dim_ff", "n_enc", "n_dec", "H", "W", "max_res")]
@@ -80,6 +90,7 @@ EXPORTS = [
     "pt_localize_constants_f32", "pt_localize_advanced_f32", "pt_localize_advanced_sync_f32",
     "pt_iou_param_floats", "pt_iou_prepared_floats", "pt_iou_prepare_f32", "pt_iou_refine_ws_bytes", "pt_iou_refine_f32", "pt_iou_refine_sync_f32",
     "pt_track_frame_replay_pass_f32", "pt_sample_patch_f32", "pt_augment_patches_f32", "pt_track_frame_head_ws_bytes", "pt_track_frame_head_f32",
+    "pt_track_frame_full_ws_bytes", "pt_track_frame_full_f32", "pt_track_frame_full_launch_f32", "pt_host_buffer_forget",
 ]
 
 
@@ -95,6 +106,20 @@ class SdParams(ctypes.Structure):
         ("uni_weight", ctypes.c_float), ("normalize_label", ctypes.c_int), ("label_shrink", ctypes.c_float),
         ("has_softmax_reg", ctypes.c_int), ("softmax_reg", ctypes.c_float), ("label_threshold", ctypes.c_float),
     ]
+
+
+class FrameFull(ctypes.Structure):
+    """`pt_frame_full` of include/pt_hot.h."""
+    _fields_ = ([("sd", ctypes.POINTER(SdParams))]
+                + [(n, ctypes.c_void_p) for n in ("filter", "mem_feat", "mem_bb", "sample_weight", "backbone_feat",
+                                                  "head_weight_tap_major")]
+                + [("norm_scale", ctypes.c_float), ("norm_eps", ctypes.c_float)]
+                + [(n, ctypes.c_int) for n in ("slot", "n", "Cin", "C", "H", "W", "K", "num_iter")]
+                + [("scores_out", ctypes.c_void_p), ("peak_out", ctypes.c_void_p),
+                   ("loc", ctypes.POINTER(LocalizeState)), ("glue", ctypes.POINTER(FrameGlue)), ("iou_dims", ctypes.POINTER(IouDims))]
+                + [(n, ctypes.c_void_p) for n in ("iou_params", "iou_prepared", "c3", "c4", "mod3", "mod4")]
+                + [("iou_iter", ctypes.c_int), ("relative", ctypes.c_int), ("step_length4", ctypes.c_float * 4),
+                   ("step_decay", ctypes.c_float), ("aux_stream", ctypes.c_void_p)])
 
 
 def _build_flags():
@@ -272,6 +297,15 @@ def lib():
     L.pt_track_frame_head_ws_bytes.argtypes = [i] * 6
     L.pt_track_frame_head_f32.restype = i
     L.pt_track_frame_head_f32.argtypes = [ctypes.POINTER(SdParams), vp, vp, vp, vp, vp, vp, f, f] + [i] * 8 + [vp, vp, vp, sz, vp]
+    ffp = ctypes.POINTER(FrameFull)
+    L.pt_track_frame_full_ws_bytes.restype = sz
+    L.pt_track_frame_full_ws_bytes.argtypes = [ffp]
+    L.pt_track_frame_full_f32.restype = i
+    L.pt_track_frame_full_f32.argtypes = [ffp, vp, vp, sz, vp]
+    L.pt_track_frame_full_launch_f32.restype = i
+    L.pt_track_frame_full_launch_f32.argtypes = [ffp, vp, vp, sz, vp]
+    L.pt_host_buffer_forget.restype = None
+    L.pt_host_buffer_forget.argtypes = [vp]
     L.pt_sample_patch_f32.restype = i
     L.pt_sample_patch_f32.argtypes = [vp, i, i, i, ctypes.POINTER(PatchGeom), i, vp, i, i, vp]
     L.pt_augment_patches_f32.restype = i

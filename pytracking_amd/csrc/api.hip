@@ -1,5 +1,7 @@
 // C-ABI entry points that are thin compositions of the kernels: filter-layer ops and the benchmark frame.
 #include <algorithm>
+#include <atomic>
+#include <chrono>
 #include "common.h"
 #include "pt_internal.h"
 
@@ -16,6 +18,48 @@ extern "C" const char* pt_strerror(int status) {
 }
 
 extern "C" int pt_abi_version(void) { return 1; }
+
+// ---------------------------------------------------------------------------------------------------
+// host-polled result buffers (declared in pt_internal.h)
+// ---------------------------------------------------------------------------------------------------
+static std::atomic<const void*> g_pinned_seen[8];
+static std::atomic<unsigned> g_pinned_next{0};
+
+bool pt_pinned_host_checked(const void* p) {
+    if (!p) return false;
+    for (auto& s : g_pinned_seen)
+        if (s.load(std::memory_order_acquire) == p) return true;
+    hipPointerAttribute_t at;
+    if (hipPointerGetAttributes(&at, p) != hipSuccess || at.type != hipMemoryTypeHost) {
+        (void)hipGetLastError();
+        return false;
+    }
+    g_pinned_seen[g_pinned_next.fetch_add(1, std::memory_order_relaxed) & 7].store(p, std::memory_order_release);
+    return true;
+}
+
+extern "C" void pt_host_buffer_forget(const void* p) {
+    for (auto& s : g_pinned_seen) {
+        const void* cur = p;
+        s.compare_exchange_strong(cur, nullptr, std::memory_order_acq_rel);
+    }
+}
+
+int pt_poll_word(volatile float* word, float seq, const void* buf, void* stream) {
+    const auto t0 = std::chrono::steady_clock::now();
+    for (unsigned spin = 1;; ++spin) {
+        if (*word == seq) break;
+        __builtin_ia32_pause();
+        if ((spin & 0xFFFF) == 0 && std::chrono::steady_clock::now() - t0 > std::chrono::seconds(2)) {
+            pt_host_buffer_forget(buf);                                  // whatever this address is now, verify it again next time
+            if (hipStreamSynchronize((hipStream_t)stream) != hipSuccess) return PT_ERR_LAUNCH;
+            if (*word != seq) return PT_ERR_LAUNCH;
+            break;
+        }
+    }
+    __atomic_thread_fence(__ATOMIC_ACQUIRE);
+    return PT_OK;
+}
 
 // ---------------------------------------------------------------------------------------------------
 // apply_filter / apply_feat_transpose
@@ -144,7 +188,7 @@ extern "C" int pt_track_frame_f32(const pt_sd_params* prm, float* filter, float*
         // Fast path: the first correlation of the solve reads sample `slot` from test_feat (and stores it into the
         // memory slot, dimp.py:429-441); its score row under the current filter IS the classification of the test
         // frame (dimp.py:190-194 -> linear_filter.py:75-80).  Localisation runs in the init stage.
-        PtClsFin cls = {nullptr, 0, slot, scores_out, peak_out, mem_bb};
+        PtClsFin cls = {nullptr, 0, slot, scores_out, peak_out, mem_bb, nullptr};
         return pt_sd_solve_impl(prm, filter, mem_feat, CHW, mem_bb, sample_weight, n, C, H, W, K, num_iter,
                                 base + cv.w_iters, nullptr, base + cv.sd, (cv.total - cv.sd) * sizeof(float), st,
                                 /*copy_w0=*/false, /*w_final=*/filter, &cls, /*src=*/test_feat);
@@ -157,7 +201,7 @@ extern "C" int pt_track_frame_f32(const pt_sd_params* prm, float* filter, float*
     if (rc) return rc;
     // 2. localisation (arg-max, box re-centring) runs as the prologue of the solver's map kernel;
     // 3. re-optimise the filter over the whole memory (dimp.py:633-639); the last iterate lands in `filter`
-    PtClsFin cls = {base + cv.spart1, p1.KS, slot, scores_out, peak_out, mem_bb};
+    PtClsFin cls = {base + cv.spart1, p1.KS, slot, scores_out, peak_out, mem_bb, nullptr};
     return pt_sd_solve_impl(prm, filter, mem_feat, CHW, mem_bb, sample_weight, n, C, H, W, K, num_iter,
                             base + cv.w_iters, nullptr, base + cv.sd, (cv.total - cv.sd) * sizeof(float), st,
                             /*copy_w0=*/false, /*w_final=*/filter, &cls, /*src=*/nullptr);
@@ -189,6 +233,14 @@ extern "C" int pt_track_frame_head_f32(const pt_sd_params* prm, float* filter, f
                                        const float* head_weight_tap_major, float norm_scale, float norm_eps, int slot, int n,
                                        int Cin, int C, int H, int W, int K, int num_iter, float* scores_out, float* peak_out,
                                        void* ws, size_t ws_bytes, void* stream) {
+    return pt_track_frame_head_impl(prm, filter, mem_feat, mem_bb, sample_weight, backbone_feat, head_weight_tap_major, norm_scale,
+                                    norm_eps, slot, n, Cin, C, H, W, K, num_iter, scores_out, peak_out, ws, ws_bytes, stream, nullptr);
+}
+
+int pt_track_frame_head_impl(const pt_sd_params* prm, float* filter, float* mem_feat, float* mem_bb, const float* sample_weight,
+                             const float* backbone_feat, const float* head_weight_tap_major, float norm_scale, float norm_eps, int slot,
+                             int n, int Cin, int C, int H, int W, int K, int num_iter, float* scores_out, float* peak_out, void* ws,
+                             size_t ws_bytes, void* stream, void* after_init_event) {
     if (!prm || !filter || !mem_feat || !mem_bb || !backbone_feat || !head_weight_tap_major || !scores_out || !peak_out || !ws)
         return PT_ERR_NULL;
     if (n <= 0 || Cin <= 0 || C <= 0 || H <= 0 || W <= 0 || K <= 0 || num_iter < 0 || slot < 0 || slot >= n) return PT_ERR_SHAPE;
@@ -206,7 +258,7 @@ extern "C" int pt_track_frame_head_f32(const pt_sd_params* prm, float* filter, f
     // 2. classification of that sample = its score row of the solve's first correlation; localisation; re-optimisation
     TfCarve cv = tf_carve(n, C, H, W, K);
     float* fb = base + hc.frame;
-    PtClsFin cls = {nullptr, 0, slot, scores_out, peak_out, mem_bb};
+    PtClsFin cls = {nullptr, 0, slot, scores_out, peak_out, mem_bb, after_init_event};
     hipStream_t st = (hipStream_t)stream;
     const int OH = H + (K + 1) % 2, OW = W + (K + 1) % 2;
     PtFast f = pt_fast_plan(n, C, H, W, K, K, OH, OW);
@@ -218,7 +270,7 @@ extern "C" int pt_track_frame_head_f32(const pt_sd_params* prm, float* filter, f
     PtPlan p1 = pt_make_plan(1, C, H, W, K, K, OH, OW);
     rc = pt_launch_corr(p1, mem_feat + (long)slot * CHW, CHW, filter, fb + cv.spart1, st, nullptr);
     if (rc) return rc;
-    PtClsFin cls2 = {fb + cv.spart1, p1.KS, slot, scores_out, peak_out, mem_bb};
+    PtClsFin cls2 = {fb + cv.spart1, p1.KS, slot, scores_out, peak_out, mem_bb, after_init_event};
     return pt_sd_solve_impl(prm, filter, mem_feat, CHW, mem_bb, sample_weight, n, C, H, W, K, num_iter, fb + cv.w_iters, nullptr,
                             fb + cv.sd, (cv.total - cv.sd) * sizeof(float), st, /*copy_w0=*/false, /*w_final=*/filter, &cls2,
                             /*src=*/nullptr);

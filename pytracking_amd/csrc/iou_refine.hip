@@ -915,21 +915,18 @@ extern "C" int pt_iou_refine_sync_f32(const pt_iou_dims* d, const float* params,
     if (P > FUSED_MAX_P) return PT_ERR_UNSUPPORTED;
     if (!pt_pinned_host_checked(out_host) || pt_stream_is_capturing(stream)) return PT_ERR_UNSUPPORTED;
     volatile float* word = out_host + 95;
-    float seq = *word + 1.0f;
-    if (!(seq >= 1.0f && seq < 8388608.0f)) seq = 1.0f;                 // stays an exactly representable integer
+    const float seq = pt_next_seq(word);
     const int rc = iou_refine_impl(d, params, prepared, c3, c4, mod3, mod4, init_boxes_host, true, out_host, out_host + 64, P, num_iter,
                                    step_length4, step_decay, relative, backtrack, ws, ws_bytes, seq, out_host + 95, stream);
     if (rc) return rc;
-    const auto t0 = std::chrono::steady_clock::now();
-    for (unsigned spin = 1;; ++spin) {
-        if (*word == seq) break;
-        __builtin_ia32_pause();
-        if ((spin & 0xFFFF) == 0 && std::chrono::steady_clock::now() - t0 > std::chrono::seconds(2)) {
-            if (hipStreamSynchronize((hipStream_t)stream) != hipSuccess) return PT_ERR_LAUNCH;
-            if (*word != seq) return PT_ERR_LAUNCH;
-            break;
-        }
-    }
-    __atomic_thread_fence(__ATOMIC_ACQUIRE);
-    return PT_OK;
+    return pt_poll_word(word, seq, out_host, stream);
+}
+
+// launch half for compositions (frame_full.hip): proposals in DEVICE memory, results + sequence word wherever the caller points
+int pt_iou_refine_launch(const pt_iou_dims* d, const float* params, const float* prepared, const float* c3, const float* c4,
+                         const float* mod3, const float* mod4, const float* init_boxes_dev, float* boxes_out, float* iou_out, int P,
+                         int num_iter, const float* step_length4, float step_decay, int relative, int backtrack, void* ws,
+                         size_t ws_bytes, float seq, float* seq_word, void* stream) {
+    return iou_refine_impl(d, params, prepared, c3, c4, mod3, mod4, init_boxes_dev, false, boxes_out, iou_out, P, num_iter,
+                           step_length4, step_decay, relative, backtrack, ws, ws_bytes, seq, seq_word, stream);
 }

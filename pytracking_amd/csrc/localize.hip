@@ -196,8 +196,8 @@ extern "C" int pt_localize_constants_f32(const pt_localize_state* st, int S, int
     return PT_OK;
 }
 
-static int localize_launch(const float* scores, const float* scores_hn, const pt_localize_params* prm, float* out16,
-                           int S, int H, int W, float seq, void* stream) {
+int pt_localize_launch(const float* scores, const float* scores_hn, const pt_localize_params* prm, float* out16, int S, int H,
+                       int W, float seq, void* stream) {
     if (!scores || !prm || !out16) return PT_ERR_NULL;
     if (S <= 0 || H <= 0 || W <= 0) return PT_ERR_SHAPE;
     if (S > 8) return PT_ERR_UNSUPPORTED;
@@ -212,7 +212,7 @@ static int localize_launch(const float* scores, const float* scores_hn, const pt
 
 extern "C" int pt_localize_decide_f32(const float* scores, const float* scores_hn, const pt_localize_params* prm,
                                       float* out16, int S, int H, int W, void* stream) {
-    return localize_launch(scores, scores_hn, prm, out16, S, H, W, 0.f, stream);
+    return pt_localize_launch(scores, scores_hn, prm, out16, S, H, W, 0.f, stream);
 }
 
 extern "C" int pt_localize_advanced_f32(const float* scores, const float* scores_hn, const pt_localize_state* st,
@@ -220,7 +220,7 @@ extern "C" int pt_localize_advanced_f32(const float* scores, const float* scores
     pt_localize_params q;
     const int rc = pt_localize_constants_f32(st, S, H, W, &q);
     if (rc) return rc;
-    return localize_launch(scores, scores_hn, &q, out16, S, H, W, 0.f, stream);
+    return pt_localize_launch(scores, scores_hn, &q, out16, S, H, W, 0.f, stream);
 }
 
 // The same, and the call returns when the 16 results are readable by the host: `out16_host` must be pinned host memory
@@ -236,22 +236,10 @@ extern "C" int pt_localize_advanced_sync_f32(const float* scores, const float* s
     int rc = pt_localize_constants_f32(st, S, H, W, &q);
     if (rc) return rc;
     volatile float* word = out16_host + 15;
-    float seq = *word + 1.0f;
-    if (!(seq >= 1.0f && seq < 8388608.0f)) seq = 1.0f;                 // stays an exactly representable integer
-    rc = localize_launch(scores, scores_hn, &q, out16_host, S, H, W, seq, stream);
+    const float seq = pt_next_seq(word);
+    rc = pt_localize_launch(scores, scores_hn, &q, out16_host, S, H, W, seq, stream);
     if (rc) return rc;
-    const auto t0 = std::chrono::steady_clock::now();
-    for (unsigned spin = 1;; ++spin) {
-        if (*word == seq) break;
-        __builtin_ia32_pause();
-        if ((spin & 0xFFFF) == 0 && std::chrono::steady_clock::now() - t0 > std::chrono::seconds(2)) {
-            if (hipStreamSynchronize((hipStream_t)stream) != hipSuccess) return PT_ERR_LAUNCH;
-            if (*word != seq) return PT_ERR_LAUNCH;
-            break;
-        }
-    }
-    __atomic_thread_fence(__ATOMIC_ACQUIRE);
-    return PT_OK;
+    return pt_poll_word(word, seq, out16_host, stream);
 }
 
 extern "C" int pt_max2d_f32(const float* a, float* max_val, long long* argmax, int n, int H, int W, void* stream) {

@@ -135,6 +135,7 @@ struct PtClsFin {
     const float* spart;   // (KS, OH*OW) classification partials
     int KS, slot;
     float *scores, *peak, *mem_bb;
+    void* after_init;     // optional hipEvent_t recorded behind the launch that writes scores / peak (frame_full.hip forks there)
 };
 
 int pt_sd_solve_impl(const pt_sd_params* prm, const float* w_in, const float* feat, long feat_stride_n, const float* bb,
@@ -157,23 +158,34 @@ int pt_launch_prroi_bwd_coor2(const float* const grad_out[2], const float* const
                               const float* rois, int R, int slices, hipStream_t st);
 
 
-// Result buffers of the *_sync_* entry points (pinned host memory the device writes and the host polls).  The pointer class
-// is verified once per buffer; the verified set is small, lock-free and shared by all threads (one tracker per stream / thread
-// alternates between its own buffers, so a single cached pointer would re-verify on every call and race between threads).
-#include <atomic>
-static inline bool pt_pinned_host_checked(const void* p) {
-    static std::atomic<const void*> seen[8];
-    static std::atomic<unsigned> next{0};
-    for (auto& s : seen)
-        if (s.load(std::memory_order_acquire) == p) return true;
-    hipPointerAttribute_t at;
-    if (hipPointerGetAttributes(&at, p) != hipSuccess || at.type != hipMemoryTypeHost) {
-        (void)hipGetLastError();
-        return false;
-    }
-    seen[next.fetch_add(1, std::memory_order_relaxed) & 7].store(p, std::memory_order_release);
-    return true;
+// Result buffers of the *_sync_* / full-frame entry points (pinned host memory the device writes and the host polls).  The pointer
+// class is verified once per buffer; the verified set is small, lock-free, shared by all threads AND by all translation units (it
+// lives in api.hip).  A buffer is dropped from the set by pt_host_buffer_forget() (the C ABI's release hook) and whenever a poll runs
+// into its time-out, so a pinned buffer that was freed and whose address came back as pageable / device memory is verified again.
+bool pt_pinned_host_checked(const void* p);
+// spin on `word` until it holds `seq` (system-scope acquire); after 2 s: forget the buffer, hipStreamSynchronize, re-check
+int pt_poll_word(volatile float* word, float seq, const void* buf, void* stream);
+// next value of a result buffer's sequence word (an exactly representable integer >= 1)
+static inline float pt_next_seq(volatile float* word) {
+    float seq = *word + 1.0f;
+    if (!(seq >= 1.0f && seq < 8388608.0f)) seq = 1.0f;
+    return seq;
 }
+
+// pt_track_frame_head_f32 with an event recorded as soon as the classification scores are queued (api.hip)
+int pt_track_frame_head_impl(const pt_sd_params* prm, float* filter, float* mem_feat, float* mem_bb, const float* sample_weight,
+                             const float* backbone_feat, const float* head_weight_tap_major, float norm_scale, float norm_eps, int slot,
+                             int n, int Cin, int C, int H, int W, int K, int num_iter, float* scores_out, float* peak_out, void* ws,
+                             size_t ws_bytes, void* stream, void* after_init_event);
+
+// launch halves of the host-polled entry points, for compositions (frame_full.hip)
+int pt_localize_launch(const float* scores, const float* scores_hn, const pt_localize_params* prm, float* out16, int S, int H,
+                       int W, float seq, void* stream);
+int pt_iou_refine_launch(const pt_iou_dims* d, const float* params, const float* prepared, const float* c3, const float* c4,
+                         const float* mod3, const float* mod4, const float* init_boxes_dev, float* boxes_out, float* iou_out, int P,
+                         int num_iter, const float* step_length4, float step_decay, int relative, int backtrack, void* ws,
+                         size_t ws_bytes, float seq, float* seq_word, void* stream);
+
 // A host-polled result cannot be waited for while the stream is being captured into a graph (nothing executes): refuse at once
 // instead of spinning into the 2 s fallback.
 static inline bool pt_stream_is_capturing(void* stream) {

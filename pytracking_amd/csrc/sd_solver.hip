@@ -630,6 +630,7 @@ static int sd_solve_fast(const PtFast& f, const pt_sd_params* prm, const float* 
     }
     else hipLaunchKernelGGL(k_fast_init, dim3(n), dim3(384), 0, st, a);
     PT_CHECK_LAUNCH();
+    if (cls && cls->after_init && hipEventRecord((hipEvent_t)cls->after_init, st) != hipSuccess) return PT_ERR_LAUNCH;
     if (num_iter == 0) {
         if (!want_loss) return PT_OK;
         a.R = nullptr;
@@ -734,6 +735,7 @@ int pt_sd_solve_impl(const pt_sd_params* prm, const float* w_in, const float* fe
 
     hipLaunchKernelGGL(k_sd_maps, dim3(n), dim3(256), 0, st, a);
     PT_CHECK_LAUNCH();
+    if (cls && cls->after_init && hipEventRecord((hipEvent_t)cls->after_init, st) != hipSuccess) return PT_ERR_LAUNCH;
     if (num_iter == 0 && !want_loss) return PT_OK;
     int rc = pt_launch_corr(p, feat, feat_stride_n, w_in, a.spart, st);
     if (rc) return rc;

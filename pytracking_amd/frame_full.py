@@ -1,0 +1,111 @@
+"""Host-side mirror of `pt_track_frame_full_f32` (include/pt_hot.h): the whole DiMP frame behind the backbone -- classification-
+feature head, classification + memory insert + re-optimisation, `localize_advanced`, the tracker's glue between localisation and
+refinement, IoU-guided refinement of the proposals -- as ONE ctypes call with ONE host wait.
+
+It replaces the call sequence of `DiMP.track` (pytracking/tracker/dimp/dimp.py:95-131): `get_classification_features`,
+`classify_target`, `localize_target`, `update_state`, `refine_target_box` (up to and including `optimize_boxes`).  `track()` itself is
+Python in the reference, so this entry point is for callers that own their frame loop (bench.py's `dimp50_frame_after_backbone`, an
+embedding that wants the 2 host round trips + the Python between them off the critical path); the unmodified tracker classes keep
+going through the per-call symbols `install()` rebinds.  The tracker object is read exactly like the rebound methods read it:
+`params`, `pos`, `target_sz`, `kernel_size`, `img_support_sz`, `img_sample_sz`, `image_sz`, `net.bb_regressor`, `iou_modulation`.
+"""
+import ctypes
+
+import torch
+
+from . import _lib, iou_refine as _ir, localization as _loc
+from .filter import _ptr, _require_device, device_guarded
+
+_NEG_INF = -float("inf")
+
+
+class FramePipeline:
+    """One sequence: `state` = bench_frame.TrackState with a head attached (filter, sample memory, solver parameters)."""
+
+    def __init__(self, state, num_iter, overlap=False):
+        """overlap: run the localisation + refinement chain on a second stream, concurrently with the steepest-descent iterations
+        (`pt_frame_full.aux_stream`, include/pt_hot.h: valid for the synthetic frame whose update label comes from the classification
+        peak; the reference's order -- update AFTER refinement -- is overlap=False)."""
+        if not hasattr(state, "head_w"):
+            raise ValueError("FramePipeline: TrackState.attach_head() first")
+        self.st, self.num_iter = state, int(num_iter)
+        dev = state.mem_feat.device
+        self.loc = _lib.LocalizeState()
+        self.glue = _lib.FrameGlue()
+        self.ff = f = _lib.FrameFull()
+        c = state.cfg
+        f.sd = ctypes.pointer(state.params)
+        f.filter, f.mem_feat, f.mem_bb = state.filter.data_ptr(), state.mem_feat.data_ptr(), state.mem_bb.data_ptr()
+        f.sample_weight, f.head_weight_tap_major = state.sample_weight.data_ptr(), state.head_w.data_ptr()
+        f.norm_scale, f.norm_eps = state.head_scale, state.head_eps
+        f.n, f.Cin, f.C, f.H, f.W, f.K, f.num_iter = state.n, state.head_cin, c["C"], c["H"], c["W"], c["K"], self.num_iter
+        f.scores_out, f.peak_out = state.scores.data_ptr(), state.peak.data_ptr()
+        f.loc, f.glue = ctypes.pointer(self.loc), ctypes.pointer(self.glue)
+        host = torch.zeros(_lib.PT_FRAME_HOST_FLOATS, dtype=torch.float32).pin_memory()
+        self._host, self._host_np, self._host_ptr = host, host.numpy(), ctypes.c_void_p(host.data_ptr())
+        self._ws = None
+        self._dims_key = None
+        self._dev = dev
+        self._aux = torch.cuda.Stream(device=dev) if overlap else None
+        f.aux_stream = self._aux.cuda_stream if overlap else None
+
+    def __del__(self):
+        try:
+            _lib.lib().pt_host_buffer_forget(self._host_ptr)
+        except Exception:                                         # noqa: BLE001 -- interpreter shutdown
+            pass
+
+    def _bind_iou(self, net, c3, c4, P):
+        key = (id(net), c3.shape, c4.shape, P)
+        if key != self._dims_key:
+            self._dims = _lib.IouDims(c3.shape[1], c4.shape[1], net.fc3_rt.linear.out_features, net.fc4_rt.linear.out_features,
+                                      c3.shape[2], c3.shape[3], c4.shape[2], c4.shape[3])
+            self.ff.iou_dims = ctypes.pointer(self._dims)
+            self.glue.num_random = P - 1
+            nb = _lib.lib().pt_track_frame_full_ws_bytes(ctypes.byref(self.ff))
+            if nb == 0:
+                raise NotImplementedError("pt_track_frame_full_f32: configuration not covered by the gfx950 kernels")
+            if self._ws is None or self._ws.numel() < nb:
+                self._ws = torch.empty(nb, dtype=torch.uint8, device=self._dev)
+            self._dims_key = key
+        pack, prepared = _ir._packs(net, self._dims)
+        self.ff.iou_params, self.ff.iou_prepared = pack.data_ptr(), prepared.data_ptr()
+
+    @device_guarded
+    def run(self, tracker, backbone_feat, slot, iou_features, sample_pos, sample_scales, rand_u):
+        """backbone_feat (Cin,H,W) device; iou_features (c3 (1,C3,H3,W3), c4 (1,C4,H4,W4)) device; sample_pos (1,2), sample_scales (1)
+        host, as `track()` forms them; rand_u = `torch.rand(num_init_random_boxes, 4)` of this frame (host).
+        -> dict(translation_vec (2), scale_ind, flag, pos (2) after update_state, init_box (4), boxes (P,4), iou (P)), CPU tensors."""
+        p = tracker.params
+        c3, c4 = iou_features
+        _require_device(backbone_feat, c3, c4)
+        num_random = int(rand_u.shape[0]) if rand_u is not None else 0
+        P = 1 + num_random
+        net = tracker.net.bb_regressor
+        if net.training:
+            raise NotImplementedError("IoU refinement: eval-mode network")
+        self._bind_iou(net, c3, c4, P)
+        f, g = self.ff, self.glue
+        _loc.tracker_state(tracker, sample_pos, sample_scales, self.loc)
+        g.image_sz[:] = tracker.image_sz.tolist()
+        g.img_sample_sz[:] = tracker.img_sample_sz.tolist()
+        g.target_inside_ratio = p.get('target_inside_ratio', 0.2)
+        g.box_jitter_pos, g.box_jitter_sz = p.box_jitter_pos, p.box_jitter_sz
+        g.use_classifier = int(bool(p.get('use_classifier', True)))
+        if num_random:
+            g.rand_u[:4 * num_random] = rand_u.reshape(-1).tolist()
+        f.backbone_feat, f.slot = backbone_feat.data_ptr(), int(slot)
+        f.c3, f.c4 = c3.data_ptr(), c4.data_ptr()
+        mod3, mod4 = tracker.iou_modulation
+        f.mod3, f.mod4 = mod3.data_ptr(), mod4.data_ptr()
+        sl = p.box_refinement_step_length
+        f.step_length4[:] = [sl[0], sl[0], sl[1], sl[1]] if isinstance(sl, (tuple, list)) else [float(sl)] * 4
+        f.step_decay = p.box_refinement_step_decay
+        f.iou_iter = p.box_refinement_iter
+        f.relative = int(p.get('box_refinement_space', 'default') == 'relative')
+        rc = _lib.lib().pt_track_frame_full_f32(ctypes.byref(f), self._host_ptr, self._ws.data_ptr(), self._ws.numel(),
+                                                torch.cuda.current_stream().cuda_stream)
+        _lib.check(rc, "pt_track_frame_full_f32")
+        h = torch.from_numpy(self._host_np.copy())
+        return {"translation_vec": h[4:6], "scale_ind": int(h[1]), "flag": _lib.PT_LOC_FLAGS[int(h[0])], "pos": h[16:18],
+                "init_box": h[18:22], "boxes": h[32:32 + 4 * P].view(P, 4), "iou": h[96:96 + P], "peak": h[2:4]}

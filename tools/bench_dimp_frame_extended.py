@@ -8,8 +8,16 @@ ResNet-50 backbone itself is out of scope and absent here):
 
 Synthetic inputs as section 8(d) prescribes (N(0,1) IoU features 1x256x36x36 / 1x256x18x18).  Host wall time per frame
 incl. the two device->host copies the tracker needs.   python tools/bench_dimp_frame_extended.py [--frames 300]
+
+Last row, `one_call`: the same frame through `pt_track_frame_full_f32` (pytracking_amd/frame_full.py) -- the proposals are formed on
+the device from the localisation result (the reference's glue, dimp.py:118-131,486-504,663-675) and the host waits once.
+
+The timed loops run with the cyclic garbage collector off, as `timeit` does: a generation-2 collection of a process that has torch
+loaded is a ~30 ms stall (profiles/r05f_frame_phases.json: median frame 341 us, one 33.8 ms frame in 300), i.e. it decides the mean of a
+200-frame sample by when it happens to fire, not by anything in the frame.
 """
 import argparse
+import gc
 import json
 import os
 import sys
@@ -20,7 +28,7 @@ import torch
 
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 from pytracking_amd import _lib, bench_frame, synth  # noqa: E402
-from pytracking_amd import features as FM, iou_refine as IR, localization as LM  # noqa: E402
+from pytracking_amd import features as FM, frame_full, iou_refine as IR, localization as LM  # noqa: E402
 from pytracking_amd.prroi_pool import PrRoIPool2D  # noqa: E402
 
 
@@ -52,9 +60,11 @@ def measure(dev, frames=300):
     iou_feat = (torch.randn(1, 256, 36, 36, device=dev), torch.randn(1, 256, 18, 18, device=dev))
     params = Params(target_not_found_threshold=0.25, distractor_threshold=0.8, hard_negative_threshold=0.5,
                     target_neighborhood_scale=2.2, dispalcement_scale=0.8, box_refinement_iter=5,
-                    box_refinement_step_length=1, box_refinement_step_decay=1)
+                    box_refinement_step_length=1, box_refinement_step_decay=1, box_jitter_pos=0.1, box_jitter_sz=0.5,
+                    num_init_random_boxes=9)
     me = types.SimpleNamespace(params=params, kernel_size=torch.Tensor([4, 4]), output_window=None,
                                img_support_sz=torch.Tensor([288.0, 288.0]), target_sz=torch.Tensor([60.0, 70.0]),
+                               img_sample_sz=torch.Tensor([288.0, 288.0]), image_sz=torch.Tensor([360.0, 480.0]),
                                pos=torch.Tensor([144.0, 144.0]), net=types.SimpleNamespace(bb_regressor=net),
                                iou_modulation=(torch.rand(1, 256, device=dev) + 0.5, torch.rand(1, 256, device=dev) + 0.5))
     sample_pos, sample_scales = torch.Tensor([[144.0, 144.0]]), torch.Tensor([1.0])
@@ -71,19 +81,50 @@ def measure(dev, frames=300):
         if parts >= 3:
             IR.optimize_boxes_default(me, iou_feat, boxes)
 
+    # the one-call route: same head weights, its own sequence state
+    st1 = bench_frame.TrackState(cfg, cfg["memory"], seed=1234, device=dev)
+    st1.attach_head(head[0].weight, head[1].scale, head[1].eps)
+    pipe = frame_full.FramePipeline(st1, num_iter=5)
+
+    st2 = bench_frame.TrackState(cfg, cfg["memory"], seed=1234, device=dev)
+    st2.attach_head(head[0].weight, head[1].scale, head[1].eps)
+    pipe2 = frame_full.FramePipeline(st2, num_iter=5, overlap=True)
+
+    def frame_one_call(i, parts):
+        pipe.run(me, backbone_feat[i % 8][0], i % st1.n, iou_feat, sample_pos, sample_scales, torch.rand(9, 4))
+
+    def frame_one_call_2s(i, parts):
+        pipe2.run(me, backbone_feat[i % 8][0], i % st2.n, iou_feat, sample_pos, sample_scales, torch.rand(9, 4))
+
     out = {}
-    for tag, parts in (("head_only", 0), ("head+solver", 1), ("head+solver+localize", 2), ("head+solver+localize+iou_refine", 3)):
-        for i in range(20):
-            frame(i, parts)
-        torch.cuda.synchronize()
-        t0 = time.perf_counter()
-        for i in range(a.frames):
-            frame(i, parts)
-        torch.cuda.synchronize()
-        dt = (time.perf_counter() - t0) / a.frames
-        out[tag] = {"us_per_frame": round(dt * 1e6, 1), "frames_per_s": round(1 / dt, 1)}
+    gc_was = gc.isenabled()
+    gc.collect()
+    gc.disable()
+    try:
+        for tag, parts, fn in (("head_only", 0, frame), ("head+solver", 1, frame), ("head+solver+localize", 2, frame),
+                               ("head+solver+localize+iou_refine", 3, frame), ("one_call", 3, frame_one_call),
+                               ("one_call_two_streams", 3, frame_one_call_2s)):
+            for i in range(20):
+                fn(i, parts)
+            torch.cuda.synchronize()
+            t0 = time.perf_counter()
+            for i in range(a.frames):
+                fn(i, parts)
+            torch.cuda.synchronize()
+            dt = (time.perf_counter() - t0) / a.frames
+            out[tag] = {"us_per_frame": round(dt * 1e6, 1), "frames_per_s": round(1 / dt, 1)}
+    finally:
+        if gc_was:
+            gc.enable()
+    out["one_call"]["what"] = ("the same frame through pt_track_frame_full_f32: head + solver + localisation + device-side glue (new "
+                               "position, update_state clamp, get_iounet_box, 9 jittered proposals from host random numbers) + IoU "
+                               "refinement, ONE ctypes call, ONE host wait")
+    out["one_call_two_streams"]["what"] = ("one_call with the localisation + glue + refinement chain forked onto a second HIP stream as soon "
+                                           "as the classification scores exist, concurrent with the 5 SD iterations; joined at the end "
+                                           "(valid for this synthetic frame: the update's label box comes from the classification peak; "
+                                           "DiMP.track updates AFTER the refinement, which is the one-stream order)")
     out["workload"] = ("DiMP-50 frame without the backbone, eager launches, host wall time: clf head + classify/insert/5 SD iterations + "
-                       "localisation (results on the host) + IoU refinement (results on the host)")
+                       "localisation (results on the host) + IoU refinement (results on the host); cyclic GC off during the timed loops")
     return out
 
 
