@@ -113,6 +113,16 @@ int pt_sd_solve_f32(const pt_sd_params* p, const float* w_in, const float* feat,
                     int n, int C, int H, int W, int K, int num_iter,
                     float* w_iters, float* losses, void* ws, size_t ws_bytes, void* stream);
 
+/* S independent sequences in one call (optimizer.py:101-104 `num_sequences`; KYS / multi-object wrappers call the optimiser with
+ * S > 1).  Arrays of S pointers (host arrays of device pointers); sample_weight / losses may be NULL as arrays; ws: S workspaces of
+ * ws_bytes_each >= pt_sd_ws_bytes each.  Sequence s runs on `stream` (s % (1 + n_aux) == 0) or on aux_streams[s % (1 + n_aux) - 1]:
+ * the auxiliary streams wait for everything queued on `stream` before the call and `stream` waits for them before the call
+ * returns, so the call is ordered on `stream` like pt_sd_solve_f32.  n_aux = 0: the sequences run back to back. */
+int pt_sd_solve_batch_f32(const pt_sd_params* p, int S, const float* const* w_in, const float* const* feat, long feat_stride_n,
+                          const float* const* bb, const float* const* sample_weight, int n, int C, int H, int W, int K,
+                          int num_iter, float* const* w_iters, float* const* losses, void* const* ws, size_t ws_bytes_each,
+                          void* stream, void* const* aux_streams, int n_aux);
+
 /* ------------------------------------------------------------------------------------------------
  * Multi-filter filter layer + LWL few-shot learner -- ltr/models/layers/filter.py (5-D `filter` / `input` branches),
  * ltr/models/meta/steepestdescent.py, ltr/models/lwl/loss_residual_modules.py

@@ -91,6 +91,7 @@ EXPORTS = [
     "pt_iou_param_floats", "pt_iou_prepared_floats", "pt_iou_prepare_f32", "pt_iou_refine_ws_bytes", "pt_iou_refine_f32", "pt_iou_refine_sync_f32",
     "pt_track_frame_replay_pass_f32", "pt_sample_patch_f32", "pt_augment_patches_f32", "pt_track_frame_head_ws_bytes", "pt_track_frame_head_f32",
     "pt_track_frame_full_ws_bytes", "pt_track_frame_full_f32", "pt_track_frame_full_launch_f32", "pt_host_buffer_forget",
+    "pt_sd_solve_batch_f32",
 ]
 
 
@@ -210,6 +211,9 @@ def lib():
     L.pt_sd_ws_bytes.argtypes = [i] * 5
     L.pt_sd_solve_f32.restype = i
     L.pt_sd_solve_f32.argtypes = [ctypes.POINTER(SdParams), vp, vp, l, vp, vp] + [i] * 6 + [vp, vp, vp, sz, vp]
+    vpp = ctypes.POINTER(ctypes.c_void_p)
+    L.pt_sd_solve_batch_f32.restype = i
+    L.pt_sd_solve_batch_f32.argtypes = [ctypes.POINTER(SdParams), i, vpp, vpp, l, vpp, vpp] + [i] * 6 + [vpp, vpp, vpp, sz, vp, vpp, i]
     L.pt_atom_cg_ws_bytes.restype = sz
     L.pt_atom_cg_ws_bytes.argtypes = [i] * 5
     L.pt_atom_cg_f32.restype = i

@@ -2,6 +2,9 @@
 #include <algorithm>
 #include <atomic>
 #include <chrono>
+#include <mutex>
+#include <utility>
+#include <vector>
 #include "common.h"
 #include "pt_internal.h"
 
@@ -43,6 +46,25 @@ extern "C" void pt_host_buffer_forget(const void* p) {
         const void* cur = p;
         s.compare_exchange_strong(cur, nullptr, std::memory_order_acq_rel);
     }
+}
+
+bool pt_stream_events(void* stream, hipEvent_t* fork, hipEvent_t* join) {
+    static std::mutex mu;
+    static std::vector<std::pair<void*, std::pair<hipEvent_t, hipEvent_t>>> pool;
+    std::lock_guard<std::mutex> lk(mu);
+    for (auto& e : pool)
+        if (e.first == stream) {
+            if (fork) *fork = e.second.first;
+            if (join) *join = e.second.second;
+            return true;
+        }
+    hipEvent_t a, b;
+    if (hipEventCreateWithFlags(&a, hipEventDisableTiming) != hipSuccess) return false;
+    if (hipEventCreateWithFlags(&b, hipEventDisableTiming) != hipSuccess) return false;
+    pool.push_back({stream, {a, b}});
+    if (fork) *fork = a;
+    if (join) *join = b;
+    return true;
 }
 
 int pt_poll_word(volatile float* word, float seq, const void* buf, void* stream) {

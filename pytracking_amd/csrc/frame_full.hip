@@ -10,9 +10,6 @@
 // get_iounet_box, the jittered proposals.  All of it is float32 tensor arithmetic on the CPU in the reference; here the same
 // operations in the same order, un-fused (__f*_rn), one thread per proposal.  Python scalars that multiply float32 tensors are
 // rounded to float32 first, as torch's binary ops do.
-#include <mutex>
-#include <utility>
-#include <vector>
 #include "common.h"
 #include "pt_internal.h"
 
@@ -112,21 +109,6 @@ extern "C" size_t pt_track_frame_full_ws_bytes(const pt_frame_full* f) {
     return ff_carve(f).total * sizeof(float);
 }
 
-// fork / join events of a second stream: created once per stream handle, never destroyed (two timing-less events hold no memory)
-static bool ff_events(void* aux, hipEvent_t* fork, hipEvent_t* join) {
-    static std::mutex mu;
-    static std::vector<std::pair<void*, std::pair<hipEvent_t, hipEvent_t>>> pool;
-    std::lock_guard<std::mutex> lk(mu);
-    for (auto& e : pool)
-        if (e.first == aux) { *fork = e.second.first; *join = e.second.second; return true; }
-    hipEvent_t a, b;
-    if (hipEventCreateWithFlags(&a, hipEventDisableTiming) != hipSuccess) return false;
-    if (hipEventCreateWithFlags(&b, hipEventDisableTiming) != hipSuccess) return false;
-    pool.push_back({aux, {a, b}});
-    *fork = a; *join = b;
-    return true;
-}
-
 static int ff_launch(const pt_frame_full* f, float* out, void* ws, size_t ws_bytes, float seq, void* stream) {
     void* const main_stream = stream;
     int rc = ff_check(f);
@@ -146,7 +128,7 @@ static int ff_launch(const pt_frame_full* f, float* out, void* ws, size_t ws_byt
     hipEvent_t ev_fork = nullptr, ev_join = nullptr;
     void* chain = stream;
     if (f->aux_stream && f->aux_stream != stream) {
-        if (!ff_events(f->aux_stream, &ev_fork, &ev_join)) return PT_ERR_LAUNCH;
+        if (!pt_stream_events(f->aux_stream, &ev_fork, &ev_join)) return PT_ERR_LAUNCH;
         chain = f->aux_stream;
     }
     rc = pt_track_frame_head_impl(f->sd, f->filter, f->mem_feat, f->mem_bb, f->sample_weight, f->backbone_feat, f->head_weight_tap_major,

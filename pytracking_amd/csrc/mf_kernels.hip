@@ -914,6 +914,7 @@ int pt_launch_mf_corr(const float* feat, long stride_n, const float* wT, float* 
     // channel splits into the caller's partial-map workspace (pt_mf_corr_part_floats), then the fixed-order sum
     const int ksp = (part && groups == 1 && out_stride_n == (long)F * H * W && ((F * H * W) % 4) == 0 &&
                      ((uintptr_t)part % 16) == 0 && ((uintptr_t)scores % 16) == 0) ? pt_mf_corr_splits(n, F, C, H, W, K) : 1;
+    if (ksp > 16) return PT_ERR_UNSUPPORTED;                            // mf_parts_quad sums at most 16 splits: refused BEFORE anything is queued
     // groups > 1: `groups` banks of F filters each (weight tables back to back, outputs F*H*W apart inside a sample)
     const long wt_zs = (long)pt_mf_wt_floats(C, K), out_zs = (long)F * H * W;
     dim3 grid(p.g.NB, n * ksp, groups), block(MF_CT);
@@ -930,7 +931,6 @@ int pt_launch_mf_corr(const float* feat, long stride_n, const float* wT, float* 
     PT_CHECK_LAUNCH();
     if (ksp > 1) {
         const long count = (long)n * out_stride_n;
-        if (ksp > 16) return PT_ERR_UNSUPPORTED;                     // mf_parts_quad sums at most 16 splits (pt_mf_corr_splits: <= 16)
         if (sq && sq->out && sq->done) {
             hipLaunchKernelGGL(k_mf_sum_parts_sq, dim3(PT_MF_SQ_PARTS), dim3(256), 0, st, part, scores, ksp, count, *sq);
             *sq->done = 1;

@@ -528,7 +528,10 @@ int launch_gemm(const GemmArgs& g, hipStream_t st, bool conv = false) {
     if (conv) {
         if (g.Cin % 64 != 0) return PT_ERR_UNSUPPORTED;
         if (g.gn_stats) {
-            if (g.gn_slices > GEMM_GN_MAX_SLICES || g.gn_slices < 1 || !g.gn_gam || !g.gn_bet || g.HW < 32) return PT_ERR_UNSUPPORTED;
+            // the fused loader reads gn_gam / gn_bet as 16-byte vectors and divides by gn_count
+            if (g.gn_slices > GEMM_GN_MAX_SLICES || g.gn_slices < 1 || !g.gn_gam || !g.gn_bet || g.HW < 32 || g.gn_count <= 0 ||
+                ((uintptr_t)g.gn_gam % 16) != 0 || ((uintptr_t)g.gn_bet % 16) != 0)
+                return PT_ERR_UNSUPPORTED;
             hipLaunchKernelGGL((k_gemm<32, 32, 2>), dim3((g.N + 31) / 32, (g.M + 31) / 32, nz), dim3(256), 0, st, g);
         } else {
             hipLaunchKernelGGL((k_gemm<32, 32, 1>), dim3((g.N + 31) / 32, (g.M + 31) / 32, nz), dim3(256), 0, st, g);

@@ -178,6 +178,10 @@ int pt_track_frame_head_impl(const pt_sd_params* prm, float* filter, float* mem_
                              int n, int Cin, int C, int H, int W, int K, int num_iter, float* scores_out, float* peak_out, void* ws,
                              size_t ws_bytes, void* stream, void* after_init_event);
 
+// Two timing-less events per stream handle (fork: recorded on it, join: recorded on it for somebody else to wait on), created on first use
+// and never destroyed (they hold no memory); thread-safe.  Either out pointer may be null.
+bool pt_stream_events(void* stream, hipEvent_t* fork, hipEvent_t* join);
+
 // launch halves of the host-polled entry points, for compositions (frame_full.hip)
 int pt_localize_launch(const float* scores, const float* scores_hn, const pt_localize_params* prm, float* out16, int S, int H,
                        int W, float seq, void* stream);

@@ -769,6 +769,47 @@ extern "C" int pt_sd_solve_f32(const pt_sd_params* prm, const float* w_in, const
                             /*src=*/nullptr);
 }
 
+// S independent sequences in ONE call (optimizer.py:101-104 `num_sequences`: the reference carries them as a tensor dimension of
+// every op).  A single-sequence solve is a chain of dependent, latency-bound launches that leaves most of the chip idle (bench.py
+// `multi_sequence`: two sequences on two streams -> 1.3x, four -> 1.5x aggregate), so the sequences are spread round-robin over
+// `stream` and the caller's `n_aux` auxiliary streams: every auxiliary stream first waits for what is queued on `stream` (fork
+// event), and `stream` waits for all of them before the call returns (join events) -- to the caller the call is ordered on `stream`
+// like the single-sequence entry.  Sequences that share a stream run back to back; each needs its own workspace.
+extern "C" int pt_sd_solve_batch_f32(const pt_sd_params* prm, int S, const float* const* w_in, const float* const* feat,
+                                     long feat_stride_n, const float* const* bb, const float* const* sample_weight, int n, int C,
+                                     int H, int W, int K, int num_iter, float* const* w_iters, float* const* losses,
+                                     void* const* ws, size_t ws_bytes_each, void* stream, void* const* aux_streams, int n_aux) {
+    if (!prm || !w_in || !feat || !bb || !w_iters || !ws) return PT_ERR_NULL;
+    if (S <= 0 || n_aux < 0 || (n_aux > 0 && !aux_streams)) return PT_ERR_SHAPE;
+    if (n_aux > 15) return PT_ERR_UNSUPPORTED;
+    const int lanes = 1 + (S > 1 ? n_aux : 0);
+    hipEvent_t fork = nullptr, join[16] = {};
+    if (lanes > 1) {
+        if (!pt_stream_events(stream, &fork, nullptr)) return PT_ERR_LAUNCH;
+        if (hipEventRecord(fork, (hipStream_t)stream) != hipSuccess) return PT_ERR_LAUNCH;
+        for (int l = 1; l < lanes && l <= S - 1; ++l) {
+            if (!aux_streams[l - 1] || aux_streams[l - 1] == stream) return PT_ERR_SHAPE;
+            if (!pt_stream_events(aux_streams[l - 1], nullptr, &join[l])) return PT_ERR_LAUNCH;
+            if (hipStreamWaitEvent((hipStream_t)aux_streams[l - 1], fork, 0) != hipSuccess) return PT_ERR_LAUNCH;
+        }
+    }
+    int rc = PT_OK;
+    for (int s = 0; s < S && rc == PT_OK; ++s) {
+        const int l = s % lanes;
+        void* st = l == 0 ? stream : aux_streams[l - 1];
+        rc = pt_sd_solve_impl(prm, w_in[s], feat[s], feat_stride_n, bb[s], sample_weight ? sample_weight[s] : nullptr, n, C, H, W, K,
+                              num_iter, w_iters[s], losses ? losses[s] : nullptr, ws[s], ws_bytes_each, (hipStream_t)st,
+                              /*copy_w0=*/true, /*w_final=*/nullptr, /*cls=*/nullptr, /*src=*/nullptr);
+    }
+    // join even after an error: work that was queued on an auxiliary stream must not outlive the call's ordering contract
+    for (int l = 1; l < lanes && l <= S - 1; ++l) {
+        if (hipEventRecord(join[l], (hipStream_t)aux_streams[l - 1]) != hipSuccess ||
+            hipStreamWaitEvent((hipStream_t)stream, join[l], 0) != hipSuccess)
+            return rc ? rc : PT_ERR_LAUNCH;
+    }
+    return rc;
+}
+
 // ----------------------------------------------------------------------------------------------------
 // Measurement helper behind pt_track_frame_replay_pass_f32 (api.hip; bench.py roofline leg): re-issue ONE feature pass of the solve
 // that last ran on this workspace, `reps` times back to back on `stream`, exactly as iteration t = num_iter - 1 of

@@ -327,16 +327,20 @@ static bool ln_rows_wide_ok(const float* in, const float* out, const float* gam,
     return D == 256 && ((uintptr_t)in % 16 == 0) && ((uintptr_t)out % 16 == 0) && ((uintptr_t)gam % 16 == 0) && ((uintptr_t)bet % 16 == 0);
 }
 
-static void launch_ln_rows(const float* in, float* out, const float* gam, const float* bet, int rows, int D, hipStream_t st,
-                           const float* in2 = nullptr, const float* in3 = nullptr, const float* gam2 = nullptr,
-                           const float* bet2 = nullptr) {
+// Returns PT_ERR_UNSUPPORTED (nothing queued) when extra operands are given that only the 256-wide vector kernel serves and that
+// kernel cannot be used: dropping in2 / in3 / the second norm silently would lose the split-K half, the residual or a LayerNorm.
+static int launch_ln_rows(const float* in, float* out, const float* gam, const float* bet, int rows, int D, hipStream_t st,
+                          const float* in2 = nullptr, const float* in3 = nullptr, const float* gam2 = nullptr,
+                          const float* bet2 = nullptr) {
     const dim3 grid((rows + 3) / 4), block(256);
     const bool al = ((uintptr_t)in % 16 == 0) && ((uintptr_t)out % 16 == 0) && ((uintptr_t)gam % 16 == 0) && ((uintptr_t)bet % 16 == 0) &&
-                    ((uintptr_t)in2 % 16 == 0) && ((uintptr_t)in3 % 16 == 0);
+                    ((uintptr_t)in2 % 16 == 0) && ((uintptr_t)in3 % 16 == 0) && ((uintptr_t)gam2 % 16 == 0) && ((uintptr_t)bet2 % 16 == 0);
+    if (!(D == 256 && al) && (in2 || in3 || gam2 || bet2)) return PT_ERR_UNSUPPORTED;
     if (D == 256 && al) hipLaunchKernelGGL(k_ln_rows_t<4>, grid, block, 0, st, in, out, gam, bet, rows, in2, in3, gam2, bet2);
     else if (D == 128) hipLaunchKernelGGL(k_ln_rows_t<2>, grid, block, 0, st, in, out, gam, bet, rows);
     else if (D == 64) hipLaunchKernelGGL(k_ln_rows_t<1>, grid, block, 0, st, in, out, gam, bet, rows);
     else hipLaunchKernelGGL(k_ln_rows, grid, block, 0, st, in, out, gam, bet, rows, D);
+    return PT_OK;
 }
 
 // ------------------------------------------------------------------------------------------------------------------
@@ -1335,7 +1339,7 @@ extern "C" int pt_tomp_predict_f32(const pt_tomp_dims* d, const float* params, c
         g = gemm_args(AO, D, rows, P + e.sa.w_out, rows, D, D, P + e.sa.b_out, Y, D);
         g.R = X;
         if ((rc = launch_gemm(g, st))) return rc;
-        launch_ln_rows(Y, X, P + e.n1g, P + e.n1b, rows, D, st);
+        if ((rc = launch_ln_rows(Y, X, P + e.n1g, P + e.n1b, rows, D, st))) return rc;
         PT_CHECK_LAUNCH();
         g = gemm_args(X, D, rows, P + e.w1, rows, ff, D, P + e.b1, Hd, ff);
         g.relu = 1;
@@ -1344,14 +1348,14 @@ extern "C" int pt_tomp_predict_f32(const pt_tomp_dims* d, const float* params, c
             g = gemm_args(Hd, ff, rows, P + e.w2, rows, D, ff, P + e.b2, AO, D);
             g.ksteps = ff / 64 / 2; g.c_zstride = (long)(cv.Y - cv.AO);          // halves -> AO, Y (bias rides on the first)
             if ((rc = launch_gemm(g, st))) return rc;
-            launch_ln_rows(AO, X, P + e.n2g, P + e.n2b, rows, D, st, Y, X);
+            if ((rc = launch_ln_rows(AO, X, P + e.n2g, P + e.n2b, rows, D, st, Y, X))) return rc;
             PT_CHECK_LAUNCH();
             continue;
         }
         g = gemm_args(Hd, ff, rows, P + e.w2, rows, D, ff, P + e.b2, Y, D);
         g.R = X;
         if ((rc = launch_gemm(g, st))) return rc;
-        launch_ln_rows(Y, X, P + e.n2g, P + e.n2b, rows, D, st);
+        if ((rc = launch_ln_rows(Y, X, P + e.n2g, P + e.n2b, rows, D, st))) return rc;
         PT_CHECK_LAUNCH();
     }
     // ---- decoder (transformer.py:224-238), one query per batch row; T = LayerNorm(pre) is applied by the consumers
@@ -1401,15 +1405,15 @@ extern "C" int pt_tomp_predict_f32(const pt_tomp_dims* d, const float* params, c
     }
     // norm3 of the last layer, then the decoder's final norm (transformer.py:141-142)
     if (d->n_dec > 0 && ln_rows_wide_ok(tpre, filters, tg, tb, D)) {
-        launch_ln_rows(tpre, filters, tg, tb, B, D, st, nullptr, nullptr, P + po.dng, P + po.dnb);   // both norms, one launch
+        if ((rc = launch_ln_rows(tpre, filters, tg, tb, B, D, st, nullptr, nullptr, P + po.dng, P + po.dnb))) return rc;   // both norms, one launch
         PT_CHECK_LAUNCH();
     } else {
         if (d->n_dec > 0) {
-            launch_ln_rows(tpre, base + cv.a, tg, tb, B, D, st);
+            if ((rc = launch_ln_rows(tpre, base + cv.a, tg, tb, B, D, st))) return rc;
             PT_CHECK_LAUNCH();
             tpre = base + cv.a;
         }
-        launch_ln_rows(tpre, filters, P + po.dng, P + po.dnb, B, D, st);
+        if ((rc = launch_ln_rows(tpre, filters, P + po.dng, P + po.dnb, B, D, st))) return rc;
         PT_CHECK_LAUNCH();
     }
     hipLaunchKernelGGL(k_tokens_to_nchw, dim3((HW + 31) / 32, (D + 31) / 32, B), dim3(256), 0, st, X, enc_feat, B, L, D,

@@ -23,9 +23,21 @@ from . import _lib
 from .filter import _ptr, _require_device, _stream, device_guarded, workspace
 
 
+_SIDE = {}
+
+
+def _side_streams(device, count):
+    """Side streams of the multi-sequence solve, per (device, calling stream): created once, reused every call."""
+    key = (device.index, torch.cuda.current_stream(device).cuda_stream)
+    pool = _SIDE.setdefault(key, [])
+    while len(pool) < count:
+        pool.append(torch.cuda.Stream(device=device))
+    return pool[:count]
+
+
 @device_guarded
 def _solve(params: _lib.SdParams, weights, feat, bb, sample_weight, num_iter, compute_losses, keep):
-    """Shared driver: loops over sequences (the C ABI solves one sequence per call)."""
+    """Shared driver.  One sequence -> pt_sd_solve_f32; S > 1 (optimizer.py:101-104) -> ONE call of pt_sd_solve_batch_f32."""
     if torch.is_grad_enabled() and (weights.requires_grad or feat.requires_grad):
         raise NotImplementedError("back-propagation through the unrolled optimiser (offline training) is out of scope")
     _require_device(weights, feat, bb)
@@ -46,16 +58,40 @@ def _solve(params: _lib.SdParams, weights, feat, bb, sample_weight, num_iter, co
     iters = torch.empty((S, num_iter + 1, C, K, K), dtype=torch.float32, device=feat.device)
     losses = torch.zeros((S, num_iter + 1), dtype=torch.float32, device=feat.device) if compute_losses else None
     nb = L.pt_sd_ws_bytes(n, C, H, W, K)
-    ws = workspace(nb, feat.device)
-    for s in range(S):
-        fs = f5[:, s]
-        bs = bb3[:, s].contiguous()
-        ss = sw2[:, s].contiguous() if sw2 is not None else None
+    if S == 1:
+        ws = workspace(nb, feat.device)
+        fs = f5[:, 0]
+        bs = bb3[:, 0].contiguous()
+        ss = sw2[:, 0].contiguous() if sw2 is not None else None
         keep.extend((bs, ss))
-        rc = L.pt_sd_solve_f32(ctypes.byref(params), _ptr(w_in[s]), _ptr(fs), fs.stride(0), _ptr(bs),
-                               _ptr(ss) if ss is not None else None, n, C, H, W, K, num_iter, _ptr(iters[s]),
-                               _ptr(losses[s]) if losses is not None else None, _ptr(ws), ws.numel(), _stream())
+        rc = L.pt_sd_solve_f32(ctypes.byref(params), _ptr(w_in[0]), _ptr(fs), fs.stride(0), _ptr(bs),
+                               _ptr(ss) if ss is not None else None, n, C, H, W, K, num_iter, _ptr(iters[0]),
+                               _ptr(losses[0]) if losses is not None else None, _ptr(ws), ws.numel(), _stream())
         _lib.check(rc, "pt_sd_solve_f32")
+    else:
+        # all sequences in one call (pt_sd_solve_batch_f32).  Spreading them over side streams pays only when the launches are not
+        # the bottleneck: issued eagerly, two chains need two launches per ~6 us of device time, which is the host's launch rate, and
+        # the second chain starts a whole chain's launch time late (profiles/r05i_multi_seq_solve.json: 0.80x / 0.97x / 1.07x for
+        # S = 2 / 4 / 8).  Inside a graph capture the fork / join events become parallel branches of the graph and the replay runs
+        # the chains concurrently (bench.py `multi_sequence`: 1.3x / 1.5x for 2 / 4 sequences), so side streams are used there only.
+        nb_al = (nb + 255) // 256 * 256
+        ws = workspace(nb_al * S, feat.device)
+        bsT = bb3.permute(1, 0, 2).contiguous()                   # (S, n, 4): one dense box array per sequence
+        ssT = sw2.t().contiguous() if sw2 is not None else None
+        keep.extend((bsT, ssT))
+        arr = ctypes.c_void_p * S
+        p_w = arr(*[w_in[s].data_ptr() for s in range(S)])
+        p_f = arr(*[f5[:, s].data_ptr() for s in range(S)])
+        p_b = arr(*[bsT[s].data_ptr() for s in range(S)])
+        p_s = arr(*[ssT[s].data_ptr() for s in range(S)]) if ssT is not None else None
+        p_i = arr(*[iters[s].data_ptr() for s in range(S)])
+        p_l = arr(*[losses[s].data_ptr() for s in range(S)]) if losses is not None else None
+        p_ws = arr(*[ws.data_ptr() + s * nb_al for s in range(S)])
+        aux = _side_streams(feat.device, min(S - 1, 3)) if torch.cuda.is_current_stream_capturing() else []
+        p_aux = (ctypes.c_void_p * max(len(aux), 1))(*[a.cuda_stream for a in aux])
+        rc = L.pt_sd_solve_batch_f32(ctypes.byref(params), S, p_w, p_f, f5.stride(0), p_b, p_s, n, C, H, W, K, num_iter, p_i, p_l,
+                                     p_ws, nb_al, _stream(), p_aux, len(aux))
+        _lib.check(rc, "pt_sd_solve_batch_f32")
     weight_iterates = [weights] + [iters[:, t] for t in range(1, num_iter + 1)]
     loss_list = []
     if compute_losses:

@@ -1399,3 +1399,32 @@ def test_track_frame_with_head_writes_the_memory_slot():
     torch.cuda.synchronize()
     assert torch.equal(a.mem_feat[5], feat) and torch.equal(a.mem_feat, b.mem_feat)
     assert torch.equal(a.scores, b.scores) and torch.equal(a.filter, b.filter) and torch.equal(a.mem_bb, b.mem_bb)
+
+
+@pytest.mark.parametrize("kind", ["dimp", "prdimp"])
+def test_sd_multi_sequence_batch_equals_single_sequence_calls(kind):
+    """S = 5 sequences through ONE pt_sd_solve_batch_f32 call (this stream + 3 side streams, the fifth sequence sharing the first lane)
+    against five single-sequence solves: bit-equal iterates and losses (the same kernels on the same operands; only the streams
+    differ), at the deployed map size."""
+    import time
+    cfg = synth.DIMP50 if kind == "dimp" else synth.PRDIMP50
+    S, n, C = 5, 9, 128
+    probs = [synth.dimp_problem(900 + s, n, dict(cfg, C=C)) for s in range(S)]
+    w0 = torch.stack([T(p[0]) for p in probs])                                   # (S,C,K,K)
+    feat = torch.stack([T(p[1]) for p in probs], dim=1).contiguous()              # (n,S,C,H,W)
+    bb = torch.stack([T(p[2]) for p in probs], dim=1).contiguous()                # (n,S,4)
+    sw = torch.stack([T(p[3]) for p in probs], dim=1).contiguous()                # (n,S)
+    mod = _dimp_module(cfg) if kind == "dimp" else _prdimp_module(cfg)
+    with torch.no_grad():
+        _, its, losses = mod(w0, feat, bb, sample_weight=sw, num_iter=4, compute_losses=True)
+        torch.cuda.synchronize()
+        single = []
+        for s in range(S):
+            _, its_s, l_s = mod(w0[s:s + 1], feat[:, s].contiguous(), bb[:, s].contiguous(), sample_weight=sw[:, s].contiguous(),
+                                num_iter=4, compute_losses=True)
+            single.append((torch.stack(its_s)[:, 0], torch.cat(l_s)))
+    batch_its = torch.stack(its)                                                  # (T+1,S,C,K,K)
+    for s in range(S):
+        assert torch.equal(batch_its[:, s], single[s][0]), s
+    tot = sum(x[1] for x in single) / S
+    close(torch.cat(losses), tot.cpu().numpy(), atol=1e-6, rtol=1e-6)
