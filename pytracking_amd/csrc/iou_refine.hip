@@ -14,6 +14,7 @@
 #include "pt_internal.h"
 #include "mfma_gemm.h"
 #include "prroi_dev.h"
+#include "frame_mid.h"
 
 #include <math.h>
 #include <stdlib.h>
@@ -106,13 +107,9 @@ struct SetupArgs {
     float hb[4 * 16];
 };
 
-// per-column modulation of the pooled features, the optimisation variable (rect or relative) and the first rois
-__global__ __launch_bounds__(256) void k_iou_setup(SetupArgs a) {
-    const int idx = blockIdx.x * 256 + threadIdx.x;
-    if (idx < a.K3) a.msc3[idx] = a.mod3[idx / (P3 * P3)];
-    if (idx < a.K4) a.msc4[idx] = a.mod4[idx / (P4 * P4)];
-    if (idx < a.P) {
-        const float* bx = a.use_hb ? a.hb : a.boxes;
+// the optimisation variable (rect or relative), step state and first rois of proposal idx; bx: the P initial boxes
+__device__ __forceinline__ void iou_setup_proposal(const SetupArgs& a, int idx, const float* bx) {
+    {
         const float x = bx[4 * idx], y = bx[4 * idx + 1], w = bx[4 * idx + 2], h = bx[4 * idx + 3];
         const float sw = bx[2], sh = bx[3];                             // sz_norm = size of the first box (dimp.py:767)
         if (idx == 0) { a.szn[0] = sw; a.szn[1] = sh; }
@@ -138,6 +135,31 @@ __global__ __launch_bounds__(256) void k_iou_setup(SetupArgs a) {
         }
         r[0] = 0.f; r[1] = rx; r[2] = ry; r[3] = rx + rw; r[4] = ry + rh;
     }
+}
+
+// per-column modulation of the pooled features (unfused route) + the per-proposal set-up
+__global__ __launch_bounds__(256) void k_iou_setup(SetupArgs a) {
+    const int idx = blockIdx.x * 256 + threadIdx.x;
+    if (idx < a.K3) a.msc3[idx] = a.mod3[idx / (P3 * P3)];
+    if (idx < a.K4) a.msc4[idx] = a.mod4[idx / (P4 * P4)];
+    if (idx < a.P) iou_setup_proposal(a, idx, a.use_hb ? a.hb : a.boxes);
+}
+
+// The middle of the one-call frame (frame_full.hip): localize_advanced on the frame's score map, the tracker's glue (new position,
+// update_state, get_iounet_box, jittered proposals) and the refinement's set-up stage for those proposals -- one workgroup, the
+// hand-offs through LDS instead of three dependent launches.
+__global__ __launch_bounds__(256) void k_frame_mid(DecideArgs d, GlueArgs g, SetupArgs a) {
+    __shared__ Peak sh[4];
+    __shared__ float res[16];
+    __shared__ float bx[4 * 16];
+    localize_decide(d, sh, res);
+    if (threadIdx.x == 0) {
+        for (int k = 0; k < 15; ++k) d.out[k] = res[k];                  // device copy of the results (workspace)
+    }
+    __syncthreads();
+    if (threadIdx.x < a.P) frame_glue(g, res, bx);
+    __syncthreads();
+    if (threadIdx.x < a.P) iou_setup_proposal(a, threadIdx.x, bx);
 }
 
 struct HeadArgs {
@@ -793,8 +815,9 @@ extern "C" size_t pt_iou_refine_ws_bytes(const pt_iou_dims* d, int P) {
 static int iou_refine_impl(const pt_iou_dims* d, const float* params, const float* prepared, const float* c3, const float* c4,
                            const float* mod3, const float* mod4, const float* init_boxes, bool boxes_on_host, float* boxes_out,
                            float* iou_out, int P, int num_iter, const float* step_length4, float step_decay, int relative,
-                           int backtrack, void* ws, size_t ws_bytes, float seq, float* seq_word, void* stream) {
-    if (!params || !prepared || !c3 || !c4 || !mod3 || !mod4 || !init_boxes || !boxes_out || !iou_out || !step_length4 || !ws)
+                           int backtrack, void* ws, size_t ws_bytes, float seq, float* seq_word, void* stream,
+                           const PtFrameMid* mid = nullptr) {
+    if (!params || !prepared || !c3 || !c4 || !mod3 || !mod4 || (!init_boxes && !mid) || !boxes_out || !iou_out || !step_length4 || !ws)
         return PT_ERR_NULL;
     int rc = iou_check(d);
     if (rc) return rc;
@@ -819,7 +842,12 @@ static int iou_refine_impl(const pt_iou_dims* d, const float* params, const floa
         sa.boxes = nullptr; sa.use_hb = 1;
         for (int i = 0; i < 4 * P; ++i) sa.hb[i] = init_boxes[i];
     }
-    hipLaunchKernelGGL(k_iou_setup, dim3((std::max(std::max(sa.K3, sa.K4), P) + 255) / 256), dim3(256), 0, st, sa);
+    if (mid) {                                                          // proposals are formed inside the launch (fused route only)
+        if (!fused || P > 16) return PT_ERR_UNSUPPORTED;
+        hipLaunchKernelGGL(k_frame_mid, dim3(1), dim3(256), 0, st, mid->dec, mid->glue, sa);
+    } else {
+        hipLaunchKernelGGL(k_iou_setup, dim3((std::max(std::max(sa.K3, sa.K4), P) + 255) / 256), dim3(256), 0, st, sa);
+    }
     PT_CHECK_LAUNCH();
     float step[4] = {step_length4[0], step_length4[1], step_length4[2], step_length4[3]};
     const float* const feats[2] = {c3, c4};
@@ -926,7 +954,8 @@ extern "C" int pt_iou_refine_sync_f32(const pt_iou_dims* d, const float* params,
 int pt_iou_refine_launch(const pt_iou_dims* d, const float* params, const float* prepared, const float* c3, const float* c4,
                          const float* mod3, const float* mod4, const float* init_boxes_dev, float* boxes_out, float* iou_out, int P,
                          int num_iter, const float* step_length4, float step_decay, int relative, int backtrack, void* ws,
-                         size_t ws_bytes, float seq, float* seq_word, void* stream) {
+                         size_t ws_bytes, float seq, float* seq_word, void* stream, const void* frame_mid) {
     return iou_refine_impl(d, params, prepared, c3, c4, mod3, mod4, init_boxes_dev, false, boxes_out, iou_out, P, num_iter,
-                           step_length4, step_decay, relative, backtrack, ws, ws_bytes, seq, seq_word, stream);
+                           step_length4, step_decay, relative, backtrack, ws, ws_bytes, seq, seq_word, stream,
+                           (const PtFrameMid*)frame_mid);
 }

@@ -188,7 +188,7 @@ int pt_localize_launch(const float* scores, const float* scores_hn, const pt_loc
 int pt_iou_refine_launch(const pt_iou_dims* d, const float* params, const float* prepared, const float* c3, const float* c4,
                          const float* mod3, const float* mod4, const float* init_boxes_dev, float* boxes_out, float* iou_out, int P,
                          int num_iter, const float* step_length4, float step_decay, int relative, int backtrack, void* ws,
-                         size_t ws_bytes, float seq, float* seq_word, void* stream);
+                         size_t ws_bytes, float seq, float* seq_word, void* stream, const void* frame_mid = nullptr);
 
 // A host-polled result cannot be waited for while the stream is being captured into a graph (nothing executes): refuse at once
 // instead of spinning into the 2 s fallback.

@@ -48,6 +48,10 @@ class FramePipeline:
         self._dev = dev
         self._aux = torch.cuda.Stream(device=dev) if overlap else None
         f.aux_stream = self._aux.cuda_stream if overlap else None
+        self._bound = None
+        self._call = _lib.lib().pt_track_frame_full_f32
+        self._ffref = ctypes.byref(f)
+        self._ws_ptr, self._ws_len = None, 0
 
     def __del__(self):
         try:
@@ -67,45 +71,73 @@ class FramePipeline:
                 raise NotImplementedError("pt_track_frame_full_f32: configuration not covered by the gfx950 kernels")
             if self._ws is None or self._ws.numel() < nb:
                 self._ws = torch.empty(nb, dtype=torch.uint8, device=self._dev)
+            self._ws_ptr, self._ws_len = self._ws.data_ptr(), self._ws.numel()
             self._dims_key = key
         pack, prepared = _ir._packs(net, self._dims)
         self.ff.iou_params, self.ff.iou_prepared = pack.data_ptr(), prepared.data_ptr()
+
+    def bind(self, tracker, iou_features, num_random):
+        """Everything of the call that does not change from frame to frame: the tracker's parameters (thresholds, jitter, refinement
+        settings, image / sample sizes) and the IoU network's packed weights.  `run` calls it when it sees a new tracker object, a new
+        proposal count or new feature shapes; call it yourself after changing `tracker.params` or the network's weights."""
+        p = tracker.params
+        c3, c4 = iou_features
+        net = tracker.net.bb_regressor
+        if net.training:
+            raise NotImplementedError("IoU refinement: eval-mode network")
+        self._bind_iou(net, c3, c4, 1 + num_random)
+        f, g, st = self.ff, self.glue, self.loc
+        st.target_not_found_threshold = p.target_not_found_threshold
+        st.uncertain_threshold = p.get('uncertain_threshold', _NEG_INF)
+        st.hard_sample_threshold = p.get('hard_sample_threshold', _NEG_INF)
+        st.distractor_threshold = p.distractor_threshold
+        st.hard_negative_threshold = p.hard_negative_threshold
+        st.target_neighborhood_scale = p.target_neighborhood_scale
+        st.dispalcement_scale = p.dispalcement_scale
+        st.kernel_size[:] = tracker.kernel_size.tolist() if isinstance(tracker.kernel_size, torch.Tensor) else tracker.kernel_size
+        st.img_support_sz[:] = tracker.img_support_sz.tolist()
+        g.image_sz[:] = tracker.image_sz.tolist()
+        g.img_sample_sz[:] = tracker.img_sample_sz.tolist()
+        g.target_inside_ratio = p.get('target_inside_ratio', 0.2)
+        g.box_jitter_pos, g.box_jitter_sz = p.box_jitter_pos, p.box_jitter_sz
+        g.use_classifier = int(bool(p.get('use_classifier', True)))
+        sl = p.box_refinement_step_length
+        f.step_length4[:] = [sl[0], sl[0], sl[1], sl[1]] if isinstance(sl, (tuple, list)) else [float(sl)] * 4
+        f.step_decay = p.box_refinement_step_decay
+        f.iou_iter = p.box_refinement_iter
+        f.relative = int(p.get('box_refinement_space', 'default') == 'relative')
+        self._bound = (tracker, num_random, c3.shape, c4.shape)
 
     @device_guarded
     def run(self, tracker, backbone_feat, slot, iou_features, sample_pos, sample_scales, rand_u):
         """backbone_feat (Cin,H,W) device; iou_features (c3 (1,C3,H3,W3), c4 (1,C4,H4,W4)) device; sample_pos (1,2), sample_scales (1)
         host, as `track()` forms them; rand_u = `torch.rand(num_init_random_boxes, 4)` of this frame (host).
         -> dict(translation_vec (2), scale_ind, flag, pos (2) after update_state, init_box (4), boxes (P,4), iou (P)), CPU tensors."""
-        p = tracker.params
         c3, c4 = iou_features
         _require_device(backbone_feat, c3, c4)
         num_random = int(rand_u.shape[0]) if rand_u is not None else 0
         P = 1 + num_random
-        net = tracker.net.bb_regressor
-        if net.training:
-            raise NotImplementedError("IoU refinement: eval-mode network")
-        self._bind_iou(net, c3, c4, P)
-        f, g = self.ff, self.glue
-        _loc.tracker_state(tracker, sample_pos, sample_scales, self.loc)
-        g.image_sz[:] = tracker.image_sz.tolist()
-        g.img_sample_sz[:] = tracker.img_sample_sz.tolist()
-        g.target_inside_ratio = p.get('target_inside_ratio', 0.2)
-        g.box_jitter_pos, g.box_jitter_sz = p.box_jitter_pos, p.box_jitter_sz
-        g.use_classifier = int(bool(p.get('use_classifier', True)))
+        b = self._bound
+        if b is None or b[0] is not tracker or b[1] != num_random or b[2] != c3.shape or b[3] != c4.shape:
+            self.bind(tracker, iou_features, num_random)
+        f, g, st = self.ff, self.glue, self.loc
+        # the per-frame state: where the target is, where the sample was taken, this frame's random numbers, this frame's tensors
+        st.target_sz[:] = tracker.target_sz.tolist()
+        st.pos[:] = tracker.pos.tolist()
+        scales = sample_scales.reshape(-1).tolist()
+        if len(scales) != 1:
+            raise NotImplementedError("pt_track_frame_full_f32: one sample scale")
+        st.sample_scales[0] = scales[0]
+        st.sample_pos[:2] = sample_pos.reshape(-1).tolist()
         if num_random:
             g.rand_u[:4 * num_random] = rand_u.reshape(-1).tolist()
         f.backbone_feat, f.slot = backbone_feat.data_ptr(), int(slot)
         f.c3, f.c4 = c3.data_ptr(), c4.data_ptr()
         mod3, mod4 = tracker.iou_modulation
         f.mod3, f.mod4 = mod3.data_ptr(), mod4.data_ptr()
-        sl = p.box_refinement_step_length
-        f.step_length4[:] = [sl[0], sl[0], sl[1], sl[1]] if isinstance(sl, (tuple, list)) else [float(sl)] * 4
-        f.step_decay = p.box_refinement_step_decay
-        f.iou_iter = p.box_refinement_iter
-        f.relative = int(p.get('box_refinement_space', 'default') == 'relative')
-        rc = _lib.lib().pt_track_frame_full_f32(ctypes.byref(f), self._host_ptr, self._ws.data_ptr(), self._ws.numel(),
-                                                torch.cuda.current_stream().cuda_stream)
-        _lib.check(rc, "pt_track_frame_full_f32")
+        rc = self._call(self._ffref, self._host_ptr, self._ws_ptr, self._ws_len, torch.cuda.current_stream().cuda_stream)
+        if rc:
+            _lib.check(rc, "pt_track_frame_full_f32")
         h = torch.from_numpy(self._host_np.copy())
         return {"translation_vec": h[4:6], "scale_ind": int(h[1]), "flag": _lib.PT_LOC_FLAGS[int(h[0])], "pos": h[16:18],
                 "init_box": h[18:22], "boxes": h[32:32 + 4 * P].view(P, 4), "iou": h[96:96 + P], "peak": h[2:4]}
