@@ -793,6 +793,8 @@ def gen_trackers():
     save("tracker_tomp50", **rec.to_npz_dict())
     outs, rec, _ = TH.run_atom(**TH.ATOM_RUN)
     save("tracker_atom18", **rec.to_npz_dict())
+    outs, rec, _ = TH.run_dimp(**TH.PRDIMP_RUN)
+    save("tracker_prdimp50", **rec.to_npz_dict())
 
 
 if __name__ == "__main__":

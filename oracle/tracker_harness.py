@@ -111,14 +111,24 @@ DIMP50_TEST = dict(C_backbone=1024, C_layer2=512, C=512, H=18, W=18, H2=36, W2=3
 DIMP_RUN = dict(seed=4100, n_frames=10, dims=DIMP50_TEST, thresholds=dict(target_not_found_threshold=0.1))
 
 
-def seed_dimp_net(net, seed, dims):
+# PrDiMP-50 (pytracking/parameter/dimp/prdimp50.py): 22x22 maps from 352x352 samples, Newton / KL optimiser, soft-max score
+# preprocessing, box refinement in the relative parametrisation (10 iterations).  Random-init soft-max scores sit near 1 / 23^2: the
+# not-found threshold is lowered to that level so that the run reaches refinement and update, the hard-negative threshold to 0.3 so that
+# the 8 frames hold both outcomes (6 hard negatives: 1-iteration updates; 2 normal frames: the regular 2-iteration update).
+PRDIMP50_TEST = dict(C_backbone=1024, C_layer2=512, C=512, H=22, W=22, H2=44, W2=44, C_iou=256, K=4, base_seed=43, noise=0.3)
+PRDIMP_RUN = dict(seed=4700, n_frames=8, dims=PRDIMP50_TEST, variant="prdimp",
+                  thresholds=dict(target_not_found_threshold=0.0021, hard_negative_threshold=0.3))
+
+
+def seed_dimp_net(net, seed, dims, init=True):
     """Overwrite the hot-path parameters of a reference `dimpnet50` with the seeded values of pytracking_amd/synth.py
     (the same generators rebuild them on the GPU box)."""
     p = synth.tracker_dimp_params(seed, dims)
     with torch.no_grad():
         net.classifier.feature_extractor[0].weight.copy_(torch.from_numpy(p["head.weight"]))
-        net.classifier.filter_initializer.filter_conv.weight.copy_(torch.from_numpy(p["init.weight"]))
-        net.classifier.filter_initializer.filter_conv.bias.copy_(torch.from_numpy(p["init.bias"]))
+        if init:
+            net.classifier.filter_initializer.filter_conv.weight.copy_(torch.from_numpy(p["init.weight"]))
+            net.classifier.filter_initializer.filter_conv.bias.copy_(torch.from_numpy(p["init.bias"]))
         sd = net.bb_regressor.state_dict()
         for k, v in p.items():
             if k.startswith("iou."):
@@ -139,6 +149,37 @@ def build_dimp50(seed, dims=DIMP50_TEST):
     net.eval()
     seed_dimp_net(net, seed, dims)
     return net
+
+
+def build_prdimp50(seed, dims=PRDIMP50_TEST):
+    """`klcedimpnet50` with the deployed hyper-parameters (ltr/train_settings/dimp/prdimp50.py:95-98: zero filter initialiser,
+    step 1.0, reg 0.05, alpha_eps 0.05, normalised label density with sigma = output_sigma * feature_sz), head + IoU weights seeded."""
+    ref_harness.install()
+    import ltr.models.tracking.dimpnet as dimpnet
+    torch.manual_seed(seed)
+    net = dimpnet.klcedimpnet50(filter_size=4, backbone_pretrained=False, optim_iter=5, clf_feat_norm=True, clf_feat_blocks=0,
+                                final_conv=True, out_feature_dim=dims["C"], optim_init_step=1.0, optim_init_reg=0.05,
+                                optim_min_reg=0.05, gauss_sigma=(1 / 4 / 6.0) * dims["H"], alpha_eps=0.05, normalize_label=True,
+                                init_initializer='zero')
+    net.eval()
+    seed_dimp_net(net, seed, dims, init=False)
+    return net
+
+
+def prdimp50_params(net_stub):
+    """pytracking/parameter/dimp/prdimp50.py on top of the DiMP set (same cadence shortening, cv2-only / random augmentations dropped)."""
+    p = dimp50_params(net_stub)
+    p.image_sample_size = 22 * 16
+    p.search_area_scale = 6
+    p.border_mode = 'inside_major'
+    p.patch_max_scale_change = 1.5
+    p.score_preprocess = 'softmax'
+    p.target_not_found_threshold = 0.04
+    p.box_refinement_space = 'relative'
+    p.box_refinement_iter = 10
+    p.box_refinement_step_length = 2.5e-3
+    p.box_refinement_step_decay = 1
+    return p
 
 
 class NetStub:
@@ -210,16 +251,16 @@ def synthetic_frame(rng, hw=(360, 480)):
     return rng.integers(0, 256, size=(hw[0], hw[1], 3), dtype=np.uint8)
 
 
-def run_dimp(seed=4100, n_frames=6, dims=DIMP50_TEST, record=True, score_gain=None, thresholds=None, device="cpu"):
+def run_dimp(seed=4100, n_frames=6, dims=DIMP50_TEST, record=True, score_gain=None, thresholds=None, device="cpu", variant="dimp"):
     """initialize() + n_frames x track() of the reference DiMP on a stubbed backbone.  Returns (outputs, recorder).
     `device="cuda"`: the same unmodified tracker as the reference runs it on a GPU (`params.use_gpu = True`, network and
     features on the device)."""
     ref_harness.install()
     from pytracking.tracker.dimp.dimp import DiMP
-    net = build_dimp50(seed, dims).to(device)
+    net = (build_prdimp50 if variant == "prdimp" else build_dimp50)(seed, dims).to(device)
     stub = StubBackbone(seed, dims, device)
     ns = NetStub(net, stub)
-    params = use_device(dimp50_params(ns), device)
+    params = use_device((prdimp50_params if variant == "prdimp" else dimp50_params)(ns), device)
     if thresholds:
         for k, v in thresholds.items():
             setattr(params, k, v)
@@ -307,7 +348,10 @@ def run_dimp(seed=4100, n_frames=6, dims=DIMP50_TEST, record=True, score_gain=No
     box = [200.0, 140.0, 70.0, 90.0]
     tracker.initialize(synthetic_frame(rng), {"init_bbox": box})
     opt_mod = net.classifier.filter_optimizer
-    if record:
+    if record and variant == "prdimp":
+        rec.add("optimizer_params", log_step_length=opt_mod.log_step_length.detach(), filter_reg=opt_mod.filter_reg.detach(),
+                min_filter_reg=float(opt_mod.min_filter_reg), gauss_sigma=float(opt_mod.gauss_sigma), alpha_eps=float(opt_mod.alpha_eps))
+    elif record:
         rec.add("optimizer_params", log_step_length=opt_mod.log_step_length.detach(), filter_reg=opt_mod.filter_reg.detach(),
                 min_filter_reg=float(opt_mod.min_filter_reg), label_lut=opt_mod.label_map_predictor.weight.detach().reshape(-1),
                 mask_lut=opt_mod.target_mask_predictor[0].weight.detach().reshape(-1),

@@ -159,3 +159,37 @@ def test_gfx950_modules_replay_the_atom_tracker_log():
     dev = TR.replay_atom(evs, TR.AtomMirrorOps(evs, "cuda"), atol=1e-4)
     assert set(dev) == {"gn_filter", "gn_projection", "classify", "refine_iou", "refine_boxes", "cg_filter"}
     print("ATOM: max deviation per boundary call over the 8-frame trajectory:", {k: f"{v:.2e}" for k, v in dev.items()})
+
+
+# ------------------------------------------------------------------------------------------------------
+# PrDiMP-50: the DiMP tracker class with pytracking/parameter/dimp/prdimp50.py (Newton / KL optimiser, soft-max score preprocessing,
+# 22x22 maps, relative box refinement, 10 iterations): tests/golden/tracker_prdimp50.npz.  The whole-tracker comparison on the device
+# is tests/test_trackers_on_device.py.
+# ------------------------------------------------------------------------------------------------------
+def test_prdimp_log_covers_both_outcomes_and_the_relative_refinement():
+    evs = TR.events_from_npz(load_golden("tracker_prdimp50"))
+    kinds = [e["kind"] for e in evs]
+    assert sum(k == "classify" for k in kinds) == int(evs[0]["n_frames"]) == 8
+    assert {str(e["flag"]) for e in evs if e["kind"] == "localize"} == {"normal", "hard_negative"}
+    assert {str(e["method"]) for e in evs if e["kind"] == "refine"} == {"optimize_boxes_relative"}
+    assert {int(e["num_iter"]) for e in evs if e["kind"] == "optimize"} == {1, 2}
+    assert next(e for e in evs if e["kind"] == "classify")["scores"].shape[-2:] == (23, 23)
+
+
+def test_reference_prdimp_tracker_reproduces_its_log():
+    """The recorded run is reproducible here (same seeds, same reference): guards the harness against drift."""
+    _need_reference()
+    from oracle import tracker_harness as TH
+    import torch
+    torch.set_num_threads(8)
+    outs, rec, _ = TH.run_dimp(**TH.PRDIMP_RUN)
+    want = TR.events_from_npz(load_golden("tracker_prdimp50"))
+    got = TR.events_from_npz({k: np.asarray(v) for k, v in rec.to_npz_dict().items()})
+    assert [e["kind"] for e in got] == [e["kind"] for e in want]
+    for a, b in zip(got, want):
+        for k in ("scores", "filter", "boxes", "iou", "target_bbox", "tv"):
+            if k in b:
+                np.testing.assert_allclose(np.asarray(a[k], dtype=np.float64), np.asarray(b[k], dtype=np.float64), atol=2e-5,
+                                           err_msg=f"{a['kind']}.{k}")
+        if "flag" in b:
+            assert str(a["flag"]) == str(b["flag"])

