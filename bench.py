@@ -179,6 +179,22 @@ def event_period_us(st, stream, which, reps=200):
     return e0.elapsed_time(e1) * 1e3 / reps
 
 
+def stream_floor_us(st, stream, reps=200):
+    """Event-pair period of `reps` back-to-back launches of the read-only probe over the sample memory (pt_stream_probe_f32): what the
+    memory system delivers for this footprint (the 33 MB stay in the Infinity Cache / L2s between launches, like between passes)."""
+    L = _lib.lib()
+    scratch = torch.zeros(2048, dtype=torch.float32, device=st.mem_feat.device)
+    sp = ctypes.c_void_p(stream.cuda_stream)
+    args = (st.mem_feat.data_ptr(), st.mem_feat.numel(), scratch.data_ptr())
+    _lib.check(L.pt_stream_probe_f32(*args, 20, sp), "pt_stream_probe_f32")
+    e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+    e0.record(stream)
+    _lib.check(L.pt_stream_probe_f32(*args, reps, sp), "pt_stream_probe_f32")
+    e1.record(stream)
+    e1.synchronize()
+    return e0.elapsed_time(e1) * 1e3 / reps
+
+
 PROF_FRAMES, PROF_WARMUP = 200, 10
 
 
@@ -241,7 +257,7 @@ def _frames_in_trace(stats):
     return sum(calls) if calls else None
 
 
-def roofline(cfg, cfg_name, n, period, stats, why, stats_eager=None):
+def roofline(cfg, cfg_name, n, period, stats, why, stats_eager=None, floor_period_us=None):
     """Assemble the roofline object from the kernel-level legs measured in front of the frame timing: `period` (HIP event
     pairs around 200 back-to-back pass launches), `stats` (rocprofv3 kernel averages of the GRAPH-REPLAY child: the mode
     the headline is timed in) and `stats_eager` (the same frames launched one by one)."""
@@ -287,9 +303,24 @@ def roofline(cfg, cfg_name, n, period, stats, why, stats_eager=None):
 
     def per_frame(table):
         fr = _frames_in_trace(table) if table else None
-        return None if not fr else round(sum(c * a for c, a in table.values()) / 1e3 / fr, 2)
+        return None if not fr else round(sum(c * a for nm, (c, a) in table.items() if "k_stream_probe" not in nm) / 1e3 / fr, 2)
+    # the streaming floor of a pass: the read-only probe over the same memory, by the same clock as `avg_launch_us` when the trace has
+    # it (rocprofv3 duration of k_stream_probe in the graph child), else by the event-pair period
+    probe = avg(stats, "k_stream_probe") or avg(stats_eager, "k_stream_probe")
+    floor_us = probe[0] if probe else (round(floor_period_us, 3) if floor_period_us else None)
+    dom_us = kern[dom].get("avg_launch_us", kern[dom]["period_us"])
+    floor = None
+    if floor_us:
+        floor = {"stream_floor_us": floor_us, "stream_floor_GBs": round(feat_bytes / floor_us / 1e3, 1),
+                 "stream_floor_period_us": None if floor_period_us is None else round(floor_period_us, 3),
+                 "frac_of_floor": round(floor_us / dom_us, 4),
+                 "what": "a kernel that only reads the same sample memory (2048 workgroups, 16-byte loads, 8 in flight per lane; "
+                         "pt_stream_probe_f32): the footprint lives in the Infinity Cache / L2s between launches, so this -- not 8 TB/s -- "
+                         "is what the memory system can deliver to a pass; frac_of_floor = stream_floor_us / the dominant pass's duration"}
     return {"bound": "hbm", "kernel": dom, "achieved": kern[dom]["achieved_GBs"], "peak": HBM_PEAK_GBS, "unit": "GB/s",
-            "frac": round(kern[dom]["achieved_GBs"] / HBM_PEAK_GBS, 4), "traffic": traffic, "traffic_source": traffic_src,
+            "frac": round(kern[dom]["achieved_GBs"] / HBM_PEAK_GBS, 4), "stream_floor_us": floor_us if floor_us else None,
+            "frac_of_floor": floor["frac_of_floor"] if floor else None, "stream_floor": floor,
+            "traffic": traffic, "traffic_source": traffic_src,
             "avg_launch_us": kern[dom].get("avg_launch_us", kern[dom]["period_us"]), "timing": timing,
             "algorithmic_bytes_per_launch": feat_bytes, "kernels": kern,
             "sum_kernels_us_per_frame": {"graph": per_frame(stats), "eager": per_frame(stats_eager),
@@ -479,6 +510,7 @@ def main():
                     run_frames(st, pool, Wm, PROF_GRAPH)
                 for _ in range(max(1, K // PROF_GRAPH)):
                     g.replay()
+            stream_floor_us(st, stream, reps=40)               # the read-only probe, so that the same trace times it (k_stream_probe)
             stream.synchronize()
         return
 
@@ -568,7 +600,13 @@ def main():
                 stream.synchronize()
                 repeats.append(round(1e6 * (time.perf_counter() - t1) / K, 2))
 
-        roof = roofline(cfg, cfg_name, n, period, stats, why, stats_eager) if want_roof and period else None
+        floor_period = None
+        if want_roof and period:
+            try:
+                floor_period = stream_floor_us(st, stream)
+            except RuntimeError:
+                floor_period = None
+        roof = roofline(cfg, cfg_name, n, period, stats, why, stats_eager, floor_period) if want_roof and period else None
 
     # the only collective: the end-of-batch (frames, seconds) gather; whole-job rate = all frames / slowest rank
     total_frames, tmax, per_rank = sequences.gather_throughput(K, elapsed, device=dev)

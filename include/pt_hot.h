@@ -453,6 +453,10 @@ int pt_track_frame_full_f32(const pt_frame_full* f, float* out_host, void* ws, s
 /* the launches without the wait (graph capture, or a caller that waits on the stream itself) */
 int pt_track_frame_full_launch_f32(const pt_frame_full* f, float* out, void* ws, size_t ws_bytes, void* stream);
 
+/* Measurement helper (bench.py): `reps` back-to-back launches of a kernel that only READS `floats` floats of `mem` (16-byte aligned)
+ * with every CU -- the streaming floor of one feature pass over that footprint.  scratch2048: 2048 floats of device memory. */
+int pt_stream_probe_f32(const float* mem, size_t floats, float* scratch2048, int reps, void* stream);
+
 /* Result buffers of the *_sync_* / full-frame entry points are verified once (pinned, device-writable) and remembered;
  * call this before freeing such a buffer so that a later allocation at the same address is verified again. */
 void pt_host_buffer_forget(const void* p);

@@ -91,7 +91,7 @@ EXPORTS = [
     "pt_iou_param_floats", "pt_iou_prepared_floats", "pt_iou_prepare_f32", "pt_iou_refine_ws_bytes", "pt_iou_refine_f32", "pt_iou_refine_sync_f32",
     "pt_track_frame_replay_pass_f32", "pt_sample_patch_f32", "pt_augment_patches_f32", "pt_track_frame_head_ws_bytes", "pt_track_frame_head_f32",
     "pt_track_frame_full_ws_bytes", "pt_track_frame_full_f32", "pt_track_frame_full_launch_f32", "pt_host_buffer_forget",
-    "pt_sd_solve_batch_f32",
+    "pt_sd_solve_batch_f32", "pt_stream_probe_f32",
 ]
 
 
@@ -308,6 +308,8 @@ def lib():
     L.pt_track_frame_full_f32.argtypes = [ffp, vp, vp, sz, vp]
     L.pt_track_frame_full_launch_f32.restype = i
     L.pt_track_frame_full_launch_f32.argtypes = [ffp, vp, vp, sz, vp]
+    L.pt_stream_probe_f32.restype = i
+    L.pt_stream_probe_f32.argtypes = [vp, sz, vp, i, vp]
     L.pt_host_buffer_forget.restype = None
     L.pt_host_buffer_forget.argtypes = [vp]
     L.pt_sample_patch_f32.restype = i

@@ -32,6 +32,15 @@ def test_roofline_object_from_graph_and_eager_tables():
     per = r["sum_kernels_us_per_frame"]
     want = (5 * 8.2 + 7.7 + 5 * 7.6 + 7 * 5.0)
     assert abs(per["graph"] - want) < 0.02 and per["eager"] > per["graph"]
+    # the streaming floor: the probe's duration from the same trace when it is there, the event period otherwise
+    st = _stats(8200.0, 7600.0, 200)
+    st["k_stream_probe(float const*, long, float*)"] = (40, 3700.0)
+    r3 = bench.roofline(cfg, "dimp50", n, {"corr": 8.1, "adj": 7.6}, st, "", None, floor_period_us=4.4)
+    assert r3["stream_floor_us"] == 3.7 and abs(r3["frac_of_floor"] - 3.7 / r3["avg_launch_us"]) < 1e-3
+    assert r3["stream_floor"]["stream_floor_period_us"] == 4.4 and r3["stream_floor"]["stream_floor_GBs"] > 8000
+    assert abs(r3["sum_kernels_us_per_frame"]["graph"] - want) < 0.02          # the probe launches are not part of a frame
+    r4 = bench.roofline(cfg, "dimp50", n, {"corr": 8.1, "adj": 7.6}, None, "x", None, floor_period_us=4.4)
+    assert r4["stream_floor_us"] == 4.4 and r["stream_floor_us"] is None
     # no trace at all: the event period (pessimistic by one launch boundary) carries the fraction and `timing` says so
     r2 = bench.roofline(cfg, "dimp50", n, {"corr": 8.1, "adj": 7.6}, None, "multi-rank run: no profiling child", None)
     assert r2["avg_launch_us"] == 8.1 and "event pair" in r2["timing"] and r2["sum_kernels_us_per_frame"]["graph"] is None
