@@ -184,11 +184,20 @@ __global__ __launch_bounds__(256) void k_acg_red(const float* __restrict__ gpart
     }
 }
 
-template <bool LEFT>
+// FOLD (round 5): the partial-sum launch between the adjoint and this kernel is gone -- in phases 1 / 2 `h_in` points at the adjoint's
+// KSPL position-slice partials (KSPL in h_geo bits 16..22) and every workgroup adds them itself (256 KB from its XCD's L2, one round of
+// 16-byte loads issued in front of everything else, two halves met in LDS in a fixed order), forms r = -(sum + lambda x) or
+// q = sum + lambda p and the dot product p.q with the block reduction the recurrences already use.  13 instead of 19 launches per
+// 5-iteration update.  MEASURED SLOWER (106.4 vs 97.7 us, profiles/r05p_atom_fold_ab.txt) and therefore off unless PT_ACG_FOLD=1.
+#ifndef PT_ACG_INFLIGHT
+#define PT_ACG_INFLIGHT 16                 // 16-byte partial loads in flight per thread in the folded sum (32 per thread at KSPL = 64)
+#endif
+template <bool LEFT, bool FOLD>
 __global__ __launch_bounds__(640, 2) void k_acg_fwd(const float* h_feat, long h_stride, const float* h_cur, const float* h_in, unsigned h_dims,
                                                     unsigned h_geo, float h_lambda, AcgLate l_arg) {
-    // h_in: phase 0 the filter x; phase 1 the right-hand side r (k_acg_red); phase 2 q.   h_cur: state block of the previous step.
-    // h_dims = C << 16 | H*W;  h_geo = tiles | TF << 5 | rem << 10 | phase << 14 | num_iter-step info unused
+    // h_in: phase 0 the filter x; phase 1 the right-hand side r (k_acg_red); phase 2 q (FOLD: the adjoint's partials in phases 1, 2).
+    // h_cur: state block of the previous step.
+    // h_dims = C << 16 | H*W;  h_geo = tiles | TF << 5 | rem << 10 | phase << 14 | KSPL << 16
     extern __shared__ __attribute__((aligned(16))) float lds[];     // afilt[C][16] | T[2][16][HWp]
     __shared__ float scratch[16];
     constexpr int NK = 8;
@@ -210,10 +219,32 @@ __global__ __launch_bounds__(640, 2) void k_acg_fwd(const float* h_feat, long h_
         return;
     }
 
+    // ---- FOLD: this workgroup's share of the partial sums goes out first (the memory counter retires in order: the feature loads
+    //      behind it stay in flight while these are waited for)
+    const int ncol = CKK >> 2;                                      // 16-byte columns of a partial
+    const int fsub = nthreads / ncol;                               // partial subsets summed side by side (2 for 1024 elements)
+    const int fs = (int)threadIdx.x / ncol, fcol = (int)threadIdx.x - fs * ncol;
+    f32x4 facc = {0.f, 0.f, 0.f, 0.f};
+    if (FOLD && phase >= 1 && fs < fsub) {
+        const int KSPL = (int)((h_geo >> 16) & 127u);
+        const f32x4* __restrict__ gp = (const f32x4*)h_in + fcol;
+        for (int k0 = fs; k0 < KSPL; k0 += PT_ACG_INFLIGHT * fsub) {
+            f32x4 v[PT_ACG_INFLIGHT];
+#pragma unroll
+            for (int u = 0; u < PT_ACG_INFLIGHT; ++u) v[u] = gp[(long)min(k0 + u * fsub, KSPL - 1) * ncol];
+#pragma unroll
+            for (int u = 0; u < PT_ACG_INFLIGHT; ++u) {
+                const bool ok = k0 + u * fsub < KSPL;
+#pragma unroll
+                for (int r = 0; r < 4; ++r) facc[r] += ok ? v[u][r] : 0.f;
+            }
+        }
+    }
     // ---- operands of the vector stage (2 filter elements per thread) and the first feature tiles
     const int e0 = threadIdx.x, e1 = threadIdx.x + nthreads;
     const int c0 = min(e0, CKK - 1), c1 = min(e1, CKK - 1);
-    float in0 = h_in[c0], in1 = h_in[c1];
+    float in0 = 0.f, in1 = 0.f;
+    if (!FOLD || phase == 0) { in0 = h_in[c0]; in1 = h_in[c1]; }
     float p0 = 0.f, p1 = 0.f, r0 = 0.f, r1 = 0.f, d0 = 0.f, d1 = 0.f, rp0 = 0.f, rp1 = 0.f, st0 = 0.f, st1 = 0.f;
     if (phase >= 1) {
         p0 = h_cur[c0]; p1 = h_cur[c1];
@@ -251,7 +282,20 @@ __global__ __launch_bounds__(640, 2) void k_acg_fwd(const float* h_feat, long h_
     const float sq = sqrtf(l.sw[i]);
     const float pw_in = phase == 0 ? l.y[qo] : l.d[qo];
     float pq = 0.f;
-    if (phase == 2) pq = lane < l.nred ? l.pqp[lane] : 0.f;
+    if (!FOLD && phase == 2) pq = lane < l.nred ? l.pqp[lane] : 0.f;
+    if (FOLD && phase >= 1) {                                       // the halves meet in LDS (the tap-plane region is free until the MFMAs)
+        float* __restrict__ fsum = lds + nsl;
+        if (fs < fsub) *(f32x4*)(fsum + (long)fs * CKK + 4 * fcol) = facc;
+        __syncthreads();
+        float s0 = 0.f, s1 = 0.f;
+        for (int q = 0; q < fsub; ++q) { s0 += fsum[(long)q * CKK + c0]; s1 += fsum[(long)q * CKK + c1]; }
+        if (phase == 1) {                                           // r = -(sum_k gpart[k] + lambda x)   (optimization.py:262-265)
+            in0 = -(s0 + h_lambda * l.x[c0]); in1 = -(s1 + h_lambda * l.x[c1]);
+        } else {                                                    // q = sum_k gpart[k] + lambda p
+            in0 = s0 + h_lambda * p0; in1 = s1 + h_lambda * p1;
+        }
+        __syncthreads();                                            // fsum is the tap-plane buffer again from here on
+    }
 
     // ---- the conjugate-gradient recurrences (optimization.py:100-146), identical in every workgroup
     float f0, f1;                                                   // this thread's two elements of the filter operand
@@ -267,7 +311,9 @@ __global__ __launch_bounds__(640, 2) void k_acg_fwd(const float* h_feat, long h_
             rn0 = in0; rn1 = in1;
             rpn0 = rp0; rpn1 = rp1;
         } else {                                                    // step: alpha, delta, residual (:127-146)
-            const float pqs = wave_sum(pq);
+            float pqs;
+            if (FOLD) pqs = block_sum((e0 < CKK ? p0 * in0 : 0.f) + (e1 < CKK ? p1 * in1 : 0.f), scratch, nthreads);
+            else pqs = wave_sum(pq);
             const float alpha = st0 / pqs;                          // :131
             dn0 = d0 + alpha * p0; dn1 = d1 + alpha * p1;           // :140-143
             rn0 = r0 - alpha * in0; rn1 = r1 - alpha * in1;         // :145-146
@@ -364,6 +410,53 @@ __global__ __launch_bounds__(640, 2) void k_acg_fwd(const float* h_feat, long h_
     }
 }
 
+// FOLD variant of the last step: p.q from the adjoint's partials directly (1024 threads = 16-byte columns x 4 partial subsets, one round
+// of loads, met in LDS), then as k_acg_final
+__global__ __launch_bounds__(1024) void k_acg_final_fold(const float* __restrict__ cur, const float* __restrict__ gpart, int KSPL, float lambda,
+                                                         float* __restrict__ x, float* __restrict__ cg_state, int CKK, int fr) {
+    __shared__ __attribute__((aligned(16))) float fsum[4 * 1280];
+    __shared__ float scratch[16];
+    const float* st = cur + 2 * CKK;
+    const bool stopped = st[2] != 0.f;
+    const int ncol = CKK >> 2, fsub = min(4, 1024 / ncol);
+    const int fs = (int)threadIdx.x / ncol, fcol = (int)threadIdx.x - fs * ncol;
+    float alpha = 0.f;
+    if (!stopped) {                                                  // uniform
+        f32x4 facc = {0.f, 0.f, 0.f, 0.f};
+        if (fs < fsub) {
+            const f32x4* __restrict__ gp = (const f32x4*)gpart + fcol;
+            for (int k0 = fs; k0 < KSPL; k0 += 16 * fsub) {
+                f32x4 v[16];
+#pragma unroll
+                for (int u = 0; u < 16; ++u) v[u] = gp[(long)min(k0 + u * fsub, KSPL - 1) * ncol];
+#pragma unroll
+                for (int u = 0; u < 16; ++u) {
+                    const bool ok = k0 + u * fsub < KSPL;
+#pragma unroll
+                    for (int r = 0; r < 4; ++r) facc[r] += ok ? v[u][r] : 0.f;
+                }
+            }
+            *(f32x4*)(fsum + (long)fs * CKK + 4 * fcol) = facc;
+        }
+        __syncthreads();
+        float acc = 0.f;
+        for (int e = threadIdx.x; e < CKK; e += 1024) {
+            float sv = 0.f;
+            for (int q = 0; q < fsub; ++q) sv += fsum[(long)q * CKK + e];
+            const float pv = cur[e];
+            acc += pv * (sv + lambda * pv);
+        }
+        alpha = st[0] / block_sum(acc, scratch);
+    }
+    for (int e = threadIdx.x; e < CKK; e += blockDim.x) {
+        const float pv = cur[e];
+        if (!stopped) x[e] += cur[3 * CKK + ACG_ST + e] + alpha * pv;
+        cg_state[e] = pv;
+        cg_state[CKK + e] = (!stopped && !fr) ? cur[2 * CKK + ACG_ST + e] : cur[CKK + e];
+    }
+    if (threadIdx.x == 0) { cg_state[2 * CKK] = st[0]; cg_state[2 * CKK + 1] = st[1]; }
+}
+
 // the last step of a solve (optimization.py:127-143, 259-260): alpha, delta, x += delta; persistent state back to the caller
 __global__ __launch_bounds__(1024) void k_acg_final(const float* __restrict__ cur, const float* __restrict__ q, const float* __restrict__ pqp,
                                                     float* __restrict__ x, float* __restrict__ cg_state, int CKK, int nred, int fr) {
@@ -441,12 +534,48 @@ static int acg_solve_fast(const PtFast& f, float* x, const float* samples, long 
     l.act_min = act_min; l.forget = forget;
     const unsigned dims = ((unsigned)f.C << 16) | (unsigned)f.HW;
     const unsigned geo0 = (unsigned)f.tiles | ((unsigned)f.TF << 5) | ((unsigned)f.rem << 10);
+    // A/B knob, OFF by default: measured in round 5 and lost -- 106.4 vs 97.7 us per 5-iteration update on the same box
+    // (profiles/r05p_atom_fold_ab.txt): every one of the 250 workgroups pulls the 256 KB of partials through its XCD's L2 (8 MB per XCD
+    // and step), which costs more than the dependent launch it removes.  Kept as the record of the experiment; parity-tested once with
+    // the knob on (tests/test_gpu_parity.py::test_atom_cg_folded_partial_sum_knob).
+    static const bool fold_env = [] { const char* e = getenv("PT_ACG_FOLD"); return e && e[0] == '1'; }();
+    // the folded sum keeps 4-float columns of a partial per thread and parks fsub * CKK floats in the tap-plane buffer
+    const int HWp = 64 * (f.TF + (f.rem > 0 ? 1 : 0)) + 4;
+    const bool fold = fold_env && (CKK % 4) == 0 && f.corr_threads >= CKK / 4 && (size_t)(f.corr_threads / (CKK / 4)) * CKK <= (size_t)2 * 16 * HWp &&
+                      CKK <= 1280 && ((uintptr_t)gpart % 16) == 0;
     auto fwd = [&](int phase, const float* cur, const float* in, float* nxt) {
         l.nxt = (pt_gf)nxt;
-        const unsigned geo = geo0 | ((unsigned)phase << 14);
-        if (f.left) hipLaunchKernelGGL((k_acg_fwd<true>), dim3(n), dim3(f.corr_threads), f.corr_lds, st, samples, stride_n, cur, in, dims, geo, lambda, l);
-        else hipLaunchKernelGGL((k_acg_fwd<false>), dim3(n), dim3(f.corr_threads), f.corr_lds, st, samples, stride_n, cur, in, dims, geo, lambda, l);
+        const unsigned geo = geo0 | ((unsigned)phase << 14) | ((unsigned)f.KSPL << 16);
+        if (fold) {
+            if (f.left) hipLaunchKernelGGL((k_acg_fwd<true, true>), dim3(n), dim3(f.corr_threads), f.corr_lds, st, samples, stride_n, cur, in, dims, geo, lambda, l);
+            else hipLaunchKernelGGL((k_acg_fwd<false, true>), dim3(n), dim3(f.corr_threads), f.corr_lds, st, samples, stride_n, cur, in, dims, geo, lambda, l);
+        } else {
+            if (f.left) hipLaunchKernelGGL((k_acg_fwd<true, false>), dim3(n), dim3(f.corr_threads), f.corr_lds, st, samples, stride_n, cur, in, dims, geo, lambda, l);
+            else hipLaunchKernelGGL((k_acg_fwd<false, false>), dim3(n), dim3(f.corr_threads), f.corr_lds, st, samples, stride_n, cur, in, dims, geo, lambda, l);
+        }
     };
+    if (fold) {
+        // fwd(0) -> adjoint -> [fwd(1 / 2) -> adjoint] x num_iter -> final: the partials go straight from the adjoint to their consumer
+        fwd(0, cg_state, x, nullptr);
+        PT_CHECK_LAUNCH();
+        int rc = pt_launch_adj2_plain(f, samples, stride_n, (const float*)l.rmap, gpart, st);
+        if (rc) return rc;
+        fwd(1, cg_state, gpart, S[0]);
+        PT_CHECK_LAUNCH();
+        rc = pt_launch_adj2_plain(f, samples, stride_n, (const float*)l.rmap, gpart, st);
+        if (rc) return rc;
+        int cur = 0;
+        for (int ii = 0; ii < num_iter - 1; ++ii) {
+            fwd(2, S[cur], gpart, S[cur ^ 1]);
+            PT_CHECK_LAUNCH();
+            cur ^= 1;
+            rc = pt_launch_adj2_plain(f, samples, stride_n, (const float*)l.rmap, gpart, st);
+            if (rc) return rc;
+        }
+        hipLaunchKernelGGL(k_acg_final_fold, dim3(1), dim3(1024), 0, st, (const float*)S[cur], (const float*)gpart, f.KSPL, lambda, x, cg_state, CKK, fr);
+        PT_CHECK_LAUNCH();
+        return PT_OK;
+    }
     // linearisation point: s0 = conv(x), d, J^T f0
     fwd(0, cg_state, x, nullptr);
     PT_CHECK_LAUNCH();

@@ -2,6 +2,7 @@
 vectors on identical seeded inputs.  Tolerance: BASELINE.json north_star asks for 1e-4 abs on score maps /
 filters; 2e-5 is asserted where the arithmetic is smooth, 1e-4 where a sign(s) flip of a near-zero score can
 move an iterate discontinuously (LeakyReluParDeriv, activation.py:43-44)."""
+import os
 import types
 
 import numpy as np
@@ -1428,3 +1429,20 @@ def test_sd_multi_sequence_batch_equals_single_sequence_calls(kind):
         assert torch.equal(batch_its[:, s], single[s][0]), s
     tot = sum(x[1] for x in single) / S
     close(torch.cat(losses), tot.cpu().numpy(), atol=1e-6, rtol=1e-6)
+
+
+def test_atom_cg_folded_partial_sum_knob():
+    """The round-5 experiment kept behind PT_ACG_FOLD=1 (partial sums folded into the forward kernel: measured slower, off by default)
+    computes the same update: run in a child process with the knob on, against the BASELINE configs[0]-size golden."""
+    import subprocess
+    import sys
+    code = ("import os,sys,numpy as np,torch;sys.path.insert(0,'tests');sys.path.insert(0,'.');"
+            "import test_gpu_parity as G;from conftest import load_golden;from pytracking_amd import synth;"
+            "g=load_golden('atom_cg_cfg1_n250');x0,s,y,sw=synth.atom_problem(int(g['seed']),int(g['n']));"
+            "o=G._atom_run(x0,s,y,sw,5,False,1).cpu().numpy();print('ERR',float(np.abs(o-g['x_out']).max()))")
+    env = dict(os.environ, PT_ACG_FOLD="1")
+    res = subprocess.run([sys.executable, "-c", code], cwd=os.path.dirname(os.path.dirname(os.path.abspath(__file__))), env=env,
+                         capture_output=True, text=True, timeout=600)
+    assert res.returncode == 0, res.stderr[-2000:]
+    err = float([ln for ln in res.stdout.splitlines() if ln.startswith("ERR")][0].split()[1])
+    assert err < 5e-6, err
