@@ -159,3 +159,67 @@ def test_full_frame_argument_checks():
     assert L.pt_track_frame_full_f32(ctypes.byref(f), None, None, 0, None) == _lib.PT_ERR_NULL
     pageable = torch.zeros(128)
     assert L.pt_track_frame_full_f32(ctypes.byref(f), pageable.data_ptr(), None, 0, None) == _lib.PT_ERR_UNSUPPORTED
+
+
+def test_full_frame_launch_variant_is_graph_capturable():
+    """`pt_track_frame_full_launch_f32` (launches only, no host wait) captured into a hipGraph and replayed: the replay leaves the same
+    result block as the eager, host-polled call on an identical sequence (one stream and two)."""
+    import ctypes
+    from pytracking_amd import _lib, bench_frame, frame_full
+    dev = torch.device("cuda", 0)
+    C, n = 64, 6
+    cfg = dict(synth.DIMP50, C=C)
+    rng = np.random.default_rng(5)
+    head_w = torch.from_numpy(rng.standard_normal((C, 256, 3, 3), dtype=np.float32) * np.float32(0.02)).to(dev)
+    net = _iou_net(dev, 9)
+    gen = torch.Generator().manual_seed(321)
+    iou_feat = (torch.randn(1, 256, 36, 36, generator=gen).to(dev), torch.randn(1, 256, 18, 18, generator=gen).to(dev))
+    mod = ((torch.rand(1, 256, generator=gen) + 0.5).to(dev), (torch.rand(1, 256, generator=gen) + 0.5).to(dev))
+    p = Params(target_not_found_threshold=0.05, distractor_threshold=0.8, hard_negative_threshold=0.5, target_neighborhood_scale=2.2,
+               dispalcement_scale=0.8, box_refinement_iter=5, box_refinement_step_length=1, box_refinement_step_decay=1,
+               box_jitter_pos=0.1, box_jitter_sz=0.5, num_init_random_boxes=9)
+    me = types.SimpleNamespace(params=p, kernel_size=torch.Tensor([4, 4]), output_window=None, img_support_sz=torch.Tensor([288.0, 288.0]),
+                               img_sample_sz=torch.Tensor([288.0, 288.0]), image_sz=torch.Tensor([360.0, 480.0]),
+                               target_sz=torch.Tensor([60.0, 70.0]), pos=torch.Tensor([144.0, 150.0]),
+                               net=types.SimpleNamespace(bb_regressor=net), iou_modulation=mod)
+    xb = torch.from_numpy(rng.standard_normal((256, 18, 18), dtype=np.float32)).to(dev)
+    sample_pos, sample_scales, rand_u = torch.Tensor([[144.0, 150.0]]), torch.Tensor([1.0]), torch.rand(9, 4, generator=gen)
+    for overlap in (False, True):
+        pipes = []
+        for _ in range(2):
+            st = bench_frame.TrackState(cfg, n, seed=77, device=dev)
+            st.attach_head(head_w, (1.0 / (C * 16)) ** 0.5)
+            pipes.append(frame_full.FramePipeline(st, num_iter=2, overlap=overlap))
+        want = pipes[0].run(me, xb, 2, iou_feat, sample_pos, sample_scales, rand_u)          # eager, polled
+        torch.cuda.synchronize()
+        pb = pipes[1]
+        pb.bind(me, iou_feat, 9)
+        # fill the per-frame fields exactly as run() does, then capture the launches
+        st_, g_, f_ = pb.loc, pb.glue, pb.ff
+        st_.target_sz[:] = me.target_sz.tolist(); st_.pos[:] = me.pos.tolist()
+        st_.sample_scales[0] = 1.0; st_.sample_pos[:2] = [144.0, 150.0]
+        g_.rand_u[:36] = rand_u.reshape(-1).tolist()
+        f_.backbone_feat, f_.slot = xb.data_ptr(), 2
+        f_.c3, f_.c4, f_.mod3, f_.mod4 = iou_feat[0].data_ptr(), iou_feat[1].data_ptr(), mod[0].data_ptr(), mod[1].data_ptr()
+        out = torch.zeros(_lib.PT_FRAME_HOST_FLOATS, device=dev)
+        side = torch.cuda.Stream(device=dev)
+        L = _lib.lib()
+        with torch.cuda.stream(side):
+            g = torch.cuda.CUDAGraph()
+            with torch.cuda.graph(g, stream=side):
+                rc = L.pt_track_frame_full_launch_f32(ctypes.byref(f_), out.data_ptr(), pb._ws_ptr, pb._ws_len, side.cuda_stream)
+            assert rc == 0, rc
+            g.replay()
+            side.synchronize()
+        h = out.cpu()
+        assert torch.equal(h[4:6], want["translation_vec"]) and torch.equal(h[16:18], want["pos"]) and torch.equal(h[18:22], want["init_box"])
+        assert torch.equal(h[32:72].view(10, 4), want["boxes"]) and torch.equal(h[96:106], want["iou"]), overlap
+        assert float(h[127]) == -1.0                               # the launch variant's completion mark
+        torch.cuda.synchronize()
+        assert torch.equal(pipes[0].st.filter, pipes[1].st.filter)
+        # the host-polled entry refuses to run inside a capture instead of spinning on a word nothing will write
+        with torch.cuda.stream(side):
+            g2 = torch.cuda.CUDAGraph()
+            with torch.cuda.graph(g2, stream=side):
+                rc = L.pt_track_frame_full_f32(ctypes.byref(f_), pb._host_ptr, pb._ws_ptr, pb._ws_len, side.cuda_stream)
+            assert rc == _lib.PT_ERR_UNSUPPORTED

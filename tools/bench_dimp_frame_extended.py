@@ -116,6 +116,32 @@ def measure(dev, frames=300):
     finally:
         if gc_was:
             gc.enable()
+    # device-side floor of the one-call frame: its launches captured ONCE (fixed slot / feature / random numbers: a graph bakes the
+    # kernel arguments, so this is a measurement aid, not a way to run a tracker) and replayed back to back
+    import ctypes
+    for tag, pp in (("one_call_graph_replay_floor", pipe), ("one_call_two_streams_graph_replay_floor", pipe2)):
+        try:
+            pp.run(me, backbone_feat[0][0], 0, iou_feat, sample_pos, sample_scales, torch.rand(9, 4))     # fills every field
+            dev_out = torch.zeros(_lib.PT_FRAME_HOST_FLOATS, device=dev)
+            side = torch.cuda.Stream(device=dev)
+            with torch.cuda.stream(side):
+                g = torch.cuda.CUDAGraph()
+                with torch.cuda.graph(g, stream=side):
+                    rc = _lib.lib().pt_track_frame_full_launch_f32(ctypes.byref(pp.ff), dev_out.data_ptr(), pp._ws_ptr, pp._ws_len,
+                                                                   side.cuda_stream)
+                _lib.check(rc, "pt_track_frame_full_launch_f32")
+                for _ in range(5):
+                    g.replay()
+                side.synchronize()
+                t0 = time.perf_counter()
+                for _ in range(a.frames):
+                    g.replay()
+                side.synchronize()
+                dt = (time.perf_counter() - t0) / a.frames
+            out[tag] = {"us_per_frame": round(dt * 1e6, 1), "what": "the one-call frame's launches captured once and replayed back to back "
+                        "(fixed slot / inputs): what the device needs for the frame with no launch overhead and no host in the loop"}
+        except Exception as exc:                                  # noqa: BLE001
+            out[tag] = {"error": f"{type(exc).__name__}: {exc}"[:200]}
     out["one_call"]["what"] = ("the same frame through pt_track_frame_full_f32: head + solver + localisation + device-side glue (new "
                                "position, update_state clamp, get_iounet_box, 9 jittered proposals from host random numbers) + IoU "
                                "refinement, ONE ctypes call, ONE host wait")
