@@ -88,14 +88,15 @@ static int ff_launch(const pt_frame_full* f, float* out, void* ws, size_t ws_byt
     // 4. refinement; the last kernel writes boxes, IoU and the sequence word into the result block
     const int P = 1 + g->num_random;
     rc = pt_iou_refine_launch(f->iou_dims, f->iou_params, f->iou_prepared, f->c3, f->c4, f->mod3, f->mod4, base + cv.boxes, out + 32,
-                                out + 96, P, f->iou_iter, f->step_length4, f->step_decay, f->relative, 0, base + cv.iou,
-                                (cv.total - cv.iou) * sizeof(float), seq, out + 127, stream, &mid);
-    if (rc) return rc;
-    if (ev_join) {                                               // the caller's stream joins the chain
-        if (hipEventRecord(ev_join, (hipStream_t)chain) != hipSuccess) return PT_ERR_LAUNCH;
-        if (hipStreamWaitEvent((hipStream_t)main_stream, ev_join, 0) != hipSuccess) return PT_ERR_LAUNCH;
+                              out + 96, P, f->iou_iter, f->step_length4, f->step_decay, f->relative, 0, base + cv.iou,
+                              (cv.total - cv.iou) * sizeof(float), seq, out + 127, stream, &mid);
+    if (ev_join) {
+        // the caller's stream joins the chain -- also when the refinement refused its arguments: whatever was queued on the second
+        // stream stays inside the call's ordering contract (and a capture in progress must not be left with an open fork)
+        if (hipEventRecord(ev_join, (hipStream_t)chain) != hipSuccess || hipStreamWaitEvent((hipStream_t)main_stream, ev_join, 0) != hipSuccess)
+            return rc ? rc : PT_ERR_LAUNCH;
     }
-    return PT_OK;
+    return rc;
 }
 
 extern "C" int pt_track_frame_full_launch_f32(const pt_frame_full* f, float* out, void* ws, size_t ws_bytes, void* stream) {
