@@ -783,6 +783,12 @@ def gen_augment():
     save("augment", **out)
 
 
+def _lwl_compact(d):
+    """The decoder's 480 x 832 score maps are stock-PyTorch outputs and 1.6 MB each: stored as float16 (they are compared at 2e-3);
+    everything on the hot path (filters, mask encodings) stays float32."""
+    return {k: (np.asarray(v).astype(np.float16) if k.endswith("_scores") else v) for k, v in d.items()}
+
+
 def gen_trackers():
     """Trajectory-level vectors: the unmodified reference DiMP tracker (initialize + 10 x track) on a stubbed backbone,
     every boundary call recorded (oracle/tracker_harness.py)."""
@@ -795,6 +801,8 @@ def gen_trackers():
     save("tracker_atom18", **rec.to_npz_dict())
     outs, rec, _ = TH.run_dimp(**TH.PRDIMP_RUN)
     save("tracker_prdimp50", **rec.to_npz_dict())
+    outs, rec, _ = TH.run_lwl(**TH.LWL_RUN)
+    save("tracker_lwl", **_lwl_compact(rec.to_npz_dict()))
 
 
 if __name__ == "__main__":

@@ -910,3 +910,118 @@ class AtomRefOps:
         me = types.SimpleNamespace(params=self.params, iou_predictor=self.iounet,
                                    target_feat=TensorList([torch.from_numpy(m) for m in mods]))
         return ATOM.optimize_boxes(me, TensorList([torch.from_numpy(f) for f in feats]), torch.from_numpy(init_boxes))
+
+
+# ------------------------------------------------------------------------------------------------------
+# LWL (pytracking/tracker/lwl/lwl.py): video object segmentation; the few-shot learner (GNSteepestDescent on LWTLResidual, 16 filters
+# 3x3 over 512 x 30 x 52 maps) runs 20 iterations on the first frame and 3 on every later one over the growing memory
+# ------------------------------------------------------------------------------------------------------
+LWL_TEST = dict(C_layer1=256, C_layer2=512, C_backbone=1024, C_layer4=2048, C=512, H=30, W=52, H2=60, W2=104, base_seed=47, noise=0.3)
+LWL_RUN = dict(seed=4900, n_frames=6, dims=LWL_TEST)
+
+
+def build_lwl(seed, dims=LWL_TEST):
+    """`steepest_descent_resnet50` as ltr/train_settings/lwl/lwl_stage2.py:94-102 builds it (3x3 filters, 16 of them, label encoder
+    (16, 32, 64) without BatchNorm, no residual blocks + final conv in the target-model feature extractor); the 'imagenet' backbone
+    variant is constructed instead of 'mrcnn' -- the backbone is stubbed and never runs.  Random init under `torch.manual_seed`; the
+    decoder's and label encoder's BatchNorm / conv parameters are whatever that seed draws (stock modules on both sides)."""
+    ref_harness.install()
+    import ltr.models.lwl.lwl_net as lwl_net
+    torch.manual_seed(seed)
+    net = lwl_net.steepest_descent_resnet50(filter_size=3, num_filters=16, optim_iter=5, backbone_pretrained=False, out_feature_dim=dims["C"],
+                                            label_encoder_dims=(16, 32, 64), use_bn_in_label_enc=False, clf_feat_blocks=0, final_conv=True,
+                                            backbone_type='imagenet')
+    net.eval()
+    return net
+
+
+def lwl_params(net_stub):
+    """pytracking/parameter/lwl/lwl_ytvos.py."""
+    from pytracking.utils import TrackerParams
+    p = TrackerParams()
+    p.debug = 0
+    p.visualization = False
+    p.seg_to_bb_mode = 'var'
+    p.max_scale_change = (0.95, 1.1)
+    p.min_mask_area = 100
+    p.use_gpu = False
+    p.device = "cpu"
+    p.image_sample_size = (30 * 16, 52 * 16)
+    p.search_area_scale = 5.0
+    p.border_mode = 'inside_major'
+    p.patch_max_scale_change = None
+    p.sample_memory_size = 32
+    p.learning_rate = 0.1
+    p.init_samples_minimum_weight = 0.25
+    p.train_skipping = 1
+    p.update_target_model = True
+    p.net_opt_iter = 20
+    p.net_opt_update_iter = 3
+    p.net = net_stub
+    return p
+
+
+def run_lwl(seed=4900, n_frames=4, dims=LWL_TEST, device="cpu"):
+    """initialize() (with a box-shaped first-frame mask) + n_frames x track() of the reference LWL tracker on a stubbed backbone.
+    Events: lwl_init (the 20-iteration target model), lwl_segment (mask encoding = the multi-filter apply_filter, and the decoder's
+    raw scores), lwl_update (the 3-iteration few-shot learner over the memory), state."""
+    ref_harness.install()
+    from pytracking.tracker.lwl.lwl import LWL
+    net = build_lwl(seed, dims).to(device)
+    stub = StubBackbone(seed, dims, device)
+    ns = NetStub(net, stub)
+    params = use_device(lwl_params(ns), device)
+    tracker = LWL(params)
+    tracker.visdom = None
+    rec = Recorder()
+    rec.add("config", seed=seed, n_frames=n_frames, memory_size=params.sample_memory_size, **{f"dim_{k}": v for k, v in dims.items()})
+    tm = net.target_model
+    orig_get_filter = tm.get_filter
+
+    state = {"in_get_filter": False}
+
+    def get_filter(feat, *a, **kw):
+        state["in_get_filter"] = True
+        try:
+            w, its, losses = orig_get_filter(feat, *a, **kw)
+        finally:
+            state["in_get_filter"] = False
+        rec.add("lwl_init", num_iter=kw.get("num_iter"), filter=w[:, :, ::4], n=feat.shape[0])      # every 4th channel: the log stays small
+        rec.notes.append(("lwl_init", type(tm.filter_optimizer).__mro__[1].__module__ if len(type(tm.filter_optimizer).__mro__) > 1 else ""))
+        return w, its, losses
+    tm.get_filter = get_filter
+    opt = tm.filter_optimizer
+    orig_fwd = opt.forward
+
+    def opt_forward(meta_parameter, *a, **kw):
+        out = orig_fwd(meta_parameter, *a, **kw)
+        if not state["in_get_filter"] and kw.get("feat") is not None:                 # the per-frame update (lwl.py:574-578)
+            rec.add("lwl_update", num_iter=kw.get("num_iter"), n=kw["feat"].shape[0], filter=out[0][0][:, :, ::4])
+            rec.notes.append(("lwl_update", type(opt).__mro__[1].__module__))
+        return out
+    opt.forward = opt_forward
+    orig_seg = tracker.segment_target
+
+    def segment_target(sample_tm_feat, sample_x):
+        with torch.no_grad():
+            scores, enc = tracker.net.segment_target(tracker.target_filter, sample_tm_feat, sample_x)
+        rec.add("lwl_segment", mask_encoding=enc, scores=scores[..., ::8, ::8])                 # decoder output (stock), subsampled
+        return scores
+    tracker.segment_target = segment_target
+
+    rng = np.random.default_rng(seed + 77)
+    torch.manual_seed(seed)
+    hw = (480, 854)
+    box = [300.0, 180.0, 160.0, 120.0]                           # x, y, w, h
+    init_mask = np.zeros(hw, dtype=np.float32)
+    init_mask[int(box[1]):int(box[1] + box[3]), int(box[0]):int(box[0] + box[2])] = 1.0
+    out = tracker.initialize(synthetic_frame(rng, hw), {"init_bbox": box, "init_mask": init_mask})
+    prev = {"segmentation_raw": init_mask}
+    outs = []
+    for _ in range(n_frames):
+        rec.add("frame", frame=tracker.frame_num + 1)
+        out = tracker.track(synthetic_frame(rng, hw), {"previous_output": prev})
+        prev = {"segmentation_raw": np.asarray(out["segmentation_raw"]).reshape(hw)}
+        outs.append(np.array(out["target_bbox"], dtype=np.float64))
+        rec.add("state", target_bbox=outs[-1], mask_area=float(np.asarray(out["segmentation"]).sum()))
+    return np.stack(outs), rec, (tracker, net)

@@ -296,7 +296,15 @@ def tracker_backbone(seed, n, dims):
     sg = np.float32(dims.get("noise", 1.0))
     l3 = b3 + sg * rng.standard_normal((n, dims["C_backbone"], dims["H"], dims["W"]), dtype=np.float32)
     l2 = b2 + sg * rng.standard_normal((n, dims["C_layer2"], dims["H2"], dims["W2"]), dtype=np.float32)
-    return {"layer2": l2, "layer3": l3}
+    out = {"layer2": l2, "layer3": l3}
+    # the segmentation trackers' decoder also reads layer1 (stride 4) and layer4 (stride 32); drawn BEHIND the two maps above, so the
+    # streams of the dims without them are what they always were
+    if "C_layer4" in dims:
+        b4 = base.standard_normal((1, dims["C_layer4"], (dims["H"] + 1) // 2, (dims["W"] + 1) // 2), dtype=np.float32)
+        b1 = base.standard_normal((1, dims["C_layer1"], 2 * dims["H2"], 2 * dims["W2"]), dtype=np.float32)
+        out["layer4"] = b4 + sg * rng.standard_normal((n,) + b4.shape[1:], dtype=np.float32)
+        out["layer1"] = b1 + sg * rng.standard_normal((n,) + b1.shape[1:], dtype=np.float32)
+    return out
 
 
 def tracker_iou_feat(seed, n, dims):

@@ -194,3 +194,19 @@ def test_reference_prdimp_tracker_reproduces_its_log():
                                            err_msg=f"{a['kind']}.{k}")
         if "flag" in b:
             assert str(a["flag"]) == str(b["flag"])
+
+
+# ------------------------------------------------------------------------------------------------------
+# LWL: initialize() (box-shaped first-frame mask) + 6 x track() of the unmodified reference tracker on a stubbed backbone
+# (tests/golden/tracker_lwl.npz; filters logged on every 4th channel, decoder scores on every 8th pixel).  The whole-tracker comparison on
+# the device is tests/test_trackers_on_device.py.
+# ------------------------------------------------------------------------------------------------------
+def test_lwl_log_covers_the_growing_memory():
+    evs = TR.events_from_npz(load_golden("tracker_lwl"))
+    kinds = [e["kind"] for e in evs]
+    assert kinds.count("lwl_init") == 1 and kinds.count("lwl_segment") == 6
+    init = next(e for e in evs if e["kind"] == "lwl_init")
+    assert int(init["num_iter"]) == 20 and init["filter"].shape == (1, 16, 128, 3, 3)            # 20 iterations, 16 filters 3x3
+    ups = [e for e in evs if e["kind"] == "lwl_update"]
+    assert [int(e["n"]) for e in ups] == [2, 3, 4, 5, 6] and {int(e["num_iter"]) for e in ups} == {3}
+    assert next(e for e in evs if e["kind"] == "lwl_segment")["mask_encoding"].shape == (1, 1, 16, 30, 52)

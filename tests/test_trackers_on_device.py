@@ -10,7 +10,7 @@ import trackers_on_device as TOD
 pytestmark = [pytest.mark.gpu, pytest.mark.skipif(not ref_harness.available(), reason="no reference tree / bundle (oracle/_ref)")]
 
 
-@pytest.mark.parametrize("which", ["dimp", "prdimp", "tomp", "atom"])
+@pytest.mark.parametrize("which", ["dimp", "prdimp", "tomp", "atom", "lwl"])
 def test_reference_tracker_on_device_matches_its_cpu_run(which):
     dev, stats, times, extra = TOD.check(which, atol=1e-4)
     print(f"{which}: max deviation per boundary payload", {k: f"{v:.2e}" for k, v in sorted(dev.items())})

@@ -44,10 +44,14 @@ _REL_KEYS = {"checksum": 2e-5}
 # the reference's own stock-PyTorch GPU run deviates from its CPU run by 9.2e-5 on `refine.boxes`), so these payloads get 1e-4 plus
 # 1e-6 relative (~3 ulp) on top.  On identical inputs the 1e-4 bound is asserted without it by the replay tests
 # (tests/test_tracker_trajectory.py) and the golden tests of the refinement.
+# LWL only: outputs of the STOCK-PyTorch decoder behind the path (480 x 832 raw scores, stored as float16 in the log) and the box /
+# mask area the tracker derives from them -- not hot-path payloads; the hot-path payloads of the same events (filters, mask encodings)
+# keep the 1e-4 bound
+STOCK_OVERRIDES = {"lwl": {"scores": 2e-3, "target_bbox": 5e-2, "mask_area": 64.0}}
 _COORD_RTOL = {"boxes": 1e-6, "init_boxes": 1e-6, "target_bbox": 1e-6, "bb": 1e-6, "pos": 1e-6, "target_sz": 1e-6, "bbox": 1e-6}
 
 
-def compare_logs(got, want, atol=1e-4):
+def compare_logs(got, want, atol=1e-4, overrides=None):
     """Event-by-event comparison; returns {"kind.key": max abs deviation}.  Raises AssertionError with the first mismatch."""
     kg, kw = [e["kind"] for e in got], [e["kind"] for e in want]
     assert kg == kw, "event sequence differs from the CPU run:\n  got  %s\n  want %s" % (kg, kw)
@@ -75,6 +79,7 @@ def compare_logs(got, want, atol=1e-4):
                     assert np.array_equal(fin, np.isfinite(gv)), (i, tag, "non-finite pattern")
                     err = float(np.abs(gv[fin] - wv[fin]).max()) if fin.any() else 0.0
                     tol = atol + _COORD_RTOL.get(key, 0.0) * (float(np.abs(wv[fin]).max()) if fin.any() else 0.0)
+                    tol = max(tol, (overrides or {}).get(key, 0.0))
                     assert err <= tol, (i, tag, err, tol)
                 dev[tag] = max(dev.get(tag, 0.0), err)
     return dev
@@ -108,6 +113,7 @@ EXPECT_FAST = {
     "prdimp": ("residual_bottleneck", "PrRoIPool2D", "PrDiMPSteepestDescentNewton", "apply_filter", "DiMP.localize_advanced",
                "DiMP.optimize_boxes_relative"),
     "tomp": ("residual_bottleneck", "ToMP.localize_advanced"),
+    "lwl": ("GNSteepestDescent", "apply_filter"),
     "atom": ("GaussNewtonCG", "ConjugateGradient", "operation.conv2d[same]", "ATOM.optimize_boxes", "PrRoIPool2D"),
 }
 
@@ -140,6 +146,15 @@ def run(which, installed=True, device="cuda"):
             extra = {"filter_predictor": type(net.head.filter_predictor).__module__,
                      "transformer": type(net.head.filter_predictor.transformer).__module__,
                      "classifier": type(net.head.classifier).__module__, "bb_regressor": type(net.head.bb_regressor).__module__}
+        elif which == "lwl":
+            from pytracking.tracker.lwl.lwl import LWL as cls
+            times, undo = _timed_track(cls)
+            try:
+                outs, rec, (tracker, net) = TH.run_lwl(device=device, **TH.LWL_RUN)
+            finally:
+                undo()
+            extra = {"filter_optimizer": type(net.target_model.filter_optimizer).__mro__[1].__module__,
+                     "residual_module": type(net.target_model.filter_optimizer.residual_module).__mro__[1].__module__}
         elif which == "atom":
             from pytracking.tracker.atom.atom import ATOM as cls
             times, undo = _timed_track(cls)
@@ -159,12 +174,12 @@ def run(which, installed=True, device="cuda"):
     return events, stats, times, extra
 
 
-GOLDEN_NAME = {"dimp": "tracker_dimp50", "prdimp": "tracker_prdimp50", "tomp": "tracker_tomp50", "atom": "tracker_atom18"}
+GOLDEN_NAME = {"dimp": "tracker_dimp50", "prdimp": "tracker_prdimp50", "tomp": "tracker_tomp50", "atom": "tracker_atom18", "lwl": "tracker_lwl"}
 
 
 def check(which, atol=1e-4):
     events, stats, times, extra = run(which, installed=True)
-    dev = compare_logs(events, _golden(GOLDEN_NAME[which]), atol=atol)
+    dev = compare_logs(events, _golden(GOLDEN_NAME[which]), atol=atol, overrides=STOCK_OVERRIDES.get(which))
     for name in EXPECT_FAST[which]:
         assert stats.get(name + ".fast", 0) > 0, f"{which}: gfx950 branch of `{name}` never taken: {stats}"
     fell = {k: v for k, v in stats.items() if k.endswith(".reference") and not k.startswith(("sample_patch", "max2d"))}
@@ -176,7 +191,7 @@ def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--stock", action="store_true")
     ap.add_argument("--out", default=None)
-    ap.add_argument("--only", default="dimp,prdimp,tomp,atom")
+    ap.add_argument("--only", default="dimp,prdimp,tomp,atom,lwl")
     args = ap.parse_args()
     import torch
     lines = [f"unmodified reference trackers on {torch.cuda.get_device_name(0)} through pytracking_amd.install(); "
@@ -203,7 +218,7 @@ def main():
                 lines.append(f"   same tracker WITHOUT install() on the GPU (reference's stock PyTorch-ROCm ops, PrRoIPool = autograd "
                              f"restatement): track() wall ms per call: " + json.dumps([round(1e3 * t, 2) for t in t_stock]))
                 try:
-                    d2 = compare_logs(ev, _golden(GOLDEN_NAME[which]), atol=1e-3)
+                    d2 = compare_logs(ev, _golden(GOLDEN_NAME[which]), atol=1e-3, overrides=STOCK_OVERRIDES.get(which))
                     lines.append("   its deviation from the CPU run: " + json.dumps({k: float(f"{v:.3g}") for k, v in sorted(d2.items())}))
                 except AssertionError as exc:
                     lines.append(f"   its log does not match the CPU run within 1e-3: {str(exc)[:500]}")
