@@ -75,9 +75,11 @@ def _host_glue(me, tv, scale_ind, flag, sample_pos, sample_scales, rand_u):
     return me.pos.clone(), init_box, init_boxes
 
 
+NUM_ITER = {"no_update": 0}          # per case; 3 otherwise
 CASES = [
     # name, C, n, pos, target_sz, image_sz, thresholds (not_found), num_random, relative
     ("centre", 64, 6, (144.0, 150.0), (60.0, 70.0), (360.0, 480.0), 0.05, 9, False),
+    ("no_update", 64, 6, (140.0, 155.0), (64.0, 66.0), (360.0, 480.0), 0.05, 9, False),      # num_iter = 0: 19 of 20 real frames
     ("clamped_at_the_border", 64, 6, (4.0, 470.0), (90.0, 40.0), (200.0, 300.0), 0.05, 9, False),
     ("not_found", 64, 5, (100.0, 120.0), (50.0, 50.0), (360.0, 480.0), 1e9, 9, False),
     ("relative_space_no_random", 128, 7, (150.0, 133.0), (45.0, 85.0), (360.0, 480.0), 0.05, 0, True),
@@ -117,7 +119,8 @@ def test_full_frame_equals_the_per_call_route(case, overlap):
                                      net=types.SimpleNamespace(bb_regressor=net), iou_modulation=mod)
     me_a, me_b = tracker(), tracker()
     worst = [0.0]
-    pipe = frame_full.FramePipeline(states[1], num_iter=3, overlap=overlap)
+    nit = NUM_ITER.get(name, 3)
+    pipe = frame_full.FramePipeline(states[1], num_iter=nit, overlap=overlap)
     for frame in range(4):
         xb = torch.from_numpy(rng.standard_normal((256, 18, 18), dtype=np.float32)).to(dev)
         sample_pos = (me_a.pos + torch.Tensor([3.0 * frame, -2.0 * frame])).round().view(1, 2)
@@ -125,7 +128,7 @@ def test_full_frame_equals_the_per_call_route(case, overlap):
         rand_u = torch.rand(num_random, 4, generator=gen) if num_random else None
         slot = frame % n
         # ---- route A: three calls, two host round trips, the glue on the host
-        states[0].step_from_backbone(xb, slot, 3)
+        states[0].step_from_backbone(xb, slot, nit)
         tv, scale_ind, _, flag = LM.localize_advanced(me_a, states[0].scores[None], sample_pos, sample_scales)
         pos_a, init_box, init_boxes = _host_glue(me_a, tv, int(scale_ind), flag, sample_pos, sample_scales, rand_u)
         fn = IR.optimize_boxes_relative if relative else IR.optimize_boxes_default

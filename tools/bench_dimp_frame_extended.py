@@ -90,6 +90,15 @@ def measure(dev, frames=300):
     st2.attach_head(head[0].weight, head[1].scale, head[1].eps)
     pipe2 = frame_full.FramePipeline(st2, num_iter=5, overlap=True)
 
+    # what 19 of 20 real DiMP frames do (train_skipping = 20, parameter/dimp/dimp50.py:19): head, classification, memory insert,
+    # localisation, refinement -- no re-optimisation of the filter (num_iter = 0)
+    st3 = bench_frame.TrackState(cfg, cfg["memory"], seed=1234, device=dev)
+    st3.attach_head(head[0].weight, head[1].scale, head[1].eps)
+    pipe3 = frame_full.FramePipeline(st3, num_iter=0)
+
+    def frame_one_call_no_update(i, parts):
+        pipe3.run(me, backbone_feat[i % 8][0], i % st3.n, iou_feat, sample_pos, sample_scales, torch.rand(9, 4))
+
     def frame_one_call(i, parts):
         pipe.run(me, backbone_feat[i % 8][0], i % st1.n, iou_feat, sample_pos, sample_scales, torch.rand(9, 4))
 
@@ -103,7 +112,8 @@ def measure(dev, frames=300):
     try:
         for tag, parts, fn in (("head_only", 0, frame), ("head+solver", 1, frame), ("head+solver+localize", 2, frame),
                                ("head+solver+localize+iou_refine", 3, frame), ("one_call", 3, frame_one_call),
-                               ("one_call_two_streams", 3, frame_one_call_2s)):
+                               ("one_call_two_streams", 3, frame_one_call_2s),
+                               ("one_call_no_update", 3, frame_one_call_no_update)):
             for i in range(20):
                 fn(i, parts)
             torch.cuda.synchronize()
@@ -145,6 +155,8 @@ def measure(dev, frames=300):
     out["one_call"]["what"] = ("the same frame through pt_track_frame_full_f32: head + solver + localisation + device-side glue (new "
                                "position, update_state clamp, get_iounet_box, 9 jittered proposals from host random numbers) + IoU "
                                "refinement, ONE ctypes call, ONE host wait")
+    out["one_call_no_update"]["what"] = ("the one-call frame with num_iter = 0: head + classification + memory insert + localisation + glue + "
+                                         "refinement, no re-optimisation -- what 19 of 20 frames of the real tracker do (train_skipping = 20)")
     out["one_call_two_streams"]["what"] = ("one_call with the localisation + glue + refinement chain forked onto a second HIP stream as soon "
                                            "as the classification scores exist, concurrent with the 5 SD iterations; joined at the end "
                                            "(valid for this synthetic frame: the update's label box comes from the classification peak; "
