@@ -46,9 +46,10 @@ def test_multirank_line(n, extra, via):
     assert len(d["per_rank"]) == n and [r["rank"] for r in d["per_rank"]] == list(range(n))
     assert all(r["frames"] == 20 and r["seconds"] > 0 for r in d["per_rank"])
     assert d["collective"]["ranks"] == n and d["collective"]["backend"] == "gloo"
-    # whole-job value = all frames / slowest rank
+    # whole-job value = all frames / slowest rank (the dry run's 20 steps take a few hundred microseconds and `seconds` is printed
+    # with 6 decimals: the round-off alone is up to 0.5 %)
     tmax = max(r["seconds"] for r in d["per_rank"])
-    assert abs(d["value"] - 20 * n / tmax) / d["value"] < 1e-3
+    assert abs(d["value"] - 20 * n / tmax) / d["value"] < 2e-2
     assert abs(d["ms_per_step"] - 1e3 * tmax / 20) < 1e-3
     assert d["bracket"]["rank0_seconds_incl_closing_barrier"] >= d["per_rank"][0]["seconds"]
     assert f"{n} independent sequences" == d["config"]["parallelism"]
