@@ -13,8 +13,6 @@ bench.py times it as `cpu_baseline` (kind "reference") on the host cores and, wi
 the two ops (arg-max, re-centred box, memory insert) is the one of `TorchCpuTracker.step` / `bench_frame.TrackState.step`.
 Never imported by the product path.
 """
-import numpy as np
-
 from oracle import ref_harness
 from pytracking_amd import synth
 

@@ -13,8 +13,8 @@ import ctypes
 
 import torch
 
-from . import _lib, iou_refine as _ir, localization as _loc
-from .filter import _ptr, _require_device, device_guarded
+from . import _lib, iou_refine as _ir
+from .filter import _require_device, device_guarded
 
 _NEG_INF = -float("inf")
 
