@@ -257,3 +257,41 @@ def test_iou_head_tensor_gathering_matches_attribute_access():
     assert len(got) == 14 and all(a is b for a, b in zip(got, want))
     loose = types.SimpleNamespace(fc3_rt=net.fc3_rt, fc4_rt=net.fc4_rt, iou_predictor=net.iou_predictor)   # no registries: attribute path
     assert all(a is b for a, b in zip(IR._iou_tensors(loose), want))
+
+
+def test_round5_entry_points_argument_checks(L):
+    """pt_track_frame_full_* / pt_sd_solve_batch_f32 / pt_stream_probe_f32 refuse bad arguments before anything is queued (no GPU here)."""
+    n = None
+    one = ctypes.c_void_p(256)
+    # full frame: null descriptor / sub-structs, proposal count, workspace
+    assert L.pt_track_frame_full_ws_bytes(None) == 0
+    f = _lib.FrameFull()
+    assert L.pt_track_frame_full_ws_bytes(ctypes.byref(f)) == 0                            # sd / loc / glue / iou_dims missing
+    assert L.pt_track_frame_full_launch_f32(ctypes.byref(f), one, one, 1 << 30, n) == _lib.PT_ERR_NULL
+    sd, loc, glue, dims = _lib.SdParams(), _lib.LocalizeState(), _lib.FrameGlue(), _lib.IouDims(256, 256, 256, 256, 36, 36, 18, 18)
+    f.sd, f.loc, f.glue, f.iou_dims = ctypes.pointer(sd), ctypes.pointer(loc), ctypes.pointer(glue), ctypes.pointer(dims)
+    f.n, f.Cin, f.C, f.H, f.W, f.K, f.num_iter = 50, 1024, 512, 18, 18, 4, 5
+    glue.num_random = 9
+    need = L.pt_track_frame_full_ws_bytes(ctypes.byref(f))
+    assert need > L.pt_track_frame_head_ws_bytes(50, 1024, 512, 18, 18, 4) + L.pt_iou_refine_ws_bytes(ctypes.byref(dims), 10) - 1
+    glue.num_random = 16                                                                    # P = 17 > 16 proposals
+    assert L.pt_track_frame_full_ws_bytes(ctypes.byref(f)) == 0
+    assert L.pt_track_frame_full_launch_f32(ctypes.byref(f), one, one, 1 << 30, n) == _lib.PT_ERR_UNSUPPORTED
+    glue.num_random = 9
+    f.scores_out = 256
+    assert L.pt_track_frame_full_launch_f32(ctypes.byref(f), one, one, 0, n) == _lib.PT_ERR_WORKSPACE
+    assert L.pt_track_frame_full_launch_f32(ctypes.byref(f), n, one, 1 << 30, n) == _lib.PT_ERR_NULL
+    f.K = 5                                                                                 # 25 taps: the frame's solver refuses
+    assert L.pt_track_frame_full_ws_bytes(ctypes.byref(f)) > 0
+    f.K = 4
+    # batched solve
+    arr = (ctypes.c_void_p * 2)(256, 256)
+    assert L.pt_sd_solve_batch_f32(ctypes.byref(sd), 2, None, arr, 1, arr, None, 4, 16, 6, 6, 4, 1, arr, None, arr, 1 << 20, n, None, 0) == _lib.PT_ERR_NULL
+    assert L.pt_sd_solve_batch_f32(ctypes.byref(sd), 0, arr, arr, 1, arr, None, 4, 16, 6, 6, 4, 1, arr, None, arr, 1 << 20, n, None, 0) == _lib.PT_ERR_SHAPE
+    assert L.pt_sd_solve_batch_f32(ctypes.byref(sd), 2, arr, arr, 1, arr, None, 4, 16, 6, 6, 4, 1, arr, None, arr, 1 << 20, n, None, 2) == _lib.PT_ERR_SHAPE
+    assert L.pt_sd_solve_batch_f32(ctypes.byref(sd), 2, arr, arr, 1, arr, None, 4, 16, 6, 6, 4, 1, arr, None, arr, 1 << 20, n, arr, 16) == _lib.PT_ERR_UNSUPPORTED
+    # probe
+    assert L.pt_stream_probe_f32(n, 1024, one, 1, n) == _lib.PT_ERR_NULL
+    assert L.pt_stream_probe_f32(one, 2, one, 1, n) == _lib.PT_ERR_SHAPE
+    assert L.pt_stream_probe_f32(ctypes.c_void_p(260), 1024, one, 1, n) == _lib.PT_ERR_SHAPE   # not 16-byte aligned
+    L.pt_host_buffer_forget(one)                                                                 # unknown pointer: no-op
