@@ -445,8 +445,13 @@ typedef struct pt_frame_full {
      * `stream` afterwards is ordered behind both chains).  Valid because in this synthetic frame the new
      * sample's label box comes from the classification peak; `DiMP.track` labels the update with the REFINED state (dimp.py:139-145),
      * which makes its update depend on the refinement: leave aux_stream NULL for that order.  On return the result block is
-     * host-visible; the filter / memory are complete in `stream` order, not necessarily yet. */
+     * host-visible; the filter / memory are complete in `stream` order, not necessarily yet: the call returns when the refinement
+     * chain has written the sequence word, the steepest-descent tail on `stream` may still be running, so reading filter / mem_bb /
+     * scores from the host or from another stream right after the return needs a wait on `stream` first.
+     * Because the update is REORDERED relative to dimp.py:139-145, a call with aux_stream set AND num_iter > 0 is refused
+     * (PT_ERR_UNSUPPORTED, nothing queued) unless aux_reordered_update_ok is non-zero. */
     void* aux_stream;
+    int aux_reordered_update_ok;
 } pt_frame_full;
 size_t pt_track_frame_full_ws_bytes(const pt_frame_full* f);
 int pt_track_frame_full_f32(const pt_frame_full* f, float* out_host, void* ws, size_t ws_bytes, void* stream);

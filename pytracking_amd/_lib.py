@@ -120,7 +120,7 @@ class FrameFull(ctypes.Structure):
                    ("loc", ctypes.POINTER(LocalizeState)), ("glue", ctypes.POINTER(FrameGlue)), ("iou_dims", ctypes.POINTER(IouDims))]
                 + [(n, ctypes.c_void_p) for n in ("iou_params", "iou_prepared", "c3", "c4", "mod3", "mod4")]
                 + [("iou_iter", ctypes.c_int), ("relative", ctypes.c_int), ("step_length4", ctypes.c_float * 4),
-                   ("step_decay", ctypes.c_float), ("aux_stream", ctypes.c_void_p)])
+                   ("step_decay", ctypes.c_float), ("aux_stream", ctypes.c_void_p), ("aux_reordered_update_ok", ctypes.c_int)])
 
 
 def _build_flags():
@@ -130,6 +130,8 @@ def _build_flags():
 def needs_build() -> bool:
     if not os.path.exists(LIB_PATH):
         return True
+    if "PT_HOT_LIB" in os.environ:                           # an experiment's prebuilt variant is never rebuilt from the current sources
+        return False
     stamp = os.path.join(_HERE, "build", "flags.txt")       # a changed PT_HOT_CFLAGS is a rebuild, not a silently stale library
     if os.path.exists(stamp) and open(stamp).read() != " ".join(_build_flags()):
         return True

@@ -48,20 +48,28 @@ extern "C" void pt_host_buffer_forget(const void* p) {
     }
 }
 
-bool pt_stream_events(void* stream, hipEvent_t* fork, hipEvent_t* join) {
+bool pt_stream_events(void* main_stream, void* aux_stream, hipEvent_t* fork, hipEvent_t* join) {
+    struct Key { int dev; void* main; void* aux; };
+    struct Ent { Key k; hipEvent_t fork, join; };
     static std::mutex mu;
-    static std::vector<std::pair<void*, std::pair<hipEvent_t, hipEvent_t>>> pool;
+    static std::vector<Ent> pool;
+    int dev = -1;
+    if (hipGetDevice(&dev) != hipSuccess) { (void)hipGetLastError(); return false; }
     std::lock_guard<std::mutex> lk(mu);
     for (auto& e : pool)
-        if (e.first == stream) {
-            if (fork) *fork = e.second.first;
-            if (join) *join = e.second.second;
+        if (e.k.dev == dev && e.k.main == main_stream && e.k.aux == aux_stream) {
+            if (fork) *fork = e.fork;
+            if (join) *join = e.join;
             return true;
         }
     hipEvent_t a, b;
-    if (hipEventCreateWithFlags(&a, hipEventDisableTiming) != hipSuccess) return false;
-    if (hipEventCreateWithFlags(&b, hipEventDisableTiming) != hipSuccess) return false;
-    pool.push_back({stream, {a, b}});
+    if (hipEventCreateWithFlags(&a, hipEventDisableTiming) != hipSuccess) { (void)hipGetLastError(); return false; }
+    if (hipEventCreateWithFlags(&b, hipEventDisableTiming) != hipSuccess) {
+        (void)hipGetLastError();
+        (void)hipEventDestroy(a);
+        return false;
+    }
+    pool.push_back({{dev, main_stream, aux_stream}, a, b});
     if (fork) *fork = a;
     if (join) *join = b;
     return true;

@@ -20,6 +20,13 @@ static int ff_check(const pt_frame_full* f) {
     return PT_OK;
 }
 
+// Two-stream mode runs the memory update CONCURRENTLY with the refinement, i.e. it labels the new sample from the classification peak
+// instead of from the refined state (dimp.py:139-145): only on the caller's explicit word (include/pt_hot.h)
+static int ff_check_order(const pt_frame_full* f, void* stream) {
+    if (f->aux_stream && f->aux_stream != stream && f->num_iter > 0 && !f->aux_reordered_update_ok) return PT_ERR_UNSUPPORTED;
+    return PT_OK;
+}
+
 static FfCarve ff_carve(const pt_frame_full* f) {
     FfCarve c;
     const int P = 1 + f->glue->num_random;
@@ -43,6 +50,7 @@ static int ff_launch(const pt_frame_full* f, float* out, void* ws, size_t ws_byt
     void* const main_stream = stream;
     int rc = ff_check(f);
     if (rc) return rc;
+    if ((rc = ff_check_order(f, stream))) return rc;
     if (!out || !ws || !f->scores_out) return PT_ERR_NULL;
     const size_t need = pt_track_frame_full_ws_bytes(f);
     if (need == 0) return PT_ERR_UNSUPPORTED;
@@ -53,12 +61,19 @@ static int ff_launch(const pt_frame_full* f, float* out, void* ws, size_t ws_byt
     pt_localize_params q;                                        // host-side constants first: nothing is queued if they are invalid
     rc = pt_localize_constants_f32(f->loc, 1, OH, OW, &q);
     if (rc) return rc;
+    // ... and every argument of the refinement (pointers, head dimensions, proposal count, iteration count, fused route, workspace):
+    // a refusal must come BEFORE the head, the memory insert and the re-optimisation are queued -- they mutate mem_feat[slot],
+    // mem_bb[slot] and the filter, and the host block's sequence word must not go stale on a call that returns an error
+    rc = pt_iou_refine_validate(f->iou_dims, f->iou_params, f->iou_prepared, f->c3, f->c4, f->mod3, f->mod4, /*have_init_boxes=*/false,
+                                out + 32, out + 96, 1 + f->glue->num_random, f->iou_iter, f->step_length4, base + cv.iou,
+                                (cv.total - cv.iou) * sizeof(float), /*boxes_on_host=*/false, seq, /*with_mid=*/true);
+    if (rc) return rc;
     // 1. head + classification + memory insert + re-optimisation; with a second stream the rest of the frame forks off as soon as the
     //    scores are queued and joins at the end
     hipEvent_t ev_fork = nullptr, ev_join = nullptr;
     void* chain = stream;
     if (f->aux_stream && f->aux_stream != stream) {
-        if (!pt_stream_events(f->aux_stream, &ev_fork, &ev_join)) return PT_ERR_LAUNCH;
+        if (!pt_stream_events(stream, f->aux_stream, &ev_fork, &ev_join)) return PT_ERR_LAUNCH;
         chain = f->aux_stream;
     }
     rc = pt_track_frame_head_impl(f->sd, f->filter, f->mem_feat, f->mem_bb, f->sample_weight, f->backbone_feat, f->head_weight_tap_major,

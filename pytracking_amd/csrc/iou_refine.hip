@@ -812,12 +812,16 @@ extern "C" size_t pt_iou_refine_ws_bytes(const pt_iou_dims* d, int P) {
 
 // init_boxes: device pointer, or (boxes_on_host) a host pointer whose P <= 16 boxes travel in the first kernel's argument block;
 // seq / seq_word: see pt_iou_refine_sync_f32
-static int iou_refine_impl(const pt_iou_dims* d, const float* params, const float* prepared, const float* c3, const float* c4,
-                           const float* mod3, const float* mod4, const float* init_boxes, bool boxes_on_host, float* boxes_out,
-                           float* iou_out, int P, int num_iter, const float* step_length4, float step_decay, int relative,
-                           int backtrack, void* ws, size_t ws_bytes, float seq, float* seq_word, void* stream,
-                           const PtFrameMid* mid = nullptr) {
-    if (!params || !prepared || !c3 || !c4 || !mod3 || !mod4 || (!init_boxes && !mid) || !boxes_out || !iou_out || !step_length4 || !ws)
+// Every argument / shape / route check of a refinement call, WITHOUT queuing anything (advisor, round 5: pt_track_frame_full_f32 used to
+// learn about a bad refinement argument only after the head, the memory insert and the re-optimisation of the same call were queued and
+// had mutated the tracker state).  iou_refine_impl starts with this; frame_full.hip calls it in front of its first launch.
+//   have_init_boxes : the caller passes initial boxes (otherwise `with_mid`: k_frame_mid forms the proposals inside the launch)
+//   seq != 0 / boxes_on_host / with_mid need the fused iteration kernels (P <= FUSED_MAX_P); with_mid also P <= 16
+int pt_iou_refine_validate(const pt_iou_dims* d, const float* params, const float* prepared, const float* c3, const float* c4,
+                           const float* mod3, const float* mod4, bool have_init_boxes, const float* boxes_out, const float* iou_out, int P,
+                           int num_iter, const float* step_length4, const void* ws, size_t ws_bytes, bool boxes_on_host, float seq,
+                           bool with_mid) {
+    if (!params || !prepared || !c3 || !c4 || !mod3 || !mod4 || (!have_init_boxes && !with_mid) || !boxes_out || !iou_out || !step_length4 || !ws)
         return PT_ERR_NULL;
     int rc = iou_check(d);
     if (rc) return rc;
@@ -825,6 +829,22 @@ static int iou_refine_impl(const pt_iou_dims* d, const float* params, const floa
     if (P > 256) return PT_ERR_UNSUPPORTED;
     const IouCarve cv = iou_carve(d, P);
     if (ws_bytes < cv.total * sizeof(float) || ((uintptr_t)ws % 256) != 0) return PT_ERR_WORKSPACE;
+    static const bool unfused = [] { const char* e = getenv("PT_IOU_UNFUSED"); return e && e[0] == '1'; }();   // ablation switch
+    const bool fused = P <= FUSED_MAX_P && !unfused;
+    if ((boxes_on_host || seq != 0.f) && !fused) return PT_ERR_UNSUPPORTED;
+    if (with_mid && (!fused || P > 16)) return PT_ERR_UNSUPPORTED;
+    return PT_OK;
+}
+
+static int iou_refine_impl(const pt_iou_dims* d, const float* params, const float* prepared, const float* c3, const float* c4,
+                           const float* mod3, const float* mod4, const float* init_boxes, bool boxes_on_host, float* boxes_out,
+                           float* iou_out, int P, int num_iter, const float* step_length4, float step_decay, int relative,
+                           int backtrack, void* ws, size_t ws_bytes, float seq, float* seq_word, void* stream,
+                           const PtFrameMid* mid = nullptr) {
+    int rc = pt_iou_refine_validate(d, params, prepared, c3, c4, mod3, mod4, init_boxes != nullptr, boxes_out, iou_out, P, num_iter,
+                                    step_length4, ws, ws_bytes, boxes_on_host, seq, mid != nullptr);
+    if (rc) return rc;
+    const IouCarve cv = iou_carve(d, P);
     hipStream_t st = (hipStream_t)stream;
     float* base = (float*)ws;
     const IouOff po = iou_layout(d);
@@ -836,14 +856,12 @@ static int iou_refine_impl(const pt_iou_dims* d, const float* params, const floa
                  {step_length4[0], step_length4[1], step_length4[2], step_length4[3]}, nullptr};
     static const bool unfused = [] { const char* e = getenv("PT_IOU_UNFUSED"); return e && e[0] == '1'; }();   // ablation switch
     const bool fused = P <= FUSED_MAX_P && !unfused;
-    if ((boxes_on_host || seq != 0.f) && !fused) return PT_ERR_UNSUPPORTED;
     if (fused) { sa.st0 = base + cv.st2; sa.K3 = sa.K4 = 0; }          // the per-column modulation tables belong to the unfused path
     if (boxes_on_host) {
         sa.boxes = nullptr; sa.use_hb = 1;
         for (int i = 0; i < 4 * P; ++i) sa.hb[i] = init_boxes[i];
     }
     if (mid) {                                                          // proposals are formed inside the launch (fused route only)
-        if (!fused || P > 16) return PT_ERR_UNSUPPORTED;
         hipLaunchKernelGGL(k_frame_mid, dim3(1), dim3(256), 0, st, mid->dec, mid->glue, sa);
     } else {
         hipLaunchKernelGGL(k_iou_setup, dim3((std::max(std::max(sa.K3, sa.K4), P) + 255) / 256), dim3(256), 0, st, sa);

@@ -31,6 +31,7 @@ __device__ __forceinline__ int mf_fdiv(int v, float inv_d) { return (int)(((floa
 // unknown offset) and the backend splits the access into two ds_read2_b32 / ds_write2_b32.
 __device__ __forceinline__ f32x4 mf_lds_ld4(const float* p) { return *(const f32x4*)__builtin_assume_aligned(p, 16); }
 __device__ __forceinline__ void mf_lds_st4(float* p, f32x4 v) { *(f32x4*)__builtin_assume_aligned(p, 16) = v; }
+__device__ __forceinline__ f32x2 mf_lds_ld2(const float* p) { return *(const f32x2*)__builtin_assume_aligned(p, 8); }
 
 // VW (1, 2, 4) consecutive floats: range-checked buffer load / LDS store (VW*4-byte aligned)
 template <int VW>
@@ -78,17 +79,18 @@ struct MfStage {
 // What bounds it (experiments/mfma_issue.hip, profiles/r02i_mfma_issue_microbench.json): on this chip nothing issues in
 // the shadow of a v_mfma_f32_16x16x4_f32 -- every other VALU instruction of the wavefront costs ~5 cycles on top of the
 // MFMA's 32, every LDS instruction ~4-8.  So the kernel is laid out for FEW instructions per MFMA, not for overlap:
-//   * positions are counted on rows padded to Wp = roundup4(W); lane (kq, j) of wave w owns the 4 CONSECUTIVE positions
-//     64w + 4j + q, q = 0..3 (its 4 MFMA tiles).  One ds_read_b128 and two ds_read_b32 of the padded row (6 floats) hold
-//     the B operands of all 4 tiles x 3 horizontal taps: 9 LDS reads per 36 MFMAs of a k-step (was 29);
+//   * positions are counted on rows padded to Wp (roundup4(W + 1) for 3x3); lane (kq, j) of wave w owns the 4 CONSECUTIVE
+//     positions 64w + 4j + q, q = 0..3 (its 4 MFMA tiles).  One ds_read_b128 and two ds_read_b64 of the padded row (the lane's
+//     quad and the pairs either side of it; 6 of the 8 floats are used) hold the B operands of all 4 tiles x 3 horizontal taps:
+//     9 LDS reads per 36 MFMAs of a k-step at 4 LDS cycles each (round 6; the neighbours used to be two ds_read_b32 with 5-way
+//     bank conflicts, 10 cycles each);
 //   * the weights sit in LDS as [k-step][lane][12] (9 taps + pad): 3 ds_read_b128 per k-step, conflict-free (lane stride
 //     12 dwords); k_mf_wtrans writes the table in exactly this order, staging it is a straight 16-byte copy;
 //   * no masks on the operands: lanes beyond the band read offset 0 and only feed output columns that are never stored.
 // Channels are streamed in chunks of MF_CK (MF_KS k-steps) through two LDS buffers:
-//      fl[MF_CK][CS]   zero-padded band: 4 floats, then rows of PS = Wp + 4 floats with the data at column x -- the zero
-//                      tail of a row is the left padding of the next one, and a float4 of the image lands 16-byte aligned
-//                      (at column p + x every lane's 4 ds_write_b32 hit 16 banks: the staging stores alone took 1500 of
-//                      a chunk's 6800 cycles, profiles/r02i_lwl_kernel_ablation.txt)
+//      fl[MF_CK][CS]   zero-padded band: 4 floats, then rows of PS = Wp floats with the data at column x -- the zero tail of a
+//                      row is the right padding of that row and the left padding of the next one, and a float4 of the image
+//                      lands 16-byte aligned; CS == 0 (mod 64), see mf_plan
 //      wl[MF_KS][64][TP]
 // 8 waves: wave w owns position group w & 3 (64 positions) and k-steps 2(w>>2), 2(w>>2)+1 of every chunk -- two waves per
 // SIMD, because a wave's LDS / global / barrier time does not overlap its own MFMAs either (measured: with one wave per
@@ -231,17 +233,17 @@ __global__ __launch_bounds__(128 * NPG) void k_mf_corr(const float* __restrict__
 #pragma unroll
             for (int e = 0; e < 4; ++e) av[set][4 * k + e] = v[e];
         } else if (k == 2) {
-            av[set][8] = wl[8];
-        } else {                                                    // columns px - 1 .. px + 4 of row pr + u
-            const int u = (k - 3) / 3, part = (k - 3) % 3;
-            if (part == 0) {
+            av[set][8] = mf_lds_ld2(wl + 8)[0];                     // 8-byte read: as a ds_read_b32 at a lane stride of 12 dwords a 4-way conflict
+        } else {                                                    // columns px - 1 .. px + 4 of row pr + u: the lane's aligned quad, the
+            const int u = (k - 3) / 3, part = (k - 3) % 3;          // pair left of it and the pair right of it.  (The neighbours as two
+            if (part == 0) {                                        // ds_read_b32 were 5-way bank conflicts: 32 lanes on 8 banks.)
                 const f32x4 v = mf_lds_ld4(fb + u * g.PS);
 #pragma unroll
                 for (int e = 0; e < 4; ++e) bv[set][u][e + 1] = v[e];
             } else if (part == 1) {
-                bv[set][u][0] = fb[u * g.PS - 1];
+                bv[set][u][0] = mf_lds_ld2(fb + u * g.PS - 2)[1];
             } else {
-                bv[set][u][5] = fb[u * g.PS + 4];
+                bv[set][u][5] = mf_lds_ld2(fb + u * g.PS + 4)[0];
             }
         }
     };
@@ -472,9 +474,9 @@ __global__ void k_mf_wtrans(const float* __restrict__ filt, float* __restrict__ 
 // x) and the input band rl[16][RS2] (rows of Wp) in LDS, and  D_tap[f][c] += in[f][pos] * feat[c][pos+tap]  with K =
 // positions on the matrix cores.  Same issue model as the correlation (few instructions per MFMA, see there):
 //   * positions are counted on rows of Wp and taken in groups of 16; lane kq owns the 4 CONSECUTIVE positions 16g + 4kq + m
-//     and feeds them to 4 MFMAs: one ds_read_b128 of the input row, and per vertical tap one ds_read_b128 + one
-//     ds_read2_b32 of the feature row (6 floats = 4 positions x 3 horizontal taps): 7 LDS reads per 36 MFMAs (was 8 per 9,
-//     plus a division per k-step);
+//     and feeds them to 4 MFMAs: one ds_read_b128 of the input row, and per vertical tap one ds_read_b128 + two ds_read_b64 of
+//     the feature row (the quad and the pairs either side; 6 floats = 4 positions x 3 horizontal taps are used): 10 LDS reads of
+//     4 LDS cycles each per 36 MFMAs (round 6; the neighbours were one ds_read2_b32 = two 4-way bank conflicts, 16 cycles);
 //   * wave w takes the groups 4 s + (w + stage) % 4 -- rotating, so that a band of 13 groups costs every SIMD 3.25 slots
 //     on average; a slot without a group skips its MFMAs;
 //   * two LDS buffers; while stage t is multiplied, stage t+1 goes from registers to the other buffer and the buffer loads
@@ -494,7 +496,7 @@ __global__ __launch_bounds__(256) void k_mf_adj(const float* __restrict__ feat, 
     constexpr int K = KK == 1 ? 1 : 3;
     constexpr int NQF = 8 / VW, NQI = 4 / VW;                       // staging items per lane: feature channel / input plane
     constexpr int NB6 = K == 1 ? 4 : 6;
-    constexpr int NRD = K == 1 ? 2 : 7;
+    constexpr int NRD = K == 1 ? 2 : 10;
     constexpr int NWR = NQF + NQI;
     static_assert(NRD + 2 * NWR <= 4 * KK || KK == 1, "memory instructions of a slot fit behind its MFMAs");
     const int BUF = 16 * (CS2 + RS2);
@@ -589,10 +591,11 @@ __global__ __launch_bounds__(256) void k_mf_adj(const float* __restrict__ feat, 
 #pragma unroll
             for (int e = 0; e < 4; ++e) bv[set][0][e] = v[e];
         } else {
-            const int u = (k - 1) >> 1;
-            if ((k - 1) & 1) {                                      // columns x - 1 and x + 4: one ds_read2_b32
-                bv[set][u][0] = lds[b_at + u * g.PS - 1];
-                bv[set][u][5] = lds[b_at + u * g.PS + 4];
+            const int u = (k - 1) / 3;
+            if ((k - 1) % 3 == 1) {                                 // columns x - 1 and x + 4 from the neighbouring aligned pairs: a
+                bv[set][u][0] = mf_lds_ld2(lds + b_at + u * g.PS - 2)[1];      // ds_read2_b32 here was two 4-way bank conflicts
+            } else if ((k - 1) % 3 == 2) {
+                bv[set][u][5] = mf_lds_ld2(lds + b_at + u * g.PS + 4)[0];
             } else {
                 const f32x4 v = mf_lds_ld4(lds + b_at + u * g.PS);
 #pragma unroll
@@ -723,8 +726,15 @@ static MfPlan mf_plan(int n, int F, int C, int H, int W, int K, int br_force = 0
     g.PWs = W + K - 1;
     // correlation band: <= 256 positions counted on rows of Wp (4 consecutive positions per lane) and <= 512 staged floats
     // per channel; a small problem gets shorter bands until the grid covers the CUs, as long as half the lanes stay busy
-    g.Wp = (W + 3) & ~3;
-    g.PS = g.Wp + 4;
+    // Correlation rows in LDS are LINEAR: row stride PS == Wp, data at column x, and Wp >= W + 1 for a 3x3 filter, so that the zero
+    // tail of a row is the right padding of that row and the left padding of the next.  The 4 positions of lane (kq, j) then
+    // start at dword 4 + 64 pg + 4 j of the channel plane -- 16 consecutive lanes cover 64 consecutive dwords -- and with a
+    // plane stride CS == 0 (mod 64) every 16-lane group of a ds_read_b128 (which mixes the lanes of two kq, see
+    // MI355X_MICROARCH.md section LDS) touches each of the 64 banks once.  Round 5 counters on the old layout (rows of Wp + 4,
+    // CS = 484, neighbours as ds_read_b32): 65 % of the LDS-active cycles were bank conflicts (profiles/r05u_head_pmc.txt).
+    const int Wpa = (W + 3) & ~3;                                   // adjoint: rows of roundup4(W), stride + 4 (unchanged)
+    g.Wp = K == 1 ? Wpa : ((W + 1 + 3) & ~3);
+    g.PS = g.Wp;
     g.out_vec = 0;
     int BR = 64 * npg / g.Wp;
     if (BR > H) BR = H;
@@ -741,16 +751,20 @@ static MfPlan mf_plan(int n, int F, int C, int H, int W, int K, int br_force = 0
     g.RSmax = BR + K - 1;
     // adjoint band: <= 256 positions on rows of Wp, <= 512 staged feature floats per channel
     p.ga = g;
-    int BRa = 256 / g.Wp;
+    p.ga.Wp = Wpa;
+    p.ga.PS = Wpa + 4;
+    int BRa = 256 / Wpa;
     if (BRa > H) BRa = H;
     while (BRa > 1 && (BRa + K - 1) * W > 64 * MF_NQ) --BRa;
     if (BRa < 1 || (BRa + K - 1) * W > 64 * MF_NQ) return p;
     p.ga.BR = BRa;
     p.ga.NB = (H + BRa - 1) / BRa;
     p.ga.RSmax = BRa + K - 1;
-    p.CS = 4 + g.RSmax * g.PS;
-    p.CS2 = mf_pad_to(4 + p.ga.RSmax * g.PS, 8, 4);     // == 4 mod 8: the 16 rows of a b128 read hit 16 different bank quads
-    p.RS2 = mf_pad_to((BRa * g.Wp + 15) & ~15, 8, 4);   // whole groups of 16 positions; the tail of a row stays zero
+    p.CS = mf_pad_to(4 + g.RSmax * g.PS + 4, 64, 0);    // + 4: the right-hand quad of the last staged row
+    // adjoint: lane (kq, j) reads row j at a column that depends on kq only; strides == 8 (mod 16) put the 16 rows of every
+    // ds_read_b128 lane group on 16 different bank quads (== 4 mod 8, the round-2 choice, was a 2-way conflict on this chip's groups)
+    p.CS2 = mf_pad_to(4 + p.ga.RSmax * p.ga.PS + 4, 16, 8);
+    p.RS2 = mf_pad_to((BRa * Wpa + 15) & ~15, 16, 8);   // whole groups of 16 positions; the tail of a row stays zero
     p.corr_lds = std::max(2 * ((size_t)MF_CK * p.CS + MF_KS * 64 * MF_TP(g.KK)) + 4 * 128 * npg, (size_t)1024 * npg) * sizeof(float);   // two buffers + dump slots | k-half sum
     p.adj_lds = std::max((size_t)2 * 16 * (p.CS2 + p.RS2) + 4 * 256, (size_t)4 * g.KK * 256) * sizeof(float);   // two buffers + dump slots | reduction
     const int CBn = (C + 15) / 16;
@@ -946,10 +960,10 @@ int pt_launch_mf_corr(const float* feat, long stride_n, const float* wT, float* 
 // (rounds of 256 workgroups) x (chunks per workgroup + ~4 chunks of fixed cost) x (waves / 8), balanced bands on a tie.
 static int mf_tm_config(int n, int Ftot, int C, int H, int W, int* br_out, int* npg_out, long* cost_out = nullptr) {
     if (Ftot <= 0 || Ftot % 16 || C <= 0 || C % 16 || H <= 0 || W <= 0) return 0;
-    const int Wp = (W + 3) & ~3, nch = C / MF_CK, groups = Ftot / 16;
+    const int Wp = (W + 1 + 3) & ~3, nch = C / MF_CK, groups = Ftot / 16;   // rows of the 3x3 correlation in LDS (mf_plan)
     int best_ks = 0, best_br = 0, best_npg = 4;
     long best_cost = -1;
-    for (int npg = 4; npg <= 6; npg += 2) {                         // a chunk costs a SIMD npg/4 as much
+    for (int npg = 4; npg <= ((W % 2) == 0 ? 6 : 4); npg += 2) {    // a chunk costs a SIMD npg/4 as much; 12 waves: 8-byte staging items only (registers)
         for (int br = std::min(H, 64 * npg / std::max(Wp, 1)); br >= 1; --br) {
             if ((br + 2) * W > 64 * MF_NQ) continue;
             const int nb = (H + br - 1) / br;
@@ -998,7 +1012,8 @@ int pt_launch_mf_corr_tm(const float* feat, long stride_n, const float* w_tap_ma
     p.g.out_vec = vw == 4 && ((H * W) % 4) == 0;
 #define PT_MFT(VWV, NPGV) \
     hipLaunchKernelGGL((k_mf_corr<9, VWV, true, NPGV>), grid, block, p.corr_lds, st, feat, stride_n, w_tap_major, part, out_stride_n, p.g, p.CS, wt_zs, out_zs, ksplit, (long)n * out_stride_n)
-    if (npg == 6) { if (vw == 4) PT_MFT(4, 6); else if (vw == 2) PT_MFT(2, 6); else PT_MFT(1, 6); }
+    if (npg == 6 && vw == 1) return PT_ERR_UNSUPPORTED;             // scalar staging at 3 waves per SIMD would spill (the caller has a GEMM route)
+    if (npg == 6) { if (vw == 4) PT_MFT(4, 6); else PT_MFT(2, 6); }
     else { if (vw == 4) PT_MFT(4, 4); else if (vw == 2) PT_MFT(2, 4); else PT_MFT(1, 4); }
 #undef PT_MFT
     PT_CHECK_LAUNCH();

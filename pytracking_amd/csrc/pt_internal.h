@@ -178,9 +178,11 @@ int pt_track_frame_head_impl(const pt_sd_params* prm, float* filter, float* mem_
                              int n, int Cin, int C, int H, int W, int K, int num_iter, float* scores_out, float* peak_out, void* ws,
                              size_t ws_bytes, void* stream, void* after_init_event);
 
-// Two timing-less events per stream handle (fork: recorded on it, join: recorded on it for somebody else to wait on), created on first use
-// and never destroyed (they hold no memory); thread-safe.  Either out pointer may be null.
-bool pt_stream_events(void* stream, hipEvent_t* fork, hipEvent_t* join);
+// Two timing-less events per (current device, main stream, auxiliary stream) triple -- fork: recorded on `main_stream`, join: recorded on
+// `aux_stream` for `main_stream` to wait on -- created on first use and never destroyed (they hold no memory); thread-safe.  Keyed by the
+// device as well (a stream address recycled on another GPU must not meet an event of the first one) and by the PAIR (two host threads
+// that share an auxiliary stream under different main streams do not share events).  Either out pointer may be null.
+bool pt_stream_events(void* main_stream, void* aux_stream, hipEvent_t* fork, hipEvent_t* join);
 
 // launch halves of the host-polled entry points, for compositions (frame_full.hip)
 int pt_localize_launch(const float* scores, const float* scores_hn, const pt_localize_params* prm, float* out16, int S, int H,
@@ -189,6 +191,12 @@ int pt_iou_refine_launch(const pt_iou_dims* d, const float* params, const float*
                          const float* mod3, const float* mod4, const float* init_boxes_dev, float* boxes_out, float* iou_out, int P,
                          int num_iter, const float* step_length4, float step_decay, int relative, int backtrack, void* ws,
                          size_t ws_bytes, float seq, float* seq_word, void* stream, const void* frame_mid = nullptr);
+
+// the argument / shape / route checks of a refinement call, nothing queued (iou_refine.hip)
+int pt_iou_refine_validate(const pt_iou_dims* d, const float* params, const float* prepared, const float* c3, const float* c4,
+                           const float* mod3, const float* mod4, bool have_init_boxes, const float* boxes_out, const float* iou_out, int P,
+                           int num_iter, const float* step_length4, const void* ws, size_t ws_bytes, bool boxes_on_host, float seq,
+                           bool with_mid);
 
 // A host-polled result cannot be waited for while the stream is being captured into a graph (nothing executes): refuse at once
 // instead of spinning into the 2 s fallback.

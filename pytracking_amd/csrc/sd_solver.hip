@@ -785,13 +785,18 @@ extern "C" int pt_sd_solve_batch_f32(const pt_sd_params* prm, int S, const float
     const int lanes = 1 + (S > 1 ? n_aux : 0);
     hipEvent_t fork = nullptr, join[16] = {};
     if (lanes > 1) {
-        if (!pt_stream_events(stream, &fork, nullptr)) return PT_ERR_LAUNCH;
-        if (hipEventRecord(fork, (hipStream_t)stream) != hipSuccess) return PT_ERR_LAUNCH;
+        // every auxiliary stream is validated and has its events BEFORE the fork is recorded: a bad later entry must not leave earlier
+        // streams forked and never joined (inside a graph capture that would invalidate the capture)
         for (int l = 1; l < lanes && l <= S - 1; ++l) {
             if (!aux_streams[l - 1] || aux_streams[l - 1] == stream) return PT_ERR_SHAPE;
-            if (!pt_stream_events(aux_streams[l - 1], nullptr, &join[l])) return PT_ERR_LAUNCH;
-            if (hipStreamWaitEvent((hipStream_t)aux_streams[l - 1], fork, 0) != hipSuccess) return PT_ERR_LAUNCH;
+            for (int m = 1; m < l; ++m)
+                if (aux_streams[m - 1] == aux_streams[l - 1]) return PT_ERR_SHAPE;
+            if (!pt_stream_events(stream, aux_streams[l - 1], nullptr, &join[l])) return PT_ERR_LAUNCH;
         }
+        if (!pt_stream_events(stream, nullptr, &fork, nullptr)) return PT_ERR_LAUNCH;
+        if (hipEventRecord(fork, (hipStream_t)stream) != hipSuccess) return PT_ERR_LAUNCH;
+        for (int l = 1; l < lanes && l <= S - 1; ++l)
+            if (hipStreamWaitEvent((hipStream_t)aux_streams[l - 1], fork, 0) != hipSuccess) return PT_ERR_LAUNCH;
     }
     int rc = PT_OK;
     for (int s = 0; s < S && rc == PT_OK; ++s) {

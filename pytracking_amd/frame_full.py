@@ -22,10 +22,12 @@ _NEG_INF = -float("inf")
 class FramePipeline:
     """One sequence: `state` = bench_frame.TrackState with a head attached (filter, sample memory, solver parameters)."""
 
-    def __init__(self, state, num_iter, overlap=False):
+    def __init__(self, state, num_iter, overlap=False, reordered_update_ok=False):
         """overlap: run the localisation + refinement chain on a second stream, concurrently with the steepest-descent iterations
-        (`pt_frame_full.aux_stream`, include/pt_hot.h: valid for the synthetic frame whose update label comes from the classification
-        peak; the reference's order -- update AFTER refinement -- is overlap=False)."""
+        (`pt_frame_full.aux_stream`, include/pt_hot.h).  That REORDERS the memory update relative to `DiMP.track`
+        (dimp.py:139-145 labels the new sample with the refined state; here the label comes from the classification peak, as in the
+        synthetic frame of SURVEY.md section 8d), so with `num_iter > 0` the library refuses the call unless `reordered_update_ok=True`
+        says the caller wants exactly that.  The reference's order -- update AFTER refinement -- is overlap=False."""
         if not hasattr(state, "head_w"):
             raise ValueError("FramePipeline: TrackState.attach_head() first")
         self.st, self.num_iter = state, int(num_iter)
@@ -48,6 +50,7 @@ class FramePipeline:
         self._dev = dev
         self._aux = torch.cuda.Stream(device=dev) if overlap else None
         f.aux_stream = self._aux.cuda_stream if overlap else None
+        f.aux_reordered_update_ok = int(bool(reordered_update_ok))
         self._bound = None
         self._call = _lib.lib().pt_track_frame_full_f32
         self._ffref = ctypes.byref(f)
@@ -112,7 +115,10 @@ class FramePipeline:
     def run(self, tracker, backbone_feat, slot, iou_features, sample_pos, sample_scales, rand_u):
         """backbone_feat (Cin,H,W) device; iou_features (c3 (1,C3,H3,W3), c4 (1,C4,H4,W4)) device; sample_pos (1,2), sample_scales (1)
         host, as `track()` forms them; rand_u = `torch.rand(num_init_random_boxes, 4)` of this frame (host).
-        -> dict(translation_vec (2), scale_ind, flag, pos (2) after update_state, init_box (4), boxes (P,4), iou (P)), CPU tensors."""
+        -> dict(translation_vec (2), scale_ind, flag, pos (2) after update_state, init_box (4), boxes (P,4), iou (P)), CPU tensors.
+        With overlap=True the call returns when the REFINEMENT chain has delivered its result block; the steepest-descent tail (filter,
+        sample memory, `mem_bb`) may still be running on the current stream -- synchronise that stream before reading them from the host
+        or from another stream.  Timings of this mode are return latencies, not frame periods."""
         c3, c4 = iou_features
         _require_device(backbone_feat, c3, c4)
         num_random = int(rand_u.shape[0]) if rand_u is not None else 0

@@ -35,6 +35,11 @@ def _side_streams(device, count):
     return pool[:count]
 
 
+# Experiment / test knob: spread the sequences of an S > 1 solve over side streams in eager mode as well (default: only inside a graph
+# capture, see _solve).  tests/test_gpu_parity.py sets it to check the fork / join path of pt_sd_solve_batch_f32 result by result.
+EAGER_SIDE_STREAMS = False
+
+
 @device_guarded
 def _solve(params: _lib.SdParams, weights, feat, bb, sample_weight, num_iter, compute_losses, keep):
     """Shared driver.  One sequence -> pt_sd_solve_f32; S > 1 (optimizer.py:101-104) -> ONE call of pt_sd_solve_batch_f32."""
@@ -87,7 +92,7 @@ def _solve(params: _lib.SdParams, weights, feat, bb, sample_weight, num_iter, co
         p_i = arr(*[iters[s].data_ptr() for s in range(S)])
         p_l = arr(*[losses[s].data_ptr() for s in range(S)]) if losses is not None else None
         p_ws = arr(*[ws.data_ptr() + s * nb_al for s in range(S)])
-        aux = _side_streams(feat.device, min(S - 1, 3)) if torch.cuda.is_current_stream_capturing() else []
+        aux = _side_streams(feat.device, min(S - 1, 3)) if (EAGER_SIDE_STREAMS or torch.cuda.is_current_stream_capturing()) else []
         p_aux = (ctypes.c_void_p * max(len(aux), 1))(*[a.cuda_stream for a in aux])
         rc = L.pt_sd_solve_batch_f32(ctypes.byref(params), S, p_w, p_f, f5.stride(0), p_b, p_s, n, C, H, W, K, num_iter, p_i, p_l,
                                      p_ws, nb_al, _stream(), p_aux, len(aux))

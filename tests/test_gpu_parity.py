@@ -1402,12 +1402,17 @@ def test_track_frame_with_head_writes_the_memory_slot():
     assert torch.equal(a.scores, b.scores) and torch.equal(a.filter, b.filter) and torch.equal(a.mem_bb, b.mem_bb)
 
 
+@pytest.mark.parametrize("mode", ["back_to_back", "side_streams_eager", "side_streams_captured"])
 @pytest.mark.parametrize("kind", ["dimp", "prdimp"])
-def test_sd_multi_sequence_batch_equals_single_sequence_calls(kind):
-    """S = 5 sequences through ONE pt_sd_solve_batch_f32 call (this stream + 3 side streams, the fifth sequence sharing the first lane)
-    against five single-sequence solves: bit-equal iterates and losses (the same kernels on the same operands; only the streams
-    differ), at the deployed map size."""
-    import time
+def test_sd_multi_sequence_batch_equals_single_sequence_calls(kind, mode):
+    """S = 5 sequences through ONE pt_sd_solve_batch_f32 call against five single-sequence solves: bit-equal iterates and losses (the
+    same kernels on the same operands; only the streams differ), at the deployed map size.
+      back_to_back          : n_aux = 0, what an eager call of the module does -- all sequences on the current stream
+      side_streams_eager    : n_aux = 3 in eager mode (optimizer.EAGER_SIDE_STREAMS): this stream + 3 side streams, the fifth sequence
+                              sharing the first lane -- the fork / join path of sd_solver.hip with every result checked
+      side_streams_captured : the same inside a torch.cuda.graph capture (what the module does on its own when captured), replayed twice
+    A missing join or overlapping workspaces would show up as differing iterates."""
+    from pytracking_amd import optimizer as OM
     cfg = synth.DIMP50 if kind == "dimp" else synth.PRDIMP50
     S, n, C = 5, 9, 128
     probs = [synth.dimp_problem(900 + s, n, dict(cfg, C=C)) for s in range(S)]
@@ -1417,18 +1422,65 @@ def test_sd_multi_sequence_batch_equals_single_sequence_calls(kind):
     sw = torch.stack([T(p[3]) for p in probs], dim=1).contiguous()                # (n,S)
     mod = _dimp_module(cfg) if kind == "dimp" else _prdimp_module(cfg)
     with torch.no_grad():
-        _, its, losses = mod(w0, feat, bb, sample_weight=sw, num_iter=4, compute_losses=True)
-        torch.cuda.synchronize()
         single = []
         for s in range(S):
             _, its_s, l_s = mod(w0[s:s + 1], feat[:, s].contiguous(), bb[:, s].contiguous(), sample_weight=sw[:, s].contiguous(),
                                 num_iter=4, compute_losses=True)
             single.append((torch.stack(its_s)[:, 0], torch.cat(l_s)))
-    batch_its = torch.stack(its)                                                  # (T+1,S,C,K,K)
+        torch.cuda.synchronize()
+        if mode == "side_streams_captured":
+            mod(w0, feat, bb, sample_weight=sw, num_iter=4, compute_losses=True)          # workspaces / side streams exist before the capture
+            torch.cuda.synchronize()
+            side = torch.cuda.Stream(device=DEV)
+            with torch.cuda.stream(side):
+                g = torch.cuda.CUDAGraph()
+                with torch.cuda.graph(g, stream=side):
+                    _, its, losses = mod(w0, feat, bb, sample_weight=sw, num_iter=4, compute_losses=True)
+                for _ in range(2):
+                    g.replay()
+                side.synchronize()
+        else:
+            OM.EAGER_SIDE_STREAMS = mode == "side_streams_eager"
+            try:
+                _, its, losses = mod(w0, feat, bb, sample_weight=sw, num_iter=4, compute_losses=True)
+            finally:
+                OM.EAGER_SIDE_STREAMS = False
+            torch.cuda.synchronize()
+    batch_its = torch.stack(its[1:])                                              # (T,S,C,K,K); its[0] is the caller's tensor
     for s in range(S):
-        assert torch.equal(batch_its[:, s], single[s][0]), s
+        assert torch.equal(batch_its[:, s], single[s][0][1:]), (mode, s)
     tot = sum(x[1] for x in single) / S
     close(torch.cat(losses), tot.cpu().numpy(), atol=1e-6, rtol=1e-6)
+
+
+def test_sd_multi_sequence_refuses_bad_side_streams_before_forking():
+    """pt_sd_solve_batch_f32 validates EVERY auxiliary stream before it records the fork event: a null or repeated later entry returns
+    PT_ERR_SHAPE with nothing queued on the earlier streams (sd_solver.hip; advisor finding of round 5)."""
+    import ctypes
+    cfg = synth.DIMP50
+    S, n, C = 3, 4, 64
+    L = _lib.lib()
+    probs = [synth.dimp_problem(950 + s, n, dict(cfg, C=C)) for s in range(S)]
+    from pytracking_amd import bench_frame
+    holder = bench_frame.TrackState(dict(cfg, C=C), n, seed=3, device=DEV)       # owns a filled pt_sd_params (+ its look-up tables)
+    prm = holder.params
+    H, W, K = cfg["H"], cfg["W"], cfg["K"]
+    nb = (L.pt_sd_ws_bytes(n, C, H, W, K) + 255) // 256 * 256
+    ws = torch.empty(nb * S, dtype=torch.uint8, device=DEV)
+    w = [T(p[0]) for p in probs]; f = [T(p[1]) for p in probs]; b = [T(p[2]) for p in probs]
+    its = [torch.zeros(3, C, K, K, device=DEV) for _ in range(S)]
+    arr = ctypes.c_void_p * S
+    side = torch.cuda.Stream(device=DEV)
+    cur = torch.cuda.current_stream().cuda_stream
+    for aux in ([side.cuda_stream, None], [side.cuda_stream, side.cuda_stream], [side.cuda_stream, cur]):
+        p_aux = (ctypes.c_void_p * 2)(*aux)
+        rc = L.pt_sd_solve_batch_f32(ctypes.byref(prm), S, arr(*[x.data_ptr() for x in w]), arr(*[x.data_ptr() for x in f]),
+                                     f[0].stride(0), arr(*[x.data_ptr() for x in b]), None, n, C, H, W, K, 2,
+                                     arr(*[x.data_ptr() for x in its]), None, arr(*[ws.data_ptr() + s * nb for s in range(S)]), nb, cur,
+                                     p_aux, 2)
+        assert rc == _lib.PT_ERR_SHAPE, (aux, rc)
+    torch.cuda.synchronize()
+    assert all(float(x.abs().max()) == 0.0 for x in its)           # nothing ran
 
 
 def test_atom_cg_folded_partial_sum_knob():

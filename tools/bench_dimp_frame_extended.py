@@ -88,7 +88,7 @@ def measure(dev, frames=300):
 
     st2 = bench_frame.TrackState(cfg, cfg["memory"], seed=1234, device=dev)
     st2.attach_head(head[0].weight, head[1].scale, head[1].eps)
-    pipe2 = frame_full.FramePipeline(st2, num_iter=5, overlap=True)
+    pipe2 = frame_full.FramePipeline(st2, num_iter=5, overlap=True, reordered_update_ok=True)
 
     # what 19 of 20 real DiMP frames do (train_skipping = 20, parameter/dimp/dimp50.py:19): head, classification, memory insert,
     # localisation, refinement -- no re-optimisation of the filter (num_iter = 0)
