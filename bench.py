@@ -73,10 +73,19 @@ def make_pool(cfg, seed, device):
     return torch.from_numpy(synth.clf_features(rng, POOL, cfg["C"], cfg["H"], cfg["W"], cfg["K"])).to(device)
 
 
+# Frame chains (pt_track_frame_chain_f32, include/pt_hot.h): inside a run of consecutive frames the last filter update of every solve
+# is applied in the prologue of the next frame's first correlation instead of by its own dependent launch; the run ends with the
+# flush, so every graph / every eager call of run_frames leaves the complete state.  Same bits as the plain frame
+# (tests/test_gpu_parity.py::test_frame_chain_deferred_last_update_is_bit_identical).  PT_BENCH_NO_CHAIN=1: the round-5 launch sequence.
+CHAIN = os.environ.get("PT_BENCH_NO_CHAIN", "") != "1"
+
+
 def run_frames(st, pool, first, count):
     n = st.n
     for f in range(first, first + count):
-        st.step(pool[f % POOL], slot=f % n, num_iter=NUM_ITER)
+        st.step(pool[f % POOL], slot=f % n, num_iter=NUM_ITER, defer=CHAIN)
+    if CHAIN:
+        st.flush()
 
 
 def reference_available():
@@ -410,8 +419,11 @@ class _DryState:
         self.cfg, self.n = dict(cfg), n
         self.acc = torch.zeros(64, dtype=torch.float64) + seed
 
-    def step(self, feat, slot, num_iter):
+    def step(self, feat, slot, num_iter, defer=False):
         self.acc = (self.acc * 1.0000001 + slot + num_iter).sin_()
+
+    def flush(self):
+        pass
 
     def bytes_per_solve(self, num_iter):
         c = self.cfg
@@ -623,6 +635,9 @@ def main():
                   + ("" if args.no_clock_warmup else "; clock warm-up: ~40 ms of idempotent pass replays in front of the warm-up frames")
                   + ")" if use_graph
                   else "eager (18 launches per frame)")
+        if CHAIN:
+            launch += ("; frame chain: the last filter update of each solve rides on the next frame's first correlation "
+                       "(17 launches per frame + one flush per run of frames)")
         out = {
             "metric": "frames/sec DiMP-50 online track (288x288, 5 SD iters)" if cfg_name == "dimp50" else "frames/sec PrDiMP-50 online track (352x352, 5 SD iters)", "value": round(value, 2),
             "unit": "frames/s", "n_gpus": world, "steps": K, "warmup": Wm,

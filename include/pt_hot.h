@@ -378,6 +378,30 @@ int pt_track_frame_f32(const pt_sd_params* p, float* filter, float* mem_feat, fl
                        int n, int C, int H, int W, int K, int num_iter,
                        float* scores_out, float* peak_out, void* ws, size_t ws_bytes, void* stream);
 
+/* Frame CHAINS (round 6).  pt_track_frame_f32 leaves the last iterate in `filter` before its launches end: the solve's last
+ * statement, w_T = w_{T-1} - step*alpha_T*g_T (optimizer.py:155-160), is one dependent launch whose ONLY consumer is the next
+ * frame's first correlation (classification + s_0).  In a chain of frames on one stream and one workspace that launch can ride on
+ * its consumer: with defer != 0 the call leaves (w_{T-1}, g_T, the operands of alpha_T) in the workspace and describes them in
+ * *pending; the next pt_track_frame_chain_f32 call (same filter / workspace / n, C, H, W, K) finds pending->iters > 0, forms w_T in
+ * the prologue of its first correlation -- the same expressions on the same operands: the same bits as pt_track_frame_f32 -- and
+ * stores it to `filter`; pt_track_frame_flush_f32 applies a pending update on its own (end of the chain, or before anything else
+ * reads `filter`).  While an update is pending `filter` holds w_0 of the last solve, NOT its result.
+ *   *pending: caller-owned host struct, zero-initialised at the start of a chain; in-out.  A solve of fewer than 2 iterations is
+ *   never deferred (pending->iters stays 0).  4x4 filters on the XCD-aligned path only: PT_ERR_UNSUPPORTED otherwise with nothing
+ *   queued -- fall back to pt_track_frame_f32 (after a flush). */
+typedef struct {
+    int iters;            /* 0: nothing pending; else the iteration count T of the solve whose last update is pending */
+    float step_length;    /* of that solve */
+    float reg_eps;        /* its reg + alpha_eps */
+} pt_frame_pending;
+int pt_track_frame_chain_f32(const pt_sd_params* p, float* filter, float* mem_feat, float* mem_bb,
+                             const float* sample_weight, const float* test_feat, int slot,
+                             int n, int C, int H, int W, int K, int num_iter,
+                             float* scores_out, float* peak_out, void* ws, size_t ws_bytes,
+                             pt_frame_pending* pending, int defer, void* stream);
+int pt_track_frame_flush_f32(pt_frame_pending* pending, float* filter, int n, int C, int H, int W, int K,
+                             void* ws, size_t ws_bytes, void* stream);
+
 /* ------------------------------------------------------------------------------------------------
  * The tracking frame with the classification-feature head in front.
  * Replaces: ltr/models/target_classifier/features.py:66-72 (final 3x3 conv + InstanceL2Norm of the test frame) feeding

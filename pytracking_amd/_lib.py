@@ -81,7 +81,7 @@ EXPORTS = [
     "pt_sd_ws_bytes", "pt_sd_solve_f32",
     "pt_atom_cg_ws_bytes", "pt_atom_cg_f32", "pt_atom_gn_ws_bytes", "pt_atom_gn_f32",
     "pt_prroi_fwd_f32", "pt_prroi_bwd_feat_f32", "pt_prroi_bwd_coor_f32",
-    "pt_track_frame_ws_bytes", "pt_track_frame_f32",
+    "pt_track_frame_ws_bytes", "pt_track_frame_f32", "pt_track_frame_chain_f32", "pt_track_frame_flush_f32",
     "pt_apply_filter_mf_ws_bytes", "pt_apply_filter_mf_f32", "pt_feat_transpose_mf_ws_bytes", "pt_feat_transpose_mf_f32",
     "pt_lwl_ws_bytes", "pt_lwl_gn_solve_f32",
     "pt_tomp_param_floats", "pt_tomp_prepared_floats", "pt_tomp_prepare_f32", "pt_tomp_posenc_f32", "pt_tomp_predict_ws_bytes", "pt_tomp_predict_f32", "pt_tomp_linear_f32",
@@ -93,6 +93,11 @@ EXPORTS = [
     "pt_track_frame_full_ws_bytes", "pt_track_frame_full_f32", "pt_track_frame_full_launch_f32", "pt_host_buffer_forget",
     "pt_sd_solve_batch_f32", "pt_stream_probe_f32",
 ]
+
+
+class FramePending(ctypes.Structure):
+    """`pt_frame_pending` of include/pt_hot.h."""
+    _fields_ = [("iters", ctypes.c_int), ("step_length", ctypes.c_float), ("reg_eps", ctypes.c_float)]
 
 
 class SdParams(ctypes.Structure):
@@ -234,6 +239,11 @@ def lib():
     L.pt_track_frame_ws_bytes.argtypes = [i] * 5
     L.pt_track_frame_f32.restype = i
     L.pt_track_frame_f32.argtypes = [ctypes.POINTER(SdParams), vp, vp, vp, vp, vp] + [i] * 7 + [vp, vp, vp, sz, vp]
+    L.pt_track_frame_chain_f32.restype = i
+    L.pt_track_frame_chain_f32.argtypes = ([ctypes.POINTER(SdParams), vp, vp, vp, vp, vp] + [i] * 7 +
+                                           [vp, vp, vp, sz, ctypes.POINTER(FramePending), i, vp])
+    L.pt_track_frame_flush_f32.restype = i
+    L.pt_track_frame_flush_f32.argtypes = [ctypes.POINTER(FramePending), vp] + [i] * 5 + [vp, sz, vp]
     L.pt_apply_filter_mf_ws_bytes.restype = sz
     L.pt_apply_filter_mf_ws_bytes.argtypes = [i] * 6
     L.pt_apply_filter_mf_f32.restype = i

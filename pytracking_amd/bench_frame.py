@@ -61,17 +61,40 @@ class TrackState:
         if nb == 0:
             raise RuntimeError("pt_track_frame_ws_bytes rejected the configuration")
         self.ws = torch.empty(nb, dtype=torch.uint8, device=dev)
+        self.pending = _lib.FramePending()                          # frame chains (pt_track_frame_chain_f32): host-side, zero = nothing pending
 
     @device_guarded
-    def step(self, test_feat, slot, num_iter):
-        """test_feat (C,H,W) device tensor.  Asynchronous."""
+    def step(self, test_feat, slot, num_iter, defer=False):
+        """test_feat (C,H,W) device tensor.  Asynchronous.
+        defer=True: frame-chain mode (`pt_track_frame_chain_f32`, include/pt_hot.h): the solve's last filter update stays pending and
+        rides on the NEXT step's first correlation; `self.filter` is complete only after `flush()` (or the next non-deferred step).
+        A pending update of the previous step is always applied first, whatever `defer` says."""
         c = self.cfg
         assert test_feat.is_contiguous() and test_feat.dtype == torch.float32
+        if defer or self.pending.iters > 0:
+            rc = _lib.lib().pt_track_frame_chain_f32(
+                ctypes.byref(self.params), _ptr(self.filter), _ptr(self.mem_feat), _ptr(self.mem_bb),
+                _ptr(self.sample_weight), _ptr(test_feat), int(slot), self.n, c["C"], c["H"], c["W"], c["K"], int(num_iter),
+                _ptr(self.scores), _ptr(self.peak), _ptr(self.ws), self.ws.numel(), ctypes.byref(self.pending), int(bool(defer)),
+                _stream())
+            if rc == _lib.PT_ERR_UNSUPPORTED and self.pending.iters == 0:
+                defer = False                                       # shape outside the chain's path: the plain frame below
+            else:
+                _lib.check(rc, "pt_track_frame_chain_f32")
+                return
         rc = _lib.lib().pt_track_frame_f32(
             ctypes.byref(self.params), _ptr(self.filter), _ptr(self.mem_feat), _ptr(self.mem_bb),
             _ptr(self.sample_weight), _ptr(test_feat), int(slot), self.n, c["C"], c["H"], c["W"], c["K"], int(num_iter),
             _ptr(self.scores), _ptr(self.peak), _ptr(self.ws), self.ws.numel(), _stream())
         _lib.check(rc, "pt_track_frame_f32")
+
+    @device_guarded
+    def flush(self):
+        """Apply a pending last update (end of a chain of `step(..., defer=True)` calls).  Asynchronous; no-op when nothing is pending."""
+        c = self.cfg
+        rc = _lib.lib().pt_track_frame_flush_f32(ctypes.byref(self.pending), _ptr(self.filter), self.n, c["C"], c["H"], c["W"], c["K"],
+                                                 _ptr(self.ws), self.ws.numel(), _stream())
+        _lib.check(rc, "pt_track_frame_flush_f32")
 
     def attach_head(self, weight, norm_scale, norm_eps=1e-5):
         """Classification-feature head in front of the frame: weight (C, Cin, 3, 3) of the final conv

@@ -200,10 +200,49 @@ extern "C" size_t pt_track_frame_ws_bytes(int n, int C, int H, int W, int K) {
     return tf_carve(n, C, H, W, K).total * sizeof(float);
 }
 
+static int track_frame_impl(const pt_sd_params* prm, float* filter, float* mem_feat, float* mem_bb,
+                            const float* sample_weight, const float* test_feat, int slot, int n, int C, int H,
+                            int W, int K, int num_iter, float* scores_out, float* peak_out, void* ws,
+                            size_t ws_bytes, void* stream, pt_frame_pending* pend, bool defer);
+
 extern "C" int pt_track_frame_f32(const pt_sd_params* prm, float* filter, float* mem_feat, float* mem_bb,
                                   const float* sample_weight, const float* test_feat, int slot, int n, int C, int H,
                                   int W, int K, int num_iter, float* scores_out, float* peak_out, void* ws,
                                   size_t ws_bytes, void* stream) {
+    return track_frame_impl(prm, filter, mem_feat, mem_bb, sample_weight, test_feat, slot, n, C, H, W, K, num_iter, scores_out, peak_out,
+                            ws, ws_bytes, stream, nullptr, false);
+}
+
+// Frame chain: the same frame, with the solve's LAST filter update (one dependent launch whose only consumer is the next frame's first
+// correlation) deferred into that correlation's prologue -- include/pt_hot.h.
+extern "C" int pt_track_frame_chain_f32(const pt_sd_params* prm, float* filter, float* mem_feat, float* mem_bb,
+                                        const float* sample_weight, const float* test_feat, int slot, int n, int C, int H,
+                                        int W, int K, int num_iter, float* scores_out, float* peak_out, void* ws,
+                                        size_t ws_bytes, pt_frame_pending* pending, int defer, void* stream) {
+    if (!pending) return PT_ERR_NULL;
+    if (pending->iters < 0) return PT_ERR_SHAPE;
+    return track_frame_impl(prm, filter, mem_feat, mem_bb, sample_weight, test_feat, slot, n, C, H, W, K, num_iter, scores_out, peak_out,
+                            ws, ws_bytes, stream, pending, defer != 0);
+}
+
+extern "C" int pt_track_frame_flush_f32(pt_frame_pending* pending, float* filter, int n, int C, int H, int W, int K, void* ws,
+                                        size_t ws_bytes, void* stream) {
+    if (!pending || !filter || !ws) return PT_ERR_NULL;
+    if (pending->iters == 0) return PT_OK;
+    if (n <= 0 || C <= 0 || H <= 0 || W <= 0 || K <= 0) return PT_ERR_SHAPE;
+    TfCarve cv = tf_carve(n, C, H, W, K);
+    if (ws_bytes < cv.total * sizeof(float) || ((uintptr_t)ws % 256) != 0) return PT_ERR_WORKSPACE;
+    float* base = (float*)ws;
+    const int rc = pt_sd_flush_impl(pending, filter, n, C, H, W, K, base + cv.w_iters, base + cv.sd, (cv.total - cv.sd) * sizeof(float),
+                                    (hipStream_t)stream);
+    if (rc == PT_OK) pending->iters = 0;
+    return rc;
+}
+
+static int track_frame_impl(const pt_sd_params* prm, float* filter, float* mem_feat, float* mem_bb,
+                            const float* sample_weight, const float* test_feat, int slot, int n, int C, int H,
+                            int W, int K, int num_iter, float* scores_out, float* peak_out, void* ws,
+                            size_t ws_bytes, void* stream, pt_frame_pending* pend, bool defer) {
     if (!prm || !filter || !mem_feat || !mem_bb || !test_feat || !scores_out || !peak_out || !ws) return PT_ERR_NULL;
     if (n <= 0 || C <= 0 || H <= 0 || W <= 0 || K <= 0 || num_iter < 0 || slot < 0 || slot >= n) return PT_ERR_SHAPE;
     if (K * K > 16 || num_iter > 64) return PT_ERR_UNSUPPORTED;
@@ -221,8 +260,9 @@ extern "C" int pt_track_frame_f32(const pt_sd_params* prm, float* filter, float*
         PtClsFin cls = {nullptr, 0, slot, scores_out, peak_out, mem_bb, nullptr};
         return pt_sd_solve_impl(prm, filter, mem_feat, CHW, mem_bb, sample_weight, n, C, H, W, K, num_iter,
                                 base + cv.w_iters, nullptr, base + cv.sd, (cv.total - cv.sd) * sizeof(float), st,
-                                /*copy_w0=*/false, /*w_final=*/filter, &cls, /*src=*/test_feat);
+                                /*copy_w0=*/false, /*w_final=*/filter, &cls, /*src=*/test_feat, pend, defer);
     }
+    if (defer || (pend && pend->iters > 0)) return PT_ERR_UNSUPPORTED;   // frame chains exist on the fast path only
     // 1. classify the test frame with the current filter (dimp.py:190-194 -> linear_filter.py:75-80); the pass also
     //    stores the features it streams into memory slot `slot` (dimp.py:429-441 update_memory)
     PtPlan p1 = pt_make_plan(1, C, H, W, K, K, OH, OW);

@@ -175,7 +175,7 @@ struct Corr2Args {                  // pointer members global-qualified: fetched
     pt_gcf feat; long stride_n; pt_gcf filt; pt_gf spart;
     int n, C, H, W, KH, KW, OH, OW, CX, TF, rem, tiles, HWp, nh, KSC;
     // fused gradient reduction (optimizer.py:146-148): filter operand = sum_k gpart[k] + reg*w
-    pt_gcf gpart; int KSPL; pt_gcf w; float reg; pt_gf g_out; pt_gf anum_part;
+    pt_gcf gpart; int KSPL; pt_gcf w; float reg; float step; pt_gf g_out; pt_gf anum_part;   // FUSE < 0: reg = reg + alpha_eps, step = step length of the pending solve
     // source override: sample `slot` is read from `src` (C,H,W) and stored to copy_dst (the memory slot)
     int slot; pt_gcf src; pt_gf copy_dst;
     PT_STAMP_ARG
@@ -211,16 +211,22 @@ __device__ __forceinline__ float corr2_filter_elem(const Corr2Args& a, int KK, i
 // -- a whole memory round trip -- in front of the first feature load (round 3, profiles/r03g_pass_phase_stamps.txt).
 // NH: k-step halves per tile (2 for 18x18 maps, 1 for 22x22) -- compile time as well: as a run-time value every tap of the
 // shift-and-add became `ds_read; branch; ds_read; s_waitcnt lgkmcnt(0)`, 16 serialised LDS round trips (0.9 us of the pass).
+// FUSE < 0 (round 6, 4x4 filters only): the DEFERRED last update of the previous solve.  A frame chain leaves (w_{T-1}, g_T, the operands
+// of alpha_T) in the workspace instead of spending a dependent launch (k_fast_final) on w_T = w_{T-1} - step*alpha_T*g_T, whose only
+// consumer is the next frame's first correlation: here the operand is formed from h_filt = w_{T-1}, h_w = g_T, alpha_T from the n
+// per-sample curvature terms and the channel-range sums of g^2 (h_w + h_aux: anum, 64 floats further: qs) with the expressions of
+// k_fast_final (sd_final_astep / sd_final_apply: same bits), and the workgroups of sample 0 store w_T into a.g_out = the filter.
 template <int NK, bool LEFT, int FUSE, bool K16, int NH>
 __global__ __launch_bounds__(1024, (NK <= 8 && NH == 2 ? PT_C2_MINW : 4)) void k_corr2(const float* h_feat, long h_stride, const float* h_filt, const float* h_w, const float* h_src, int h_slot,
-                                                                              unsigned h_dims, unsigned h_geo, Corr2Args a_arg) {
+                                                                              unsigned h_dims, unsigned h_geo, unsigned h_aux, Corr2Args a_arg) {
     // The h_* parameters repeat what the prologue needs to REQUEST its operands (13 dwords).  Scalar kernel parameters are
     // preloaded into SGPRs at wave launch (-amdgpu-kernarg-preload-count), the argument block `a` arrives by scalar loads about
     // 1.2 us later (measured in round 3: a kernel whose arguments are all preloaded is that much shorter, eager and in graph
     // replay alike) -- by then the filter partials and the first feature tiles are on their way.
     //   h_filt = gradient partials (FUSE > 0) or the filter (FUSE == 0);  h_dims = C << 16 | H*W;
     //   h_geo  = tiles | TF << 5 | rem << 10 | KSPL << 14 | (16 channel ranges) << 20 | (1 channel range: C = 64) << 21 |
-    //            (sample pairs: workgroup b >> 3 takes samples 2 (b >> 3) and 2 (b >> 3) + 1) << 22
+    //            (sample pairs: workgroup b >> 3 takes samples 2 (b >> 3) and 2 (b >> 3) + 1) << 22 | (FUSE < 0: n) << 23
+    //   h_aux  = FUSE < 0: float offset of the anum block from h_w
     extern __shared__ __attribute__((aligned(16))) float lds[];     // afilt[CX][16] | T[2][KK][HWp]
     __shared__ float scratch[16];
     PT_STAMP(a_arg, 0);
@@ -248,7 +254,9 @@ __global__ __launch_bounds__(1024, (NK <= 8 && NH == 2 ? PT_C2_MINW : 4)) void k
     float* __restrict__ Tl = lds + nsl + (long)(ws * NH + h) * KK * hHWp;
     const bool over = h_src != nullptr && i == h_slot;
     const float* __restrict__ fi = over ? h_src : h_feat + (long)i * h_stride;
-    const bool publish = FUSE > 0 && i0 == 0;                       // uniform per workgroup
+    const bool publish = FUSE != 0 && i0 == 0;                      // uniform per workgroup
+    const int h_n = (int)(h_geo >> 23);                             // FUSE < 0: samples of the pending solve
+    float lz_q = 0.f, lz_an = 0.f;
 
     // ---- filter operand: straight-line, clamped addresses, all loads in flight together.  With 16 taps the slice
     //      is one contiguous run of CX*16 floats: 16-byte loads, one per thread; otherwise up to EPT scalars.
@@ -269,6 +277,12 @@ __global__ __launch_bounds__(1024, (NK <= 8 && NH == 2 ? PT_C2_MINW : 4)) void k
             for (int k = 0; k < FP; ++k)
                 part4[k] = __builtin_bit_cast(f32x2, __builtin_amdgcn_raw_buffer_load_b64(rg, (unsigned)g4 * 8u, (unsigned)min(k, h_KSPL - 1) * ckk_b, 0));
             wv4 = ((const f32x2*)h_w)[g4];
+        } else if (FUSE < 0) {
+            part4[0] = ((const f32x2*)h_filt)[g4];                  // w_{T-1}
+            wv4 = ((const f32x2*)h_w)[g4];                          // g_T
+            const float* __restrict__ anp = h_w + h_aux;
+            lz_an = lane < (ksc16 ? 16 : (ksc1 ? 1 : 8)) ? anp[lane] : 0.f;
+            lz_q = lane < h_n ? anp[64 + lane] : 0.f;
         } else {
             part4[0] = ((const f32x2*)h_filt)[g4];
         }
@@ -336,6 +350,12 @@ __global__ __launch_bounds__(1024, (NK <= 8 && NH == 2 ? PT_C2_MINW : 4)) void k
                 gsq = v4[0] * v4[0] + v4[1] * v4[1];
                 if (publish) ((f32x2*)a.g_out)[((long)cx0 * 16 >> 1) + e4] = v4;
             }
+        } else if (FUSE < 0) {
+            float qt = 0.f;
+            for (int k = lane + 64; k < h_n; k += 64) qt += (h_w + h_aux)[64 + k];   // memories of more than 64 samples
+            const float astep = sd_final_astep(lz_q, qt, lz_an, a.step, a.reg);
+            v4 = (f32x2){sd_final_apply(part4[0][0], wv4[0], astep), sd_final_apply(part4[0][1], wv4[1], astep)};
+            if ((int)threadIdx.x < n4 && publish) ((f32x2*)a.g_out)[((long)cx0 * 16 >> 1) + e4] = v4;
         } else {
             v4 = part4[0];
         }
@@ -364,7 +384,7 @@ __global__ __launch_bounds__(1024, (NK <= 8 && NH == 2 ? PT_C2_MINW : 4)) void k
         for (int e = threadIdx.x + EPT * nthreads; e < nsl; e += nthreads)
             afilt[e] = corr2_filter_elem(a, KK, cx0, e, publish, gsq);
     }
-    if (publish) {                                                  // uniform per workgroup
+    if (FUSE > 0 && publish) {                                      // uniform per workgroup
         const float tot = block_sum(gsq, scratch, nthreads);
         if (threadIdx.x == 0) a.anum_part[x] = tot;
     }
@@ -469,7 +489,7 @@ __global__ __launch_bounds__(1024, (NK <= 8 && NH == 2 ? PT_C2_MINW : 4)) void k
 }
 
 int pt_launch_corr2(const PtFast& p, const float* feat, long stride_n, const float* filt, float* spart, hipStream_t st,
-                    const PtCorrFuse* fuse, int slot, const float* src, float* copy_dst) {
+                    const PtCorrFuse* fuse, int slot, const float* src, float* copy_dst, const PtCorrLazy* lazy) {
     Corr2Args a;
     a.feat = (pt_gcf)feat; a.stride_n = stride_n; a.filt = (pt_gcf)filt; a.spart = (pt_gf)spart;
     a.n = p.n; a.C = p.C; a.H = p.H; a.W = p.W; a.KH = p.KH; a.KW = p.KW; a.OH = p.OH; a.OW = p.OW;
@@ -480,6 +500,18 @@ int pt_launch_corr2(const PtFast& p, const float* feat, long stride_n, const flo
         a.anum_part = (pt_gf)fuse->anum_part;
     }
     a.slot = slot; a.src = (pt_gcf)src; a.copy_dst = (pt_gf)copy_dst;
+    a.step = 0.f;
+    unsigned h_aux = 0, h_nbits = 0;
+    if (lazy) {
+        // the deferred last update of the previous solve forms the filter operand (k_corr2, FUSE < 0); `filt` is not read
+        if (fuse || p.KK != 16 || p.n > 511 || p.CX * 8 > p.corr_threads || !lazy->w_prev || !lazy->g || !lazy->anum || !lazy->w_out ||
+            lazy->qs != lazy->anum + 64 || lazy->anum < lazy->g || (lazy->anum - lazy->g) > 0x3fffffffL)
+            return PT_ERR_UNSUPPORTED;
+        if (((uintptr_t)lazy->w_prev % 16) || ((uintptr_t)lazy->g % 16) || ((uintptr_t)lazy->w_out % 16)) return PT_ERR_UNSUPPORTED;
+        a.filt = (pt_gcf)lazy->w_prev; a.w = (pt_gcf)lazy->g; a.g_out = (pt_gf)lazy->w_out; a.reg = lazy->reg_eps; a.step = lazy->step;
+        h_aux = (unsigned)(lazy->anum - lazy->g);
+        h_nbits = (unsigned)p.n << 23;
+    }
     PT_STAMP_SET(a);
     if (((uintptr_t)feat % 16) || (stride_n % 4) || ((uintptr_t)src % 16) || ((uintptr_t)copy_dst % 16)) return PT_ERR_UNSUPPORTED;
     if ((long)p.n * stride_n * 4 >= (1L << 31)) return PT_ERR_UNSUPPORTED;
@@ -489,11 +521,12 @@ int pt_launch_corr2(const PtFast& p, const float* feat, long stride_n, const flo
     if (p.C >= (1 << 16) || p.HW >= (1 << 16) || p.tiles > 31 || p.TF > 31 || p.rem > 15 || a.KSPL > 16) return PT_ERR_UNSUPPORTED;
     const unsigned h_dims = ((unsigned)p.C << 16) | (unsigned)p.HW;
     const unsigned h_geo = (unsigned)p.tiles | ((unsigned)p.TF << 5) | ((unsigned)p.rem << 10) | ((unsigned)a.KSPL << 14) |
-                           ((p.KSC == 16 ? 1u : 0u) << 20) | ((p.KSC == 1 ? 1u : 0u) << 21) | ((p.spw == 2 ? 1u : 0u) << 22);
-#define PT_C2_HOT(FPTR) (const float*)a.feat, a.stride_n, (const float*)(FPTR), (const float*)a.w, (const float*)a.src, a.slot, h_dims, h_geo
+                           ((p.KSC == 16 ? 1u : 0u) << 20) | ((p.KSC == 1 ? 1u : 0u) << 21) | ((p.spw == 2 ? 1u : 0u) << 22) | h_nbits;
+#define PT_C2_HOT(FPTR) (const float*)a.feat, a.stride_n, (const float*)(FPTR), (const float*)a.w, (const float*)a.src, a.slot, h_dims, h_geo, h_aux
 #define PT_C2G(NKV, LF, KF, NHV)                                                                                    \
     do {                                                                                                         \
-        if (!a.gpart) hipLaunchKernelGGL((k_corr2<NKV, LF, 0, KF, NHV>), grid, block, p.corr_lds, st, PT_C2_HOT(a.filt), a);             \
+        if (lazy) { if constexpr (KF) hipLaunchKernelGGL((k_corr2<NKV, LF, -1, true, NHV>), grid, block, p.corr_lds, st, PT_C2_HOT(a.filt), a); } \
+        else if (!a.gpart) hipLaunchKernelGGL((k_corr2<NKV, LF, 0, KF, NHV>), grid, block, p.corr_lds, st, PT_C2_HOT(a.filt), a);             \
         else if (a.KSPL <= 8) hipLaunchKernelGGL((k_corr2<NKV, LF, 8, KF, NHV>), grid, block, p.corr_lds, st, PT_C2_HOT(a.gpart), a);     \
         else hipLaunchKernelGGL((k_corr2<NKV, LF, 16, KF, NHV>), grid, block, p.corr_lds, st, PT_C2_HOT(a.gpart), a);                     \
     } while (0)

@@ -83,9 +83,12 @@ static inline size_t pt_fast_spart_floats(const PtFast& p) { return (size_t)16 *
 static inline size_t pt_fast_gpart_floats(const PtFast& p) { return (size_t)p.KSPL * p.C * p.KK; }
 // spart[x][i][OH*OW], x = XCD channel range (8 slices).  `slot`/`src`/`copy_dst`: sample `slot` is read from `src`
 // and stored to `copy_dst` while it streams (src == nullptr: no override).
+// `lazy`: the filter operand is the deferred last update of the previous solve (k_corr2 FUSE < 0): w_out = w_prev - step*alpha*g with
+// alpha from qs (n values, at anum + 64) and anum; the workgroups of sample 0 store it to w_out.  4x4 filters, n <= 511 only.
+struct PtCorrLazy { const float* w_prev; const float* g; const float* anum; const float* qs; float step, reg_eps; float* w_out; };
 int pt_launch_corr2(const PtFast& p, const float* feat, long stride_n, const float* filt, float* spart, hipStream_t st,
                     const PtCorrFuse* fuse = nullptr, int slot = -1, const float* src = nullptr,
-                    float* copy_dst = nullptr);
+                    float* copy_dst = nullptr, const PtCorrLazy* lazy = nullptr);
 int pt_launch_adj2_plain(const PtFast& p, const float* feat, long stride_n, const float* inp, float* gpart,
                          hipStream_t st);
 struct SdArgs;
@@ -138,10 +141,17 @@ struct PtClsFin {
     void* after_init;     // optional hipEvent_t recorded behind the launch that writes scores / peak (frame_full.hip forks there)
 };
 
+// Frame chains (pt_track_frame_chain_f32): `pend` in-out, nullable.  On entry pend->iters > 0 = the previous solve on this workspace
+// left its last update pending (that many iterations; its step length and reg + alpha_eps): it is applied in the prologue of this
+// solve's first correlation and stored to w_final.  `defer`: this solve leaves ITS last update pending (pend is filled) instead of
+// launching it.  Both need the fast path (PT_ERR_UNSUPPORTED otherwise, nothing queued) and w_final == w_in (the chain's filter).
 int pt_sd_solve_impl(const pt_sd_params* prm, const float* w_in, const float* feat, long feat_stride_n, const float* bb,
                      const float* sample_weight, int n, int C, int H, int W, int K, int num_iter, float* w_iters,
                      float* losses, void* ws, size_t ws_bytes, hipStream_t st, bool copy_w0, float* w_final,
-                     const PtClsFin* cls, const float* src);
+                     const PtClsFin* cls, const float* src, pt_frame_pending* pend = nullptr, bool defer = false);
+// the pending update on its own (end of a chain)
+int pt_sd_flush_impl(const pt_frame_pending* pend, float* filter, int n, int C, int H, int W, int K, float* w_iters, void* ws,
+                     size_t ws_bytes, hipStream_t st);
 
 int pt_sd_replay_impl(const pt_sd_params* prm, const float* w_in, const float* feat, long feat_stride_n, const float* bb,
                       const float* sample_weight, int n, int C, int H, int W, int K, int num_iter, float* w_iters, void* ws,

@@ -196,6 +196,17 @@ __device__ __forceinline__ SdQLane sd_q_lane(const float* __restrict__ qs, int n
     return r;
 }
 
+// The LAST update of a solve, w_T = w_{T-1} - step*alpha_T*g_T (optimizer.py:155-160), from the operands the last iteration left in
+// the workspace: one wave, explicit fused multiply-adds -- so that k_fast_final and the deferred form in the prologue of the next
+// frame's first correlation (k_corr2, FUSE < 0) produce the same bits.
+__device__ __forceinline__ float sd_final_astep(float q_head, float q_tail, float an, float step, float reg_eps) {
+    float den = wave_sum(q_head + q_tail);
+    const float a_num = wave_sum(an);
+    den = fmaxf(__builtin_fmaf(reg_eps, a_num, den), 1e-8f);
+    return step * (a_num / den);
+}
+__device__ __forceinline__ float sd_final_apply(float w, float g, float astep) { return __builtin_fmaf(-astep, g, w); }
+
 // optimizer.py:155-160 / :425-430: alpha = |g|^2 / max(sum_i q_i + (reg+eps)|g|^2, 1e-8), times the step length;
 // from one wave (every lane gets it): wave-parallel fixed-order sums, identical in every workgroup.
 __device__ __forceinline__ float sd_alpha_step_wave(const SdArgs& a, int lane) {

@@ -335,17 +335,23 @@ __global__ __launch_bounds__(1024) void k_fast_sgq2(const float* __restrict__ sp
     const int oc = min(o, OO - 1);
     const long q = (long)i * OO + oc;
     const int nthreads = ((OO + 63) >> 6) << 6;
+    // PT_SGQ_EXP (experiments only, profiles/r06c_*: where do the 1.9 us between this kernel and an empty one go?):
+    //   1: no loads (operands from the thread index)   2: no stores   3: neither   4: no block reduction (q_i of wave 0 only)
+#ifndef PT_SGQ_EXP
+#define PT_SGQ_EXP 0
+#endif
     float v[PT_PW_MAXKS];
     {
         const float* p = spart + q;
         const long st = (long)n * OO;
 #pragma unroll
-        for (int k = 0; k < PT_PW_MAXKS; ++k) v[k] = p[(long)min(k, KS - 1) * st];
+        for (int k = 0; k < PT_PW_MAXKS; ++k) v[k] = (PT_SGQ_EXP & 1) && PT_SGQ_EXP != 4 ? 1e-3f * (float)(o + k) : p[(long)min(k, KS - 1) * st];
     }
-    const float sv = sp[q];
+    const float sv = (PT_SGQ_EXP & 1) && PT_SGQ_EXP != 4 ? 0.5f : sp[q];
     f32x4 lm = {0, 0, 0, 0};
     float P = 0.f, L = 0.f;
-    if (kind != PT_SD_PRDIMP) lm = ((const f32x4*)p3)[q];
+    if ((PT_SGQ_EXP & 1) && PT_SGQ_EXP != 4) { lm = (f32x4){0.1f, 0.5f, 1.0f, 0.f}; P = 0.01f; L = 0.01f; }
+    else if (kind != PT_SD_PRDIMP) lm = ((const f32x4*)p3)[q];
     else { P = p3[q]; L = p4[q]; }
     __builtin_amdgcn_sched_barrier(0);
     const SgqLate l = pt_late_args<SgqLate>(48);                    // 4 pointers + 3 dwords = 44 bytes, 8-aligned
@@ -357,7 +363,11 @@ __global__ __launch_bounds__(1024) void k_fast_sgq2(const float* __restrict__ sp
         float act, der;
         act_pair(sact, act_param, sv, lm[1], act, der);
         const float qq = lm[2] * (der * sgv);                                       // :151-152
-        const float tot = block_sum(ok ? qq * qq : 0.f, scratch, nthreads);
+#if PT_SGQ_EXP == 0
+        // Round 6 (profiles/r06c_sgq_ablation.txt: the block reduction cost 0.43 us of this launch in the chain -- two barriers with the
+        // result stores queued behind them): the element stores go out first, then ONE barrier; the waves that only contribute a
+        // partial sum end there, thread 0 adds the partials in block_sum's order (same bits) and stores q_i.
+        const float wq = wave_sum(ok ? qq * qq : 0.f);
         if (ok) {
             l.sg[q] = sgv;
             f32x4 pk;
@@ -365,7 +375,24 @@ __global__ __launch_bounds__(1024) void k_fast_sgq2(const float* __restrict__ sp
             else { const float w2 = lm[2] * lm[2]; pk = (f32x4){w2 * sv, w2 * sgv, w2 * lm[0], lm[1]}; }
             ((f32x4*)l.pk)[q] = pk;
         }
+        if ((o & 63) == 0) scratch[o >> 6] = wq;
+        __syncthreads();
+        if (o == 0) {
+            float tot = 0.f;
+            for (int w = 0; w < (nthreads >> 6); ++w) tot += scratch[w];
+            l.qs[i] = tot;
+        }
+#else
+        const float tot = PT_SGQ_EXP == 4 ? wave_sum(ok ? qq * qq : 0.f) : block_sum(ok ? qq * qq : 0.f, scratch, nthreads);
+        if (ok && !((PT_SGQ_EXP & 2) && PT_SGQ_EXP != 4 && tot != 123.456f)) {
+            l.sg[q] = sgv;
+            f32x4 pk;
+            if (kind == PT_SD_DIMP && score_act == PT_ACT_BENTPAR) pk = (f32x4){sv, sgv, lm[0], lm[1]};
+            else { const float w2 = lm[2] * lm[2]; pk = (f32x4){w2 * sv, w2 * sgv, w2 * lm[0], lm[1]}; }
+            ((f32x4*)l.pk)[q] = pk;
+        }
         if (o == 0) l.qs[i] = tot;
+#endif
     } else {
         const float swp = has_sw ? l.sw[i] : 1.0f / (float)n;
         const float tot = block_sum(ok ? P * sgv : 0.f, scratch, nthreads);                   // :419
@@ -527,17 +554,14 @@ __global__ __launch_bounds__(512) void k_fast_final(const float* __restrict__ wp
     const bool ok = (int)threadIdx.x < chunk && e < CKK;
     const int ec = ok ? e : 0;
     const float wv = wp[ec], gv = g[ec];
-    // alpha as sd_alpha_step_wave computes it: same operands, same order
+    // alpha as sd_alpha_step_wave computes it: same operands, same order (sd_final_astep: shared with the deferred form in k_corr2)
     const float qh = lane < n ? qs[lane] : 0.f;
     float qt = 0.f;
     for (int k = lane + 64; k < n; k += 64) qt += qs[k];
     const float an = lane < KS ? anum[lane] : 0.f;
-    float den = wave_sum(qh + qt);
-    const float a_num = wave_sum(an);
-    den = fmaxf(den + reg_eps * a_num, 1e-8f);
-    const float astep = step * (a_num / den);
-    if (ok) wn[e] = wv - astep * gv;
-    for (int e2 = e + blockDim.x; e2 < min(CKK, (i + 1) * chunk); e2 += blockDim.x) wn[e2] = wp[e2] - astep * g[e2];
+    const float astep = sd_final_astep(qh, qt, an, step, reg_eps);
+    if (ok) wn[e] = sd_final_apply(wv, gv, astep);
+    for (int e2 = e + blockDim.x; e2 < min(CKK, (i + 1) * chunk); e2 += blockDim.x) wn[e2] = sd_final_apply(wp[e2], g[e2], astep);
 }
 
 #define PT_SD_MAX_ITER 64
@@ -585,14 +609,31 @@ static int sd_fast_setup(const PtFast& f, const pt_sd_params* prm, const float* 
     return PT_OK;
 }
 
+// what a pending last update needs from the workspace of the solve that left it (same carve every call)
+static int sd_pending_operands(const PtFast& f, const pt_frame_pending* pend, const float* filter, float* w_iters, const SdArgs& a,
+                               PtCorrLazy& lz) {
+    if (pend->iters < 2 || pend->iters > PT_SD_MAX_ITER) return PT_ERR_SHAPE;    // (a one-iteration solve is never deferred: w_{T-1} would BE the filter)
+    lz.w_prev = w_iters + (long)(pend->iters - 1) * a.CKK;
+    lz.g = a.g; lz.anum = a.anum; lz.qs = a.qs; lz.step = pend->step_length; lz.reg_eps = pend->reg_eps;
+    lz.w_out = const_cast<float*>(filter);
+    return PT_OK;
+}
+
 static int sd_solve_fast(const PtFast& f, const pt_sd_params* prm, const float* w_in, const float* feat, long stride_n,
                          const float* bb, const float* sample_weight, int num_iter, float* w_iters, float* losses,
                          void* ws, size_t ws_bytes, hipStream_t st, bool copy_w0, float* w_final, const PtClsFin* cls,
-                         const float* src) {
+                         const float* src, pt_frame_pending* pend, bool defer) {
     SdArgs a;
     float* sbuf[2];
     int rc = sd_fast_setup(f, prm, w_in, bb, sample_weight, w_iters, w_final, ws, ws_bytes, a, sbuf);
     if (rc) return rc;
+    const bool have_pending = pend && pend->iters > 0;
+    PtCorrLazy lz{};
+    if (have_pending || defer) {
+        // chain mode: the filter is updated in place (w_final == w_in), no loss read-out, no iterate 0 copy, 4x4 filters
+        if (!pend || w_final != w_in || losses || copy_w0 || f.KK != 16 || f.n > 511 || f.CX * 8 > f.corr_threads) return PT_ERR_UNSUPPORTED;
+        if (have_pending && (rc = sd_pending_operands(f, pend, w_in, w_iters, a, lz))) return rc;
+    }
     const int n = f.n;
     const int slot = cls ? cls->slot : -1;
     if (cls) {
@@ -606,11 +647,21 @@ static int sd_solve_fast(const PtFast& f, const pt_sd_params* prm, const float* 
         if (hipMemcpyAsync(w_iters, w_in, (size_t)a.CKK * sizeof(float), hipMemcpyDeviceToDevice, st) != hipSuccess)
             return PT_ERR_LAUNCH;
     }
-    if (num_iter == 0 && !want_loss && !cls) return PT_OK;
+    if (num_iter == 0 && !want_loss && !cls) {
+        if (have_pending) {                                          // nothing of this call would consume it: apply it on its own
+            hipLaunchKernelGGL(k_fast_final, dim3(f.n), dim3(512), 0, st, lz.w_prev, lz.g, lz.w_out, lz.qs, lz.anum, f.n, a.CKK, a.KS,
+                               lz.step, lz.reg_eps);
+            PT_CHECK_LAUNCH();
+            pend->iters = 0;
+        }
+        return PT_OK;
+    }
 
     float* copy_dst = src ? const_cast<float*>(feat) + (long)slot * stride_n : nullptr;
-    rc = pt_launch_corr2(f, feat, stride_n, w_in, a.spart, st, nullptr, src ? slot : -1, src, copy_dst);
+    // (a pending last update of the previous solve is applied HERE: it forms this pass's filter operand and lands in the filter)
+    rc = pt_launch_corr2(f, feat, stride_n, w_in, a.spart, st, nullptr, src ? slot : -1, src, copy_dst, have_pending ? &lz : nullptr);
     if (rc) return rc;
+    if (have_pending) pend->iters = 0;
     const int pw_threads = ((a.OO + 63) / 64) * 64;                 // one element per thread (OO <= 1024 on this path)
     const size_t lut_lds = a.kind == PT_SD_DIMP ? (size_t)3 * a.num_bins * sizeof(float) : 0;
     const bool pw2 = a.KS <= PT_PW_MAXKS && lut_lds <= 48 * 1024;
@@ -657,7 +708,10 @@ static int sd_solve_fast(const PtFast& f, const pt_sd_params* prm, const float* 
         else hipLaunchKernelGGL(k_fast_sgq, dim3(n), dim3(384), pw_lds, st, a);
         PT_CHECK_LAUNCH();
     }
-    if (num_iter > 0) {
+    if (num_iter > 1 && defer) {
+        // the last update stays pending: (w_{T-1}, g_T, qs, anum) are in the workspace, the next call of the chain applies it
+        pend->iters = num_iter; pend->step_length = a.step; pend->reg_eps = a.reg + a.alpha_eps;
+    } else if (num_iter > 0) {
         static const bool final_old = std::getenv("PT_SD_FINAL_OLD") != nullptr;     // experiment: the struct-argument kernel
         if (!want_loss && !final_old)
             hipLaunchKernelGGL(k_fast_final, dim3(n), dim3(512), 0, st, sd_w_host(a, num_iter - 1), (const float*)a.g,
@@ -680,7 +734,7 @@ static int sd_solve_fast(const PtFast& f, const pt_sd_params* prm, const float* 
 int pt_sd_solve_impl(const pt_sd_params* prm, const float* w_in, const float* feat, long feat_stride_n, const float* bb,
                      const float* sample_weight, int n, int C, int H, int W, int K, int num_iter, float* w_iters,
                      float* losses, void* ws, size_t ws_bytes, hipStream_t st, bool copy_w0, float* w_final,
-                     const PtClsFin* cls, const float* src) {
+                     const PtClsFin* cls, const float* src, pt_frame_pending* pend, bool defer) {
     if (!prm || !w_in || !feat || !bb || !w_iters || !ws) return PT_ERR_NULL;
     if (n <= 0 || C <= 0 || H <= 0 || W <= 0 || K <= 0 || num_iter < 0) return PT_ERR_SHAPE;
     if (K * K > 16 || num_iter > PT_SD_MAX_ITER) return PT_ERR_UNSUPPORTED;
@@ -693,8 +747,9 @@ int pt_sd_solve_impl(const pt_sd_params* prm, const float* w_in, const float* fe
         PtFast f = pt_fast_plan(n, C, H, W, K, K, OH, OW);
         if (pt_fast_usable(f, feat, feat_stride_n, w_in, src) && ((uintptr_t)w_iters % 16) == 0 && f.KSPL <= 16)
             return sd_solve_fast(f, prm, w_in, feat, feat_stride_n, bb, sample_weight, num_iter, w_iters, losses, ws,
-                                 ws_bytes, st, copy_w0, w_final, cls, src);
+                                 ws_bytes, st, copy_w0, w_final, cls, src, pend, defer);
     }
+    if (defer || (pend && pend->iters > 0)) return PT_ERR_UNSUPPORTED;   // frame chains exist on the fast path only
     if (src) return PT_ERR_UNSUPPORTED;                                 // source override exists on the fast path only
     PtPlan p = pt_make_plan(n, C, H, W, K, K, OH, OW);
     if (p.KS > 64) return PT_ERR_UNSUPPORTED;
@@ -758,6 +813,26 @@ int pt_sd_solve_impl(const pt_sd_params* prm, const float* w_in, const float* fe
         hipLaunchKernelGGL(k_sd_loss, dim3(num_iter + 1), dim3(256), 0, st, a, losses);
         PT_CHECK_LAUNCH();
     }
+    return PT_OK;
+}
+
+int pt_sd_flush_impl(const pt_frame_pending* pend, float* filter, int n, int C, int H, int W, int K, float* w_iters, void* ws,
+                     size_t ws_bytes, hipStream_t st) {
+    if (!pend || !filter || !w_iters || !ws) return PT_ERR_NULL;
+    if (pend->iters == 0) return PT_OK;
+    if (n <= 0 || C <= 0 || H <= 0 || W <= 0 || K <= 0) return PT_ERR_SHAPE;
+    const int OH = H + (K + 1) % 2, OW = W + (K + 1) % 2;
+    PtFast f = pt_fast_plan(n, C, H, W, K, K, OH, OW);
+    if (!f.ok) return PT_ERR_UNSUPPORTED;
+    FastCarve cv = fast_carve(f, PT_SD_MAX_ITER);
+    if (ws_bytes < cv.total * sizeof(float) || ((uintptr_t)ws % 256) != 0) return PT_ERR_WORKSPACE;
+    if (pend->iters < 2 || pend->iters > PT_SD_MAX_ITER) return PT_ERR_SHAPE;
+    float* base = (float*)ws;
+    const int CKK = C * K * K;
+    hipLaunchKernelGGL(k_fast_final, dim3(n), dim3(512), 0, st, (const float*)(w_iters + (long)(pend->iters - 1) * CKK),
+                       (const float*)(base + cv.g), filter, (const float*)(base + cv.qs), (const float*)(base + cv.anum), n, CKK, f.KSC,
+                       pend->step_length, pend->reg_eps);
+    PT_CHECK_LAUNCH();
     return PT_OK;
 }
 

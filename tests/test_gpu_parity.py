@@ -609,6 +609,86 @@ def test_bench_trajectory_closed_loop_60_frames():
     print("closed-loop worst errors over 60 frames:", worst)
 
 
+@pytest.mark.parametrize("kind,n,C", [("dimp", 50, 512), ("dimp", 16, 128), ("prdimp", 50, 512), ("dimp", 70, 256)])
+def test_frame_chain_deferred_last_update_is_bit_identical(kind, n, C):
+    """Frame chains (pt_track_frame_chain_f32, round 6): the solve's last filter update rides on the NEXT frame's first correlation
+    instead of being its own dependent launch.  Two identical sequences, one through pt_track_frame_f32, one through the chain with
+    every update deferred: classification scores, peak, re-centred boxes and memory BIT-EQUAL at every frame (the deferred update is
+    evaluated by the same expressions on the same operands), the filter bit-equal whenever the chain is flushed -- with frames of 5,
+    2, 1 (never deferred) and 0 iterations (classification-only frames consume a pending update as well) in the schedule; then the
+    chain captured into a hipGraph (the launch mode of bench.py) and replayed."""
+    from pytracking_amd import bench_frame
+    cfg = dict(synth.DIMP50 if kind == "dimp" else synth.PRDIMP50, C=C)
+    a = bench_frame.TrackState(cfg, n, seed=77, device=DEV, kind=kind)
+    b = bench_frame.TrackState(cfg, n, seed=77, device=DEV, kind=kind)
+    pool = T(synth.clf_features(np.random.default_rng(78), 24, C, cfg["H"], cfg["W"], cfg["K"]))
+    sched = [5, 5, 2, 0, 5, 1, 5, 0, 0, 3, 5, 5]
+    for f, nit in enumerate(sched):
+        a.step(pool[f], slot=(3 * f) % n, num_iter=nit)
+        b.step(pool[f], slot=(3 * f) % n, num_iter=nit, defer=True)
+        assert b.pending.iters == (nit if nit >= 2 else 0), (f, nit, b.pending.iters)
+        torch.cuda.synchronize()
+        assert torch.equal(a.scores, b.scores) and torch.equal(a.peak, b.peak) and torch.equal(a.mem_bb, b.mem_bb), f
+        assert torch.equal(a.mem_feat, b.mem_feat), f
+        if f % 4 == 3 or nit < 2:
+            b.flush()
+            assert b.pending.iters == 0
+            torch.cuda.synchronize()
+            assert torch.equal(a.filter, b.filter), f
+        elif nit >= 2:
+            assert not torch.equal(a.filter, b.filter), f        # the update really is pending: `filter` still holds w_0 of the solve
+    b.flush()
+    torch.cuda.synchronize()
+    assert torch.equal(a.filter, b.filter)
+    # graph replay of a deferred chain: 6 frames + the flush captured once, replayed twice from the same start state
+    f0, m0, b0 = a.filter.clone(), a.mem_feat.clone(), a.mem_bb.clone()
+    for f in range(6):
+        a.step(pool[12 + f], slot=f, num_iter=5)
+    torch.cuda.synchronize()
+    want = (a.filter.clone(), a.scores.clone(), a.mem_bb.clone())
+    stream = torch.cuda.Stream()
+    stream.wait_stream(torch.cuda.current_stream())
+    with torch.cuda.stream(stream):
+        g = torch.cuda.CUDAGraph()
+        with torch.cuda.graph(g, stream=stream):
+            for f in range(6):
+                b.step(pool[12 + f], slot=f, num_iter=5, defer=True)
+            b.flush()
+        for _ in range(2):
+            b.filter.copy_(f0); b.mem_feat.copy_(m0); b.mem_bb.copy_(b0)
+            g.replay()
+            stream.synchronize()
+            assert torch.equal(b.filter, want[0]) and torch.equal(b.scores, want[1]) and torch.equal(b.mem_bb, want[2])
+    torch.cuda.current_stream().wait_stream(stream)
+
+
+def test_frame_chain_argument_checks():
+    import ctypes
+    from pytracking_amd import _lib, bench_frame
+    L = _lib.lib()
+    pend = _lib.FramePending()
+    assert L.pt_track_frame_flush_f32(None, None, 1, 1, 1, 1, 1, None, 0, None) == _lib.PT_ERR_NULL
+    st = bench_frame.TrackState(dict(synth.DIMP50, C=128), 8, seed=1, device=DEV)
+    assert L.pt_track_frame_flush_f32(ctypes.byref(pend), st.filter.data_ptr(), 8, 128, 18, 18, 4, st.ws.data_ptr(), st.ws.numel(), None) == 0
+    pend.iters = -1
+    x = T(synth.clf_features(np.random.default_rng(2), 1, 128, 18, 18, 4))[0]
+    rc = L.pt_track_frame_chain_f32(ctypes.byref(st.params), st.filter.data_ptr(), st.mem_feat.data_ptr(), st.mem_bb.data_ptr(),
+                                    st.sample_weight.data_ptr(), x.data_ptr(), 0, 8, 128, 18, 18, 4, 2, st.scores.data_ptr(),
+                                    st.peak.data_ptr(), st.ws.data_ptr(), st.ws.numel(), ctypes.byref(pend), 1, None)
+    assert rc == _lib.PT_ERR_SHAPE
+    pend.iters = 1                                                 # a one-iteration solve is never pending
+    rc = L.pt_track_frame_chain_f32(ctypes.byref(st.params), st.filter.data_ptr(), st.mem_feat.data_ptr(), st.mem_bb.data_ptr(),
+                                    st.sample_weight.data_ptr(), x.data_ptr(), 0, 8, 128, 18, 18, 4, 2, st.scores.data_ptr(),
+                                    st.peak.data_ptr(), st.ws.data_ptr(), st.ws.numel(), ctypes.byref(pend), 1, None)
+    assert rc == _lib.PT_ERR_SHAPE
+    # a 3x3 filter is outside the chain's path: refused, and TrackState.step(defer=True) falls back to the plain frame
+    st3 = bench_frame.TrackState(dict(synth.DIMP50, C=64, K=3), 8, seed=1, device=DEV)
+    x3 = T(synth.clf_features(np.random.default_rng(2), 1, 64, 18, 18, 3))[0]
+    st3.step(x3, slot=1, num_iter=2, defer=True)
+    assert st3.pending.iters == 0
+    torch.cuda.synchronize()
+
+
 @pytest.mark.parametrize("n,C", [(34, 128), (64, 256), (35, 128), (40, 512)])
 def test_apply_filter_sample_pair_workgroups(n, C):
     """Round 4: with more than 32 samples (even count) the XCD-aligned correlation runs two samples per workgroup
@@ -1457,6 +1537,7 @@ def test_sd_multi_sequence_refuses_bad_side_streams_before_forking():
     """pt_sd_solve_batch_f32 validates EVERY auxiliary stream before it records the fork event: a null or repeated later entry returns
     PT_ERR_SHAPE with nothing queued on the earlier streams (sd_solver.hip; advisor finding of round 5)."""
     import ctypes
+    from pytracking_amd import _lib
     cfg = synth.DIMP50
     S, n, C = 3, 4, 64
     L = _lib.lib()
