@@ -165,6 +165,11 @@ def baselines(cfg, n, dev, want_cpu, want_gpu):
         else:
             gpu = stock_baseline(cfg, n, dev, budget_s=4.0, min_frames=50, impl="port")
         out["gpu_stock_baseline"] = gpu
+    # loud at the TOP level of the line: without the bundle every "reference"-kind figure silently becomes a "port" one
+    out["reference_bundle"] = "present" if ref else "ABSENT"
+    if not ref:
+        out["reference_unavailable"] = ("oracle/_ref/reference not found: cpu_baseline / gpu_stock_baseline are kind \"port\" "
+                                        "(python -B oracle/make_ref_bundle.py where /root/reference is mounted)")
     return out
 
 

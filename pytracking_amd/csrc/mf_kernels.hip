@@ -139,8 +139,6 @@ __global__ __launch_bounds__(128 * NPG) void k_mf_corr(const float* __restrict__
     const float inv_w = 1.0f / (float)g.W;
     const float* __restrict__ fi = feat + (long)i * stride_n;
 
-    for (int e = threadIdx.x; e < 2 * BUF; e += NT) lds[e] = 0.f;   // padding (and rows outside the image) stay zero
-
     // image rows [ys, ye) of the band + halo are contiguous in every channel plane
     const int ys = max(y0 - g.p, 0), ye = min(y0 + rows + g.p, g.H);
     MfStage<VW, NQ> sp;
@@ -279,6 +277,9 @@ __global__ __launch_bounds__(128 * NPG) void k_mf_corr(const float* __restrict__
 
     fetch_piece(0, 0);
     fetch_piece(0, 1);
+    // padding (and rows outside the image) stay zero; 16-byte stores, issued BEHIND the first loads so that the fill runs under their
+    // round trip (round 6: it used to be 2 BUF scalar stores in front of everything -- 27 per thread on the 12-wave head kernel)
+    for (int e = 4 * (int)threadIdx.x; e < 2 * BUF; e += 4 * NT) mf_lds_st4(lds + e, (f32x4){0.f, 0.f, 0.f, 0.f});
     __syncthreads();                                                // zero fill done
     stage_piece(0, 0);
     stage_piece(0, 1);

@@ -124,6 +124,45 @@ __device__ __forceinline__ void gemm_store(const GemmArgs& g, f32x4 (&acc)[MT][N
     }
 }
 
+// Epilogue for accumulators computed TRANSPOSED (the MFMA's operands swapped: accumulator rows <-> columns n of C, accumulator
+// columns <-> rows m of C), plain row-major C only.  Lane (kq, j) then holds, for tile row prow(j), the four columns prow(4 kq + r) --
+// {1,3,5,7} / {0,2,4,6} / {8,10,12,14} / {9,11,13,15} for kq = 0..3: the lane pairs (kq ^ 1, i.e. lane ^ 16) hold interleaved halves of
+// eight consecutive columns.  Two lane exchanges per accumulator turn them into FOUR CONSECUTIVE columns per lane, which leave as one
+// 16-byte store (gemm_store: sixteen 4-byte stores per 32 x 32 wave tile and lane; the FFN's first product writes 15.9 MB that way).
+// bias / ReLU / split-K offset as gemm_store; no residual, no affine, no exp, no row maps (the launcher checks).
+template <int MT, int NT>
+__device__ __forceinline__ void gemm_store_t(const GemmArgs& g, f32x4 (&acc)[MT][NT], int mrow0, int ncol0, int lane, int bz) {
+    const int kq = lane >> 4, j = lane & 15;
+    const bool low = (kq & 1) != 0;                                  // kq = 1, 3 keep their even columns and take the partner's odd ones below them
+    const int quarter = kq == 1 ? 0 : (kq == 0 ? 1 : kq);            // which 4-column group of the 16 this lane ends up with
+    const __amdgpu_buffer_rsrc_t rsC = pt_rsrc(g.C, 0xFFFFFFE0u);
+    const unsigned zoff = (unsigned)((long)bz * g.c_zstride * 4);
+#pragma unroll
+    for (int mt = 0; mt < MT; ++mt) {
+        const int row = mrow0 + mt * 16 + gemm_prow(j);
+        const unsigned rbase = row < g.M ? (unsigned)((long)row * g.ldc * 4) : OOB;
+#pragma unroll
+        for (int nt = 0; nt < NT; ++nt) {
+            const f32x4 a = acc[mt][nt];
+            // kq even (columns 1,3,5,7 of its eight): sends its first two, keeps the last two; kq odd (0,2,4,6): sends its last two
+            const float s0 = low ? a[2] : a[0], s1 = low ? a[3] : a[1];
+            const float r0 = __shfl_xor(s0, 16, 64), r1 = __shfl_xor(s1, 16, 64);
+            f32x4 v = low ? f32x4{a[0], r0, a[1], r1} : f32x4{r0, a[2], r1, a[3]};
+            const int col = ncol0 + nt * 16 + 4 * quarter;
+            if (g.bias && (g.batch || bz == 0)) {
+                const f32x4 bv = col + 3 < g.N ? *reinterpret_cast<const f32x4*>(g.bias + col) : f32x4{0.f, 0.f, 0.f, 0.f};
+                v += bv;
+            }
+            if (g.relu) {
+#pragma unroll
+                for (int e = 0; e < 4; ++e) v[e] = fmaxf(v[e], 0.f);
+            }
+            const unsigned off = (rbase != OOB && col + 3 < g.N) ? rbase + (unsigned)col * 4u + zoff : OOB;
+            __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(pt_u32x4, v), rsC, off, 0, 0);
+        }
+    }
+}
+
 // one workgroup tile of the problem `g`: (bxi, byi) tile coordinates in a grid of gx column tiles, bzi the split / batch index
 template <int BM, int BN, int MODE, int BK = 64>
 __device__ __forceinline__ void gemm_tile(const GemmArgs& g, const int bxi, const int byi, const int bzi, const int gx) {
@@ -482,6 +521,126 @@ __global__ __launch_bounds__(512) void k_gemm_big(GemmArgs g) {
     gemm_store<MT, NT>(g, acc, m0 + wm * WM, n0 + wn * WN, lane, blockIdx.z);
 }
 
+// ------------------------------------------------------------------------------------------------------------------
+// k_gemm_big's pinned schedule on other tile shapes (round 6): WGM x WGN wavefronts, each MT x NT MFMA fragments, tile
+// BM = 16 WGM MT by BN = 16 WGN NT, K stages of 32.  What it is for: a 128 x 128 workgroup of the ToMP FFN's first product
+// (K = 256: 8 stages) spends as long in its prologue (two memory round trips) and epilogue (16384 result stores) as in its K loop,
+// and with 256 such workgroups a CU holds ONE, so nothing hides them (24 us where the matrix pipe needs 13).  128 x 64 tiles
+// (4 x 2 waves of 32 x 32) make 512 workgroups of 55 KB LDS and <= 128 VGPRs: TWO per CU, each other's prologue / epilogue under
+// the other's MFMAs.  The same kernel with 4 K splits serves the second product (K = 2048: 256 workgroups x 16 stages).
+// TG: the M tile index is blockIdx.x (workgroups are dealt to the XCDs round-robin in x: all column tiles / K splits of a row tile
+// then share that XCD's L2 copy of the A slab -- the long-K product's A operand is 16 MB).
+// MODE 0 only (plain A).  K % 32 == 0.  Same LDS layout / fragment permutation / epilogue as k_gemm.
+// ------------------------------------------------------------------------------------------------------------------
+// SW: accumulators transposed (MFMA operands swapped) and stored with 16-byte stores (gemm_store_t; plain row-major C, N % 4 == 0).
+template <int WGM, int WGN, int MT, int NT, bool TG, bool SW = false>
+__global__ __launch_bounds__(64 * WGM * WGN) void k_gemm_ps(GemmArgs g) {
+    extern __shared__ __attribute__((aligned(16))) float gb_lds[];  // [2][STAGE]
+    constexpr int NTHR = 64 * WGM * WGN, WM = 16 * MT, WN = 16 * NT, BM = WGM * WM, BN = WGN * WN, LS = GB_LS;
+    constexpr int STAGE = (BM + BN) * LS, NP = (BM + BN) * 8 / NTHR, NPA = BM * 8 / NTHR;
+    static_assert((BM + BN) * 8 % NTHR == 0 && BM * 8 % NTHR == 0, "whole loader pieces per thread, A / W split on a piece boundary");
+    static_assert(MT + NT + 2 * NP <= 4 * MT * NT, "memory instructions of a stage fit behind its first sub-step's MFMAs");
+    const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6), wm = wave / WGN, wn = wave % WGN;
+    const int m0 = (TG ? blockIdx.x : blockIdx.y) * BM, n0 = (TG ? blockIdx.y : blockIdx.x) * BN;
+    const long zb = g.batch ? (long)blockIdx.z : 0;
+    const __amdgpu_buffer_rsrc_t rsA = pt_rsrc(g.A + zb * g.a_zstride, g.a_bytes), rsW = pt_rsrc(g.Wt + zb * g.w_zstride, g.w_bytes);
+    // "+pos" on the A operand of the leading column tiles (the q | k blocks of the attention's input projection), as k_gemm does it
+    const bool addpos = g.pos != nullptr && n0 < g.pos_cols;        // workgroup-uniform
+    const __amdgpu_buffer_rsrc_t rsP = pt_rsrc(addpos ? g.pos : g.A, addpos ? g.pos_bytes : 16u);
+    // loader: piece p = tid + NTHR k covers 16 bytes (k-quad p & 7) of tile row p >> 3; rows [0, BM) are A, [BM, BM + BN) are W
+    unsigned goff[NP], poff[NPA];
+    int lds_at[NP];
+#pragma unroll
+    for (int k = 0; k < NP; ++k) {
+        const int p = tid + NTHR * k, r = p >> 3, lc4 = (p & 7) * 4;
+        if (k < NPA) {
+            const int row = m0 + r;
+            goff[k] = row < g.M ? (unsigned)(((long)row * g.lda + lc4) * 4) : OOB;
+            poff[k] = (addpos && row < g.M) ? (unsigned)(((long)((row % g.L) % g.HW) * g.K + lc4) * 4) : OOB;
+        } else {
+            const int n = n0 + r - BM;
+            goff[k] = n < g.N ? (unsigned)(((long)n * g.K + lc4) * 4) : OOB;
+        }
+        lds_at[k] = r * LS + lc4;
+    }
+    const int nst_all = g.K / 32;
+    const int s0 = g.ksteps ? blockIdx.z * g.ksteps * 2 : 0;       // g.ksteps counts 64-wide steps
+    const int nst = (g.ksteps ? min(nst_all, s0 + g.ksteps * 2) : nst_all) - s0;
+    f32x4 rr[NP], rp[NPA];
+    auto fetch_one = [&](int st, int k) {                           // past the end: the last stage again (never consumed)
+        const unsigned kbytes = (unsigned)(s0 + min(st, nst - 1)) * 128u;
+        rr[k] = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(k < NPA ? rsA : rsW, goff[k], kbytes, 0));
+        if (k < NPA && addpos) rp[k < NPA ? k : 0] = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(rsP, poff[k < NPA ? k : 0], kbytes, 0));
+    };
+    auto stash_one = [&](int buf, int k) {
+        f32x4 v = rr[k];
+        if (k < NPA && addpos) v += rp[k < NPA ? k : 0];
+        *reinterpret_cast<f32x4*>(__builtin_assume_aligned(gb_lds + buf * STAGE + lds_at[k], 16)) = v;
+    };
+    const int qoff = ((lane >> 4) & 1) * 2 + (lane >> 5);
+    const int aso = (wm * WM + gemm_prow(lane & 15)) * LS + qoff * 4;
+    const int bso = BM * LS + (wn * WN + gemm_prow(lane & 15)) * LS + qoff * 4;
+    f32x4 fa[2][MT], fb[2][NT];
+    auto frag_one = [&](int buf, int hh, int set, int k) {          // k < MT: A fragment k, else W fragment k - MT
+        const float* base = gb_lds + buf * STAGE + hh * 16;
+        if (k < MT) fa[set][k] = *reinterpret_cast<const f32x4*>(__builtin_assume_aligned(base + aso + k * 16 * LS, 16));
+        else fb[set][k - MT] = *reinterpret_cast<const f32x4*>(__builtin_assume_aligned(base + bso + (k - MT) * 16 * LS, 16));
+    };
+    f32x4 acc[MT][NT];
+#pragma unroll
+    for (int a = 0; a < MT; ++a)
+#pragma unroll
+        for (int b = 0; b < NT; ++b) acc[a][b] = f32x4{0.f, 0.f, 0.f, 0.f};
+    auto substep = [&](int set, auto&& mem) {
+#pragma unroll
+        for (int j = 0; j < 4; ++j)
+#pragma unroll
+            for (int mt = 0; mt < MT; ++mt)
+#pragma unroll
+                for (int nt = 0; nt < NT; ++nt) {
+                    acc[mt][nt] = SW ? mfma16(fb[set][nt][j], fa[set][mt][j], acc[mt][nt]) : mfma16(fa[set][mt][j], fb[set][nt][j], acc[mt][nt]);
+                    __builtin_amdgcn_sched_barrier(0);
+                    mem((j * MT + mt) * NT + nt);
+                    __builtin_amdgcn_sched_barrier(0);
+                }
+    };
+    if (nst > 0) {
+        {   // stages 0 and 1 requested together: one exposed memory round trip in front of the first MFMA
+            f32x4 p0[NP];
+#pragma unroll
+            for (int k = 0; k < NP; ++k) fetch_one(0, k);
+#pragma unroll
+            for (int k = 0; k < NP; ++k) { p0[k] = rr[k]; if (k < NPA && addpos) p0[k] += rp[k < NPA ? k : 0]; }
+#pragma unroll
+            for (int k = 0; k < NP; ++k) fetch_one(1, k);
+#pragma unroll
+            for (int k = 0; k < NP; ++k) *reinterpret_cast<f32x4*>(__builtin_assume_aligned(gb_lds + lds_at[k], 16)) = p0[k];
+        }
+        __syncthreads();
+#pragma unroll
+        for (int k = 0; k < MT + NT; ++k) frag_one(0, 0, 0, k);
+        __builtin_amdgcn_sched_barrier(0);
+        for (int st = 0; st < nst; st += 2) {
+#pragma unroll
+            for (int h = 0; h < 2; ++h) {
+                const int s = st + h;                               // buffer h
+                if (h == 1 && s >= nst) break;
+                substep(0, [&](int i) {
+                    if (i < MT + NT) frag_one(h, 1, 1, i);                          // fragments of this stage's second sub-step
+                    else if (i < MT + NT + NP) stash_one(h ^ 1, i - (MT + NT));     // stage s+1 -> the other buffer
+                    else if (i < MT + NT + 2 * NP) fetch_one(s + 2, i - (MT + NT + NP));   // stage s+2 -> registers
+                });
+                __syncthreads();
+                substep(1, [&](int i) {
+                    if (i < MT + NT) frag_one(h ^ 1, 0, 0, i);                      // first fragments of stage s+1
+                });
+            }
+        }
+    }
+    if (SW) gemm_store_t<MT, NT>(g, acc, m0 + wm * WM, n0 + wn * WN, lane, blockIdx.z);
+    else gemm_store<MT, NT>(g, acc, m0 + wm * WM, n0 + wn * WN, lane, blockIdx.z);
+}
+
 GemmArgs gemm_args(const float* A, long lda, long a_rows, const float* Wt, int M, int N, int K, const float* bias,
                    float* C, long ldc) {
     GemmArgs g{};
@@ -511,6 +670,14 @@ static int pt_gemm_longk_tile() {
     return v;
 }
 
+// gemm_store_t's conditions: plain row-major C, 16-byte aligned rows and bias, nothing but bias / ReLU / split offset in the epilogue
+// (PT_GEMM_WIDE_STORE=0: the 4-byte epilogue, A/B knob)
+static bool wide_store_ok(const GemmArgs& g) {
+    static const bool on = [] { const char* e = getenv("PT_GEMM_WIDE_STORE"); return !(e && e[0] == '0'); }();
+    return on && !g.R && !g.scale && !g.shift && !g.expo && !g.nchw && g.c_segstride == 0 && g.N % 4 == 0 && g.ldc % 4 == 0 && g.c_zstride % 4 == 0 &&
+           ((uintptr_t)g.C % 16) == 0 && (!g.bias || ((uintptr_t)g.bias % 16) == 0);
+}
+
 int launch_gemm(const GemmArgs& g, hipStream_t st, bool conv = false) {
     // K % 4: a loader thread fetches 4 consecutive k (16 bytes); quads past K are not requested at all (zeros)
     if (g.K % 4 != 0 || (conv && g.K % 32 != 0) || g.M <= 0 || g.N <= 0 || (g.batch && g.ksteps)) return PT_ERR_UNSUPPORTED;
@@ -519,6 +686,31 @@ int launch_gemm(const GemmArgs& g, hipStream_t st, bool conv = false) {
     const long rows = g.nchw ? (long)g.M * g.N : (g.c_segstride ? ((long)(g.M / g.c_seg) + 1) * g.c_segstride * g.ldc
                                                                    : (long)g.M * g.ldc);
     if ((rows + (long)(nz - 1) * g.c_zstride) * 4 >= 0xFFFFFFE0L) return PT_ERR_UNSUPPORTED;
+    // round 6: 128 x 64 tiles, two workgroups per CU (PT_GEMM_PS=0: the round-5 routes), for
+    //   * wide outputs at short K (FFN first product: N = 2048, K = 256 -> 512 workgroups of 8 stages)
+    //   * split-K products the caller asked to be cut in >= 4 (FFN second product: 256 workgroups of 16 stages, M tiles on x)
+    static const bool ps_on = [] { const char* e = getenv("PT_GEMM_PS"); return !(e && e[0] == '0'); }();
+    static const bool ps_qkv = [] { const char* e = getenv("PT_GEMM_PS_QKV"); return !(e && e[0] == '0'); }();
+    if (ps_on && ps_qkv && !conv && g.pos && g.M >= 1024 && g.K % 32 == 0 && !g.batch && !g.nchw && nz == 1 && g.N % 64 == 0 && g.pos_cols % 64 == 0 &&
+        g.c_segstride == 0 && g.N >= 512) {
+        // the attention's input projection (N = 3 D = 768, K = 256, "+pos" on the q | k column tiles): 64 x 64 tiles of 4 waves, 37 KB LDS,
+        // up to four workgroups per CU; the 32 x 32 route took 16.2 us for 0.76 GFLOP (1464 workgroups = 1.45 rounds)
+        constexpr size_t lds = 2 * (64 + 64) * GB_LS * sizeof(float);
+        if (wide_store_ok(g)) hipLaunchKernelGGL((k_gemm_ps<2, 2, 2, 2, false, true>), dim3((g.N + 63) / 64, (g.M + 63) / 64, 1), dim3(256), lds, st, g);
+        else hipLaunchKernelGGL((k_gemm_ps<2, 2, 2, 2, false>), dim3((g.N + 63) / 64, (g.M + 63) / 64, 1), dim3(256), lds, st, g);
+        PT_CHECK_LAUNCH();
+        return PT_OK;
+    }
+    if (ps_on && !conv && g.M >= 1024 && g.K % 32 == 0 && !g.pos && !g.batch && !g.nchw && ((g.N >= 1024 && nz == 1) || (nz >= 4 && g.N % 64 == 0))) {
+        constexpr size_t lds = 2 * (128 + 64) * GB_LS * sizeof(float);
+        const bool sw = wide_store_ok(g);
+        if (nz == 1 && sw) hipLaunchKernelGGL((k_gemm_ps<4, 2, 2, 2, false, true>), dim3((g.N + 63) / 64, (g.M + 127) / 128, 1), dim3(512), lds, st, g);
+        else if (nz == 1) hipLaunchKernelGGL((k_gemm_ps<4, 2, 2, 2, false>), dim3((g.N + 63) / 64, (g.M + 127) / 128, 1), dim3(512), lds, st, g);
+        else if (sw) hipLaunchKernelGGL((k_gemm_ps<4, 2, 2, 2, true, true>), dim3((g.M + 127) / 128, (g.N + 63) / 64, nz), dim3(512), lds, st, g);
+        else hipLaunchKernelGGL((k_gemm_ps<4, 2, 2, 2, true>), dim3((g.M + 127) / 128, (g.N + 63) / 64, nz), dim3(512), lds, st, g);
+        PT_CHECK_LAUNCH();
+        return PT_OK;
+    }
     if (!conv && g.N >= 1024 && g.M >= 1024 && g.K % 32 == 0 && !g.pos && !g.batch) {
         hipLaunchKernelGGL(k_gemm_big, dim3((g.N + 127) / 128, (g.M + 127) / 128, nz), dim3(512), 2 * GB_STAGE * sizeof(float),
                            st, g);

@@ -238,7 +238,8 @@ __global__ __launch_bounds__(512) void k_attn(AttnArgs a) {
 template <int PER>
 __global__ __launch_bounds__(256) void k_ln_rows_t(const float* in, float* out, const float* __restrict__ gam,
                                                    const float* __restrict__ bet, int rows, const float* in2 = nullptr,
-                                                   const float* in3 = nullptr, const float* gam2 = nullptr, const float* bet2 = nullptr) {
+                                                   const float* in3 = nullptr, const float* gam2 = nullptr, const float* bet2 = nullptr,
+                                                   const float* in4 = nullptr, const float* in5 = nullptr) {
     constexpr int D = 64 * PER;
     const int row = blockIdx.x * 4 + (threadIdx.x >> 6), lane = threadIdx.x & 63;
     if (row >= rows) return;
@@ -247,11 +248,15 @@ __global__ __launch_bounds__(256) void k_ln_rows_t(const float* in, float* out, 
     const float* src = in + ro;
     if (PER == 4) {
         const f32x4 t = *(const f32x4*)src, tg = *(const f32x4*)(gam + lane * 4), tb = *(const f32x4*)(bet + lane * 4);
-        f32x4 t2 = {0, 0, 0, 0}, t3 = {0, 0, 0, 0};
+        f32x4 t2 = {0, 0, 0, 0}, t3 = {0, 0, 0, 0}, t4 = {0, 0, 0, 0}, t5 = {0, 0, 0, 0};
         if (in2) t2 = *(const f32x4*)(in2 + ro);                     // uniform branches: all loads requested together
         if (in3) t3 = *(const f32x4*)(in3 + ro);
+        if (in4) { t4 = *(const f32x4*)(in4 + ro); t5 = *(const f32x4*)(in5 + ro); }   // splits 3 and 4 of a four-way split-K product (both or neither)
 #pragma unroll
-        for (int i = 0; i < 4; ++i) { v[i] = in2 ? (t[i] + t2[i]) + t3[i] : t[i]; g[i] = tg[i]; b[i] = tb[i]; }
+        for (int i = 0; i < 4; ++i) {
+            v[i] = in4 ? (((t[i] + t2[i]) + t4[i]) + t5[i]) + t3[i] : (in2 ? (t[i] + t2[i]) + t3[i] : t[i]);
+            g[i] = tg[i]; b[i] = tb[i];
+        }
     } else {
 #pragma unroll
         for (int i = 0; i < PER; ++i) {
@@ -318,7 +323,7 @@ __global__ __launch_bounds__(256) void k_ln_rows(const float* in, float* out, co
 // (which then also adds the residual): 976 instead of 488 workgroups of half the K loop, ToMP frame 1.006 -> 0.996 ms (round 4,
 // profiles/r04e_*).  PT_TOMP_FFN2_SPLIT=0 restores the single product (A/B knob).
 static int pt_tomp_ffn2_split() {
-    static const int v = [] { const char* e = getenv("PT_TOMP_FFN2_SPLIT"); return e ? atoi(e) : 2; }();
+    static const int v = [] { const char* e = getenv("PT_TOMP_FFN2_SPLIT"); return e ? atoi(e) : 4; }();   // round 6: 4 (k_gemm_ps); 2 = round 4's halves
     return v;
 }
 
@@ -331,12 +336,14 @@ static bool ln_rows_wide_ok(const float* in, const float* out, const float* gam,
 // kernel cannot be used: dropping in2 / in3 / the second norm silently would lose the split-K half, the residual or a LayerNorm.
 static int launch_ln_rows(const float* in, float* out, const float* gam, const float* bet, int rows, int D, hipStream_t st,
                           const float* in2 = nullptr, const float* in3 = nullptr, const float* gam2 = nullptr,
-                          const float* bet2 = nullptr) {
+                          const float* bet2 = nullptr, const float* in4 = nullptr, const float* in5 = nullptr) {
     const dim3 grid((rows + 3) / 4), block(256);
     const bool al = ((uintptr_t)in % 16 == 0) && ((uintptr_t)out % 16 == 0) && ((uintptr_t)gam % 16 == 0) && ((uintptr_t)bet % 16 == 0) &&
-                    ((uintptr_t)in2 % 16 == 0) && ((uintptr_t)in3 % 16 == 0) && ((uintptr_t)gam2 % 16 == 0) && ((uintptr_t)bet2 % 16 == 0);
-    if (!(D == 256 && al) && (in2 || in3 || gam2 || bet2)) return PT_ERR_UNSUPPORTED;
-    if (D == 256 && al) hipLaunchKernelGGL(k_ln_rows_t<4>, grid, block, 0, st, in, out, gam, bet, rows, in2, in3, gam2, bet2);
+                    ((uintptr_t)in2 % 16 == 0) && ((uintptr_t)in3 % 16 == 0) && ((uintptr_t)gam2 % 16 == 0) && ((uintptr_t)bet2 % 16 == 0) &&
+                    ((uintptr_t)in4 % 16 == 0) && ((uintptr_t)in5 % 16 == 0);
+    if (!(D == 256 && al) && (in2 || in3 || gam2 || bet2 || in4 || in5)) return PT_ERR_UNSUPPORTED;
+    if ((in4 == nullptr) != (in5 == nullptr) || (in4 && !in2)) return PT_ERR_UNSUPPORTED;
+    if (D == 256 && al) hipLaunchKernelGGL(k_ln_rows_t<4>, grid, block, 0, st, in, out, gam, bet, rows, in2, in3, gam2, bet2, in4, in5);
     else if (D == 128) hipLaunchKernelGGL(k_ln_rows_t<2>, grid, block, 0, st, in, out, gam, bet, rows);
     else if (D == 64) hipLaunchKernelGGL(k_ln_rows_t<1>, grid, block, 0, st, in, out, gam, bet, rows);
     else hipLaunchKernelGGL(k_ln_rows, grid, block, 0, st, in, out, gam, bet, rows, D);
@@ -1344,6 +1351,18 @@ extern "C" int pt_tomp_predict_f32(const pt_tomp_dims* d, const float* params, c
         g = gemm_args(X, D, rows, P + e.w1, rows, ff, D, P + e.b1, Hd, ff);
         g.relu = 1;
         if ((rc = launch_gemm(g, st))) return rc;
+        const long rD = (long)rows * D;
+        if (pt_tomp_ffn2_split() == 4 && (ff / 64) % 4 == 0 && rows >= 1024 && D % 64 == 0 && cv.AO == cv.QKV + 3 * (size_t)rD &&
+            ln_rows_wide_ok(QKV, X, P + e.n2g, P + e.n2b, D)) {
+            // round 6: four K-quarters on 128 x 64 tiles (k_gemm_ps: 256 workgroups x 16 stages, M tiles on x) into the four row blocks
+            // QKV[0..2], AO -- all free here -- that meet, with the residual, in the LayerNorm
+            g = gemm_args(Hd, ff, rows, P + e.w2, rows, D, ff, P + e.b2, QKV, D);
+            g.ksteps = ff / 64 / 4; g.c_zstride = rD;
+            if ((rc = launch_gemm(g, st))) return rc;
+            if ((rc = launch_ln_rows(QKV, X, P + e.n2g, P + e.n2b, rows, D, st, QKV + rD, X, nullptr, nullptr, QKV + 2 * rD, AO))) return rc;
+            PT_CHECK_LAUNCH();
+            continue;
+        }
         if (pt_tomp_ffn2_split() == 2 && (ff / 64) % 2 == 0 && cv.Y > cv.AO && ln_rows_wide_ok(AO, X, P + e.n2g, P + e.n2b, D)) {
             g = gemm_args(Hd, ff, rows, P + e.w2, rows, D, ff, P + e.b2, AO, D);
             g.ksteps = ff / 64 / 2; g.c_zstride = (long)(cv.Y - cv.AO);          // halves -> AO, Y (bias rides on the first)

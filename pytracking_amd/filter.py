@@ -274,6 +274,10 @@ def apply_filter(feat, filter, dilation_factors=None):
         assert filter.shape[0] == num_sequences and feat.shape[-3] == filter.shape[-3], "groups != 1 is not covered"
         return _ApplyFilterMF.apply(feat, filter)
     assert filter.shape[0] == num_sequences and feat.shape[-3] == filter.shape[-3]
+    if num_sequences == 1 and not (torch.is_grad_enabled() and (feat.requires_grad or filter.requires_grad)):
+        # tracking time (one sequence, nothing to differentiate): straight to the kernel -- no autograd.Function frame, no torch.stack
+        # (profiles/r06_installed_track_breakdown.txt: this wrapper was the largest host item of ours in an installed track())
+        return corr_raw(_as5d(feat)[:, 0], filter[0]).unsqueeze(1)
     return _ApplyFilter.apply(feat, filter)
 
 
@@ -287,6 +291,8 @@ def apply_feat_transpose(feat, input, filter_ksz, training=True, groups=1):
         filter_ksz = (filter_ksz, filter_ksz)
     if input.dim() == 5:                                    # (images, sequences, filters, H, W), filter.py:158-176
         return _ApplyFeatTransposeMF.apply(feat, input, tuple(filter_ksz))
+    if (feat.dim() == 4 or feat.shape[1] == 1) and not (torch.is_grad_enabled() and (feat.requires_grad or input.requires_grad)):
+        return adj_raw(_as5d(feat)[:, 0], input[:, 0], tuple(filter_ksz)).unsqueeze(0)
     return _ApplyFeatTranspose.apply(feat, input, tuple(filter_ksz))
 
 

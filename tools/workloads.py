@@ -96,9 +96,13 @@ def atom_cg(dev, reps=50):
     dt = _timed(lambda: opt.run(c["cg_iter"]), reps)
     passes = 2 * c["cg_iter"] + 2
     byts = passes * 4.0 * n * c["C"] * c["H"] * c["W"]
+    byts_8d = 2 * c["cg_iter"] * 4.0 * n * c["C"] * c["H"] * c["W"]     # 2 feature reads per CG iteration, nothing for the linearisation
     return {"workload": f"ATOM ConvProblem CG update n={n} C=64 18x18 K=4, {c['cg_iter']} iterations ({passes} feature passes)",
             "ms": round(dt * 1e3, 5), "updates_per_s": round(1 / dt, 1), "bound": "hbm", "algorithmic_bytes": byts,
-            "achieved_GBs": round(byts / dt / 1e9, 1), "frac": round(byts / dt / HBM_PEAK, 4)}
+            "achieved_GBs": round(byts / dt / 1e9, 1), "frac": round(byts / dt / HBM_PEAK, 4),
+            "survey_8d_count": {"algorithmic_bytes": byts_8d, "achieved_GBs": round(byts_8d / dt / 1e9, 1), "frac": round(byts_8d / dt / HBM_PEAK, 4),
+                                "note": "SURVEY.md 8(d) counts 2 x 4 n C H W bytes per CG iteration x 5 (the two passes of the "
+                                        "linearisation are not in it); `frac` above counts the 12 passes the update really makes"}}
 
 
 def atom_first_frame(dev, reps=5):
