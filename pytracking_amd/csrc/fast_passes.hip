@@ -30,7 +30,7 @@ typedef float f32x2a4 __attribute__((ext_vector_type(2), aligned(4)));   // 8-by
 #define PT_ADJ_UMAX (128 / PT_ADJ_WAVES)   // 16-position groups per wave of the common instantiations
 #endif
 // 22x22 / 23x23 maps (PrDiMP-50: E == 9): up to 24 groups per wave, so that n = 50 is EIGHT position slices = 256 workgroups, one
-// per CU, instead of sixteen = 512 (round 4: k_adj2 15.1 -> see DESIGN section 7; the correlation's prologue then sums 8 gradient
+// per CU, instead of sixteen = 512 (round 4: k_adj2 15.1 -> see profiles/HISTORY.md section 7; the correlation's prologue then sums 8 gradient
 // partials instead of 16).  The loads are pipelined PD groups ahead, so the register cost of a longer run is the unrolled loop only.
 #ifndef PT_ADJ_UMAX_WIDE
 #define PT_ADJ_UMAX_WIDE (192 / PT_ADJ_WAVES)

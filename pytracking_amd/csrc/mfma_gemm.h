@@ -13,6 +13,7 @@
 namespace {
 
 constexpr unsigned OOB = 0xFFFFFFF0u;      // raw buffer loads past num_records return 0
+typedef unsigned pt_u32x4 __attribute__((ext_vector_type(4)));
 
 // ------------------------------------------------------------------------------------------------------------------
 // generic NT GEMM on MFMA
@@ -133,7 +134,7 @@ __device__ __forceinline__ void gemm_store(const GemmArgs& g, f32x4 (&acc)[MT][N
 template <int MT, int NT>
 __device__ __forceinline__ void gemm_store_t(const GemmArgs& g, f32x4 (&acc)[MT][NT], int mrow0, int ncol0, int lane, int bz) {
     const int kq = lane >> 4, j = lane & 15;
-    const bool low = (kq & 1) != 0;                                  // kq = 1, 3 keep their even columns and take the partner's odd ones below them
+    const bool low = kq == 1 || kq == 2;                             // holds the EVEN columns of its eight: takes the lower four (partner: odd, upper four)
     const int quarter = kq == 1 ? 0 : (kq == 0 ? 1 : kq);            // which 4-column group of the 16 this lane ends up with
     const __amdgpu_buffer_rsrc_t rsC = pt_rsrc(g.C, 0xFFFFFFE0u);
     const unsigned zoff = (unsigned)((long)bz * g.c_zstride * 4);
@@ -144,7 +145,7 @@ __device__ __forceinline__ void gemm_store_t(const GemmArgs& g, f32x4 (&acc)[MT]
 #pragma unroll
         for (int nt = 0; nt < NT; ++nt) {
             const f32x4 a = acc[mt][nt];
-            // kq even (columns 1,3,5,7 of its eight): sends its first two, keeps the last two; kq odd (0,2,4,6): sends its last two
+            // even-column holder (kq = 1, 2): keeps e0, e1, sends e2, e3, receives o0, o1; odd-column holder (kq = 0, 3): the mirror image
             const float s0 = low ? a[2] : a[0], s1 = low ? a[3] : a[1];
             const float r0 = __shfl_xor(s0, 16, 64), r1 = __shfl_xor(s1, 16, 64);
             f32x4 v = low ? f32x4{a[0], r0, a[1], r1} : f32x4{r0, a[2], r1, a[3]};

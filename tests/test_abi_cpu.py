@@ -295,3 +295,43 @@ def test_round5_entry_points_argument_checks(L):
     assert L.pt_stream_probe_f32(one, 2, one, 1, n) == _lib.PT_ERR_SHAPE
     assert L.pt_stream_probe_f32(ctypes.c_void_p(260), 1024, one, 1, n) == _lib.PT_ERR_SHAPE   # not 16-byte aligned
     L.pt_host_buffer_forget(one)                                                                 # unknown pointer: no-op
+
+
+def test_round6_entry_points_argument_checks(L):
+    """Frame chains (pt_track_frame_chain_f32 / pt_track_frame_flush_f32), the two-stream acknowledgement of the one-call frame and the
+    up-front refinement checks refuse bad arguments before anything is queued (no GPU here)."""
+    n = None
+    one = ctypes.c_void_p(256)
+    sd = _lib.SdParams()
+    pend = _lib.FramePending()
+    # flush: nulls, nothing pending, bad shapes, workspace, iteration counts that can never be pending
+    assert L.pt_track_frame_flush_f32(None, one, 50, 512, 18, 18, 4, one, 1 << 30, n) == _lib.PT_ERR_NULL
+    assert L.pt_track_frame_flush_f32(ctypes.byref(pend), None, 50, 512, 18, 18, 4, one, 1 << 30, n) == _lib.PT_ERR_NULL
+    assert L.pt_track_frame_flush_f32(ctypes.byref(pend), one, 50, 512, 18, 18, 4, one, 1 << 30, n) == 0            # iters == 0: no-op
+    pend.iters = 5
+    assert L.pt_track_frame_flush_f32(ctypes.byref(pend), one, 0, 512, 18, 18, 4, one, 1 << 30, n) == _lib.PT_ERR_SHAPE
+    assert L.pt_track_frame_flush_f32(ctypes.byref(pend), one, 50, 512, 18, 18, 4, one, 16, n) == _lib.PT_ERR_WORKSPACE
+    pend.iters = 1
+    assert L.pt_track_frame_flush_f32(ctypes.byref(pend), one, 50, 512, 18, 18, 4, one, 1 << 30, n) == _lib.PT_ERR_SHAPE
+    pend.iters = 65
+    assert L.pt_track_frame_flush_f32(ctypes.byref(pend), one, 50, 512, 18, 18, 4, one, 1 << 30, n) == _lib.PT_ERR_SHAPE
+    # chain: the pending block is mandatory, its count cannot be negative; the frame's own checks come next
+    args = [ctypes.byref(sd), one, one, one, None, one, 0, 50, 512, 18, 18, 4, 5, one, one, one, 1 << 30]
+    assert L.pt_track_frame_chain_f32(*args, None, 1, n) == _lib.PT_ERR_NULL
+    pend.iters = -1
+    assert L.pt_track_frame_chain_f32(*args, ctypes.byref(pend), 1, n) == _lib.PT_ERR_SHAPE
+    pend.iters = 0
+    bad = list(args); bad[6] = 50                                                                              # slot == n
+    assert L.pt_track_frame_chain_f32(*bad, ctypes.byref(pend), 1, n) == _lib.PT_ERR_SHAPE
+    bad = list(args); bad[16] = 16                                                                             # workspace too small
+    assert L.pt_track_frame_chain_f32(*bad, ctypes.byref(pend), 1, n) == _lib.PT_ERR_WORKSPACE
+    # one-call frame: two streams + an update need the caller's acknowledgement; refinement arguments are checked before the head is queued
+    f = _lib.FrameFull()
+    loc, glue, dims = _lib.LocalizeState(), _lib.FrameGlue(), _lib.IouDims(256, 256, 256, 256, 36, 36, 18, 18)
+    f.sd, f.loc, f.glue, f.iou_dims = ctypes.pointer(sd), ctypes.pointer(loc), ctypes.pointer(glue), ctypes.pointer(dims)
+    f.n, f.Cin, f.C, f.H, f.W, f.K, f.num_iter = 50, 1024, 512, 18, 18, 4, 5
+    glue.num_random = 9
+    f.scores_out = 256
+    f.aux_stream, f.aux_reordered_update_ok = 512, 0
+    assert L.pt_track_frame_full_launch_f32(ctypes.byref(f), one, one, 1 << 30, n) == _lib.PT_ERR_UNSUPPORTED
+    assert ctypes.sizeof(_lib.FramePending) == 12 and _lib.FrameFull.aux_reordered_update_ok.offset == _lib.FrameFull.aux_stream.offset + 8

@@ -1341,7 +1341,7 @@ def test_iou_refinement_deployed_size_unfused_route(tag):
 def test_track_frame_is_deterministic_under_repeated_launches():
     """Determinism under cache churn: every reduction of the frame (score-map slices, gradient partials, per-sample
     curvature terms) is summed in a fixed order by a fixed owner, and kernels hand data to each other only across launch
-    boundaries (the in-launch hand-offs tried in round 2 were reverted) -- so 300 frames from identical
+    boundaries (the in-launch hand-offs tried in round 2 were reverted, profiles/HISTORY.md section 8) -- so 300 frames from identical
     state must give bit-identical filters, scores and boxes every time, whatever ran in between."""
     from pytracking_amd import bench_frame
     cfg = synth.DIMP50

@@ -72,7 +72,7 @@ def test_fused_iou_kernels_keep_their_state_in_registers(iou):
 
 def test_pass_kernels_have_no_scratch_and_admit_two_workgroups_per_cu(passes):
     """Every instantiation of the two solver passes: no scratch; the correlation runs 400 workgroups of <= 10 waves on 256 CUs, i.e. two
-    co-resident workgroups on most CUs -- that needs >= 5 waves per SIMD by registers."""
+    co-resident workgroups on most CUs (profiles/HISTORY.md section 7) -- that needs >= 5 waves per SIMD by registers."""
     corr, adj = _pick(passes, "k_corr2"), _pick(passes, "k_adj2")
     assert len(corr) >= 8 and len(adj) >= 8
     for k, v in {**corr, **adj}.items():

@@ -42,8 +42,9 @@ def sd_frame(dev, kind="prdimp", frames=100, graph_frames=25, num_iter=5):
         stream.synchronize()
         g = torch.cuda.CUDAGraph()
         with torch.cuda.graph(g, stream=stream):
-            for f in range(graph_frames):
-                st.step(pool[f % n], f % n, num_iter)
+            for f in range(graph_frames):                       # a frame chain that ends with its flush, like bench.run_frames
+                st.step(pool[f % n], f % n, num_iter, defer=True)
+            st.flush()
         g.replay()
         stream.synchronize()
         reps = max(1, frames // graph_frames)
@@ -55,7 +56,7 @@ def sd_frame(dev, kind="prdimp", frames=100, graph_frames=25, num_iter=5):
     byts = st.bytes_per_solve(num_iter)
     name = "PrDiMP-50" if kind == "prdimp" else "DiMP-50"
     return {"workload": f"{name} frame: classify + arg-max + insert + {num_iter} SD iterations over n={n}x{cfg['C']}x{cfg['H']}x{cfg['W']}, K=4 "
-                        f"(hipGraph, {graph_frames} frames per graph)",
+                        f"(hipGraph, {graph_frames} frames per graph, frame chain + flush)",
             "ms": round(dt * 1e3, 5), "frames_per_s": round(1 / dt, 1), "bound": "hbm", "algorithmic_bytes": byts,
             "achieved_GBs": round(byts / dt / 1e9, 1), "frac": round(byts / dt / HBM_PEAK, 4)}
 
