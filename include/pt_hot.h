@@ -476,11 +476,26 @@ typedef struct pt_frame_full {
      * (PT_ERR_UNSUPPORTED, nothing queued) unless aux_reordered_update_ok is non-zero. */
     void* aux_stream;
     int aux_reordered_update_ok;
+    /* Graph replay (round 6).  A captured frame freezes every kernel ARGUMENT; with dyn != NULL (device memory, 16-byte aligned,
+     * pt_track_frame_full_dyn_bytes() bytes) the per-frame VALUES -- the memory slot, the tracker state of the localisation and of the
+     * glue (pos, target_sz, sample position / scale, thresholds), this frame's random numbers, the sequence number -- are read by the
+     * kernels from that block instead, and the captured launches depend on pointers and shapes only.  Per frame the host writes the
+     * block with pt_track_frame_full_dyn_fill_f32 into pinned memory, a copy node at the head of the graph moves it to `dyn`, the graph
+     * is replayed and pt_host_wait_word_f32(out + 127, seq) waits for the result block.  Pointers (backbone_feat, c3, c4, mod3 / mod4,
+     * scores_out, the result block, the workspace) are those of the capture: the caller's backbone writes into fixed buffers.  One
+     * stream only (aux_stream must be NULL); num_iter / iou_iter / the proposal count are properties of the captured graph. */
+    void* dyn;
 } pt_frame_full;
 size_t pt_track_frame_full_ws_bytes(const pt_frame_full* f);
 int pt_track_frame_full_f32(const pt_frame_full* f, float* out_host, void* ws, size_t ws_bytes, void* stream);
 /* the launches without the wait (graph capture, or a caller that waits on the stream itself) */
 int pt_track_frame_full_launch_f32(const pt_frame_full* f, float* out, void* ws, size_t ws_bytes, void* stream);
+/* graph replay: size of the per-frame block, and its host-side fill for the frame described by *f (slot, loc, glue; seq != 0) --
+ * `out` / `ws` as captured; `dyn_host`: pinned host memory the graph's copy node reads.  Nothing is queued. */
+size_t pt_track_frame_full_dyn_bytes(void);
+int pt_track_frame_full_dyn_fill_f32(const pt_frame_full* f, float seq, float* out, void* ws, size_t ws_bytes, void* dyn_host);
+/* wait until *word == seq (a result block's sequence word in pinned host memory; polled, falls back to hipStreamSynchronize after 2 s) */
+int pt_host_wait_word_f32(const float* word, float seq, void* stream);
 
 /* Measurement helper (bench.py): `reps` back-to-back launches of a kernel that only READS `floats` floats of `mem` (16-byte aligned)
  * with every CU -- the streaming floor of one feature pass over that footprint.  scratch2048: 2048 floats of device memory. */

@@ -91,6 +91,7 @@ EXPORTS = [
     "pt_iou_param_floats", "pt_iou_prepared_floats", "pt_iou_prepare_f32", "pt_iou_refine_ws_bytes", "pt_iou_refine_f32", "pt_iou_refine_sync_f32",
     "pt_track_frame_replay_pass_f32", "pt_sample_patch_f32", "pt_augment_patches_f32", "pt_track_frame_head_ws_bytes", "pt_track_frame_head_f32",
     "pt_track_frame_full_ws_bytes", "pt_track_frame_full_f32", "pt_track_frame_full_launch_f32", "pt_host_buffer_forget",
+    "pt_track_frame_full_dyn_bytes", "pt_track_frame_full_dyn_fill_f32", "pt_host_wait_word_f32",
     "pt_sd_solve_batch_f32", "pt_stream_probe_f32",
 ]
 
@@ -125,7 +126,8 @@ class FrameFull(ctypes.Structure):
                    ("loc", ctypes.POINTER(LocalizeState)), ("glue", ctypes.POINTER(FrameGlue)), ("iou_dims", ctypes.POINTER(IouDims))]
                 + [(n, ctypes.c_void_p) for n in ("iou_params", "iou_prepared", "c3", "c4", "mod3", "mod4")]
                 + [("iou_iter", ctypes.c_int), ("relative", ctypes.c_int), ("step_length4", ctypes.c_float * 4),
-                   ("step_decay", ctypes.c_float), ("aux_stream", ctypes.c_void_p), ("aux_reordered_update_ok", ctypes.c_int)])
+                   ("step_decay", ctypes.c_float), ("aux_stream", ctypes.c_void_p), ("aux_reordered_update_ok", ctypes.c_int),
+                   ("dyn", ctypes.c_void_p)])
 
 
 def _build_flags():
@@ -320,6 +322,12 @@ def lib():
     L.pt_track_frame_full_f32.argtypes = [ffp, vp, vp, sz, vp]
     L.pt_track_frame_full_launch_f32.restype = i
     L.pt_track_frame_full_launch_f32.argtypes = [ffp, vp, vp, sz, vp]
+    L.pt_track_frame_full_dyn_bytes.restype = sz
+    L.pt_track_frame_full_dyn_bytes.argtypes = []
+    L.pt_track_frame_full_dyn_fill_f32.restype = i
+    L.pt_track_frame_full_dyn_fill_f32.argtypes = [ffp, ctypes.c_float, vp, vp, sz, vp]
+    L.pt_host_wait_word_f32.restype = i
+    L.pt_host_wait_word_f32.argtypes = [vp, ctypes.c_float, vp]
     L.pt_stream_probe_f32.restype = i
     L.pt_stream_probe_f32.argtypes = [vp, sz, vp, i, vp]
     L.pt_host_buffer_forget.restype = None

@@ -304,13 +304,13 @@ extern "C" int pt_track_frame_head_f32(const pt_sd_params* prm, float* filter, f
                                        int Cin, int C, int H, int W, int K, int num_iter, float* scores_out, float* peak_out,
                                        void* ws, size_t ws_bytes, void* stream) {
     return pt_track_frame_head_impl(prm, filter, mem_feat, mem_bb, sample_weight, backbone_feat, head_weight_tap_major, norm_scale,
-                                    norm_eps, slot, n, Cin, C, H, W, K, num_iter, scores_out, peak_out, ws, ws_bytes, stream, nullptr);
+                                    norm_eps, slot, n, Cin, C, H, W, K, num_iter, scores_out, peak_out, ws, ws_bytes, stream, nullptr, nullptr);
 }
 
 int pt_track_frame_head_impl(const pt_sd_params* prm, float* filter, float* mem_feat, float* mem_bb, const float* sample_weight,
                              const float* backbone_feat, const float* head_weight_tap_major, float norm_scale, float norm_eps, int slot,
                              int n, int Cin, int C, int H, int W, int K, int num_iter, float* scores_out, float* peak_out, void* ws,
-                             size_t ws_bytes, void* stream, void* after_init_event) {
+                             size_t ws_bytes, void* stream, void* after_init_event, const int* slot_dyn) {
     if (!prm || !filter || !mem_feat || !mem_bb || !backbone_feat || !head_weight_tap_major || !scores_out || !peak_out || !ws)
         return PT_ERR_NULL;
     if (n <= 0 || Cin <= 0 || C <= 0 || H <= 0 || W <= 0 || K <= 0 || num_iter < 0 || slot < 0 || slot >= n) return PT_ERR_SHAPE;
@@ -321,18 +321,22 @@ int pt_track_frame_head_impl(const pt_sd_params* prm, float* filter, float* mem_
     const TfhCarve hc = tfh_carve(n, Cin, C, H, W, K);
     float* base = (float*)ws;
     const long CHW = (long)C * H * W;
+    hipStream_t st = (hipStream_t)stream;
+    const int OH = H + (K + 1) % 2, OW = W + (K + 1) % 2;
+    PtFast f = pt_fast_plan(n, C, H, W, K, K, OH, OW);
+    const bool fast = pt_fast_usable(f, mem_feat, CHW, filter) && f.KSPL <= 16;
+    // slot_dyn (graph-replayed frame): the slot index lives in device memory -- the head's last kernel and the solve's init stage read
+    // it there; only the XCD-aligned path serves that (checked before anything is queued)
+    if (slot_dyn && !fast) return PT_ERR_UNSUPPORTED;
     // 1. head: conv 3x3 + InstanceL2Norm of the test frame's backbone features -> memory slot (features.py:66-72)
-    int rc = pt_clf_head_f32(backbone_feat, head_weight_tap_major, mem_feat + (long)slot * CHW, 1, Cin, C, H, W, norm_scale,
-                             norm_eps, base + hc.head, hc.frame * sizeof(float), stream);
+    int rc = pt_clf_head_impl(backbone_feat, head_weight_tap_major, slot_dyn ? mem_feat : mem_feat + (long)slot * CHW, 1, Cin, C, H, W, norm_scale,
+                              norm_eps, base + hc.head, hc.frame * sizeof(float), stream, slot_dyn, CHW);
     if (rc) return rc;
     // 2. classification of that sample = its score row of the solve's first correlation; localisation; re-optimisation
     TfCarve cv = tf_carve(n, C, H, W, K);
     float* fb = base + hc.frame;
-    PtClsFin cls = {nullptr, 0, slot, scores_out, peak_out, mem_bb, after_init_event};
-    hipStream_t st = (hipStream_t)stream;
-    const int OH = H + (K + 1) % 2, OW = W + (K + 1) % 2;
-    PtFast f = pt_fast_plan(n, C, H, W, K, K, OH, OW);
-    if (pt_fast_usable(f, mem_feat, CHW, filter) && f.KSPL <= 16)
+    PtClsFin cls = {nullptr, 0, slot, scores_out, peak_out, mem_bb, after_init_event, slot_dyn};
+    if (fast)
         return pt_sd_solve_impl(prm, filter, mem_feat, CHW, mem_bb, sample_weight, n, C, H, W, K, num_iter, fb + cv.w_iters,
                                 nullptr, fb + cv.sd, (cv.total - cv.sd) * sizeof(float), st, /*copy_w0=*/false,
                                 /*w_final=*/filter, &cls, /*src=*/nullptr);

@@ -162,6 +162,27 @@ __global__ __launch_bounds__(256) void k_frame_mid(DecideArgs d, GlueArgs g, Set
     if (threadIdx.x < a.P) iou_setup_proposal(a, threadIdx.x, bx);
 }
 
+// The same with the per-frame part of its arguments -- the localisation constants and the tracker state of the glue, i.e. the whole
+// PtFrameMid block -- read from DEVICE memory (graph-replayed one-call frame: a captured launch cannot carry per-frame values; the
+// host refreshes the block through a copy node in front of the graph, frame_full.hip).  The block is staged in LDS first.
+__global__ __launch_bounds__(256) void k_frame_mid_dyn(const PtFrameMid* __restrict__ mid, SetupArgs a) {
+    __shared__ Peak sh[4];
+    __shared__ float res[16];
+    __shared__ float bx[4 * 16];
+    __shared__ __attribute__((aligned(16))) int blk[(sizeof(PtFrameMid) + 3) / 4];
+    for (int e = threadIdx.x; e < (int)(sizeof(PtFrameMid) / 4); e += 256) blk[e] = ((const int*)mid)[e];
+    __syncthreads();
+    const PtFrameMid& m = *reinterpret_cast<const PtFrameMid*>(blk);
+    localize_decide(m.dec, sh, res);
+    if (threadIdx.x == 0) {
+        for (int k = 0; k < 15; ++k) m.dec.out[k] = res[k];
+    }
+    __syncthreads();
+    if (threadIdx.x < a.P) frame_glue(m.glue, res, bx);
+    __syncthreads();
+    if (threadIdx.x < a.P) iou_setup_proposal(a, threadIdx.x, bx);
+}
+
 struct HeadArgs {
     const float *part3, *part4, *b3, *bn3, *b4, *bn4, *wp, *bp;
     float *G3, *G4, *iou;
@@ -770,13 +791,15 @@ __global__ __launch_bounds__(FT) void k_iou_bwd(int nz0, int P, const float* __r
 }
 
 // the update after the last iteration: boxes and predicted IoU out
-__global__ __launch_bounds__(FT) void k_iou_final(int P, UpdLate U) {
+// seq_dyn (graph-replayed frame): the sequence number comes from device memory instead of the captured argument block
+__global__ __launch_bounds__(FT) void k_iou_final(int P, UpdLate U, const float* __restrict__ seq_dyn) {
     __shared__ float red[8][64];
     __shared__ float rois_s[FUSED_MAX_P][5];
+    const float seq = seq_dyn ? *seq_dyn : U.seq;
     iou_step(U, P, red, rois_s, true);
-    if (U.seq != 0.f && threadIdx.x == 0) {         // boxes_out / iou_out were stored by lanes of this wave: program order + release
+    if (seq != 0.f && threadIdx.x == 0) {           // boxes_out / iou_out were stored by lanes of this wave: program order + release
         __threadfence_system();
-        *(volatile float*)U.seq_word = U.seq;
+        *(volatile float*)U.seq_word = seq;
     }
 }
 
@@ -840,7 +863,7 @@ static int iou_refine_impl(const pt_iou_dims* d, const float* params, const floa
                            const float* mod3, const float* mod4, const float* init_boxes, bool boxes_on_host, float* boxes_out,
                            float* iou_out, int P, int num_iter, const float* step_length4, float step_decay, int relative,
                            int backtrack, void* ws, size_t ws_bytes, float seq, float* seq_word, void* stream,
-                           const PtFrameMid* mid = nullptr) {
+                           const PtFrameMid* mid = nullptr, const PtFrameMid* mid_dev = nullptr, const float* seq_dyn = nullptr) {
     int rc = pt_iou_refine_validate(d, params, prepared, c3, c4, mod3, mod4, init_boxes != nullptr, boxes_out, iou_out, P, num_iter,
                                     step_length4, ws, ws_bytes, boxes_on_host, seq, mid != nullptr);
     if (rc) return rc;
@@ -862,7 +885,8 @@ static int iou_refine_impl(const pt_iou_dims* d, const float* params, const floa
         for (int i = 0; i < 4 * P; ++i) sa.hb[i] = init_boxes[i];
     }
     if (mid) {                                                          // proposals are formed inside the launch (fused route only)
-        hipLaunchKernelGGL(k_frame_mid, dim3(1), dim3(256), 0, st, mid->dec, mid->glue, sa);
+        if (mid_dev) hipLaunchKernelGGL(k_frame_mid_dyn, dim3(1), dim3(256), 0, st, mid_dev, sa);     // per-frame values from device memory
+        else hipLaunchKernelGGL(k_frame_mid, dim3(1), dim3(256), 0, st, mid->dec, mid->glue, sa);
     } else {
         hipLaunchKernelGGL(k_iou_setup, dim3((std::max(std::max(sa.K3, sa.K4), P) + 255) / 256), dim3(256), 0, st, sa);
     }
@@ -893,7 +917,7 @@ static int iou_refine_impl(const pt_iou_dims* d, const float* params, const floa
             up.st_in = stb[it & 1]; up.st_out = stb[(it + 1) & 1];
             up.first = it == 0; up.last = it == num_iter;
             if (it == num_iter) {
-                hipLaunchKernelGGL(k_iou_final, dim3(1), dim3(FT), 0, st, P, up);
+                hipLaunchKernelGGL(k_iou_final, dim3(1), dim3(FT), 0, st, P, up, seq_dyn);
                 PT_CHECK_LAUNCH();
                 break;
             }
@@ -972,8 +996,9 @@ extern "C" int pt_iou_refine_sync_f32(const pt_iou_dims* d, const float* params,
 int pt_iou_refine_launch(const pt_iou_dims* d, const float* params, const float* prepared, const float* c3, const float* c4,
                          const float* mod3, const float* mod4, const float* init_boxes_dev, float* boxes_out, float* iou_out, int P,
                          int num_iter, const float* step_length4, float step_decay, int relative, int backtrack, void* ws,
-                         size_t ws_bytes, float seq, float* seq_word, void* stream, const void* frame_mid) {
+                         size_t ws_bytes, float seq, float* seq_word, void* stream, const void* frame_mid, const void* frame_mid_dev,
+                         const float* seq_dyn) {
     return iou_refine_impl(d, params, prepared, c3, c4, mod3, mod4, init_boxes_dev, false, boxes_out, iou_out, P, num_iter,
                            step_length4, step_decay, relative, backtrack, ws, ws_bytes, seq, seq_word, stream,
-                           (const PtFrameMid*)frame_mid);
+                           (const PtFrameMid*)frame_mid, (const PtFrameMid*)frame_mid_dev, seq_dyn);
 }

@@ -139,6 +139,7 @@ struct PtClsFin {
     int KS, slot;
     float *scores, *peak, *mem_bb;
     void* after_init;     // optional hipEvent_t recorded behind the launch that writes scores / peak (frame_full.hip forks there)
+    const int* slot_dyn;  // optional: the slot is read from this device int by the init stage (graph-replayed frames); `slot` then only bounds checks
 };
 
 // Frame chains (pt_track_frame_chain_f32): `pend` in-out, nullable.  On entry pend->iters > 0 = the previous solve on this workspace
@@ -186,7 +187,7 @@ static inline float pt_next_seq(volatile float* word) {
 int pt_track_frame_head_impl(const pt_sd_params* prm, float* filter, float* mem_feat, float* mem_bb, const float* sample_weight,
                              const float* backbone_feat, const float* head_weight_tap_major, float norm_scale, float norm_eps, int slot,
                              int n, int Cin, int C, int H, int W, int K, int num_iter, float* scores_out, float* peak_out, void* ws,
-                             size_t ws_bytes, void* stream, void* after_init_event);
+                             size_t ws_bytes, void* stream, void* after_init_event, const int* slot_dyn = nullptr);
 
 // Two timing-less events per (current device, main stream, auxiliary stream) triple -- fork: recorded on `main_stream`, join: recorded on
 // `aux_stream` for `main_stream` to wait on -- created on first use and never destroyed (they hold no memory); thread-safe.  Keyed by the
@@ -200,7 +201,12 @@ int pt_localize_launch(const float* scores, const float* scores_hn, const pt_loc
 int pt_iou_refine_launch(const pt_iou_dims* d, const float* params, const float* prepared, const float* c3, const float* c4,
                          const float* mod3, const float* mod4, const float* init_boxes_dev, float* boxes_out, float* iou_out, int P,
                          int num_iter, const float* step_length4, float step_decay, int relative, int backtrack, void* ws,
-                         size_t ws_bytes, float seq, float* seq_word, void* stream, const void* frame_mid = nullptr);
+                         size_t ws_bytes, float seq, float* seq_word, void* stream, const void* frame_mid = nullptr,
+                         const void* frame_mid_dev = nullptr, const float* seq_dyn = nullptr);
+
+// pt_clf_head_f32 with the memory slot read from a device int (graph-replayed one-call frame); tomp.hip
+int pt_clf_head_impl(const float* feat, const float* weight_tap_major, float* out, int n, int Cin, int Cout, int H, int W,
+                     float norm_scale, float eps, void* ws, size_t ws_bytes, void* stream, const int* slot_dyn, long slot_stride);
 
 // the argument / shape / route checks of a refinement call, nothing queued (iou_refine.hip)
 int pt_iou_refine_validate(const pt_iou_dims* d, const float* params, const float* prepared, const float* c3, const float* c4,

@@ -32,6 +32,7 @@ struct SdArgs {
     int cls_KS, cls_slot;
     long cls_stride;             // floats between consecutive classification slices
     float *cls_scores, *cls_peak, *cls_bb;
+    const int* cls_slot_dyn;     // optional: cls_slot is read from this device int (k_fast_init2 only; graph-replayed frames)
 };
 
 // (returns the member's own pointer type: plain in the argument structs passed by value, global-qualified in the late-fetched ones)

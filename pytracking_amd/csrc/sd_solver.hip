@@ -416,15 +416,20 @@ struct InitLate {
     float bin_disp, gauss_sigma, hinge_thr, uni_weight, label_shrink, label_thr;
 };
 static_assert(sizeof(InitLate) <= 3 * 64, "InitLate: three 16-dword blocks");
+//   slot_dyn (preloaded like the other scalars): when non-null the classification slot comes from this device int instead of pb -- the
+//   graph-replayed one-call frame (frame_full.hip) cannot bake a per-frame slot into its captured launches
 __global__ __launch_bounds__(1024) void k_fast_init2(const float* __restrict__ spart, const float* __restrict__ bb, const float* __restrict__ swp_,
-                                                     unsigned pa, unsigned pb, unsigned pc, float feat_stride, InitLate l_arg) {
+                                                     const int* __restrict__ slot_dyn, unsigned pa, unsigned pb, unsigned pc, float feat_stride,
+                                                     InitLate l_arg) {
     extern __shared__ __attribute__((aligned(16))) float lut[];    // DiMP: label | mask | spatial look-up tables
     __shared__ float scratch[16];
     __shared__ float bv[16];
     __shared__ int bi[16];
     __shared__ float bbs[4];
     const int n = (int)(pa & 0xffffu), OO = (int)(pa >> 16);
-    const int KS = (int)(pb & 255u), kind = (int)((pb >> 8) & 15u), cls_slot = (int)(pb >> 12);
+    const int KS = (int)(pb & 255u), kind = (int)((pb >> 8) & 15u);
+    const int slot_d = slot_dyn ? *slot_dyn : 0;                    // requested with the first loads
+    const int cls_slot = slot_dyn ? slot_d : (int)(pb >> 12);
     const int OW = (int)(pc & 0xfffu), K = (int)((pc >> 12) & 15u), num_bins = (int)(pc >> 16);
     const int i = blockIdx.x, o = threadIdx.x;
     const bool ok = o < OO;
@@ -443,7 +448,7 @@ __global__ __launch_bounds__(1024) void k_fast_init2(const float* __restrict__ s
     float b0 = bp[0], b1 = bp[1], b2 = bp[2], b3 = bp[3];
     const float swv = swp_ ? swp_[i] : 1.0f / (float)n;
     __builtin_amdgcn_sched_barrier(0);
-    const InitLate l = pt_late_args<InitLate>(40);                  // 3 pointers + 4 dwords = 40 bytes
+    const InitLate l = pt_late_args<InitLate>(48);                  // 4 pointers + 4 dwords = 48 bytes
     if (kind == PT_SD_DIMP) {
         for (int e = o; e < 3 * num_bins; e += nthreads) {
             const int t = e / num_bins, k = e - t * num_bins;
@@ -589,6 +594,7 @@ static void sd_fill_params(SdArgs& a, const pt_sd_params* prm, const float* bb, 
     a.spatial_lut = prm->spatial_lut;
     a.s_in = nullptr; a.lms = nullptr; a.pk = nullptr; a.R = nullptr; a.cls_stride = 0;
     a.cls_spart = nullptr; a.cls_KS = 0; a.cls_slot = -1; a.cls_scores = nullptr; a.cls_peak = nullptr; a.cls_bb = nullptr;
+    a.cls_slot_dyn = nullptr;
 }
 
 // Solver state of the fast path laid out in the caller's workspace (shared by the solve and by the measurement replay).
@@ -640,6 +646,9 @@ static int sd_solve_fast(const PtFast& f, const pt_sd_params* prm, const float* 
         // the inserted sample's scores under w_in ARE the classification scores of the test frame
         a.cls_spart = a.spart + (long)slot * a.OO; a.cls_KS = a.KS; a.cls_stride = (long)n * a.OO; a.cls_slot = slot;
         a.cls_scores = cls->scores; a.cls_peak = cls->peak; a.cls_bb = cls->mem_bb;
+        a.cls_slot_dyn = cls->slot_dyn;
+        // a device-resident slot is served by k_fast_init2 only: refuse before anything is queued
+        if (cls->slot_dyn && !(a.KS <= PT_PW_MAXKS && (a.kind != PT_SD_DIMP || (size_t)3 * a.num_bins * sizeof(float) <= 48 * 1024))) return PT_ERR_UNSUPPORTED;
     }
     const int want_loss = losses != nullptr;
     const size_t pw_lds = (size_t)a.OO * sizeof(float) * (a.kind == PT_SD_PRDIMP ? 2 : 1);
@@ -676,9 +685,10 @@ static int sd_solve_fast(const PtFast& f, const pt_sd_params* prm, const float* 
         il.label_shrink = a.label_shrink; il.label_thr = a.label_thr;
         const unsigned cslot = (a.cls_spart && a.cls_slot >= 0) ? (unsigned)a.cls_slot : 0xfffffu;
         hipLaunchKernelGGL(k_fast_init2, dim3(n), dim3(pw_threads), lut_lds, st, (const float*)a.spart, a.bb, a.has_sw ? a.sw : (const float*)nullptr,
-                           (unsigned)n | ((unsigned)a.OO << 16), (unsigned)a.KS | ((unsigned)a.kind << 8) | (cslot << 12),
+                           a.cls_slot_dyn, (unsigned)n | ((unsigned)a.OO << 16), (unsigned)a.KS | ((unsigned)a.kind << 8) | (cslot << 12),
                            (unsigned)a.OW | ((unsigned)a.K << 12) | ((unsigned)(a.kind == PT_SD_DIMP ? a.num_bins : 0) << 16), a.feat_stride, il);
     }
+    else if (a.cls_slot_dyn) return PT_ERR_UNSUPPORTED;             // (refused before the first correlation: see below)
     else hipLaunchKernelGGL(k_fast_init, dim3(n), dim3(384), 0, st, a);
     PT_CHECK_LAUNCH();
     if (cls && cls->after_init && hipEventRecord((hipEvent_t)cls->after_init, st) != hipSuccess) return PT_ERR_LAUNCH;
@@ -774,6 +784,8 @@ int pt_sd_solve_impl(const pt_sd_params* prm, const float* w_in, const float* fe
     a.w0 = w_in; a.w_final = w_final;
     a.s_in = nullptr; a.lms = nullptr; a.pk = nullptr; a.cls_stride = 0;
     a.cls_spart = nullptr; a.cls_KS = 0; a.cls_slot = -1; a.cls_scores = nullptr; a.cls_peak = nullptr; a.cls_bb = nullptr;
+    a.cls_slot_dyn = nullptr;
+    if (cls && cls->slot_dyn) return PT_ERR_UNSUPPORTED;                // a device-resident slot exists on the fast path only
     if (cls) {
         a.cls_spart = cls->spart; a.cls_KS = cls->KS; a.cls_stride = a.OO; a.cls_slot = cls->slot; a.cls_scores = cls->scores;
         a.cls_peak = cls->peak; a.cls_bb = cls->mem_bb;

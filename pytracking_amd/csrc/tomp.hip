@@ -1596,9 +1596,13 @@ __global__ __launch_bounds__(256) void k_head_finish(const float* X, const float
 }
 
 // out = y * scale * sqrt(C*HW / (sum y^2 + eps)) for maps that already are (n, C, H, W)
+// slot_dyn (graph-replayed one-call frame, frame_full.hip): the output lands slot_stride * *slot_dyn floats further -- the memory slot of
+// this frame is read from a device descriptor instead of being baked into the captured launch
 __global__ __launch_bounds__(256) void k_head_scale(const float* __restrict__ Y, const float* __restrict__ stats, int slices,
-                                                    float* __restrict__ out, int C, int HW, float scale, float eps) {
+                                                    float* __restrict__ out, int C, int HW, float scale, float eps,
+                                                    const int* __restrict__ slot_dyn, long slot_stride) {
     __shared__ double sh[256];
+    if (slot_dyn) out += (long)(*slot_dyn) * slot_stride;
     const int img = blockIdx.y;
     double q = 0.0;                                                 // fixed order: thread t sums slices t, t+256, ...; then a tree
     for (int k = threadIdx.x; k < slices; k += 256) q += (double)stats[((long)img * slices + k) * 2 + 1];
@@ -1645,6 +1649,12 @@ extern "C" size_t pt_clf_head_ws_bytes(int n, int Cin, int Cout, int H, int W) {
 
 extern "C" int pt_clf_head_f32(const float* feat, const float* weight_tap_major, float* out, int n, int Cin, int Cout,
                                int H, int W, float norm_scale, float eps, void* ws, size_t ws_bytes, void* stream) {
+    return pt_clf_head_impl(feat, weight_tap_major, out, n, Cin, Cout, H, W, norm_scale, eps, ws, ws_bytes, stream, nullptr, 0);
+}
+
+// slot_dyn != nullptr (one frame, banded-correlation route only): `out` is the BASE of the sample memory and the slot comes from the device
+int pt_clf_head_impl(const float* feat, const float* weight_tap_major, float* out, int n, int Cin, int Cout, int H, int W,
+                     float norm_scale, float eps, void* ws, size_t ws_bytes, void* stream, const int* slot_dyn, long slot_stride) {
     if (!feat || !weight_tap_major || !out || !ws) return PT_ERR_NULL;
     int rc = head_check(n, Cin, Cout, H, W);
     if (rc) return rc;
@@ -1660,17 +1670,19 @@ extern "C" int pt_clf_head_f32(const float* feat, const float* weight_tap_major,
     // GEMM path below, 76 vs 90 us)
     const int ks = ((Cout * HW) % 4 == 0 && ((uintptr_t)out % 16) == 0 && pt_mf_corr_tm_cost(n, Cout, Cin, H, W) <= 22)
                        ? pt_mf_corr_tm_splits(n, Cout, Cin, H, W) : 0;
+    if (slot_dyn && !(ks > 0 && ks <= 9 && n == 1)) return PT_ERR_UNSUPPORTED;
     if (ks > 0 && ks <= 9) {
         if ((rc = pt_launch_mf_corr_tm(feat, (long)Cin * HW, weight_tap_major, base + cv.part, n, Cout, Cin, H, W, ks, st)) == PT_OK) {
             hipLaunchKernelGGL(k_gn_reduce, dim3(cv.slices, n), dim3(256), 0, st, base + cv.part, ks, (long)M * Cout, base + cv.Y,
                                base + cv.stats, HW * Cout);
             PT_CHECK_LAUNCH();
             hipLaunchKernelGGL(k_head_scale, dim3((Cout * HW / 4 + 255) / 256, n), dim3(256), 0, st, base + cv.Y, base + cv.stats,
-                               cv.slices, out, Cout, HW, norm_scale, eps);
+                               cv.slices, out, Cout, HW, norm_scale, eps, slot_dyn, slot_stride);
             PT_CHECK_LAUNCH();
             return PT_OK;
         }
     }
+    if (slot_dyn) return PT_ERR_UNSUPPORTED;                           // the token route writes through k_head_finish: static slot only
     hipLaunchKernelGGL(k_nchw_to_tokens, dim3((HW + 31) / 32, (Cin + 31) / 32, n), dim3(256), 0, st, feat, base + cv.X, Cin,
                        HW);
     PT_CHECK_LAUNCH();

@@ -315,6 +315,63 @@ def test_full_frame_refuses_before_anything_is_queued():
         frame_full.FramePipeline(st, num_iter=2, overlap=True).run(me, xb, 1, iou_feat, sample_pos, sample_scales, rand_u)
 
 
+def test_full_frame_graph_replay_equals_eager_calls():
+    """Graph mode of the one-call frame (`pt_frame_full.dyn`, round 6): the launches are captured once per iteration count and the per-frame
+    VALUES (memory slot, tracker state, thresholds, random numbers, sequence number) come from a device block the host refreshes through
+    the graph's copy node.  Two identical sequences, one through `run` (eager, kernel arguments), one through `run_graph`: every result
+    and the whole sequence state BIT-EQUAL over 10 frames with changing slots, positions, scales, random numbers and iteration counts
+    (2 / 0 / 3: three captured graphs)."""
+    from pytracking_amd import bench_frame, frame_full
+    dev = torch.device("cuda", 0)
+    C, n, num_random = 128, 9, 9
+    cfg = dict(synth.DIMP50, C=C)
+    rng = np.random.default_rng(41)
+    head_w = torch.from_numpy(rng.standard_normal((C, 256, 3, 3), dtype=np.float32) * np.float32(0.02)).to(dev)
+    net = _iou_net(dev, 3)
+    gen = torch.Generator().manual_seed(9)
+    iou_feat = (torch.randn(1, 256, 36, 36, generator=gen).to(dev), torch.randn(1, 256, 18, 18, generator=gen).to(dev))
+    mod = ((torch.rand(1, 256, generator=gen) + 0.5).to(dev), (torch.rand(1, 256, generator=gen) + 0.5).to(dev))
+
+    def tracker():
+        p = Params(target_not_found_threshold=0.05, distractor_threshold=0.8, hard_negative_threshold=0.5, target_neighborhood_scale=2.2,
+                   dispalcement_scale=0.8, box_refinement_iter=5, box_refinement_step_length=1, box_refinement_step_decay=1,
+                   box_jitter_pos=0.1, box_jitter_sz=0.5, num_init_random_boxes=num_random)
+        return types.SimpleNamespace(params=p, kernel_size=torch.Tensor([4, 4]), output_window=None, img_support_sz=torch.Tensor([288.0, 288.0]),
+                                     img_sample_sz=torch.Tensor([288.0, 288.0]), image_sz=torch.Tensor([360.0, 480.0]),
+                                     target_sz=torch.Tensor([60.0, 70.0]), pos=torch.Tensor([144.0, 150.0]),
+                                     net=types.SimpleNamespace(bb_regressor=net), iou_modulation=mod)
+    states, pipes, mes = [], [], []
+    for mode in (False, True):
+        st = bench_frame.TrackState(cfg, n, seed=13, device=dev)
+        st.attach_head(head_w, (1.0 / (C * 16)) ** 0.5)
+        states.append(st)
+        pipes.append(frame_full.FramePipeline(st, num_iter=2, graph=mode))
+        mes.append(tracker())
+    for frame in range(10):
+        nit = (2, 0, 3, 2, 0, 0, 3, 2, 2, 0)[frame]
+        xb = torch.from_numpy(rng.standard_normal((256, 18, 18), dtype=np.float32)).to(dev)
+        sample_pos = (mes[0].pos + torch.Tensor([2.0 * frame, -3.0 * (frame % 4)])).round().view(1, 2)
+        sample_scales = torch.Tensor([1.0 + 0.03 * (frame % 5)])
+        rand_u = torch.rand(num_random, 4, generator=gen)
+        slot = (5 * frame) % n
+        outs = []
+        for k in range(2):
+            pipes[k].ff.num_iter = nit
+            fn = pipes[k].run_graph if k == 1 else pipes[k].run
+            outs.append(fn(mes[k], xb, slot, iou_feat, sample_pos, sample_scales, rand_u))
+            mes[k].pos = outs[k]["pos"].clone()
+        torch.cuda.synchronize()
+        a, b = outs
+        assert a["flag"] == b["flag"] and a["scale_ind"] == b["scale_ind"], frame
+        for key in ("translation_vec", "pos", "init_box", "boxes", "iou", "peak"):
+            assert torch.equal(a[key], b[key]), (frame, key, a[key], b[key])
+        assert torch.equal(states[0].filter, states[1].filter) and torch.equal(states[0].scores, states[1].scores), frame
+        assert torch.equal(states[0].mem_feat, states[1].mem_feat) and torch.equal(states[0].mem_bb, states[1].mem_bb), frame
+    assert len(pipes[1]._graphs) == 3                              # one capture per iteration count
+    with pytest.raises(RuntimeError):
+        pipes[0].run_graph(mes[0], xb, 0, iou_feat, sample_pos, sample_scales, rand_u)
+
+
 def test_full_frame_argument_checks():
     import ctypes
     from pytracking_amd import _lib

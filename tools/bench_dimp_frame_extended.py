@@ -102,6 +102,29 @@ def measure(dev, frames=300):
     def frame_one_call(i, parts):
         pipe.run(me, backbone_feat[i % 8][0], i % st1.n, iou_feat, sample_pos, sample_scales, torch.rand(9, 4))
 
+    # graph mode (round 6): the one-call frame as ONE graph replay per frame, its per-frame values read from a device block.  The IoU
+    # features sit in the pipeline's fixed buffers (the caller's backbone would write them there); the backbone feature of the frame is
+    # copied into its fixed buffer on the clock (1.3 MB device-to-device: what a backbone writing elsewhere would cost).
+    st4 = bench_frame.TrackState(cfg, cfg["memory"], seed=1234, device=dev)
+    st4.attach_head(head[0].weight, head[1].scale, head[1].eps)
+    pipe4 = frame_full.FramePipeline(st4, num_iter=5, graph=True)
+    gb, giou = pipe4.graph_inputs(backbone_feat[0][0], iou_feat)
+    giou[0].copy_(iou_feat[0]); giou[1].copy_(iou_feat[1])
+    st5 = bench_frame.TrackState(cfg, cfg["memory"], seed=1234, device=dev)
+    st5.attach_head(head[0].weight, head[1].scale, head[1].eps)
+    pipe5 = frame_full.FramePipeline(st5, num_iter=0, graph=True)
+    gb5, giou5 = pipe5.graph_inputs(backbone_feat[0][0], iou_feat)
+    giou5[0].copy_(iou_feat[0]); giou5[1].copy_(iou_feat[1])
+
+    def frame_one_call_graph(i, parts):
+        pipe4.run_graph(me, backbone_feat[i % 8][0], i % st4.n, giou, sample_pos, sample_scales, torch.rand(9, 4))
+
+    def frame_one_call_graph_in_place(i, parts):                  # the backbone feature already sits in the fixed buffer: no copy on the clock
+        pipe4.run_graph(me, gb, i % st4.n, giou, sample_pos, sample_scales, torch.rand(9, 4))
+
+    def frame_one_call_graph_no_update(i, parts):
+        pipe5.run_graph(me, backbone_feat[i % 8][0], i % st5.n, giou5, sample_pos, sample_scales, torch.rand(9, 4))
+
     def frame_one_call_2s(i, parts):
         pipe2.run(me, backbone_feat[i % 8][0], i % st2.n, iou_feat, sample_pos, sample_scales, torch.rand(9, 4))
 
@@ -113,7 +136,10 @@ def measure(dev, frames=300):
         for tag, parts, fn in (("head_only", 0, frame), ("head+solver", 1, frame), ("head+solver+localize", 2, frame),
                                ("head+solver+localize+iou_refine", 3, frame), ("one_call", 3, frame_one_call),
                                ("one_call_two_streams", 3, frame_one_call_2s),
-                               ("one_call_no_update", 3, frame_one_call_no_update)):
+                               ("one_call_no_update", 3, frame_one_call_no_update),
+                               ("one_call_graph", 3, frame_one_call_graph),
+                               ("one_call_graph_inputs_in_place", 3, frame_one_call_graph_in_place),
+                               ("one_call_graph_no_update", 3, frame_one_call_graph_no_update)):
             for i in range(20):
                 fn(i, parts)
             torch.cuda.synchronize()
@@ -161,6 +187,10 @@ def measure(dev, frames=300):
                                            "as the classification scores exist, concurrent with the 5 SD iterations; joined at the end "
                                            "(valid for this synthetic frame: the update's label box comes from the classification peak; "
                                            "DiMP.track updates AFTER the refinement, which is the one-stream order)")
+    out["one_call_graph"]["what"] = ("one_call as ONE hipGraph replay per frame (pt_frame_full.dyn): launches captured once, per-frame values "
+                                     "(slot, tracker state, thresholds, random numbers, sequence word) from a device block refreshed by the graph's "
+                                     "copy node; includes the 1.3 MB copy of the frame's backbone feature into its fixed buffer")
+    out["one_call_graph_no_update"]["what"] = "the same with num_iter = 0 (19 of 20 real frames)"
     out["workload"] = ("DiMP-50 frame without the backbone, eager launches, host wall time: clf head + classify/insert/5 SD iterations + "
                        "localisation (results on the host) + IoU refinement (results on the host); cyclic GC off during the timed loops")
     return out
