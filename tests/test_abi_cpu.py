@@ -335,3 +335,25 @@ def test_round6_entry_points_argument_checks(L):
     f.aux_stream, f.aux_reordered_update_ok = 512, 0
     assert L.pt_track_frame_full_launch_f32(ctypes.byref(f), one, one, 1 << 30, n) == _lib.PT_ERR_UNSUPPORTED
     assert ctypes.sizeof(_lib.FramePending) == 12 and _lib.FrameFull.aux_reordered_update_ok.offset == _lib.FrameFull.aux_stream.offset + 8
+
+
+def test_round6_graph_mode_entry_points_argument_checks(L):
+    """pt_frame_full.dyn: block size, host-side fill and the word wait refuse bad arguments without touching a device."""
+    n = None
+    one = ctypes.c_void_p(256)
+    assert L.pt_track_frame_full_dyn_bytes() >= 512 and L.pt_track_frame_full_dyn_bytes() % 256 == 0
+    f = _lib.FrameFull()
+    assert L.pt_track_frame_full_dyn_fill_f32(ctypes.byref(f), 1.0, one, one, 1 << 30, one) == _lib.PT_ERR_NULL      # sd / loc / glue / iou_dims missing
+    sd, loc, glue, dims = _lib.SdParams(), _lib.LocalizeState(), _lib.FrameGlue(), _lib.IouDims(256, 256, 256, 256, 36, 36, 18, 18)
+    f.sd, f.loc, f.glue, f.iou_dims = ctypes.pointer(sd), ctypes.pointer(loc), ctypes.pointer(glue), ctypes.pointer(dims)
+    f.n, f.Cin, f.C, f.H, f.W, f.K, f.num_iter = 50, 1024, 512, 18, 18, 4, 5
+    glue.num_random = 9
+    f.scores_out = 256
+    assert L.pt_track_frame_full_dyn_fill_f32(ctypes.byref(f), 1.0, one, one, 1 << 30, n) == _lib.PT_ERR_NULL
+    f.slot = 50
+    assert L.pt_track_frame_full_dyn_fill_f32(ctypes.byref(f), 1.0, one, one, 1 << 30, one) == _lib.PT_ERR_SHAPE       # slot == n
+    f.slot = 3
+    assert L.pt_track_frame_full_dyn_fill_f32(ctypes.byref(f), 0.0, one, one, 1 << 30, one) == _lib.PT_ERR_SHAPE       # seq 0 = "no word"
+    assert L.pt_track_frame_full_dyn_fill_f32(ctypes.byref(f), 1.0, one, one, 16, one) == _lib.PT_ERR_WORKSPACE
+    f.dyn, f.aux_stream, f.aux_reordered_update_ok = 264, 512, 1                    # misaligned block / two streams: refused, nothing queued
+    assert L.pt_host_wait_word_f32(n, 1.0, n) == _lib.PT_ERR_NULL
