@@ -48,13 +48,13 @@ def test_roofline_object_from_graph_and_eager_tables():
 
 def test_committed_counter_summary_is_this_rounds():
     """`roofline.traffic` comes from profiles/pmc_traffic.json, which tools/pmc_traffic.py writes from the counter file of the
-    CURRENT kernels: the source must name a round-5 file and the instantiations the passes run now (sample pairs: NK = 16, one
+    CURRENT kernels: the source must name a round-6 file and the instantiations the passes run now (sample pairs: NK = 16, one
     wave per tile; PrDiMP's 24-group adjoint)."""
     rec = json.load(open(os.path.join(ROOT, "profiles", "pmc_traffic.json")))
     for wl, kern, inst in (("dimp50", "k_corr2", "k_corr2<16, true, 8, true, 1>"), ("dimp50", "k_adj2", "k_adj2<1, 6, 16>"),
                            ("prdimp50", "k_corr2", "k_corr2<16, false, 8, true, 1>"), ("prdimp50", "k_adj2", "k_adj2<4, 9, 24>")):
         r = rec[wl][kern]
-        assert "profiles/r05" in r["source"] and inst in r["source"], r["source"]
+        assert "profiles/r06" in r["source"] and inst in r["source"], r["source"]
         assert os.path.exists(os.path.join(ROOT, r["source"].split(":")[0]))
     alg = 4 * 50 * 512 * 18 * 18
     assert 1.0 <= rec["dimp50"]["k_corr2"]["hbm_bytes_per_launch"] / alg < 1.1       # traffic = 1.03 x the algorithmic bytes
