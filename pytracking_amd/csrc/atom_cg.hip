@@ -385,6 +385,28 @@ __global__ __launch_bounds__(640, 2) void k_acg_fwd(const float* h_feat, long h_
     if (o < OO) {
         const int y = o / l.OW, xx0 = o - y * l.OW;
         float tv[16];
+        if (HWp >= HW + 2 * l.W + 2 && nsl >= 2 * l.W + 2) {        // uniform.  As k_corr2 (fast_passes.hip, round 6): uniform tap steps, all 32 LDS reads
+            const int su = 4 * HWp + l.W, sv_ = HWp + 1;            // requested before the first use, validity as row / column bit masks; same sums
+            const int base = (y - 2) * l.W + (xx0 - 2);
+            float t0[16], t1[16];
+#pragma unroll
+            for (int u = 0; u < 4; ++u)
+#pragma unroll
+                for (int v = 0; v < 4; ++v) {
+                    const int idx = base + (u * su + v * sv_);
+                    t0[u * 4 + v] = T0[idx];
+                    t1[u * 4 + v] = T1[idx];
+                }
+            int rok[4], cok[4];
+#pragma unroll
+            for (int u = 0; u < 4; ++u) rok[u] = (unsigned)(y + u - 2) < (unsigned)l.H ? -1 : 0;
+#pragma unroll
+            for (int v = 0; v < 4; ++v) cok[v] = (unsigned)(xx0 + v - 2) < (unsigned)l.W ? -1 : 0;
+            __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+            for (int q = 0; q < 16; ++q)
+                tv[q] = __builtin_bit_cast(float, __builtin_bit_cast(int, t0[q] + t1[q]) & (rok[q >> 2] & cok[q & 3]));
+        } else {
 #pragma unroll
         for (int u = 0; u < 4; ++u) {
             const int yy = y + u - 2;
@@ -396,6 +418,7 @@ __global__ __launch_bounds__(640, 2) void k_acg_fwd(const float* h_feat, long h_
                 const float tsum = T0[idx] + T1[idx];
                 tv[u * 4 + v] = ok ? tsum : 0.f;
             }
+        }
         }
         float sv = 0.f;
 #pragma unroll

@@ -58,6 +58,23 @@ __device__ __forceinline__ float wave_max(float v) {
     return fmaxf(fmaxf(pt_lane(v, 0), pt_lane(v, 16)), fmaxf(pt_lane(v, 32), pt_lane(v, 48)));
 }
 
+// Workgroup barrier for hand-offs THROUGH LDS ONLY.  __syncthreads() is a workgroup-scope fence + s_barrier: in front of it the compiler
+// waits for every outstanding vector-memory operation as well (s_waitcnt vmcnt(0)) -- prefetched feature loads, and the write
+// acknowledgements of result stores nobody in the workgroup reads (k_adj2's home waves: ~0.4 us in front of the barrier the whole
+// workgroup then sits at).  Here: LDS / scalar counter only, then the barrier.  NOT for data exchanged through global memory.
+#ifndef PT_LDS_BARRIER
+#define PT_LDS_BARRIER 1
+#endif
+__device__ __forceinline__ void pt_lds_barrier() {
+#if PT_LDS_BARRIER
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup", "local");
+    __builtin_amdgcn_s_barrier();
+    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup", "local");
+#else
+    __syncthreads();
+#endif
+}
+
 // Deterministic block-wide sum; `scratch` needs blockDim.x/64 floats of LDS.  Every thread gets the result.
 // (`nthreads`: pass the block size when the kernel knows it -- blockDim.x is an implicit kernel argument, a scalar load of its own)
 __device__ __forceinline__ float block_sum(float v, float* scratch, int nthreads = 0) {

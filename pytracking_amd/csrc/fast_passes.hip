@@ -63,6 +63,12 @@ typedef float f32x2a4 __attribute__((ext_vector_type(2), aligned(4)));   // 8-by
 //                          than the two scalar reads and two address adds it replaces; as two ds_read2_b32 (dword pairs, no alignment demand): 7.55 -> 7.94 us
 //                          (profiles/r04j_adjoint_pair_gather_ab.txt) -- fewer instructions in the loop do not make it faster
 #endif
+#ifndef PT_C2_AV_UPFRONT
+#define PT_C2_AV_UPFRONT 1 // 1: k_corr2 reads its NK filter-operand values from LDS in one batch in front of the MFMA loop (round 6)
+#endif
+#ifndef PT_C2_SA_DIRECT
+#define PT_C2_SA_DIRECT 1 // 1: k_corr2's 4x4 shift-and-add with uniform tap steps and row / column masks (round 6); 0: per-tap index arithmetic
+#endif
 #ifndef PT_ADJ_EARLY
 #define PT_ADJ_EARLY 1   // 1: first feature loads in front of the LDS work; 0: behind barrier 1
 #endif
@@ -132,6 +138,10 @@ PtFast pt_fast_plan(int n, int C, int H, int W, int KH, int KW, int OH, int OW) 
     p.HWp = 64 * (p.TF + (p.rem > 0 ? 1 : 0)) + 4;
     p.corr_threads = p.spw * p.nh * p.tiles * 64;
     p.corr_lds = ((size_t)p.CX * 16 + (size_t)p.spw * p.nh * p.KK * p.HWp) * sizeof(float);
+    // direct 4x4 shift-and-add (k_corr2): masked taps may read up to 2W+2 floats in front of the first tap plane (the filter operand is
+    // there) and behind the last one (its padding, else slack added here)
+    p.sa_direct = (KH == 4 && KW == 4 && p.CX * 16 >= 2 * W + 2) ? 1 : 0;
+    if (p.sa_direct && p.HWp < p.HW + 2 * W + 2) p.corr_lds += (size_t)(p.HW + 2 * W + 2 - p.HWp) * sizeof(float);
     if (p.corr_lds > 150 * 1024) return p;
     p.CB = C / 16;
     p.bpx = p.CB / 8;                                               // 0: fewer channel blocks than XCDs (workgroup b: block b % CB, slice b / CB)
@@ -174,6 +184,7 @@ __device__ __forceinline__ int fdiv(int v, float inv_d) { return (int)(((float)v
 struct Corr2Args {                  // pointer members global-qualified: fetched late (pt_late_args), see pt_gcf in common.h
     pt_gcf feat; long stride_n; pt_gcf filt; pt_gf spart;
     int n, C, H, W, KH, KW, OH, OW, CX, TF, rem, tiles, HWp, nh, KSC;
+    int sa_direct;   // 4x4 shift-and-add with uniform tap steps (the plan guarantees 2W+2 floats in front of and behind the tap planes)
     // fused gradient reduction (optimizer.py:146-148): filter operand = sum_k gpart[k] + reg*w
     pt_gcf gpart; int KSPL; pt_gcf w; float reg; float step; pt_gf g_out; pt_gf anum_part;   // FUSE < 0: reg = reg + alpha_eps, step = step length of the pending solve
     // source override: sample `slot` is read from `src` (C,H,W) and stored to copy_dst (the memory slot)
@@ -393,10 +404,22 @@ __global__ __launch_bounds__(1024, (NK <= 8 && NH == 2 ? PT_C2_MINW : 4)) void k
     PT_STAMP(a, 3);
 
     f32x4 acc0 = {0, 0, 0, 0}, acc1 = {0, 0, 0, 0}, acc2 = {0, 0, 0, 0}, acc3 = {0, 0, 0, 0}, accL = {0, 0, 0, 0};
+#if PT_C2_AV_UPFRONT
+    // the wave's NK filter-operand values in one batch of LDS reads in front of the loop (round 6: inside the loop every k-step was
+    // read -> wait -> 4 MFMAs, the uniform leftover-tile branches keep the compiler from hoisting the next read over them)
+    float avv[NK];
+#pragma unroll
+    for (int k = 0; k < NK; ++k) avv[k] = afilt[(4 * (h * NK + k) + kq) * 16 + j];
+    __builtin_amdgcn_sched_barrier(0);
+#endif
 #pragma unroll
     for (int k = 0; k < NK; ++k) {
         if (k + CD < NK) ldq(k + CD);
+#if PT_C2_AV_UPFRONT
+        const float av = avv[k];
+#else
         const float av = afilt[(4 * (h * NK + k) + kq) * 16 + j];
+#endif
         acc0 = mfma16(av, bq[k][0], acc0);
         acc1 = mfma16(av, bq[k][1], acc1);
         acc2 = mfma16(av, bq[k][2], acc2);
@@ -439,7 +462,55 @@ __global__ __launch_bounds__(1024, (NK <= 8 && NH == 2 ? PT_C2_MINW : 4)) void k
       for (int s2 = 0; s2 < nsm; ++s2) {                            // uniform: one round of the block per sample of the pair
         const float* __restrict__ T0 = lds + nsl + (long)s2 * NH * KK * hHWp;
         const float* __restrict__ T1 = T0 + (long)KK * hHWp;      // second k-step half (NH == 2)
+#if defined(PT_C2_OUT_GLOBAL) && PT_C2_OUT_GLOBAL
+        const auto out = pt_global((float*)a.spart) + ((long)x * a.n + (pair ? 2 * i0 + s2 : i0)) * OO;   // global_store instead of flat_store (A/B knob)
+#else
         const pt_gf out = a.spart + ((long)x * a.n + (pair ? 2 * i0 + s2 : i0)) * OO;
+#endif
+        // Round 6 (profiles/r06l_pass_ablation.txt: this loop is 0.9 us of the pass, bound by VALU issue -- ~100 vector instructions per output
+        // around 16 LDS reads): the 16 taps of an output sit at  base + u (4 HWp + W) + v (HWp + 1)  with a per-output base and UNIFORM
+        // steps, and whether a tap lies inside the map is (row u ok) & (column v ok): 8 compares and one add per tap instead of two compares,
+        // a multiply-add and two selects.  An invalid tap reads a finite value somewhere inside the LDS allocation (the filter operand and
+        // earlier planes lie in front of it; behind the last plane its own padding, or -- 22x22: HWp = 516 < HW + 2 W + 2 -- slack the plan
+        // adds to the allocation) and is replaced by 0 through a BIT mask, so uninitialised slack cannot leak a NaN.  Same values added in
+        // the same order: same bits.
+        const bool direct = PT_C2_SA_DIRECT && a.sa_direct;                                         // uniform
+        if (direct) {
+            const int su = 4 * hHWp + a.W, sv = hHWp + 1;
+            for (int o = threadIdx.x; o < OO; o += nthreads) {
+                const int y = fdiv(o, inv_ow), xx0 = o - y * a.OW;
+                const int base = (y - 2) * a.W + (xx0 - 2);
+                // all 16 (32) LDS reads are requested before the first use: written as a select around the load, the compiler made every
+                // read conditional (branch, read, wait -- 16 serialised LDS round trips; and the per-tap form below waits after every one
+                // or two reads as well).  The masks are applied as bit masks so that the reads stay unconditional.
+                float t0[16], t1[16];
+#pragma unroll
+                for (int u = 0; u < 4; ++u)
+#pragma unroll
+                    for (int v = 0; v < 4; ++v) {
+                        const int idx = base + (u * su + v * sv);
+                        t0[u * 4 + v] = T0[idx];
+                        if (NH == 2) t1[u * 4 + v] = T1[idx];
+                    }
+                int rok[4], cok[4];
+#pragma unroll
+                for (int u = 0; u < 4; ++u) rok[u] = (unsigned)(y + u - 2) < (unsigned)a.H ? -1 : 0;
+#pragma unroll
+                for (int v = 0; v < 4; ++v) cok[v] = (unsigned)(xx0 + v - 2) < (unsigned)a.W ? -1 : 0;
+                __builtin_amdgcn_sched_barrier(0);
+                float tv[16];
+#pragma unroll
+                for (int q = 0; q < 16; ++q) {
+                    const float tsum = NH == 2 ? t0[q] + t1[q] : t0[q];
+                    tv[q] = __builtin_bit_cast(float, __builtin_bit_cast(int, tsum) & (rok[q >> 2] & cok[q & 3]));
+                }
+                float s = 0.f;
+#pragma unroll
+                for (int q = 0; q < 16; ++q) s += tv[q];
+                out[o] = s;
+            }
+            continue;
+        }
         for (int o = threadIdx.x; o < OO; o += nthreads) {
             const int y = fdiv(o, inv_ow), xx0 = o - y * a.OW;
             float tv[16];
@@ -458,6 +529,9 @@ __global__ __launch_bounds__(1024, (NK <= 8 && NH == 2 ? PT_C2_MINW : 4)) void k
             float s = 0.f;
 #pragma unroll
             for (int q = 0; q < 16; ++q) s += tv[q];
+#if defined(PT_C2_EXP) && PT_C2_EXP == 1
+            s = T0[o];                                               // ABLATION (wrong results, timing only): no shift-and-add
+#endif
             out[o] = s;
         }
       }
@@ -494,6 +568,7 @@ int pt_launch_corr2(const PtFast& p, const float* feat, long stride_n, const flo
     a.feat = (pt_gcf)feat; a.stride_n = stride_n; a.filt = (pt_gcf)filt; a.spart = (pt_gf)spart;
     a.n = p.n; a.C = p.C; a.H = p.H; a.W = p.W; a.KH = p.KH; a.KW = p.KW; a.OH = p.OH; a.OW = p.OW;
     a.CX = p.CX; a.TF = p.TF; a.rem = p.rem; a.tiles = p.tiles; a.HWp = p.HWp; a.nh = p.nh; a.KSC = p.KSC;
+    a.sa_direct = p.sa_direct;
     a.gpart = nullptr; a.KSPL = 0; a.w = nullptr; a.reg = 0.f; a.g_out = nullptr; a.anum_part = nullptr;
     if (fuse) {
         a.gpart = (pt_gcf)fuse->gpart; a.KSPL = fuse->KSPL; a.w = (pt_gcf)fuse->w; a.reg = fuse->reg; a.g_out = (pt_gf)fuse->g_out;
@@ -618,16 +693,18 @@ __device__ __forceinline__ void sdp_load_rest(const A& a, int i, int lane, bool 
     const int OO = a.OH * a.OW;
     const long base = (long)i * OO;
     // t == 0: there is no F g yet; astep is 0 and any finite operand does
-    const pt_gcf sgp = a.t > 0 ? (pt_gcf)a.sd.sg : a.sd.s_in;
+    // (global-qualified accesses: a flat operation in front of the LDS-only barriers would have to be waited for, see pt_lds_barrier)
+    const auto sgp = a.t > 0 ? pt_global((const float*)a.sd.sg) : pt_global((const float*)a.sd.s_in);
     if (V == V_DIMP_BENT) {
 #pragma unroll
-        for (int e = 0; e < E; ++e) r.sw[e] = a.sd.sws[base + min(lane + 64 * e, OO - 1)];
+        for (int e = 0; e < E; ++e) r.sw[e] = pt_global((const float*)a.sd.sws)[base + min(lane + 64 * e, OO - 1)];
     }
     if (V != V_PLAIN && home) {                                     // uniform per wave
+        const auto sin = pt_global((const float*)a.sd.s_in);
 #pragma unroll
         for (int e = 0; e < E; ++e) {
             const long q = base + min(lane + 64 * e, OO - 1);
-            r.s[e] = a.sd.s_in[q];
+            r.s[e] = sin[q];
             r.sg[e] = sgp[q];
         }
     }
@@ -673,7 +750,7 @@ __device__ __forceinline__ void sdp_compute(const A& a, int i, int lane, const P
             val[e] = der * (r.sw[e] * (r.sw[e] * (act - L)));
         }
     } else {
-        const float swp = sd.has_sw ? sd.sw[i] : 1.0f / (float)sd.n;                // :387-390
+        const float swp = sd.has_sw ? pt_global((const float*)sd.sw)[i] : 1.0f / (float)sd.n;   // :387-390
         float sv[E];
         float mx = sd.has_softmax_reg ? sd.softmax_reg : -INFINITY;
 #pragma unroll
@@ -713,9 +790,9 @@ __device__ __forceinline__ void sdp_compute(const A& a, int i, int lane, const P
 #pragma unroll
         for (int e = 0; e < E; ++e) {
             const int o = lane + 64 * e;
-            if (o < OO) {
-                if (a.t > 0) sd.s[base + o] = r.s[e] - astep * r.sg[e];
-                if (V == V_PRDIMP) sd.mask[base + o] = aux[e];
+            if (o < OO) {                                           // global_store (not flat): the LDS-only barrier behind the update stage
+                if (a.t > 0) pt_global((float*)sd.s)[base + o] = r.s[e] - astep * r.sg[e];   // must not have to wait for these (pt_lds_barrier)
+                if (V == V_PRDIMP) pt_global((float*)sd.mask)[base + o] = aux[e];
             }
         }
         if (a.want_loss) {
@@ -723,7 +800,7 @@ __device__ __forceinline__ void sdp_compute(const A& a, int i, int lane, const P
                 const int sact = V == V_L2 ? 2 : (V == V_DIMP_BENT ? PT_ACT_BENTPAR : PT_ACT_RELU);
 #pragma unroll
                 for (int e = 0; e < E; ++e) {
-                    const f32x4 lm = ((const f32x4*)sd.lms)[base + min(lane + 64 * e, OO - 1)];   // {label, mask, sws, -}
+                    const f32x4 lm = pt_global((const f32x4*)sd.lms)[base + min(lane + 64 * e, OO - 1)];   // {label, mask, sws, -}
                     float act, der;
                     act_pair(sact, sd.act_param, r.s[e] - astep * r.sg[e], lm[1], act, der);
                     const float rr = lm[2] * (act - lm[0]);
@@ -731,7 +808,7 @@ __device__ __forceinline__ void sdp_compute(const A& a, int i, int lane, const P
                 }
                 lacc = wave_sum(lacc);
             }
-            if (lane == 0) sd.lossp[(long)a.t * sd.n + i] = lacc;
+            if (lane == 0) pt_global((float*)sd.lossp)[(long)a.t * sd.n + i] = lacc;
         }
     }
 }
@@ -860,13 +937,13 @@ __global__ __launch_bounds__(PT_ADJ_WAVES * 64) void k_adj2(const float* h_feat,
     if (V != V_PLAIN && a.t > 0) {
         for (int k = lane + 64; k < hn; k += 64) q_in.tail += h_qs[k];          // memories of more than 64 samples
         if (wupd) {                                                 // uniform per workgroup; consumed at the end of the kernel
-            w_prev = sd_w(a.sd, a.t - 1)[wge];
-            g_prev = a.sd.g[wge];
+            w_prev = pt_global((const float*)sd_w(a.sd, a.t - 1))[wge];   // global-qualified: these two stay in flight across both barriers
+            g_prev = pt_global((const float*)a.sd.g)[wge];
         }
     }
     PT_STAMP_A(a, 1);
     PT_STAMP_B(a, 4);
-    __syncthreads();                                                // maps zeroed, quad table written
+    pt_lds_barrier();                                               // maps zeroed, quad table written
     PT_STAMP_A(a, 2);
     PT_STAMP_B(a, 5);
 
@@ -902,7 +979,7 @@ __global__ __launch_bounds__(PT_ADJ_WAVES * 64) void k_adj2(const float* h_feat,
     }
     PT_STAMP_A(a, 3);
     PT_STAMP_B(a, 6);
-    __syncthreads();
+    pt_lds_barrier();                                               // residual maps built (the home waves' result stores stay in flight)
     PT_STAMP_A(a, 4);
 
     // ---- G[c][tap] += feat[c][P] * r[P shifted by tap] over the U contiguous 16-position groups of this wave.
@@ -921,8 +998,16 @@ __global__ __launch_bounds__(PT_ADJ_WAVES * 64) void k_adj2(const float* h_feat,
                 const f32x2a4 hi = *(const f32x2a4*)((const char*)maps + ((unsigned)cell[u][2] + tapoff4));
                 bv[u][0] = lo[0]; bv[u][1] = lo[1]; bv[u][2] = hi[0]; bv[u][3] = hi[1];
             } else {
+#if defined(PT_ADJ_EXP) && PT_ADJ_EXP == 1
+                // ABLATION (wrong results, timing only; profiles/r06l_*): the four scalar gathers of a group as ONE aligned 16-byte read -- what a
+                // layout with four shifted copies of every residual map could reach at best
+                const f32x4 qv = *(const f32x4*)__builtin_assume_aligned((const char*)maps + (((unsigned)cell[u][0] + tapoff4) & ~15u), 16);
+#pragma unroll
+                for (int k = 0; k < 4; ++k) bv[u][k] = qv[k];
+#else
 #pragma unroll
                 for (int k = 0; k < 4; ++k) bv[u][k] = *(const float*)((const char*)maps + ((unsigned)cell[u][k] + tapoff4));
+#endif
             }
         };
         cells(0);

@@ -65,6 +65,7 @@ struct PtFast {
     int n, C, H, W, KH, KW, OH, OW, HW, KK, OO, Q;
     int CX, NK, TF, rem, tiles, left, HWp, corr_threads, nh;   // corr2: grid KSC*n/spw, waves = spw samples x nh halves x tiles
     int spw;                                                    // samples per k_corr2 workgroup (2: sample pairs, see pt_fast_plan)
+    int sa_direct;                                              // k_corr2's 4x4 shift-and-add may use uniform tap steps (LDS slack guaranteed)
     int KSC;                                                    // channel ranges = partial score maps per sample: 8 (one per XCD) or 16
     size_t corr_lds;
     int CB, bpx, NG, KSPL, gper, U, PH, PW, ns_max, E, zn; // adj2: grid CB*KSPL, 8 waves x U contiguous groups; zero block
