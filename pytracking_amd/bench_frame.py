@@ -36,10 +36,14 @@ class TrackState:
         p.alpha_eps = float(c["alpha_eps"])
         if kind == "dimp":
             p.kind = _lib.PT_SD_DIMP
-            self._luts = [torch.from_numpy(a).to(dev) for a in (
+            # ONE contiguous array (label | mask | spatial): the init stage then requests the tables with its first loads (k_fast_init2: lut3)
+            lut3 = torch.from_numpy(np.concatenate((
                 synth.gauss_lut(c["num_dist_bins"], c["bin_displacement"], c["init_gauss_sigma"]),
                 synth.mask_lut(c["num_dist_bins"], c["bin_displacement"], c["mask_init_factor"], c["mask_act"]),
-                np.ones(c["num_dist_bins"], np.float32))]
+                np.ones(c["num_dist_bins"], np.float32))).astype(np.float32)).to(dev)
+            nb = c["num_dist_bins"]
+            self._lut3 = lut3
+            self._luts = [lut3[0:nb], lut3[nb:2 * nb], lut3[2 * nb:3 * nb]]
             p.num_bins = c["num_dist_bins"]
             p.bin_displacement = float(c["bin_displacement"])
             p.label_lut, p.mask_lut, p.spatial_lut = (t.data_ptr() for t in self._luts)

@@ -409,6 +409,9 @@ __global__ __launch_bounds__(1024) void k_fast_sgq2(const float* __restrict__ sp
 // label / mask / weight maps (optimizer.py:111-125, 201-208, 331-353); packed operands for k_adj2.
 // Scalar kernel parameters (preloaded) = what the first loads need; the rest in the late block.
 //   pa = n | OO << 16;  pb = KS | kind << 8 | cls_slot << 12 (0xfffff: none);  pc = OW | K << 12 | num_bins << 16
+#ifndef PT_INIT_LUT_HOT
+#define PT_INIT_LUT_HOT 1      // 0 (A/B builds): always take the look-up tables through the late argument block
+#endif
 struct InitLate {
     pt_gcf label_lut, mask_lut, spatial_lut;
     pt_gf s, label, mask, sws, lms, pk, cls_scores, cls_peak, cls_bb;
@@ -416,11 +419,14 @@ struct InitLate {
     float bin_disp, gauss_sigma, hinge_thr, uni_weight, label_shrink, label_thr;
 };
 static_assert(sizeof(InitLate) <= 3 * 64, "InitLate: three 16-dword blocks");
+//   lut3 (preloaded; round 6): the three DiMP look-up tables as ONE contiguous array (label | mask | spatial, 3 x num_bins) when the caller
+//   keeps them that way -- their loads then leave with the first ones instead of behind the late argument block (one round trip less in
+//   front of the maps); null: the three pointers of the late block
 //   slot_dyn (preloaded like the other scalars): when non-null the classification slot comes from this device int instead of pb -- the
 //   graph-replayed one-call frame (frame_full.hip) cannot bake a per-frame slot into its captured launches
 __global__ __launch_bounds__(1024) void k_fast_init2(const float* __restrict__ spart, const float* __restrict__ bb, const float* __restrict__ swp_,
-                                                     const int* __restrict__ slot_dyn, unsigned pa, unsigned pb, unsigned pc, float feat_stride,
-                                                     InitLate l_arg) {
+                                                     const int* __restrict__ slot_dyn, const float* __restrict__ lut3, unsigned pa, unsigned pb,
+                                                     unsigned pc, float feat_stride, InitLate l_arg) {
     extern __shared__ __attribute__((aligned(16))) float lut[];    // DiMP: label | mask | spatial look-up tables
     __shared__ float scratch[16];
     __shared__ float bv[16];
@@ -447,9 +453,15 @@ __global__ __launch_bounds__(1024) void k_fast_init2(const float* __restrict__ s
     const float* bp = bb + 4 * i;
     float b0 = bp[0], b1 = bp[1], b2 = bp[2], b3 = bp[3];
     const float swv = swp_ ? swp_[i] : 1.0f / (float)n;
+    const bool lut_hot = kind == PT_SD_DIMP && lut3 != nullptr;     // uniform
+    float lv0 = 0.f;
+    if (lut_hot) lv0 = lut3[min(o, 3 * num_bins - 1)];
     __builtin_amdgcn_sched_barrier(0);
-    const InitLate l = pt_late_args<InitLate>(48);                  // 4 pointers + 4 dwords = 48 bytes
-    if (kind == PT_SD_DIMP) {
+    const InitLate l = pt_late_args<InitLate>(56);                  // 5 pointers + 4 dwords = 56 bytes
+    if (lut_hot) {
+        if (o < 3 * num_bins) lut[o] = lv0;
+        for (int e = o + nthreads; e < 3 * num_bins; e += nthreads) lut[e] = lut3[e];      // tables longer than the block
+    } else if (kind == PT_SD_DIMP) {
         for (int e = o; e < 3 * num_bins; e += nthreads) {
             const int t = e / num_bins, k = e - t * num_bins;
             lut[e] = (t == 0 ? l.label_lut : (t == 1 ? l.mask_lut : l.spatial_lut))[k];
@@ -685,7 +697,10 @@ static int sd_solve_fast(const PtFast& f, const pt_sd_params* prm, const float* 
         il.label_shrink = a.label_shrink; il.label_thr = a.label_thr;
         const unsigned cslot = (a.cls_spart && a.cls_slot >= 0) ? (unsigned)a.cls_slot : 0xfffffu;
         hipLaunchKernelGGL(k_fast_init2, dim3(n), dim3(pw_threads), lut_lds, st, (const float*)a.spart, a.bb, a.has_sw ? a.sw : (const float*)nullptr,
-                           a.cls_slot_dyn, (unsigned)n | ((unsigned)a.OO << 16), (unsigned)a.KS | ((unsigned)a.kind << 8) | (cslot << 12),
+                           a.cls_slot_dyn,
+                           (PT_INIT_LUT_HOT && a.kind == PT_SD_DIMP && a.mask_lut == a.label_lut + a.num_bins &&
+                            a.spatial_lut == a.label_lut + 2 * a.num_bins) ? a.label_lut : (const float*)nullptr,
+                           (unsigned)n | ((unsigned)a.OO << 16), (unsigned)a.KS | ((unsigned)a.kind << 8) | (cslot << 12),
                            (unsigned)a.OW | ((unsigned)a.K << 12) | ((unsigned)(a.kind == PT_SD_DIMP ? a.num_bins : 0) << 16), a.feat_stride, il);
     }
     else if (a.cls_slot_dyn) return PT_ERR_UNSUPPORTED;             // (refused before the first correlation: see below)

@@ -132,6 +132,7 @@ def refresh_host_scalars(mod):
     parameter through `.data`, e.g. `opt.filter_reg.data.fill_(x)`)."""
     for m in mod.modules():
         m.__dict__.pop("_host_scalars", None)
+        m.__dict__.pop("_lut3_cache", None)
 
 
 class _ScalarCacheMixin:
@@ -139,11 +140,35 @@ class _ScalarCacheMixin:
 
     def _load_from_state_dict(self, *args, **kw):
         self.__dict__.pop("_host_scalars", None)
+        self.__dict__.pop("_lut3_cache", None)
         return super()._load_from_state_dict(*args, **kw)
 
     def _apply(self, fn, *args, **kw):
         self.__dict__.pop("_host_scalars", None)
+        self.__dict__.pop("_lut3_cache", None)
         return super()._apply(fn, *args, **kw)
+
+
+def _contiguous_luts(mod, weights):
+    """The look-up tables of the DiMP optimiser (three 1x1-conv weights, optimizer.py:45-72) as views of ONE contiguous float32 array
+    (label | mask | spatial): the solver's init stage then requests them with its first loads (k_fast_init2, `lut3`) instead of behind its
+    late argument block.  Concatenated once and reused while the weights are unchanged -- same invalidation rules as `_host_scalar`
+    (version counters; `refresh_host_scalars` after a write through `.data`); tables of different lengths stay separate tensors."""
+    ws = [w.detach() for w in weights]
+    if len({w.numel() for w in ws}) != 1:
+        return [w.to(torch.float32).contiguous().reshape(-1) for w in ws]
+    try:
+        key = tuple((w.data_ptr(), w._version, str(w.device), w.dtype) for w in weights)
+    except RuntimeError:                                   # inference tensors do not track versions
+        key = None
+    hit = mod.__dict__.get("_lut3_cache") if key is not None else None
+    if hit is None or hit[0] != key:
+        buf = torch.cat([w.to(torch.float32).reshape(-1) for w in ws]).contiguous()
+        hit = (key, buf)
+        if key is not None:
+            mod.__dict__["_lut3_cache"] = hit
+    n = ws[0].numel()
+    return [hit[1][k * n:(k + 1) * n] for k in range(3)]
 
 
 def _reg_value(mod):
@@ -186,8 +211,8 @@ class DiMPSteepestDescentGN(_ScalarCacheMixin, nn.Module):
 
     def forward(self, weights, feat, bb, sample_weight=None, num_iter=None, compute_losses=True):
         num_iter = self.num_iter if num_iter is None else num_iter
-        luts = [m.weight.detach().to(torch.float32).contiguous().reshape(-1) for m in
-                (self.label_map_predictor, self.target_mask_predictor[0], self.spatial_weight_predictor)]
+        luts = _contiguous_luts(self, (self.label_map_predictor.weight, self.target_mask_predictor[0].weight,
+                                       self.spatial_weight_predictor.weight))
         p = _lib.SdParams()
         p.kind = _lib.PT_SD_DIMP
         p.step_length = math.exp(_host_scalar(self, "log_step_length"))

@@ -39,6 +39,11 @@ def test_roofline_object_from_graph_and_eager_tables():
     assert r3["stream_floor_us"] == 3.7 and abs(r3["frac_of_floor"] - 3.7 / r3["avg_launch_us"]) < 1e-3
     assert r3["stream_floor"]["stream_floor_period_us"] == 4.4 and r3["stream_floor"]["stream_floor_GBs"] > 8000
     assert abs(r3["sum_kernels_us_per_frame"]["graph"] - want) < 0.02          # the probe launches are not part of a frame
+    # chained frames (round 6): k_fast_final only in the flushes -- the frame count comes from the init stage
+    ch = _stats(8200.0, 7600.0, 200)
+    ch["k_fast_final(float const*)"] = (10, 5000.0)
+    r5 = bench.roofline(cfg, "dimp50", n, {"corr": 8.1, "adj": 7.6}, ch, "", None)
+    assert abs(r5["sum_kernels_us_per_frame"]["graph"] - (want - 5.0 + 10 * 5.0 / 200)) < 0.02
     r4 = bench.roofline(cfg, "dimp50", n, {"corr": 8.1, "adj": 7.6}, None, "x", None, floor_period_us=4.4)
     assert r4["stream_floor_us"] == 4.4 and r["stream_floor_us"] is None
     # no trace at all: the event period (pessimistic by one launch boundary) carries the fraction and `timing` says so
