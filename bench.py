@@ -78,6 +78,10 @@ def make_pool(cfg, seed, device):
 # flush, so every graph / every eager call of run_frames leaves the complete state.  Same bits as the plain frame
 # (tests/test_gpu_parity.py::test_frame_chain_deferred_last_update_is_bit_identical).  PT_BENCH_NO_CHAIN=1: the round-5 launch sequence.
 CHAIN = os.environ.get("PT_BENCH_NO_CHAIN", "") != "1"
+# Closing side of the timed bracket: PT_BENCH_SPIN=1 polls an event recorded behind the K frames before the contract's
+# stream.synchronize() + torch.cuda.synchronize() (which then return at once) -- experiment: is the blocking wait's wake-up latency part
+# of the 2 ms driver-style region?  (profiles/r06n_*)
+SPIN_WAIT = os.environ.get("PT_BENCH_SPIN", "0") == "1"
 
 
 def run_frames(st, pool, first, count):
@@ -599,6 +603,11 @@ def main():
         sync_all()
         t0 = time.perf_counter()
         advance(Wm, K)
+        if SPIN_WAIT and not dry:                              # poll for completion, THEN the contract's synchronize (returns at once)
+            done = torch.cuda.Event()
+            done.record(stream)
+            while not done.query():
+                pass
         stream.synchronize()
         sync_all()
         elapsed = time.perf_counter() - t0                     # this rank's K frames; the job's time is the MAX over ranks (gather below)
@@ -617,6 +626,11 @@ def main():
                 stream.synchronize()
                 t1 = time.perf_counter()
                 advance(Wm, K)
+                if SPIN_WAIT and not dry:
+                    done = torch.cuda.Event()
+                    done.record(stream)
+                    while not done.query():
+                        pass
                 stream.synchronize()
                 repeats.append(round(1e6 * (time.perf_counter() - t1) / K, 2))
 

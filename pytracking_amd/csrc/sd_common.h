@@ -53,6 +53,25 @@ __device__ __forceinline__ float pl_lut(const float* __restrict__ w, int bins, f
     return w[k0] * (1.0f - fr) + w[k0 + 1] * fr;
 }
 
+// Label / mask / sample-weight map values of ONE element of the DiMP kinds (optimizer.py:111-125 / :201-208, :245, :249-252), given its
+// offset (d0, d1) from the target centre and the sample weight swv.  Shared by the init stage (k_fast_init2) and by the first adjoint
+// pass when it builds the maps itself (k_adj2<.., INIT>, fast_passes.hip): one body, so the two produce the same bits.
+__device__ __forceinline__ void sd_init_elem_dimp(const float* __restrict__ lut, int num_bins, int mask_act, float bin_disp, float d0, float d1,
+                                                  float swv, float& lb, float& m, float& sw) {
+    const float t = sqrtf(d0 * d0 + d1 * d1) / bin_disp;
+    lb = pl_lut(lut, num_bins, t);
+    m = pl_lut(lut + num_bins, num_bins, t);
+    if (mask_act == PT_MASK_SIGMOID) m = 1.0f / (1.0f + expf(-m));
+    sw = sqrtf(swv) * pl_lut(lut + 2 * num_bins, num_bins, t);                      // :122-125
+}
+__device__ __forceinline__ void sd_init_elem_l2(float gauss_sigma, float hinge_thr, float d0, float d1, float swv, float& lb, float& m, float& sw) {
+    const float coef = -1.0f / (2.0f * gauss_sigma * gauss_sigma);
+    const float gss = expf(coef * d0 * d0) * expf(coef * d1 * d1);                  // :201-208
+    m = gss > hinge_thr ? 1.0f : 0.0f;                                              // :245
+    lb = gss * m;
+    sw = sqrtf(swv);                                                                // :249-252
+}
+
 // sums the classification partials, finds the first maximum (torch.max semantics, pytracking/libs/dcf.py:156-164)
 // and re-centres the box of memory slot `cls_slot` on it (inverse of the centre formula of optimizer.py:112-113).
 __device__ void sd_classify_fin(const SdArgs& a) {

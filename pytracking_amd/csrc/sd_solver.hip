@@ -511,17 +511,9 @@ __global__ __launch_bounds__(1024) void k_fast_init2(const float* __restrict__ s
     const float d0 = (float)y - ctr_r, d1 = (float)x - ctr_c;
     float lb, m = 0.f, sw = 0.f;
     if (kind == PT_SD_DIMP) {
-        const float t = sqrtf(d0 * d0 + d1 * d1) / l.bin_disp;
-        lb = pl_lut(lut, num_bins, t);
-        m = pl_lut(lut + num_bins, num_bins, t);
-        if (l.mask_act == PT_MASK_SIGMOID) m = 1.0f / (1.0f + expf(-m));
-        sw = sqrtf(swv) * pl_lut(lut + 2 * num_bins, num_bins, t);                  // :122-125
+        sd_init_elem_dimp(lut, num_bins, l.mask_act, l.bin_disp, d0, d1, swv, lb, m, sw);
     } else if (kind == PT_SD_DIMP_L2) {
-        const float coef = -1.0f / (2.0f * l.gauss_sigma * l.gauss_sigma);
-        const float gss = expf(coef * d0 * d0) * expf(coef * d1 * d1);              // :201-208
-        m = gss > l.hinge_thr ? 1.0f : 0.0f;                                        // :245
-        lb = gss * m;
-        sw = sqrtf(swv);                                                            // :249-252
+        sd_init_elem_l2(l.gauss_sigma, l.hinge_thr, d0, d1, swv, lb, m, sw);
     } else {                                                                        // PrDiMP label density, :331-353
         float gss;
         if (l.gauss_sigma == 0.f) {
