@@ -715,6 +715,121 @@ __device__ __forceinline__ void sdp_load(const A& a, const float* __restrict__ p
     sdp_load_rest<V, E>(a, i, lane, home, r);
 }
 
+// ---- Fused init stage (round 6, experiment O): the FIRST adjoint pass of a solve builds the label / mask / weight maps itself ----------
+// The init stage (k_fast_init2, sd_solver.hip) sums the channel-range slices of s_0 = F w, re-centres the box of the classification slot on
+// the arg-max and evaluates the maps -- all per sample, nothing global -- and its only hurry is the first adjoint pass, whose update
+// stage has one wave per sample anyway.  k_adj2<.., INIT = true> takes the slices / the boxes / the look-up tables through the three
+// preloaded pointers the t > 0 launches use for (pk, qs, anum), forms the packed operands in registers and lets the sample's home wave
+// store what the later stages read (s_0, label, mask, sws, lms, classification outputs): one dependent launch less per frame.
+// Every workgroup of a position slice redoes the maps of its <= 8 samples (32 channel blocks: L2 traffic, no HBM traffic).
+// DiMP kinds only (PrDiMP's label needs a block-wide normalisation); <= 8 slices; tables of <= 127 bins in one contiguous array.
+struct Adj2InitLate {                                              // 16 dwords: ONE scalar load, fetched behind Adj2Late
+    pt_gf label, cls_scores, cls_peak, cls_bb;
+    const int* slot_dyn;
+    int slot, mask_act;
+    float feat_stride, bin_disp, gauss_sigma, hinge_thr;
+};
+static_assert(sizeof(Adj2InitLate) == 64, "Adj2InitLate: one 16-dword block");
+#define PT_INIT_MAXKS 8
+template <int E>
+struct IReg { float sl[E][PT_INIT_MAXKS]; float bb[4]; };
+
+// hot part: the slices of s_0 and the box of sample i, through preloaded pointers.  Slice k in the scalar offset of the buffer load.
+template <int E>
+__device__ __forceinline__ void sdi_load_hot(const float* __restrict__ spart, const float* __restrict__ bb, int n, int OO, int KS, int i, int lane,
+                                             IReg<E>& r) {
+    const unsigned stb = (unsigned)n * (unsigned)OO * 4u;
+    const __amdgpu_buffer_rsrc_t rs = pt_rsrc(spart, (unsigned)KS * stb);
+#pragma unroll
+    for (int e = 0; e < E; ++e) {
+        const unsigned vo = ((unsigned)i * (unsigned)OO + (unsigned)min(lane + 64 * e, OO - 1)) * 4u;
+#pragma unroll
+        for (int k = 0; k < PT_INIT_MAXKS; ++k)
+            r.sl[e][k] = __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(rs, vo, (unsigned)min(k, KS - 1) * stb, 0));
+    }
+#pragma unroll
+    for (int k = 0; k < 4; ++k) r.bb[k] = bb[4 * i + k];
+}
+
+// s_0, classification epilogue (pytracking/libs/dcf.py:156-164: first maximum), maps (optimizer.py:111-125 / :201-252) -> packed operands
+// of the update stage, exactly as k_fast_init2 forms them; `lutl`: the look-up tables in LDS.
+template <int V, int E, typename A>
+__device__ __forceinline__ void sdi_make(const A& a, const Adj2InitLate& il, const float* __restrict__ lutl, int num_bins, int KS, int i, int lane,
+                                         bool home, const IReg<E>& ir, PReg<E>& r) {
+    const int OO = a.OH * a.OW;
+    const long base = (long)i * OO;
+    const float inv_ow = 1.0f / (float)a.OW;
+    float s0[E];
+#pragma unroll
+    for (int e = 0; e < E; ++e) {
+        float sm = 0.f;
+#pragma unroll
+        for (int k = 0; k < PT_INIT_MAXKS; ++k) sm += k < KS ? ir.sl[e][k] : 0.f;   // fixed order
+        s0[e] = sm;
+    }
+    float b0 = ir.bb[0], b1 = ir.bb[1];
+    const float b2 = ir.bb[2], b3 = ir.bb[3];
+    const float off = (float)(a.KH % 2) * 0.5f;
+    const int slot = il.slot_dyn ? *pt_global(il.slot_dyn) : il.slot;
+    if (i == slot) {                                                // uniform per wave
+        float best = -INFINITY;
+        int besti = 0x7fffffff;
+#pragma unroll
+        for (int e = 0; e < E; ++e) {
+            const int o = lane + 64 * e;
+            if (o < OO && (s0[e] > best || (s0[e] == best && o < besti))) { best = s0[e]; besti = o; }
+        }
+#pragma unroll
+        for (int sh = 32; sh > 0; sh >>= 1) {
+            const float ov = __shfl_xor(best, sh, 64);
+            const int oi = __shfl_xor(besti, sh, 64);
+            if (ov > best || (ov == best && oi < besti)) { best = ov; besti = oi; }
+        }
+        const int row = besti / a.OW, col = besti - row * a.OW;
+        b0 = ((float)col + off) * il.feat_stride - b2 * 0.5f;
+        b1 = ((float)row + off) * il.feat_stride - b3 * 0.5f;
+        if (home) {
+            if (lane == 0) {
+                pt_global((float*)il.cls_peak)[0] = (float)row;
+                pt_global((float*)il.cls_peak)[1] = (float)col;
+                pt_global((float*)il.cls_bb)[4 * slot] = b0;
+                pt_global((float*)il.cls_bb)[4 * slot + 1] = b1;
+            }
+#pragma unroll
+            for (int e = 0; e < E; ++e)
+                if (lane + 64 * e < OO) pt_global((float*)il.cls_scores)[lane + 64 * e] = s0[e];
+        }
+    }
+    const float ctr_r = (b1 + b3 * 0.5f) / il.feat_stride - off;   // optimizer.py:112-113 (flip -> row first)
+    const float ctr_c = (b0 + b2 * 0.5f) / il.feat_stride - off;
+    const float swv = a.sd.has_sw ? pt_global((const float*)a.sd.sw)[i] : 1.0f / (float)a.sd.n;
+#pragma unroll
+    for (int e = 0; e < E; ++e) {
+        const int o = lane + 64 * e, oc = min(o, OO - 1);
+        const int y = fdiv(oc, inv_ow), x = oc - y * a.OW;
+        const float d0 = (float)y - ctr_r, d1 = (float)x - ctr_c;
+        float lb, m, sw;
+        if (V == V_L2) sd_init_elem_l2(il.gauss_sigma, il.hinge_thr, d0, d1, swv, lb, m, sw);
+        else sd_init_elem_dimp(lutl, num_bins, il.mask_act, il.bin_disp, d0, d1, swv, lb, m, sw);
+        if (V == V_DIMP_BENT) {
+            r.pk[e] = (f32x4){s0[e], 0.f, lb, m};
+            r.sw[e] = sw;
+        } else {
+            const float w2 = sw * sw;
+            r.pk[e] = (f32x4){w2 * s0[e], w2 * 0.f, w2 * lb, m};
+        }
+        r.s[e] = s0[e];
+        r.sg[e] = 0.f;
+        if (home && o < OO) {                                       // what the later stages read (k_fast_sgq2: s, lms; bentpar passes: sws)
+            pt_global((float*)a.sd.s)[base + o] = s0[e];
+            pt_global((float*)il.label)[base + o] = lb;
+            pt_global((float*)a.sd.mask)[base + o] = m;
+            pt_global((float*)a.sd.sws)[base + o] = sw;
+            pt_global((f32x4*)a.sd.lms)[base + o] = (f32x4){lb, m, sw, 0.f};
+        }
+    }
+}
+
 // Update stage of the steepest-descent iteration for sample i, executed by one wave
 // (optimizer.py:137-146,160 / :403-408,430): s_t = s_{t-1} - step*alpha*(F g); residual map -> zero-padded LDS map;
 // the owning workgroup (`home`) also stores s_t (and the PrDiMP softmax) and the sample's loss term.
@@ -814,9 +929,13 @@ __device__ __forceinline__ void sdp_compute(const A& a, int i, int lane, const P
 }
 
 // UM: 16-position groups per wave (compile-time trip count of the pipelined loop; 12 for the 22x22 PrDiMP geometry)
-template <int V, int E, int UM>
+//   INIT (round 6): the launch of iterate 0 also does the init stage -- h_pk = slices of s_0, h_qs = boxes, h_anum = the three look-up
+//   tables as one array (null: L2 kind), the `t` bits of h_g1 carry num_bins (t is 0); see sdi_make above.  i_arg is only read by
+//   the INIT instantiations (same signature for all: the late-fetch offsets are checked against the code object's metadata)
+template <int V, int E, int UM, bool INIT = false>
 __global__ __launch_bounds__(PT_ADJ_WAVES * 64) void k_adj2(const float* h_feat, long h_stride, const float* h_pk, const float* h_qs, const float* h_anum, unsigned h_g1,
-                                                                unsigned h_g2, unsigned h_g3, unsigned h_g4, Adj2Late a_arg) {
+                                                                unsigned h_g2, unsigned h_g3, unsigned h_g4, Adj2Late a_arg,
+                                                                Adj2InitLate i_arg) {
     // h_*: everything up to the first barrier, as scalar kernel parameters preloaded into SGPRs at wave launch (14 dwords; the
     // argument block arrives by scalar loads ~1.2 us later -- see k_corr2 -- and is fetched behind the prologue, pt_late_issue):
     //   h_pk = packed update-stage operands (V_PLAIN: the input maps);
@@ -827,7 +946,8 @@ __global__ __launch_bounds__(PT_ADJ_WAVES * 64) void k_adj2(const float* h_feat,
     PT_STAMP_A(a_arg, 0);
     PT_STAMP_B(a_arg, 0);
     const int hH = (int)(h_g1 & 255u), hW = (int)((h_g1 >> 8) & 255u), hU = (int)((h_g1 >> 16) & 31u), hbpx = (int)((h_g1 >> 21) & 15u);
-    const int ht = (int)(h_g1 >> 25);
+    const int ht = INIT ? 0 : (int)(h_g1 >> 25);
+    const int h_bins = INIT ? (int)(h_g1 >> 25) : 0;
     const int hn = (int)(h_g2 & 0xffffu), hgper = (int)(h_g2 >> 16);
     const int hOO = (int)(h_g3 & 0xffffu), hC = 16 * (int)((h_g3 >> 16) & 255u), hKS = (int)((h_g3 >> 24) & 127u);
     const int hPH = (int)(h_g4 & 63u), hPW = (int)((h_g4 >> 6) & 63u), hzn = (int)((h_g4 >> 12) & 255u), hns_max = (int)((h_g4 >> 20) & 63u);
@@ -876,7 +996,15 @@ __global__ __launch_bounds__(PT_ADJ_WAVES * 64) void k_adj2(const float* h_feat,
     const bool have = wave < ns;
     const int hg0 = ((i_lo + wave) * HW) >> 4;                      // the slice holding a sample's first group owns it
     const bool home0 = have && cb == 0 && hg0 >= gbeg && hg0 < gend;
-    sdp_load_hot<V, E>(h_pk, hOO, i_lo + min(wave, ns - 1), lane, pr);
+    IReg<INIT ? E : 1> ir;
+    float lutv = 0.f;
+    if constexpr (INIT) {
+        // the table element first: the counter retires in order, and the tables are staged into LDS in front of the first barrier
+        if (V != V_L2) lutv = h_anum[min((int)threadIdx.x, 3 * h_bins - 1)];
+        sdi_load_hot<E>(h_pk, h_qs, hn, hOO, hKS, i_lo + min(wave, ns - 1), lane, ir);
+    } else {
+        sdp_load_hot<V, E>(h_pk, hOO, i_lo + min(wave, ns - 1), lane, pr);
+    }
     float an_in = 0.f;
     SdQLane q_in = {0.f, 0.f};
     if (V != V_PLAIN && ht > 0) {                                   // optimizer.py:155-160 / :425-430 (operands of alpha)
@@ -896,6 +1024,11 @@ __global__ __launch_bounds__(PT_ADJ_WAVES * 64) void k_adj2(const float* h_feat,
     }
     __builtin_amdgcn_sched_barrier(0);                              // nothing that needs the argument block above this line
     PtLate<Adj2Late> late = pt_late_issue<Adj2Late>(56);            // 5 pointers / longs + 4 dwords = 56 bytes
+    PtLate<Adj2InitLate> late_i;
+#ifndef PT_STAMPS
+    static_assert(56 + sizeof(Adj2Late) == 240, "offset of the init block in the kernel-argument segment");
+#endif
+    if constexpr (INIT) late_i = pt_late_issue<Adj2InitLate>(240);
     const int KK = hKH * hKW, PHPW = hPH * hPW;
     const int ZB = hns_max * PHPW;                                  // hzn zeros: what masked quads gather (any tap)
     // residual coordinate of (position (y,x), tap (u,v)) is (y-u+KH/2, x-v+KW/2); in the padded map the residual
@@ -929,8 +1062,14 @@ __global__ __launch_bounds__(PT_ADJ_WAVES * 64) void k_adj2(const float* h_feat,
 #pragma unroll
         for (int k = 0; k < 4; ++k) tabI[4 * e + k] = 4 * (okk ? base + k + (x0 + k >= hW ? wr : 0) : ZB);
     }
+    float* __restrict__ lutl = (float*)(tabI + 16 * PT_ADJ_WAVES * UM);   // INIT: look-up tables behind the quad table
+    if constexpr (INIT) {
+        if (V != V_L2 && (int)threadIdx.x < 3 * h_bins) lutl[threadIdx.x] = lutv;
+    }
     const Adj2Late a = pt_late_get<Adj2Late>(late);
-    sdp_load_rest<V, E>(a, i_lo + min(wave, ns - 1), lane, home0, pr);
+    Adj2InitLate il;
+    if constexpr (INIT) il = pt_late_get<Adj2InitLate>(late_i);
+    else sdp_load_rest<V, E>(a, i_lo + min(wave, ns - 1), lane, home0, pr);
     const bool wupd = V != V_PLAIN && a.t > 0 && ks == 0;
     const long wge = (long)cb * 16 * KK + min((int)threadIdx.x, 16 * KK - 1);
     float w_prev = 0.f, g_prev = 0.f;
@@ -969,12 +1108,20 @@ __global__ __launch_bounds__(PT_ADJ_WAVES * 64) void k_adj2(const float* h_feat,
         const float den = fmaxf(wave_sum(q_in.head + q_in.tail) + (a.sd.reg + a.sd.alpha_eps) * a_num, 1e-8f);
         astep = a.sd.step * (a_num / den);
     }
+    if constexpr (INIT) {
+        if (have) sdi_make<V, E>(a, il, lutl, h_bins, hKS, i_lo + wave, lane, home0, ir, pr);
+    }
     if (have) sdp_compute<V, E>(a, i_lo + wave, lane, pr, astep, maps + wave * PHPW, oy, ox, home0);
     for (int sl = wave + PT_ADJ_WAVES; sl < ns; sl += PT_ADJ_WAVES) {   // more samples than waves (tiny maps)
         const int i = i_lo + sl;
         const int hg = (i * HW) >> 4;
         const bool home = cb == 0 && hg >= gbeg && hg < gend;
-        sdp_load<V, E>(a, h_pk, i, lane, home, pr);
+        if constexpr (INIT) {
+            sdi_load_hot<E>(h_pk, h_qs, hn, hOO, hKS, i, lane, ir);
+            sdi_make<V, E>(a, il, lutl, h_bins, hKS, i, lane, home, ir, pr);
+        } else {
+            sdp_load<V, E>(a, h_pk, i, lane, home, pr);
+        }
         sdp_compute<V, E>(a, i, lane, pr, astep, maps + sl * PHPW, oy, ox, home);
     }
     PT_STAMP_A(a, 3);
@@ -1054,13 +1201,26 @@ static void adj2_fill(const PtFast& p, Adj2Args& a, const float* feat, long stri
     PT_STAMP_SET(a);
 }
 
+// Can the first adjoint pass of this solve do the init stage itself (k_adj2<.., INIT>)?
+bool pt_adj2_init_fusable(const PtFast& p, const SdArgs& sd) {
+    if (sd.kind != PT_SD_DIMP && sd.kind != PT_SD_DIMP_L2) return false;
+    if (p.E > 9 || sd.KS > PT_INIT_MAXKS || PT_ADJ_WAVES != 8) return false;
+    if (sd.kind == PT_SD_DIMP) {
+        if (sd.num_bins < 1 || sd.num_bins > 127 || 3 * sd.num_bins > PT_ADJ_WAVES * 64) return false;
+        if (sd.mask_lut != sd.label_lut + sd.num_bins || sd.spatial_lut != sd.label_lut + 2 * sd.num_bins) return false;   // one array
+    }
+    return (long)sd.KS * sd.n * sd.OO * 4 < (1L << 31);
+}
+
 template <int V>
-static int adj2_dispatch(const PtFast& p, const Adj2Args& a, hipStream_t st) {
+static int adj2_dispatch(const PtFast& p, const Adj2Args& a, hipStream_t st, bool fuse_init = false) {
     dim3 grid(p.CB * p.KSPL), block(PT_ADJ_WAVES * 64);
     if (p.H > 255 || p.W > 255 || p.U > 31 || p.bpx > 15 || a.t > 127 || p.n > 65535 || p.gper > 65535 || p.OO > 65535 || p.CB > 255 ||
         a.sd.KS > 127 || p.PH > 63 || p.PW > 63 || p.zn > 255 || p.ns_max > 63 || p.KH > 7 || p.KW > 7)
         return PT_ERR_UNSUPPORTED;
-    const unsigned g1 = (unsigned)p.H | ((unsigned)p.W << 8) | ((unsigned)p.U << 16) | ((unsigned)p.bpx << 21) | ((unsigned)a.t << 25);
+    // (fused init stage: t is 0 and its bits carry the number of look-up table bins)
+    const unsigned g1 = (unsigned)p.H | ((unsigned)p.W << 8) | ((unsigned)p.U << 16) | ((unsigned)p.bpx << 21) |
+                        ((unsigned)(fuse_init ? (a.sd.kind == PT_SD_DIMP ? a.sd.num_bins : 0) : a.t) << 25);
     const unsigned g2 = (unsigned)p.n | ((unsigned)p.gper << 16);
     const unsigned g3 = (unsigned)p.OO | ((unsigned)p.CB << 16) | ((unsigned)(V == V_PLAIN ? 0 : a.sd.KS) << 24);
     const unsigned g4 = (unsigned)p.PH | ((unsigned)p.PW << 6) | ((unsigned)p.zn << 12) | ((unsigned)p.ns_max << 20) | ((unsigned)p.KH << 26) |
@@ -1080,7 +1240,25 @@ static int adj2_dispatch(const PtFast& p, const Adj2Args& a, hipStream_t st) {
 #ifdef PT_STAMPS
     l.stamps = a.stamps;
 #endif
-#define PT_A2_HOT a.feat, a.stride_n, pkp, qsp, anp, g1, g2, g3, g4, l
+    if constexpr (V == V_DIMP_RELU || V == V_DIMP_BENT || V == V_L2) {
+        if (fuse_init) {
+            if (!pt_adj2_init_fusable(p, sd) || a.t != 0 || a.want_loss) return PT_ERR_UNSUPPORTED;
+            Adj2InitLate il;
+            il.label = (pt_gf)sd.label; il.cls_scores = (pt_gf)sd.cls_scores; il.cls_peak = (pt_gf)sd.cls_peak; il.cls_bb = (pt_gf)sd.cls_bb;
+            il.slot_dyn = sd.cls_slot_dyn; il.slot = (sd.cls_spart && sd.cls_slot >= 0) ? sd.cls_slot : -1; il.mask_act = sd.mask_act;
+            il.feat_stride = sd.feat_stride; il.bin_disp = sd.bin_disp; il.gauss_sigma = sd.gauss_sigma; il.hinge_thr = sd.hinge_thr;
+            const float* lut3 = sd.kind == PT_SD_DIMP ? sd.label_lut : nullptr;
+            const size_t lds = p.adj_lds + (size_t)3 * (sd.kind == PT_SD_DIMP ? sd.num_bins : 0) * sizeof(float);
+#define PT_A2_INIT a.feat, a.stride_n, (const float*)sd.spart, sd.bb, lut3, g1, g2, g3, g4, l, il
+            if (p.E == 6) hipLaunchKernelGGL((k_adj2<V, 6, 16, true>), grid, block, lds, st, PT_A2_INIT);
+            else if (p.U <= 12) hipLaunchKernelGGL((k_adj2<V, 9, 12, true>), grid, block, lds, st, PT_A2_INIT);
+            else if (p.U <= 16) hipLaunchKernelGGL((k_adj2<V, 9, 16, true>), grid, block, lds, st, PT_A2_INIT);
+            else hipLaunchKernelGGL((k_adj2<V, 9, PT_ADJ_UMAX_WIDE, true>), grid, block, lds, st, PT_A2_INIT);
+#undef PT_A2_INIT
+            return PT_OK;
+        }
+    } else if (fuse_init) return PT_ERR_UNSUPPORTED;
+#define PT_A2_HOT a.feat, a.stride_n, pkp, qsp, anp, g1, g2, g3, g4, l, Adj2InitLate{}
     if (p.E == 6 && p.U <= 12 && PT_ADJ_WAVES != 8) hipLaunchKernelGGL((k_adj2<V, 6, 12>), grid, block, p.adj_lds, st, PT_A2_HOT);   // experiment builds only
     else if (p.E == 6) hipLaunchKernelGGL((k_adj2<V, 6, 16>), grid, block, p.adj_lds, st, PT_A2_HOT);
     else if (p.E == 9 && p.U <= 12) hipLaunchKernelGGL((k_adj2<V, 9, 12>), grid, block, p.adj_lds, st, PT_A2_HOT);
@@ -1105,7 +1283,7 @@ int pt_launch_adj2_plain(const PtFast& p, const float* feat, long stride_n, cons
 }
 
 int pt_launch_adj2_sd(const PtFast& p, const float* feat, long stride_n, const SdArgs& sd, int t, int want_loss,
-                      hipStream_t st) {
+                      hipStream_t st, bool fuse_init) {
     if (((uintptr_t)feat % 16) || (stride_n % 4) || (long)p.n * stride_n * 4 >= (1L << 31)) return PT_ERR_UNSUPPORTED;
     Adj2Args a;
     adj2_fill(p, a, feat, stride_n, sd.gpart);
@@ -1113,10 +1291,10 @@ int pt_launch_adj2_sd(const PtFast& p, const float* feat, long stride_n, const S
     a.t = t;
     a.want_loss = want_loss;
     int rc;
-    if (sd.kind == PT_SD_PRDIMP) rc = adj2_dispatch<V_PRDIMP>(p, a, st);
-    else if (sd.kind == PT_SD_DIMP_L2) rc = adj2_dispatch<V_L2>(p, a, st);
-    else if (sd.score_act == PT_ACT_BENTPAR) rc = adj2_dispatch<V_DIMP_BENT>(p, a, st);
-    else rc = adj2_dispatch<V_DIMP_RELU>(p, a, st);
+    if (sd.kind == PT_SD_PRDIMP) rc = adj2_dispatch<V_PRDIMP>(p, a, st, fuse_init);
+    else if (sd.kind == PT_SD_DIMP_L2) rc = adj2_dispatch<V_L2>(p, a, st, fuse_init);
+    else if (sd.score_act == PT_ACT_BENTPAR) rc = adj2_dispatch<V_DIMP_BENT>(p, a, st, fuse_init);
+    else rc = adj2_dispatch<V_DIMP_RELU>(p, a, st, fuse_init);
     if (rc) return rc;
     PT_CHECK_LAUNCH();
     return PT_OK;

@@ -93,8 +93,10 @@ int pt_launch_corr2(const PtFast& p, const float* feat, long stride_n, const flo
 int pt_launch_adj2_plain(const PtFast& p, const float* feat, long stride_n, const float* inp, float* gpart,
                          hipStream_t st);
 struct SdArgs;
+//   fuse_init (t == 0 only): the pass also does the init stage (slices -> s_0, classification epilogue, maps); see pt_adj2_init_fusable
 int pt_launch_adj2_sd(const PtFast& p, const float* feat, long stride_n, const SdArgs& sd, int t, int want_loss,
-                      hipStream_t st);
+                      hipStream_t st, bool fuse_init = false);
+bool pt_adj2_init_fusable(const PtFast& p, const SdArgs& sd);
 
 // ---- multi-filter passes (mf_kernels.hip): F <= 16 filters, odd K, C % 16 == 0 -----------------------------
 size_t pt_mf_gpart_floats(int n, int F, int C, int H, int W, int K);     // 0: configuration not covered

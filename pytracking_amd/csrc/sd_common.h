@@ -47,10 +47,21 @@ __device__ __forceinline__ auto sd_w(const A& a, int t) -> decltype(a.w0) {
 __device__ __forceinline__ float pl_lut(const float* __restrict__ w, int bins, float t) {
     // DistanceMap (ltr/models/layers/distance.py:17-39) followed by a 1x1 conv over the bins is the
     // piecewise-linear interpolation of the conv weights at t = d / bin_displacement, constant past the last bin.
+    // Branch-free (round 6): both table reads are unconditional (clamped indices) and the constant tail is a select, so that a caller
+    // evaluating several tables / elements gets all its reads in flight together instead of branch -> read -> wait per table.  Inside
+    // the table the indices and the expression are the ones above: same bits.
     const int k0 = (int)floorf(t);
+#if defined(PT_PL_LUT_BRANCHY) && PT_PL_LUT_BRANCHY                 // A/B builds: the first form
     if (k0 >= bins - 1) return w[bins - 1];
     const float fr = t - (float)k0;
     return w[k0] * (1.0f - fr) + w[k0 + 1] * fr;
+#else
+    const int i0 = max(min(k0, bins - 2), 0), i1 = min(i0 + 1, bins - 1);
+    const float w0 = w[i0], w1 = w[i1];
+    const float fr = t - (float)i0;
+    const float v = w0 * (1.0f - fr) + w1 * fr;
+    return k0 >= bins - 1 ? w1 : v;                                 // (i1 == bins - 1 there)
+#endif
 }
 
 // Label / mask / sample-weight map values of ONE element of the DiMP kinds (optimizer.py:111-125 / :201-208, :245, :249-252), given its

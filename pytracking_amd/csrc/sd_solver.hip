@@ -409,6 +409,13 @@ __global__ __launch_bounds__(1024) void k_fast_sgq2(const float* __restrict__ sp
 // label / mask / weight maps (optimizer.py:111-125, 201-208, 331-353); packed operands for k_adj2.
 // Scalar kernel parameters (preloaded) = what the first loads need; the rest in the late block.
 //   pa = n | OO << 16;  pb = KS | kind << 8 | cls_slot << 12 (0xfffff: none);  pc = OW | K << 12 | num_bins << 16
+#ifndef PT_SD_FUSE_INIT
+#ifdef PT_STAMPS
+#define PT_SD_FUSE_INIT 0      // phase-stamp builds: the stamp pointer moves the init block of k_adj2<.., INIT> in the argument segment
+#else
+#define PT_SD_FUSE_INIT 1      // 0 (A/B builds): never fold the init stage into the first adjoint pass
+#endif
+#endif
 #ifndef PT_INIT_LUT_HOT
 #define PT_INIT_LUT_HOT 1      // 0 (A/B builds): always take the look-up tables through the late argument block
 #endif
@@ -678,7 +685,17 @@ static int sd_solve_fast(const PtFast& f, const pt_sd_params* prm, const float* 
     const int pw_threads = ((a.OO + 63) / 64) * 64;                 // one element per thread (OO <= 1024 on this path)
     const size_t lut_lds = a.kind == PT_SD_DIMP ? (size_t)3 * a.num_bins * sizeof(float) : 0;
     const bool pw2 = a.KS <= PT_PW_MAXKS && lut_lds <= 48 * 1024;
-    if (pw2) {
+    // Round 6 (experiment O, LOST -- profiles/r06o_fused_init_stage.txt): with at least one iteration to run, no loss read-out and nobody
+    // waiting on an event behind the init stage, the first adjoint pass can do the init stage itself (k_adj2<.., INIT>): one dependent
+    // launch less, bit-identical -- but every one of the 32 channel-block workgroups of a position slice then redoes the maps of its
+    // 6-7 samples (8 slice loads + the look-up-table arithmetic per element, six elements per lane): that pass is 15.3 us instead of
+    // 7.9 and the frame 4.7 us SLOWER.  Opt-in for experiments: PT_SD_FUSE_INIT=1 in the environment (read per solve).
+    const bool fuse_env = std::getenv("PT_SD_FUSE_INIT") && std::getenv("PT_SD_FUSE_INIT")[0] == '1';
+    const bool fuse_init = PT_SD_FUSE_INIT && fuse_env && pw2 && num_iter > 0 && !want_loss && !(cls && cls->after_init) &&
+                           pt_adj2_init_fusable(f, a);
+    if (fuse_init) {
+        if (n > 65535 || a.OO > 65535) return PT_ERR_UNSUPPORTED;
+    } else if (pw2) {
         if (n > 65535 || a.OO > 65535 || a.OW > 4095 || a.K > 15 || a.num_bins > 65535 || n >= 0xfffff) return PT_ERR_UNSUPPORTED;
         InitLate il;
         il.label_lut = (pt_gcf)a.label_lut; il.mask_lut = (pt_gcf)a.mask_lut; il.spatial_lut = (pt_gcf)a.spatial_lut;
@@ -697,7 +714,7 @@ static int sd_solve_fast(const PtFast& f, const pt_sd_params* prm, const float* 
     }
     else if (a.cls_slot_dyn) return PT_ERR_UNSUPPORTED;             // (refused before the first correlation: see below)
     else hipLaunchKernelGGL(k_fast_init, dim3(n), dim3(384), 0, st, a);
-    PT_CHECK_LAUNCH();
+    if (!fuse_init) PT_CHECK_LAUNCH();
     if (cls && cls->after_init && hipEventRecord((hipEvent_t)cls->after_init, st) != hipSuccess) return PT_ERR_LAUNCH;
     if (num_iter == 0) {
         if (!want_loss) return PT_OK;
@@ -708,7 +725,7 @@ static int sd_solve_fast(const PtFast& f, const pt_sd_params* prm, const float* 
     for (int t = 0; t < num_iter; ++t) {
         a.s_in = sbuf[t == 0 ? 0 : (t - 1) & 1];
         a.s = sbuf[t & 1];
-        rc = pt_launch_adj2_sd(f, feat, stride_n, a, t, want_loss, st);        // alpha_{t-1}, w_t, s_t, residual maps
+        rc = pt_launch_adj2_sd(f, feat, stride_n, a, t, want_loss, st, fuse_init && t == 0);   // alpha_{t-1}, w_t, s_t, residual maps
         if (rc) return rc;
         PtCorrFuse fz = {a.gpart, f.KSPL, t == 0 ? w_in : w_iters + (long)t * a.CKK, a.reg, a.g, a.anum, nullptr};
         rc = pt_launch_corr2(f, feat, stride_n, nullptr, a.spart, st, &fz);    // g_t, |g_t|^2, F g_t

@@ -662,6 +662,99 @@ def test_frame_chain_deferred_last_update_is_bit_identical(kind, n, C):
     torch.cuda.current_stream().wait_stream(stream)
 
 
+class _FuseInit:
+    """PT_SD_FUSE_INIT=1 for the calls inside (opt-in experiment; the library reads the switch per solve)."""
+    def __enter__(self):
+        import os
+        self.old = os.environ.get("PT_SD_FUSE_INIT")
+        os.environ["PT_SD_FUSE_INIT"] = "1"
+
+    def __exit__(self, *a):
+        import os
+        if self.old is None:
+            os.environ.pop("PT_SD_FUSE_INIT", None)
+        else:
+            os.environ["PT_SD_FUSE_INIT"] = self.old
+
+
+@pytest.mark.parametrize("variant", ["relu", "bentpar", "linmask", "l2", "relu_22x22", "relu_8x8_many", "relu_nosw", "relu_c512_n50"])
+def test_fused_init_stage_is_bit_identical_solver(variant):
+    """Round 6, experiment O (opt-in, PT_SD_FUSE_INIT=1: measured slower, profiles/r06o_fused_init_stage.txt): the first adjoint pass of a
+    solve does the init stage itself (k_adj2<.., INIT>: slices -> s_0, maps, packed operands in registers) instead of a k_fast_init2
+    launch in front of it.  Same expressions on the same operands: every iterate of the optimiser mirror BIT-EQUAL with the default path, for the relu / bentpar / L2 residuals, sigmoid and
+    linear masks, 18x18 (E = 6) and 22x22 maps (E = 9, 24-group plan), slices holding more samples than the workgroup has waves
+    (8x8 maps, n = 200), with and without sample weights -- and the fused iterates stay inside 2e-5 of the loss-returning call's
+    (which never fuses: the loss read-out wants the raw maps)."""
+    from pytracking_amd import optimizer
+    cfg = dict(synth.DIMP50, C=128)
+    n, nit = 15, 3
+    if variant == "relu_22x22":
+        cfg.update(H=22, W=22); n = 50; nit = 2
+    elif variant == "relu_8x8_many":
+        cfg.update(H=8, W=8); n = 200; nit = 2
+    elif variant == "relu_c512_n50":
+        cfg.update(C=512); n = 50; nit = 5
+    w0, feat, bb, sw = synth.dimp_problem(6100 + len(variant), n, cfg)
+    if variant == "relu_nosw":
+        sw = None
+    if variant == "l2":
+        mod = optimizer.DiMPL2SteepestDescentGN(num_iter=nit, feat_stride=16, init_step_length=1.0, gauss_sigma=1.0, hinge_threshold=-999.0,
+                                                init_filter_reg=0.1, min_filter_reg=1e-3).to(DEV).eval()
+    else:
+        over = {"bentpar": dict(score_act="bentpar"), "linmask": dict(mask_act="linear")}.get(variant, {})
+        mod = _dimp_module(cfg, **over)
+    with _FuseInit():
+        fused, _ = _run(mod, w0, feat, bb, sw, nit, compute_losses=False)
+    plain, _ = _run(mod, w0, feat, bb, sw, nit, compute_losses=False)
+    assert torch.equal(fused, plain), float((fused - plain).abs().max())
+    lossy, losses = _run(mod, w0, feat, bb, sw, nit, compute_losses=True)
+    assert torch.equal(plain, lossy) and losses is not None
+    assert float((fused[1:] - fused[:-1]).abs().max()) > 0                # the solve moved
+
+
+@pytest.mark.parametrize("C,n", [(512, 50), (256, 16)])
+def test_fused_init_stage_is_bit_identical_frames(C, n):
+    """The same through the frame entry points (classification epilogue inside the init stage: scores of the inserted slot, first
+    maximum, re-centred box): two identical sequences, one with PT_SD_FUSE_INIT=1; scores, peak, boxes, memory, filter AND the whole
+    solver workspace (s_0 ... s_T, label / mask / weight maps, packed operands, gradient partials) bit-equal at every frame, plain
+    frames and deferred chains, 5 / 2 / 1 / 0 iterations; then a graph-captured fused chain against the eager unfused one."""
+    from pytracking_amd import bench_frame
+    cfg = dict(synth.DIMP50, C=C)
+    a = bench_frame.TrackState(cfg, n, seed=91, device=DEV, kind="dimp")
+    b = bench_frame.TrackState(cfg, n, seed=91, device=DEV, kind="dimp")
+    a.ws.zero_(); b.ws.zero_()
+    pool = T(synth.clf_features(np.random.default_rng(92), 20, C, cfg["H"], cfg["W"], cfg["K"]))
+    sched = [5, 5, 2, 0, 5, 1, 5, 3]
+    for defer in (False, True):
+        for f, nit in enumerate(sched):
+            a.step(pool[f], slot=(5 * f) % n, num_iter=nit, defer=defer)
+            with _FuseInit():
+                b.step(pool[f], slot=(5 * f) % n, num_iter=nit, defer=defer)
+            torch.cuda.synchronize()
+            assert torch.equal(a.scores, b.scores) and torch.equal(a.peak, b.peak) and torch.equal(a.mem_bb, b.mem_bb), (defer, f)
+            assert torch.equal(a.mem_feat, b.mem_feat) and torch.equal(a.filter, b.filter), (defer, f)
+            assert torch.equal(a.ws, b.ws), (defer, f)
+        if defer:
+            a.flush(); b.flush()
+            torch.cuda.synchronize()
+            assert torch.equal(a.filter, b.filter)
+    stream = torch.cuda.Stream()
+    stream.wait_stream(torch.cuda.current_stream())
+    with torch.cuda.stream(stream), _FuseInit():
+        g = torch.cuda.CUDAGraph()
+        with torch.cuda.graph(g, stream=stream):
+            for f in range(4):
+                b.step(pool[8 + f], slot=f, num_iter=5, defer=True)
+            b.flush()
+        g.replay()
+        stream.synchronize()
+    torch.cuda.current_stream().wait_stream(stream)
+    for f in range(4):
+        a.step(pool[8 + f], slot=f, num_iter=5)
+    torch.cuda.synchronize()
+    assert torch.equal(a.filter, b.filter) and torch.equal(a.scores, b.scores) and torch.equal(a.mem_bb, b.mem_bb)
+
+
 def test_frame_chain_argument_checks():
     import ctypes
     from pytracking_amd import _lib, bench_frame
