@@ -38,6 +38,9 @@ struct GemmArgs {
                                                 // partial product to C + z*c_zstride (bias on z = 0 only); 0 = no split
     int batch; long a_zstride, w_zstride;       // batch > 0 (no split-K): blockIdx.z is an independent problem, operands
                                                 // a_zstride / w_zstride floats apart, output at C + z*c_zstride
+    // k_gemm_ps<.., LNA> (round 6): the A operand is LayerNorm(A) over its K = 256 columns (eps 1e-5, affine ln_gam / ln_bet), formed
+    // in registers on the way into LDS; the column-tile-0 workgroups also store the normalised rows to ln_out (row stride K)
+    const float* ln_gam; const float* ln_bet; float* ln_out;
 };
 
 // ------------------------------------------------------------------------------------------------------------------
@@ -534,7 +537,12 @@ __global__ __launch_bounds__(512) void k_gemm_big(GemmArgs g) {
 // MODE 0 only (plain A).  K % 32 == 0.  Same LDS layout / fragment permutation / epilogue as k_gemm.
 // ------------------------------------------------------------------------------------------------------------------
 // SW: accumulators transposed (MFMA operands swapped) and stored with 16-byte stores (gemm_store_t; plain row-major C, N % 4 == 0).
-template <int WGM, int WGN, int MT, int NT, bool TG, bool SW = false>
+// LNA (round 6, ToMP encoder: norm1 folded into the FFN's first product): A := LayerNorm_K(A) with K == 256 == 8 stages.  The workgroup
+// needs its whole A slab anyway (K is the full row), so the slab is requested UP FRONT into registers (NPA x 8 16-byte pieces per thread:
+// the same bytes the staged loader would have fetched), the row statistics are formed across the 8 lanes that share a row (two passes:
+// mean, then centred squares -- the LayerNorm kernel's formula), the pieces are normalised in place and go to LDS stage by stage where
+// the staged loader's registers would have gone.  One launch and one round trip through memory less per encoder layer.
+template <int WGM, int WGN, int MT, int NT, bool TG, bool SW = false, bool LNA = false>
 __global__ __launch_bounds__(64 * WGM * WGN) void k_gemm_ps(GemmArgs g) {
     extern __shared__ __attribute__((aligned(16))) float gb_lds[];  // [2][STAGE]
     constexpr int NTHR = 64 * WGM * WGN, WM = 16 * MT, WN = 16 * NT, BM = WGM * WM, BN = WGN * WN, LS = GB_LS;
@@ -564,20 +572,67 @@ __global__ __launch_bounds__(64 * WGM * WGN) void k_gemm_ps(GemmArgs g) {
         }
         lds_at[k] = r * LS + lc4;
     }
-    const int nst_all = g.K / 32;
-    const int s0 = g.ksteps ? blockIdx.z * g.ksteps * 2 : 0;       // g.ksteps counts 64-wide steps
-    const int nst = (g.ksteps ? min(nst_all, s0 + g.ksteps * 2) : nst_all) - s0;
+    constexpr int LN_ST = 8;                                        // LNA: K == 256, no split
+    const int nst_all = LNA ? LN_ST : g.K / 32;
+    const int s0 = (!LNA && g.ksteps) ? blockIdx.z * g.ksteps * 2 : 0;   // g.ksteps counts 64-wide steps
+    const int nst = LNA ? LN_ST : (g.ksteps ? min(nst_all, s0 + g.ksteps * 2) : nst_all) - s0;
     f32x4 rr[NP], rp[NPA];
+    f32x4 ra[LNA ? NPA : 1][LNA ? LN_ST : 1];                       // LNA: the A slab of this thread (row p >> 3, k-quad p & 7 of every stage)
     auto fetch_one = [&](int st, int k) {                           // past the end: the last stage again (never consumed)
+        if (LNA && k < NPA) return;                                 // (compile-time k at every call site)
         const unsigned kbytes = (unsigned)(s0 + min(st, nst - 1)) * 128u;
         rr[k] = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(k < NPA ? rsA : rsW, goff[k], kbytes, 0));
         if (k < NPA && addpos) rp[k < NPA ? k : 0] = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(rsP, poff[k < NPA ? k : 0], kbytes, 0));
     };
-    auto stash_one = [&](int buf, int k) {
+    auto stash_one = [&](int buf, int k, int st = 0) {              // st: the stage being stashed (LNA; compile time: its loops are unrolled)
         f32x4 v = rr[k];
+        if (LNA && k < NPA) v = ra[LNA ? (k < NPA ? k : 0) : 0][LNA ? min(st, LN_ST - 1) : 0];
         if (k < NPA && addpos) v += rp[k < NPA ? k : 0];
         *reinterpret_cast<f32x4*>(__builtin_assume_aligned(gb_lds + buf * STAGE + lds_at[k], 16)) = v;
     };
+    if constexpr (LNA) {
+        float* __restrict__ lnp = gb_lds + 2 * STAGE;               // gamma[256] | beta[256]
+        // ---- the slab, gamma / beta, then the first two W stages: everything requested before the first wait
+#pragma unroll
+        for (int k = 0; k < NPA; ++k)
+#pragma unroll
+            for (int st = 0; st < LN_ST; ++st)
+                ra[k][st] = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(rsA, goff[k], (unsigned)st * 128u, 0));
+        f32x4 gbv = {0, 0, 0, 0};
+        if (tid < 128) gbv = *reinterpret_cast<const f32x4*>((tid < 64 ? g.ln_gam : g.ln_bet) + 4 * (tid & 63));
+        if (tid < 128) *reinterpret_cast<f32x4*>(__builtin_assume_aligned(lnp + 4 * tid, 16)) = gbv;
+        // ---- row statistics: a row's 256 values sit in the 8 lanes tid & 7 (k-quad) x 8 stages
+        float mean[NPA], rstd[NPA];
+#pragma unroll
+        for (int k = 0; k < NPA; ++k) {
+            float sm = 0.f;
+#pragma unroll
+            for (int st = 0; st < LN_ST; ++st) sm += (ra[k][st][0] + ra[k][st][1]) + (ra[k][st][2] + ra[k][st][3]);
+            sm += __shfl_xor(sm, 1, 64); sm += __shfl_xor(sm, 2, 64); sm += __shfl_xor(sm, 4, 64);
+            mean[k] = sm / 256.0f;
+            float q = 0.f;
+#pragma unroll
+            for (int st = 0; st < LN_ST; ++st)
+#pragma unroll
+                for (int e = 0; e < 4; ++e) q += (ra[k][st][e] - mean[k]) * (ra[k][st][e] - mean[k]);
+            q += __shfl_xor(q, 1, 64); q += __shfl_xor(q, 2, 64); q += __shfl_xor(q, 4, 64);
+            rstd[k] = rsqrtf(q / 256.0f + 1e-5f);
+        }
+        __syncthreads();                                            // gamma / beta staged
+        const bool keep = (TG ? blockIdx.y : blockIdx.x) == 0 && g.ln_out != nullptr;   // uniform: column tile 0 stores the normalised rows
+        const __amdgpu_buffer_rsrc_t rsO = pt_rsrc(g.ln_out ? g.ln_out : g.C, g.ln_out ? g.a_bytes : 16u);
+#pragma unroll
+        for (int st = 0; st < LN_ST; ++st) {
+            const f32x4 gv = *reinterpret_cast<const f32x4*>(__builtin_assume_aligned(lnp + 32 * st + 4 * (tid & 7), 16));
+            const f32x4 bv = *reinterpret_cast<const f32x4*>(__builtin_assume_aligned(lnp + 256 + 32 * st + 4 * (tid & 7), 16));
+#pragma unroll
+            for (int k = 0; k < NPA; ++k) {
+#pragma unroll
+                for (int e = 0; e < 4; ++e) ra[k][st][e] = (ra[k][st][e] - mean[k]) * rstd[k] * gv[e] + bv[e];
+                if (keep) __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(pt_u32x4, ra[k][st]), rsO, goff[k], (unsigned)st * 128u, 0);
+            }
+        }
+    }
     const int qoff = ((lane >> 4) & 1) * 2 + (lane >> 5);
     const int aso = (wm * WM + gemm_prow(lane & 15)) * LS + qoff * 4;
     const int bso = BM * LS + (wn * WN + gemm_prow(lane & 15)) * LS + qoff * 4;
@@ -611,7 +666,10 @@ __global__ __launch_bounds__(64 * WGM * WGN) void k_gemm_ps(GemmArgs g) {
 #pragma unroll
             for (int k = 0; k < NP; ++k) fetch_one(0, k);
 #pragma unroll
-            for (int k = 0; k < NP; ++k) { p0[k] = rr[k]; if (k < NPA && addpos) p0[k] += rp[k < NPA ? k : 0]; }
+            for (int k = 0; k < NP; ++k) {
+                p0[k] = (LNA && k < NPA) ? ra[LNA ? (k < NPA ? k : 0) : 0][0] : rr[k];
+                if (k < NPA && addpos) p0[k] += rp[k < NPA ? k : 0];
+            }
 #pragma unroll
             for (int k = 0; k < NP; ++k) fetch_one(1, k);
 #pragma unroll
@@ -621,14 +679,14 @@ __global__ __launch_bounds__(64 * WGM * WGN) void k_gemm_ps(GemmArgs g) {
 #pragma unroll
         for (int k = 0; k < MT + NT; ++k) frag_one(0, 0, 0, k);
         __builtin_amdgcn_sched_barrier(0);
-        for (int st = 0; st < nst; st += 2) {
+        auto stage_pair = [&](int st) {
 #pragma unroll
             for (int h = 0; h < 2; ++h) {
                 const int s = st + h;                               // buffer h
                 if (h == 1 && s >= nst) break;
                 substep(0, [&](int i) {
                     if (i < MT + NT) frag_one(h, 1, 1, i);                          // fragments of this stage's second sub-step
-                    else if (i < MT + NT + NP) stash_one(h ^ 1, i - (MT + NT));     // stage s+1 -> the other buffer
+                    else if (i < MT + NT + NP) stash_one(h ^ 1, i - (MT + NT), s + 1);   // stage s+1 -> the other buffer
                     else if (i < MT + NT + 2 * NP) fetch_one(s + 2, i - (MT + NT + NP));   // stage s+2 -> registers
                 });
                 __syncthreads();
@@ -636,6 +694,12 @@ __global__ __launch_bounds__(64 * WGM * WGN) void k_gemm_ps(GemmArgs g) {
                     if (i < MT + NT) frag_one(h ^ 1, 0, 0, i);                      // first fragments of stage s+1
                 });
             }
+        };
+        if constexpr (LNA) {                                        // 8 stages, unrolled: the slab registers are indexed by the stage
+#pragma unroll
+            for (int st = 0; st < LN_ST; st += 2) stage_pair(st);
+        } else {
+            for (int st = 0; st < nst; st += 2) stage_pair(st);
         }
     }
     if (SW) gemm_store_t<MT, NT>(g, acc, m0 + wm * WM, n0 + wn * WN, lane, blockIdx.z);
@@ -699,6 +763,16 @@ int launch_gemm(const GemmArgs& g, hipStream_t st, bool conv = false) {
         constexpr size_t lds = 2 * (64 + 64) * GB_LS * sizeof(float);
         if (wide_store_ok(g)) hipLaunchKernelGGL((k_gemm_ps<2, 2, 2, 2, false, true>), dim3((g.N + 63) / 64, (g.M + 63) / 64, 1), dim3(256), lds, st, g);
         else hipLaunchKernelGGL((k_gemm_ps<2, 2, 2, 2, false>), dim3((g.N + 63) / 64, (g.M + 63) / 64, 1), dim3(256), lds, st, g);
+        PT_CHECK_LAUNCH();
+        return PT_OK;
+    }
+    if (g.ln_gam) {
+        // LayerNorm on the A operand: served by the 128 x 64 pinned-schedule kernel only (never dropped silently)
+        if (!(ps_on && !conv && g.K == 256 && g.lda == 256 && !g.pos && !g.batch && !g.nchw && nz == 1 && !g.ksteps && g.ln_bet && wide_store_ok(g) &&
+              ((uintptr_t)g.A % 16) == 0 && ((uintptr_t)g.ln_gam % 16) == 0 && ((uintptr_t)g.ln_bet % 16) == 0 && ((uintptr_t)g.ln_out % 16) == 0))
+            return PT_ERR_UNSUPPORTED;
+        constexpr size_t lds = (2 * (128 + 64) * GB_LS + 512) * sizeof(float);
+        hipLaunchKernelGGL((k_gemm_ps<4, 2, 2, 2, false, true, true>), dim3((g.N + 63) / 64, (g.M + 127) / 128, 1), dim3(512), lds, st, g);
         PT_CHECK_LAUNCH();
         return PT_OK;
     }

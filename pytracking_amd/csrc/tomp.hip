@@ -1346,11 +1346,26 @@ extern "C" int pt_tomp_predict_f32(const pt_tomp_dims* d, const float* params, c
         g = gemm_args(AO, D, rows, P + e.sa.w_out, rows, D, D, P + e.sa.b_out, Y, D);
         g.R = X;
         if ((rc = launch_gemm(g, st))) return rc;
-        if ((rc = launch_ln_rows(Y, X, P + e.n1g, P + e.n1b, rows, D, st))) return rc;
-        PT_CHECK_LAUNCH();
+        // round 6, experiment P (LOST, profiles/r06p_tomp_ln1_fold.txt; opt-in PT_TOMP_LN1_FOLD=1): norm1 riding on the FFN's first
+        // product (k_gemm_ps<.., LNA>: the A slab normalised in registers, the column-tile-0 workgroups store X for the residual of
+        // norm2) saves a launch per layer, but the slab-up-front prologue costs that product 4.6 us (23.5 -> 28.1) against the 4.6 us
+        // LayerNorm launch (~3 in the chain): frame 0.885 -> 0.894 ms.
+        static const bool ln1_fold = [] { const char* e = getenv("PT_TOMP_LN1_FOLD"); return e && e[0] == '1'; }();
         g = gemm_args(X, D, rows, P + e.w1, rows, ff, D, P + e.b1, Hd, ff);
         g.relu = 1;
-        if ((rc = launch_gemm(g, st))) return rc;
+        bool folded = false;
+        if (ln1_fold && D == 256 && rows >= 1024 && ff >= 1024) {
+            GemmArgs gl = g;
+            gl.A = Y; gl.ln_gam = P + e.n1g; gl.ln_bet = P + e.n1b; gl.ln_out = X;
+            const int rl = launch_gemm(gl, st);
+            if (rl == PT_OK) folded = true;
+            else if (rl != PT_ERR_UNSUPPORTED) return rl;
+        }
+        if (!folded) {
+            if ((rc = launch_ln_rows(Y, X, P + e.n1g, P + e.n1b, rows, D, st))) return rc;
+            PT_CHECK_LAUNCH();
+            if ((rc = launch_gemm(g, st))) return rc;
+        }
         const long rD = (long)rows * D;
         if (pt_tomp_ffn2_split() == 4 && (ff / 64) % 4 == 0 && rows >= 1024 && D % 64 == 0 && cv.AO == cv.QKV + 3 * (size_t)rD &&
             ln_rows_wide_ok(QKV, X, P + e.n2g, P + e.n2b, D)) {
