@@ -44,6 +44,12 @@ struct AttnArgs {
 // Workgroup = 64 queries x 2 key halves: wavefronts 0-3 own the even 64-key chunks, 4-7 the odd ones (two wavefronts per
 // SIMD, so one half's softmax / LDS waits hide behind the other's MFMAs -- B*nhead*L/16 query tiles alone are only one
 // wavefront per SIMD); the halves' (max, sum, O^T) are merged through LDS at the end.
+// PT_ATTN_EXP (experiments only, WRONG results, timing: profiles/r06q_attention_ablation.txt) -- bit mask:
+//   1: no exponentials (P = S - m)      2: K / V staged once (no stash, no barriers after the first iteration)
+//   4: fragments read from LDS once per iteration instead of per tile      8: K / V fetched from memory once
+#ifndef PT_ATTN_EXP
+#define PT_ATTN_EXP 0
+#endif
 template <int HD>
 __global__ __launch_bounds__(512) void k_attn(AttnArgs a) {
     constexpr int KS = HD + 4, NV = HD / 4, NF4 = HD / 16, DT = HD / 16;   // NV floats of q/k per lane, NF4 float4s
@@ -110,15 +116,19 @@ __global__ __launch_bounds__(512) void k_attn(AttnArgs a) {
 #pragma unroll
     for (int r = 0; r < 4; ++r) pk[r] = prow(4 * kq + r);
     int it = 0;
+    bool first = true;                                            // (ablation builds only)
     while (it < nit && !live(it)) ++it;
     if (it < nit) fetch(it * 128);
     while (it < nit) {
         int nx = it + 1;
         while (nx < nit && !live(nx)) ++nx;
-        __syncthreads();                                          // previous iteration's LDS reads are done
-        stash();
-        __syncthreads();
-        if (nx < nit) fetch(nx * 128);
+        if (!(PT_ATTN_EXP & 2) || first) {
+            __syncthreads();                                      // previous iteration's LDS reads are done
+            stash();
+            __syncthreads();
+        }
+        if (nx < nit && !((PT_ATTN_EXP & 8) && !first)) fetch(nx * 128);
+        first = false;
         const int c0 = it * 128 + half * 64;
         it = nx;
         if (c0 >= a.L || (c0 >= mlo && c0 + 64 <= mhi)) continue;  // wave-uniform: nothing but padding in this half chunk
@@ -146,10 +156,12 @@ __global__ __launch_bounds__(512) void k_attn(AttnArgs a) {
             }
         };
         read_k(0, 0);
+        if (PT_ATTN_EXP & 4) { read_k(1, 1); read_v(0, 0); read_v(1, 1); }
         __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
         for (int kt = 0; kt < 4; ++kt) {
-            if (kt < 3) read_k(kt + 1, (kt + 1) & 1);
+            if (PT_ATTN_EXP & 4) {}
+            else if (kt < 3) read_k(kt + 1, (kt + 1) & 1);
             else read_v(0, 0);
             __builtin_amdgcn_sched_barrier(0);
             f32x4 sc = f32x4{0.f, 0.f, 0.f, 0.f};
@@ -174,7 +186,7 @@ __global__ __launch_bounds__(512) void k_attn(AttnArgs a) {
         mc = fmaxf(mc, __shfl_xor(mc, 32, 64));
         const float m_new = fmaxf(m_run, mc);
         const float m_use = m_new == -INFINITY ? 0.f : m_new;
-        const float alpha = __expf(m_run - m_use);                 // m_run = -inf -> 0
+        const float alpha = (PT_ATTN_EXP & 1) ? 0.5f : __expf(m_run - m_use);                 // m_run = -inf -> 0
         l_run *= alpha;
 #pragma unroll
         for (int d = 0; d < DT; ++d) ot[d] *= alpha;
@@ -184,11 +196,11 @@ __global__ __launch_bounds__(512) void k_attn(AttnArgs a) {
         __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
         for (int kt = 0; kt < 4; ++kt) {
-            if (kt < 3) read_v(kt + 1, (kt + 1) & 1);
+            if (kt < 3 && !(PT_ATTN_EXP & 4)) read_v(kt + 1, (kt + 1) & 1);
             __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
             for (int r = 0; r < 4; ++r) {
-                const float pe = __expf(st[kt][r] - m_use);
+                const float pe = (PT_ATTN_EXP & 1) ? st[kt][r] - m_use : __expf(st[kt][r] - m_use);
                 l_run += pe;
 #pragma unroll
                 for (int d = 0; d < DT; ++d) ot[d] = mfma16(vf[kt & 1][r][d], pe, ot[d]);
