@@ -50,6 +50,9 @@ struct AttnArgs {
 #ifndef PT_ATTN_EXP
 #define PT_ATTN_EXP 0
 #endif
+#ifndef PT_ATTN_PIPE_EXP
+#define PT_ATTN_PIPE_EXP 0   // 1 (experiment, no gain: r06q): exponentials of the next key tile issued between the PV MFMAs of the current one
+#endif
 template <int HD>
 __global__ __launch_bounds__(512) void k_attn(AttnArgs a) {
     constexpr int KS = HD + 4, NV = HD / 4, NF4 = HD / 16, DT = HD / 16;   // NV floats of q/k per lane, NF4 float4s
@@ -194,6 +197,31 @@ __global__ __launch_bounds__(512) void k_attn(AttnArgs a) {
         // ---- P^T = exp(S^T - m) feeds the PV product straight from the accumulator registers:
         //      O^T[d][query] += sum_key V[key][d] * P^T[key][query]; k-slot kq of MFMA r <-> key prow(4*kq + r) of the tile
         __builtin_amdgcn_sched_barrier(0);
+#if PT_ATTN_PIPE_EXP
+        // Round 6 experiment (profiles/r06q_attention_ablation.txt: the exponentials are 2.3 us of the launch): the four exponentials of
+        // tile kt + 1 issued one behind each PV MFMA pair of tile kt (ISA: M M E x 12), only tile 0's in front.  Same bits -- and NO gain
+        // (0.8875-0.8890 vs 0.8850-0.8878 ms): the transcendental issue does not overlap the matrix pipe's issue on this SIMD.
+        auto pexp = [&](float sv) { return (PT_ATTN_EXP & 1) ? sv - m_use : __expf(sv - m_use); };
+        float pc[4], pn[4];
+#pragma unroll
+        for (int r = 0; r < 4; ++r) pc[r] = pexp(st[0][r]);
+#pragma unroll
+        for (int kt = 0; kt < 4; ++kt) {
+            if (kt < 3 && !(PT_ATTN_EXP & 4)) read_v(kt + 1, (kt + 1) & 1);
+            __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+            for (int r = 0; r < 4; ++r) {
+                l_run += pc[r];
+#pragma unroll
+                for (int d = 0; d < DT; ++d) ot[d] = mfma16(vf[kt & 1][r][d], pc[r], ot[d]);
+                __builtin_amdgcn_sched_barrier(0);
+                if (kt < 3) pn[r] = pexp(st[kt < 3 ? kt + 1 : 3][r]);
+                __builtin_amdgcn_sched_barrier(0);
+            }
+#pragma unroll
+            for (int r = 0; r < 4; ++r) pc[r] = pn[r];
+        }
+#else
 #pragma unroll
         for (int kt = 0; kt < 4; ++kt) {
             if (kt < 3 && !(PT_ATTN_EXP & 4)) read_v(kt + 1, (kt + 1) & 1);
@@ -207,6 +235,7 @@ __global__ __launch_bounds__(512) void k_attn(AttnArgs a) {
             }
             __builtin_amdgcn_sched_barrier(0);
         }
+#endif
     }
     l_run += __shfl_xor(l_run, 16, 64);
     l_run += __shfl_xor(l_run, 32, 64);
