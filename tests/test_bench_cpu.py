@@ -11,7 +11,7 @@ sys.path.insert(0, ROOT)
 def _stats(corr_ns, adj_ns, frames):
     return {"void k_corr2<16, true, 8, true, 1>(float const*, long)": (5 * frames, corr_ns),
             "void k_corr2<16, true, 0, true, 1>(float const*, long)": (frames, corr_ns - 500.0),
-            "void k_adj2<1, 6, 16>(float const*, long)": (5 * frames, adj_ns),
+            "void k_adj2<1, 6, 16, false>(float const*, long)": (5 * frames, adj_ns),
             "k_fast_sgq2(float const*)": (5 * frames, 5000.0), "k_fast_init2(float const*)": (frames, 5000.0),
             "k_fast_final(float const*)": (frames, 5000.0)}
 
@@ -57,7 +57,7 @@ def test_committed_counter_summary_is_this_rounds():
     wave per tile; PrDiMP's 24-group adjoint)."""
     rec = json.load(open(os.path.join(ROOT, "profiles", "pmc_traffic.json")))
     for wl, kern, inst in (("dimp50", "k_corr2", "k_corr2<16, true, 8, true, 1>"), ("dimp50", "k_adj2", "k_adj2<1, 6, 16>"),
-                           ("prdimp50", "k_corr2", "k_corr2<16, false, 8, true, 1>"), ("prdimp50", "k_adj2", "k_adj2<4, 9, 24>")):
+                           ("prdimp50", "k_corr2", "k_corr2<16, false, 8, true, 1>"), ("prdimp50", "k_adj2", "k_adj2<4, 9, 24, false>")):
         r = rec[wl][kern]
         assert "profiles/r06" in r["source"] and inst in r["source"], r["source"]
         assert os.path.exists(os.path.join(ROOT, r["source"].split(":")[0]))
