@@ -56,7 +56,7 @@ def test_committed_counter_summary_is_this_rounds():
     CURRENT kernels: the source must name a round-6 file and the instantiations the passes run now (sample pairs: NK = 16, one
     wave per tile; PrDiMP's 24-group adjoint)."""
     rec = json.load(open(os.path.join(ROOT, "profiles", "pmc_traffic.json")))
-    for wl, kern, inst in (("dimp50", "k_corr2", "k_corr2<16, true, 8, true, 1>"), ("dimp50", "k_adj2", "k_adj2<1, 6, 16>"),
+    for wl, kern, inst in (("dimp50", "k_corr2", "k_corr2<16, true, 8, true, 1>"), ("dimp50", "k_adj2", "k_adj2<1, 6, 16, false>"),
                            ("prdimp50", "k_corr2", "k_corr2<16, false, 8, true, 1>"), ("prdimp50", "k_adj2", "k_adj2<4, 9, 24, false>")):
         r = rec[wl][kern]
         assert "profiles/r06" in r["source"] and inst in r["source"], r["source"]
